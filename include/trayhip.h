@@ -1,0 +1,293 @@
+/*
+ * trayhip.h — C ABI of libtrayhip.so, the MI355X (gfx950) path-tracing core that
+ * replaces tray_rust's tile worker.
+ *
+ * Drop-in seam (reference, /root/reference):
+ *   trait Exec::render(&mut self, &mut Scene, &mut RenderTarget, &Config)   src/exec/mod.rs:41-49
+ *   MultiThreaded::render_parallel + thread_work                            src/exec/multithreaded.rs:30-114
+ *   Scene::load_file                                                        src/scene.rs:101-145
+ *   RenderTarget::{write,get_render,get_renderf32}                          src/film/render_target.rs:77,185,243
+ *   film::Image::add_pixels (merge of per-worker RGBW)                      src/film/image.rs:21-34
+ *   BlockQueue::new (Morton tile list + select_blocks)                      src/sampler/block_queue.rs:28-48
+ *
+ * Everything is plain C: PODs, pointers and sizes. No torch / C++ types cross this line.
+ * All entry points return 0 on success and a negative TRAY_E_* code on failure; the message is
+ * available from tray_last_error() (thread local). Nothing aborts across the ABI: the reference's
+ * panics (scene.rs:104-136, block_queue.rs:29-31, multithreaded.rs:39) become checked errors.
+ *
+ * The same TrayFlatScene POD is what the CPU oracle (oracle/, test infrastructure only) consumes,
+ * so oracle and HIP path are fed bit-identical scene data.
+ */
+#ifndef TRAYHIP_H
+#define TRAYHIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRAY_ABI_VERSION 1
+
+enum {
+    TRAY_OK = 0,
+    TRAY_E_INVALID = -1,   /* bad argument / precondition (reference would panic) */
+    TRAY_E_IO = -2,        /* file could not be opened / read */
+    TRAY_E_PARSE = -3,     /* JSON / OBJ / MERL parse error */
+    TRAY_E_UNSUPPORTED = -4, /* feature outside the hot-path scope */
+    TRAY_E_DEVICE = -5,    /* HIP runtime error */
+    TRAY_E_NOMEM = -6
+};
+
+/* ---------------------------------------------------------------- flat scene (SoA/AoS PODs) */
+
+/* Flattened BVH2 node, 32 B: reference FlatNode (src/geometry/bvh.rs:278-295).
+ * count > 0  : leaf, prims ordered[offset .. offset+count)
+ * count == 0 : interior, first child = this+1, second child = offset, split axis = axis */
+typedef struct TrayBvhNode {
+    float bmin[3];
+    float bmax[3];
+    uint32_t offset;
+    uint16_t count;
+    uint8_t axis;
+    uint8_t pad;
+} TrayBvhNode;
+
+/* Hot triangle record (48 B, 3 x float4) in mesh-BVH leaf order: positions only.
+ * Reference Triangle{a,b,c,positions} (src/geometry/mesh.rs:88-111), pre-gathered. */
+typedef struct TrayTriVerts {
+    float pa[3]; uint32_t tri_id;  /* index of this triangle in the OBJ order (for debugging) */
+    float pb[3]; uint32_t pad0;
+    float pc[3]; uint32_t pad1;
+} TrayTriVerts;
+
+/* Cold triangle record (64 B): shading normals + texcoords, read once for the final hit. */
+typedef struct TrayTriAttrs {
+    float na[3], nb[3], nc[3];
+    float ta[2], tb[2], tc[2];
+    float pad;
+} TrayTriAttrs;
+
+typedef struct TrayMesh {
+    uint32_t node_offset;  /* into TrayFlatScene.mesh_nodes */
+    uint32_t node_count;
+    uint32_t tri_offset;   /* into tri_verts / tri_attrs (leaf order) */
+    uint32_t tri_count;
+} TrayMesh;
+
+enum { TRAY_GEOM_SPHERE = 0, TRAY_GEOM_DISK = 1, TRAY_GEOM_RECT = 2, TRAY_GEOM_MESH = 3, TRAY_GEOM_NONE = 4 };
+enum { TRAY_INST_RECEIVER = 0, TRAY_INST_AREA_EMITTER = 1, TRAY_INST_POINT_EMITTER = 2 };
+
+/* One Instance (src/geometry/instance.rs:72-105) with its transform evaluated for the frame.
+ * mat/inv are the full row-major 4x4 of Transform{mat,inv} (src/linalg/transform.rs:11-14) built
+ * in the reference's order: per spline level translate*rot*scale (keyframe.rs:60-63), stacked
+ * object-first (animated_transform.rs:40-56). Row 3 is kept because Transform*Point divides by w
+ * only when |w-1| < eps (transform.rs:211-215). */
+typedef struct TrayInstance {
+    uint32_t kind;        /* TRAY_INST_* */
+    uint32_t geom_type;   /* TRAY_GEOM_* */
+    uint32_t mesh_id;     /* valid for TRAY_GEOM_MESH */
+    uint32_t material_id; /* 0xffffffff for point emitters */
+    float geom_params[4]; /* sphere: radius | disk: radius, inner_radius | rect: width, height */
+    float emission[4];    /* AnimatedColor::color(time) for the frame (rgb, a) */
+    float mat[16];
+    float inv[16];
+    uint32_t light_index; /* index in lights[] or 0xffffffff */
+    uint32_t xf_first;    /* first TrayXformLevel of this instance's spline stack */
+    uint32_t xf_count;    /* number of levels (object first, then group parents) */
+    uint32_t pad;
+} TrayInstance;
+
+/* TRS keyframe (src/linalg/keyframe.rs:13-17) */
+typedef struct TrayKeyframe {
+    float translation[3];
+    float rotation[4];    /* quaternion v.xyz, w */
+    float scaling[3];
+} TrayKeyframe;
+
+/* One B-spline level of an AnimatedTransform (src/linalg/animated_transform.rs:15-19) */
+typedef struct TrayXformLevel {
+    uint32_t kf_first, kf_count;     /* control points in keyframes[] */
+    uint32_t knot_first, knot_count; /* knots in knots[] */
+    uint32_t degree;
+} TrayXformLevel;
+
+enum {
+    TRAY_MAT_MATTE = 0, TRAY_MAT_PLASTIC = 1, TRAY_MAT_METAL = 2, TRAY_MAT_GLASS = 3,
+    TRAY_MAT_ROUGH_GLASS = 4, TRAY_MAT_SPECULAR_METAL = 5, TRAY_MAT_MERL = 6
+};
+
+/* Closed lowering of the reference's Material trait objects (src/material/*.rs); every texture
+ * parameter is a constant (texture/mod.rs:43-76), scalars read from colour textures are luminance.
+ *   MATTE          c0 = diffuse,            f0 = roughness            (matte.rs:52-65)
+ *   PLASTIC        c0 = diffuse, c1 = gloss, f0 = roughness           (plastic.rs:59-88)
+ *   METAL          c0 = eta, c1 = k,        f0 = roughness            (metal.rs:56-67)
+ *   GLASS          c0 = reflect, c1 = transmit, f0 = eta              (glass.rs:51-78)
+ *   ROUGH_GLASS    c0 = reflect, c1 = transmit, f0 = eta, f1 = roughness (rough_glass.rs:57-85)
+ *   SPECULAR_METAL c0 = eta, c1 = k                                   (specular_metal.rs:49-58)
+ *   MERL           table = index into merl tables                     (material/merl.rs:88-92) */
+typedef struct TrayMaterial {
+    uint32_t kind;
+    uint32_t table;
+    float f0, f1;
+    float c0[4];
+    float c1[4];
+} TrayMaterial;
+
+/* MERL table header: 90*90*180 RGB-interleaved f32, already scaled (material/merl.rs:60-82) */
+typedef struct TrayMerlTable {
+    uint64_t offset;  /* float offset into merl_data */
+    uint32_t n_theta_h, n_theta_d, n_phi_d;
+    uint32_t pad;
+} TrayMerlTable;
+
+/* Camera for one frame (src/film/camera.rs:64-157).
+ * raster_to_cam = (proj_div_inv * raster_screen).mat, a genuinely projective 4x4 (Q5). */
+typedef struct TrayCamera {
+    float raster_to_cam[16];
+    float scaling[3];
+    float shutter_open, shutter_close;
+    float cam_world[16];   /* cam_world.transform(t).mat for an unanimated camera */
+    uint32_t animated;     /* 1 => cam_world must be evaluated per ray (not yet supported on device) */
+    uint32_t xf_first, xf_count;
+} TrayCamera;
+
+#define TRAY_FILTER_TABLE_SIZE 16
+
+/* Film + reconstruction filter (src/film/render_target.rs:41-75) */
+typedef struct TrayFilm {
+    uint32_t width, height;
+    float filter_w, filter_h, inv_w, inv_h;
+    int32_t filter_pixel_w, filter_pixel_h;   /* floor(w/0.5), floor(h/0.5) */
+    float table[TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE];
+} TrayFilm;
+
+typedef struct TrayFlatScene {
+    uint32_t abi_version;
+    uint32_t frame;
+    TrayFilm film;
+    TrayCamera camera;
+    uint32_t min_depth, max_depth;       /* Path integrator (src/integrator/path.rs:33-43) */
+
+    uint32_t n_instances;   const TrayInstance* instances;
+    uint32_t n_top_nodes;   const TrayBvhNode* top_nodes;       /* BVH<Instance>, leaf <= 4 */
+    uint32_t n_top_order;   const uint32_t* top_order;          /* ordered_geom of the top BVH */
+    uint32_t n_meshes;      const TrayMesh* meshes;
+    uint32_t n_mesh_nodes;  const TrayBvhNode* mesh_nodes;      /* all BVH<Triangle>, leaf <= 16 */
+    uint32_t n_tris;        const TrayTriVerts* tri_verts;      /* leaf order, per mesh */
+                            const TrayTriAttrs* tri_attrs;
+    uint32_t n_materials;   const TrayMaterial* materials;
+    uint32_t n_merl;        const TrayMerlTable* merl_tables;
+    uint64_t n_merl_floats; const float* merl_data;
+    uint32_t n_lights;      const uint32_t* lights;             /* instance ids, scene order */
+    uint32_t n_xf_levels;   const TrayXformLevel* xf_levels;
+    uint32_t n_keyframes;   const TrayKeyframe* keyframes;
+    uint32_t n_knots;       const float* knots;
+} TrayFlatScene;
+
+/* ---------------------------------------------------------------- host side: loader (scene.rs) */
+
+typedef struct TrayHostScene TrayHostScene;
+
+typedef struct TraySceneInfo {
+    uint32_t width, height;
+    uint32_t spp;                /* film.samples as written in the file */
+    uint32_t frames, start_frame, end_frame;
+    float scene_time;
+    uint32_t n_instances, n_lights, n_meshes, n_tris;
+} TraySceneInfo;
+
+/* Scene::load_file (src/scene.rs:101-145). The JSON schema is the reference's. */
+int tray_scene_load_file(const char* path, TrayHostScene** out);
+/* Same, from an in-memory JSON string; base_dir resolves relative mesh / MERL paths. */
+int tray_scene_load_string(const char* json, const char* base_dir, TrayHostScene** out);
+int tray_host_scene_info(const TrayHostScene* s, TraySceneInfo* info);
+/* Scene::update_frame (scene.rs:152-176) + flattening for frame `frame`: camera shutter, top-level
+ * BVH rebuilt over the shutter interval, per-instance matrices. The returned view borrows from `s`
+ * and is valid until the next flatten / free on `s`. */
+int tray_host_scene_flatten(TrayHostScene* s, uint32_t frame, const TrayFlatScene** out);
+void tray_host_scene_free(TrayHostScene* s);
+
+/* BlockQueue::new (src/sampler/block_queue.rs:28-48): 8x8 tiles sorted by Morton code of the
+ * tile index. Writes up to `cap` (x,y) tile coordinates into xy (2*u32 each), returns the number
+ * of tiles through n_out. select (start,count) applies after sorting; count 0 = all. */
+int tray_block_queue(uint32_t width, uint32_t height, uint32_t select_start, uint32_t select_count,
+                     uint32_t* xy, uint32_t cap, uint32_t* n_out);
+
+/* LowDiscrepancy::new rounding (src/sampler/ld.rs:22-25) */
+uint32_t tray_round_spp(uint32_t spp);
+
+/* RenderTarget::get_render (render_target.rs:185-210): RGBW f32 -> sRGB8 (3 bytes / pixel). */
+int tray_resolve_srgb8(const float* rgbw, uint32_t width, uint32_t height, uint8_t* rgb8);
+
+/* ---------------------------------------------------------------- device side: the tile worker */
+
+typedef struct TrayDeviceScene TrayDeviceScene;
+
+/* Bind the calling thread's library state to HIP device `device` (one process per GPU). */
+int tray_init(int device);
+int tray_device_count(int* n);
+
+/* Deep-copies the flat scene to the current device. */
+int tray_scene_create(const TrayFlatScene* flat, TrayDeviceScene** out);
+void tray_scene_destroy(TrayDeviceScene* s);
+
+/* thread_work over tiles [tile_start, tile_start+tile_count) of the Morton queue
+ * (exec/multithreaded.rs:72-114 with Config.select_blocks, exec/mod.rs:25-27).
+ * Adds filtered samples into rgbw_dev: device pointer, width*height*4 f32, the layout of
+ * RenderTarget::get_renderf32 (render_target.rs:243-266). Asynchronous on `stream`
+ * (a hipStream_t; NULL = default stream). spp must already be a power of two. */
+int tray_render_tiles_device(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count,
+                             uint32_t spp, uint64_t seed, float* rgbw_dev, void* stream);
+
+/* Synchronous convenience wrapper: renders into a zeroed device buffer, adds it into rgbw_host
+ * (host, width*height*4 f32) — semantics of film::Image::add_pixels. */
+int tray_render_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count,
+                      uint32_t spp, uint64_t seed, float* rgbw_host);
+
+/* Timing of the most recent tray_render_tiles_device launch sequence on this scene, measured with
+ * HIP events on the launch stream. Blocks until those kernels finished. */
+typedef struct TrayKernelTiming {
+    float render_ms;        /* k_path_tiles */
+    uint32_t launches;
+    uint64_t samples;       /* camera samples traced */
+    uint64_t vertices;      /* path vertices shaded (iterations of path.rs:69) */
+    uint64_t rays;          /* Scene::intersect calls */
+} TrayKernelTiming;
+int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t);
+
+/* ---- parity / debug entry points (same device code as the renderer, one thread per item) ---- */
+
+typedef struct TrayRay { float o[3]; float d[3]; float min_t, max_t, time; } TrayRay;   /* ray.rs:9-22 */
+typedef struct TrayHit {
+    float t;
+    uint32_t inst;      /* instance id or 0xffffffff on miss */
+    uint32_t prim;      /* triangle slot (leaf order) for meshes, else 0 */
+    float p[3], n[3], ng[3];
+    float u, v;
+    float dp_du[3], dp_dv[3];
+} TrayHit;
+/* Scene::intersect (scene.rs:148-150) for n host rays -> n host hits. */
+int tray_debug_intersect(TrayDeviceScene* s, uint32_t n, const TrayRay* rays, TrayHit* hits);
+
+/* Radiance of individual camera samples: for item i, pixel (px[i], py[i]), sample index si[i]:
+ * out[i*8 + 0..2] = clamped rgb (multithreaded.rs:98-99), [3] = sample x, [4] = sample y,
+ * [5] = number of path vertices, [6] = number of rays, [7] = 0. */
+int tray_debug_sample_radiance(TrayDeviceScene* s, uint32_t n, const uint32_t* px, const uint32_t* py,
+                               const uint32_t* si, uint32_t spp, uint64_t seed, float* out);
+
+/* BSDF::eval / pdf / sample (src/bxdf/bsdf.rs:66-125) of material `material_id` on a canonical
+ * frame (n = +z, dp_du = +x). For item i: wo = dirs[i*6..+3], wi = dirs[i*6+3..+6], u = u3[i*3..+3]
+ * (two_d.0, two_d.1, one_d). out[i*12]: eval rgb(3), pdf(1), sample f rgb(3), sample wi(3),
+ * sample pdf(1), sampled type bits(1, as float). flags: 0 = BxDFType::all(), 1 = non_specular(). */
+int tray_debug_bsdf(TrayDeviceScene* s, uint32_t material_id, uint32_t flags, uint32_t n,
+                    const float* dirs, const float* u3, float* out);
+
+const char* tray_last_error(void);
+const char* tray_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAYHIP_H */

@@ -1,0 +1,135 @@
+"""ctypes binding of oracle/liboracle.so — the CPU checker. Test infrastructure only: nothing under
+tray_rust_amd/ imports this module."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from tray_rust_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+
+FAITHFUL_XF, BRUTE_FORCE = 1, 2
+
+
+class OracleStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("vertices", C.c_uint64), ("rays", C.c_uint64), ("seconds", C.c_double)]
+
+
+_o = None
+
+
+def build():
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+
+
+def oracle():
+    global _o
+    if _o is None:
+        if not os.path.exists(ORACLE_SO):
+            build()
+        o = C.CDLL(ORACLE_SO)
+        FS = C.POINTER(L.TrayFlatScene)
+        o.oracle_render_tiles.restype = C.c_int
+        o.oracle_render_tiles.argtypes = [FS, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int, C.c_int,
+                                          C.POINTER(OracleStats)]
+        o.oracle_intersect.restype = C.c_int
+        o.oracle_intersect.argtypes = [FS, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+        o.oracle_camera_rays.restype = C.c_int
+        o.oracle_camera_rays.argtypes = [FS, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        o.oracle_sample_radiance.restype = C.c_int
+        o.oracle_sample_radiance.argtypes = [FS, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int]
+        o.oracle_bsdf.restype = C.c_int
+        o.oracle_bsdf.argtypes = [FS, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        o.oracle_instance_matrices.restype = C.c_int
+        o.oracle_instance_matrices.argtypes = [FS, C.c_void_p]
+        for name in ("oracle_mat4_mul", "oracle_mat4_add", "oracle_mat4_sub"):
+            getattr(o, name).restype = None
+            getattr(o, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        o.oracle_mat4_inverse.restype = None
+        o.oracle_mat4_inverse.argtypes = [C.c_void_p, C.c_void_p]
+        o.oracle_transform.restype = None
+        o.oracle_transform.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+        o.oracle_transform_apply.restype = None
+        o.oracle_transform_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        o.oracle_cross.restype = None
+        o.oracle_cross.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        o.oracle_dot.restype = C.c_float
+        o.oracle_dot.argtypes = [C.c_void_p, C.c_void_p]
+        o.oracle_van_der_corput.restype = C.c_float
+        o.oracle_van_der_corput.argtypes = [C.c_uint32, C.c_uint32]
+        o.oracle_sobol.restype = C.c_float
+        o.oracle_sobol.argtypes = [C.c_uint32, C.c_uint32]
+        o.oracle_permute.restype = C.c_uint32
+        o.oracle_permute.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        o.oracle_shuffle_small.restype = None
+        o.oracle_shuffle_small.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+        o.oracle_mix32.restype = C.c_uint32
+        o.oracle_mix32.argtypes = [C.c_uint32]
+        o.oracle_pixel_sample.restype = None
+        o.oracle_pixel_sample.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        o.oracle_path_samples.restype = None
+        o.oracle_path_samples.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        o.oracle_film_write.restype = None
+        o.oracle_film_write.argtypes = [FS, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        _o = o
+    return _o
+
+
+def render_tiles(flat, spp, seed=1, tile_start=0, tile_count=0, stride=1, threads=None, flags=0):
+    """Returns (rgbw float32[h, w, 4], OracleStats)."""
+    fs = flat.contents
+    w, h = fs.film.width, fs.film.height
+    img = np.zeros((h, w, 4), dtype=np.float32)
+    st = OracleStats()
+    if threads is None:
+        threads = os.cpu_count() or 1
+    rc = oracle().oracle_render_tiles(flat, tile_start, tile_count, stride, spp, seed, img.ctypes.data, threads, flags, C.byref(st))
+    if rc != 0:
+        raise RuntimeError("oracle_render_tiles failed")
+    return img, st
+
+
+def sample_radiance(flat, px, py, si, spp, seed=1, flags=0):
+    px = np.ascontiguousarray(px, dtype=np.uint32); py = np.ascontiguousarray(py, dtype=np.uint32); si = np.ascontiguousarray(si, dtype=np.uint32)
+    out = np.zeros((len(px), 8), dtype=np.float32)
+    rc = oracle().oracle_sample_radiance(flat, len(px), px.ctypes.data, py.ctypes.data, si.ctypes.data, spp, seed, out.ctypes.data, flags)
+    if rc != 0:
+        raise RuntimeError("oracle_sample_radiance failed")
+    return out
+
+
+def intersect(flat, rays, flags=0):
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 9)
+    hits = np.zeros(len(rays), dtype=HIT_DTYPE)
+    rc = oracle().oracle_intersect(flat, len(rays), rays.ctypes.data, hits.ctypes.data, flags)
+    if rc != 0:
+        raise RuntimeError("oracle_intersect failed")
+    return hits
+
+
+def camera_rays(flat, xy, time=None):
+    xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+    rays = np.zeros((len(xy), 9), dtype=np.float32)
+    t = None if time is None else np.ascontiguousarray(time, dtype=np.float32)
+    oracle().oracle_camera_rays(flat, len(xy), xy.ctypes.data, None if t is None else t.ctypes.data, rays.ctypes.data)
+    return rays
+
+
+def bsdf(flat, material_id, flags_sel, dirs, u3):
+    dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 6)
+    u3 = np.ascontiguousarray(u3, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros((len(dirs), 12), dtype=np.float32)
+    rc = oracle().oracle_bsdf(flat, material_id, flags_sel, len(dirs), dirs.ctypes.data, u3.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("oracle_bsdf failed")
+    return out
+
+
+# numpy view of TrayHit (include/trayhip.h)
+HIT_DTYPE = np.dtype([("t", "<f4"), ("inst", "<u4"), ("prim", "<u4"), ("p", "<f4", 3), ("n", "<f4", 3), ("ng", "<f4", 3),
+                      ("u", "<f4"), ("v", "<f4"), ("dp_du", "<f4", 3), ("dp_dv", "<f4", 3)])
+assert HIT_DTYPE.itemsize == C.sizeof(L.TrayHit)

@@ -1,0 +1,203 @@
+"""tray_rust_amd — MI355X-native tile worker for tray_rust scenes.
+
+Host-side mirror of the reference's interface for the hot path (names, argument meaning and error
+behaviour follow /root/reference):
+
+    Scene.load_file(path) -> (scene, rt, spp, frame_info)      src/scene.rs:101-145
+    FrameInfo, Config                                           src/film/mod.rs:19-36, src/exec/mod.rs:17-38
+    Hip().render(scene, rt, config)                             trait Exec, src/exec/mod.rs:41-49
+    RenderTarget.get_renderf32 / get_render / clear             src/film/render_target.rs:168-266
+    BlockQueue(img, dim, select_blocks)                         src/sampler/block_queue.rs:11-66
+
+Everything below the Python layer is libtrayhip.so (include/trayhip.h): a C++ scene loader and
+hand-written HIP kernels for gfx950. The reference panics on invalid input; here the same
+preconditions raise TrayError. There is no CPU fallback: without the library / a GPU the calls fail.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import TrayError, lib, check
+
+__all__ = ["Scene", "FrameInfo", "Config", "RenderTarget", "Hip", "BlockQueue", "TrayError", "round_spp"]
+
+
+def round_spp(spp):
+    """LowDiscrepancy::new rounds spp up to a power of two (src/sampler/ld.rs:22-25)."""
+    r = int(lib().tray_round_spp(int(spp)))
+    if r != spp:
+        print(f"Warning: LowDiscrepancy sampler requires power of two samples per pixel, rounding up to {r}")
+    return r
+
+
+class FrameInfo:
+    """src/film/mod.rs:19-36"""
+
+    def __init__(self, frames, time, start, end):
+        self.frames, self.time, self.start, self.end = int(frames), float(time), int(start), int(end)
+
+    def __repr__(self):
+        return f"FrameInfo(frames={self.frames}, time={self.time}, start={self.start}, end={self.end})"
+
+
+class Config:
+    """src/exec/mod.rs:17-38; select_blocks = (start, count) into the Morton tile queue, count 0 = all."""
+
+    def __init__(self, out_path, scene_file, spp, num_threads, frame_info, select_blocks=(0, 0)):
+        self.out_path, self.scene_file, self.spp, self.num_threads = out_path, scene_file, int(spp), int(num_threads)
+        self.frame_info, self.current_frame, self.select_blocks = frame_info, frame_info.start, tuple(select_blocks)
+
+
+class BlockQueue:
+    """src/sampler/block_queue.rs:28-48: 8x8 tiles in Morton order, optional (start, count) sub-range."""
+
+    def __init__(self, img, dim=(8, 8), select_blocks=(0, 0)):
+        if tuple(dim) != (8, 8):
+            raise TrayError(_lib.TRAY_E_UNSUPPORTED, "only (8, 8) blocks are supported (exec/multithreaded.rs:32)")
+        n = C.c_uint32(0)
+        check(lib().tray_block_queue(img[0], img[1], select_blocks[0], select_blocks[1], None, 0, C.byref(n)))
+        buf = (C.c_uint32 * (2 * n.value))()
+        check(lib().tray_block_queue(img[0], img[1], select_blocks[0], select_blocks[1], buf, n.value, C.byref(n)))
+        self.blocks = [(buf[2 * i], buf[2 * i + 1]) for i in range(n.value)]
+        self.dimensions = (8, 8)
+        if not self.blocks:
+            print("Warning: This block queue is empty!")
+
+    def block_dim(self):
+        return self.dimensions
+
+    def __len__(self):
+        return len(self.blocks)
+
+    def __iter__(self):
+        return iter(self.blocks)
+
+
+class RenderTarget:
+    """Accumulated RGBW f32 film in the layout of RenderTarget::get_renderf32
+    (src/film/render_target.rs:243-266). The GPU accumulates on the device; this host object merges
+    results by addition like film::Image::add_pixels (src/film/image.rs:21-34)."""
+
+    def __init__(self, width, height):
+        self.width, self.height = int(width), int(height)
+        self.pixels = np.zeros(self.width * self.height * 4, dtype=np.float32)
+
+    def dimensions(self):
+        return (self.width, self.height)
+
+    def clear(self):
+        self.pixels[:] = 0.0
+
+    def add_pixels(self, rgbw):
+        self.pixels += np.asarray(rgbw, dtype=np.float32).reshape(-1)
+
+    def get_renderf32(self):
+        return self.pixels.copy()
+
+    def get_render(self):
+        """sRGB8, 3 bytes per pixel (render_target.rs:185-210)."""
+        out = np.zeros(self.width * self.height * 3, dtype=np.uint8)
+        check(lib().tray_resolve_srgb8(self.pixels.ctypes.data, self.width, self.height, out.ctypes.data))
+        return out
+
+
+class Scene:
+    """Loaded scene (host side) + its device copy for the current frame."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._dev = None
+        self._dev_frame = None
+        self._dev_device = None
+        info = _lib.TraySceneInfo()
+        check(lib().tray_host_scene_info(self._h, C.byref(info)))
+        self.info = info
+
+    @staticmethod
+    def load_file(path):
+        """Scene::load_file -> (scene, render_target, spp, frame_info)"""
+        h = C.c_void_p()
+        check(lib().tray_scene_load_file(os.fsencode(path), C.byref(h)))
+        return Scene._finish(h)
+
+    @staticmethod
+    def load_string(text, base_dir=""):
+        h = C.c_void_p()
+        check(lib().tray_scene_load_string(text.encode("utf-8"), os.fsencode(base_dir), C.byref(h)))
+        return Scene._finish(h)
+
+    @staticmethod
+    def _finish(h):
+        s = Scene(h)
+        i = s.info
+        return s, RenderTarget(i.width, i.height), int(i.spp), FrameInfo(i.frames, i.scene_time, i.start_frame, i.end_frame)
+
+    def flatten(self, frame=0):
+        """Scene::update_frame + lowering to the TrayFlatScene POD (borrowed from this scene)."""
+        p = C.POINTER(_lib.TrayFlatScene)()
+        check(lib().tray_host_scene_flatten(self._h, int(frame), C.byref(p)))
+        return p
+
+    def device_scene(self, frame=0, device=None):
+        if self._dev is not None and (self._dev_frame != frame or (device is not None and device != self._dev_device)):
+            self.release_device()
+        if self._dev is None:
+            if device is not None:
+                check(lib().tray_init(int(device)))
+            flat = self.flatten(frame)
+            d = C.c_void_p()
+            check(lib().tray_scene_create(flat, C.byref(d)))
+            self._dev, self._dev_frame, self._dev_device = d, frame, device
+        return self._dev
+
+    def release_device(self):
+        if self._dev is not None:
+            lib().tray_scene_destroy(self._dev)
+            self._dev = None
+
+    def close(self):
+        self.release_device()
+        if self._h is not None:
+            lib().tray_host_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Hip:
+    """Execution backend in the place of exec::MultiThreaded (src/exec/multithreaded.rs:20-70): renders
+    config.select_blocks of frame config.current_frame on one MI355X and adds the result into rt."""
+
+    def __init__(self, device=0, seed=1):
+        self.device, self.seed = int(device), int(seed)
+        check(lib().tray_init(self.device))
+        self.last_timing = None
+
+    def render(self, scene, rt, config):
+        spp = round_spp(config.spp)
+        dev = scene.device_scene(config.current_frame, self.device)
+        start, count = config.select_blocks
+        check(lib().tray_render_tiles(dev, int(start), int(count), spp, self.seed, rt.pixels.ctypes.data))
+        t = _lib.TrayKernelTiming()
+        if lib().tray_last_timing(dev, C.byref(t)) == _lib.TRAY_OK:
+            self.last_timing = t
+            print(f"Frame {config.current_frame}: rendering took {t.render_ms * 1e-3:.4f}s")
+
+    def render_device(self, scene, frame, select_blocks, spp, rgbw_ptr, stream=None):
+        """Asynchronous variant: accumulate into a device RGBW buffer (e.g. torch tensor .data_ptr())."""
+        dev = scene.device_scene(frame, self.device)
+        check(lib().tray_render_tiles_device(dev, int(select_blocks[0]), int(select_blocks[1]), int(spp), self.seed,
+                                             C.c_void_p(int(rgbw_ptr)), C.c_void_p(int(stream)) if stream else None))
+        return dev
+
+    def timing(self, scene):
+        t = _lib.TrayKernelTiming()
+        check(lib().tray_last_timing(scene.device_scene(scene._dev_frame, self.device), C.byref(t)))
+        self.last_timing = t
+        return t

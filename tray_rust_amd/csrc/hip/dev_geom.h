@@ -1,0 +1,418 @@
+// Device-side geometry: two-level BVH traversal (closest / any hit), primitive tests, deferred
+// differential geometry, area-light sampling. One thread = one ray. Mirrors, per function:
+//   Scene::intersect scene.rs:148-150        BVH::intersect bvh.rs:81-130     fast_intersect bbox.rs:75-104
+//   Instance/Receiver/Emitter::intersect receiver.rs:29-44, emitter.rs:118-137
+//   intersect_triangle mesh.rs:136-198       Sphere sphere.rs:33-140          Rectangle rectangle.rs:38-104
+//   Disk disk.rs:42-110                      Light for Emitter emitter.rs:140-203
+// Difference by design (results identical): the reference builds a DifferentialGeometry for every
+// accepted candidate; here traversal only keeps (t, instance, primitive, barycentrics) and the
+// differential geometry of the final hit is rebuilt once from exactly the same inputs.
+#pragma once
+#include "../../../include/trayhip.h"
+#include "dev_math.h"
+
+namespace tr {
+
+struct DevScene {
+    const TrayInstance* __restrict__ instances;
+    const TrayBvhNode* __restrict__ top_nodes;
+    const uint32_t* __restrict__ top_order;
+    const TrayMesh* __restrict__ meshes;
+    const TrayBvhNode* __restrict__ mesh_nodes;
+    const TrayTriVerts* __restrict__ tri_verts;
+    const TrayTriAttrs* __restrict__ tri_attrs;
+    const TrayMaterial* __restrict__ materials;
+    const TrayMerlTable* __restrict__ merl_tables;
+    const float* __restrict__ merl_data;
+    const uint32_t* __restrict__ lights;
+    const float* __restrict__ filter_table;
+    uint32_t n_instances, n_lights, min_depth, max_depth;
+    uint32_t width, height, frame, pad;
+    float filter_w, filter_h, inv_w, inv_h;
+    int32_t fpw, fph;
+    TrayCamera camera;
+};
+
+struct Ray {
+    f3 o, d;
+    float min_t, max_t, time;
+};
+TR_DEV f3 ray_at(const Ray& r, float t) { return r.o + r.d * t; }   // ray.rs:43-45
+
+struct HitRec {   // what traversal keeps for the closest candidate
+    float t;
+    uint32_t inst;
+    uint32_t prim;
+    float b1, b2;
+};
+
+struct Hit {   // DifferentialGeometry in world space (differential_geometry.rs:9-27) + instance id
+    f3 p, n, ng, dp_du;
+    uint32_t inst;
+};
+
+struct Counters { uint32_t rays, vertices; };
+
+// BBox::fast_intersect (bbox.rs:75-104); comparison directions kept so NaNs fall the same way
+TR_DEV bool bbox_hit(const float4 lo, const float4 hi, const f3 o, const f3 inv_dir, const bool nx, const bool ny, const bool nz,
+                     float min_t, float max_t) {
+    // lo = (bmin.x, bmin.y, bmin.z, bmax.x), hi = (bmax.y, bmax.z, ...)
+    float bminx = lo.x, bminy = lo.y, bminz = lo.z, bmaxx = lo.w, bmaxy = hi.x, bmaxz = hi.y;
+    float tmin = ((nx ? bmaxx : bminx) - o.x) * inv_dir.x;
+    float tmax = ((nx ? bminx : bmaxx) - o.x) * inv_dir.x;
+    float tymin = ((ny ? bmaxy : bminy) - o.y) * inv_dir.y;
+    float tymax = ((ny ? bminy : bmaxy) - o.y) * inv_dir.y;
+    if (tmin > tymax || tymin > tmax) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = ((nz ? bmaxz : bminz) - o.z) * inv_dir.z;
+    float tzmax = ((nz ? bminz : bmaxz) - o.z) * inv_dir.z;
+    if (tmin > tzmax || tzmin > tmax) return false;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    return tmin < max_t && tmax > min_t;
+}
+
+// Test part of intersect_triangle (mesh.rs:136-171). Inclusive range test, no back-face culling.
+TR_DEV bool triangle_test(const TrayTriVerts* __restrict__ tv, f3 o, f3 d, float min_t, float max_t, float& t_out, float& b1_out, float& b2_out) {
+    const float4* q = reinterpret_cast<const float4*>(tv);
+    float4 A = q[0], B = q[1], C = q[2];
+    f3 pa = mk(A.x, A.y, A.z), pb = mk(B.x, B.y, B.z), pc = mk(C.x, C.y, C.z);
+    f3 e0 = pb - pa, e1 = pc - pa;
+    f3 s0 = cross(d, e1);
+    float dv = dot(s0, e0);
+    if (dv == 0.0f) return false;
+    float div = 1.0f / dv;
+    f3 dd = o - pa;
+    float b1 = dot(dd, s0) * div;
+    if (b1 < 0.0f || b1 > 1.0f) return false;
+    f3 s1 = cross(dd, e0);
+    float b2 = dot(d, s1) * div;
+    if (b2 < 0.0f || b1 + b2 > 1.0f) return false;
+    float t = dot(e1, s1) * div;
+    if (t < min_t || t > max_t) return false;
+    t_out = t; b1_out = b1; b2_out = b2;
+    return true;
+}
+
+TR_DEV bool sphere_test(float radius, f3 o, f3 d, float min_t, float max_t, float& t_out) {   // sphere.rs:33-53
+    float a = length_sqr(d);
+    float b = 2.0f * dot(d, o);
+    float c = dot(o, o) - radius * radius;
+    float t0, t1;
+    if (!solve_quadratic(a, b, c, t0, t1)) return false;
+    if (t0 > max_t || t1 < min_t) return false;
+    float t_hit = t0;
+    if (t_hit < min_t) {
+        t_hit = t1;
+        if (t_hit > max_t) return false;
+    }
+    t_out = t_hit;
+    return true;
+}
+TR_DEV bool rect_test(float width, float height, f3 o, f3 d, float min_t, float max_t, float& t_out) {   // rectangle.rs:38-52
+    if (fabsf(d.z) < 1e-8f) return false;
+    float t = -o.z / d.z;
+    if (t < min_t || t > max_t) return false;
+    f3 p = o + d * t;
+    float hw = width / 2.0f, hh = height / 2.0f;
+    if (p.x >= -hw && p.x <= hw && p.y >= -hh && p.y <= hh) { t_out = t; return true; }
+    return false;
+}
+TR_DEV bool disk_test(float radius, float inner_radius, f3 o, f3 d, float min_t, float max_t, float& t_out) {   // disk.rs:42-66
+    if (fabsf(d.z) == 0.0f) return false;
+    float t = -o.z / d.z;
+    if (t < min_t || t > max_t) return false;
+    f3 p = o + d * t;
+    float dist_sqr = p.x * p.x + p.y * p.y;
+    if (dist_sqr > radius * radius || dist_sqr < inner_radius * inner_radius) return false;
+    float phi = atan2f(p.y, p.x);
+    if (phi < 0.0f) phi += kPi * 2.0f;
+    if (phi > kPi * 2.0f) return false;
+    t_out = t;
+    return true;
+}
+
+#define TR_STACK 32
+
+// BVH<Triangle>::intersect over one mesh (bvh.rs:81-130, leaf <= 16). Returns true if any triangle
+// was accepted; max_t shrinks as candidates are accepted. ANY: stop at the first accepted candidate.
+template <bool ANY>
+TR_DEV bool mesh_traverse(const DevScene& sc, const TrayMesh m, f3 o, f3 d, float min_t, float& max_t, uint32_t& prim, float& b1, float& b2) {
+    const TrayBvhNode* __restrict__ tree = sc.mesh_nodes + m.node_offset;
+    const TrayTriVerts* __restrict__ tris = sc.tri_verts + m.tri_offset;
+    f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
+    uint32_t stack[TR_STACK];
+    int sp = 0;
+    uint32_t current = 0;
+    bool any = false;
+    for (;;) {
+        const float4* nq = reinterpret_cast<const float4*>(tree + current);
+        float4 lo = nq[0], hi = nq[1];
+        uint32_t offset = __float_as_uint(hi.z);
+        uint32_t meta = __float_as_uint(hi.w);   // count (16) | axis (8) | pad (8)
+        uint32_t count = meta & 0xffffu, axis = (meta >> 16) & 0xffu;
+        if (bbox_hit(lo, hi, o, inv_dir, nx, ny, nz, min_t, max_t)) {
+            if (count > 0) {
+                for (uint32_t k = 0; k < count; ++k) {
+                    float t, bb1, bb2;
+                    if (triangle_test(tris + offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
+                        max_t = t; prim = m.tri_offset + offset + k; b1 = bb1; b2 = bb2; any = true;
+                        if (ANY) return true;
+                    }
+                }
+                if (sp == 0) break;
+                current = stack[--sp];
+            } else {
+                bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
+                if (neg) { stack[sp++] = current + 1; current = offset; }
+                else { stack[sp++] = offset; current = current + 1; }
+            }
+        } else {
+            if (sp == 0) break;
+            current = stack[--sp];
+        }
+    }
+    return any;
+}
+
+// Instance::intersect, test part (receiver.rs:29-35): world ray -> object ray by `inv`
+// (direction not renormalised, so t is shared between spaces), then the primitive test.
+template <bool ANY>
+TR_DEV bool instance_test(const DevScene& sc, uint32_t i, const Ray& ray, float& max_t, HitRec& rec) {
+    const TrayInstance* __restrict__ in = sc.instances + i;
+    uint32_t kind = in->kind;
+    if (kind == TRAY_INST_POINT_EMITTER) return false;   // emitter.rs:120
+    f3 o = xf_point(in->inv, ray.o);
+    f3 d = xf_vector(in->inv, ray.d);
+    uint32_t gt = in->geom_type;
+    float t;
+    bool hit = false;
+    uint32_t prim = 0;
+    float b1 = 0.0f, b2 = 0.0f;
+    if (gt == TRAY_GEOM_RECT) {
+        hit = rect_test(in->geom_params[0], in->geom_params[1], o, d, ray.min_t, max_t, t);
+    } else if (gt == TRAY_GEOM_SPHERE) {
+        hit = sphere_test(in->geom_params[0], o, d, ray.min_t, max_t, t);
+    } else if (gt == TRAY_GEOM_MESH) {
+        t = max_t;
+        hit = mesh_traverse<ANY>(sc, sc.meshes[in->mesh_id], o, d, ray.min_t, t, prim, b1, b2);
+    } else if (gt == TRAY_GEOM_DISK) {
+        hit = disk_test(in->geom_params[0], in->geom_params[1], o, d, ray.min_t, max_t, t);
+    }
+    if (hit) {
+        max_t = t;
+        rec.t = t; rec.inst = i; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
+    }
+    return hit;
+}
+
+// Scene::intersect: BVH<Instance> traversal (leaf <= 4). Returns true on hit, rec holds the closest
+// candidate (the last accepted one, bvh.rs:93-98).
+template <bool ANY>
+TR_DEV bool scene_traverse(const DevScene& sc, const Ray& ray, HitRec& rec) {
+    const TrayBvhNode* __restrict__ tree = sc.top_nodes;
+    f3 inv_dir = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    bool nx = ray.d.x < 0.0f, ny = ray.d.y < 0.0f, nz = ray.d.z < 0.0f;
+    float max_t = ray.max_t;
+    uint32_t stack[TR_STACK];
+    int sp = 0;
+    uint32_t current = 0;
+    bool any = false;
+    for (;;) {
+        const float4* nq = reinterpret_cast<const float4*>(tree + current);
+        float4 lo = nq[0], hi = nq[1];
+        uint32_t offset = __float_as_uint(hi.z);
+        uint32_t meta = __float_as_uint(hi.w);
+        uint32_t count = meta & 0xffffu, axis = (meta >> 16) & 0xffu;
+        if (bbox_hit(lo, hi, ray.o, inv_dir, nx, ny, nz, ray.min_t, max_t)) {
+            if (count > 0) {
+                for (uint32_t k = 0; k < count; ++k) {
+                    uint32_t i = sc.top_order[offset + k];
+                    if (instance_test<ANY>(sc, i, ray, max_t, rec)) {
+                        any = true;
+                        if (ANY) return true;
+                    }
+                }
+                if (sp == 0) break;
+                current = stack[--sp];
+            } else {
+                bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
+                if (neg) { stack[sp++] = current + 1; current = offset; }
+                else { stack[sp++] = offset; current = current + 1; }
+            }
+        } else {
+            if (sp == 0) break;
+            current = stack[--sp];
+        }
+    }
+    return any;
+}
+
+// Rebuilds the DifferentialGeometry of the final candidate in object space and moves it to world
+// space (receiver.rs:36-42; DifferentialGeometry::{new,with_normal} differential_geometry.rs:32-64).
+TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, float* uv_out = nullptr, f3* dp_dv_out = nullptr) {
+    const TrayInstance* __restrict__ in = sc.instances + rec.inst;
+    f3 o = xf_point(in->inv, ray.o);
+    f3 d = xf_vector(in->inv, ray.d);
+    f3 p = o + d * rec.t;
+    f3 n, ng, dp_du, dp_dv;
+    float u = 0.0f, v = 0.0f;
+    uint32_t gt = in->geom_type;
+    if (gt == TRAY_GEOM_RECT) {   // rectangle.rs:53-60
+        float hw = in->geom_params[0] / 2.0f, hh = in->geom_params[1] / 2.0f;
+        u = (p.x + hw) / (2.0f * hw); v = (p.y + hh) / (2.0f * hh);
+        dp_du = mk(hw * 2.0f, 0.0f, 0.0f); dp_dv = mk(0.0f, hh * 2.0f, 0.0f);
+        n = normalized(cross(dp_du, dp_dv));
+        ng = normalized(mk(0.0f, 0.0f, 1.0f));
+    } else if (gt == TRAY_GEOM_SPHERE) {   // sphere.rs:56-81
+        float radius = in->geom_params[0];
+        float theta = acosf(clampf(p.z / radius, -1.0f, 1.0f));
+        float inv_z = 1.0f / sqrtf(p.x * p.x + p.y * p.y);
+        float cos_phi = p.x * inv_z, sin_phi = p.y * inv_z;
+        u = atan2f(p.x, p.y) / (2.0f * kPi);
+        if (u < 0.0f) u = u + 1.0f;
+        v = theta / kPi;
+        dp_du = mk(-kPi * 2.0f * p.y, kPi * 2.0f * p.x, 0.0f);
+        dp_dv = mk(p.z * cos_phi, p.z * sin_phi, -radius * sinf(theta)) * kPi;
+        n = normalized(p);
+        ng = n;
+    } else if (gt == TRAY_GEOM_MESH) {   // mesh.rs:172-197
+        const float4* q = reinterpret_cast<const float4*>(sc.tri_verts + rec.prim);
+        float4 A = q[0], B = q[1], C = q[2];
+        f3 pa = mk(A.x, A.y, A.z), pb = mk(B.x, B.y, B.z), pc = mk(C.x, C.y, C.z);
+        const float4* aq = reinterpret_cast<const float4*>(sc.tri_attrs + rec.prim);
+        float4 a0 = aq[0], a1 = aq[1], a2 = aq[2], a3 = aq[3];
+        f3 na = mk(a0.x, a0.y, a0.z), nb = mk(a0.w, a1.x, a1.y), nc = mk(a1.z, a1.w, a2.x);
+        f3 ta = mk(a2.y, a2.z, 0.0f), tb = mk(a2.w, a3.x, 0.0f), tc = mk(a3.y, a3.z, 0.0f);
+        float b1 = rec.b1, b2 = rec.b2;
+        float b0 = 1.0f - b1 - b2;
+        n = normalized(b0 * na + b1 * nb + b2 * nc);
+        ng = n;
+        f3 texcoord = b0 * ta + b1 * tb + b2 * tc;
+        u = texcoord.x; v = texcoord.y;
+        float du0 = ta.x - tc.x, du1 = tb.x - tc.x;
+        float dv0 = ta.y - tc.y, dv1 = tb.y - tc.y;
+        float det = du0 * dv1 - dv0 * du1;
+        if (det == 0.0f) {
+            f3 e0 = pb - pa, e1 = pc - pa;
+            coordinate_system(normalized(cross(e1, e0)), dp_du, dp_dv);
+        } else {
+            det = 1.0f / det;
+            f3 dp0 = pa - pc, dp1 = pb - pc;
+            dp_du = (dv1 * dp0 - dv0 * dp1) * det;
+            dp_dv = (-du1 * dp0 + du0 * dp1) * det;
+        }
+    } else {   // disk.rs:67-75
+        float radius = in->geom_params[0], inner_radius = in->geom_params[1];
+        float dist_sqr = p.x * p.x + p.y * p.y;
+        float phi = atan2f(p.y, p.x);
+        if (phi < 0.0f) phi += kPi * 2.0f;
+        float hit_radius = sqrtf(dist_sqr);
+        u = phi / (2.0f * kPi);
+        v = 1.0f - (hit_radius - inner_radius) / (radius - inner_radius);
+        dp_du = mk(-kPi * 2.0f * p.y, kPi * 2.0f * p.x, 0.0f);
+        dp_dv = ((inner_radius - radius) / hit_radius) * mk(p.x, p.y, 0.0f);
+        n = normalized(cross(dp_du, dp_dv));
+        ng = normalized(mk(0.0f, 0.0f, 1.0f));
+    }
+    Hit h;
+    h.p = xf_point(in->mat, p);
+    h.n = xf_normal_t(in->inv, n);
+    h.ng = xf_normal_t(in->inv, ng);
+    h.dp_du = xf_vector(in->mat, dp_du);
+    h.inst = rec.inst;
+    if (uv_out) { uv_out[0] = u; uv_out[1] = v; }
+    if (dp_dv_out) *dp_dv_out = xf_vector(in->mat, dp_dv);
+    return h;
+}
+
+// ---- Sampleable (object space) -------------------------------------------------------------
+TR_DEV f3 uniform_sample_sphere(float u0, float u1) {   // mc.rs:84-89
+    float z = 1.0f - 2.0f * u0;
+    float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    float phi = kPi * 2.0f * u1;
+    return mk(cosf(phi) * r, sinf(phi) * r, z);
+}
+TR_DEV f3 uniform_sample_cone_frame(float u0, float u1, float cos_theta_max, f3 wx, f3 wy, f3 wz) {   // mc.rs:76-82
+    float cos_theta = lerpf(u0, cos_theta_max, 1.0f);
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    float phi = u1 * kPi * 2.0f;
+    return cosf(phi) * sin_theta * wx + sinf(phi) * sin_theta * wy + cos_theta * wz;
+}
+
+// Sampleable::sample: point + normal on the emitter's geometry as seen from object-space p
+TR_DEV void geom_sample(const TrayInstance* __restrict__ in, f3 p, float u0, float u1, f3& ps, f3& ns) {
+    uint32_t gt = in->geom_type;
+    if (gt == TRAY_GEOM_RECT) {   // rectangle.rs:77-83
+        float w = in->geom_params[0], h = in->geom_params[1];
+        ps = mk(u0 * w - w / 2.0f, u1 * h - h / 2.0f, 0.0f);
+        ns = mk(0.0f, 0.0f, 1.0f);
+    } else if (gt == TRAY_GEOM_DISK) {   // disk.rs:85-93
+        float dx, dy;
+        concentric_sample_disk(u0, u1, dx, dy);
+        ps = mk(dx * in->geom_params[0], dy * in->geom_params[0], 0.0f);
+        ns = mk(0.0f, 0.0f, 1.0f);
+    } else {   // sphere.rs:92-123
+        float radius = in->geom_params[0];
+        float dist_sqr = length_sqr(p - mk(0.0f, 0.0f, 0.0f));
+        if (dist_sqr - radius * radius < 0.0001f) {
+            ps = mk(0.0f, 0.0f, 0.0f) + radius * uniform_sample_sphere(u0, u1);
+            ns = normalized(ps);
+            return;
+        }
+        f3 w_z = normalized(mk(0.0f, 0.0f, 0.0f) - p);
+        f3 w_x, w_y;
+        coordinate_system(w_z, w_x, w_y);
+        float cos_theta_max = sqrtf(fmaxf(0.0f, 1.0f - radius * radius / dist_sqr));
+        f3 dir = normalized(uniform_sample_cone_frame(u0, u1, cos_theta_max, w_x, w_y, w_z));
+        float t;
+        if (sphere_test(radius, p, dir, 0.0f, TR_INF, t)) {
+            ps = p + dir * t;
+            ns = normalized(ps);   // dg.ng of with_normal
+        } else {
+            float tt = dot(mk(0.0f, 0.0f, 0.0f) - p, dir);
+            ps = p + dir * tt;
+            ns = normalized(ps);
+        }
+    }
+}
+// Sampleable::pdf (rectangle.rs:91-104, disk.rs:97-110, sphere.rs:131-140)
+TR_DEV float geom_pdf(const TrayInstance* __restrict__ in, f3 p, f3 w_i) {
+    uint32_t gt = in->geom_type;
+    if (gt == TRAY_GEOM_SPHERE) {
+        float radius = in->geom_params[0];
+        float dist_sqr = length_sqr(p - mk(0.0f, 0.0f, 0.0f));
+        if (dist_sqr - radius * radius < 0.0001f) return 1.0f / (4.0f * kPi * radius);   // quirk Q7
+        float cos_theta_max = sqrtf(fmaxf(0.0f, 1.0f - radius * radius / dist_sqr));
+        return 1.0f / (kPi * 2.0f * (1.0f - cos_theta_max));   // mc::uniform_cone_pdf
+    }
+    float t, area;
+    bool hit;
+    f3 n;
+    if (gt == TRAY_GEOM_RECT) {
+        hit = rect_test(in->geom_params[0], in->geom_params[1], p, w_i, 0.001f, TR_INF, t);
+        area = in->geom_params[0] * in->geom_params[1];
+        float hw = in->geom_params[0] / 2.0f, hh = in->geom_params[1] / 2.0f;
+        n = normalized(cross(mk(hw * 2.0f, 0.0f, 0.0f), mk(0.0f, hh * 2.0f, 0.0f)));
+    } else {
+        hit = disk_test(in->geom_params[0], in->geom_params[1], p, w_i, 0.001f, TR_INF, t);
+        area = kPi * (in->geom_params[0] * in->geom_params[0] - in->geom_params[1] * in->geom_params[1]);
+        if (hit) {
+            f3 ph = p + w_i * t;
+            float hit_radius = sqrtf(ph.x * ph.x + ph.y * ph.y);
+            f3 dp_du = mk(-kPi * 2.0f * ph.y, kPi * 2.0f * ph.x, 0.0f);
+            f3 dp_dv = ((in->geom_params[1] - in->geom_params[0]) / hit_radius) * mk(ph.x, ph.y, 0.0f);
+            n = normalized(cross(dp_du, dp_dv));
+        } else {
+            n = mk(0.0f, 0.0f, 1.0f);
+        }
+    }
+    if (!hit) return 0.0f;
+    f3 w = -w_i;
+    float pdf = length_sqr(p - (p + w_i * t)) / (fabsf(dot(n, w)) * area);
+    return isfinite(pdf) ? pdf : 0.0f;
+}
+
+}  // namespace tr

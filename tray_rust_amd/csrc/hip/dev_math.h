@@ -1,0 +1,179 @@
+// Device-side math for the gfx950 path tracer: float3 helpers, affine/projective point transforms
+// with the reference's w test, the TRAY-CBRNG counter RNG and the (0,2)-sequence.
+// Arithmetic order follows the reference expression by expression (file:line cited per function);
+// the translation unit is compiled with -ffp-contract=off so nothing is fused that rustc would not fuse.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tr {
+
+#define TR_DEV __device__ __forceinline__
+
+static constexpr float kPi = 3.14159265358979323846f;
+static constexpr float kInvPi = 0.318309886183790671538f;
+static constexpr float kPiOver4 = 0.785398163397448309616f;
+static constexpr float kEps = 1.1920929e-7f;   // f32::EPSILON
+#define TR_INF __builtin_huge_valf()
+
+struct f3 {
+    float x, y, z;
+};
+TR_DEV f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+TR_DEV f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+TR_DEV f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+TR_DEV f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+TR_DEV f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+TR_DEV f3 operator*(float s, f3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+TR_DEV f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+TR_DEV f3 operator/(f3 a, f3 b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }
+TR_DEV f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+TR_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   // linalg/mod.rs:42-44
+TR_DEV f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+TR_DEV float length_sqr(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+TR_DEV f3 normalized(f3 a) { float l = sqrtf(length_sqr(a)); return mk(a.x / l, a.y / l, a.z / l); }   // vector.rs:33-36
+TR_DEV bool is_black(f3 c) { return c.x == 0.0f && c.y == 0.0f && c.z == 0.0f; }   // color.rs:47-49
+TR_DEV float luminance(f3 c) { return 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z; }
+TR_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }   // linalg/mod.rs:51-53
+TR_DEV float lerpf(float t, float a, float b) { return a * (1.0f - t) + b * t; }
+TR_DEV float to_radians(float d) { return kPi / 180.0f * d; }
+
+// Transform * Point / inv_mul_point (transform.rs:152-163,199-216): m is a row-major 4x4
+TR_DEV f3 xf_point(const float* __restrict__ m, f3 p) {
+    f3 r;
+    r.x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    r.y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    r.z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    float w = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    if (fabsf(w - 1.0f) < kEps) r = r / w;   // quirk Q5: divides only when w is (almost) one
+    return r;
+}
+TR_DEV f3 xf_vector(const float* __restrict__ m, f3 v) {   // transform.rs:165-172,218-229
+    return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+TR_DEV f3 xf_normal_t(const float* __restrict__ inv, f3 n) {   // Transform * Normal uses inv^T (transform.rs:231-243)
+    return mk(inv[0] * n.x + inv[4] * n.y + inv[8] * n.z, inv[1] * n.x + inv[5] * n.y + inv[9] * n.z, inv[2] * n.x + inv[6] * n.y + inv[10] * n.z);
+}
+
+TR_DEV void coordinate_system(f3 e1, f3& e2, f3& e3) {   // linalg/mod.rs:96-108
+    if (fabsf(e1.x) > fabsf(e1.y)) {
+        float inv_len = 1.0f / sqrtf(e1.x * e1.x + e1.z * e1.z);
+        e2 = mk(-e1.z * inv_len, 0.0f, e1.x * inv_len);
+    } else {
+        float inv_len = 1.0f / sqrtf(e1.y * e1.y + e1.z * e1.z);
+        e2 = mk(0.0f, e1.z * inv_len, -e1.y * inv_len);
+    }
+    e3 = cross(e1, e2);
+}
+TR_DEV f3 reflect(f3 w, f3 v) { return 2.0f * dot(w, v) * v - w; }   // linalg/mod.rs:110-112
+TR_DEV bool refract(f3 w, f3 n, float eta, f3& out) {   // linalg/mod.rs:117-127
+    float cos_t1 = dot(n, w);
+    float sin_t1_sqr = fmaxf(0.0f, 1.0f - cos_t1 * cos_t1);
+    float sin_t2_sqr = eta * eta * sin_t1_sqr;
+    if (sin_t2_sqr >= 1.0f) return false;
+    float cos_t2 = sqrtf(1.0f - sin_t2_sqr);
+    out = eta * -w + (eta * cos_t1 - cos_t2) * n;
+    return true;
+}
+TR_DEV bool solve_quadratic(float a, float b, float c, float& t0, float& t1) {   // linalg/mod.rs:78-94
+    float discrim_sqr = b * b - 4.0f * a * c;
+    if (discrim_sqr < 0.0f) return false;
+    float discrim = sqrtf(discrim_sqr);
+    float q = b < 0.0f ? -0.5f * (b - discrim) : -0.5f * (b + discrim);
+    float x = q / a, y = c / q;
+    if (x > y) { t0 = y; t1 = x; } else { t0 = x; t1 = y; }
+    return true;
+}
+
+// ---- mc.rs
+TR_DEV void concentric_sample_disk(float u0, float u1, float& dx, float& dy) {   // mc.rs:23-51
+    float sx = 2.0f * u0 - 1.0f, sy = 2.0f * u1 - 1.0f;
+    if (sx == 0.0f && sy == 0.0f) { dx = sx; dy = sy; return; }
+    float radius, theta;
+    if (sx >= -sy) {
+        if (sx > sy) { radius = sx; theta = sy > 0.0f ? sy / sx : 8.0f + sy / sx; }
+        else { radius = sy; theta = 2.0f - sx / sy; }
+    } else if (sx <= sy) { radius = -sx; theta = 4.0f + sy / sx; }
+    else { radius = -sy; theta = 6.0f - sx / sy; }
+    theta = theta * kPiOver4;
+    dx = radius * cosf(theta);
+    dy = radius * sinf(theta);
+}
+TR_DEV f3 cos_sample_hemisphere(float u0, float u1) {   // mc.rs:11-16
+    float dx, dy;
+    concentric_sample_disk(u0, u1, dx, dy);
+    return mk(dx, dy, sqrtf(fmaxf(0.0f, 1.0f - dx * dx - dy * dy)));
+}
+TR_DEV float power_heuristic(float n_f, float pdf_f, float n_g, float pdf_g) {   // mc.rs:56-60
+    float f = n_f * pdf_f, g = n_g * pdf_g;
+    return (f * f) / (f * f + g * g);
+}
+
+// ---- TRAY-CBRNG: stateless counter-based draws (definition: DESIGN.md; oracle has its own copy)
+TR_DEV uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+TR_DEV uint32_t key_frame(uint64_t seed, uint32_t frame) {
+    uint32_t h = mix32((uint32_t)seed + 0x9E3779B9u);
+    h = mix32(h ^ (uint32_t)(seed >> 32));
+    return mix32(h + frame);
+}
+TR_DEV uint32_t key_pixel(uint32_t kf, uint32_t pixel_index) { return mix32(kf + 0x9E3779B1u * (pixel_index + 1u)); }
+TR_DEV uint32_t key_sample(uint32_t kp, uint32_t s) { return mix32((kp ^ 0xA511E9B3u) + 0x9E3779B1u * (s + 1u)); }
+TR_DEV uint32_t draw(uint32_t key, uint32_t dim) { return mix32(key + 0x9E3779B9u * (dim + 1u)); }
+
+enum { PD_SCR_X = 0, PD_SCR_Y = 1, PD_PERM_XY = 2, PD_SCR_T = 3, PD_PERM_T = 4 };
+enum { SD_L2 = 0, SD_B2 = 3, SD_P2 = 6, SD_L1 = 9, SD_B1 = 11, SD_P1 = 13, SD_RR = 16 };
+
+// Kensler's hashed permutation of [0, l): random access replacement of rng.shuffle (ld.rs:58,63)
+TR_DEV uint32_t permute(uint32_t i, uint32_t l, uint32_t p) {
+    uint32_t w = l - 1;
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    do {
+        i ^= p; i *= 0xe170893du;
+        i ^= p >> 16;
+        i ^= (i & w) >> 4;
+        i ^= p >> 8; i *= 0x0929eb3fu;
+        i ^= p >> 23;
+        i ^= (i & w) >> 1; i *= 1u | p >> 27;
+        i *= 0x6935fa69u;
+        i ^= (i & w) >> 11; i *= 0x74dcb303u;
+        i ^= (i & w) >> 2; i *= 0x9e501cc3u;
+        i ^= (i & w) >> 2; i *= 0xc860a3dfu;
+        i &= w;
+        i ^= i >> 5;
+    } while (i >= l);
+    return (i + p) % l;
+}
+// Fisher-Yates over [0, n), n <= 16, nibble-packed: nibble k of the result is the source index that
+// ends up at position k. Same draw schedule as the oracle's shuffle_small.
+TR_DEV uint64_t shuffle_small(uint32_t key, uint32_t n) {
+    uint64_t perm = 0xFEDCBA9876543210ull;
+    uint32_t word = 0;
+    for (uint32_t i = n - 1, k = 0; i >= 1 && n > 0; --i, ++k) {
+        if ((k & 1u) == 0) word = draw(key, k >> 1);
+        uint32_t r16 = (k & 1u) ? (word >> 16) : (word & 0xffffu);
+        uint32_t j = (r16 * (i + 1u)) >> 16;
+        uint32_t si = i * 4u, sj = j * 4u;
+        uint64_t x = ((perm >> si) ^ (perm >> sj)) & 0xFull;
+        perm ^= (x << si) | (x << sj);
+    }
+    return perm;
+}
+TR_DEV uint32_t perm_at(uint64_t perm, uint32_t k) { return (uint32_t)(perm >> (k * 4u)) & 0xFu; }
+
+// ---- sampler/ld.rs:91-119
+TR_DEV float u24_to_unit(uint32_t v) { return fminf((float)((v >> 8) & 0xffffffu) / 16777216.0f, 1.0f - kEps); }
+TR_DEV float van_der_corput(uint32_t n, uint32_t scramble) { return u24_to_unit(__brev(n) ^ scramble); }
+TR_DEV float sobol(uint32_t n, uint32_t scramble) {
+    uint32_t i = 1u << 31;
+    while (n != 0) {
+        if (n & 1u) scramble ^= i;
+        n >>= 1;
+        i ^= i >> 1;
+    }
+    return u24_to_unit(scramble);
+}
+
+}  // namespace tr

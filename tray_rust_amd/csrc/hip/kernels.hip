@@ -1,0 +1,520 @@
+// gfx950 kernels + device-side C ABI of libtrayhip.so.
+//
+// k_path_tiles — the tile worker (exec/multithreaded.rs:72-114) as a persistent-threads kernel:
+//   * a workgroup (4 x wave64) owns one 8x8 tile at a time, pulled from a global atomic counter in
+//     Morton order (block_queue.rs:52-59); lane l of every wave owns pixel l of the tile, wave w
+//     takes the samples s = w, w+4, ... of that pixel;
+//   * paths are regenerated in place: a lane whose path ended splats its sample and starts the next
+//     one while its neighbours keep bouncing, so waves stay full without a global ray queue;
+//   * the film lives in LDS while the tile is rendered: a 17x17 RGBW window (tile + 4 px filter halo)
+//     updated with ds_add_f32 (RenderTarget::write, render_target.rs:77-165), flushed once per tile
+//     with global f32 atomics into the caller's RGBW buffer.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../../include/trayhip.h"
+#include "dev_integrator.h"
+
+namespace trayh { void set_error(const std::string& msg); }
+using trayh::set_error;
+using namespace tr;
+
+#define WIN_MAX 17          // 8 + 2*4 + 1 window columns/rows
+#define WIN_STRIDE 24       // row stride in floats: 4 rows of 8 lanes land on 32 distinct banks
+#define WIN_PLANE (WIN_MAX * WIN_STRIDE)
+
+struct DevStats { unsigned long long samples, vertices, rays; };
+
+// RenderTarget::write for one sample into the LDS window (render_target.rs:118-146).
+// win origin = (x0 - fpw, y0 - fph); ranges already clipped to the image.
+__device__ __forceinline__ void film_splat(const DevScene& sc, float* __restrict__ s_win, const float* __restrict__ s_table,
+                                           int x0, int y0, float sx, float sy, f3 c) {
+    const int fpw = sc.fpw, fph = sc.fph;
+    const int xr0 = max(x0 - fpw, 0), xr1 = min(x0 + 8 + fpw, (int)sc.width - 1);
+    const int yr0 = max(y0 - fph, 0), yr1 = min(y0 + 8 + fph, (int)sc.height - 1);
+    const float img_x = sx - 0.5f, img_y = sy - 0.5f;
+    const int bx = (int)floorf(img_x), by = (int)floorf(img_y);
+    const int ix_lo = max(xr0, bx - fpw), ix_hi = min(xr1, bx + fpw + 1);
+    const int iy_lo = max(yr0, by - fph), iy_hi = min(yr1, by + fph + 1);
+    const int wx0 = x0 - fpw, wy0 = y0 - fph;
+    for (int iy = iy_lo; iy <= iy_hi; ++iy) {
+        float fy = fabsf((float)iy - img_y) * sc.inv_h;
+        if (fy > sc.filter_h) continue;
+        int fy_idx = min((int)(fy * (float)TRAY_FILTER_TABLE_SIZE), TRAY_FILTER_TABLE_SIZE - 1);
+        for (int ix = ix_lo; ix <= ix_hi; ++ix) {
+            float fx = fabsf((float)ix - img_x) * sc.inv_w;
+            if (fx > sc.filter_w) continue;
+            int fx_idx = min((int)(fx * (float)TRAY_FILTER_TABLE_SIZE), TRAY_FILTER_TABLE_SIZE - 1);
+            float weight = s_table[fy_idx * TRAY_FILTER_TABLE_SIZE + fx_idx];
+            int o = (iy - wy0) * WIN_STRIDE + (ix - wx0);
+            atomicAdd(&s_win[o], weight * c.x);
+            atomicAdd(&s_win[o + WIN_PLANE], weight * c.y);
+            atomicAdd(&s_win[o + 2 * WIN_PLANE], weight * c.z);
+            atomicAdd(&s_win[o + 3 * WIN_PLANE], weight);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_path_tiles(DevScene sc, const uint2* __restrict__ tiles, uint32_t tile_count, uint32_t spp,
+                                                    uint32_t kf, float* __restrict__ rgbw, uint32_t* __restrict__ counter,
+                                                    DevStats* __restrict__ stats) {
+    __shared__ float s_win[4 * WIN_PLANE];
+    __shared__ float s_table[TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE];
+    __shared__ uint32_t s_tile;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    s_table[tid] = sc.filter_table[tid];
+    Counters cnt;
+    cnt.rays = 0; cnt.vertices = 0;
+    uint32_t n_samples = 0;
+    for (;;) {
+        __syncthreads();   // previous tile fully flushed
+        if (tid == 0) s_tile = atomicAdd(counter, 1u);
+        for (uint32_t i = tid; i < 4 * WIN_PLANE; i += 256) s_win[i] = 0.0f;
+        __syncthreads();
+        const uint32_t ti = s_tile;
+        if (ti >= tile_count) break;
+        const uint2 tile = tiles[ti];
+        const int x0 = (int)tile.x * 8, y0 = (int)tile.y * 8;
+        const uint32_t px = (uint32_t)x0 + (lane & 7u), py = (uint32_t)y0 + (lane >> 3);   // Region order: x fastest (ld.rs:47-51)
+        const PixelSampler pix = pixel_sampler(kf, py * sc.width + px);
+
+        uint32_t s_next = wave;
+        bool active = false, pending = false;
+        f3 result = mk(0.0f, 0.0f, 0.0f);
+        float sx = 0.0f, sy = 0.0f;
+        PathState st;
+        PathSampler ps;
+        st.bounce = 0; st.specular_bounce = false;
+        st.throughput = mk(1.0f, 1.0f, 1.0f); st.illum = mk(0.0f, 0.0f, 0.0f); st.first_ng = mk(0.0f, 0.0f, 0.0f);
+        for (;;) {
+            if (!active) {
+                if (pending) {
+                    film_splat(sc, s_win, s_table, x0, y0, sx, sy, result);
+                    pending = false;
+                }
+                if (s_next < spp) {
+                    float t;
+                    pixel_sample(pix, s_next, spp, px, py, sx, sy, t);
+                    st.ray = camera_ray(sc, sx, sy, t);
+                    st.throughput = mk(1.0f, 1.0f, 1.0f);
+                    st.illum = mk(0.0f, 0.0f, 0.0f);
+                    st.bounce = 0u;
+                    st.specular_bounce = false;
+                    path_sampler_init(ps, key_sample(pix.kp, s_next), sc.max_depth + 1u);
+                    s_next += 4u;
+                    ++n_samples;
+                    active = true;
+                }
+            }
+            if (!__any(active)) break;
+            if (active) {
+                cnt.rays++;
+                bool cont = scene_traverse<false>(sc, st.ray, st.rec);
+                if (cont) cont = path_vertex(sc, st, ps, cnt);
+                if (!cont) {
+                    result = mk(clampf(st.illum.x, 0.0f, 1.0f), clampf(st.illum.y, 0.0f, 1.0f), clampf(st.illum.z, 0.0f, 1.0f));   // quirk Q3
+                    pending = true;
+                    active = false;
+                }
+            }
+        }
+        __syncthreads();
+        // flush the window: film::Image::add_pixels semantics on the caller's RGBW buffer
+        const int wx0 = x0 - sc.fpw, wy0 = y0 - sc.fph;
+        const int ww = 8 + 2 * sc.fpw + 1, wh = 8 + 2 * sc.fph + 1;
+        for (int i = (int)tid; i < ww * wh; i += 256) {
+            int wy = i / ww, wx = i - wy * ww;
+            int ix = wx0 + wx, iy = wy0 + wy;
+            if (ix < 0 || iy < 0 || ix >= (int)sc.width || iy >= (int)sc.height) continue;
+            int o = wy * WIN_STRIDE + wx;
+            float a = s_win[o + 3 * WIN_PLANE];
+            if (a == 0.0f && s_win[o] == 0.0f && s_win[o + WIN_PLANE] == 0.0f && s_win[o + 2 * WIN_PLANE] == 0.0f) continue;
+            float* dst = rgbw + ((size_t)iy * sc.width + ix) * 4;
+            atomicAdd(dst + 0, s_win[o]);
+            atomicAdd(dst + 1, s_win[o + WIN_PLANE]);
+            atomicAdd(dst + 2, s_win[o + 2 * WIN_PLANE]);
+            atomicAdd(dst + 3, a);
+        }
+    }
+    if (stats) {
+        atomicAdd(&stats->samples, (unsigned long long)n_samples);
+        atomicAdd(&stats->vertices, (unsigned long long)cnt.vertices);
+        atomicAdd(&stats->rays, (unsigned long long)cnt.rays);
+    }
+}
+
+// ---- parity / debug kernels: the same device functions, one thread per item -------------------
+__global__ __launch_bounds__(64) void k_debug_intersect(DevScene sc, uint32_t n, const TrayRay* __restrict__ rays, TrayHit* __restrict__ hits) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    r.o = mk(rays[i].o[0], rays[i].o[1], rays[i].o[2]);
+    r.d = mk(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
+    r.min_t = rays[i].min_t; r.max_t = rays[i].max_t; r.time = rays[i].time;
+    HitRec rec;
+    TrayHit o;
+    memset(&o, 0, sizeof o);
+    if (scene_traverse<false>(sc, r, rec)) {
+        float uv[2];
+        f3 dp_dv;
+        Hit h = finish_hit(sc, r, rec, uv, &dp_dv);
+        o.t = rec.t; o.inst = rec.inst; o.prim = rec.prim;
+        o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
+        o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z;
+        o.ng[0] = h.ng.x; o.ng[1] = h.ng.y; o.ng[2] = h.ng.z;
+        o.u = uv[0]; o.v = uv[1];
+        o.dp_du[0] = h.dp_du.x; o.dp_du[1] = h.dp_du.y; o.dp_du[2] = h.dp_du.z;
+        o.dp_dv[0] = dp_dv.x; o.dp_dv[1] = dp_dv.y; o.dp_dv[2] = dp_dv.z;
+    } else {
+        o.t = r.max_t; o.inst = 0xffffffffu;
+    }
+    hits[i] = o;
+}
+
+__global__ __launch_bounds__(64) void k_debug_sample_radiance(DevScene sc, uint32_t n, const uint32_t* __restrict__ px, const uint32_t* __restrict__ py,
+                                        const uint32_t* __restrict__ si, uint32_t spp, uint32_t kf, float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Counters cnt;
+    cnt.rays = 0; cnt.vertices = 0;
+    float sx, sy;
+    f3 c = trace_sample(sc, kf, px[i], py[i], si[i], spp, sx, sy, cnt);
+    float* o = out + (size_t)i * 8;
+    o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = sx; o[4] = sy; o[5] = (float)cnt.vertices; o[6] = (float)cnt.rays; o[7] = 0.0f;
+}
+
+__global__ __launch_bounds__(64) void k_debug_bsdf(DevScene sc, uint32_t material_id, uint32_t flags_sel, uint32_t n, const float* __restrict__ dirs,
+                             const float* __restrict__ u3, float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // canonical frame: n = +z, dp_du = +x; the material comes from a fake instance lookup
+    Hit h;
+    h.p = mk(0.0f, 0.0f, 0.0f); h.n = mk(0.0f, 0.0f, 1.0f); h.ng = mk(0.0f, 0.0f, 1.0f); h.dp_du = mk(1.0f, 0.0f, 0.0f);
+    h.inst = 0;
+    DevScene tmp = sc;
+    // instances[0].material_id is patched on a private copy made by the host (see tray_debug_bsdf)
+    Bsdf b = make_bsdf(tmp, h);
+    (void)material_id;
+    uint32_t flags = flags_sel == 0 ? BX_ALL : BX_NON_SPECULAR;
+    f3 wo = mk(dirs[6 * i], dirs[6 * i + 1], dirs[6 * i + 2]), wi = mk(dirs[6 * i + 3], dirs[6 * i + 4], dirs[6 * i + 5]);
+    float* o = out + (size_t)i * 12;
+    f3 e = bsdf_eval(b, wo, wi, flags);
+    o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = bsdf_pdf(b, wo, wi, flags);
+    f3 swi;
+    float spdf;
+    uint32_t st;
+    f3 f = bsdf_sample(b, wo, flags, u3[3 * i], u3[3 * i + 1], u3[3 * i + 2], swi, spdf, st);
+    o[4] = f.x; o[5] = f.y; o[6] = f.z; o[7] = swi.x; o[8] = swi.y; o[9] = swi.z; o[10] = spdf; o[11] = (float)st;
+}
+
+// ================================================================== host side of the device ABI
+
+struct TrayDeviceScene {
+    int device = 0;
+    DevScene dev{};
+    std::vector<void*> allocs;
+    uint2* d_tiles = nullptr;      // full Morton queue
+    uint32_t n_tiles = 0;
+    uint32_t* d_counter = nullptr;
+    DevStats* d_stats = nullptr;
+    TrayInstance* d_instances = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing_valid = false;
+    uint32_t launches = 0;
+    int n_blocks = 0;
+    uint32_t n_materials = 0;
+};
+
+static thread_local int g_device = 0;
+
+#define HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) {                                                                           \
+            set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));                          \
+            return TRAY_E_DEVICE;                                                                         \
+        }                                                                                                 \
+    } while (0)
+
+template <class T>
+static int upload(TrayDeviceScene* s, const T* host, size_t n, const T** out) {
+    *out = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    void* d = nullptr;
+    HIP_CHECK(hipMalloc(&d, bytes));
+    s->allocs.push_back(d);
+    if (n) HIP_CHECK(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+    else HIP_CHECK(hipMemset(d, 0, bytes));
+    *out = static_cast<const T*>(d);
+    return TRAY_OK;
+}
+
+extern "C" {
+
+int tray_device_count(int* n) {
+    if (!n) { set_error("tray_device_count: null argument"); return TRAY_E_INVALID; }
+    hipError_t e = hipGetDeviceCount(n);
+    if (e != hipSuccess) { *n = 0; set_error(std::string("hipGetDeviceCount failed: ") + hipGetErrorString(e)); return TRAY_E_DEVICE; }
+    return TRAY_OK;
+}
+
+int tray_init(int device) {
+    int n = 0;
+    HIP_CHECK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) { set_error("tray_init: no such HIP device " + std::to_string(device)); return TRAY_E_INVALID; }
+    HIP_CHECK(hipSetDevice(device));
+    g_device = device;
+    return TRAY_OK;
+}
+
+void tray_scene_destroy(TrayDeviceScene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    for (void* p : s->allocs) (void)hipFree(p);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+}
+
+int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
+    if (!f || !out) { set_error("tray_scene_create: null argument"); return TRAY_E_INVALID; }
+    *out = nullptr;
+    if (f->abi_version != TRAY_ABI_VERSION) { set_error("tray_scene_create: ABI version mismatch"); return TRAY_E_INVALID; }
+    if (f->n_lights == 0) { set_error("At least one light is required"); return TRAY_E_INVALID; }   // multithreaded.rs:39
+    if (f->film.width % 8 != 0 || f->film.height % 8 != 0 || f->film.width == 0 || f->film.height == 0) {
+        set_error("Image dimensions not evenly divided by blocks of (8, 8)");
+        return TRAY_E_INVALID;
+    }
+    if (f->film.filter_pixel_w > 4 || f->film.filter_pixel_h > 4 || f->film.filter_pixel_w < 0 || f->film.filter_pixel_h < 0) {
+        set_error("reconstruction filters wider than 2 px are not supported by the LDS film window");
+        return TRAY_E_UNSUPPORTED;
+    }
+    if (f->film.filter_w > 2.0f || f->film.filter_h > 2.0f) {
+        set_error("reconstruction filters wider than 2.0 are not supported by the LDS film window");
+        return TRAY_E_UNSUPPORTED;
+    }
+    if (f->max_depth > 15) { set_error("pathtracer max_depth > 15 is not supported"); return TRAY_E_UNSUPPORTED; }
+    if (f->camera.animated) { set_error("animated cameras are not supported yet (SURVEY 8f)"); return TRAY_E_UNSUPPORTED; }
+    for (uint32_t i = 0; i < f->n_instances; ++i) {
+        const TrayInstance& in = f->instances[i];
+        if (in.kind != TRAY_INST_POINT_EMITTER && in.material_id >= f->n_materials) { set_error("instance references a missing material"); return TRAY_E_INVALID; }
+        if (in.geom_type == TRAY_GEOM_MESH && in.mesh_id >= f->n_meshes) { set_error("instance references a missing mesh"); return TRAY_E_INVALID; }
+    }
+    TrayDeviceScene* s = new TrayDeviceScene();
+    s->device = g_device;
+    if (hipSetDevice(s->device) != hipSuccess) { delete s; set_error("hipSetDevice failed (is a GPU present?)"); return TRAY_E_DEVICE; }
+    DevScene& d = s->dev;
+    int rc = TRAY_OK;
+    const TrayInstance* d_inst = nullptr;
+#define UP(field, hostptr, count)                                                     \
+    if (rc == TRAY_OK) {                                                              \
+        std::remove_cv_t<std::remove_pointer_t<decltype(hostptr)>> const* _p = nullptr; \
+        rc = upload(s, hostptr, (size_t)(count), &_p);                                \
+        d.field = _p;                                                                 \
+    }
+    if (rc == TRAY_OK) rc = upload(s, f->instances, f->n_instances, &d_inst);
+    d.instances = d_inst;
+    s->d_instances = const_cast<TrayInstance*>(d_inst);
+    UP(top_nodes, f->top_nodes, f->n_top_nodes)
+    UP(top_order, f->top_order, f->n_top_order)
+    UP(meshes, f->meshes, f->n_meshes)
+    UP(mesh_nodes, f->mesh_nodes, f->n_mesh_nodes)
+    UP(tri_verts, f->tri_verts, f->n_tris)
+    UP(tri_attrs, f->tri_attrs, f->n_tris)
+    UP(materials, f->materials, f->n_materials)
+    UP(merl_tables, f->merl_tables, f->n_merl)
+    UP(merl_data, f->merl_data, f->n_merl_floats)
+    UP(lights, f->lights, f->n_lights)
+    UP(filter_table, &f->film.table[0], TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE)
+#undef UP
+    if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
+    s->n_materials = f->n_materials;
+    d.n_instances = f->n_instances; d.n_lights = f->n_lights; d.min_depth = f->min_depth; d.max_depth = f->max_depth;
+    d.width = f->film.width; d.height = f->film.height; d.frame = f->frame; d.pad = 0;
+    d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
+    d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
+    d.camera = f->camera;
+    // Morton tile queue (BlockQueue::new)
+    uint32_t n_tiles = 0;
+    rc = tray_block_queue(d.width, d.height, 0, 0, nullptr, 0, &n_tiles);
+    std::vector<uint32_t> xy(2 * (size_t)n_tiles);
+    if (rc == TRAY_OK) rc = tray_block_queue(d.width, d.height, 0, 0, xy.data(), n_tiles, &n_tiles);
+    const uint2* d_tiles = nullptr;
+    if (rc == TRAY_OK) rc = upload(s, reinterpret_cast<const uint2*>(xy.data()), n_tiles, &d_tiles);
+    s->d_tiles = const_cast<uint2*>(d_tiles);
+    s->n_tiles = n_tiles;
+    const uint32_t* d_counter = nullptr;
+    const DevStats* d_stats = nullptr;
+    uint32_t zero = 0;
+    DevStats zs{};
+    if (rc == TRAY_OK) rc = upload(s, &zero, 1, &d_counter);
+    if (rc == TRAY_OK) rc = upload(s, &zs, 1, &d_stats);
+    s->d_counter = const_cast<uint32_t*>(d_counter);
+    s->d_stats = const_cast<DevStats*>(d_stats);
+    if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
+    if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
+        tray_scene_destroy(s); set_error("hipEventCreate failed"); return TRAY_E_DEVICE;
+    }
+    int per_cu = 0, cus = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (cus < 1) cus = 256;
+    s->n_blocks = cus * per_cu;
+    *out = s;
+    return TRAY_OK;
+}
+
+int tray_render_tiles_device(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t spp, uint64_t seed,
+                             float* rgbw_dev, void* stream_) {
+    if (!s || !rgbw_dev) { set_error("tray_render_tiles_device: null argument"); return TRAY_E_INVALID; }
+    if (spp == 0 || (spp & (spp - 1)) != 0) { set_error("spp must be a power of two (LowDiscrepancy sampler, ld.rs:22-25); use tray_round_spp"); return TRAY_E_INVALID; }
+    if (tile_start > s->n_tiles) tile_start = s->n_tiles;                       // skip(start).take(count)
+    if (tile_count == 0 || tile_count > s->n_tiles - tile_start) tile_count = s->n_tiles - tile_start;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HIP_CHECK(hipSetDevice(s->device));
+    s->timing_valid = false;
+    if (tile_count == 0) { std::fprintf(stderr, "Warning: This block queue is empty!\n"); return TRAY_OK; }   // block_queue.rs:42-44
+    HIP_CHECK(hipMemsetAsync(s->d_counter, 0, sizeof(uint32_t), stream));
+    HIP_CHECK(hipMemsetAsync(s->d_stats, 0, sizeof(DevStats), stream));
+    // key_frame on the host (same mixing as the device function)
+    auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
+    uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
+    kf = mix(kf ^ (uint32_t)(seed >> 32));
+    kf = mix(kf + s->dev.frame);
+    int blocks = (int)std::min<uint32_t>((uint32_t)s->n_blocks, tile_count);
+    HIP_CHECK(hipEventRecord(s->ev0, stream));
+    hipLaunchKernelGGL(k_path_tiles, dim3(blocks), dim3(256), 0, stream, s->dev, s->d_tiles + tile_start, tile_count, spp, kf, rgbw_dev,
+                       s->d_counter, s->d_stats);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(s->ev1, stream));
+    s->timing_valid = true;
+    s->launches = 1;
+    return TRAY_OK;
+}
+
+int tray_render_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t spp, uint64_t seed, float* rgbw_host) {
+    if (!s || !rgbw_host) { set_error("tray_render_tiles: null argument"); return TRAY_E_INVALID; }
+    HIP_CHECK(hipSetDevice(s->device));
+    size_t n = (size_t)s->dev.width * s->dev.height * 4;
+    float* d = nullptr;
+    HIP_CHECK(hipMalloc(&d, n * sizeof(float)));
+    int rc = TRAY_OK;
+    hipError_t e = hipMemset(d, 0, n * sizeof(float));
+    if (e == hipSuccess) {
+        rc = tray_render_tiles_device(s, tile_start, tile_count, spp, seed, d, nullptr);
+        if (rc == TRAY_OK) {
+            std::vector<float> tmp(n);
+            e = hipMemcpy(tmp.data(), d, n * sizeof(float), hipMemcpyDeviceToHost);
+            if (e == hipSuccess)
+                for (size_t i = 0; i < n; ++i) rgbw_host[i] += tmp[i];
+        }
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) { set_error(std::string("tray_render_tiles: ") + hipGetErrorString(e)); return TRAY_E_DEVICE; }
+    return rc;
+}
+
+int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t) {
+    if (!s || !t) { set_error("tray_last_timing: null argument"); return TRAY_E_INVALID; }
+    std::memset(t, 0, sizeof *t);
+    if (!s->timing_valid) { set_error("tray_last_timing: no launch recorded"); return TRAY_E_INVALID; }
+    HIP_CHECK(hipSetDevice(s->device));
+    HIP_CHECK(hipEventSynchronize(s->ev1));
+    HIP_CHECK(hipEventElapsedTime(&t->render_ms, s->ev0, s->ev1));
+    DevStats st{};
+    HIP_CHECK(hipMemcpy(&st, s->d_stats, sizeof st, hipMemcpyDeviceToHost));
+    t->launches = s->launches;
+    t->samples = st.samples; t->vertices = st.vertices; t->rays = st.rays;
+    return TRAY_OK;
+}
+
+int tray_debug_intersect(TrayDeviceScene* s, uint32_t n, const TrayRay* rays, TrayHit* hits) {
+    if (!s || !rays || !hits) { set_error("tray_debug_intersect: null argument"); return TRAY_E_INVALID; }
+    if (n == 0) return TRAY_OK;
+    HIP_CHECK(hipSetDevice(s->device));
+    TrayRay* d_r = nullptr;
+    TrayHit* d_h = nullptr;
+    HIP_CHECK(hipMalloc(&d_r, n * sizeof(TrayRay)));
+    hipError_t e = hipMalloc(&d_h, n * sizeof(TrayHit));
+    if (e == hipSuccess) e = hipMemcpy(d_r, rays, n * sizeof(TrayRay), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_intersect, dim3((n + 63) / 64), dim3(64), 0, 0, s->dev, n, d_r, d_h);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(hits, d_h, n * sizeof(TrayHit), hipMemcpyDeviceToHost);
+    (void)hipFree(d_r);
+    (void)hipFree(d_h);
+    if (e != hipSuccess) { set_error(std::string("tray_debug_intersect: ") + hipGetErrorString(e)); return TRAY_E_DEVICE; }
+    return TRAY_OK;
+}
+
+int tray_debug_sample_radiance(TrayDeviceScene* s, uint32_t n, const uint32_t* px, const uint32_t* py, const uint32_t* si,
+                               uint32_t spp, uint64_t seed, float* out) {
+    if (!s || !px || !py || !si || !out) { set_error("tray_debug_sample_radiance: null argument"); return TRAY_E_INVALID; }
+    if (spp == 0 || (spp & (spp - 1)) != 0) { set_error("spp must be a power of two"); return TRAY_E_INVALID; }
+    if (n == 0) return TRAY_OK;
+    for (uint32_t i = 0; i < n; ++i)
+        if (px[i] >= s->dev.width || py[i] >= s->dev.height || si[i] >= spp) { set_error("tray_debug_sample_radiance: item out of range"); return TRAY_E_INVALID; }
+    HIP_CHECK(hipSetDevice(s->device));
+    uint32_t* d_in = nullptr;
+    float* d_out = nullptr;
+    HIP_CHECK(hipMalloc(&d_in, 3 * (size_t)n * sizeof(uint32_t)));
+    hipError_t e = hipMalloc(&d_out, 8 * (size_t)n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_in, px, n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_in + n, py, n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_in + 2 * (size_t)n, si, n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
+        uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
+        kf = mix(kf ^ (uint32_t)(seed >> 32));
+        kf = mix(kf + s->dev.frame);
+        hipLaunchKernelGGL(k_debug_sample_radiance, dim3((n + 63) / 64), dim3(64), 0, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, 8 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) { set_error(std::string("tray_debug_sample_radiance: ") + hipGetErrorString(e)); return TRAY_E_DEVICE; }
+    return TRAY_OK;
+}
+
+int tray_debug_bsdf(TrayDeviceScene* s, uint32_t material_id, uint32_t flags, uint32_t n, const float* dirs, const float* u3, float* out) {
+    if (!s || !dirs || !u3 || !out) { set_error("tray_debug_bsdf: null argument"); return TRAY_E_INVALID; }
+    if (n == 0) return TRAY_OK;
+    if (material_id >= s->n_materials) { set_error("tray_debug_bsdf: no such material"); return TRAY_E_INVALID; }
+    HIP_CHECK(hipSetDevice(s->device));
+    // private one-instance table carrying the requested material
+    TrayInstance fake;
+    std::memset(&fake, 0, sizeof fake);
+    fake.material_id = material_id;
+    TrayInstance* d_fake = nullptr;
+    float *d_dirs = nullptr, *d_u = nullptr, *d_out = nullptr;
+    HIP_CHECK(hipMalloc(&d_fake, sizeof fake));
+    hipError_t e = hipMalloc(&d_dirs, 6 * (size_t)n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&d_u, 3 * (size_t)n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&d_out, 12 * (size_t)n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_fake, &fake, sizeof fake, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_dirs, dirs, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_u, u3, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        DevScene tmp = s->dev;
+        tmp.instances = d_fake;
+        hipLaunchKernelGGL(k_debug_bsdf, dim3((n + 63) / 64), dim3(64), 0, 0, tmp, material_id, flags, n, d_dirs, d_u, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, 12 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_fake); (void)hipFree(d_dirs); (void)hipFree(d_u); (void)hipFree(d_out);
+    if (e != hipSuccess) { set_error(std::string("tray_debug_bsdf: ") + hipGetErrorString(e)); return TRAY_E_DEVICE; }
+    return TRAY_OK;
+}
+
+}  // extern "C"
