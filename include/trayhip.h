@@ -241,6 +241,19 @@ void tray_scene_destroy(TrayDeviceScene* s);
 int tray_render_tiles_device(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count,
                              uint32_t spp, uint64_t seed, float* rgbw_dev, void* stream);
 
+/* Multi-GPU sharding of one frame: shard g of n_shards renders chunks g, g+n_shards, g+2*n_shards...
+ * of the Morton queue, chunk_tiles tiles per chunk (round-robin instead of the reference's contiguous
+ * per = n/workers split, src/exec/distrib/master.rs:91-93,218-227, for load balance; per-pixel results
+ * do not depend on the partition because the RNG is keyed by pixel and sample). The per-shard buffers
+ * are merged by addition (film/image.rs:21-50), e.g. ncclReduce(sum). */
+int tray_render_shard_device(TrayDeviceScene* s, uint32_t shard, uint32_t n_shards, uint32_t chunk_tiles,
+                             uint32_t spp, uint64_t seed, float* rgbw_dev, void* stream);
+
+/* Host-side enumeration of the Morton-queue indices tray_render_shard_device renders for `shard`
+ * (same mapping; lets callers and tests reason about the partition without a GPU). */
+int tray_shard_tiles(uint32_t n_tiles, uint32_t shard, uint32_t n_shards, uint32_t chunk_tiles,
+                     uint32_t* out, uint32_t cap, uint32_t* n_out);
+
 /* Synchronous convenience wrapper: renders into a zeroed device buffer, adds it into rgbw_host
  * (host, width*height*4 f32) — semantics of film::Image::add_pixels. */
 int tray_render_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count,

@@ -1,0 +1,35 @@
+"""Generates the committed golden fixtures from the CPU oracle (the reference cannot run here: no
+Rust toolchain, and its RNG is OS-seeded). They pin the oracle against regressions and give the GPU
+tests a fixed target that does not depend on rebuilding the oracle.
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import tray_rust_amd as T
+from tray_rust_amd import scenes
+import _oracle as O
+
+for name, build in (("cornell_box", scenes.cornell_box), ("smallpt", scenes.smallpt)):
+    with tempfile.TemporaryDirectory() as d:
+        scenes.write_assets(d)
+        p = os.path.join(d, "s.json")
+        json.dump(build(48, 32, 16), open(p, "w"))
+        scene, *_ = T.Scene.load_file(p)
+        flat = scene.flatten(0)
+        img, st = O.render_tiles(flat, 16, seed=9)
+        rng = np.random.default_rng(42)
+        n = 512
+        px = rng.integers(0, 48, n).astype(np.uint32); py = rng.integers(0, 32, n).astype(np.uint32); si = rng.integers(0, 16, n).astype(np.uint32)
+        rad = O.sample_radiance(flat, px, py, si, 16, seed=9)
+        np.savez_compressed(os.path.join(HERE, f"{name}_48x32_16spp_seed9.npz"), rgbw=img, vertices=st.vertices, rays=st.rays,
+                            px=px, py=py, si=si, radiance=rad)
+        print(name, img.shape, st.vertices, st.rays)

@@ -1,0 +1,54 @@
+"""The C-ABI library loads and exports every symbol include/trayhip.h declares (no GPU needed)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "trayhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tray_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(built):
+    from tray_rust_amd import _lib as L
+    names = header_functions()
+    assert len(names) >= 20
+    handle = C.CDLL(L.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/trayhip.h but not exported"
+    assert set(names) == set(L.SYMBOLS), set(names) ^ set(L.SYMBOLS)
+
+
+def test_struct_sizes_match_header(built):
+    from tray_rust_amd import _lib as L
+    assert C.sizeof(L.TrayBvhNode) == 32
+    assert C.sizeof(L.TrayTriVerts) == 48
+    assert C.sizeof(L.TrayTriAttrs) == 64
+    assert C.sizeof(L.TrayInstance) == 4 * 4 + 16 + 16 + 64 + 64 + 16
+    assert C.sizeof(L.TrayMaterial) == 48
+    assert C.sizeof(L.TrayRay) == 36
+    assert C.sizeof(L.TrayHit) == 4 * 3 + 12 * 3 + 8 + 24
+
+
+def test_version_and_error_channel(built):
+    import tray_rust_amd as T
+    assert b"trayhip" in T.lib().tray_version()
+    with pytest.raises(T.TrayError) as e:
+        T.Scene.load_file("/nonexistent/scene.json")
+    assert e.value.code == T._lib.TRAY_E_IO and "Failed to open scene file" in e.value.message
+
+
+def test_device_calls_fail_loudly_without_gpu(assets):
+    """No silent CPU fallback: creating a device scene without a GPU is an error, never a no-op."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import tray_rust_amd as T
+    scene, rt, spp, fi = T.Scene.load_file(os.path.join(assets, "cornell_box.json"))
+    with pytest.raises(T.TrayError):
+        T.Hip(0).render(scene, rt, T.Config(".", "x", spp, 1, fi))

@@ -196,6 +196,13 @@ class Hip:
                                              C.c_void_p(int(rgbw_ptr)), C.c_void_p(int(stream)) if stream else None))
         return dev
 
+    def render_shard_device(self, scene, frame, shard, n_shards, spp, rgbw_ptr, chunk_tiles=16, stream=None):
+        """One rank's share of a frame (round-robin chunks of the Morton queue); merge = sum over ranks."""
+        dev = scene.device_scene(frame, self.device)
+        check(lib().tray_render_shard_device(dev, int(shard), int(n_shards), int(chunk_tiles), int(spp), self.seed,
+                                             C.c_void_p(int(rgbw_ptr)), C.c_void_p(int(stream)) if stream else None))
+        return dev
+
     def timing(self, scene):
         t = _lib.TrayKernelTiming()
         check(lib().tray_last_timing(scene.device_scene(scene._dev_frame, self.device), C.byref(t)))

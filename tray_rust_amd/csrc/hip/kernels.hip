@@ -62,7 +62,10 @@ __device__ __forceinline__ void film_splat(const DevScene& sc, float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_path_tiles(DevScene sc, const uint2* __restrict__ tiles, uint32_t tile_count, uint32_t spp,
+// Work item w (0 <= w < n_work) maps to queue entry (w / chunk) * chunk_stride * chunk + (w % chunk):
+// contiguous ranges use chunk_stride = 1; multi-GPU sharding interleaves chunks round-robin.
+__global__ __launch_bounds__(256) void k_path_tiles(DevScene sc, const uint2* __restrict__ tiles, uint32_t tile_count, uint32_t chunk,
+                                                    uint32_t chunk_stride, uint32_t spp,
                                                     uint32_t kf, float* __restrict__ rgbw, uint32_t* __restrict__ counter,
                                                     DevStats* __restrict__ stats) {
     __shared__ float s_win[4 * WIN_PLANE];
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void k_path_tiles(DevScene sc, const uint2* __
         __syncthreads();
         const uint32_t ti = s_tile;
         if (ti >= tile_count) break;
-        const uint2 tile = tiles[ti];
+        const uint2 tile = tiles[(ti / chunk) * chunk_stride * chunk + (ti % chunk)];
         const int x0 = (int)tile.x * 8, y0 = (int)tile.y * 8;
         const uint32_t px = (uint32_t)x0 + (lane & 7u), py = (uint32_t)y0 + (lane >> 3);   // Region order: x fastest (ld.rs:47-51)
         const PixelSampler pix = pixel_sampler(kf, py * sc.width + px);
@@ -373,12 +376,35 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     return TRAY_OK;
 }
 
+static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride,
+                        uint32_t spp, uint64_t seed, float* rgbw_dev, void* stream_);
+
 int tray_render_tiles_device(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t spp, uint64_t seed,
                              float* rgbw_dev, void* stream_) {
     if (!s || !rgbw_dev) { set_error("tray_render_tiles_device: null argument"); return TRAY_E_INVALID; }
-    if (spp == 0 || (spp & (spp - 1)) != 0) { set_error("spp must be a power of two (LowDiscrepancy sampler, ld.rs:22-25); use tray_round_spp"); return TRAY_E_INVALID; }
     if (tile_start > s->n_tiles) tile_start = s->n_tiles;                       // skip(start).take(count)
     if (tile_count == 0 || tile_count > s->n_tiles - tile_start) tile_count = s->n_tiles - tile_start;
+    return launch_tiles(s, tile_start, tile_count, tile_count ? tile_count : 1, 1, spp, seed, rgbw_dev, stream_);
+}
+
+int tray_render_shard_device(TrayDeviceScene* s, uint32_t shard, uint32_t n_shards, uint32_t chunk_tiles, uint32_t spp, uint64_t seed,
+                             float* rgbw_dev, void* stream_) {
+    if (!s || !rgbw_dev) { set_error("tray_render_shard_device: null argument"); return TRAY_E_INVALID; }
+    if (n_shards == 0 || shard >= n_shards || chunk_tiles == 0) { set_error("tray_render_shard_device: bad shard / chunk arguments"); return TRAY_E_INVALID; }
+    // chunks c = shard, shard + n_shards, ... of chunk_tiles tiles each; the last chunk may be short
+    uint32_t n_chunks = (s->n_tiles + chunk_tiles - 1) / chunk_tiles;
+    uint32_t my_chunks = shard < n_chunks ? (n_chunks - shard + n_shards - 1) / n_shards : 0;
+    if (my_chunks == 0) return launch_tiles(s, 0, 0, 1, 1, spp, seed, rgbw_dev, stream_);
+    uint32_t last_chunk = shard + (my_chunks - 1) * n_shards;
+    uint32_t tail = s->n_tiles - last_chunk * chunk_tiles;   // tiles in my last chunk
+    if (tail > chunk_tiles) tail = chunk_tiles;
+    uint32_t work = (my_chunks - 1) * chunk_tiles + tail;
+    return launch_tiles(s, shard * chunk_tiles, work, chunk_tiles, n_shards, spp, seed, rgbw_dev, stream_);
+}
+
+static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride,
+                        uint32_t spp, uint64_t seed, float* rgbw_dev, void* stream_) {
+    if (spp == 0 || (spp & (spp - 1)) != 0) { set_error("spp must be a power of two (LowDiscrepancy sampler, ld.rs:22-25); use tray_round_spp"); return TRAY_E_INVALID; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HIP_CHECK(hipSetDevice(s->device));
     s->timing_valid = false;
@@ -392,7 +418,7 @@ int tray_render_tiles_device(TrayDeviceScene* s, uint32_t tile_start, uint32_t t
     kf = mix(kf + s->dev.frame);
     int blocks = (int)std::min<uint32_t>((uint32_t)s->n_blocks, tile_count);
     HIP_CHECK(hipEventRecord(s->ev0, stream));
-    hipLaunchKernelGGL(k_path_tiles, dim3(blocks), dim3(256), 0, stream, s->dev, s->d_tiles + tile_start, tile_count, spp, kf, rgbw_dev,
+    hipLaunchKernelGGL(k_path_tiles, dim3(blocks), dim3(256), 0, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev,
                        s->d_counter, s->d_stats);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(s->ev1, stream));

@@ -57,6 +57,21 @@ int tray_block_queue(uint32_t width, uint32_t height, uint32_t select_start, uin
     return TRAY_OK;
 }
 
+int tray_shard_tiles(uint32_t n_tiles, uint32_t shard, uint32_t n_shards, uint32_t chunk_tiles, uint32_t* out, uint32_t cap, uint32_t* n_out) {
+    if (!n_out || n_shards == 0 || shard >= n_shards || chunk_tiles == 0) { set_error("tray_shard_tiles: bad arguments"); return TRAY_E_INVALID; }
+    uint32_t n = 0;
+    for (uint32_t c = shard; (uint64_t)c * chunk_tiles < n_tiles; c += n_shards)
+        for (uint32_t k = 0; k < chunk_tiles && (uint64_t)c * chunk_tiles + k < n_tiles; ++k) {
+            if (out) {
+                if (n >= cap) { set_error("tray_shard_tiles: output capacity too small"); return TRAY_E_INVALID; }
+                out[n] = c * chunk_tiles + k;
+            }
+            ++n;
+        }
+    *n_out = n;
+    return TRAY_OK;
+}
+
 uint32_t tray_round_spp(uint32_t spp) {   // ld.rs:22-25 (usize::next_power_of_two; 0 -> 1)
     uint32_t p = 1;
     while (p < spp && p < 0x80000000u) p <<= 1;
