@@ -7,6 +7,8 @@
 //                             fresnel.rs
 // Colours are RGB only: the reference's alpha channel never reaches the film (render_target.rs:142-145).
 #pragma once
+#include <cstring>
+
 #include "dev_geom.h"
 
 namespace tr {
@@ -16,6 +18,7 @@ enum { BX_ALL = 31, BX_NON_SPECULAR = 15 };   // BxDFType::all / non_specular (b
 
 enum { LB_LAMBERTIAN = 0, LB_OREN_NAYAR, LB_SPEC_REFL_DIEL, LB_SPEC_REFL_COND, LB_SPEC_TRANS, LB_TS_DIEL, LB_TS_COND, LB_MF_TRANS, LB_MERL };
 
+// Register copy of one precomputed DevLobe
 struct Lobe {
     uint32_t kind, type;
     f3 color;
@@ -24,13 +27,21 @@ struct Lobe {
     float ob;      // Oren-Nayar b
 };
 
+// BSDF: shading frame in registers, lobes fetched from the material table when needed
 struct Bsdf {
-    f3 p, n, ng, tan, bitan;
-    const TrayMaterial* __restrict__ mat;
-    const float* __restrict__ merl;
-    int n_lobes;
-    Lobe lobe[2];
+    f3 p, n, tan, bitan;
+    const DevMaterial* __restrict__ mat;
+    const float* __restrict__ merl_data;
 };
+
+TR_DEV Lobe load_lobe(const DevMaterial* __restrict__ m, int i) {
+    const DevLobe* __restrict__ d = m->lobe + i;
+    Lobe l;
+    l.kind = d->kind; l.type = d->type;
+    l.color = mk(d->color[0], d->color[1], d->color[2]);
+    l.eta_t = d->eta_t; l.width = d->width; l.ob = d->ob;
+    return l;
+}
 
 TR_DEV float cos_theta(f3 v) { return v.z; }
 TR_DEV float cos_theta_sqr(f3 v) { return v.z * v.z; }
@@ -160,7 +171,7 @@ TR_DEV f3 lobe_eval(const Bsdf& b, const Lobe& l, f3 w_o, f3 w_i) {
             float d = beckmann_d(l.width, w_h);
             f3 f;
             if (l.kind == LB_TS_DIEL) { float fr = fresnel_dielectric(l.eta_t, dot(w_i, w_h)); f = mk(fr, fr, fr); }
-            else f = fresnel_conductor(mk(b.mat->c0[0], b.mat->c0[1], b.mat->c0[2]), mk(b.mat->c1[0], b.mat->c1[1], b.mat->c1[2]), dot(w_i, w_h));
+            else f = fresnel_conductor(mk(b.mat->eta[0], b.mat->eta[1], b.mat->eta[2]), mk(b.mat->k[0], b.mat->k[1], b.mat->k[2]), dot(w_i, w_h));
             float g = beckmann_g1(l.width, w_i) * beckmann_g1(l.width, w_o);
             return l.color * f * d * g / (4.0f * cos_ti * cos_to);
         }
@@ -179,7 +190,7 @@ TR_DEV f3 lobe_eval(const Bsdf& b, const Lobe& l, f3 w_o, f3 w_i) {
             f3 f = mk(fr, fr, fr);
             return l.color * (fabsf(wi_dot_h) / (fabsf(w_i.z) * fabsf(w_o.z))) * (f * g * d) * jac;
         }
-        case LB_MERL: return merl_eval(b.merl, w_o, w_i);
+        case LB_MERL: return merl_eval(b.merl_data + b.mat->merl_offset, w_o, w_i);
         default: return mk(0.0f, 0.0f, 0.0f);   // specular lobes evaluate to black
     }
 }
@@ -199,6 +210,8 @@ TR_DEV float lobe_pdf(const Lobe& l, f3 w_o, f3 w_i) {
     }
     return same_hemisphere(w_o, w_i) ? fabsf(cos_theta(w_i)) * kInvPi : 0.0f;   // bxdf/mod.rs:112-121
 }
+// BxDF::sample. For specular lobes returns f; for the others only the direction and the lobe's own pdf
+// are produced: BSDF::sample (bsdf.rs:103-109) replaces f by BSDF::eval for every non-specular lobe.
 TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, f3& w_i, float& pdf) {
     const f3 zero = mk(0.0f, 0.0f, 0.0f);
     switch (l.kind) {
@@ -208,7 +221,7 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
             if (w_i.z != 0.0f) {
                 f3 f;
                 if (l.kind == LB_SPEC_REFL_DIEL) { float fr = fresnel_dielectric(l.eta_t, cos_theta(w_o)); f = mk(fr, fr, fr); }
-                else f = fresnel_conductor(mk(b.mat->c0[0], b.mat->c0[1], b.mat->c0[2]), mk(b.mat->c1[0], b.mat->c1[1], b.mat->c1[2]), cos_theta(w_o));
+                else f = fresnel_conductor(mk(b.mat->eta[0], b.mat->eta[1], b.mat->eta[2]), mk(b.mat->k[0], b.mat->k[1], b.mat->k[2]), cos_theta(w_o));
                 pdf = 1.0f;
                 return f * l.color / fabsf(cos_theta(w_i));
             }
@@ -235,7 +248,7 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
             w_i = reflect(w_o, w_h);
             if (!same_hemisphere(w_o, w_i)) { w_i = zero; pdf = 0.0f; return zero; }
             pdf = lobe_pdf(l, w_o, w_i);
-            return lobe_eval(b, l, w_o, w_i);
+            return zero;
         }
         case LB_MF_TRANS: {
             f3 w_h = beckmann_sample(l.width, u0, u1);
@@ -247,7 +260,7 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
                 if (same_hemisphere(w_o, wi)) { w_i = zero; pdf = 0.0f; return zero; }
                 w_i = wi;
                 pdf = lobe_pdf(l, w_o, w_i);
-                return lobe_eval(b, l, w_o, w_i);
+                return zero;
             }
             w_i = zero; pdf = 0.0f;
             return zero;
@@ -256,7 +269,7 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
             w_i = cos_sample_hemisphere(u0, u1);
             if (w_o.z < 0.0f) w_i.z *= -1.0f;
             pdf = lobe_pdf(l, w_o, w_i);
-            return lobe_eval(b, l, w_o, w_i);
+            return zero;
         }
     }
 }
@@ -267,35 +280,41 @@ TR_DEV f3 from_shading(const Bsdf& b, f3 v) {   // bsdf.rs:57-61
     return mk(b.bitan.x * v.x + b.tan.x * v.y + b.n.x * v.z, b.bitan.y * v.x + b.tan.y * v.y + b.n.y * v.z,
               b.bitan.z * v.x + b.tan.z * v.y + b.n.z * v.z);
 }
-TR_DEV f3 bsdf_eval(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {   // bsdf.rs:66-79
+__device__ __noinline__ f3 bsdf_eval(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {   // bsdf.rs:66-79
     f3 w_o = normalized(to_shading(b, wo_world)), w_i = normalized(to_shading(b, wi_world));
     if (w_o.z * w_i.z > 0.0f) flags &= ~(uint32_t)BX_TRANSMISSION; else flags &= ~(uint32_t)BX_REFLECTION;
     f3 sum = mk(0.0f, 0.0f, 0.0f);
-    for (int i = 0; i < 2; ++i)
-        if (i < b.n_lobes && lobe_matches(b.lobe[i].type, flags)) sum = sum + lobe_eval(b, b.lobe[i], w_o, w_i);
+    const int n = (int)b.mat->n_lobes;
+    for (int i = 0; i < n; ++i) {
+        Lobe l = load_lobe(b.mat, i);
+        if (lobe_matches(l.type, flags)) sum = sum + lobe_eval(b, l, w_o, w_i);
+    }
     return sum;
 }
-TR_DEV float bsdf_pdf(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {   // bsdf.rs:114-125
+__device__ __noinline__ float bsdf_pdf(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {   // bsdf.rs:114-125
     f3 w_o = normalized(to_shading(b, wo_world)), w_i = normalized(to_shading(b, wi_world));
     float pdf_val = 0.0f;
     int n_comps = 0;
-    for (int i = 0; i < 2; ++i)
-        if (i < b.n_lobes && lobe_matches(b.lobe[i].type, flags)) { pdf_val = pdf_val + lobe_pdf(b.lobe[i], w_o, w_i); ++n_comps; }
+    const int n = (int)b.mat->n_lobes;
+    for (int i = 0; i < n; ++i) {
+        Lobe l = load_lobe(b.mat, i);
+        if (lobe_matches(l.type, flags)) { pdf_val = pdf_val + lobe_pdf(l, w_o, w_i); ++n_comps; }
+    }
     return n_comps > 0 ? pdf_val / (float)n_comps : 0.0f;
 }
 // bsdf.rs:85-111; returns f, writes wi_world, pdf, sampled lobe type bits (0 = nothing sampled)
 TR_DEV f3 bsdf_sample(const Bsdf& b, f3 wo_world, uint32_t flags, float u0, float u1, float one_d, f3& wi_world, float& pdf_out, uint32_t& sampled_type) {
     const f3 zero = mk(0.0f, 0.0f, 0.0f);
-    bool m0 = b.n_lobes > 0 && lobe_matches(b.lobe[0].type, flags);
-    bool m1 = b.n_lobes > 1 && lobe_matches(b.lobe[1].type, flags);
+    const uint32_t n_lobes = b.mat->n_lobes;
+    bool m0 = n_lobes > 0u && lobe_matches(b.mat->lobe[0].type, flags);
+    bool m1 = n_lobes > 1u && lobe_matches(b.mat->lobe[1].type, flags);
     int n_matching = (int)m0 + (int)m1;
     if (n_matching == 0) { wi_world = zero; pdf_out = 0.0f; sampled_type = 0u; return zero; }
     float fc = one_d * (float)n_matching;
     int comp = fc > 0.0f ? (int)fc : 0;
     if (comp > n_matching - 1) comp = n_matching - 1;
-    // matching_at(comp): the comp-th matching lobe
-    int li = (m0 && comp == 0) ? 0 : 1;
-    const Lobe l = b.lobe[li];
+    int li = (m0 && comp == 0) ? 0 : 1;   // matching_at(comp): the comp-th matching lobe
+    const Lobe l = load_lobe(b.mat, li);
     f3 w_o = normalized(to_shading(b, wo_world));
     f3 w_i;
     float pdf_v;
@@ -310,7 +329,7 @@ TR_DEV f3 bsdf_sample(const Bsdf& b, f3 wo_world, uint32_t flags, float u0, floa
     return f;
 }
 
-// Material::bsdf + BSDF::new (bsdf.rs:38-44; quirk Q8: tan is not renormalised)
+// BSDF::new (bsdf.rs:38-44; quirk Q8: tan is not renormalised); lobes come from the material table
 TR_DEV Bsdf make_bsdf(const DevScene& sc, const Hit& hit) {
     Bsdf b;
     b.n = normalized(hit.n);
@@ -318,68 +337,62 @@ TR_DEV Bsdf make_bsdf(const DevScene& sc, const Hit& hit) {
     b.tan = cross(b.n, bt);
     b.bitan = cross(b.tan, b.n);
     b.p = hit.p;
-    b.ng = hit.ng;
-    const TrayMaterial* __restrict__ m = sc.materials + sc.instances[hit.inst].material_id;
-    b.mat = m;
-    b.merl = nullptr;
-    b.n_lobes = 0;
-    f3 c0 = mk(m->c0[0], m->c0[1], m->c0[2]), c1 = mk(m->c1[0], m->c1[1], m->c1[2]);
-    const f3 white = mk(1.0f, 1.0f, 1.0f);
-    float f0 = m->f0, f1 = m->f1;
-    Lobe l;
-    l.eta_t = 1.0f; l.width = 0.0f; l.ob = 0.0f;
-    switch (m->kind) {
-        case TRAY_MAT_MATTE: {   // matte.rs:52-65, oren_nayar.rs:26-34
-            l.color = c0; l.type = BX_DIFFUSE | BX_REFLECTION;
-            if (f0 == 0.0f) { l.kind = LB_LAMBERTIAN; }
-            else {
-                l.kind = LB_OREN_NAYAR;
-                float sigma = to_radians(f0);
-                sigma *= sigma;
-                l.width = 1.0f - 0.5f * sigma / (sigma + 0.33f);
-                l.ob = 0.45f * sigma / (sigma + 0.09f);
-            }
-            b.lobe[b.n_lobes++] = l;
-            break;
-        }
-        case TRAY_MAT_PLASTIC: {   // plastic.rs:59-88
-            if (!is_black(c0)) { l.kind = LB_LAMBERTIAN; l.type = BX_DIFFUSE | BX_REFLECTION; l.color = c0; b.lobe[b.n_lobes++] = l; }
-            if (!is_black(c1)) {
-                l.kind = LB_TS_DIEL; l.type = BX_GLOSSY | BX_REFLECTION; l.color = c1; l.eta_t = 1.5f; l.width = fmaxf(f0, 0.000001f);
-                b.lobe[b.n_lobes++] = l;
-            }
-            break;
-        }
-        case TRAY_MAT_METAL: {   // metal.rs:56-67
-            l.kind = LB_TS_COND; l.type = BX_GLOSSY | BX_REFLECTION; l.color = white; l.width = fmaxf(f0, 0.000001f);
-            b.lobe[b.n_lobes++] = l;
-            break;
-        }
-        case TRAY_MAT_GLASS: {   // glass.rs:51-78
-            l.eta_t = f0;
-            if (!is_black(c0)) { l.kind = LB_SPEC_REFL_DIEL; l.type = BX_SPECULAR | BX_REFLECTION; l.color = c0; b.lobe[b.n_lobes++] = l; }
-            if (!is_black(c1)) { l.kind = LB_SPEC_TRANS; l.type = BX_SPECULAR | BX_TRANSMISSION; l.color = c1; b.lobe[b.n_lobes++] = l; }
-            break;
-        }
-        case TRAY_MAT_ROUGH_GLASS: {   // rough_glass.rs:57-85
-            l.eta_t = f0; l.width = fmaxf(f1, 0.000001f);
-            if (!is_black(c0)) { l.kind = LB_TS_DIEL; l.type = BX_GLOSSY | BX_REFLECTION; l.color = c0; b.lobe[b.n_lobes++] = l; }
-            if (!is_black(c1)) { l.kind = LB_MF_TRANS; l.type = BX_GLOSSY | BX_TRANSMISSION; l.color = c1; b.lobe[b.n_lobes++] = l; }
-            break;
-        }
-        case TRAY_MAT_SPECULAR_METAL: {   // specular_metal.rs:49-58
-            l.kind = LB_SPEC_REFL_COND; l.type = BX_SPECULAR | BX_REFLECTION; l.color = white;
-            b.lobe[b.n_lobes++] = l;
-            break;
-        }
-        default: {   // TRAY_MAT_MERL, material/merl.rs:88-92
-            l.kind = LB_MERL; l.type = BX_GLOSSY | BX_REFLECTION; l.color = white;
-            b.merl = sc.merl_data + sc.merl_tables[m->table].offset;
-            b.lobe[b.n_lobes++] = l;
-            break;
-        }
-    }
+    b.mat = sc.materials + sc.instances[hit.inst].material_id;
+    b.merl_data = sc.merl_data;
     return b;
+}
+
+// Material::bsdf for the seven materials, evaluated once per material on the host
+// (material/{matte,plastic,metal,glass,rough_glass,specular_metal,merl}.rs). f32 arithmetic in the
+// reference's order; this translation unit is built with -ffp-contract=off for host and device.
+inline DevMaterial lower_material(const TrayMaterial& m, const TrayMerlTable* tables) {
+    DevMaterial d;
+    std::memset(&d, 0, sizeof d);
+    auto black = [](const float* c) { return c[0] == 0.0f && c[1] == 0.0f && c[2] == 0.0f; };
+    auto add = [&](uint32_t kind, uint32_t type, const float* color, float eta_t, float width, float ob) {
+        DevLobe& l = d.lobe[d.n_lobes++];
+        l.kind = kind; l.type = type;
+        l.color[0] = color[0]; l.color[1] = color[1]; l.color[2] = color[2];
+        l.eta_t = eta_t; l.width = width; l.ob = ob;
+    };
+    const float white[3] = {1.0f, 1.0f, 1.0f};
+    for (int i = 0; i < 3; ++i) { d.eta[i] = m.c0[i]; d.k[i] = m.c1[i]; }
+    auto beckmann = [](float w) { return w > 0.000001f ? w : 0.000001f; };   // Beckmann::new (f32::max)
+    switch (m.kind) {
+        case TRAY_MAT_MATTE:   // matte.rs:52-65, oren_nayar.rs:26-34
+            if (m.f0 == 0.0f) add(LB_LAMBERTIAN, BX_DIFFUSE | BX_REFLECTION, m.c0, 1.0f, 0.0f, 0.0f);
+            else {
+                float sigma = 3.14159265358979323846f / 180.0f * m.f0;
+                sigma *= sigma;
+                float a = 1.0f - 0.5f * sigma / (sigma + 0.33f);
+                float bb = 0.45f * sigma / (sigma + 0.09f);
+                add(LB_OREN_NAYAR, BX_DIFFUSE | BX_REFLECTION, m.c0, 1.0f, a, bb);
+            }
+            break;
+        case TRAY_MAT_PLASTIC:   // plastic.rs:59-88
+            if (!black(m.c0)) add(LB_LAMBERTIAN, BX_DIFFUSE | BX_REFLECTION, m.c0, 1.0f, 0.0f, 0.0f);
+            if (!black(m.c1)) add(LB_TS_DIEL, BX_GLOSSY | BX_REFLECTION, m.c1, 1.5f, beckmann(m.f0), 0.0f);
+            break;
+        case TRAY_MAT_METAL:   // metal.rs:56-67
+            add(LB_TS_COND, BX_GLOSSY | BX_REFLECTION, white, 1.0f, beckmann(m.f0), 0.0f);
+            break;
+        case TRAY_MAT_GLASS:   // glass.rs:51-78
+            if (!black(m.c0)) add(LB_SPEC_REFL_DIEL, BX_SPECULAR | BX_REFLECTION, m.c0, m.f0, 0.0f, 0.0f);
+            if (!black(m.c1)) add(LB_SPEC_TRANS, BX_SPECULAR | BX_TRANSMISSION, m.c1, m.f0, 0.0f, 0.0f);
+            break;
+        case TRAY_MAT_ROUGH_GLASS:   // rough_glass.rs:57-85
+            if (!black(m.c0)) add(LB_TS_DIEL, BX_GLOSSY | BX_REFLECTION, m.c0, m.f0, beckmann(m.f1), 0.0f);
+            if (!black(m.c1)) add(LB_MF_TRANS, BX_GLOSSY | BX_TRANSMISSION, m.c1, m.f0, beckmann(m.f1), 0.0f);
+            break;
+        case TRAY_MAT_SPECULAR_METAL:   // specular_metal.rs:49-58
+            add(LB_SPEC_REFL_COND, BX_SPECULAR | BX_REFLECTION, white, 1.0f, 0.0f, 0.0f);
+            break;
+        default:   // TRAY_MAT_MERL, material/merl.rs:88-92
+            add(LB_MERL, BX_GLOSSY | BX_REFLECTION, white, 1.0f, 0.0f, 0.0f);
+            d.merl_offset = tables ? tables[m.table].offset : 0;
+            break;
+    }
+    return d;
 }
 
 }  // namespace tr

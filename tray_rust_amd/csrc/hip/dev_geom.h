@@ -1,17 +1,39 @@
-// Device-side geometry: two-level BVH traversal (closest / any hit), primitive tests, deferred
-// differential geometry, area-light sampling. One thread = one ray. Mirrors, per function:
+// Device-side geometry: one-loop two-level BVH traversal (closest / any hit), primitive tests,
+// deferred differential geometry, area-light sampling. One thread = one ray. Mirrors, per function:
 //   Scene::intersect scene.rs:148-150        BVH::intersect bvh.rs:81-130     fast_intersect bbox.rs:75-104
 //   Instance/Receiver/Emitter::intersect receiver.rs:29-44, emitter.rs:118-137
 //   intersect_triangle mesh.rs:136-198       Sphere sphere.rs:33-140          Rectangle rectangle.rs:38-104
 //   Disk disk.rs:42-110                      Light for Emitter emitter.rs:140-203
-// Difference by design (results identical): the reference builds a DifferentialGeometry for every
-// accepted candidate; here traversal only keeps (t, instance, primitive, barycentrics) and the
-// differential geometry of the final hit is rebuilt once from exactly the same inputs.
+// Differences by design (results identical):
+//  * the reference builds a DifferentialGeometry for every accepted candidate; here traversal only
+//    keeps (t, instance, primitive, barycentrics) and the differential geometry of the final hit is
+//    rebuilt once from exactly the same inputs;
+//  * the reference nests BVH<Triangle>::intersect inside BVH<Instance>::intersect; here both levels
+//    run in ONE loop over a shared stack (instances of a leaf and an "exit mesh" sentinel are stack
+//    entries), so lanes that are in different levels still execute the same node-test code. The
+//    visiting order of nodes, instances and triangles is the reference's.
 #pragma once
 #include "../../../include/trayhip.h"
 #include "dev_math.h"
 
 namespace tr {
+
+// Lobes of a material, precomputed on the host at scene creation (dev_bsdf.h)
+struct DevLobe {
+    uint32_t kind, type;
+    float color[3];
+    float eta_t;   // Dielectric::new(1.0, eta_t)
+    float width;   // Beckmann width | Oren-Nayar A
+    float ob;      // Oren-Nayar B
+};
+struct DevMaterial {
+    uint32_t n_lobes;
+    uint32_t pad0;
+    uint64_t merl_offset;   // float offset into merl_data
+    DevLobe lobe[2];
+    float eta[4];           // conductor eta (rgb)
+    float k[4];             // conductor k (rgb)
+};
 
 struct DevScene {
     const TrayInstance* __restrict__ instances;
@@ -21,8 +43,7 @@ struct DevScene {
     const TrayBvhNode* __restrict__ mesh_nodes;
     const TrayTriVerts* __restrict__ tri_verts;
     const TrayTriAttrs* __restrict__ tri_attrs;
-    const TrayMaterial* __restrict__ materials;
-    const TrayMerlTable* __restrict__ merl_tables;
+    const DevMaterial* __restrict__ materials;
     const float* __restrict__ merl_data;
     const uint32_t* __restrict__ lights;
     const float* __restrict__ filter_table;
@@ -35,9 +56,8 @@ struct DevScene {
 
 struct Ray {
     f3 o, d;
-    float min_t, max_t, time;
+    float min_t, max_t;
 };
-TR_DEV f3 ray_at(const Ray& r, float t) { return r.o + r.d * t; }   // ray.rs:43-45
 
 struct HitRec {   // what traversal keeps for the closest candidate
     float t;
@@ -56,7 +76,7 @@ struct Counters { uint32_t rays, vertices; };
 // BBox::fast_intersect (bbox.rs:75-104); comparison directions kept so NaNs fall the same way
 TR_DEV bool bbox_hit(const float4 lo, const float4 hi, const f3 o, const f3 inv_dir, const bool nx, const bool ny, const bool nz,
                      float min_t, float max_t) {
-    // lo = (bmin.x, bmin.y, bmin.z, bmax.x), hi = (bmax.y, bmax.z, ...)
+    // lo = (bmin.x, bmin.y, bmin.z, bmax.x), hi = (bmax.y, bmax.z, offset, meta)
     float bminx = lo.x, bminy = lo.y, bminz = lo.z, bmaxx = lo.w, bmaxy = hi.x, bmaxz = hi.y;
     float tmin = ((nx ? bmaxx : bminx) - o.x) * inv_dir.x;
     float tmax = ((nx ? bminx : bmaxx) - o.x) * inv_dir.x;
@@ -133,119 +153,119 @@ TR_DEV bool disk_test(float radius, float inner_radius, f3 o, f3 d, float min_t,
     return true;
 }
 
-#define TR_STACK 32
+// Per-thread traversal stack in LDS: entry e of thread t lives at base[e * TR_BLOCK + t], so the 64
+// lanes of a wave always touch 64 consecutive dwords (conflict free).
+#ifndef TR_STACK
+#define TR_STACK 24
+#endif
+#ifndef TR_BLOCK
+#define TR_BLOCK 256
+#endif
+enum : uint32_t { STK_NODE = 0u, STK_INSTANCE = 1u << 30, STK_EXIT_MESH = 2u << 30, STK_KIND_MASK = 3u << 30 };
 
-// BVH<Triangle>::intersect over one mesh (bvh.rs:81-130, leaf <= 16). Returns true if any triangle
-// was accepted; max_t shrinks as candidates are accepted. ANY: stop at the first accepted candidate.
-template <bool ANY>
-TR_DEV bool mesh_traverse(const DevScene& sc, const TrayMesh m, f3 o, f3 d, float min_t, float& max_t, uint32_t& prim, float& b1, float& b2) {
-    const TrayBvhNode* __restrict__ tree = sc.mesh_nodes + m.node_offset;
-    const TrayTriVerts* __restrict__ tris = sc.tri_verts + m.tri_offset;
+// Scene::intersect. Returns true on hit; rec = closest candidate (the last accepted one,
+// bvh.rs:93-98). any_hit: return at the first accepted candidate (OcclusionTester::occluded only
+// needs the boolean, light/mod.rs:30-37; the first accepted candidate is the same in both modes).
+__device__ __noinline__ bool trace(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, HitRec& rec) {
+    const TrayBvhNode* __restrict__ tree = sc.top_nodes;
+    f3 o = ray.o, d = ray.d;
     f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
-    uint32_t stack[TR_STACK];
+    const float min_t = ray.min_t;
+    float max_t = ray.max_t;
     int sp = 0;
-    uint32_t current = 0;
+    uint32_t current = 0;          // node index in the current tree
+    uint32_t cur_inst = 0;         // instance being traversed when in a mesh
+    const TrayTriVerts* __restrict__ tris = nullptr;
+    uint32_t tri_base = 0;
+    bool in_mesh = false;
     bool any = false;
     for (;;) {
+        // ---- node test (both levels)
         const float4* nq = reinterpret_cast<const float4*>(tree + current);
         float4 lo = nq[0], hi = nq[1];
         uint32_t offset = __float_as_uint(hi.z);
         uint32_t meta = __float_as_uint(hi.w);   // count (16) | axis (8) | pad (8)
         uint32_t count = meta & 0xffffu, axis = (meta >> 16) & 0xffu;
+        bool descend = false;
         if (bbox_hit(lo, hi, o, inv_dir, nx, ny, nz, min_t, max_t)) {
-            if (count > 0) {
+            if (count == 0u) {   // interior: near child first by the sign of the split axis (bvh.rs:105-119)
+                bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
+                uint32_t far_child = neg ? current + 1u : offset;
+                current = neg ? offset : current + 1u;
+                stack[sp * TR_BLOCK] = far_child;
+                ++sp;
+                descend = true;
+            } else if (in_mesh) {   // BVH<Triangle> leaf (<= 16 triangles), tested in order
                 for (uint32_t k = 0; k < count; ++k) {
                     float t, bb1, bb2;
                     if (triangle_test(tris + offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
-                        max_t = t; prim = m.tri_offset + offset + k; b1 = bb1; b2 = bb2; any = true;
-                        if (ANY) return true;
-                    }
-                }
-                if (sp == 0) break;
-                current = stack[--sp];
-            } else {
-                bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
-                if (neg) { stack[sp++] = current + 1; current = offset; }
-                else { stack[sp++] = offset; current = current + 1; }
-            }
-        } else {
-            if (sp == 0) break;
-            current = stack[--sp];
-        }
-    }
-    return any;
-}
-
-// Instance::intersect, test part (receiver.rs:29-35): world ray -> object ray by `inv`
-// (direction not renormalised, so t is shared between spaces), then the primitive test.
-template <bool ANY>
-TR_DEV bool instance_test(const DevScene& sc, uint32_t i, const Ray& ray, float& max_t, HitRec& rec) {
-    const TrayInstance* __restrict__ in = sc.instances + i;
-    uint32_t kind = in->kind;
-    if (kind == TRAY_INST_POINT_EMITTER) return false;   // emitter.rs:120
-    f3 o = xf_point(in->inv, ray.o);
-    f3 d = xf_vector(in->inv, ray.d);
-    uint32_t gt = in->geom_type;
-    float t;
-    bool hit = false;
-    uint32_t prim = 0;
-    float b1 = 0.0f, b2 = 0.0f;
-    if (gt == TRAY_GEOM_RECT) {
-        hit = rect_test(in->geom_params[0], in->geom_params[1], o, d, ray.min_t, max_t, t);
-    } else if (gt == TRAY_GEOM_SPHERE) {
-        hit = sphere_test(in->geom_params[0], o, d, ray.min_t, max_t, t);
-    } else if (gt == TRAY_GEOM_MESH) {
-        t = max_t;
-        hit = mesh_traverse<ANY>(sc, sc.meshes[in->mesh_id], o, d, ray.min_t, t, prim, b1, b2);
-    } else if (gt == TRAY_GEOM_DISK) {
-        hit = disk_test(in->geom_params[0], in->geom_params[1], o, d, ray.min_t, max_t, t);
-    }
-    if (hit) {
-        max_t = t;
-        rec.t = t; rec.inst = i; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
-    }
-    return hit;
-}
-
-// Scene::intersect: BVH<Instance> traversal (leaf <= 4). Returns true on hit, rec holds the closest
-// candidate (the last accepted one, bvh.rs:93-98).
-template <bool ANY>
-TR_DEV bool scene_traverse(const DevScene& sc, const Ray& ray, HitRec& rec) {
-    const TrayBvhNode* __restrict__ tree = sc.top_nodes;
-    f3 inv_dir = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-    bool nx = ray.d.x < 0.0f, ny = ray.d.y < 0.0f, nz = ray.d.z < 0.0f;
-    float max_t = ray.max_t;
-    uint32_t stack[TR_STACK];
-    int sp = 0;
-    uint32_t current = 0;
-    bool any = false;
-    for (;;) {
-        const float4* nq = reinterpret_cast<const float4*>(tree + current);
-        float4 lo = nq[0], hi = nq[1];
-        uint32_t offset = __float_as_uint(hi.z);
-        uint32_t meta = __float_as_uint(hi.w);
-        uint32_t count = meta & 0xffffu, axis = (meta >> 16) & 0xffu;
-        if (bbox_hit(lo, hi, ray.o, inv_dir, nx, ny, nz, ray.min_t, max_t)) {
-            if (count > 0) {
-                for (uint32_t k = 0; k < count; ++k) {
-                    uint32_t i = sc.top_order[offset + k];
-                    if (instance_test<ANY>(sc, i, ray, max_t, rec)) {
+                        max_t = t;
+                        rec.t = t; rec.inst = cur_inst; rec.prim = tri_base + offset + k; rec.b1 = bb1; rec.b2 = bb2;
                         any = true;
-                        if (ANY) return true;
+                        if (any_hit) return true;
                     }
                 }
-                if (sp == 0) break;
-                current = stack[--sp];
-            } else {
-                bool neg = axis == 0 ? nx : (axis == 1 ? ny : nz);
-                if (neg) { stack[sp++] = current + 1; current = offset; }
-                else { stack[sp++] = offset; current = current + 1; }
+            } else {   // BVH<Instance> leaf (<= 4 instances): queue them so that pops come in leaf order
+                for (uint32_t k = count; k > 0u; --k) {
+                    stack[sp * TR_BLOCK] = STK_INSTANCE | (offset + k - 1u);
+                    ++sp;
+                }
             }
-        } else {
-            if (sp == 0) break;
-            current = stack[--sp];
         }
+        if (descend) continue;
+        // ---- pop until there is a node to test
+        bool have_node = false;
+        while (sp > 0) {
+            --sp;
+            uint32_t e = stack[sp * TR_BLOCK];
+            uint32_t kind = e & STK_KIND_MASK;
+            if (kind == STK_NODE) { current = e; have_node = true; break; }
+            if (kind == STK_EXIT_MESH) {   // back to world space and the top-level tree
+                in_mesh = false;
+                tree = sc.top_nodes;
+                o = ray.o; d = ray.d;
+                inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
+                continue;
+            }
+            // Instance::intersect (receiver.rs:29-35): world ray -> object ray by `inv`; the direction is
+            // not renormalised, so t is shared between the two spaces
+            uint32_t i = sc.top_order[e & ~STK_KIND_MASK];
+            const TrayInstance* __restrict__ in = sc.instances + i;
+            if (in->kind == TRAY_INST_POINT_EMITTER) continue;   // emitter.rs:120
+            f3 lo_ = xf_point(in->inv, ray.o);
+            f3 ld = xf_vector(in->inv, ray.d);
+            uint32_t gt = in->geom_type;
+            if (gt == TRAY_GEOM_MESH) {
+                const TrayMesh m = sc.meshes[in->mesh_id];
+                stack[sp * TR_BLOCK] = STK_EXIT_MESH;
+                ++sp;
+                in_mesh = true;
+                cur_inst = i;
+                tree = sc.mesh_nodes + m.node_offset;
+                tris = sc.tri_verts + m.tri_offset;
+                tri_base = m.tri_offset;
+                o = lo_; d = ld;
+                inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
+                current = 0;
+                have_node = true;
+                break;
+            }
+            float t;
+            bool hit;
+            if (gt == TRAY_GEOM_RECT) hit = rect_test(in->geom_params[0], in->geom_params[1], lo_, ld, min_t, max_t, t);
+            else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(in->geom_params[0], lo_, ld, min_t, max_t, t);
+            else hit = disk_test(in->geom_params[0], in->geom_params[1], lo_, ld, min_t, max_t, t);
+            if (hit) {
+                max_t = t;
+                rec.t = t; rec.inst = i; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
+                any = true;
+                if (any_hit) return true;
+            }
+        }
+        if (!have_node) break;
     }
     return any;
 }

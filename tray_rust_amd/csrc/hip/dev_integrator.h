@@ -1,9 +1,16 @@
-// Device-side camera, per-sample LD sampler and the Path integrator, one path vertex per call.
+// Device-side camera, per-sample LD sampler and the Path integrator as a per-lane phase machine.
 //   Camera::generate_ray            film/camera.rs:150-157
 //   LowDiscrepancy::get_samples*    sampler/ld.rs:33-64 (draws replaced by TRAY-CBRNG)
 //   Path::illumination              integrator/path.rs:45-120
 //   sample_one_light/estimate_direct integrator/mod.rs:106-169
 //   Light for Emitter, OcclusionTester  geometry/emitter.rs:164-203, light/mod.rs:14-39
+//
+// The reference recurses Path::illumination -> estimate_direct -> Scene::intersect three times per
+// path vertex. Here every lane is a small state machine whose step is "trace ONE ray, then process
+// the answer": PH_EXTEND (camera / continuation ray), PH_SHADOW (occlusion ray of the light sample),
+// PH_MIS (BSDF-sampled ray of estimate_direct). All lanes of a wave therefore meet in the same
+// traversal code whatever stage of the reference's control flow they are in; the arithmetic and the
+// order of every evaluation are the reference's.
 #pragma once
 #include "dev_bsdf.h"
 
@@ -14,11 +21,11 @@ TR_DEV Ray camera_ray(const DevScene& sc, float px, float py, float time) {
     f3 q = xf_point(c.raster_to_cam, mk(px, py, 0.0f));
     f3 px_pos = mk(c.scaling[0], c.scaling[1], c.scaling[2]) * q;
     f3 d = normalized(px_pos);
-    float frame_time = (c.shutter_close - c.shutter_open) * time + c.shutter_open;
+    (void)time;   // frame_time only selects the (unanimated) camera / instance transforms
     Ray r;
     r.o = xf_point(c.cam_world, mk(0.0f, 0.0f, 0.0f));
     r.d = xf_vector(c.cam_world, d);
-    r.min_t = 0.0f; r.max_t = TR_INF; r.time = frame_time;
+    r.min_t = 0.0f; r.max_t = TR_INF;
     return r;
 }
 
@@ -40,21 +47,6 @@ TR_DEV void pixel_sample(const PixelSampler& p, uint32_t s, uint32_t spp, uint32
     t = van_der_corput(permute(s, spp, p.key_t), p.scr_t);
 }
 
-// The six LD arrays of path.rs:48-60 for one camera sample, evaluated lazily per bounce
-struct PathSampler {
-    uint32_t ks;
-    uint32_t scr[9];
-    uint64_t perm[6];
-};
-TR_DEV void path_sampler_init(PathSampler& ps, uint32_t ks, uint32_t n) {
-    ps.ks = ks;
-    ps.scr[0] = draw(ks, SD_L2); ps.scr[1] = draw(ks, SD_L2 + 1); ps.perm[0] = shuffle_small(draw(ks, SD_L2 + 2), n);
-    ps.scr[2] = draw(ks, SD_B2); ps.scr[3] = draw(ks, SD_B2 + 1); ps.perm[1] = shuffle_small(draw(ks, SD_B2 + 2), n);
-    ps.scr[4] = draw(ks, SD_P2); ps.scr[5] = draw(ks, SD_P2 + 1); ps.perm[2] = shuffle_small(draw(ks, SD_P2 + 2), n);
-    ps.scr[6] = draw(ks, SD_L1); ps.perm[3] = shuffle_small(draw(ks, SD_L1 + 1), n);
-    ps.scr[7] = draw(ks, SD_B1); ps.perm[4] = shuffle_small(draw(ks, SD_B1 + 1), n);
-    ps.scr[8] = draw(ks, SD_P1); ps.perm[5] = shuffle_small(draw(ks, SD_P1 + 1), n);
-}
 TR_DEV float rr_draw(uint32_t ks, uint32_t bounce) { return (float)(draw(ks, SD_RR + bounce) >> 8) / 16777216.0f; }   // Rng::next_f32
 
 TR_DEV f3 inst_emission(const TrayInstance* __restrict__ in) { return mk(in->emission[0], in->emission[1], in->emission[2]); }
@@ -63,165 +55,207 @@ TR_DEV f3 emitter_radiance(const TrayInstance* __restrict__ in, f3 w, f3 n) {
     return dot(w, n) > 0.0f ? inst_emission(in) : mk(0.0f, 0.0f, 0.0f);
 }
 
-// Integrator::estimate_direct (integrator/mod.rs:122-169)
-TR_DEV f3 estimate_direct(const DevScene& sc, f3 w_o, f3 p, const Bsdf& bsdf, float l2x, float l2y, float b2x, float b2y, float b1,
-                          uint32_t light_inst, float time, Counters& cnt) {
-    const uint32_t flags = BX_NON_SPECULAR;
-    const TrayInstance* __restrict__ light = sc.instances + light_inst;
-    const bool delta = light->kind == TRAY_INST_POINT_EMITTER;
-    f3 direct = mk(0.0f, 0.0f, 0.0f);
-    // Light::sample_incident (emitter.rs:165-186)
-    f3 li, w_i, p_w;
-    float pdf_light;
-    if (delta) {
-        f3 pos = xf_point(light->mat, mk(0.0f, 0.0f, 0.0f));
-        w_i = normalized(pos - bsdf.p);
-        li = inst_emission(light) / length_sqr(pos - bsdf.p);
-        pdf_light = 1.0f;
-        p_w = pos;
-    } else {
-        f3 p_l = xf_point(light->inv, bsdf.p);
-        f3 p_sampled, normal;
-        geom_sample(light, p_l, l2x, l2y, p_sampled, normal);
-        f3 w_il = normalized(p_sampled - p_l);
-        pdf_light = geom_pdf(light, p_l, w_il);
-        li = emitter_radiance(light, -w_il, normal);
-        p_w = xf_point(light->mat, p_sampled);
-        w_i = xf_vector(light->mat, w_il);
-    }
-    bool unoccluded = false;
-    if (pdf_light > 0.0f && !is_black(li)) {
-        Ray sh;   // OcclusionTester::test_points (light/mod.rs:21-23): unnormalised segment (quirk Q4)
-        sh.o = bsdf.p; sh.d = p_w - bsdf.p; sh.min_t = 0.001f; sh.max_t = 0.999f; sh.time = time;
-        HitRec tmp;
-        cnt.rays++;
-        unoccluded = !scene_traverse<true>(sc, sh, tmp);
-    }
-    if (unoccluded) {
-        f3 f = bsdf_eval(bsdf, w_o, w_i, flags);
-        if (!is_black(f)) {
-            if (delta) {
-                direct = f * li * fabsf(dot(w_i, bsdf.n)) / pdf_light;
-            } else {
-                float pdf_bsdf = bsdf_pdf(bsdf, w_o, w_i, flags);
-                float w = power_heuristic(1.0f, pdf_light, 1.0f, pdf_bsdf);
-                direct = f * li * fabsf(dot(w_i, bsdf.n)) * w / pdf_light;
-            }
-        }
-    }
-    if (!delta) {
-        f3 wi2;
-        float pdf_bsdf;
-        uint32_t sampled_type;
-        f3 f = bsdf_sample(bsdf, w_o, flags, b2x, b2y, b1, wi2, pdf_bsdf, sampled_type);
-        if (pdf_bsdf > 0.0f && !is_black(f)) {
-            float w = 1.0f;
-            if (!(sampled_type & BX_SPECULAR)) {
-                // Light::pdf (emitter.rs:193-203)
-                f3 p_l = xf_point(light->inv, p);
-                f3 wl = normalized(xf_vector(light->inv, wi2));
-                float pl = geom_pdf(light, p_l, wl);
-                if (pl == 0.0f) return direct;
-                w = power_heuristic(1.0f, pdf_bsdf, 1.0f, pl);
-            }
-            Ray r;
-            r.o = p; r.d = wi2; r.min_t = 0.001f; r.max_t = TR_INF; r.time = time;
-            f3 li2 = mk(0.0f, 0.0f, 0.0f);
-            HitRec rec;
-            cnt.rays++;
-            if (scene_traverse<false>(sc, r, rec)) {
-                if (rec.inst == light_inst) {   // same emitter object (mod.rs:157-160)
-                    Hit h = finish_hit(sc, r, rec);
-                    li2 = emitter_radiance(light, -wi2, h.ng);
-                }
-            }
-            if (!is_black(li2)) direct = direct + f * li2 * fabsf(dot(wi2, bsdf.n)) * w / pdf_bsdf;
-        }
-    }
-    return direct;
-}
+enum : uint32_t { PH_NEW = 0, PH_EXTEND = 1, PH_SHADOW = 2, PH_MIS = 3, PH_DONE = 4 };
+enum : uint32_t { WANT_NONE = 0, WANT_MIS = 1, WANT_PATH = 2 };
 
-struct PathState {
-    Ray ray;          // the ray that is (or was last) traced
-    HitRec rec;       // closest hit of `ray`
-    f3 throughput, illum;
-    f3 first_ng;      // hit.dg.ng of the camera ray's hit (quirk Q1)
-    uint32_t bounce;  // index of the vertex `rec` describes
+// Everything a lane keeps between two traced rays
+struct Lane {
+    Ray ray;               // ray to trace next / traced last
+    uint32_t phase;
+    uint32_t bounce;       // index of the path vertex being shaded
     bool specular_bounce;
+    f3 throughput, illum;
+    f3 first_ng;           // hit.dg.ng of the camera ray's hit (quirk Q1)
+    // shading context of the current vertex (BSDF::new)
+    Bsdf bsdf;
+    f3 w_o;
+    // light sample waiting for its occlusion ray (PH_SHADOW)
+    uint32_t light_inst;
+    f3 li, wi_l;
+    float pdf_l;
+    f3 direct;             // direct_light of estimate_direct, accumulated over the light / BSDF halves
+    f3 mis_weight;         // f * |cos| * w / pdf_bsdf of the BSDF-sampled half (PH_MIS)
+    // per camera sample LD arrays (path.rs:48-60): sample key + six shuffles (nibble packed)
+    uint32_t ks;
+    uint64_t perm[6];
 };
 
-// One iteration of the loop in Path::illumination (path.rs:69-117) for the vertex in st.rec.
-// Returns true when st.ray holds the continuation ray (to be traced by the caller, who then
-// increments nothing: st.bounce already names the next vertex); false when the path ended.
-TR_DEV bool path_vertex(const DevScene& sc, PathState& st, const PathSampler& ps, Counters& cnt) {
+TR_DEV void lane_start_sample(const DevScene& sc, Lane& ln, const Ray& cam_ray, uint32_t ks) {
+    ln.ray = cam_ray;
+    ln.phase = PH_EXTEND;
+    ln.bounce = 0u;
+    ln.specular_bounce = false;
+    ln.throughput = mk(1.0f, 1.0f, 1.0f);
+    ln.illum = mk(0.0f, 0.0f, 0.0f);
+    ln.ks = ks;
+    const uint32_t n = sc.max_depth + 1u;
+    ln.perm[0] = shuffle_small(draw(ks, SD_L2 + 2), n);
+    ln.perm[1] = shuffle_small(draw(ks, SD_B2 + 2), n);
+    ln.perm[2] = shuffle_small(draw(ks, SD_P2 + 2), n);
+    ln.perm[3] = shuffle_small(draw(ks, SD_L1 + 1), n);
+    ln.perm[4] = shuffle_small(draw(ks, SD_B1 + 1), n);
+    ln.perm[5] = shuffle_small(draw(ks, SD_P1 + 1), n);
+}
+
+// sample_02 / van_der_corput of array `a` at the current bounce (ld.rs:54-64, 91-93)
+TR_DEV void lane_2d(const Lane& ln, int a, uint32_t dim, float& u0, float& u1) {
+    uint32_t idx = perm_at(ln.perm[a], ln.bounce);
+    u0 = van_der_corput(idx, draw(ln.ks, dim));
+    u1 = sobol(idx, draw(ln.ks, dim + 1u));
+}
+TR_DEV float lane_1d(const Lane& ln, int a, uint32_t dim) { return van_der_corput(perm_at(ln.perm[a], ln.bounce), draw(ln.ks, dim)); }
+
+// After the PH_EXTEND ray hit something: head of the loop body of Path::illumination (path.rs:69-82)
+// up to the light half of estimate_direct (mod.rs:124-127). Returns WANT_* for the sampling stage.
+TR_DEV uint32_t shade_extend(const DevScene& sc, Lane& ln, const HitRec& rec, Counters& cnt) {
     cnt.vertices++;
-    const uint32_t bounce = st.bounce;
-    Hit hit = finish_hit(sc, st.ray, st.rec);
-    if (bounce == 0u) st.first_ng = hit.ng;
+    Hit hit = finish_hit(sc, ln.ray, rec);
+    if (ln.bounce == 0u) ln.first_ng = hit.ng;
     const TrayInstance* __restrict__ inst = sc.instances + hit.inst;
-    if (bounce == 0u || st.specular_bounce) {
+    if (ln.bounce == 0u || ln.specular_bounce) {
         if (inst->kind != TRAY_INST_RECEIVER) {
-            f3 w = -st.ray.d;
-            st.illum = st.illum + st.throughput * emitter_radiance(inst, w, st.first_ng);
+            f3 w = -ln.ray.d;
+            ln.illum = ln.illum + ln.throughput * emitter_radiance(inst, w, ln.first_ng);
         }
     }
-    Bsdf bsdf = make_bsdf(sc, hit);
-    f3 w_o = -st.ray.d;
-    uint32_t iL2 = perm_at(ps.perm[0], bounce), iB2 = perm_at(ps.perm[1], bounce), iP2 = perm_at(ps.perm[2], bounce);
-    float l2x = van_der_corput(iL2, ps.scr[0]), l2y = sobol(iL2, ps.scr[1]);
-    float b2x = van_der_corput(iB2, ps.scr[2]), b2y = sobol(iB2, ps.scr[3]);
-    float l1 = van_der_corput(perm_at(ps.perm[3], bounce), ps.scr[6]);
-    float b1 = van_der_corput(perm_at(ps.perm[4], bounce), ps.scr[7]);
+    ln.bsdf = make_bsdf(sc, hit);
+    ln.w_o = -ln.ray.d;
+    ln.direct = mk(0.0f, 0.0f, 0.0f);
     // sample_one_light (mod.rs:106-111), no 1/p_select (quirk Q6)
+    float l1 = lane_1d(ln, 3, SD_L1);
     float fl = l1 * (float)sc.n_lights;
     uint32_t li_idx = fl > 0.0f ? (uint32_t)fl : 0u;
     if (li_idx > sc.n_lights - 1u) li_idx = sc.n_lights - 1u;
-    f3 li = estimate_direct(sc, w_o, hit.p, bsdf, l2x, l2y, b2x, b2y, b1, sc.lights[li_idx], st.ray.time, cnt);
-    st.illum = st.illum + st.throughput * li;
+    ln.light_inst = sc.lights[li_idx];
+    const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
+    // Light::sample_incident (emitter.rs:165-186)
+    f3 p_w;
+    if (light->kind == TRAY_INST_POINT_EMITTER) {
+        f3 pos = xf_point(light->mat, mk(0.0f, 0.0f, 0.0f));
+        ln.wi_l = normalized(pos - ln.bsdf.p);
+        ln.li = inst_emission(light) / length_sqr(pos - ln.bsdf.p);
+        ln.pdf_l = 1.0f;
+        p_w = pos;
+    } else {
+        float l2x, l2y;
+        lane_2d(ln, 0, SD_L2, l2x, l2y);
+        f3 p_l = xf_point(light->inv, ln.bsdf.p);
+        f3 p_sampled, normal;
+        geom_sample(light, p_l, l2x, l2y, p_sampled, normal);
+        f3 w_il = normalized(p_sampled - p_l);
+        ln.pdf_l = geom_pdf(light, p_l, w_il);
+        ln.li = emitter_radiance(light, -w_il, normal);
+        p_w = xf_point(light->mat, p_sampled);
+        ln.wi_l = xf_vector(light->mat, w_il);
+    }
+    if (ln.pdf_l > 0.0f && !is_black(ln.li)) {
+        // OcclusionTester::test_points (light/mod.rs:21-23): unnormalised segment (quirk Q4)
+        ln.ray.o = ln.bsdf.p; ln.ray.d = p_w - ln.bsdf.p; ln.ray.min_t = 0.001f; ln.ray.max_t = 0.999f;
+        ln.phase = PH_SHADOW;
+        return WANT_NONE;
+    }
+    return light->kind == TRAY_INST_POINT_EMITTER ? WANT_PATH : WANT_MIS;
+}
 
-    float p2x = van_der_corput(iP2, ps.scr[4]), p2y = sobol(iP2, ps.scr[5]);
-    float p1 = van_der_corput(perm_at(ps.perm[5], bounce), ps.scr[8]);
+// After the PH_SHADOW ray: rest of the light half of estimate_direct (mod.rs:127-139)
+TR_DEV uint32_t shade_shadow(const DevScene& sc, Lane& ln, bool occluded) {
+    const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
+    const bool delta = light->kind == TRAY_INST_POINT_EMITTER;
+    if (!occluded) {
+        f3 f = bsdf_eval(ln.bsdf, ln.w_o, ln.wi_l, BX_NON_SPECULAR);
+        if (!is_black(f)) {
+            if (delta) {
+                ln.direct = f * ln.li * fabsf(dot(ln.wi_l, ln.bsdf.n)) / ln.pdf_l;
+            } else {
+                float pdf_bsdf = bsdf_pdf(ln.bsdf, ln.w_o, ln.wi_l, BX_NON_SPECULAR);
+                float w = power_heuristic(1.0f, ln.pdf_l, 1.0f, pdf_bsdf);
+                ln.direct = f * ln.li * fabsf(dot(ln.wi_l, ln.bsdf.n)) * w / ln.pdf_l;
+            }
+        }
+    }
+    return delta ? WANT_PATH : WANT_MIS;
+}
+
+// BSDF sampling stage shared by the BSDF half of estimate_direct (WANT_MIS, mod.rs:141-153) and the
+// path continuation (WANT_PATH, path.rs:82-115). Returns the follow-up WANT_* (WANT_MIS lanes that
+// produce no ray fall through to WANT_PATH) or WANT_NONE once a ray has been queued / the path ended.
+TR_DEV uint32_t sample_stage(const DevScene& sc, Lane& ln, uint32_t want) {
+    const bool mis = want == WANT_MIS;
+    float u0, u1;
+    lane_2d(ln, mis ? 1 : 2, mis ? SD_B2 : SD_P2, u0, u1);
+    float one_d = lane_1d(ln, mis ? 4 : 5, mis ? SD_B1 : SD_P1);
     f3 w_i;
     float pdf;
     uint32_t sampled_type;
-    f3 f = bsdf_sample(bsdf, w_o, BX_ALL, p2x, p2y, p1, w_i, pdf, sampled_type);
-    if (is_black(f) || pdf == 0.0f) return false;
-    st.specular_bounce = (sampled_type & BX_SPECULAR) != 0u;
-    st.throughput = st.throughput * f * fabsf(dot(w_i, bsdf.n)) / pdf;
-    if (bounce > sc.min_depth) {   // quirk Q2
-        float cont_prob = fmaxf(0.5f, luminance(st.throughput));
-        if (rr_draw(ps.ks, bounce) > cont_prob) return false;
-        st.throughput = st.throughput / cont_prob;
+    f3 f = bsdf_sample(ln.bsdf, ln.w_o, mis ? BX_NON_SPECULAR : BX_ALL, u0, u1, one_d, w_i, pdf, sampled_type);
+    if (mis) {
+        if (pdf > 0.0f && !is_black(f)) {
+            float w = 1.0f;
+            if (!(sampled_type & BX_SPECULAR)) {
+                // Light::pdf (emitter.rs:193-203)
+                const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
+                f3 p_l = xf_point(light->inv, ln.bsdf.p);
+                f3 wl = normalized(xf_vector(light->inv, w_i));
+                float pl = geom_pdf(light, p_l, wl);
+                if (pl == 0.0f) return WANT_PATH;   // `return direct_light` (mod.rs:146-148)
+                w = power_heuristic(1.0f, pdf, 1.0f, pl);
+            }
+            // contribution f * li * |cos| * w / pdf with li known only after the ray (mod.rs:163-165)
+            float c = fabsf(dot(w_i, ln.bsdf.n));
+            ln.mis_weight = mk(f.x, f.y, f.z);
+            ln.ray.o = ln.bsdf.p; ln.ray.d = w_i; ln.ray.min_t = 0.001f; ln.ray.max_t = TR_INF;
+            // keep the reference's evaluation order f * li * c * w / pdf: store the factors, apply in shade_mis
+            ln.pdf_l = pdf;      // reuse: pdf_bsdf
+            ln.li = mk(c, w, 0.0f);
+            ln.phase = PH_MIS;
+            return WANT_NONE;
+        }
+        return WANT_PATH;
     }
-    if (bounce == sc.max_depth) return false;
-    st.ray.o = bsdf.p;
-    st.ray.d = normalized(w_i);
-    st.ray.min_t = 0.001f; st.ray.max_t = TR_INF;   // time is inherited (ray.rs:35-37)
-    st.bounce = bounce + 1u;
-    return true;
+    // path.rs:80-117
+    ln.illum = ln.illum + ln.throughput * ln.direct;
+    if (is_black(f) || pdf == 0.0f) { ln.phase = PH_NEW; return WANT_NONE; }
+    ln.specular_bounce = (sampled_type & BX_SPECULAR) != 0u;
+    ln.throughput = ln.throughput * f * fabsf(dot(w_i, ln.bsdf.n)) / pdf;
+    if (ln.bounce > sc.min_depth) {   // quirk Q2
+        float cont_prob = fmaxf(0.5f, luminance(ln.throughput));
+        if (rr_draw(ln.ks, ln.bounce) > cont_prob) { ln.phase = PH_NEW; return WANT_NONE; }
+        ln.throughput = ln.throughput / cont_prob;
+    }
+    if (ln.bounce == sc.max_depth) { ln.phase = PH_NEW; return WANT_NONE; }
+    ln.ray.o = ln.bsdf.p;
+    ln.ray.d = normalized(w_i);
+    ln.ray.min_t = 0.001f; ln.ray.max_t = TR_INF;
+    ln.bounce = ln.bounce + 1u;
+    ln.phase = PH_EXTEND;
+    return WANT_NONE;
 }
 
-// Whole camera sample without regeneration (debug kernel): thread_work's inner loop body
-// (multithreaded.rs:94-103). Returns the clamped radiance.
-TR_DEV f3 trace_sample(const DevScene& sc, uint32_t kf, uint32_t px, uint32_t py, uint32_t s, uint32_t spp, float& sx, float& sy, Counters& cnt) {
-    PixelSampler pix = pixel_sampler(kf, py * sc.width + px);
-    float t;
-    pixel_sample(pix, s, spp, px, py, sx, sy, t);
-    PathState st;
-    st.ray = camera_ray(sc, sx, sy, t);
-    st.throughput = mk(1.0f, 1.0f, 1.0f);
-    st.illum = mk(0.0f, 0.0f, 0.0f);
-    st.first_ng = mk(0.0f, 0.0f, 0.0f);
-    st.bounce = 0u;
-    st.specular_bounce = false;
-    PathSampler ps;
-    path_sampler_init(ps, key_sample(pix.kp, s), sc.max_depth + 1u);
-    for (;;) {
-        cnt.rays++;
-        if (!scene_traverse<false>(sc, st.ray, st.rec)) break;
-        if (!path_vertex(sc, st, ps, cnt)) break;
+// One step of the machine for a lane whose ray has just been traced. After the call either
+// ln.phase is PH_NEW (sample finished: ln.illum is its radiance) or ln.ray holds the next ray.
+TR_DEV void lane_step(const DevScene& sc, Lane& ln, bool hit, const HitRec& rec, Counters& cnt) {
+    uint32_t want = WANT_NONE;
+    if (ln.phase == PH_EXTEND) {
+        if (!hit) { ln.phase = PH_NEW; return; }   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
+        want = shade_extend(sc, ln, rec, cnt);
+    } else if (ln.phase == PH_SHADOW) {
+        want = shade_shadow(sc, ln, hit);
+    } else {   // PH_MIS
+        // direct += f * li * |cos| * w / pdf_bsdf, factors in the reference's order (mod.rs:163-165)
+        if (hit && rec.inst == ln.light_inst) {
+            const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
+            Hit h = finish_hit(sc, ln.ray, rec);
+            f3 li2 = emitter_radiance(light, -ln.ray.d, h.ng);
+            if (!is_black(li2)) ln.direct = ln.direct + ln.mis_weight * li2 * ln.li.x * ln.li.y / ln.pdf_l;
+        }
+        want = WANT_PATH;
     }
-    return mk(clampf(st.illum.x, 0.0f, 1.0f), clampf(st.illum.y, 0.0f, 1.0f), clampf(st.illum.z, 0.0f, 1.0f));   // quirk Q3
+    // at most two passes: WANT_MIS may fall through to WANT_PATH
+    for (int pass = 0; pass < 2 && want != WANT_NONE; ++pass) want = sample_stage(sc, ln, want);
+}
+
+TR_DEV f3 lane_result(const Lane& ln) {   // per-sample clamp (multithreaded.rs:98-99, quirk Q3)
+    return mk(clampf(ln.illum.x, 0.0f, 1.0f), clampf(ln.illum.y, 0.0f, 1.0f), clampf(ln.illum.z, 0.0f, 1.0f));
 }
 
 }  // namespace tr

@@ -64,15 +64,18 @@ __device__ __forceinline__ void film_splat(const DevScene& sc, float* __restrict
 
 // Work item w (0 <= w < n_work) maps to queue entry (w / chunk) * chunk_stride * chunk + (w % chunk):
 // contiguous ranges use chunk_stride = 1; multi-GPU sharding interleaves chunks round-robin.
-__global__ __launch_bounds__(256) void k_path_tiles(DevScene sc, const uint2* __restrict__ tiles, uint32_t tile_count, uint32_t chunk,
-                                                    uint32_t chunk_stride, uint32_t spp,
-                                                    uint32_t kf, float* __restrict__ rgbw, uint32_t* __restrict__ counter,
-                                                    DevStats* __restrict__ stats) {
+__global__ __launch_bounds__(TR_BLOCK) void k_path_tiles(const DevScene* __restrict__ scp, const uint2* __restrict__ tiles, uint32_t tile_count,
+                                                         uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf,
+                                                         float* __restrict__ rgbw, uint32_t* __restrict__ counter,
+                                                         DevStats* __restrict__ stats) {
     __shared__ float s_win[4 * WIN_PLANE];
     __shared__ float s_table[TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE];
+    __shared__ uint32_t s_stack[TR_STACK * TR_BLOCK];
     __shared__ uint32_t s_tile;
+    const DevScene& sc = *scp;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint32_t* const my_stack = s_stack + tid;
     s_table[tid] = sc.filter_table[tid];
     Counters cnt;
     cnt.rays = 0; cnt.vertices = 0;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void k_path_tiles(DevScene sc, const uint2* __
     for (;;) {
         __syncthreads();   // previous tile fully flushed
         if (tid == 0) s_tile = atomicAdd(counter, 1u);
-        for (uint32_t i = tid; i < 4 * WIN_PLANE; i += 256) s_win[i] = 0.0f;
+        for (uint32_t i = tid; i < 4 * WIN_PLANE; i += TR_BLOCK) s_win[i] = 0.0f;
         __syncthreads();
         const uint32_t ti = s_tile;
         if (ti >= tile_count) break;
@@ -90,50 +93,42 @@ __global__ __launch_bounds__(256) void k_path_tiles(DevScene sc, const uint2* __
         const PixelSampler pix = pixel_sampler(kf, py * sc.width + px);
 
         uint32_t s_next = wave;
-        bool active = false, pending = false;
-        f3 result = mk(0.0f, 0.0f, 0.0f);
+        bool pending = false;
         float sx = 0.0f, sy = 0.0f;
-        PathState st;
-        PathSampler ps;
-        st.bounce = 0; st.specular_bounce = false;
-        st.throughput = mk(1.0f, 1.0f, 1.0f); st.illum = mk(0.0f, 0.0f, 0.0f); st.first_ng = mk(0.0f, 0.0f, 0.0f);
+        Lane ln;
+        ln.phase = PH_NEW;
+        ln.illum = mk(0.0f, 0.0f, 0.0f);
         for (;;) {
-            if (!active) {
+            if (ln.phase == PH_NEW) {
                 if (pending) {
-                    film_splat(sc, s_win, s_table, x0, y0, sx, sy, result);
+                    film_splat(sc, s_win, s_table, x0, y0, sx, sy, lane_result(ln));
                     pending = false;
                 }
                 if (s_next < spp) {
                     float t;
                     pixel_sample(pix, s_next, spp, px, py, sx, sy, t);
-                    st.ray = camera_ray(sc, sx, sy, t);
-                    st.throughput = mk(1.0f, 1.0f, 1.0f);
-                    st.illum = mk(0.0f, 0.0f, 0.0f);
-                    st.bounce = 0u;
-                    st.specular_bounce = false;
-                    path_sampler_init(ps, key_sample(pix.kp, s_next), sc.max_depth + 1u);
-                    s_next += 4u;
+                    lane_start_sample(sc, ln, camera_ray(sc, sx, sy, t), key_sample(pix.kp, s_next));
+                    s_next += TR_BLOCK / 64;
                     ++n_samples;
-                    active = true;
+                    pending = true;
+                } else {
+                    ln.phase = PH_DONE;
                 }
             }
+            const bool active = ln.phase != PH_DONE;
             if (!__any(active)) break;
             if (active) {
                 cnt.rays++;
-                bool cont = scene_traverse<false>(sc, st.ray, st.rec);
-                if (cont) cont = path_vertex(sc, st, ps, cnt);
-                if (!cont) {
-                    result = mk(clampf(st.illum.x, 0.0f, 1.0f), clampf(st.illum.y, 0.0f, 1.0f), clampf(st.illum.z, 0.0f, 1.0f));   // quirk Q3
-                    pending = true;
-                    active = false;
-                }
+                HitRec rec;
+                bool hit = trace(sc, my_stack, ln.ray, ln.phase == PH_SHADOW, rec);
+                lane_step(sc, ln, hit, rec, cnt);
             }
         }
         __syncthreads();
         // flush the window: film::Image::add_pixels semantics on the caller's RGBW buffer
         const int wx0 = x0 - sc.fpw, wy0 = y0 - sc.fph;
         const int ww = 8 + 2 * sc.fpw + 1, wh = 8 + 2 * sc.fph + 1;
-        for (int i = (int)tid; i < ww * wh; i += 256) {
+        for (int i = (int)tid; i < ww * wh; i += TR_BLOCK) {
             int wy = i / ww, wx = i - wy * ww;
             int ix = wx0 + wx, iy = wy0 + wy;
             if (ix < 0 || iy < 0 || ix >= (int)sc.width || iy >= (int)sc.height) continue;
@@ -155,17 +150,20 @@ __global__ __launch_bounds__(256) void k_path_tiles(DevScene sc, const uint2* __
 }
 
 // ---- parity / debug kernels: the same device functions, one thread per item -------------------
-__global__ __launch_bounds__(64) void k_debug_intersect(DevScene sc, uint32_t n, const TrayRay* __restrict__ rays, TrayHit* __restrict__ hits) {
+__global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene* __restrict__ scp, uint32_t n, const TrayRay* __restrict__ rays,
+                                                              TrayHit* __restrict__ hits) {
+    __shared__ uint32_t s_stack[TR_STACK * TR_BLOCK];
+    const DevScene& sc = *scp;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ray r;
     r.o = mk(rays[i].o[0], rays[i].o[1], rays[i].o[2]);
     r.d = mk(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
-    r.min_t = rays[i].min_t; r.max_t = rays[i].max_t; r.time = rays[i].time;
+    r.min_t = rays[i].min_t; r.max_t = rays[i].max_t;
     HitRec rec;
     TrayHit o;
     memset(&o, 0, sizeof o);
-    if (scene_traverse<false>(sc, r, rec)) {
+    if (trace(sc, s_stack + threadIdx.x, r, false, rec)) {
         float uv[2];
         f3 dp_dv;
         Hit h = finish_hit(sc, r, rec, uv, &dp_dv);
@@ -182,30 +180,43 @@ __global__ __launch_bounds__(64) void k_debug_intersect(DevScene sc, uint32_t n,
     hits[i] = o;
 }
 
-__global__ __launch_bounds__(64) void k_debug_sample_radiance(DevScene sc, uint32_t n, const uint32_t* __restrict__ px, const uint32_t* __restrict__ py,
-                                        const uint32_t* __restrict__ si, uint32_t spp, uint32_t kf, float* __restrict__ out) {
+// thread_work's inner loop body for individual (pixel, sample) items (multithreaded.rs:94-103),
+// driven through the same lane machine as the tile kernel
+__global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevScene* __restrict__ scp, uint32_t n, const uint32_t* __restrict__ px,
+                                                                    const uint32_t* __restrict__ py, const uint32_t* __restrict__ si,
+                                                                    uint32_t spp, uint32_t kf, float* __restrict__ out) {
+    __shared__ uint32_t s_stack[TR_STACK * TR_BLOCK];
+    const DevScene& sc = *scp;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Counters cnt;
     cnt.rays = 0; cnt.vertices = 0;
-    float sx, sy;
-    f3 c = trace_sample(sc, kf, px[i], py[i], si[i], spp, sx, sy, cnt);
+    PixelSampler pix = pixel_sampler(kf, py[i] * sc.width + px[i]);
+    float sx, sy, t;
+    pixel_sample(pix, si[i], spp, px[i], py[i], sx, sy, t);
+    Lane ln;
+    lane_start_sample(sc, ln, camera_ray(sc, sx, sy, t), key_sample(pix.kp, si[i]));
+    while (ln.phase != PH_NEW) {
+        cnt.rays++;
+        HitRec rec;
+        bool hit = trace(sc, s_stack + threadIdx.x, ln.ray, ln.phase == PH_SHADOW, rec);
+        lane_step(sc, ln, hit, rec, cnt);
+    }
+    f3 c = lane_result(ln);
     float* o = out + (size_t)i * 8;
     o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = sx; o[4] = sy; o[5] = (float)cnt.vertices; o[6] = (float)cnt.rays; o[7] = 0.0f;
 }
 
-__global__ __launch_bounds__(64) void k_debug_bsdf(DevScene sc, uint32_t material_id, uint32_t flags_sel, uint32_t n, const float* __restrict__ dirs,
-                             const float* __restrict__ u3, float* __restrict__ out) {
+__global__ __launch_bounds__(64) void k_debug_bsdf(const DevScene* __restrict__ scp, uint32_t flags_sel, uint32_t n,
+                                                   const float* __restrict__ dirs, const float* __restrict__ u3, float* __restrict__ out) {
+    const DevScene& sc = *scp;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    // canonical frame: n = +z, dp_du = +x; the material comes from a fake instance lookup
+    // canonical frame: n = +z, dp_du = +x; instance 0 of the (private) scene copy carries the material
     Hit h;
     h.p = mk(0.0f, 0.0f, 0.0f); h.n = mk(0.0f, 0.0f, 1.0f); h.ng = mk(0.0f, 0.0f, 1.0f); h.dp_du = mk(1.0f, 0.0f, 0.0f);
     h.inst = 0;
-    DevScene tmp = sc;
-    // instances[0].material_id is patched on a private copy made by the host (see tray_debug_bsdf)
-    Bsdf b = make_bsdf(tmp, h);
-    (void)material_id;
+    Bsdf b = make_bsdf(sc, h);
     uint32_t flags = flags_sel == 0 ? BX_ALL : BX_NON_SPECULAR;
     f3 wo = mk(dirs[6 * i], dirs[6 * i + 1], dirs[6 * i + 2]), wi = mk(dirs[6 * i + 3], dirs[6 * i + 4], dirs[6 * i + 5]);
     float* o = out + (size_t)i * 12;
@@ -223,6 +234,7 @@ __global__ __launch_bounds__(64) void k_debug_bsdf(DevScene sc, uint32_t materia
 struct TrayDeviceScene {
     int device = 0;
     DevScene dev{};
+    DevScene* d_dev = nullptr;   // the same struct in device memory (kernels read it through scalar loads)
     std::vector<void*> allocs;
     uint2* d_tiles = nullptr;      // full Morton queue
     uint32_t n_tiles = 0;
@@ -332,8 +344,12 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     UP(mesh_nodes, f->mesh_nodes, f->n_mesh_nodes)
     UP(tri_verts, f->tri_verts, f->n_tris)
     UP(tri_attrs, f->tri_attrs, f->n_tris)
-    UP(materials, f->materials, f->n_materials)
-    UP(merl_tables, f->merl_tables, f->n_merl)
+    std::vector<DevMaterial> mats(f->n_materials);
+    for (uint32_t i = 0; i < f->n_materials; ++i) {
+        if (f->materials[i].kind == TRAY_MAT_MERL && f->materials[i].table >= f->n_merl) { rc = TRAY_E_INVALID; set_error("material references a missing MERL table"); }
+        else mats[i] = lower_material(f->materials[i], f->merl_tables);
+    }
+    UP(materials, mats.data(), f->n_materials)
     UP(merl_data, f->merl_data, f->n_merl_floats)
     UP(lights, f->lights, f->n_lights)
     UP(filter_table, &f->film.table[0], TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE)
@@ -363,13 +379,19 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     s->d_counter = const_cast<uint32_t*>(d_counter);
     s->d_stats = const_cast<DevStats*>(d_stats);
     if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
+    {
+        const DevScene* d_dev = nullptr;
+        rc = upload(s, &s->dev, 1, &d_dev);
+        s->d_dev = const_cast<DevScene*>(d_dev);
+        if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
+    }
     if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
         tray_scene_destroy(s); set_error("hipEventCreate failed"); return TRAY_E_DEVICE;
     }
     int per_cu = 0, cus = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles, TR_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (cus < 1) cus = 256;
     s->n_blocks = cus * per_cu;
     *out = s;
@@ -418,7 +440,7 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     kf = mix(kf + s->dev.frame);
     int blocks = (int)std::min<uint32_t>((uint32_t)s->n_blocks, tile_count);
     HIP_CHECK(hipEventRecord(s->ev0, stream));
-    hipLaunchKernelGGL(k_path_tiles, dim3(blocks), dim3(256), 0, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev,
+    hipLaunchKernelGGL(k_path_tiles, dim3(blocks), dim3(TR_BLOCK), 0, stream, s->d_dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev,
                        s->d_counter, s->d_stats);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(s->ev1, stream));
@@ -473,7 +495,7 @@ int tray_debug_intersect(TrayDeviceScene* s, uint32_t n, const TrayRay* rays, Tr
     hipError_t e = hipMalloc(&d_h, n * sizeof(TrayHit));
     if (e == hipSuccess) e = hipMemcpy(d_r, rays, n * sizeof(TrayRay), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_debug_intersect, dim3((n + 63) / 64), dim3(64), 0, 0, s->dev, n, d_r, d_h);
+        hipLaunchKernelGGL(k_debug_intersect, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, 0, s->d_dev, n, d_r, d_h);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(hits, d_h, n * sizeof(TrayHit), hipMemcpyDeviceToHost);
@@ -503,7 +525,7 @@ int tray_debug_sample_radiance(TrayDeviceScene* s, uint32_t n, const uint32_t* p
         uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
         kf = mix(kf ^ (uint32_t)(seed >> 32));
         kf = mix(kf + s->dev.frame);
-        hipLaunchKernelGGL(k_debug_sample_radiance, dim3((n + 63) / 64), dim3(64), 0, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
+        hipLaunchKernelGGL(k_debug_sample_radiance, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, 0, s->d_dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(out, d_out, 8 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
@@ -524,7 +546,9 @@ int tray_debug_bsdf(TrayDeviceScene* s, uint32_t material_id, uint32_t flags, ui
     fake.material_id = material_id;
     TrayInstance* d_fake = nullptr;
     float *d_dirs = nullptr, *d_u = nullptr, *d_out = nullptr;
+    DevScene* d_tmp = nullptr;
     HIP_CHECK(hipMalloc(&d_fake, sizeof fake));
+    HIP_CHECK(hipMalloc(&d_tmp, sizeof(DevScene)));
     hipError_t e = hipMalloc(&d_dirs, 6 * (size_t)n * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&d_u, 3 * (size_t)n * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&d_out, 12 * (size_t)n * sizeof(float));
@@ -534,10 +558,14 @@ int tray_debug_bsdf(TrayDeviceScene* s, uint32_t material_id, uint32_t flags, ui
     if (e == hipSuccess) {
         DevScene tmp = s->dev;
         tmp.instances = d_fake;
-        hipLaunchKernelGGL(k_debug_bsdf, dim3((n + 63) / 64), dim3(64), 0, 0, tmp, material_id, flags, n, d_dirs, d_u, d_out);
-        e = hipGetLastError();
+        e = hipMemcpy(d_tmp, &tmp, sizeof tmp, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_debug_bsdf, dim3((n + 63) / 64), dim3(64), 0, 0, d_tmp, flags, n, d_dirs, d_u, d_out);
+            e = hipGetLastError();
+        }
     }
     if (e == hipSuccess) e = hipMemcpy(out, d_out, 12 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_tmp);
     (void)hipFree(d_fake); (void)hipFree(d_dirs); (void)hipFree(d_u); (void)hipFree(d_out);
     if (e != hipSuccess) { set_error(std::string("tray_debug_bsdf: ") + hipGetErrorString(e)); return TRAY_E_DEVICE; }
     return TRAY_OK;
