@@ -161,6 +161,11 @@ typedef struct TrayFilm {
     float filter_w, filter_h, inv_w, inv_h;
     int32_t filter_pixel_w, filter_pixel_h;   /* floor(w/0.5), floor(h/0.5) */
     float table[TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE];
+    /* 1-D factors when the filter is a product of per-axis weights (both reference filters are):
+     * table[y*16 + x] == table_x[x] * table_y[y] in f32. separable = 0 if no such factors exist. */
+    float table_x[TRAY_FILTER_TABLE_SIZE];
+    float table_y[TRAY_FILTER_TABLE_SIZE];
+    uint32_t separable;
 } TrayFilm;
 
 typedef struct TrayFlatScene {

@@ -1,0 +1,19 @@
+"""Short fixed workload for profiling: cornell 1920x1080 at --spp (default 64), prints Msamples/s."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import tray_rust_amd as T
+from tray_rust_amd import scenes
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+scene_name = sys.argv[3] if len(sys.argv) > 3 else "cornell_box"
+d = "/tmp/sc_small"
+scenes.write_assets(d, cornell=(1920, 1080, spp), small=(1920, 1080, spp))
+scene, rt, spp, fi = T.Scene.load_file(f"{d}/{scene_name}.json")
+hip = T.Hip(0, seed=1)
+buf = torch.zeros(1080 * 1920 * 4, dtype=torch.float32, device="cuda")
+for rep in range(reps):
+    hip.render_device(scene, 0, (0, 0), spp, buf.data_ptr())
+    tim = hip.timing(scene)
+    print(f"{scene_name} 1080p {spp}spp: kernel ms {tim.render_ms:.2f} Msamples/s {tim.samples / tim.render_ms / 1e3:.2f} V {tim.vertices / tim.samples:.3f} rays/sample {tim.rays / tim.samples:.3f}", flush=True)

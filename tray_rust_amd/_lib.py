@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrayhip.so")
+LIB_PATH = os.environ.get("TRAYHIP_LIB") or os.path.join(_HERE, "libtrayhip.so")   # TRAYHIP_LIB: A/B builds of the same library
 
 TRAY_OK = 0
 TRAY_E_INVALID, TRAY_E_IO, TRAY_E_PARSE, TRAY_E_UNSUPPORTED, TRAY_E_DEVICE, TRAY_E_NOMEM = -1, -2, -3, -4, -5, -6
@@ -74,7 +74,8 @@ class TrayCamera(C.Structure):
 class TrayFilm(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("filter_w", C.c_float), ("filter_h", C.c_float),
                 ("inv_w", C.c_float), ("inv_h", C.c_float), ("filter_pixel_w", C.c_int32), ("filter_pixel_h", C.c_int32),
-                ("table", C.c_float * (FILTER_TABLE_SIZE * FILTER_TABLE_SIZE))]
+                ("table", C.c_float * (FILTER_TABLE_SIZE * FILTER_TABLE_SIZE)),
+                ("table_x", C.c_float * FILTER_TABLE_SIZE), ("table_y", C.c_float * FILTER_TABLE_SIZE), ("separable", C.c_uint32)]
 
 
 def _P(t):

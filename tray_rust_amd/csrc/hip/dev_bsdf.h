@@ -280,7 +280,7 @@ TR_DEV f3 from_shading(const Bsdf& b, f3 v) {   // bsdf.rs:57-61
     return mk(b.bitan.x * v.x + b.tan.x * v.y + b.n.x * v.z, b.bitan.y * v.x + b.tan.y * v.y + b.n.y * v.z,
               b.bitan.z * v.x + b.tan.z * v.y + b.n.z * v.z);
 }
-__device__ __noinline__ f3 bsdf_eval(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {   // bsdf.rs:66-79
+TR_DEV f3 bsdf_eval(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {   // bsdf.rs:66-79
     f3 w_o = normalized(to_shading(b, wo_world)), w_i = normalized(to_shading(b, wi_world));
     if (w_o.z * w_i.z > 0.0f) flags &= ~(uint32_t)BX_TRANSMISSION; else flags &= ~(uint32_t)BX_REFLECTION;
     f3 sum = mk(0.0f, 0.0f, 0.0f);
@@ -291,7 +291,7 @@ __device__ __noinline__ f3 bsdf_eval(const Bsdf& b, f3 wo_world, f3 wi_world, ui
     }
     return sum;
 }
-__device__ __noinline__ float bsdf_pdf(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {   // bsdf.rs:114-125
+TR_DEV float bsdf_pdf(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {   // bsdf.rs:114-125
     f3 w_o = normalized(to_shading(b, wo_world)), w_i = normalized(to_shading(b, wi_world));
     float pdf_val = 0.0f;
     int n_comps = 0;
@@ -302,14 +302,24 @@ __device__ __noinline__ float bsdf_pdf(const Bsdf& b, f3 wo_world, f3 wi_world, 
     }
     return n_comps > 0 ? pdf_val / (float)n_comps : 0.0f;
 }
-// bsdf.rs:85-111; returns f, writes wi_world, pdf, sampled lobe type bits (0 = nothing sampled)
-TR_DEV f3 bsdf_sample(const Bsdf& b, f3 wo_world, uint32_t flags, float u0, float u1, float one_d, f3& wi_world, float& pdf_out, uint32_t& sampled_type) {
+// Head of BSDF::sample (bsdf.rs:85-102): choose the lobe, sample its direction. Outputs the world
+// direction, the lobe's own pdf, f for specular lobes, the sampled type bits (0 = nothing sampled)
+// and which of BSDF::pdf / BSDF::eval the tail (bsdf.rs:103-109) still has to evaluate.
+struct SampleHead {
+    f3 wi_world, f;
+    float pdf;
+    uint32_t sampled_type;
+    bool need_eval, need_pdf;
+};
+TR_DEV SampleHead bsdf_sample_head(const Bsdf& b, f3 wo_world, uint32_t flags, float u0, float u1, float one_d) {
     const f3 zero = mk(0.0f, 0.0f, 0.0f);
+    SampleHead h;
+    h.wi_world = zero; h.f = zero; h.pdf = 0.0f; h.sampled_type = 0u; h.need_eval = false; h.need_pdf = false;
     const uint32_t n_lobes = b.mat->n_lobes;
     bool m0 = n_lobes > 0u && lobe_matches(b.mat->lobe[0].type, flags);
     bool m1 = n_lobes > 1u && lobe_matches(b.mat->lobe[1].type, flags);
     int n_matching = (int)m0 + (int)m1;
-    if (n_matching == 0) { wi_world = zero; pdf_out = 0.0f; sampled_type = 0u; return zero; }
+    if (n_matching == 0) return h;
     float fc = one_d * (float)n_matching;
     int comp = fc > 0.0f ? (int)fc : 0;
     if (comp > n_matching - 1) comp = n_matching - 1;
@@ -319,14 +329,22 @@ TR_DEV f3 bsdf_sample(const Bsdf& b, f3 wo_world, uint32_t flags, float u0, floa
     f3 w_i;
     float pdf_v;
     f3 f = lobe_sample(b, l, w_o, u0, u1, w_i, pdf_v);
-    if (length_sqr(w_i) == 0.0f) { wi_world = zero; pdf_out = 0.0f; sampled_type = 0u; return zero; }
-    wi_world = normalized(from_shading(b, w_i));
+    if (length_sqr(w_i) == 0.0f) return h;
+    h.wi_world = normalized(from_shading(b, w_i));
     bool specular = (l.type & BX_SPECULAR) != 0u;
-    if (!specular && n_matching > 1) pdf_v = bsdf_pdf(b, wo_world, wi_world, flags);
-    if (!specular) f = bsdf_eval(b, wo_world, wi_world, flags);
-    pdf_out = pdf_v;
-    sampled_type = l.type;
-    return f;
+    h.f = f; h.pdf = pdf_v; h.sampled_type = l.type;
+    h.need_pdf = !specular && n_matching > 1;
+    h.need_eval = !specular;
+    return h;
+}
+// Whole BSDF::sample (used by the BSDF debug kernel; the tile kernel shares one eval / pdf site
+// between the light and the BSDF halves of estimate_direct and the path continuation, dev_integrator.h)
+TR_DEV f3 bsdf_sample(const Bsdf& b, f3 wo_world, uint32_t flags, float u0, float u1, float one_d, f3& wi_world, float& pdf_out, uint32_t& sampled_type) {
+    SampleHead h = bsdf_sample_head(b, wo_world, flags, u0, u1, one_d);
+    if (h.need_pdf) h.pdf = bsdf_pdf(b, wo_world, h.wi_world, flags);
+    if (h.need_eval) h.f = bsdf_eval(b, wo_world, h.wi_world, flags);
+    wi_world = h.wi_world; pdf_out = h.pdf; sampled_type = h.sampled_type;
+    return h.f;
 }
 
 // BSDF::new (bsdf.rs:38-44; quirk Q8: tan is not renormalised); lobes come from the material table

@@ -47,8 +47,10 @@ struct DevScene {
     const float* __restrict__ merl_data;
     const uint32_t* __restrict__ lights;
     const float* __restrict__ filter_table;
+    const float* __restrict__ filter_x;   // separable factors: table[y*16+x] == filter_x[x] * filter_y[y]
+    const float* __restrict__ filter_y;
     uint32_t n_instances, n_lights, min_depth, max_depth;
-    uint32_t width, height, frame, pad;
+    uint32_t width, height, frame, film_rows;   // film_rows: 1 = row-binned film (separable, filter_h == 2)
     float filter_w, filter_h, inv_w, inv_h;
     int32_t fpw, fph;
     TrayCamera camera;
@@ -163,10 +165,92 @@ TR_DEV bool disk_test(float radius, float inner_radius, f3 o, f3 d, float min_t,
 #endif
 enum : uint32_t { STK_NODE = 0u, STK_INSTANCE = 1u << 30, STK_EXIT_MESH = 2u << 30, STK_KIND_MASK = 3u << 30 };
 
+// BVH<Triangle>::intersect over one mesh (bvh.rs:81-130, leaf <= 16). Returns true if a triangle was
+// accepted; max_t shrinks as candidates are accepted. any_hit: stop at the first accepted candidate.
+TR_DEV bool mesh_traverse(const DevScene& sc, uint32_t* __restrict__ stack, const TrayMesh m, f3 o, f3 d, float min_t, float& max_t,
+                          bool any_hit, uint32_t& prim, float& b1, float& b2) {
+    const TrayBvhNode* __restrict__ tree = sc.mesh_nodes + m.node_offset;
+    const TrayTriVerts* __restrict__ tris = sc.tri_verts + m.tri_offset;
+    f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
+    int sp = 0;
+    uint32_t current = 0;
+    bool any = false;
+    for (;;) {
+        const float4* nq = reinterpret_cast<const float4*>(tree + current);
+        float4 lo = nq[0], hi = nq[1];
+        uint32_t offset = __float_as_uint(hi.z);
+        uint32_t meta = __float_as_uint(hi.w);
+        uint32_t count = meta & 0xffffu, axis = (meta >> 16) & 0xffu;
+        if (bbox_hit(lo, hi, o, inv_dir, nx, ny, nz, min_t, max_t)) {
+            if (count == 0u) {
+                bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
+                stack[sp * TR_BLOCK] = neg ? current + 1u : offset;
+                ++sp;
+                current = neg ? offset : current + 1u;
+                continue;
+            }
+            for (uint32_t k = 0; k < count; ++k) {
+                float t, bb1, bb2;
+                if (triangle_test(tris + offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
+                    max_t = t; prim = m.tri_offset + offset + k; b1 = bb1; b2 = bb2; any = true;
+                    if (any_hit) return true;
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        current = stack[sp * TR_BLOCK];
+    }
+    return any;
+}
+
+// Scene::intersect for scenes with a handful of instances: every lane tests the instances in scene
+// order inside one wave-uniform loop. The instance index is uniform, so the transform and the geometry
+// parameters are scalar loads and the primitive type never diverges; only BVH<Triangle> traversal is
+// per lane. Versus BVH<Instance>::intersect this skips the (conservative) node culling and visits the
+// instances in a different order: the closest hit is the same except for exactly tied t (two
+// instances hit at the same f32 distance) and for rays the reference's slab test drops by rounding.
+#ifndef TR_FLAT_MAX
+#define TR_FLAT_MAX 16
+#endif
+TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, HitRec& rec) {
+    const float min_t = ray.min_t;
+    float max_t = ray.max_t;
+    bool any = false, done = false;
+    const uint32_t n = sc.n_instances;
+    for (uint32_t i = 0; i < n; ++i) {
+        const TrayInstance* __restrict__ in = sc.instances + i;
+        const uint32_t kind = in->kind, gt = in->geom_type;
+        if (kind == TRAY_INST_POINT_EMITTER) continue;   // emitter.rs:120
+        if (!done) {
+            // Instance::intersect (receiver.rs:29-35): world ray -> object ray by `inv`, direction not renormalised
+            f3 o = xf_point(in->inv, ray.o);
+            f3 d = xf_vector(in->inv, ray.d);
+            float t = max_t;
+            bool hit;
+            uint32_t prim = 0u;
+            float b1 = 0.0f, b2 = 0.0f;
+            if (gt == TRAY_GEOM_RECT) hit = rect_test(in->geom_params[0], in->geom_params[1], o, d, min_t, max_t, t);
+            else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(in->geom_params[0], o, d, min_t, max_t, t);
+            else if (gt == TRAY_GEOM_MESH) hit = mesh_traverse(sc, stack, sc.meshes[in->mesh_id], o, d, min_t, t, any_hit, prim, b1, b2);
+            else hit = disk_test(in->geom_params[0], in->geom_params[1], o, d, min_t, max_t, t);
+            if (hit) {
+                max_t = t;
+                rec.t = t; rec.inst = i; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
+                any = true;
+                done = any_hit;
+            }
+        }
+        if (__all(done)) break;
+    }
+    return any;
+}
+
 // Scene::intersect. Returns true on hit; rec = closest candidate (the last accepted one,
 // bvh.rs:93-98). any_hit: return at the first accepted candidate (OcclusionTester::occluded only
 // needs the boolean, light/mod.rs:30-37; the first accepted candidate is the same in both modes).
-__device__ __noinline__ bool trace(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, HitRec& rec) {
+TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, HitRec& rec) {
     const TrayBvhNode* __restrict__ tree = sc.top_nodes;
     f3 o = ray.o, d = ray.d;
     f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -270,6 +354,18 @@ __device__ __noinline__ bool trace(const DevScene& sc, uint32_t* __restrict__ st
     return any;
 }
 
+// Scene::intersect (scene.rs:148-150). The tile kernel calls this from exactly one site (every
+// lane traces one ray per step of its phase machine), so it is inlined there.
+struct TraceResult { HitRec rec; bool hit; };
+TR_DEV TraceResult trace(const DevScene* __restrict__ scp, uint32_t* __restrict__ stack, Ray ray, bool any_hit) {
+    const DevScene& sc = *scp;
+    TraceResult r;
+    r.rec.t = 0.0f; r.rec.inst = 0xffffffffu; r.rec.prim = 0u; r.rec.b1 = 0.0f; r.rec.b2 = 0.0f;
+    if (sc.n_instances <= TR_FLAT_MAX) r.hit = trace_flat(sc, stack, ray, any_hit, r.rec);
+    else r.hit = trace_bvh(sc, stack, ray, any_hit, r.rec);
+    return r;
+}
+
 // Rebuilds the DifferentialGeometry of the final candidate in object space and moves it to world
 // space (receiver.rs:36-42; DifferentialGeometry::{new,with_normal} differential_geometry.rs:32-64).
 TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, float* uv_out = nullptr, f3* dp_dv_out = nullptr) {
@@ -346,6 +442,29 @@ TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, flo
     if (uv_out) { uv_out[0] = u; uv_out[1] = v; }
     if (dp_dv_out) *dp_dv_out = xf_vector(in->mat, dp_dv);
     return h;
+}
+
+// Geometry normal of the final candidate only (what estimate_direct's BSDF half needs from the hit,
+// mod.rs:159): same arithmetic as finish_hit restricted to ng.
+TR_DEV f3 finish_hit_ng(const DevScene& sc, const Ray& ray, const HitRec& rec) {
+    const TrayInstance* __restrict__ in = sc.instances + rec.inst;
+    uint32_t gt = in->geom_type;
+    f3 ng;
+    if (gt == TRAY_GEOM_SPHERE) {
+        f3 o = xf_point(in->inv, ray.o);
+        f3 d = xf_vector(in->inv, ray.d);
+        ng = normalized(o + d * rec.t);
+    } else if (gt == TRAY_GEOM_MESH) {
+        const float4* aq = reinterpret_cast<const float4*>(sc.tri_attrs + rec.prim);
+        float4 a0 = aq[0], a1 = aq[1], a2 = aq[2];
+        f3 na = mk(a0.x, a0.y, a0.z), nb = mk(a0.w, a1.x, a1.y), nc = mk(a1.z, a1.w, a2.x);
+        float b1 = rec.b1, b2 = rec.b2;
+        float b0 = 1.0f - b1 - b2;
+        ng = normalized(b0 * na + b1 * nb + b2 * nc);
+    } else {
+        ng = normalized(mk(0.0f, 0.0f, 1.0f));
+    }
+    return xf_normal_t(in->inv, ng);
 }
 
 // ---- Sampleable (object space) -------------------------------------------------------------

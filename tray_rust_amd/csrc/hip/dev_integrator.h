@@ -56,7 +56,7 @@ TR_DEV f3 emitter_radiance(const TrayInstance* __restrict__ in, f3 w, f3 n) {
 }
 
 enum : uint32_t { PH_NEW = 0, PH_EXTEND = 1, PH_SHADOW = 2, PH_MIS = 3, PH_DONE = 4 };
-enum : uint32_t { WANT_NONE = 0, WANT_MIS = 1, WANT_PATH = 2 };
+enum : uint32_t { WANT_NONE = 0, WANT_LIGHT = 1, WANT_MIS = 2, WANT_PATH = 3 };
 
 // Everything a lane keeps between two traced rays
 struct Lane {
@@ -75,9 +75,9 @@ struct Lane {
     float pdf_l;
     f3 direct;             // direct_light of estimate_direct, accumulated over the light / BSDF halves
     f3 mis_weight;         // f * |cos| * w / pdf_bsdf of the BSDF-sampled half (PH_MIS)
-    // per camera sample LD arrays (path.rs:48-60): sample key + six shuffles (nibble packed)
+    // per camera sample LD arrays (path.rs:48-60): only the sample key is kept; scrambles and
+    // shuffle entries are re-derived from it when a bounce needs them
     uint32_t ks;
-    uint64_t perm[6];
 };
 
 TR_DEV void lane_start_sample(const DevScene& sc, Lane& ln, const Ray& cam_ray, uint32_t ks) {
@@ -88,22 +88,18 @@ TR_DEV void lane_start_sample(const DevScene& sc, Lane& ln, const Ray& cam_ray, 
     ln.throughput = mk(1.0f, 1.0f, 1.0f);
     ln.illum = mk(0.0f, 0.0f, 0.0f);
     ln.ks = ks;
-    const uint32_t n = sc.max_depth + 1u;
-    ln.perm[0] = shuffle_small(draw(ks, SD_L2 + 2), n);
-    ln.perm[1] = shuffle_small(draw(ks, SD_B2 + 2), n);
-    ln.perm[2] = shuffle_small(draw(ks, SD_P2 + 2), n);
-    ln.perm[3] = shuffle_small(draw(ks, SD_L1 + 1), n);
-    ln.perm[4] = shuffle_small(draw(ks, SD_B1 + 1), n);
-    ln.perm[5] = shuffle_small(draw(ks, SD_P1 + 1), n);
+    (void)sc;
 }
 
 // sample_02 / van_der_corput of array `a` at the current bounce (ld.rs:54-64, 91-93)
-TR_DEV void lane_2d(const Lane& ln, int a, uint32_t dim, float& u0, float& u1) {
-    uint32_t idx = perm_at(ln.perm[a], ln.bounce);
+TR_DEV void lane_2d(const DevScene& sc, const Lane& ln, uint32_t dim, float& u0, float& u1) {
+    uint32_t idx = shuffle_entry(draw(ln.ks, dim + 2u), sc.max_depth + 1u, ln.bounce);
     u0 = van_der_corput(idx, draw(ln.ks, dim));
     u1 = sobol(idx, draw(ln.ks, dim + 1u));
 }
-TR_DEV float lane_1d(const Lane& ln, int a, uint32_t dim) { return van_der_corput(perm_at(ln.perm[a], ln.bounce), draw(ln.ks, dim)); }
+TR_DEV float lane_1d(const DevScene& sc, const Lane& ln, uint32_t dim) {
+    return van_der_corput(shuffle_entry(draw(ln.ks, dim + 1u), sc.max_depth + 1u, ln.bounce), draw(ln.ks, dim));
+}
 
 // After the PH_EXTEND ray hit something: head of the loop body of Path::illumination (path.rs:69-82)
 // up to the light half of estimate_direct (mod.rs:124-127). Returns WANT_* for the sampling stage.
@@ -122,7 +118,7 @@ TR_DEV uint32_t shade_extend(const DevScene& sc, Lane& ln, const HitRec& rec, Co
     ln.w_o = -ln.ray.d;
     ln.direct = mk(0.0f, 0.0f, 0.0f);
     // sample_one_light (mod.rs:106-111), no 1/p_select (quirk Q6)
-    float l1 = lane_1d(ln, 3, SD_L1);
+    float l1 = lane_1d(sc, ln, SD_L1);
     float fl = l1 * (float)sc.n_lights;
     uint32_t li_idx = fl > 0.0f ? (uint32_t)fl : 0u;
     if (li_idx > sc.n_lights - 1u) li_idx = sc.n_lights - 1u;
@@ -138,7 +134,7 @@ TR_DEV uint32_t shade_extend(const DevScene& sc, Lane& ln, const HitRec& rec, Co
         p_w = pos;
     } else {
         float l2x, l2y;
-        lane_2d(ln, 0, SD_L2, l2x, l2y);
+        lane_2d(sc, ln, SD_L2, l2x, l2y);
         f3 p_l = xf_point(light->inv, ln.bsdf.p);
         f3 p_sampled, normal;
         geom_sample(light, p_l, l2x, l2y, p_sampled, normal);
@@ -157,56 +153,57 @@ TR_DEV uint32_t shade_extend(const DevScene& sc, Lane& ln, const HitRec& rec, Co
     return light->kind == TRAY_INST_POINT_EMITTER ? WANT_PATH : WANT_MIS;
 }
 
-// After the PH_SHADOW ray: rest of the light half of estimate_direct (mod.rs:127-139)
-TR_DEV uint32_t shade_shadow(const DevScene& sc, Lane& ln, bool occluded) {
+// BSDF query stage: the one place where BSDF::eval / BSDF::pdf run. Three kinds of query reach it:
+//   WANT_LIGHT  light half of estimate_direct after an unoccluded shadow ray (mod.rs:127-139)
+//   WANT_MIS    BSDF half of estimate_direct (mod.rs:141-153), may queue the PH_MIS ray
+//   WANT_PATH   path continuation (path.rs:82-115), queues the PH_EXTEND ray or ends the sample
+// Returns the follow-up query, or WANT_NONE once a ray is queued / the sample is finished.
+TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
+    const bool is_light = want == WANT_LIGHT, mis = want == WANT_MIS;
+    const uint32_t flags = want == WANT_PATH ? BX_ALL : BX_NON_SPECULAR;
     const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
     const bool delta = light->kind == TRAY_INST_POINT_EMITTER;
-    if (!occluded) {
-        f3 f = bsdf_eval(ln.bsdf, ln.w_o, ln.wi_l, BX_NON_SPECULAR);
+    SampleHead h;
+    if (is_light) {
+        h.wi_world = ln.wi_l; h.f = mk(0.0f, 0.0f, 0.0f); h.pdf = 0.0f; h.sampled_type = 0u;
+        h.need_eval = true; h.need_pdf = !delta;
+    } else {
+        float u0, u1;
+        lane_2d(sc, ln, mis ? SD_B2 : SD_P2, u0, u1);
+        float one_d = lane_1d(sc, ln, mis ? SD_B1 : SD_P1);
+        h = bsdf_sample_head(ln.bsdf, ln.w_o, flags, u0, u1, one_d);
+    }
+    if (h.need_eval) h.f = bsdf_eval(ln.bsdf, ln.w_o, h.wi_world, flags);
+    if (h.need_pdf) h.pdf = bsdf_pdf(ln.bsdf, ln.w_o, h.wi_world, flags);
+    const f3 f = h.f, w_i = h.wi_world;
+    const float pdf = h.pdf;
+    if (is_light) {
         if (!is_black(f)) {
             if (delta) {
                 ln.direct = f * ln.li * fabsf(dot(ln.wi_l, ln.bsdf.n)) / ln.pdf_l;
             } else {
-                float pdf_bsdf = bsdf_pdf(ln.bsdf, ln.w_o, ln.wi_l, BX_NON_SPECULAR);
-                float w = power_heuristic(1.0f, ln.pdf_l, 1.0f, pdf_bsdf);
+                float w = power_heuristic(1.0f, ln.pdf_l, 1.0f, pdf);
                 ln.direct = f * ln.li * fabsf(dot(ln.wi_l, ln.bsdf.n)) * w / ln.pdf_l;
             }
         }
+        return delta ? WANT_PATH : WANT_MIS;
     }
-    return delta ? WANT_PATH : WANT_MIS;
-}
-
-// BSDF sampling stage shared by the BSDF half of estimate_direct (WANT_MIS, mod.rs:141-153) and the
-// path continuation (WANT_PATH, path.rs:82-115). Returns the follow-up WANT_* (WANT_MIS lanes that
-// produce no ray fall through to WANT_PATH) or WANT_NONE once a ray has been queued / the path ended.
-TR_DEV uint32_t sample_stage(const DevScene& sc, Lane& ln, uint32_t want) {
-    const bool mis = want == WANT_MIS;
-    float u0, u1;
-    lane_2d(ln, mis ? 1 : 2, mis ? SD_B2 : SD_P2, u0, u1);
-    float one_d = lane_1d(ln, mis ? 4 : 5, mis ? SD_B1 : SD_P1);
-    f3 w_i;
-    float pdf;
-    uint32_t sampled_type;
-    f3 f = bsdf_sample(ln.bsdf, ln.w_o, mis ? BX_NON_SPECULAR : BX_ALL, u0, u1, one_d, w_i, pdf, sampled_type);
     if (mis) {
         if (pdf > 0.0f && !is_black(f)) {
             float w = 1.0f;
-            if (!(sampled_type & BX_SPECULAR)) {
+            if (!(h.sampled_type & BX_SPECULAR)) {
                 // Light::pdf (emitter.rs:193-203)
-                const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
                 f3 p_l = xf_point(light->inv, ln.bsdf.p);
                 f3 wl = normalized(xf_vector(light->inv, w_i));
                 float pl = geom_pdf(light, p_l, wl);
                 if (pl == 0.0f) return WANT_PATH;   // `return direct_light` (mod.rs:146-148)
                 w = power_heuristic(1.0f, pdf, 1.0f, pl);
             }
-            // contribution f * li * |cos| * w / pdf with li known only after the ray (mod.rs:163-165)
-            float c = fabsf(dot(w_i, ln.bsdf.n));
-            ln.mis_weight = mk(f.x, f.y, f.z);
+            // direct += f * li * |cos| * w / pdf_bsdf once li is known (mod.rs:163-165): keep the factors
+            ln.mis_weight = f;
+            ln.li = mk(fabsf(dot(w_i, ln.bsdf.n)), w, 0.0f);
+            ln.pdf_l = pdf;
             ln.ray.o = ln.bsdf.p; ln.ray.d = w_i; ln.ray.min_t = 0.001f; ln.ray.max_t = TR_INF;
-            // keep the reference's evaluation order f * li * c * w / pdf: store the factors, apply in shade_mis
-            ln.pdf_l = pdf;      // reuse: pdf_bsdf
-            ln.li = mk(c, w, 0.0f);
             ln.phase = PH_MIS;
             return WANT_NONE;
         }
@@ -215,7 +212,7 @@ TR_DEV uint32_t sample_stage(const DevScene& sc, Lane& ln, uint32_t want) {
     // path.rs:80-117
     ln.illum = ln.illum + ln.throughput * ln.direct;
     if (is_black(f) || pdf == 0.0f) { ln.phase = PH_NEW; return WANT_NONE; }
-    ln.specular_bounce = (sampled_type & BX_SPECULAR) != 0u;
+    ln.specular_bounce = (h.sampled_type & BX_SPECULAR) != 0u;
     ln.throughput = ln.throughput * f * fabsf(dot(w_i, ln.bsdf.n)) / pdf;
     if (ln.bounce > sc.min_depth) {   // quirk Q2
         float cont_prob = fmaxf(0.5f, luminance(ln.throughput));
@@ -239,19 +236,19 @@ TR_DEV void lane_step(const DevScene& sc, Lane& ln, bool hit, const HitRec& rec,
         if (!hit) { ln.phase = PH_NEW; return; }   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
         want = shade_extend(sc, ln, rec, cnt);
     } else if (ln.phase == PH_SHADOW) {
-        want = shade_shadow(sc, ln, hit);
-    } else {   // PH_MIS
-        // direct += f * li * |cos| * w / pdf_bsdf, factors in the reference's order (mod.rs:163-165)
-        if (hit && rec.inst == ln.light_inst) {
+        const bool delta = sc.instances[ln.light_inst].kind == TRAY_INST_POINT_EMITTER;
+        want = !hit ? WANT_LIGHT : (delta ? WANT_PATH : WANT_MIS);   // occluded: skip the light half
+    } else {   // PH_MIS: direct += f * li * |cos| * w / pdf_bsdf, factors in the reference's order (mod.rs:154-165)
+        if (hit && rec.inst == ln.light_inst) {   // same emitter object (mod.rs:157-160)
             const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
-            Hit h = finish_hit(sc, ln.ray, rec);
-            f3 li2 = emitter_radiance(light, -ln.ray.d, h.ng);
+            f3 ng = finish_hit_ng(sc, ln.ray, rec);
+            f3 li2 = emitter_radiance(light, -ln.ray.d, ng);
             if (!is_black(li2)) ln.direct = ln.direct + ln.mis_weight * li2 * ln.li.x * ln.li.y / ln.pdf_l;
         }
         want = WANT_PATH;
     }
-    // at most two passes: WANT_MIS may fall through to WANT_PATH
-    for (int pass = 0; pass < 2 && want != WANT_NONE; ++pass) want = sample_stage(sc, ln, want);
+    // at most three passes: WANT_LIGHT -> WANT_MIS -> WANT_PATH
+    for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) want = query_stage(sc, ln, want);
 }
 
 TR_DEV f3 lane_result(const Lane& ln) {   // per-sample clamp (multithreaded.rs:98-99, quirk Q3)

@@ -146,22 +146,26 @@ TR_DEV uint32_t permute(uint32_t i, uint32_t l, uint32_t p) {
     } while (i >= l);
     return (i + p) % l;
 }
-// Fisher-Yates over [0, n), n <= 16, nibble-packed: nibble k of the result is the source index that
-// ends up at position k. Same draw schedule as the oracle's shuffle_small.
-TR_DEV uint64_t shuffle_small(uint32_t key, uint32_t n) {
-    uint64_t perm = 0xFEDCBA9876543210ull;
-    uint32_t word = 0;
-    for (uint32_t i = n - 1, k = 0; i >= 1 && n > 0; --i, ++k) {
-        if ((k & 1u) == 0) word = draw(key, k >> 1);
+// Entry b of the Fisher-Yates shuffle of [0, n) defined by the oracle's shuffle_small(key, n)
+// (i from n-1 down to 1, j = (r16 * (i + 1)) >> 16 with r16 the 16-bit fields of draw(key, k >> 1),
+// k = n-1-i), WITHOUT materialising the array: position b is final after step i = b, so its content
+// is found by following one element backwards through steps b, b+1, .., n-1. Costs n - max(b, 1)
+// compare/select steps instead of keeping six packed permutations in registers for the whole path.
+TR_DEV uint32_t shuffle_entry(uint32_t key, uint32_t n, uint32_t b) {
+    uint32_t q = b;
+    uint32_t word = 0u;
+    uint32_t i = b > 0u ? b : 1u;
+    uint32_t k = n - 1u - i;                       // draw counter of step i, decreasing as i grows
+    if (i < n && (k & 1u) == 0u) word = draw(key, k >> 1);   // an even k shares its word with k + 1, which is not visited
+    for (; i < n; ++i, --k) {
+        if ((k & 1u) != 0u) word = draw(key, k >> 1);        // first use of this word (odd k comes before even k - 1)
         uint32_t r16 = (k & 1u) ? (word >> 16) : (word & 0xffffu);
         uint32_t j = (r16 * (i + 1u)) >> 16;
-        uint32_t si = i * 4u, sj = j * 4u;
-        uint64_t x = ((perm >> si) ^ (perm >> sj)) & 0xFull;
-        perm ^= (x << si) | (x << sj);
+        uint32_t qn = q == i ? j : (q == j ? i : q);
+        q = qn;
     }
-    return perm;
+    return q;
 }
-TR_DEV uint32_t perm_at(uint64_t perm, uint32_t k) { return (uint32_t)(perm >> (k * 4u)) & 0xFu; }
 
 // ---- sampler/ld.rs:91-119
 TR_DEV float u24_to_unit(uint32_t v) { return fminf((float)((v >> 8) & 0xffffffu) / 16777216.0f, 1.0f - kEps); }

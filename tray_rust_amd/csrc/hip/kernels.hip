@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -26,6 +27,12 @@ namespace trayh { void set_error(const std::string& msg); }
 using trayh::set_error;
 using namespace tr;
 
+#ifndef TR_MIN_WAVES
+#define TR_MIN_WAVES 3
+#endif
+#ifndef TR_REGEN_MIN
+#define TR_REGEN_MIN 8
+#endif
 #define WIN_MAX 17          // 8 + 2*4 + 1 window columns/rows
 #define WIN_STRIDE 24       // row stride in floats: 4 rows of 8 lanes land on 32 distinct banks
 #define WIN_PLANE (WIN_MAX * WIN_STRIDE)
@@ -62,14 +69,80 @@ __device__ __forceinline__ void film_splat(const DevScene& sc, float* __restrict
     }
 }
 
+// Row-binned film (filter_h == 2, separable table). With inv_h = 1/2 the y table index of pixel row
+// iy, min(int(|iy - img_y| * 8), 15), only depends on which eighth of its pixel the sample lies in
+// (class cy = floor((img_y - py) * 8)), so the y half of the filter can be applied once per
+// (pixel row, class) instead of once per sample: a sample adds table_x[fx] * rgb to 8-9 columns of
+// rowbin[py][cy] (36 LDS atomics instead of 324), and at the end of the tile every bin is spread
+// over its 8-9 rows with table_y. Samples exactly on a class boundary (img_y * 8 integral, about
+// 1 in 1000) take the direct path, which is RenderTarget::write verbatim. Products are grouped as
+// ty * sum(tx * c) instead of sum((tx * ty) * c): same real number, last-bit rounding differs.
+#define ROW_W WIN_MAX
+#define ROWBIN_SIZE (8 * 8 * ROW_W * 4)
+__device__ __forceinline__ void film_splat_rows(const DevScene& sc, float* __restrict__ s_rowbin, const float* __restrict__ s_tx,
+                                                float* __restrict__ s_win, const float* __restrict__ s_table,
+                                                int x0, int y0, int py_l, float sx, float sy, f3 c) {
+    const float img_x = sx - 0.5f, img_y = sy - 0.5f;
+    const float e8 = (img_y - (float)(y0 + py_l)) * 8.0f;   // exact in f32
+    const float fl8 = floorf(e8);
+    if (e8 == fl8 || fl8 < -4.0f || fl8 > 3.0f) { film_splat(sc, s_win, s_table, x0, y0, sx, sy, c); return; }
+    const int cy = (int)fl8 + 4;
+    const int fpw = sc.fpw;
+    const int xr0 = max(x0 - fpw, 0), xr1 = min(x0 + 8 + fpw, (int)sc.width - 1);
+    const int bx = (int)floorf(img_x);
+    const int ix_lo = max(xr0, bx - fpw), ix_hi = min(xr1, bx + fpw + 1);
+    const int wx0 = x0 - fpw;
+    float* __restrict__ row = s_rowbin + (py_l * 8 + cy) * ROW_W * 4;
+    for (int ix = ix_lo; ix <= ix_hi; ++ix) {
+        float fx = fabsf((float)ix - img_x) * sc.inv_w;
+        if (fx > sc.filter_w) continue;
+        int fx_idx = min((int)(fx * (float)TRAY_FILTER_TABLE_SIZE), TRAY_FILTER_TABLE_SIZE - 1);
+        float wx = s_tx[fx_idx];
+        float* __restrict__ o = row + (ix - wx0) * 4;
+        atomicAdd(o + 0, wx * c.x);
+        atomicAdd(o + 1, wx * c.y);
+        atomicAdd(o + 2, wx * c.z);
+        atomicAdd(o + 3, wx);
+    }
+}
+// Spread the row bins of a finished tile over the LDS window (all threads of the workgroup).
+__device__ __forceinline__ void film_resolve_rows(const DevScene& sc, const float* __restrict__ s_rowbin, const float* __restrict__ s_ty,
+                                                  float* __restrict__ s_win, int y0, uint32_t tid) {
+    const int fph = sc.fph;
+    const int yr0 = max(y0 - fph, 0), yr1 = min(y0 + 8 + fph, (int)sc.height - 1);
+    const int wy0 = y0 - fph;
+    for (int i = (int)tid; i < 8 * 8 * ROW_W; i += TR_BLOCK) {
+        const float* __restrict__ b = s_rowbin + i * 4;
+        const float r = b[0], g = b[1], bl = b[2], w = b[3];
+        if (r == 0.0f && g == 0.0f && bl == 0.0f && w == 0.0f) continue;
+        const int col = i % ROW_W, cyi = (i / ROW_W) & 7, py_l = i / (ROW_W * 8);
+        const int c = cyi - 4;   // samples of this bin have (img_y - py) * 8 strictly inside (c, c + 1)
+        for (int ky = -4; ky <= 4; ++ky) {
+            if ((ky == -4 && c >= 0) || (ky == 4 && c < 0)) continue;   // |iy - img_y| <= 4 px
+            const int iy = y0 + py_l + ky;
+            if (iy < yr0 || iy > yr1) continue;
+            const int d8 = 8 * ky - c;                       // floor(|iy - img_y| * 8)
+            const int fy_idx = min(d8 > 0 ? d8 - 1 : -d8, TRAY_FILTER_TABLE_SIZE - 1);
+            const float wy = s_ty[fy_idx];
+            const int o = (iy - wy0) * WIN_STRIDE + col;
+            atomicAdd(&s_win[o], wy * r);
+            atomicAdd(&s_win[o + WIN_PLANE], wy * g);
+            atomicAdd(&s_win[o + 2 * WIN_PLANE], wy * bl);
+            atomicAdd(&s_win[o + 3 * WIN_PLANE], wy * w);
+        }
+    }
+}
+
 // Work item w (0 <= w < n_work) maps to queue entry (w / chunk) * chunk_stride * chunk + (w % chunk):
 // contiguous ranges use chunk_stride = 1; multi-GPU sharding interleaves chunks round-robin.
-__global__ __launch_bounds__(TR_BLOCK) void k_path_tiles(const DevScene* __restrict__ scp, const uint2* __restrict__ tiles, uint32_t tile_count,
+__global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const DevScene* __restrict__ scp, const uint2* __restrict__ tiles, uint32_t tile_count,
                                                          uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf,
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ counter,
                                                          DevStats* __restrict__ stats) {
     __shared__ float s_win[4 * WIN_PLANE];
     __shared__ float s_table[TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE];
+    __shared__ float s_rowbin[ROWBIN_SIZE];
+    __shared__ float s_tx[TRAY_FILTER_TABLE_SIZE], s_ty[TRAY_FILTER_TABLE_SIZE];
     __shared__ uint32_t s_stack[TR_STACK * TR_BLOCK];
     __shared__ uint32_t s_tile;
     const DevScene& sc = *scp;
@@ -77,6 +150,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_path_tiles(const DevScene* __restr
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     uint32_t* const my_stack = s_stack + tid;
     s_table[tid] = sc.filter_table[tid];
+    if (tid < TRAY_FILTER_TABLE_SIZE) { s_tx[tid] = sc.filter_x[tid]; s_ty[tid] = sc.filter_y[tid]; }
+    const bool film_rows = sc.film_rows != 0u;
     Counters cnt;
     cnt.rays = 0; cnt.vertices = 0;
     uint32_t n_samples = 0;
@@ -84,6 +159,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_path_tiles(const DevScene* __restr
         __syncthreads();   // previous tile fully flushed
         if (tid == 0) s_tile = atomicAdd(counter, 1u);
         for (uint32_t i = tid; i < 4 * WIN_PLANE; i += TR_BLOCK) s_win[i] = 0.0f;
+        if (film_rows)
+            for (uint32_t i = tid; i < ROWBIN_SIZE; i += TR_BLOCK) s_rowbin[i] = 0.0f;
         __syncthreads();
         const uint32_t ti = s_tile;
         if (ti >= tile_count) break;
@@ -99,32 +176,47 @@ __global__ __launch_bounds__(TR_BLOCK) void k_path_tiles(const DevScene* __restr
         ln.phase = PH_NEW;
         ln.illum = mk(0.0f, 0.0f, 0.0f);
         for (;;) {
-            if (ln.phase == PH_NEW) {
-                if (pending) {
-                    film_splat(sc, s_win, s_table, x0, y0, sx, sy, lane_result(ln));
-                    pending = false;
-                }
-                if (s_next < spp) {
-                    float t;
-                    pixel_sample(pix, s_next, spp, px, py, sx, sy, t);
-                    lane_start_sample(sc, ln, camera_ray(sc, sx, sy, t), key_sample(pix.kp, s_next));
-                    s_next += TR_BLOCK / 64;
-                    ++n_samples;
-                    pending = true;
-                } else {
-                    ln.phase = PH_DONE;
+            // Regeneration is batched: finished lanes wait (masked) until at least TR_REGEN_MIN lanes of the
+            // wave are idle or nothing else is running, so the splat + sampler set-up code runs with many
+            // lanes active instead of once per iteration for the one or two lanes that just finished.
+            const bool is_new = ln.phase == PH_NEW;
+            const bool running = ln.phase != PH_NEW && ln.phase != PH_DONE;
+            const unsigned long long new_mask = __ballot(is_new);
+            if (new_mask != 0ull && (__popcll(new_mask) >= TR_REGEN_MIN || !__any(running))) {
+                if (is_new) {
+                    if (pending) {
+                        if (film_rows) film_splat_rows(sc, s_rowbin, s_tx, s_win, s_table, x0, y0, (int)(lane >> 3), sx, sy, lane_result(ln));
+                        else film_splat(sc, s_win, s_table, x0, y0, sx, sy, lane_result(ln));
+                        pending = false;
+                    }
+                    if (s_next < spp) {
+                        float t;
+                        pixel_sample(pix, s_next, spp, px, py, sx, sy, t);
+                        lane_start_sample(sc, ln, camera_ray(sc, sx, sy, t), key_sample(pix.kp, s_next));
+                        s_next += TR_BLOCK / 64;
+                        ++n_samples;
+                        pending = true;
+                    } else {
+                        ln.phase = PH_DONE;
+                    }
                 }
             }
-            const bool active = ln.phase != PH_DONE;
-            if (!__any(active)) break;
+            const bool active = ln.phase != PH_NEW && ln.phase != PH_DONE;
+            if (!__any(active)) {
+                if (!__any(ln.phase == PH_NEW)) break;   // every lane is PH_DONE
+                continue;                                 // idle lanes get regenerated on the next pass
+            }
             if (active) {
                 cnt.rays++;
-                HitRec rec;
-                bool hit = trace(sc, my_stack, ln.ray, ln.phase == PH_SHADOW, rec);
-                lane_step(sc, ln, hit, rec, cnt);
+                TraceResult tr_ = trace(scp, my_stack, ln.ray, ln.phase == PH_SHADOW);
+                lane_step(sc, ln, tr_.hit, tr_.rec, cnt);
             }
         }
         __syncthreads();
+        if (film_rows) {
+            film_resolve_rows(sc, s_rowbin, s_ty, s_win, y0, tid);
+            __syncthreads();
+        }
         // flush the window: film::Image::add_pixels semantics on the caller's RGBW buffer
         const int wx0 = x0 - sc.fpw, wy0 = y0 - sc.fph;
         const int ww = 8 + 2 * sc.fpw + 1, wh = 8 + 2 * sc.fph + 1;
@@ -160,10 +252,11 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene* __
     r.o = mk(rays[i].o[0], rays[i].o[1], rays[i].o[2]);
     r.d = mk(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
     r.min_t = rays[i].min_t; r.max_t = rays[i].max_t;
-    HitRec rec;
     TrayHit o;
     memset(&o, 0, sizeof o);
-    if (trace(sc, s_stack + threadIdx.x, r, false, rec)) {
+    TraceResult tr_ = trace(scp, s_stack + threadIdx.x, r, false);
+    const HitRec rec = tr_.rec;
+    if (tr_.hit) {
         float uv[2];
         f3 dp_dv;
         Hit h = finish_hit(sc, r, rec, uv, &dp_dv);
@@ -198,9 +291,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
     lane_start_sample(sc, ln, camera_ray(sc, sx, sy, t), key_sample(pix.kp, si[i]));
     while (ln.phase != PH_NEW) {
         cnt.rays++;
-        HitRec rec;
-        bool hit = trace(sc, s_stack + threadIdx.x, ln.ray, ln.phase == PH_SHADOW, rec);
-        lane_step(sc, ln, hit, rec, cnt);
+        TraceResult tr_ = trace(scp, s_stack + threadIdx.x, ln.ray, ln.phase == PH_SHADOW);
+        lane_step(sc, ln, tr_.hit, tr_.rec, cnt);
     }
     f3 c = lane_result(ln);
     float* o = out + (size_t)i * 8;
@@ -353,11 +445,20 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     UP(merl_data, f->merl_data, f->n_merl_floats)
     UP(lights, f->lights, f->n_lights)
     UP(filter_table, &f->film.table[0], TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE)
+    UP(filter_x, &f->film.table_x[0], TRAY_FILTER_TABLE_SIZE)
+    UP(filter_y, &f->film.table_y[0], TRAY_FILTER_TABLE_SIZE)
 #undef UP
     if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
     s->n_materials = f->n_materials;
     d.n_instances = f->n_instances; d.n_lights = f->n_lights; d.min_depth = f->min_depth; d.max_depth = f->max_depth;
-    d.width = f->film.width; d.height = f->film.height; d.frame = f->frame; d.pad = 0;
+    d.width = f->film.width; d.height = f->film.height; d.frame = f->frame;
+    {   // row-binned film needs: separable table, filter_h == 2 (class = eighth of a pixel), consistent factors
+        bool ok = f->film.separable != 0 && f->film.filter_h == 2.0f && f->film.inv_h == 0.5f && f->film.filter_pixel_h == 4;
+        for (int y = 0; ok && y < TRAY_FILTER_TABLE_SIZE; ++y)
+            for (int x = 0; x < TRAY_FILTER_TABLE_SIZE; ++x)
+                if (f->film.table[y * TRAY_FILTER_TABLE_SIZE + x] != f->film.table_x[x] * f->film.table_y[y]) { ok = false; break; }
+        d.film_rows = (ok && !getenv("TRAYHIP_DIRECT_FILM")) ? 1u : 0u;
+    }
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
     d.camera = f->camera;

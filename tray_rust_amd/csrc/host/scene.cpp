@@ -331,9 +331,12 @@ static void load_film(const Json& e, TrayHostScene& s) {   // scene.rs:185-228, 
             float fy = ((float)y + 0.5f) * h / (float)N;
             for (int x = 0; x < N; ++x) {
                 float fx = ((float)x + 0.5f) * w / (float)N;
-                film.table[y * N + x] = mn_weight_1d(2.0f * fx * film.inv_w, b, c) * mn_weight_1d(2.0f * fy * film.inv_h, b, c);
+                film.table_x[x] = mn_weight_1d(2.0f * fx * film.inv_w, b, c);
+                film.table_y[y] = mn_weight_1d(2.0f * fy * film.inv_h, b, c);
+                film.table[y * N + x] = film.table_x[x] * film.table_y[y];
             }
         }
+        film.separable = 1;
     } else if (ty == "gaussian") {   // filter/gaussian.rs
         float alpha = need_f32(f, "alpha", "An alpha parameter is required for the Gaussian filter", "alpha must be a number");
         float ex = std::exp(-alpha * w * w), ey = std::exp(-alpha * h * h);
@@ -341,9 +344,12 @@ static void load_film(const Json& e, TrayHostScene& s) {   // scene.rs:185-228, 
             float fy = ((float)y + 0.5f) * h / (float)N;
             for (int x = 0; x < N; ++x) {
                 float fx = ((float)x + 0.5f) * w / (float)N;
-                film.table[y * N + x] = std::fmax(0.0f, std::exp(-alpha * fx * fx) - ex) * std::fmax(0.0f, std::exp(-alpha * fy * fy) - ey);
+                film.table_x[x] = std::fmax(0.0f, std::exp(-alpha * fx * fx) - ex);
+                film.table_y[y] = std::fmax(0.0f, std::exp(-alpha * fy * fy) - ey);
+                film.table[y * N + x] = film.table_x[x] * film.table_y[y];
             }
         }
+        film.separable = 1;
     } else {
         fail(TRAY_E_PARSE, "Unrecognized filter type " + ty + "!");
     }
