@@ -1,16 +1,21 @@
-// Device-side camera, per-sample LD sampler and the Path integrator as a per-lane phase machine.
+// Device-side camera, per-sample LD sampler and the Path integrator, one path vertex per wave step.
 //   Camera::generate_ray            film/camera.rs:150-157
 //   LowDiscrepancy::get_samples*    sampler/ld.rs:33-64 (draws replaced by TRAY-CBRNG)
 //   Path::illumination              integrator/path.rs:45-120
 //   sample_one_light/estimate_direct integrator/mod.rs:106-169
 //   Light for Emitter, OcclusionTester  geometry/emitter.rs:164-203, light/mod.rs:14-39
 //
-// The reference recurses Path::illumination -> estimate_direct -> Scene::intersect three times per
-// path vertex. Here every lane is a small state machine whose step is "trace ONE ray, then process
-// the answer": PH_EXTEND (camera / continuation ray), PH_SHADOW (occlusion ray of the light sample),
-// PH_MIS (BSDF-sampled ray of estimate_direct). All lanes of a wave therefore meet in the same
-// traversal code whatever stage of the reference's control flow they are in; the arithmetic and the
-// order of every evaluation are the reference's.
+// Wave-synchronous schedule. Every live lane of a wave advances by exactly one path vertex per step,
+// and the step is cut into three stages that all lanes enter together:
+//   stage A  trace the camera / continuation ray           -> vertex_begin  (path.rs:69-79, mod.rs:106-127)
+//   stage B  trace the light sample's occlusion ray        -> BSDF queries  (mod.rs:127-153, path.rs:84-110)
+//   stage C  trace the BSDF-sampled ray of estimate_direct -> vertex_end    (mod.rs:154-166, path.rs:82)
+// so the divergent parts of the reference's control flow (which lobe, which light geometry, whether a
+// ray exists at all) never put lanes into different stages, and the one traversal code site is entered
+// by all lanes that have a ray of that kind. The only re-ordering w.r.t. the reference: the path
+// continuation is sampled (stage B) before the BSDF-sampled light ray is traced (stage C). Both only
+// read the vertex; `illum += throughput * direct` still happens after the full estimate_direct value is
+// known and with the pre-update throughput, so every float operation and its operands are unchanged.
 #pragma once
 #include "dev_bsdf.h"
 
@@ -30,21 +35,11 @@ TR_DEV Ray camera_ray(const DevScene& sc, float px, float py, float time) {
 }
 
 // Per-pixel part of the sampler: sub-pixel position and shutter time of sample s
-struct PixelSampler {
-    uint32_t kp, scr_x, scr_y, key_xy, scr_t, key_t;
-};
-TR_DEV PixelSampler pixel_sampler(uint32_t kf, uint32_t pixel_index) {
-    PixelSampler p;
-    p.kp = key_pixel(kf, pixel_index);
-    p.scr_x = draw(p.kp, PD_SCR_X); p.scr_y = draw(p.kp, PD_SCR_Y); p.key_xy = draw(p.kp, PD_PERM_XY);
-    p.scr_t = draw(p.kp, PD_SCR_T); p.key_t = draw(p.kp, PD_PERM_T);
-    return p;
-}
-TR_DEV void pixel_sample(const PixelSampler& p, uint32_t s, uint32_t spp, uint32_t px, uint32_t py, float& x, float& y, float& t) {
-    uint32_t idx = permute(s, spp, p.key_xy);
-    x = van_der_corput(idx, p.scr_x) + (float)px;   // ld.rs:43-46
-    y = sobol(idx, p.scr_y) + (float)py;
-    t = van_der_corput(permute(s, spp, p.key_t), p.scr_t);
+TR_DEV void pixel_sample(uint32_t kp, uint32_t s, uint32_t spp, uint32_t px, uint32_t py, float& x, float& y, float& t) {
+    uint32_t idx = permute(s, spp, draw(kp, PD_PERM_XY));
+    x = van_der_corput(idx, draw(kp, PD_SCR_X)) + (float)px;   // ld.rs:43-46
+    y = sobol(idx, draw(kp, PD_SCR_Y)) + (float)py;
+    t = van_der_corput(permute(s, spp, draw(kp, PD_PERM_T)), draw(kp, PD_SCR_T));
 }
 
 TR_DEV float rr_draw(uint32_t ks, uint32_t bounce) { return (float)(draw(ks, SD_RR + bounce) >> 8) / 16777216.0f; }   // Rng::next_f32
@@ -55,43 +50,44 @@ TR_DEV f3 emitter_radiance(const TrayInstance* __restrict__ in, f3 w, f3 n) {
     return dot(w, n) > 0.0f ? inst_emission(in) : mk(0.0f, 0.0f, 0.0f);
 }
 
-enum : uint32_t { PH_NEW = 0, PH_EXTEND = 1, PH_SHADOW = 2, PH_MIS = 3, PH_DONE = 4 };
+enum : uint32_t {
+    LF_ALIVE = 1u,       // the lane owns an unfinished camera sample
+    LF_SPECULAR = 2u,    // previous bounce sampled a specular lobe
+    LF_SHADOW = 4u,      // stage B has an occlusion ray to trace
+    LF_MIS = 8u,         // stage C has a BSDF-sampled light ray to trace
+    LF_LAST = 16u        // the path ends at this vertex (decided in stage B, applied in stage C)
+};
 enum : uint32_t { WANT_NONE = 0, WANT_LIGHT = 1, WANT_MIS = 2, WANT_PATH = 3 };
 
-// Everything a lane keeps between two traced rays
+// Everything a lane keeps between stages
 struct Lane {
-    Ray ray;               // ray to trace next / traced last
-    uint32_t phase;
+    uint32_t flags;
     uint32_t bounce;       // index of the path vertex being shaded
-    bool specular_bounce;
+    uint32_t ks;           // sample key: scrambles and shuffle entries of the six LD arrays derive from it
+    f3 o, d;               // stage A ray: camera ray, or continuation from the previous vertex
     f3 throughput, illum;
     f3 first_ng;           // hit.dg.ng of the camera ray's hit (quirk Q1)
-    // shading context of the current vertex (BSDF::new)
-    Bsdf bsdf;
+    Bsdf bsdf;             // shading context of the current vertex (BSDF::new)
     f3 w_o;
-    // light sample waiting for its occlusion ray (PH_SHADOW)
     uint32_t light_inst;
-    f3 li, wi_l;
+    f3 li, wi_l;           // light sample (stage B)           | stage C: li = (|cos|, mis weight, pdf_bsdf)
     float pdf_l;
-    f3 direct;             // direct_light of estimate_direct, accumulated over the light / BSDF halves
-    f3 mis_weight;         // f * |cos| * w / pdf_bsdf of the BSDF-sampled half (PH_MIS)
-    // per camera sample LD arrays (path.rs:48-60): only the sample key is kept; scrambles and
-    // shuffle entries are re-derived from it when a bounce needs them
-    uint32_t ks;
+    f3 aux_d;              // stage B: occlusion segment p_w - p | stage C: BSDF-sampled direction
+    f3 direct;             // direct_light of estimate_direct
+    f3 mis_f;              // f of the BSDF half (stage C)
+    f3 t_vertex;           // throughput at this vertex, kept for `illum += throughput * direct`
 };
 
-TR_DEV void lane_start_sample(const DevScene& sc, Lane& ln, const Ray& cam_ray, uint32_t ks) {
-    ln.ray = cam_ray;
-    ln.phase = PH_EXTEND;
+TR_DEV void lane_start_sample(Lane& ln, const Ray& cam_ray, uint32_t ks) {
+    ln.flags = LF_ALIVE;
     ln.bounce = 0u;
-    ln.specular_bounce = false;
+    ln.ks = ks;
+    ln.o = cam_ray.o; ln.d = cam_ray.d;
     ln.throughput = mk(1.0f, 1.0f, 1.0f);
     ln.illum = mk(0.0f, 0.0f, 0.0f);
-    ln.ks = ks;
-    (void)sc;
 }
 
-// sample_02 / van_der_corput of array `a` at the current bounce (ld.rs:54-64, 91-93)
+// sample_02 / van_der_corput of one LD array at the current bounce (ld.rs:54-64, 91-93)
 TR_DEV void lane_2d(const DevScene& sc, const Lane& ln, uint32_t dim, float& u0, float& u1) {
     uint32_t idx = shuffle_entry(draw(ln.ks, dim + 2u), sc.max_depth + 1u, ln.bounce);
     u0 = van_der_corput(idx, draw(ln.ks, dim));
@@ -101,22 +97,43 @@ TR_DEV float lane_1d(const DevScene& sc, const Lane& ln, uint32_t dim) {
     return van_der_corput(shuffle_entry(draw(ln.ks, dim + 1u), sc.max_depth + 1u, ln.bounce), draw(ln.ks, dim));
 }
 
-// After the PH_EXTEND ray hit something: head of the loop body of Path::illumination (path.rs:69-82)
-// up to the light half of estimate_direct (mod.rs:124-127). Returns WANT_* for the sampling stage.
-TR_DEV uint32_t shade_extend(const DevScene& sc, Lane& ln, const HitRec& rec, Counters& cnt) {
+TR_DEV Ray stage_a_ray(const Lane& ln) {
+    Ray r;
+    r.o = ln.o; r.d = ln.d;
+    r.min_t = ln.bounce == 0u ? 0.0f : 0.001f;   // camera ray (ray.rs:25-27) vs ray.min_t = 0.001 (path.rs:110)
+    r.max_t = TR_INF;
+    return r;
+}
+TR_DEV Ray stage_b_ray(const Lane& ln) {   // OcclusionTester::test_points (light/mod.rs:21-23): unnormalised segment (quirk Q4)
+    Ray r;
+    r.o = ln.bsdf.p; r.d = ln.aux_d; r.min_t = 0.001f; r.max_t = 0.999f;
+    return r;
+}
+TR_DEV Ray stage_c_ray(const Lane& ln) {   // Ray::segment(p, w_i, 0.001, inf) (mod.rs:154)
+    Ray r;
+    r.o = ln.bsdf.p; r.d = ln.aux_d; r.min_t = 0.001f; r.max_t = TR_INF;
+    return r;
+}
+
+// Stage A, after the ray hit: head of the loop body of Path::illumination (path.rs:69-79) and the light
+// sample of estimate_direct (mod.rs:106-127). Sets LF_SHADOW when an occlusion ray has to be traced.
+TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counters& cnt) {
     cnt.vertices++;
-    Hit hit = finish_hit(sc, ln.ray, rec);
+    const Ray ray = stage_a_ray(ln);
+    Hit hit = finish_hit(sc, ray, rec);
     if (ln.bounce == 0u) ln.first_ng = hit.ng;
     const TrayInstance* __restrict__ inst = sc.instances + hit.inst;
-    if (ln.bounce == 0u || ln.specular_bounce) {
+    if (ln.bounce == 0u || (ln.flags & LF_SPECULAR)) {
         if (inst->kind != TRAY_INST_RECEIVER) {
-            f3 w = -ln.ray.d;
+            f3 w = -ln.d;
             ln.illum = ln.illum + ln.throughput * emitter_radiance(inst, w, ln.first_ng);
         }
     }
     ln.bsdf = make_bsdf(sc, hit);
-    ln.w_o = -ln.ray.d;
+    ln.w_o = -ln.d;
     ln.direct = mk(0.0f, 0.0f, 0.0f);
+    ln.t_vertex = ln.throughput;
+    ln.flags &= ~(LF_SHADOW | LF_MIS | LF_LAST);
     // sample_one_light (mod.rs:106-111), no 1/p_select (quirk Q6)
     float l1 = lane_1d(sc, ln, SD_L1);
     float fl = l1 * (float)sc.n_lights;
@@ -145,19 +162,16 @@ TR_DEV uint32_t shade_extend(const DevScene& sc, Lane& ln, const HitRec& rec, Co
         ln.wi_l = xf_vector(light->mat, w_il);
     }
     if (ln.pdf_l > 0.0f && !is_black(ln.li)) {
-        // OcclusionTester::test_points (light/mod.rs:21-23): unnormalised segment (quirk Q4)
-        ln.ray.o = ln.bsdf.p; ln.ray.d = p_w - ln.bsdf.p; ln.ray.min_t = 0.001f; ln.ray.max_t = 0.999f;
-        ln.phase = PH_SHADOW;
-        return WANT_NONE;
+        ln.aux_d = p_w - ln.bsdf.p;
+        ln.flags |= LF_SHADOW;
     }
-    return light->kind == TRAY_INST_POINT_EMITTER ? WANT_PATH : WANT_MIS;
 }
 
-// BSDF query stage: the one place where BSDF::eval / BSDF::pdf run. Three kinds of query reach it:
+// BSDF query: the one place where BSDF::eval / BSDF::pdf run. Three kinds of query reach it:
 //   WANT_LIGHT  light half of estimate_direct after an unoccluded shadow ray (mod.rs:127-139)
-//   WANT_MIS    BSDF half of estimate_direct (mod.rs:141-153), may queue the PH_MIS ray
-//   WANT_PATH   path continuation (path.rs:82-115), queues the PH_EXTEND ray or ends the sample
-// Returns the follow-up query, or WANT_NONE once a ray is queued / the sample is finished.
+//   WANT_MIS    BSDF half of estimate_direct (mod.rs:141-153), may set LF_MIS (ray for stage C)
+//   WANT_PATH   path continuation (path.rs:84-110): next stage A ray, or LF_LAST
+// Returns the follow-up query.
 TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
     const bool is_light = want == WANT_LIGHT, mis = want == WANT_MIS;
     const uint32_t flags = want == WANT_PATH ? BX_ALL : BX_NON_SPECULAR;
@@ -200,55 +214,49 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
                 w = power_heuristic(1.0f, pdf, 1.0f, pl);
             }
             // direct += f * li * |cos| * w / pdf_bsdf once li is known (mod.rs:163-165): keep the factors
-            ln.mis_weight = f;
-            ln.li = mk(fabsf(dot(w_i, ln.bsdf.n)), w, 0.0f);
-            ln.pdf_l = pdf;
-            ln.ray.o = ln.bsdf.p; ln.ray.d = w_i; ln.ray.min_t = 0.001f; ln.ray.max_t = TR_INF;
-            ln.phase = PH_MIS;
-            return WANT_NONE;
+            ln.mis_f = f;
+            ln.li = mk(fabsf(dot(w_i, ln.bsdf.n)), w, pdf);
+            ln.aux_d = w_i;
+            ln.flags |= LF_MIS;
         }
         return WANT_PATH;
     }
-    // path.rs:80-117
-    ln.illum = ln.illum + ln.throughput * ln.direct;
-    if (is_black(f) || pdf == 0.0f) { ln.phase = PH_NEW; return WANT_NONE; }
-    ln.specular_bounce = (h.sampled_type & BX_SPECULAR) != 0u;
+    // path.rs:84-110 (the `illum += throughput * li` of path.rs:82 is applied in vertex_end)
+    if (is_black(f) || pdf == 0.0f) { ln.flags |= LF_LAST; return WANT_NONE; }
+    ln.flags = (h.sampled_type & BX_SPECULAR) ? (ln.flags | LF_SPECULAR) : (ln.flags & ~LF_SPECULAR);
     ln.throughput = ln.throughput * f * fabsf(dot(w_i, ln.bsdf.n)) / pdf;
     if (ln.bounce > sc.min_depth) {   // quirk Q2
         float cont_prob = fmaxf(0.5f, luminance(ln.throughput));
-        if (rr_draw(ln.ks, ln.bounce) > cont_prob) { ln.phase = PH_NEW; return WANT_NONE; }
+        if (rr_draw(ln.ks, ln.bounce) > cont_prob) { ln.flags |= LF_LAST; return WANT_NONE; }
         ln.throughput = ln.throughput / cont_prob;
     }
-    if (ln.bounce == sc.max_depth) { ln.phase = PH_NEW; return WANT_NONE; }
-    ln.ray.o = ln.bsdf.p;
-    ln.ray.d = normalized(w_i);
-    ln.ray.min_t = 0.001f; ln.ray.max_t = TR_INF;
-    ln.bounce = ln.bounce + 1u;
-    ln.phase = PH_EXTEND;
+    if (ln.bounce == sc.max_depth) { ln.flags |= LF_LAST; return WANT_NONE; }
+    ln.o = ln.bsdf.p;
+    ln.d = normalized(w_i);
     return WANT_NONE;
 }
 
-// One step of the machine for a lane whose ray has just been traced. After the call either
-// ln.phase is PH_NEW (sample finished: ln.illum is its radiance) or ln.ray holds the next ray.
-TR_DEV void lane_step(const DevScene& sc, Lane& ln, bool hit, const HitRec& rec, Counters& cnt) {
-    uint32_t want = WANT_NONE;
-    if (ln.phase == PH_EXTEND) {
-        if (!hit) { ln.phase = PH_NEW; return; }   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
-        want = shade_extend(sc, ln, rec, cnt);
-    } else if (ln.phase == PH_SHADOW) {
-        const bool delta = sc.instances[ln.light_inst].kind == TRAY_INST_POINT_EMITTER;
-        want = !hit ? WANT_LIGHT : (delta ? WANT_PATH : WANT_MIS);   // occluded: skip the light half
-    } else {   // PH_MIS: direct += f * li * |cos| * w / pdf_bsdf, factors in the reference's order (mod.rs:154-165)
-        if (hit && rec.inst == ln.light_inst) {   // same emitter object (mod.rs:157-160)
-            const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
-            f3 ng = finish_hit_ng(sc, ln.ray, rec);
-            f3 li2 = emitter_radiance(light, -ln.ray.d, ng);
-            if (!is_black(li2)) ln.direct = ln.direct + ln.mis_weight * li2 * ln.li.x * ln.li.y / ln.pdf_l;
-        }
-        want = WANT_PATH;
+// Stage B after the occlusion ray: all BSDF queries of the vertex
+TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
+    const bool delta = sc.instances[ln.light_inst].kind == TRAY_INST_POINT_EMITTER;
+    uint32_t want = ((ln.flags & LF_SHADOW) && !occluded) ? WANT_LIGHT : (delta ? WANT_PATH : WANT_MIS);
+    for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) want = query_stage(sc, ln, want);   // LIGHT -> MIS -> PATH
+}
+
+// Stage C: tail of the BSDF half of estimate_direct (mod.rs:154-166), then path.rs:82 and the
+// bookkeeping for the next vertex. Returns false when the camera sample is finished.
+TR_DEV bool vertex_end(const DevScene& sc, Lane& ln, bool mis_hit, const HitRec& rec) {
+    if ((ln.flags & LF_MIS) && mis_hit && rec.inst == ln.light_inst) {   // same emitter object (mod.rs:157-160)
+        const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
+        const Ray r = stage_c_ray(ln);
+        f3 ng = finish_hit_ng(sc, r, rec);
+        f3 li2 = emitter_radiance(light, -ln.aux_d, ng);
+        if (!is_black(li2)) ln.direct = ln.direct + ln.mis_f * li2 * ln.li.x * ln.li.y / ln.li.z;
     }
-    // at most three passes: WANT_LIGHT -> WANT_MIS -> WANT_PATH
-    for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) want = query_stage(sc, ln, want);
+    ln.illum = ln.illum + ln.t_vertex * ln.direct;   // path.rs:82
+    if (ln.flags & LF_LAST) return false;
+    ln.bounce = ln.bounce + 1u;
+    return true;
 }
 
 TR_DEV f3 lane_result(const Lane& ln) {   // per-sample clamp (multithreaded.rs:98-99, quirk Q3)

@@ -167,49 +167,56 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
         const uint2 tile = tiles[(ti / chunk) * chunk_stride * chunk + (ti % chunk)];
         const int x0 = (int)tile.x * 8, y0 = (int)tile.y * 8;
         const uint32_t px = (uint32_t)x0 + (lane & 7u), py = (uint32_t)y0 + (lane >> 3);   // Region order: x fastest (ld.rs:47-51)
-        const PixelSampler pix = pixel_sampler(kf, py * sc.width + px);
+        const uint32_t kp = key_pixel(kf, py * sc.width + px);
 
         uint32_t s_next = wave;
         bool pending = false;
         float sx = 0.0f, sy = 0.0f;
         Lane ln;
-        ln.phase = PH_NEW;
+        ln.flags = 0u;
         ln.illum = mk(0.0f, 0.0f, 0.0f);
-        for (;;) {
-            // Regeneration is batched: finished lanes wait (masked) until at least TR_REGEN_MIN lanes of the
-            // wave are idle or nothing else is running, so the splat + sampler set-up code runs with many
-            // lanes active instead of once per iteration for the one or two lanes that just finished.
-            const bool is_new = ln.phase == PH_NEW;
-            const bool running = ln.phase != PH_NEW && ln.phase != PH_DONE;
-            const unsigned long long new_mask = __ballot(is_new);
-            if (new_mask != 0ull && (__popcll(new_mask) >= TR_REGEN_MIN || !__any(running))) {
-                if (is_new) {
-                    if (pending) {
-                        if (film_rows) film_splat_rows(sc, s_rowbin, s_tx, s_win, s_table, x0, y0, (int)(lane >> 3), sx, sy, lane_result(ln));
-                        else film_splat(sc, s_win, s_table, x0, y0, sx, sy, lane_result(ln));
-                        pending = false;
-                    }
-                    if (s_next < spp) {
-                        float t;
-                        pixel_sample(pix, s_next, spp, px, py, sx, sy, t);
-                        lane_start_sample(sc, ln, camera_ray(sc, sx, sy, t), key_sample(pix.kp, s_next));
-                        s_next += TR_BLOCK / 64;
-                        ++n_samples;
-                        pending = true;
-                    } else {
-                        ln.phase = PH_DONE;
-                    }
+        for (;;) {   // one path vertex per live lane and step
+            if (!(ln.flags & LF_ALIVE)) {
+                // the previous sample of this lane is finished: RenderTarget::write it, start the next one
+                if (pending) {
+                    if (film_rows) film_splat_rows(sc, s_rowbin, s_tx, s_win, s_table, x0, y0, (int)(lane >> 3), sx, sy, lane_result(ln));
+                    else film_splat(sc, s_win, s_table, x0, y0, sx, sy, lane_result(ln));
+                    pending = false;
+                }
+                if (s_next < spp) {
+                    float t;
+                    pixel_sample(kp, s_next, spp, px, py, sx, sy, t);
+                    lane_start_sample(ln, camera_ray(sc, sx, sy, t), key_sample(kp, s_next));
+                    s_next += TR_BLOCK / 64;
+                    ++n_samples;
+                    pending = true;
                 }
             }
-            const bool active = ln.phase != PH_NEW && ln.phase != PH_DONE;
-            if (!__any(active)) {
-                if (!__any(ln.phase == PH_NEW)) break;   // every lane is PH_DONE
-                continue;                                 // idle lanes get regenerated on the next pass
-            }
-            if (active) {
-                cnt.rays++;
-                TraceResult tr_ = trace(scp, my_stack, ln.ray, ln.phase == PH_SHADOW);
-                lane_step(sc, ln, tr_.hit, tr_.rec, cnt);
+            if (!__any(ln.flags & LF_ALIVE)) break;
+#pragma nounroll
+            for (int stage = 0; stage < 3; ++stage) {
+                const bool alive = (ln.flags & LF_ALIVE) != 0u;
+                const bool want_ray = alive && (stage == 0 || (stage == 1 && (ln.flags & LF_SHADOW)) || (stage == 2 && (ln.flags & LF_MIS)));
+                TraceResult tr_;
+                tr_.hit = false;
+                tr_.rec.t = 0.0f; tr_.rec.inst = 0xffffffffu; tr_.rec.prim = 0u; tr_.rec.b1 = 0.0f; tr_.rec.b2 = 0.0f;
+                if (__any(want_ray)) {
+                    if (want_ray) {
+                        cnt.rays++;
+                        const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
+                        tr_ = trace(scp, my_stack, r, stage == 1);
+                    }
+                }
+                if (alive) {
+                    if (stage == 0) {
+                        if (tr_.hit) vertex_begin(sc, ln, tr_.rec, cnt);
+                        else ln.flags &= ~LF_ALIVE;   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
+                    } else if (stage == 1) {
+                        vertex_queries(sc, ln, tr_.hit);
+                    } else {
+                        if (!vertex_end(sc, ln, tr_.hit, tr_.rec)) ln.flags &= ~LF_ALIVE;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -284,15 +291,36 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
     if (i >= n) return;
     Counters cnt;
     cnt.rays = 0; cnt.vertices = 0;
-    PixelSampler pix = pixel_sampler(kf, py[i] * sc.width + px[i]);
+    const uint32_t kp = key_pixel(kf, py[i] * sc.width + px[i]);
     float sx, sy, t;
-    pixel_sample(pix, si[i], spp, px[i], py[i], sx, sy, t);
+    pixel_sample(kp, si[i], spp, px[i], py[i], sx, sy, t);
     Lane ln;
-    lane_start_sample(sc, ln, camera_ray(sc, sx, sy, t), key_sample(pix.kp, si[i]));
-    while (ln.phase != PH_NEW) {
-        cnt.rays++;
-        TraceResult tr_ = trace(scp, s_stack + threadIdx.x, ln.ray, ln.phase == PH_SHADOW);
-        lane_step(sc, ln, tr_.hit, tr_.rec, cnt);
+    lane_start_sample(ln, camera_ray(sc, sx, sy, t), key_sample(kp, si[i]));
+    uint32_t* const my_stack = s_stack + threadIdx.x;
+    while (ln.flags & LF_ALIVE) {
+#pragma nounroll
+        for (int stage = 0; stage < 3; ++stage) {
+            const bool alive = (ln.flags & LF_ALIVE) != 0u;
+            const bool want_ray = alive && (stage == 0 || (stage == 1 && (ln.flags & LF_SHADOW)) || (stage == 2 && (ln.flags & LF_MIS)));
+            TraceResult tr_;
+            tr_.hit = false;
+            tr_.rec.t = 0.0f; tr_.rec.inst = 0xffffffffu; tr_.rec.prim = 0u; tr_.rec.b1 = 0.0f; tr_.rec.b2 = 0.0f;
+            if (want_ray) {
+                cnt.rays++;
+                const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
+                tr_ = trace(scp, my_stack, r, stage == 1);
+            }
+            if (alive) {
+                if (stage == 0) {
+                    if (tr_.hit) vertex_begin(sc, ln, tr_.rec, cnt);
+                    else ln.flags &= ~LF_ALIVE;
+                } else if (stage == 1) {
+                    vertex_queries(sc, ln, tr_.hit);
+                } else {
+                    if (!vertex_end(sc, ln, tr_.hit, tr_.rec)) ln.flags &= ~LF_ALIVE;
+                }
+            }
+        }
     }
     f3 c = lane_result(ln);
     float* o = out + (size_t)i * 8;
