@@ -220,21 +220,29 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
     bool any = false, done = false;
     const uint32_t n = sc.n_instances;
     for (uint32_t i = 0; i < n; ++i) {
-        const TrayInstance* __restrict__ in = sc.instances + i;
+        // the instance index is wave-uniform: read the record through the constant address space so the
+        // transform and the geometry parameters arrive as scalar loads (SGPRs), not 64 identical lane loads
+        typedef const __attribute__((address_space(4))) TrayInstance* ConstInst;
+        ConstInst in = (ConstInst)(sc.instances + i);
         const uint32_t kind = in->kind, gt = in->geom_type;
         if (kind == TRAY_INST_POINT_EMITTER) continue;   // emitter.rs:120
+        float inv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) inv[k] = in->inv[k];
+        const float gp0 = in->geom_params[0], gp1 = in->geom_params[1];
+        const uint32_t mesh_id = in->mesh_id;
         if (!done) {
             // Instance::intersect (receiver.rs:29-35): world ray -> object ray by `inv`, direction not renormalised
-            f3 o = xf_point(in->inv, ray.o);
-            f3 d = xf_vector(in->inv, ray.d);
+            f3 o = xf_point(inv, ray.o);
+            f3 d = xf_vector(inv, ray.d);
             float t = max_t;
             bool hit;
             uint32_t prim = 0u;
             float b1 = 0.0f, b2 = 0.0f;
-            if (gt == TRAY_GEOM_RECT) hit = rect_test(in->geom_params[0], in->geom_params[1], o, d, min_t, max_t, t);
-            else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(in->geom_params[0], o, d, min_t, max_t, t);
-            else if (gt == TRAY_GEOM_MESH) hit = mesh_traverse(sc, stack, sc.meshes[in->mesh_id], o, d, min_t, t, any_hit, prim, b1, b2);
-            else hit = disk_test(in->geom_params[0], in->geom_params[1], o, d, min_t, max_t, t);
+            if (gt == TRAY_GEOM_RECT) hit = rect_test(gp0, gp1, o, d, min_t, max_t, t);
+            else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(gp0, o, d, min_t, max_t, t);
+            else if (gt == TRAY_GEOM_MESH) hit = mesh_traverse(sc, stack, sc.meshes[mesh_id], o, d, min_t, t, any_hit, prim, b1, b2);
+            else hit = disk_test(gp0, gp1, o, d, min_t, max_t, t);
             if (hit) {
                 max_t = t;
                 rec.t = t; rec.inst = i; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;

@@ -133,9 +133,70 @@ __device__ __forceinline__ void film_resolve_rows(const DevScene& sc, const floa
     }
 }
 
+// ---- film helpers of the wavefront kernels: bins live in global memory, private to one workgroup
+__device__ __forceinline__ void wg_add(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // stays in this XCD's L2
+}
+// RenderTarget::write of one sample straight into the caller's film (class-boundary samples and
+// non-separable filters): render_target.rs:118-146 verbatim, with device-scope atomics
+__device__ __forceinline__ void film_splat_global(const DevScene& sc, float* __restrict__ rgbw, const float* __restrict__ s_table,
+                                                  int x0, int y0, float sx, float sy, f3 c) {
+    const int fpw = sc.fpw, fph = sc.fph;
+    const int xr0 = max(x0 - fpw, 0), xr1 = min(x0 + 8 + fpw, (int)sc.width - 1);
+    const int yr0 = max(y0 - fph, 0), yr1 = min(y0 + 8 + fph, (int)sc.height - 1);
+    const float img_x = sx - 0.5f, img_y = sy - 0.5f;
+    const int bx = (int)floorf(img_x), by = (int)floorf(img_y);
+    const int ix_lo = max(xr0, bx - fpw), ix_hi = min(xr1, bx + fpw + 1);
+    const int iy_lo = max(yr0, by - fph), iy_hi = min(yr1, by + fph + 1);
+    for (int iy = iy_lo; iy <= iy_hi; ++iy) {
+        float fy = fabsf((float)iy - img_y) * sc.inv_h;
+        if (fy > sc.filter_h) continue;
+        int fy_idx = min((int)(fy * (float)TRAY_FILTER_TABLE_SIZE), TRAY_FILTER_TABLE_SIZE - 1);
+        for (int ix = ix_lo; ix <= ix_hi; ++ix) {
+            float fx = fabsf((float)ix - img_x) * sc.inv_w;
+            if (fx > sc.filter_w) continue;
+            int fx_idx = min((int)(fx * (float)TRAY_FILTER_TABLE_SIZE), TRAY_FILTER_TABLE_SIZE - 1);
+            float weight = s_table[fy_idx * TRAY_FILTER_TABLE_SIZE + fx_idx];
+            float* dst = rgbw + ((size_t)iy * sc.width + ix) * 4;
+            atomicAdd(dst + 0, weight * c.x);
+            atomicAdd(dst + 1, weight * c.y);
+            atomicAdd(dst + 2, weight * c.z);
+            atomicAdd(dst + 3, weight);
+        }
+    }
+}
+__device__ __forceinline__ void film_splat_rows_global(const DevScene& sc, float* __restrict__ bins, const float* __restrict__ s_tx,
+                                                       float* __restrict__ rgbw, const float* __restrict__ s_table,
+                                                       int x0, int y0, int py_l, float sx, float sy, f3 c) {
+    const float img_x = sx - 0.5f, img_y = sy - 0.5f;
+    const float e8 = (img_y - (float)(y0 + py_l)) * 8.0f;   // exact in f32
+    const float fl8 = floorf(e8);
+    if (e8 == fl8 || fl8 < -4.0f || fl8 > 3.0f) { film_splat_global(sc, rgbw, s_table, x0, y0, sx, sy, c); return; }
+    const int cy = (int)fl8 + 4;
+    const int fpw = sc.fpw;
+    const int xr0 = max(x0 - fpw, 0), xr1 = min(x0 + 8 + fpw, (int)sc.width - 1);
+    const int bx = (int)floorf(img_x);
+    const int ix_lo = max(xr0, bx - fpw), ix_hi = min(xr1, bx + fpw + 1);
+    const int wx0 = x0 - fpw;
+    float* __restrict__ row = bins + (py_l * 8 + cy) * ROW_W * 4;
+    for (int ix = ix_lo; ix <= ix_hi; ++ix) {
+        float fx = fabsf((float)ix - img_x) * sc.inv_w;
+        if (fx > sc.filter_w) continue;
+        int fx_idx = min((int)(fx * (float)TRAY_FILTER_TABLE_SIZE), TRAY_FILTER_TABLE_SIZE - 1);
+        float wx = s_tx[fx_idx];
+        float* __restrict__ o = row + (ix - wx0) * 4;
+        wg_add(o + 0, wx * c.x);
+        wg_add(o + 1, wx * c.y);
+        wg_add(o + 2, wx * c.z);
+        wg_add(o + 3, wx);
+    }
+}
+
+#include "wavefront.h"
+
 // Work item w (0 <= w < n_work) maps to queue entry (w / chunk) * chunk_stride * chunk + (w % chunk):
 // contiguous ranges use chunk_stride = 1; multi-GPU sharding interleaves chunks round-robin.
-__global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const DevScene* __restrict__ scp, const uint2* __restrict__ tiles, uint32_t tile_count,
+__global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const DevScene scv, const uint2* __restrict__ tiles, uint32_t tile_count,
                                                          uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf,
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ counter,
                                                          DevStats* __restrict__ stats) {
@@ -145,7 +206,8 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
     __shared__ float s_tx[TRAY_FILTER_TABLE_SIZE], s_ty[TRAY_FILTER_TABLE_SIZE];
     __shared__ uint32_t s_stack[TR_STACK * TR_BLOCK];
     __shared__ uint32_t s_tile;
-    const DevScene& sc = *scp;
+    const DevScene& sc = scv;
+    const DevScene* const scp = &scv;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     uint32_t* const my_stack = s_stack + tid;
@@ -249,10 +311,11 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
 }
 
 // ---- parity / debug kernels: the same device functions, one thread per item -------------------
-__global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene* __restrict__ scp, uint32_t n, const TrayRay* __restrict__ rays,
+__global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene scv, uint32_t n, const TrayRay* __restrict__ rays,
                                                               TrayHit* __restrict__ hits) {
     __shared__ uint32_t s_stack[TR_STACK * TR_BLOCK];
-    const DevScene& sc = *scp;
+    const DevScene& sc = scv;
+    const DevScene* const scp = &scv;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ray r;
@@ -282,11 +345,12 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene* __
 
 // thread_work's inner loop body for individual (pixel, sample) items (multithreaded.rs:94-103),
 // driven through the same lane machine as the tile kernel
-__global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevScene* __restrict__ scp, uint32_t n, const uint32_t* __restrict__ px,
+__global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevScene scv, uint32_t n, const uint32_t* __restrict__ px,
                                                                     const uint32_t* __restrict__ py, const uint32_t* __restrict__ si,
                                                                     uint32_t spp, uint32_t kf, float* __restrict__ out) {
     __shared__ uint32_t s_stack[TR_STACK * TR_BLOCK];
-    const DevScene& sc = *scp;
+    const DevScene& sc = scv;
+    const DevScene* const scp = &scv;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Counters cnt;
@@ -327,9 +391,10 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
     o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = sx; o[4] = sy; o[5] = (float)cnt.vertices; o[6] = (float)cnt.rays; o[7] = 0.0f;
 }
 
-__global__ __launch_bounds__(64) void k_debug_bsdf(const DevScene* __restrict__ scp, uint32_t flags_sel, uint32_t n,
+__global__ __launch_bounds__(64) void k_debug_bsdf(const DevScene scv, uint32_t flags_sel, uint32_t n,
                                                    const float* __restrict__ dirs, const float* __restrict__ u3, float* __restrict__ out) {
-    const DevScene& sc = *scp;
+    const DevScene& sc = scv;
+    const DevScene* const scp = &scv;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // canonical frame: n = +z, dp_du = +x; instance 0 of the (private) scene copy carries the material
@@ -366,6 +431,14 @@ struct TrayDeviceScene {
     uint32_t launches = 0;
     int n_blocks = 0;
     uint32_t n_materials = 0;
+    // wavefront mode (lazily allocated)
+    WfPool pool{nullptr, 0};
+    WfChunk* d_chunks = nullptr;
+    float* d_bins = nullptr;
+    uint32_t* d_wf_counters = nullptr;   // [0] tile counter, [1] tiles done
+    uint32_t* h_done = nullptr;          // pinned host mirror of tiles done
+    uint32_t n_chunks = 0;
+    bool wavefront = true;
 };
 
 static thread_local int g_device = 0;
@@ -414,6 +487,7 @@ void tray_scene_destroy(TrayDeviceScene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (void* p : s->allocs) (void)hipFree(p);
+    if (s->h_done) (void)hipHostFree(s->h_done);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -486,6 +560,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             for (int x = 0; x < TRAY_FILTER_TABLE_SIZE; ++x)
                 if (f->film.table[y * TRAY_FILTER_TABLE_SIZE + x] != f->film.table_x[x] * f->film.table_y[y]) { ok = false; break; }
         d.film_rows = (ok && !getenv("TRAYHIP_DIRECT_FILM")) ? 1u : 0u;
+        if (const char* m = getenv("TRAYHIP_MODE")) s->wavefront = std::string(m) != "mega";
     }
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
@@ -502,9 +577,10 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     const uint32_t* d_counter = nullptr;
     const DevStats* d_stats = nullptr;
     uint32_t zero = 0;
-    DevStats zs{};
+    std::vector<DevStats> zs(WF_STAT_SLOTS);
+    std::memset(zs.data(), 0, zs.size() * sizeof(DevStats));
     if (rc == TRAY_OK) rc = upload(s, &zero, 1, &d_counter);
-    if (rc == TRAY_OK) rc = upload(s, &zs, 1, &d_stats);
+    if (rc == TRAY_OK) rc = upload(s, zs.data(), zs.size(), &d_stats);
     s->d_counter = const_cast<uint32_t*>(d_counter);
     s->d_stats = const_cast<DevStats*>(d_stats);
     if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
@@ -529,6 +605,69 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
 
 static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride,
                         uint32_t spp, uint64_t seed, float* rgbw_dev, void* stream_);
+
+// Wavefront schedule: rounds of six stage kernels over the path pool until every tile is done.
+// The host only polls a "tiles done" word every WF_POLL rounds; kernels of finished chunks exit at once.
+#ifndef WF_SLOTS
+#define WF_SLOTS (4u << 20)
+#endif
+#define WF_POLL 16
+static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride,
+                            uint32_t spp, uint32_t kf, float* rgbw_dev, hipStream_t stream) {
+    if (!s->pool.data) {
+        uint32_t n_slots = WF_SLOTS;
+        if (const char* e = getenv("TRAYHIP_WF_SLOTS")) n_slots = (uint32_t)std::max(256l, atol(e)) / TR_BLOCK * TR_BLOCK;
+        s->n_chunks = n_slots / TR_BLOCK;
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, (size_t)F_COUNT * n_slots * sizeof(float)));
+        s->allocs.push_back(p);
+        s->pool.data = static_cast<float*>(p); s->pool.n_slots = n_slots;
+        HIP_CHECK(hipMalloc(&p, (size_t)s->n_chunks * sizeof(WfChunk)));
+        s->allocs.push_back(p); s->d_chunks = static_cast<WfChunk*>(p);
+        HIP_CHECK(hipMalloc(&p, (size_t)s->n_chunks * ROWBIN_SIZE * sizeof(float)));
+        s->allocs.push_back(p); s->d_bins = static_cast<float*>(p);
+        HIP_CHECK(hipMemset(s->d_bins, 0, (size_t)s->n_chunks * ROWBIN_SIZE * sizeof(float)));
+        HIP_CHECK(hipMalloc(&p, 2 * sizeof(uint32_t)));
+        s->allocs.push_back(p); s->d_wf_counters = static_cast<uint32_t*>(p);
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s->h_done), sizeof(uint32_t), hipHostMallocDefault));
+    }
+    const uint32_t n_chunks = std::min(s->n_chunks, tile_count);
+    const uint32_t n_active = n_chunks * TR_BLOCK;
+    HIP_CHECK(hipMemsetAsync(s->d_wf_counters, 0, 2 * sizeof(uint32_t), stream));
+        {   // chunks start in WF_TILE_NEED with done = 0
+        std::vector<WfChunk> init(n_chunks, WfChunk{WF_TILE_NEED, 0u});
+        HIP_CHECK(hipMemcpyAsync(s->d_chunks, init.data(), (size_t)n_chunks * sizeof(WfChunk), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));   // `init` is pageable host memory
+    }
+    HIP_CHECK(hipEventRecord(s->ev0, stream));
+    const dim3 grid(n_chunks), block(TR_BLOCK);
+    const uint2* tiles = s->d_tiles + tile_start;
+    uint32_t launches = 0;
+    // every chunk needs at most (spp/4 rounded up) samples x (max_depth + 2) rounds per tile, plus one round per tile switch
+    const uint64_t tiles_per_chunk = (tile_count + n_chunks - 1) / n_chunks;
+    const uint64_t max_rounds = tiles_per_chunk * (((uint64_t)spp + 3) / 4 * (s->dev.max_depth + 3) + 4) + 2 * WF_POLL;
+    for (uint32_t round = 0;; ++round) {
+        hipLaunchKernelGGL(k_wf_advance, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
+                           spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats);
+        hipLaunchKernelGGL(k_wf_trace<0>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats);
+        hipLaunchKernelGGL(k_wf_begin, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats);
+        hipLaunchKernelGGL(k_wf_trace<1>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats);
+        hipLaunchKernelGGL(k_wf_query, grid, block, 0, stream, s->dev, s->pool, n_active);
+        hipLaunchKernelGGL(k_wf_trace<2>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats);
+        launches += 6;
+        if (round % WF_POLL == WF_POLL - 1) {
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(s->h_done, s->d_wf_counters + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (*s->h_done >= tile_count) break;
+        }
+        if (round > max_rounds) { set_error("wavefront schedule did not terminate"); return TRAY_E_DEVICE; }
+    }
+    HIP_CHECK(hipEventRecord(s->ev1, stream));
+    s->timing_valid = true;
+    s->launches = launches;
+    return TRAY_OK;
+}
 
 int tray_render_tiles_device(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t spp, uint64_t seed,
                              float* rgbw_dev, void* stream_) {
@@ -561,15 +700,16 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     s->timing_valid = false;
     if (tile_count == 0) { std::fprintf(stderr, "Warning: This block queue is empty!\n"); return TRAY_OK; }   // block_queue.rs:42-44
     HIP_CHECK(hipMemsetAsync(s->d_counter, 0, sizeof(uint32_t), stream));
-    HIP_CHECK(hipMemsetAsync(s->d_stats, 0, sizeof(DevStats), stream));
+    HIP_CHECK(hipMemsetAsync(s->d_stats, 0, WF_STAT_SLOTS * sizeof(DevStats), stream));
     // key_frame on the host (same mixing as the device function)
     auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
     uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
     kf = mix(kf ^ (uint32_t)(seed >> 32));
     kf = mix(kf + s->dev.frame);
+    if (s->wavefront) return launch_wavefront(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
     int blocks = (int)std::min<uint32_t>((uint32_t)s->n_blocks, tile_count);
     HIP_CHECK(hipEventRecord(s->ev0, stream));
-    hipLaunchKernelGGL(k_path_tiles, dim3(blocks), dim3(TR_BLOCK), 0, stream, s->d_dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev,
+    hipLaunchKernelGGL(k_path_tiles, dim3(blocks), dim3(TR_BLOCK), 0, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev,
                        s->d_counter, s->d_stats);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(s->ev1, stream));
@@ -607,8 +747,10 @@ int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t) {
     HIP_CHECK(hipSetDevice(s->device));
     HIP_CHECK(hipEventSynchronize(s->ev1));
     HIP_CHECK(hipEventElapsedTime(&t->render_ms, s->ev0, s->ev1));
+    std::vector<DevStats> all(WF_STAT_SLOTS);
+    HIP_CHECK(hipMemcpy(all.data(), s->d_stats, all.size() * sizeof(DevStats), hipMemcpyDeviceToHost));
     DevStats st{};
-    HIP_CHECK(hipMemcpy(&st, s->d_stats, sizeof st, hipMemcpyDeviceToHost));
+    for (const DevStats& a : all) { st.samples += a.samples; st.vertices += a.vertices; st.rays += a.rays; }
     t->launches = s->launches;
     t->samples = st.samples; t->vertices = st.vertices; t->rays = st.rays;
     return TRAY_OK;
@@ -624,7 +766,7 @@ int tray_debug_intersect(TrayDeviceScene* s, uint32_t n, const TrayRay* rays, Tr
     hipError_t e = hipMalloc(&d_h, n * sizeof(TrayHit));
     if (e == hipSuccess) e = hipMemcpy(d_r, rays, n * sizeof(TrayRay), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_debug_intersect, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, 0, s->d_dev, n, d_r, d_h);
+        hipLaunchKernelGGL(k_debug_intersect, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, 0, s->dev, n, d_r, d_h);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(hits, d_h, n * sizeof(TrayHit), hipMemcpyDeviceToHost);
@@ -654,7 +796,7 @@ int tray_debug_sample_radiance(TrayDeviceScene* s, uint32_t n, const uint32_t* p
         uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
         kf = mix(kf ^ (uint32_t)(seed >> 32));
         kf = mix(kf + s->dev.frame);
-        hipLaunchKernelGGL(k_debug_sample_radiance, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, 0, s->d_dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
+        hipLaunchKernelGGL(k_debug_sample_radiance, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(out, d_out, 8 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
@@ -689,7 +831,7 @@ int tray_debug_bsdf(TrayDeviceScene* s, uint32_t material_id, uint32_t flags, ui
         tmp.instances = d_fake;
         e = hipMemcpy(d_tmp, &tmp, sizeof tmp, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_debug_bsdf, dim3((n + 63) / 64), dim3(64), 0, 0, d_tmp, flags, n, d_dirs, d_u, d_out);
+            hipLaunchKernelGGL(k_debug_bsdf, dim3((n + 63) / 64), dim3(64), 0, 0, tmp, flags, n, d_dirs, d_u, d_out);
             e = hipGetLastError();
         }
     }

@@ -1,0 +1,295 @@
+// Wavefront formulation of the tile worker: the path vertex step of dev_integrator.h cut into
+// stage kernels over an HBM-resident SoA path pool (this is the formulation SURVEY §8(d)'s
+// 368 B / vertex accounting describes).
+//
+//   pool      : F_COUNT f32/u32 fields x N slots, field-major (slot i of field f at pool[f*N + i]) so that
+//               every load / store of a stage kernel is a fully coalesced 256-B wave access
+//   chunk     : 256 consecutive slots = one workgroup = one 8x8 tile at a time (slot k <-> pixel k & 63,
+//               samples (k >> 6), +4, ... exactly like k_path_tiles), pulled from the Morton queue with a
+//               global atomic counter (block_queue.rs:52-59) when the previous tile of the chunk is complete
+//   per round : k_wf_advance (vertex_end of the previous round, film splat of finished samples, tile switch,
+//               path regeneration) -> k_wf_trace<A> -> k_wf_begin -> k_wf_trace<B> -> k_wf_query -> k_wf_trace<C>
+//   film      : per-chunk row bins in global memory (workgroup-private, L2 resident), resolved through an LDS
+//               window and flushed with global f32 atomics once per tile (same arithmetic as k_path_tiles)
+//
+// Each stage kernel only touches the fields it needs, has a small register footprint (no spills, high
+// occupancy) and a single divergent concern. The arithmetic per camera sample is bit-identical to the
+// megakernel's: both call the same device functions.
+#pragma once
+
+namespace tr {
+
+// counters are spread over WF_STAT_SLOTS records (one hot word would serialise 65536 wave atomics per launch)
+#define WF_STAT_SLOTS 1024
+enum : uint32_t {   // flags that only exist between wavefront stages
+    WF_HIT_A = 32u, WF_OCCLUDED = 64u, WF_HIT_C = 128u, WF_INVERTEX = 256u, WF_FINISHED = 512u
+};
+
+enum {
+    F_FLAGS, F_BOUNCE, F_KS, F_SNEXT, F_SX, F_SY,
+    F_O, F_D = F_O + 3, F_T = F_D + 3, F_ILLUM = F_T + 3, F_NG = F_ILLUM + 3,
+    F_REC_T = F_NG + 3, F_REC_INST, F_REC_PRIM, F_REC_B1, F_REC_B2,
+    F_P, F_N = F_P + 3, F_TAN = F_N + 3, F_BITAN = F_TAN + 3, F_MAT = F_BITAN + 3,
+    F_WO, F_LINST = F_WO + 3, F_LI, F_WL = F_LI + 3, F_PDFL = F_WL + 3,
+    F_AUX, F_DIRECT = F_AUX + 3, F_MISF = F_DIRECT + 3, F_TV = F_MISF + 3,
+    F_COUNT = F_TV + 3
+};
+
+struct WfPool {
+    float* __restrict__ data;   // F_COUNT * n_slots dwords
+    uint32_t n_slots;
+};
+struct WfChunk { uint32_t tile, done; };   // tile: index into the work list, WF_TILE_NEED or WF_TILE_IDLE
+enum : uint32_t { WF_TILE_NEED = 0xfffffffeu, WF_TILE_IDLE = 0xffffffffu };
+
+TR_DEV float& pf(const WfPool& p, int f, uint32_t i) { return p.data[(size_t)f * p.n_slots + i]; }
+TR_DEV uint32_t& pu(const WfPool& p, int f, uint32_t i) { return reinterpret_cast<uint32_t*>(p.data)[(size_t)f * p.n_slots + i]; }
+TR_DEV f3 ld3(const WfPool& p, int f, uint32_t i) { return mk(pf(p, f, i), pf(p, f + 1, i), pf(p, f + 2, i)); }
+TR_DEV void st3(const WfPool& p, int f, uint32_t i, f3 v) { pf(p, f, i) = v.x; pf(p, f + 1, i) = v.y; pf(p, f + 2, i) = v.z; }
+
+TR_DEV void ld_bsdf(const DevScene& sc, const WfPool& p, uint32_t i, Bsdf& b) {
+    b.p = ld3(p, F_P, i); b.n = ld3(p, F_N, i); b.tan = ld3(p, F_TAN, i); b.bitan = ld3(p, F_BITAN, i);
+    b.mat = sc.materials + pu(p, F_MAT, i);
+    b.merl_data = sc.merl_data;
+}
+TR_DEV void st_bsdf(const DevScene& sc, const WfPool& p, uint32_t i, const Bsdf& b) {
+    st3(p, F_P, i, b.p); st3(p, F_N, i, b.n); st3(p, F_TAN, i, b.tan); st3(p, F_BITAN, i, b.bitan);
+    pu(p, F_MAT, i) = (uint32_t)(b.mat - sc.materials);
+}
+
+// ---- stage kernels --------------------------------------------------------------------------
+
+// STAGE 0: camera / continuation ray (closest hit) -> rec, WF_HIT_A
+// STAGE 1: occlusion ray of the light sample (any hit) -> WF_OCCLUDED
+// STAGE 2: BSDF-sampled ray of estimate_direct (closest hit) -> rec, WF_HIT_C
+template <int STAGE>
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_trace(const DevScene scv, WfPool pool, uint32_t n_active, DevStats* __restrict__ stats) {
+    const DevScene* scp = &scv;
+    __shared__ uint32_t s_stack[TR_STACK * TR_BLOCK];
+    const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
+    if (i >= n_active) return;
+    uint32_t flags = pu(pool, F_FLAGS, i);
+    const uint32_t need = STAGE == 0 ? LF_ALIVE : (STAGE == 1 ? (LF_ALIVE | WF_INVERTEX | LF_SHADOW) : (LF_ALIVE | WF_INVERTEX | LF_MIS));
+    const bool want = (flags & need) == need;
+    if (!__any(want)) return;
+    if (!want) return;
+    Ray r;
+    if (STAGE == 0) {
+        r.o = ld3(pool, F_O, i); r.d = ld3(pool, F_D, i);
+        r.min_t = pu(pool, F_BOUNCE, i) == 0u ? 0.0f : 0.001f; r.max_t = TR_INF;
+    } else {
+        r.o = ld3(pool, F_P, i); r.d = ld3(pool, F_AUX, i);
+        r.min_t = 0.001f; r.max_t = STAGE == 1 ? 0.999f : TR_INF;
+    }
+    TraceResult t = trace(scp, s_stack + threadIdx.x, r, STAGE == 1);
+    if (STAGE == 1) {
+        flags = t.hit ? (flags | WF_OCCLUDED) : (flags & ~WF_OCCLUDED);
+    } else {
+        const uint32_t bit = STAGE == 0 ? WF_HIT_A : WF_HIT_C;
+        flags = t.hit ? (flags | bit) : (flags & ~bit);
+        if (t.hit) {
+            pf(pool, F_REC_T, i) = t.rec.t; pu(pool, F_REC_INST, i) = t.rec.inst; pu(pool, F_REC_PRIM, i) = t.rec.prim;
+            pf(pool, F_REC_B1, i) = t.rec.b1; pf(pool, F_REC_B2, i) = t.rec.b2;
+        }
+    }
+    pu(pool, F_FLAGS, i) = flags;
+    // one counter update per wave
+    const unsigned long long m = __ballot(1);
+    if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].rays, (unsigned long long)__popcll(m));
+}
+
+// Stage A shading: vertex_begin for the slots whose ray hit, end of the sample for those that missed
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPool pool, uint32_t n_active, DevStats* __restrict__ stats) {
+    const DevScene& sc = scv;
+    const DevScene* const scp = &scv;
+    const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
+    if (i >= n_active) return;
+    uint32_t flags = pu(pool, F_FLAGS, i);
+    if (!(flags & LF_ALIVE)) return;
+    if (!(flags & WF_HIT_A)) {   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
+        pu(pool, F_FLAGS, i) = (flags & ~(LF_ALIVE | WF_INVERTEX)) | WF_FINISHED;
+        return;
+    }
+    Lane ln;
+    ln.flags = flags;
+    ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
+    ln.o = ld3(pool, F_O, i); ln.d = ld3(pool, F_D, i);
+    ln.throughput = ld3(pool, F_T, i); ln.illum = ld3(pool, F_ILLUM, i);
+    ln.first_ng = ld3(pool, F_NG, i);
+    HitRec rec;
+    rec.t = pf(pool, F_REC_T, i); rec.inst = pu(pool, F_REC_INST, i); rec.prim = pu(pool, F_REC_PRIM, i);
+    rec.b1 = pf(pool, F_REC_B1, i); rec.b2 = pf(pool, F_REC_B2, i);
+    Counters cnt;
+    cnt.rays = 0; cnt.vertices = 0;
+    vertex_begin(sc, ln, rec, cnt);
+    pu(pool, F_FLAGS, i) = ln.flags | WF_INVERTEX;
+    st3(pool, F_ILLUM, i, ln.illum);
+    if (ln.bounce == 0u) st3(pool, F_NG, i, ln.first_ng);
+    st_bsdf(sc, pool, i, ln.bsdf);
+    st3(pool, F_WO, i, ln.w_o);
+    pu(pool, F_LINST, i) = ln.light_inst;
+    st3(pool, F_LI, i, ln.li); st3(pool, F_WL, i, ln.wi_l); pf(pool, F_PDFL, i) = ln.pdf_l;
+    if (ln.flags & LF_SHADOW) st3(pool, F_AUX, i, ln.aux_d);
+    st3(pool, F_DIRECT, i, ln.direct);
+    st3(pool, F_TV, i, ln.t_vertex);
+    const unsigned long long m = __ballot(1);
+    if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].vertices, (unsigned long long)__popcll(m));
+}
+
+// Stage B shading: the BSDF queries of the vertex (light half, BSDF half, continuation)
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPool pool, uint32_t n_active) {
+    const DevScene& sc = scv;
+    const DevScene* const scp = &scv;
+    const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
+    if (i >= n_active) return;
+    const uint32_t flags = pu(pool, F_FLAGS, i);
+    if ((flags & (LF_ALIVE | WF_INVERTEX)) != (LF_ALIVE | WF_INVERTEX)) return;
+    Lane ln;
+    ln.flags = flags;
+    ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
+    ln.throughput = ld3(pool, F_T, i);
+    ld_bsdf(sc, pool, i, ln.bsdf);
+    ln.w_o = ld3(pool, F_WO, i);
+    ln.light_inst = pu(pool, F_LINST, i);
+    ln.li = ld3(pool, F_LI, i); ln.wi_l = ld3(pool, F_WL, i); ln.pdf_l = pf(pool, F_PDFL, i);
+    ln.direct = ld3(pool, F_DIRECT, i);
+    ln.o = mk(0.0f, 0.0f, 0.0f); ln.d = mk(0.0f, 0.0f, 0.0f);
+    ln.aux_d = mk(0.0f, 0.0f, 0.0f); ln.mis_f = mk(0.0f, 0.0f, 0.0f);
+    vertex_queries(sc, ln, (flags & WF_OCCLUDED) != 0u);
+    pu(pool, F_FLAGS, i) = ln.flags;
+    st3(pool, F_T, i, ln.throughput);
+    st3(pool, F_DIRECT, i, ln.direct);
+    if (!(ln.flags & LF_LAST)) { st3(pool, F_O, i, ln.o); st3(pool, F_D, i, ln.d); }
+    if (ln.flags & LF_MIS) { st3(pool, F_AUX, i, ln.aux_d); st3(pool, F_MISF, i, ln.mis_f); st3(pool, F_LI, i, ln.li); }
+}
+
+// Round head, one workgroup per chunk: vertex_end of the previous round, film splat of finished samples,
+// tile completion / switch, path regeneration.
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfPool pool, WfChunk* __restrict__ chunks,
+                                                         float* __restrict__ bins, const uint2* __restrict__ tiles, uint32_t tile_count,
+                                                         uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf,
+                                                         float* __restrict__ rgbw, uint32_t* __restrict__ tile_counter,
+                                                         uint32_t* __restrict__ tiles_done, DevStats* __restrict__ stats) {
+    __shared__ float s_win[4 * WIN_PLANE];
+    __shared__ float s_table[TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE];
+    __shared__ float s_tx[TRAY_FILTER_TABLE_SIZE], s_ty[TRAY_FILTER_TABLE_SIZE];
+    __shared__ uint32_t s_tile, s_done, s_fin;
+    const DevScene& sc = scv;
+    const DevScene* const scp = &scv;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, sub = tid >> 6;
+    const uint32_t c = blockIdx.x;
+    const uint32_t i = c * TR_BLOCK + tid;
+    float* __restrict__ my_bins = bins + (size_t)c * ROWBIN_SIZE;
+    if (tid == 0) { s_tile = chunks[c].tile; s_done = chunks[c].done; s_fin = 0u; }
+    s_table[tid] = sc.filter_table[tid];
+    if (tid < TRAY_FILTER_TABLE_SIZE) { s_tx[tid] = sc.filter_x[tid]; s_ty[tid] = sc.filter_y[tid]; }
+    __syncthreads();
+    uint32_t tile_idx = s_tile;
+    if (tile_idx == WF_TILE_IDLE) return;
+    uint32_t flags = pu(pool, F_FLAGS, i);
+    const bool film_rows = sc.film_rows != 0u;
+    if (tile_idx != WF_TILE_NEED) {
+        const uint2 tile = tiles[(tile_idx / chunk) * chunk_stride * chunk + (tile_idx % chunk)];
+        const int x0 = (int)tile.x * 8, y0 = (int)tile.y * 8;
+        // ---- stage C shading of the previous round
+        if ((flags & (LF_ALIVE | WF_INVERTEX)) == (LF_ALIVE | WF_INVERTEX)) {
+            Lane ln;
+            ln.flags = flags;
+            ln.bounce = pu(pool, F_BOUNCE, i);
+            ln.illum = ld3(pool, F_ILLUM, i);
+            ln.direct = ld3(pool, F_DIRECT, i);
+            ln.t_vertex = ld3(pool, F_TV, i);
+            ln.light_inst = pu(pool, F_LINST, i);
+            HitRec rec;
+            rec.t = 0.0f; rec.inst = 0xffffffffu; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
+            if (flags & LF_MIS) {
+                ln.bsdf.p = ld3(pool, F_P, i); ln.aux_d = ld3(pool, F_AUX, i); ln.mis_f = ld3(pool, F_MISF, i); ln.li = ld3(pool, F_LI, i);
+                rec.t = pf(pool, F_REC_T, i); rec.inst = pu(pool, F_REC_INST, i); rec.prim = pu(pool, F_REC_PRIM, i);
+                rec.b1 = pf(pool, F_REC_B1, i); rec.b2 = pf(pool, F_REC_B2, i);
+            }
+            const bool cont = vertex_end(sc, ln, (flags & WF_HIT_C) != 0u, rec);
+            st3(pool, F_ILLUM, i, ln.illum);
+            pu(pool, F_BOUNCE, i) = ln.bounce;
+            flags = ln.flags & ~(WF_INVERTEX | WF_HIT_A | WF_HIT_C | WF_OCCLUDED | LF_SHADOW | LF_MIS | LF_LAST);
+            if (!cont) flags = (flags & ~LF_ALIVE) | WF_FINISHED;
+        }
+        // ---- RenderTarget::write of the samples that finished (here or in k_wf_begin)
+        if (flags & WF_FINISHED) {
+            const f3 il = ld3(pool, F_ILLUM, i);
+            const f3 col = mk(clampf(il.x, 0.0f, 1.0f), clampf(il.y, 0.0f, 1.0f), clampf(il.z, 0.0f, 1.0f));   // quirk Q3
+            const float sx = pf(pool, F_SX, i), sy = pf(pool, F_SY, i);
+            if (film_rows) film_splat_rows_global(sc, my_bins, s_tx, rgbw, s_table, x0, y0, (int)(lane >> 3), sx, sy, col);
+            else film_splat_global(sc, rgbw, s_table, x0, y0, sx, sy, col);
+            flags &= ~WF_FINISHED;
+            atomicAdd(&s_fin, 1u);
+        }
+        __syncthreads();
+        // ---- tile complete: spread the row bins over the window, flush it, take the next tile
+        const uint32_t done = s_done + s_fin;
+        __syncthreads();   // everybody has read s_done / s_fin before thread 0 rewrites them
+        if (done == 64u * spp) {
+            if (film_rows) {
+                for (uint32_t k = tid; k < 4 * WIN_PLANE; k += TR_BLOCK) s_win[k] = 0.0f;
+                __syncthreads();
+                film_resolve_rows(sc, my_bins, s_ty, s_win, y0, tid);
+                __syncthreads();
+                const int wx0 = x0 - sc.fpw, wy0 = y0 - sc.fph;
+                const int ww = 8 + 2 * sc.fpw + 1, wh = 8 + 2 * sc.fph + 1;
+                for (int k = (int)tid; k < ww * wh; k += TR_BLOCK) {
+                    int wy = k / ww, wx = k - wy * ww;
+                    int ix = wx0 + wx, iy = wy0 + wy;
+                    if (ix < 0 || iy < 0 || ix >= (int)sc.width || iy >= (int)sc.height) continue;
+                    int o = wy * WIN_STRIDE + wx;
+                    float a = s_win[o + 3 * WIN_PLANE];
+                    if (a == 0.0f && s_win[o] == 0.0f && s_win[o + WIN_PLANE] == 0.0f && s_win[o + 2 * WIN_PLANE] == 0.0f) continue;
+                    float* dst = rgbw + ((size_t)iy * sc.width + ix) * 4;
+                    atomicAdd(dst + 0, s_win[o]);
+                    atomicAdd(dst + 1, s_win[o + WIN_PLANE]);
+                    atomicAdd(dst + 2, s_win[o + 2 * WIN_PLANE]);
+                    atomicAdd(dst + 3, a);
+                }
+                for (uint32_t k = tid; k < ROWBIN_SIZE; k += TR_BLOCK) my_bins[k] = 0.0f;
+            }
+            if (tid == 0) { atomicAdd(tiles_done, 1u); s_tile = WF_TILE_NEED; s_done = 0u; }
+            tile_idx = WF_TILE_NEED;
+        } else if (tid == 0) {
+            s_done = done;
+        }
+    }
+    __syncthreads();
+    if (tile_idx == WF_TILE_NEED) {
+        if (tid == 0) {
+            uint32_t t = atomicAdd(tile_counter, 1u);
+            s_tile = t < tile_count ? t : WF_TILE_IDLE;
+        }
+        __syncthreads();
+        tile_idx = s_tile;
+        flags = 0u;
+        pu(pool, F_SNEXT, i) = sub;
+    }
+    if (tid == 0) { chunks[c].tile = s_tile; chunks[c].done = s_done; }
+    // ---- path regeneration (multithreaded.rs:90-96)
+    if (tile_idx != WF_TILE_IDLE && !(flags & LF_ALIVE)) {
+        const uint32_t s_next = pu(pool, F_SNEXT, i);
+        if (s_next < spp) {
+            const uint2 tile = tiles[(tile_idx / chunk) * chunk_stride * chunk + (tile_idx % chunk)];
+            const uint32_t px = tile.x * 8u + (lane & 7u), py = tile.y * 8u + (lane >> 3);
+            const uint32_t kp = key_pixel(kf, py * sc.width + px);
+            float sx, sy, t;
+            pixel_sample(kp, s_next, spp, px, py, sx, sy, t);
+            const Ray cam = camera_ray(sc, sx, sy, t);
+            pu(pool, F_SNEXT, i) = s_next + TR_BLOCK / 64;
+            pu(pool, F_BOUNCE, i) = 0u;
+            pu(pool, F_KS, i) = key_sample(kp, s_next);
+            pf(pool, F_SX, i) = sx; pf(pool, F_SY, i) = sy;
+            st3(pool, F_O, i, cam.o); st3(pool, F_D, i, cam.d);
+            st3(pool, F_T, i, mk(1.0f, 1.0f, 1.0f)); st3(pool, F_ILLUM, i, mk(0.0f, 0.0f, 0.0f));
+            flags = LF_ALIVE;
+            const unsigned long long m = __ballot(1);
+            if (lane == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].samples, (unsigned long long)__popcll(m));
+        }
+    }
+    pu(pool, F_FLAGS, i) = flags;
+}
+
+}  // namespace tr
