@@ -118,7 +118,7 @@ enum {
     TRAY_MAT_ROUGH_GLASS = 4, TRAY_MAT_SPECULAR_METAL = 5, TRAY_MAT_MERL = 6
 };
 
-/* Closed lowering of the reference's Material trait objects (src/material/*.rs); every texture
+/* Closed lowering of the reference's Material trait objects (src/material/ *.rs); every texture
  * parameter is a constant (texture/mod.rs:43-76), scalars read from colour textures are luminance.
  *   MATTE          c0 = diffuse,            f0 = roughness            (matte.rs:52-65)
  *   PLASTIC        c0 = diffuse, c1 = gloss, f0 = roughness           (plastic.rs:59-88)

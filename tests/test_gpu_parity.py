@@ -217,3 +217,74 @@ def test_point_light_disk_and_edge_tiles(tmp_path):
     assert scene.flatten(0).contents.n_lights == 3
     assert abs(int(tim.vertices) - int(st.vertices)) <= 2e-4 * st.vertices
     assert rmse(gpu, cpu) < 1e-4
+
+
+# ---- BASELINE.json configs[3] stand-in: one large mesh + a MERL material (scenes.dragon_scene) ----
+@pytest.fixture(scope="module")
+def dragon(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("dragon"))
+    path, n = scenes.write_dragon_assets(d, film=(160, 120, 16), grid=96)
+    return T.Scene.load_file(path)
+
+
+def test_dragon_mesh_intersect_is_bit_exact(dragon):
+    scene = dragon[0]
+    flat = scene.flatten(0)
+    rng = np.random.default_rng(17)
+    rays = O.camera_rays(flat, rng.uniform(0, [160, 120], (60000, 2)))
+    n = 40000   # rays towards the mesh from inside the box: deep traversals, grazing hits
+    o = rng.uniform([-14, 1, -18], [14, 23, 19], (n, 3)); tgt = rng.normal([8.5, 3.7, 1.5], 3.0, (n, 3)); d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    inner = np.concatenate([o, d, np.full((n, 1), 0.001), np.full((n, 1), np.inf), np.zeros((n, 1))], axis=1).astype(np.float32)
+    rays = np.concatenate([rays, inner])
+    a, b = O.intersect(flat, rays), gpu_intersect(scene, rays)
+    assert (a["inst"] == b["inst"]).all() and (a["prim"] == b["prim"]).all()
+    hit = a["inst"] != 0xffffffff
+    assert (a["inst"] == 6).mean() > 0.1
+    for f in ("t", "p", "n", "ng", "u", "v", "dp_du", "dp_dv"):
+        assert (a[f][hit] == b[f][hit]).all(), f
+
+
+def test_merl_bsdf(dragon):
+    scene = dragon[0]
+    flat = scene.flatten(0)
+    mid = [i for i in range(flat.contents.n_materials) if flat.contents.materials[i].kind == 6][0]
+    rng = np.random.default_rng(4)
+    n = 20000
+    dirs = rng.normal(size=(n, 6)).astype(np.float32)
+    dirs[:, :3] /= np.linalg.norm(dirs[:, :3], axis=1, keepdims=True)
+    dirs[:, 3:] /= np.linalg.norm(dirs[:, 3:], axis=1, keepdims=True)
+    u3 = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    dev = scene.device_scene(0, 0)
+    a = O.bsdf(flat, mid, 0, dirs, u3)
+    b = np.zeros((n, 12), np.float32)
+    T.check(T.lib().tray_debug_bsdf(dev, mid, 0, n, dirs.ctypes.data, u3.ctypes.data, b.ctypes.data))
+    # table lookups: an ulp in acos/atan2 moves a bin edge for a few directions; everything else is the same texel
+    same = np.abs(a - b).max(axis=1) <= 1e-5 * np.maximum(1.0, np.abs(a).max(axis=1))
+    assert same.mean() > 0.995, same.mean()
+    assert (a[:, 0:3] > 0).any()
+
+
+def test_dragon_image_rmse(dragon):
+    scene, rt, spp, fi = dragon
+    gpu, tim = gpu_render(scene, rt, 16, fi, seed=3)
+    cpu, st = O.render_tiles(scene.flatten(0), 16, seed=3)
+    assert tim.samples == st.samples
+    assert abs(int(tim.vertices) - int(st.vertices)) <= 2e-4 * st.vertices
+    r = rmse(gpu, cpu)
+    print(f"dragon(96) 160x120x16: RMSE {r:.3e} V {st.vertices / st.samples:.3f}")
+    assert r < 1e-4
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_wavefront_schedule_matches_the_oracle(name, tmp_path, monkeypatch):
+    """TRAYHIP_MODE=wave: the stage-kernel schedule over the HBM path pool renders the same image."""
+    monkeypatch.setenv("TRAYHIP_MODE", "wave")
+    monkeypatch.setenv("TRAYHIP_WF_SLOTS", "65536")
+    scene, rt, _, fi = load(SCENES[name](96, 64, 16), tmp_path)
+    gpu, tim = gpu_render(scene, rt, 16, fi, seed=6)
+    scene.release_device()
+    cpu, st = O.render_tiles(scene.flatten(0), 16, seed=6)
+    assert tim.samples == st.samples
+    assert abs(int(tim.vertices) - int(st.vertices)) <= 2e-4 * st.vertices
+    assert rmse(gpu, cpu) < 1e-4

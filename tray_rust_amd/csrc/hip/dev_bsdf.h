@@ -285,6 +285,7 @@ TR_DEV f3 bsdf_eval(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {  
     if (w_o.z * w_i.z > 0.0f) flags &= ~(uint32_t)BX_TRANSMISSION; else flags &= ~(uint32_t)BX_REFLECTION;
     f3 sum = mk(0.0f, 0.0f, 0.0f);
     const int n = (int)b.mat->n_lobes;
+#pragma nounroll
     for (int i = 0; i < n; ++i) {
         Lobe l = load_lobe(b.mat, i);
         if (lobe_matches(l.type, flags)) sum = sum + lobe_eval(b, l, w_o, w_i);
@@ -296,6 +297,7 @@ TR_DEV float bsdf_pdf(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {
     float pdf_val = 0.0f;
     int n_comps = 0;
     const int n = (int)b.mat->n_lobes;
+#pragma nounroll
     for (int i = 0; i < n; ++i) {
         Lobe l = load_lobe(b.mat, i);
         if (lobe_matches(l.type, flags)) { pdf_val = pdf_val + lobe_pdf(l, w_o, w_i); ++n_comps; }

@@ -240,6 +240,7 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
 TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
     const bool delta = sc.instances[ln.light_inst].kind == TRAY_INST_POINT_EMITTER;
     uint32_t want = ((ln.flags & LF_SHADOW) && !occluded) ? WANT_LIGHT : (delta ? WANT_PATH : WANT_MIS);
+#pragma nounroll
     for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) want = query_stage(sc, ln, want);   // LIGHT -> MIS -> PATH
 }
 

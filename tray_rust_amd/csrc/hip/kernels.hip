@@ -18,6 +18,8 @@
 #include <mutex>
 #include <string>
 #include <type_traits>
+#include <utility>
+#include <algorithm>
 #include <vector>
 
 #include "../../../include/trayhip.h"
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
     __shared__ float s_table[TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE];
     __shared__ float s_rowbin[ROWBIN_SIZE];
     __shared__ float s_tx[TRAY_FILTER_TABLE_SIZE], s_ty[TRAY_FILTER_TABLE_SIZE];
-    __shared__ uint32_t s_stack[TR_STACK * TR_BLOCK];
+    extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries, sized per scene at launch
     __shared__ uint32_t s_tile;
     const DevScene& sc = scv;
     const DevScene* const scp = &scv;
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
 // ---- parity / debug kernels: the same device functions, one thread per item -------------------
 __global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene scv, uint32_t n, const TrayRay* __restrict__ rays,
                                                               TrayHit* __restrict__ hits) {
-    __shared__ uint32_t s_stack[TR_STACK * TR_BLOCK];
+    extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries, sized per scene at launch
     const DevScene& sc = scv;
     const DevScene* const scp = &scv;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene scv
 __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevScene scv, uint32_t n, const uint32_t* __restrict__ px,
                                                                     const uint32_t* __restrict__ py, const uint32_t* __restrict__ si,
                                                                     uint32_t spp, uint32_t kf, float* __restrict__ out) {
-    __shared__ uint32_t s_stack[TR_STACK * TR_BLOCK];
+    extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries, sized per scene at launch
     const DevScene& sc = scv;
     const DevScene* const scp = &scv;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -394,7 +396,6 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
 __global__ __launch_bounds__(64) void k_debug_bsdf(const DevScene scv, uint32_t flags_sel, uint32_t n,
                                                    const float* __restrict__ dirs, const float* __restrict__ u3, float* __restrict__ out) {
     const DevScene& sc = scv;
-    const DevScene* const scp = &scv;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // canonical frame: n = +z, dp_du = +x; instance 0 of the (private) scene copy carries the material
@@ -438,7 +439,8 @@ struct TrayDeviceScene {
     uint32_t* d_wf_counters = nullptr;   // [0] tile counter, [1] tiles done
     uint32_t* h_done = nullptr;          // pinned host mirror of tiles done
     uint32_t n_chunks = 0;
-    bool wavefront = true;
+    uint32_t stack_bytes = 0;   // dynamic LDS of every kernel that traverses: stack depth x TR_BLOCK x 4
+    bool wavefront = false;   // TRAYHIP_MODE=wave selects the stage-kernel schedule (wavefront.h)
 };
 
 static thread_local int g_device = 0;
@@ -560,7 +562,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             for (int x = 0; x < TRAY_FILTER_TABLE_SIZE; ++x)
                 if (f->film.table[y * TRAY_FILTER_TABLE_SIZE + x] != f->film.table_x[x] * f->film.table_y[y]) { ok = false; break; }
         d.film_rows = (ok && !getenv("TRAYHIP_DIRECT_FILM")) ? 1u : 0u;
-        if (const char* m = getenv("TRAYHIP_MODE")) s->wavefront = std::string(m) != "mega";
+        if (const char* m = getenv("TRAYHIP_MODE")) s->wavefront = std::string(m) == "wave";
     }
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
@@ -593,10 +595,43 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
         tray_scene_destroy(s); set_error("hipEventCreate failed"); return TRAY_E_DEVICE;
     }
+    {   // traversal stack depth: deepest node of any BVH<Triangle>; the one-loop two-level traversal (more than
+        // TR_FLAT_MAX instances) also keeps the top-level path, the instances of a leaf and a sentinel
+        auto depth_of = [](const TrayBvhNode* nodes, uint32_t n) {
+            uint32_t best = 0;
+            std::vector<std::pair<uint32_t, uint32_t>> st;   // node, depth
+            if (n) st.push_back({0u, 1u});
+            while (!st.empty()) {
+                auto [idx, dep] = st.back();
+                st.pop_back();
+                best = std::max(best, dep);
+                if (idx < n && nodes[idx].count == 0) { st.push_back({idx + 1, dep + 1}); st.push_back({nodes[idx].offset, dep + 1}); }
+            }
+            return best;
+        };
+        uint32_t mesh_depth = 0;
+        for (uint32_t m = 0; m < f->n_meshes; ++m)
+            mesh_depth = std::max(mesh_depth, depth_of(f->mesh_nodes + f->meshes[m].node_offset, f->meshes[m].node_count));
+        uint32_t depth = mesh_depth + 1;
+        if (f->n_instances > TR_FLAT_MAX) depth += depth_of(f->top_nodes, f->n_top_nodes) + 4 + 1;
+        depth = std::max(depth, 4u);
+        if (depth > 96) { tray_scene_destroy(s); set_error("BVH too deep for the LDS traversal stack (" + std::to_string(depth) + " levels)"); return TRAY_E_UNSUPPORTED; }
+        s->stack_bytes = depth * TR_BLOCK * (uint32_t)sizeof(uint32_t);
+        if (s->stack_bytes > 32u * 1024u) {   // past the default dynamic-LDS window: raise the per-kernel limit (160 KB LDS per CU)
+            const int bytes = (int)s->stack_bytes;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_intersect), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_sample_radiance), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipGetLastError();
+        }
+    }
     int per_cu = 0, cus = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles, TR_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles, TR_BLOCK, s->stack_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     if (cus < 1) cus = 256;
     s->n_blocks = cus * per_cu;
     *out = s;
@@ -649,11 +684,11 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     for (uint32_t round = 0;; ++round) {
         hipLaunchKernelGGL(k_wf_advance, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
                            spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats);
-        hipLaunchKernelGGL(k_wf_trace<0>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats);
+        hipLaunchKernelGGL(k_wf_trace<0>, grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
         hipLaunchKernelGGL(k_wf_begin, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats);
-        hipLaunchKernelGGL(k_wf_trace<1>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats);
+        hipLaunchKernelGGL(k_wf_trace<1>, grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
         hipLaunchKernelGGL(k_wf_query, grid, block, 0, stream, s->dev, s->pool, n_active);
-        hipLaunchKernelGGL(k_wf_trace<2>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats);
+        hipLaunchKernelGGL(k_wf_trace<2>, grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
         launches += 6;
         if (round % WF_POLL == WF_POLL - 1) {
             HIP_CHECK(hipGetLastError());
@@ -709,7 +744,7 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     if (s->wavefront) return launch_wavefront(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
     int blocks = (int)std::min<uint32_t>((uint32_t)s->n_blocks, tile_count);
     HIP_CHECK(hipEventRecord(s->ev0, stream));
-    hipLaunchKernelGGL(k_path_tiles, dim3(blocks), dim3(TR_BLOCK), 0, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev,
+    hipLaunchKernelGGL(k_path_tiles, dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev,
                        s->d_counter, s->d_stats);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(s->ev1, stream));
@@ -766,7 +801,7 @@ int tray_debug_intersect(TrayDeviceScene* s, uint32_t n, const TrayRay* rays, Tr
     hipError_t e = hipMalloc(&d_h, n * sizeof(TrayHit));
     if (e == hipSuccess) e = hipMemcpy(d_r, rays, n * sizeof(TrayRay), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_debug_intersect, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, 0, s->dev, n, d_r, d_h);
+        hipLaunchKernelGGL(k_debug_intersect, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_r, d_h);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(hits, d_h, n * sizeof(TrayHit), hipMemcpyDeviceToHost);
@@ -796,7 +831,7 @@ int tray_debug_sample_radiance(TrayDeviceScene* s, uint32_t n, const uint32_t* p
         uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
         kf = mix(kf ^ (uint32_t)(seed >> 32));
         kf = mix(kf + s->dev.frame);
-        hipLaunchKernelGGL(k_debug_sample_radiance, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
+        hipLaunchKernelGGL(k_debug_sample_radiance, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(out, d_out, 8 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost);

@@ -65,7 +65,7 @@ TR_DEV void st_bsdf(const DevScene& sc, const WfPool& p, uint32_t i, const Bsdf&
 template <int STAGE>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace(const DevScene scv, WfPool pool, uint32_t n_active, DevStats* __restrict__ stats) {
     const DevScene* scp = &scv;
-    __shared__ uint32_t s_stack[TR_STACK * TR_BLOCK];
+    extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries
     const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
     if (i >= n_active) return;
     uint32_t flags = pu(pool, F_FLAGS, i);
@@ -101,7 +101,6 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace(const DevScene scv, WfPoo
 // Stage A shading: vertex_begin for the slots whose ray hit, end of the sample for those that missed
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPool pool, uint32_t n_active, DevStats* __restrict__ stats) {
     const DevScene& sc = scv;
-    const DevScene* const scp = &scv;
     const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
     if (i >= n_active) return;
     uint32_t flags = pu(pool, F_FLAGS, i);
@@ -139,7 +138,6 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
 // Stage B shading: the BSDF queries of the vertex (light half, BSDF half, continuation)
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPool pool, uint32_t n_active) {
     const DevScene& sc = scv;
-    const DevScene* const scp = &scv;
     const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
     if (i >= n_active) return;
     const uint32_t flags = pu(pool, F_FLAGS, i);
@@ -175,7 +173,6 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
     __shared__ float s_tx[TRAY_FILTER_TABLE_SIZE], s_ty[TRAY_FILTER_TABLE_SIZE];
     __shared__ uint32_t s_tile, s_done, s_fin;
     const DevScene& sc = scv;
-    const DevScene* const scp = &scv;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, sub = tid >> 6;
     const uint32_t c = blockIdx.x;
     const uint32_t i = c * TR_BLOCK + tid;

@@ -138,6 +138,123 @@ def cube_obj():
     return "\n".join(lines) + "\n"
 
 
+# ---- C4 stand-ins: the reference's models/dragon.obj and brdfs/*.binary are not distributed with it.
+def dragon_scene(width=1920, height=1080, samples=2048, material="merl"):
+    """BASELINE.json configs[3] stand-in: cornell walls + disk light (scenes/logo_with_friends.json:186-199) + ONE
+    ~871k-triangle mesh named 'dragon' with the transform of logo_with_friends.json:260-283 and a MERL material."""
+    d = cornell_box(width, height, samples)
+    d["camera"] = {"fov": 28, "transform": [_t(0.0, 12, -52)]}
+    mats = [m for m in d["materials"] if m["type"] == "matte"]
+    if material == "merl":
+        mats.append({"name": "blue_acrylic", "type": "merl", "file": "brdfs/blue-acrylic.binary"})
+    else:
+        mats.append({"type": "plastic", "name": "blue_acrylic", "diffuse": [0.1, 0.2, 0.7], "gloss": [0.6, 0.6, 0.6], "roughness": 0.1})
+    d["materials"] = mats
+    walls = d["objects"][0]
+    light = {"name": "light", "type": "emitter", "material": "white_wall", "emitter": "area", "emission": [1, 0.772549, 0.560784, 40],
+             "geometry": {"type": "disk", "radius": 3.5, "inner_radius": 0.0}, "transform": [_rx(90), _t(0, 23.8, 0)]}
+    dragon = {"name": "dragon", "type": "receiver", "material": "blue_acrylic",
+              "geometry": {"type": "mesh", "file": "models/dragon.obj", "model": "dragon"},
+              "transform": [_s(13.0), _ry(55), _t(8.5, 3.7, 1.5)]}
+    d["objects"] = [walls, light, dragon]
+    return d
+
+
+def write_dragon_obj(path, grid=660, seed=7):
+    """Deterministic stand-in for the Stanford dragon: a (2,3) torus-knot tube with 4-octave value-noise radial
+    displacement on a grid x grid quad mesh (grid=660 -> 871 200 triangles / 435 600 vertices; the real dragon has
+    871 414 / 437 645), written as a real OBJ with v/vt/vn (both required, src/geometry/mesh.rs:57-61)."""
+    import numpy as np
+    n = int(grid)
+    u = (np.arange(n) / n)[:, None] * 2 * np.pi          # along the knot
+    v = (np.arange(n) / n)[None, :] * 2 * np.pi          # around the tube
+    P, Q = 2, 3
+
+    def knot(t):
+        r = 0.5 * (2 + np.cos(Q * t))
+        return np.stack([r * np.cos(P * t), r * np.sin(P * t), -0.5 * np.sin(Q * t)], -1)
+    c = knot(u[:, 0])
+    dt = 1e-4
+    tangent = knot(u[:, 0] + dt) - knot(u[:, 0] - dt)
+    tangent /= np.linalg.norm(tangent, axis=1, keepdims=True)
+    ref = np.array([0.0, 0.0, 1.0])
+    nrm = np.cross(tangent, ref); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    bin_ = np.cross(tangent, nrm)
+    rng = np.random.default_rng(seed)
+    disp = np.zeros((n, n))
+    for octave in range(4):   # periodic value noise
+        k = 8 << octave
+        g = rng.uniform(-1, 1, (k, k))
+        iu = (np.arange(n) * k / n); iv = (np.arange(n) * k / n)
+        u0 = np.floor(iu).astype(int); v0 = np.floor(iv).astype(int)
+        fu = (iu - u0)[:, None]; fv = (iv - v0)[None, :]
+        fu = fu * fu * (3 - 2 * fu); fv = fv * fv * (3 - 2 * fv)
+        a = g[u0 % k][:, v0 % k]; b = g[(u0 + 1) % k][:, v0 % k]; cc = g[u0 % k][:, (v0 + 1) % k]; dd = g[(u0 + 1) % k][:, (v0 + 1) % k]
+        disp += (a * (1 - fu) * (1 - fv) + b * fu * (1 - fv) + cc * (1 - fu) * fv + dd * fu * fv) / (2 ** octave)
+    radius = 0.22 * (1 + 0.25 * disp)
+    pos = c[:, None, :] + radius[..., None] * (np.cos(v)[..., None] * nrm[:, None, :] + np.sin(v)[..., None] * bin_[:, None, :])
+    # smooth normals from the periodic grid
+    du = np.roll(pos, -1, 0) - np.roll(pos, 1, 0); dv = np.roll(pos, -1, 1) - np.roll(pos, 1, 1)
+    nn = np.cross(dv, du); nn /= np.linalg.norm(nn, axis=2, keepdims=True)
+    # normalise the bounding box to about 1 unit (scaling 13 in the scene puts it inside the box)
+    lo, hi = pos.reshape(-1, 3).min(0), pos.reshape(-1, 3).max(0)
+    pos = (pos - (lo + hi) / 2) / (hi - lo).max()
+    pos = pos[..., [0, 2, 1]]; nn = nn[..., [0, 2, 1]]          # stand it up: y is up in the scene
+    uv = np.stack(np.meshgrid(np.arange(n) / n, np.arange(n) / n, indexing="ij"), -1)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    idx = (np.arange(n)[:, None] * n + np.arange(n)[None, :])
+    a = idx; b = np.roll(idx, -1, 0); cc = np.roll(np.roll(idx, -1, 0), -1, 1); dd = np.roll(idx, -1, 1)
+    quads = np.stack([a, b, cc, dd], -1).reshape(-1, 4) + 1
+    with open(path, "w") as f:
+        f.write("o dragon\n")
+        np.savetxt(f, pos.reshape(-1, 3), fmt="v %.7f %.7f %.7f")
+        np.savetxt(f, uv.reshape(-1, 2), fmt="vt %.6f %.6f")
+        np.savetxt(f, nn.reshape(-1, 3), fmt="vn %.6f %.6f %.6f")
+        q = quads
+        np.savetxt(f, np.stack([q[:, 0]] * 3 + [q[:, 1]] * 3 + [q[:, 2]] * 3 + [q[:, 3]] * 3, -1), fmt="f %d/%d/%d %d/%d/%d %d/%d/%d %d/%d/%d")
+    return 2 * n * n
+
+
+def write_merl_binary(path, kd=(0.05, 0.12, 0.45), ks=0.35, alpha=0.08):
+    """MERL-format file (3 x i32 header 90,90,180 + three planes of f64, material/merl.rs:51-84) filled with an analytic
+    diffuse + Cook-Torrance lobe evaluated at the bin centres and divided by the loader's channel scales."""
+    import numpy as np
+    nth, ntd, npd = 90, 90, 180
+    th = ((np.arange(nth) + 0.5) / nth) ** 2 * (np.pi / 2)            # theta_h bins are sqrt-spaced (bxdf/merl.rs:76)
+    td = (np.arange(ntd) + 0.5) / ntd * (np.pi / 2)
+    pd = (np.arange(npd) + 0.5) / npd * np.pi
+    TH, TD, PD = np.meshgrid(th, td, pd, indexing="ij")
+    # half-vector frame -> cos(theta_i), cos(theta_o)
+    wd = np.stack([np.sin(TD) * np.cos(PD), np.sin(TD) * np.sin(PD), np.cos(TD)], -1)
+    ct, st = np.cos(TH), np.sin(TH)
+    wi = np.stack([ct * wd[..., 0] + st * wd[..., 2], wd[..., 1], -st * wd[..., 0] + ct * wd[..., 2]], -1)
+    wo = wi * np.array([-1.0, -1.0, 1.0]) + 0  # mirror of wd about h, rotated the same way
+    wdm = wd * np.array([-1.0, -1.0, 1.0])
+    wo = np.stack([ct * wdm[..., 0] + st * wdm[..., 2], wdm[..., 1], -st * wdm[..., 0] + ct * wdm[..., 2]], -1)
+    ci, co = np.clip(wi[..., 2], 1e-3, 1), np.clip(wo[..., 2], 1e-3, 1)
+    d = np.exp(-(np.tan(TH) ** 2) / alpha ** 2) / (np.pi * alpha ** 2 * np.cos(TH) ** 4 + 1e-12)
+    fres = 0.04 + 0.96 * (1 - np.cos(TD)) ** 5
+    spec = ks * d * fres / (4 * ci * co)
+    scales = (1.0 / 1500.0, 1.0 / 1500.0, 1.66 / 1500.0)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "wb") as f:
+        f.write(np.array([nth, ntd, npd], dtype="<i4").tobytes())
+        for ch in range(3):
+            val = (kd[ch] / np.pi + spec) / scales[ch]
+            f.write(val.astype("<f8").tobytes())
+
+
+def write_dragon_assets(directory, film=(1920, 1080, 2048), grid=660, material="merl"):
+    """models/dragon.obj + brdfs/blue-acrylic.binary + dragon.json under `directory`."""
+    n = write_dragon_obj(os.path.join(directory, "models", "dragon.obj"), grid)
+    if material == "merl":
+        write_merl_binary(os.path.join(directory, "brdfs", "blue-acrylic.binary"))
+    os.makedirs(os.path.join(directory, "models"), exist_ok=True)
+    with open(os.path.join(directory, "models", "cube.obj"), "w") as f:
+        f.write(cube_obj())
+    return write_scene(dragon_scene(*film, material=material), os.path.join(directory, "dragon.json")), n
+
+
 def write_scene(scene, path):
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
