@@ -28,6 +28,7 @@ WIDTH, HEIGHT, SPP = 1920, 1080, 1024
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E
 BYTES_PER_VERTEX = 368.0   # SURVEY 8(d) wavefront accounting
 BYTES_PER_PIXEL = 16.0
+WORKLOAD_CONFIG = {"cornell_box": 1, "smallpt": 2, "dragon": 3}
 
 
 def cpu_baseline(flat, spp, target_seconds=15.0):
@@ -59,8 +60,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=SPP, help="debug only: the reported config is 1024 spp")
+    ap.add_argument("--spp", type=int, default=0, help="debug only: the reported config is 1024 spp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["cornell_box", "smallpt", "dragon"], default="cornell_box",
+                    help="cornell_box = BASELINE.json configs[1] (the reported line); smallpt = configs[2] at 4096 spp; "
+                         "dragon = configs[3] stand-in (871 200 triangles + MERL) at 2048 spp")
     args = ap.parse_args()
 
     import torch
@@ -82,8 +86,12 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     tmp = tempfile.mkdtemp(prefix=f"traybench{rank}_")
-    scenes.write_assets(tmp, cornell=(WIDTH, HEIGHT, args.spp))
-    scene, rt, spp, frame_info = T.Scene.load_file(os.path.join(tmp, "cornell_box.json"))
+    want_spp = args.spp or {"cornell_box": SPP, "smallpt": 4096, "dragon": 2048}[args.workload]
+    if args.workload == "dragon":
+        scenes.write_dragon_assets(tmp, film=(WIDTH, HEIGHT, want_spp))
+    else:
+        scenes.write_assets(tmp, cornell=(WIDTH, HEIGHT, want_spp), small=(WIDTH, HEIGHT, want_spp))
+    scene, rt, spp, frame_info = T.Scene.load_file(os.path.join(tmp, args.workload + ".json"))
     spp = T.round_spp(spp)
     hip = T.Hip(device=local_rank, seed=1)
     film = torch.zeros(WIDTH * HEIGHT * 4, dtype=torch.float32, device="cuda")
@@ -147,7 +155,7 @@ def main():
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cornell_box 1920x1080 {spp}spp, path tracer min_depth 4 max_depth 8 (BASELINE.json configs[1])",
+            "config": {"workload": f"{args.workload} 1920x1080 {spp}spp, path tracer min_depth 4 max_depth 8 (BASELINE.json configs[{WORKLOAD_CONFIG[args.workload]}])",
                        "samples_per_step": frame_samples, "parallelism": f"tiles round-robin over {world} GPU(s), RCCL sum-reduce"
                        if distributed else "1 GPU", "seed": 1, "vertices_per_sample": round(vbar, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -19,7 +19,7 @@ def merl_table(fs):
 @pytest.fixture(scope="module")
 def dragon(tmp_path_factory, built):
     d = str(tmp_path_factory.mktemp("dragon"))
-    path, n = scenes.write_dragon_assets(d, film=(48, 32, 8), grid=40)
+    path, n = scenes.write_dragon_assets(d, film=(48, 32, 8), grid=40, extent=1.0)
     assert n == 2 * 40 * 40
     return d, T.Scene.load_file(path)
 

@@ -9,7 +9,10 @@ spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 scene_name = sys.argv[3] if len(sys.argv) > 3 else "cornell_box"
 d = "/tmp/sc_small"
-scenes.write_assets(d, cornell=(1920, 1080, spp), small=(1920, 1080, spp))
+if scene_name == "dragon":
+    scenes.write_dragon_assets(d, film=(1920, 1080, spp), extent=float(os.environ.get("DRAGON_EXTENT", "0.2")))
+else:
+    scenes.write_assets(d, cornell=(1920, 1080, spp), small=(1920, 1080, spp))
 scene, rt, spp, fi = T.Scene.load_file(f"{d}/{scene_name}.json")
 hip = T.Hip(0, seed=1)
 buf = torch.zeros(1080 * 1920 * 4, dtype=torch.float32, device="cuda")

@@ -160,10 +160,11 @@ def dragon_scene(width=1920, height=1080, samples=2048, material="merl"):
     return d
 
 
-def write_dragon_obj(path, grid=660, seed=7):
+def write_dragon_obj(path, grid=660, seed=7, extent=0.2):
     """Deterministic stand-in for the Stanford dragon: a (2,3) torus-knot tube with 4-octave value-noise radial
     displacement on a grid x grid quad mesh (grid=660 -> 871 200 triangles / 435 600 vertices; the real dragon has
-    871 414 / 437 645), written as a real OBJ with v/vt/vn (both required, src/geometry/mesh.rs:57-61)."""
+    871 414 / 437 645), written as a real OBJ with v/vt/vn (both required, src/geometry/mesh.rs:57-61). The longest
+    bounding-box side is `extent` (the scanned dragon is about 0.2 units; the scene scales it by 13)."""
     import numpy as np
     n = int(grid)
     u = (np.arange(n) / n)[:, None] * 2 * np.pi          # along the knot
@@ -196,9 +197,8 @@ def write_dragon_obj(path, grid=660, seed=7):
     # smooth normals from the periodic grid
     du = np.roll(pos, -1, 0) - np.roll(pos, 1, 0); dv = np.roll(pos, -1, 1) - np.roll(pos, 1, 1)
     nn = np.cross(dv, du); nn /= np.linalg.norm(nn, axis=2, keepdims=True)
-    # normalise the bounding box to about 1 unit (scaling 13 in the scene puts it inside the box)
     lo, hi = pos.reshape(-1, 3).min(0), pos.reshape(-1, 3).max(0)
-    pos = (pos - (lo + hi) / 2) / (hi - lo).max()
+    pos = (pos - (lo + hi) / 2) * (extent / (hi - lo).max())
     pos = pos[..., [0, 2, 1]]; nn = nn[..., [0, 2, 1]]          # stand it up: y is up in the scene
     uv = np.stack(np.meshgrid(np.arange(n) / n, np.arange(n) / n, indexing="ij"), -1)
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
@@ -244,9 +244,9 @@ def write_merl_binary(path, kd=(0.05, 0.12, 0.45), ks=0.35, alpha=0.08):
             f.write(val.astype("<f8").tobytes())
 
 
-def write_dragon_assets(directory, film=(1920, 1080, 2048), grid=660, material="merl"):
+def write_dragon_assets(directory, film=(1920, 1080, 2048), grid=660, material="merl", extent=0.2):
     """models/dragon.obj + brdfs/blue-acrylic.binary + dragon.json under `directory`."""
-    n = write_dragon_obj(os.path.join(directory, "models", "dragon.obj"), grid)
+    n = write_dragon_obj(os.path.join(directory, "models", "dragon.obj"), grid, extent=extent)
     if material == "merl":
         write_merl_binary(os.path.join(directory, "brdfs", "blue-acrylic.binary"))
     os.makedirs(os.path.join(directory, "models"), exist_ok=True)
