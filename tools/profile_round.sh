@@ -10,7 +10,8 @@ cd /tmp; export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --workload "$WL" > "$OUT/bench_profiled.log" 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU" \
-           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_FLAT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_FLAT"; do
+           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_FLAT" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA"; do
   name=$(echo "$set" | cut -d' ' -f1)
   timeout 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc_$name" -- python "$ROOT/tools/bench_small.py" 64 1 "$WL" > "$OUT/pmc_$name.log" 2>&1
 done
