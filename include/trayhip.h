@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TRAY_ABI_VERSION 1
+#define TRAY_ABI_VERSION 2
 
 enum {
     TRAY_OK = 0,
@@ -90,13 +90,17 @@ typedef struct TrayInstance {
     uint32_t mesh_id;     /* valid for TRAY_GEOM_MESH */
     uint32_t material_id; /* 0xffffffff for point emitters */
     float geom_params[4]; /* sphere: radius | disk: radius, inner_radius | rect: width, height */
-    float emission[4];    /* AnimatedColor::color(time) for the frame (rgb, a) */
-    float mat[16];
+    float emission[4];    /* AnimatedColor::color(shutter_open) (rgb, a); exact for every ray when emis_count <= 1 */
+    float mat[16];        /* transform(shutter_open); exact for every ray when animated == 0 */
     float inv[16];
     uint32_t light_index; /* index in lights[] or 0xffffffff */
     uint32_t xf_first;    /* first TrayXformLevel of this instance's spline stack */
     uint32_t xf_count;    /* number of levels (object first, then group parents) */
-    uint32_t pad;
+    uint32_t animated;    /* 1 => some level has more than one control point: evaluate the stack at ray.time
+                           * (receiver.rs:30, emitter.rs:122,161,169,190) */
+    uint32_t emis_first;  /* AnimatedColor keyframes in color_keys[] (film/animated_color.rs:45-49), sorted by time */
+    uint32_t emis_count;
+    uint32_t pad[2];
 } TrayInstance;
 
 /* TRS keyframe (src/linalg/keyframe.rs:13-17) */
@@ -106,12 +110,25 @@ typedef struct TrayKeyframe {
     float scaling[3];
 } TrayKeyframe;
 
-/* One B-spline level of an AnimatedTransform (src/linalg/animated_transform.rs:15-19) */
+/* One B-spline level of an AnimatedTransform (src/linalg/animated_transform.rs:15-19).
+ * BSpline<Keyframe> of the bspline crate (0.2.2, not vendored by the reference): clamped de Boor evaluation over the
+ * sorted knot vector, domain (knots[degree], knots[n_knots-1-degree]); a level with ONE control point is a constant
+ * (animated_transform.rs:47-48) whose Transform is stored in mat/inv. */
 typedef struct TrayXformLevel {
     uint32_t kf_first, kf_count;     /* control points in keyframes[] */
-    uint32_t knot_first, knot_count; /* knots in knots[] */
+    uint32_t knot_first, knot_count; /* knots in knots[] (sorted ascending) */
     uint32_t degree;
+    uint32_t pad[3];
+    float mat[16];                   /* control_point.transform() when kf_count == 1 (keyframe.rs:60-63) */
+    float inv[16];
 } TrayXformLevel;
+
+/* ColorKeyframe (src/film/animated_color.rs:10-14) */
+typedef struct TrayColorKey {
+    float color[4];
+    float time;
+    float pad[3];
+} TrayColorKey;
 
 enum {
     TRAY_MAT_MATTE = 0, TRAY_MAT_PLASTIC = 1, TRAY_MAT_METAL = 2, TRAY_MAT_GLASS = 3,
@@ -148,8 +165,8 @@ typedef struct TrayCamera {
     float raster_to_cam[16];
     float scaling[3];
     float shutter_open, shutter_close;
-    float cam_world[16];   /* cam_world.transform(t).mat for an unanimated camera */
-    uint32_t animated;     /* 1 => cam_world must be evaluated per ray (not yet supported on device) */
+    float cam_world[16];   /* cam_world.transform(shutter_open).mat; exact for every ray when animated == 0 */
+    uint32_t animated;     /* 1 => cam_world.transform(frame_time) is evaluated per ray (camera.rs:156) */
     uint32_t xf_first, xf_count;
 } TrayCamera;
 
@@ -189,6 +206,8 @@ typedef struct TrayFlatScene {
     uint32_t n_xf_levels;   const TrayXformLevel* xf_levels;
     uint32_t n_keyframes;   const TrayKeyframe* keyframes;
     uint32_t n_knots;       const float* knots;
+    uint32_t n_color_keys;  const TrayColorKey* color_keys;
+    uint32_t animated;      /* 1 if the camera, any instance transform or any emission varies over the open shutter */
 } TrayFlatScene;
 
 /* ---------------------------------------------------------------- host side: loader (scene.rs) */
@@ -304,6 +323,10 @@ int tray_debug_bsdf(TrayDeviceScene* s, uint32_t material_id, uint32_t flags, ui
 
 const char* tray_last_error(void);
 const char* tray_version(void);
+
+/* sizeof() of the structs above as this library was compiled, for bindings that restate the layouts (ctypes, repr(C)):
+ * name is the struct name ("TrayInstance", ...); 0 for an unknown name. */
+uint32_t tray_abi_sizeof(const char* name);
 
 #ifdef __cplusplus
 }

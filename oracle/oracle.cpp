@@ -19,13 +19,15 @@ using namespace orc;
 namespace {
 
 // Camera::generate_ray (camera.rs:150-157)
-Ray camera_generate_ray(const TrayFlatScene& fs, float px, float py, float time) {
+Ray camera_generate_ray(const SceneView& sv, float px, float py, float time) {
+    const TrayFlatScene& fs = *sv.fs;
     const TrayCamera& c = fs.camera;
     Vec3 q = Transform::mul_point(Mat4::from(c.raster_to_cam), Vec3(px, py, 0.0f));
     Vec3 px_pos = Vec3(c.scaling[0], c.scaling[1], c.scaling[2]) * q;
     Vec3 d = px_pos.normalized();
     float frame_time = (c.shutter_close - c.shutter_open) * time + c.shutter_open;
-    Mat4 cw = Mat4::from(c.cam_world);
+    // cam_world.transform(frame_time) * Ray (camera.rs:156)
+    Mat4 cw = ((sv.flags & ORC_FAITHFUL_XF) || c.animated) ? sv.stack_transform(c.xf_first, c.xf_count, frame_time).mat : Mat4::from(c.cam_world);
     Ray r;
     r.o = Transform::mul_point(cw, Vec3(0, 0, 0));
     r.d = Transform::mul_vector(cw, d);
@@ -94,7 +96,7 @@ Colorf estimate_direct(const SceneView& sv, Vec3 w_o, Vec3 p, const BSDF& bsdf, 
         if (pdf_bsdf > 0.0f && !f.is_black()) {
             float w = 1.0f;
             if (!(sampled_type & BX_SPECULAR)) {
-                float pdf_light = light_pdf(sv, light_inst, p, w_i);
+                float pdf_light = light_pdf(sv, light_inst, p, w_i, time);
                 if (pdf_light == 0.0f) return direct_light;
                 w = power_heuristic(1.0f, pdf_bsdf, 1.0f, pdf_light);
             }
@@ -104,7 +106,7 @@ Colorf estimate_direct(const SceneView& sv, Vec3 w_o, Vec3 p, const BSDF& bsdf, 
             Hit h;
             if (scene_intersect(sv, ray, h)) {
                 if (h.inst == light_inst)   // same emitter object (mod.rs:157-160)
-                    li = emitter_radiance(light, -w_i, h.ng);
+                    li = emitter_radiance(sv, light, -w_i, h.ng, time);
             }
             if (!li.is_black()) direct_light = direct_light + f * li * std::fabs(dot(w_i, bsdf.n)) * w / pdf_bsdf;
         }
@@ -127,7 +129,7 @@ Colorf path_illumination(const SceneView& sv, const Ray& r, const Hit& hit, cons
         if (bounce == 0 || specular_bounce) {
             if (inst.kind != TRAY_INST_RECEIVER) {
                 Vec3 w = -ray.d;
-                illum = illum + path_throughput * emitter_radiance(inst, w, hit.ng);   // first hit's ng (quirk Q1)
+                illum = illum + path_throughput * emitter_radiance(sv, inst, w, hit.ng, ray.time);   // first hit's ng (quirk Q1)
             }
         }
         BSDF bsdf = material_bsdf(fs, current_hit);
@@ -192,7 +194,7 @@ Colorf trace_sample(const SceneView& sv, uint32_t kf, uint32_t px, uint32_t py, 
     pix.position(s, px, py, sx, sy);
     float t = pix.time(s);
     if (sv.stats) sv.stats->samples++;
-    Ray ray = camera_generate_ray(fs, sx, sy, t);
+    Ray ray = camera_generate_ray(sv, sx, sy, t);
     Hit hit;
     if (scene_intersect(sv, ray, hit)) {
         PathSamples ps;
@@ -378,8 +380,9 @@ int oracle_intersect(const TrayFlatScene* fs, uint32_t n, const TrayRay* rays, T
 // Camera::generate_ray for n raster positions: in xy[2i..], time[i] -> rays
 int oracle_camera_rays(const TrayFlatScene* fs, uint32_t n, const float* xy, const float* time, TrayRay* rays) {
     if (!fs || !xy || !rays) return -1;
+    SceneView sv{fs, 0, nullptr};
     for (uint32_t i = 0; i < n; ++i) {
-        Ray r = camera_generate_ray(*fs, xy[2 * i], xy[2 * i + 1], time ? time[i] : 0.0f);
+        Ray r = camera_generate_ray(sv, xy[2 * i], xy[2 * i + 1], time ? time[i] : 0.0f);
         for (int k = 0; k < 3; ++k) { rays[i].o[k] = r.o[k]; rays[i].d[k] = r.d[k]; }
         rays[i].min_t = r.min_t; rays[i].max_t = r.max_t; rays[i].time = r.time;
     }
@@ -430,14 +433,41 @@ int oracle_bsdf(const TrayFlatScene* fs, uint32_t material_id, uint32_t flags_se
 
 // Rebuilds every instance's Transform from its TRS stack the way receiver.rs:30 does per ray and
 // writes mat(16)+inv(16) per instance: cross-check against the loader's matrices.
-int oracle_instance_matrices(const TrayFlatScene* fs, float* out) {
+int oracle_instance_matrices(const TrayFlatScene* fs, float time, float* out) {
     if (!fs || !out) return -1;
     SceneView sv{fs, ORC_FAITHFUL_XF, nullptr};
     for (uint32_t i = 0; i < fs->n_instances; ++i) {
-        Transform t = sv.instance_transform(i);
+        Transform t = sv.instance_transform(i, time);
         std::memcpy(out + (size_t)i * 32, t.mat.m, sizeof t.mat.m);
         std::memcpy(out + (size_t)i * 32 + 16, t.inv.m, sizeof t.inv.m);
     }
+    return 0;
+}
+
+// B-spline of TRS keyframes: ctrl = n x 10 floats (translation 3, rotation xyzw 4, scaling 3) -> out 10 floats
+int oracle_bspline_point(const float* ctrl, uint32_t n, const float* knots, uint32_t n_knots, uint32_t degree, float t, float* out) {
+    if (!ctrl || !knots || !out || n == 0 || n > 64 || degree > 7 || n_knots != n + degree + 1) return -1;
+    Key keys[64];
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* c = ctrl + (size_t)i * 10;
+        keys[i].t = Vec3(c[0], c[1], c[2]);
+        for (int k = 0; k < 4; ++k) keys[i].q[k] = c[3 + k];
+        keys[i].s = Vec3(c[7], c[8], c[9]);
+    }
+    Key k = n == 1 ? keys[0] : de_boor(keys, knots, n_knots, degree, clampf(t, knots[degree], knots[n_knots - 1 - degree]), key_interpolate);
+    out[0] = k.t.x; out[1] = k.t.y; out[2] = k.t.z;
+    for (int i = 0; i < 4; ++i) out[3 + i] = k.q[i];
+    out[7] = k.s.x; out[8] = k.s.y; out[9] = k.s.z;
+    return 0;
+}
+
+// AnimatedTransform::transform(time) of any spline stack of the flat scene (camera or instance): mat(16) + inv(16)
+int oracle_stack_transform(const TrayFlatScene* fs, uint32_t xf_first, uint32_t xf_count, float time, float* out) {
+    if (!fs || !out || xf_first + xf_count > fs->n_xf_levels) return -1;
+    SceneView sv{fs, ORC_FAITHFUL_XF, nullptr};
+    Transform t = sv.stack_transform(xf_first, xf_count, time);
+    std::memcpy(out, t.mat.m, sizeof t.mat.m);
+    std::memcpy(out + 16, t.inv.m, sizeof t.inv.m);
     return 0;
 }
 

@@ -261,6 +261,62 @@ inline Transform keyframe_transform(const float t[3], const float q[4], const fl
     return Transform::translate(Vec3(t[0], t[1], t[2])) * Transform::from_mat(m) * Transform::scale(Vec3(s[0], s[1], s[2]));
 }
 
+// ---- quaternion.rs:90-113 (dot, slerp), keyframe.rs:66-73 (Interpolate for Keyframe)
+struct Key { Vec3 t; float q[4]; Vec3 s; };
+inline float quat_dot(const float a[4], const float b[4]) { return (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]) + a[3] * b[3]; }
+inline void quat_slerp(float t, const float a[4], const float b[4], float out[4]) {
+    float cos_theta = quat_dot(a, b);
+    if (cos_theta > 0.9995f) {
+        float q[4];
+        for (int i = 0; i < 4; ++i) q[i] = (1.0f - t) * a[i] + t * b[i];
+        float len = std::sqrt(quat_dot(q, q));
+        for (int i = 0; i < 4; ++i) out[i] = q[i] / len;
+    } else {
+        float theta = std::acos(clampf(cos_theta, -1.0f, 1.0f));
+        float theta_t = theta * t;
+        float perp[4];
+        for (int i = 0; i < 4; ++i) perp[i] = b[i] - a[i] * cos_theta;
+        float len = std::sqrt(quat_dot(perp, perp));
+        for (int i = 0; i < 4; ++i) perp[i] = perp[i] / len;
+        float c = std::cos(theta_t), sn = std::sin(theta_t);
+        for (int i = 0; i < 4; ++i) out[i] = a[i] * c + perp[i] * sn;
+    }
+}
+inline Key key_interpolate(const Key& a, const Key& b, float t) {
+    Key k;
+    k.t = (1.0f - t) * a.t + t * b.t;
+    quat_slerp(t, a.q, b.q, k.q);
+    k.s = (1.0f - t) * a.s + t * b.s;
+    return k;
+}
+inline Key key_from(const TrayKeyframe& f) {
+    Key k;
+    k.t = Vec3(f.translation[0], f.translation[1], f.translation[2]);
+    for (int i = 0; i < 4; ++i) k.q[i] = f.rotation[i];
+    k.s = Vec3(f.scaling[0], f.scaling[1], f.scaling[2]);
+    return k;
+}
+
+// ---- bspline 0.2.2 `BSpline::point` (third-party crate, absent from /root/reference: PARITY UNPINNED). Textbook de Boor
+// (Piegl & Tiller A3.1 recurrence in the d[j] form) on the span mu with knots[mu] <= t < knots[mu+1], mu clamped so that a
+// t at the end of the knot domain uses the last full span. Written in the span-index form (the product library uses the
+// crate's i_start = mu + 1 form): same arithmetic per blend, different bookkeeping.
+template <class P, class Blend>
+inline P de_boor(const P* ctrl, const float* knots, uint32_t n_knots, uint32_t degree, float t, Blend&& blend) {
+    uint32_t n_ctrl = n_knots - degree - 1;
+    uint32_t mu = degree;
+    while (mu + 1 < n_ctrl && !(t < knots[mu + 1])) ++mu;   // last span whose start is <= t, never past the final one
+    P d[8];
+    for (uint32_t j = 0; j <= degree; ++j) d[j] = ctrl[mu - degree + j];
+    for (uint32_t r = 1; r <= degree; ++r)
+        for (uint32_t j = 0; j + r <= degree; ++j) {   // ascending j overwrites d[j] only after it was consumed as the left operand
+            uint32_t lo = mu - degree + r + j;         // knot under the left end of this blend's support
+            float alpha = (t - knots[lo]) / (knots[lo + degree + 1 - r] - knots[lo]);
+            d[j] = blend(d[j], d[j + 1], alpha);
+        }
+    return d[0];
+}
+
 // ------------------------------------------------------------------ TRAY-CBRNG (replaces rand::StdRng)
 // Stateless: every draw is a hash of (seed, frame, pixel, sample, dimension). See DESIGN.md.
 inline uint32_t mix32(uint32_t x) {

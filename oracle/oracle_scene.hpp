@@ -238,18 +238,33 @@ struct SceneView {
     const TrayFlatScene* fs;
     int flags;
     Stats* stats;
-    // per-instance transforms; in faithful mode rebuilt on every use like receiver.rs:30
-    Transform instance_transform(uint32_t i) const {
-        const TrayInstance& in = fs->instances[i];
-        if (flags & ORC_FAITHFUL_XF) {   // AnimatedTransform::transform (animated_transform.rs:40-56), single control points
-            Transform t = Transform::identity();
-            for (uint32_t l = 0; l < in.xf_count; ++l) {
-                const TrayXformLevel& lv = fs->xf_levels[in.xf_first + l];
+    // AnimatedTransform::transform (animated_transform.rs:40-56) from the TRS keyframes of the spline stack
+    Transform stack_transform(uint32_t xf_first, uint32_t xf_count, float time) const {
+        Transform t = Transform::identity();
+        for (uint32_t l = 0; l < xf_count; ++l) {
+            const TrayXformLevel& lv = fs->xf_levels[xf_first + l];
+            if (lv.kf_count == 1) {
                 const TrayKeyframe& k = fs->keyframes[lv.kf_first];
                 t = keyframe_transform(k.translation, k.rotation, k.scaling) * t;
+                continue;
             }
-            return t;
+            const float* knots = fs->knots + lv.knot_first;
+            float lo = knots[lv.degree], hi = knots[lv.knot_count - 1 - lv.degree];   // BSpline::knot_domain
+            float t_val = clampf(time, lo, hi);
+            Key ctrl[64];
+            uint32_t n = lv.kf_count < 64 ? lv.kf_count : 64;
+            for (uint32_t i = 0; i < n; ++i) ctrl[i] = key_from(fs->keyframes[lv.kf_first + i]);
+            Key k = de_boor(ctrl, knots, lv.knot_count, lv.degree, t_val, key_interpolate);
+            float tr[3] = {k.t.x, k.t.y, k.t.z}, sc[3] = {k.s.x, k.s.y, k.s.z};
+            t = keyframe_transform(tr, k.q, sc) * t;
         }
+        return t;
+    }
+    // per-instance transforms; in faithful mode rebuilt on every use like receiver.rs:30. An instance whose stack has a
+    // moving level is always rebuilt at the ray's time.
+    Transform instance_transform(uint32_t i, float time) const {
+        const TrayInstance& in = fs->instances[i];
+        if ((flags & ORC_FAITHFUL_XF) || in.animated) return stack_transform(in.xf_first, in.xf_count, time);
         return Transform::from_pair(Mat4::from(in.mat), Mat4::from(in.inv));
     }
 };
@@ -284,7 +299,7 @@ inline bool geom_intersect(const SceneView& sv, const TrayInstance& in, Ray& loc
 inline bool instance_intersect(const SceneView& sv, uint32_t i, Ray& ray, Hit& h) {
     const TrayInstance& in = sv.fs->instances[i];
     if (in.kind == TRAY_INST_POINT_EMITTER) return false;
-    Transform t = sv.instance_transform(i);
+    Transform t = sv.instance_transform(i, ray.time);
     Ray local = t.inv_ray(ray);
     Hit dg;
     if (!geom_intersect(sv, in, local, dg)) return false;
@@ -390,22 +405,37 @@ inline float geom_pdf(const TrayInstance& in, Vec3 p, Vec3 w_i) {
 }
 
 // ------------------------------------------------------------------ Light for Emitter (emitter.rs:140-203)
-inline Colorf inst_emission(const TrayInstance& in) { return Colorf(in.emission[0], in.emission[1], in.emission[2], in.emission[3]); }
-inline Colorf emitter_radiance(const TrayInstance& in, Vec3 w, Vec3 n) {
-    return dot(w, n) > 0.0f ? inst_emission(in) : Colorf::black();
+// AnimatedColor::color (film/animated_color.rs:52-78)
+inline Colorf inst_emission(const SceneView& sv, const TrayInstance& in, float time) {
+    if (in.emis_count < 2) return Colorf(in.emission[0], in.emission[1], in.emission[2], in.emission[3]);
+    const TrayColorKey* keys = sv.fs->color_keys + in.emis_first;
+    const TrayColorKey* first = nullptr;
+    const TrayColorKey* second = nullptr;
+    uint32_t i = 0;
+    while (i < in.emis_count && keys[i].time < time) { first = &keys[i]; ++i; }   // take_while(..).last()
+    if (i < in.emis_count) second = &keys[i];                                       // skip_while(..).next()
+    auto col = [](const TrayColorKey* k) { return Colorf(k->color[0], k->color[1], k->color[2], k->color[3]); };
+    if (!first) return col(&keys[0]);
+    if (!second) return col(&keys[in.emis_count - 1]);
+    float t = (time - first->time) / (second->time - first->time);
+    return Colorf(lerp(t, first->color[0], second->color[0]), lerp(t, first->color[1], second->color[1]),
+                  lerp(t, first->color[2], second->color[2]), lerp(t, first->color[3], second->color[3]));
+}
+inline Colorf emitter_radiance(const SceneView& sv, const TrayInstance& in, Vec3 w, Vec3 n, float time) {   // emitter.rs:139-141
+    return dot(w, n) > 0.0f ? inst_emission(sv, in, time) : Colorf::black();
 }
 struct LightSample { Colorf li; Vec3 w_i; float pdf; Ray occlusion; };
 inline LightSample light_sample_incident(const SceneView& sv, uint32_t inst, Vec3 p, float u0, float u1, float time) {
     const TrayInstance& in = sv.fs->instances[inst];
     LightSample ls;
-    Transform t = sv.instance_transform(inst);
+    Transform t = sv.instance_transform(inst, time);
     auto test_points = [&](Vec3 a, Vec3 b) {   // OcclusionTester::test_points (light/mod.rs:21-23)
         Ray r; r.o = a; r.d = b - a; r.min_t = 0.001f; r.max_t = 0.999f; r.time = time; return r;
     };
     if (in.kind == TRAY_INST_POINT_EMITTER) {
         Vec3 pos = t.point(Vec3(0, 0, 0));
         ls.w_i = (pos - p).normalized();
-        ls.li = inst_emission(in) / (pos - p).length_sqr();
+        ls.li = inst_emission(sv, in, time) / (pos - p).length_sqr();
         ls.pdf = 1.0f;
         ls.occlusion = test_points(p, pos);
         return ls;
@@ -415,16 +445,16 @@ inline LightSample light_sample_incident(const SceneView& sv, uint32_t inst, Vec
     geom_sample(in, p_l, u0, u1, p_sampled, normal);
     Vec3 w_il = (p_sampled - p_l).normalized();
     ls.pdf = geom_pdf(in, p_l, w_il);
-    ls.li = emitter_radiance(in, -w_il, normal);
+    ls.li = emitter_radiance(sv, in, -w_il, normal, time);
     Vec3 p_w = t.point(p_sampled);
     ls.w_i = t.vector(w_il);
     ls.occlusion = test_points(p, p_w);
     return ls;
 }
-inline float light_pdf(const SceneView& sv, uint32_t inst, Vec3 p, Vec3 w_i) {
+inline float light_pdf(const SceneView& sv, uint32_t inst, Vec3 p, Vec3 w_i, float time) {
     const TrayInstance& in = sv.fs->instances[inst];
     if (in.kind == TRAY_INST_POINT_EMITTER) return 0.0f;
-    Transform t = sv.instance_transform(inst);
+    Transform t = sv.instance_transform(inst, time);
     Vec3 p_l = t.inv_point(p);
     Vec3 w = t.inv_vector(w_i).normalized();
     return geom_pdf(in, p_l, w);

@@ -45,7 +45,11 @@ def oracle():
         o.oracle_bsdf.restype = C.c_int
         o.oracle_bsdf.argtypes = [FS, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         o.oracle_instance_matrices.restype = C.c_int
-        o.oracle_instance_matrices.argtypes = [FS, C.c_void_p]
+        o.oracle_instance_matrices.argtypes = [FS, C.c_float, C.c_void_p]
+        o.oracle_bspline_point.restype = C.c_int
+        o.oracle_bspline_point.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
+        o.oracle_stack_transform.restype = C.c_int
+        o.oracle_stack_transform.argtypes = [FS, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
         for name in ("oracle_mat4_mul", "oracle_mat4_add", "oracle_mat4_sub"):
             getattr(o, name).restype = None
             getattr(o, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

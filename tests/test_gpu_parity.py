@@ -294,3 +294,58 @@ def test_wavefront_schedule_matches_the_oracle(name, tmp_path, monkeypatch):
     assert tim.samples == st.samples
     assert abs(int(tim.vertices) - int(st.vertices)) <= 2e-4 * st.vertices
     assert rmse(gpu, cpu) < 1e-4
+
+
+# ---- moving scenes: per-ray spline evaluation, animated emission and camera ----
+@pytest.fixture(scope="module")
+def moving(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("moving"))
+    return T.Scene.load_file(scenes.write_moving_box(d, width=160, height=120, samples=32))
+
+
+def test_moving_scene_intersect(moving):
+    """Same BVH, same visiting order; the per-ray transforms go through acosf / sinf / cosf (ocml vs glibc), so hit
+    distances agree to a few ulps instead of bit for bit."""
+    scene = moving[0]
+    frame = 3
+    flat = scene.flatten(frame)
+    rng = np.random.default_rng(23)
+    n = 60000
+    times = rng.uniform(0, 1, n).astype(np.float32)
+    rays = O.camera_rays(flat, rng.uniform(0, [160, 120], (n, 2)), times)
+    assert rays[:, 8].min() >= flat.contents.camera.shutter_open and rays[:, 8].max() <= flat.contents.camera.shutter_close
+    assert np.unique(rays[:, 8]).size > 1000
+    dev = scene.device_scene(frame, 0)
+    b = np.zeros(n, dtype=O.HIT_DTYPE)
+    T.check(T.lib().tray_debug_intersect(dev, n, rays.ctypes.data, b.ctypes.data))
+    a = O.intersect(flat, rays)
+    same = (a["inst"] == b["inst"]) & (a["prim"] == b["prim"])
+    assert same.mean() > 0.9995, same.mean()
+    hit = same & (a["inst"] != 0xffffffff)
+    moving_hits = np.isin(a["inst"][hit], [i for i in range(flat.contents.n_instances) if flat.contents.instances[i].animated])
+    assert moving_hits.mean() > 0.05
+    assert np.abs(a["t"][hit] - b["t"][hit]).max() <= 2e-5 * np.abs(a["t"][hit]).max()
+    assert np.abs(a["p"][hit] - b["p"][hit]).max() <= 1e-3
+    assert np.abs(a["n"][hit] - b["n"][hit]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("frame", [0, 5])
+def test_moving_scene_image_rmse(moving, frame):
+    scene, rt, spp, fi = moving
+    rt.clear()
+    hip = T.Hip(0, seed=4)
+    hip.render(scene, rt, _config_at(fi, frame))
+    gpu = rt.get_renderf32().reshape(rt.height, rt.width, 4).copy()
+    tim = hip.last_timing
+    cpu, st = O.render_tiles(scene.flatten(frame), 32, seed=4)
+    assert tim.samples == st.samples
+    assert abs(int(tim.vertices) - int(st.vertices)) <= 5e-4 * st.vertices
+    r = rmse(gpu, cpu)
+    print(f"moving_box frame {frame} 160x120x32: RMSE {r:.3e} V {st.vertices / st.samples:.3f}")
+    assert r < 1e-4
+
+
+def _config_at(fi, frame):
+    c = T.Config(".", "s", 32, 1, fi, (0, 0))
+    c.current_frame = frame
+    return c

@@ -57,7 +57,7 @@ def test_instance_matrices_agree_with_the_oracles_linalg(assets):
         flat = scene.flatten(0)
         fs = flat.contents
         out = np.zeros((fs.n_instances, 32), np.float32)
-        assert O.oracle().oracle_instance_matrices(flat, out.ctypes.data) == 0
+        assert O.oracle().oracle_instance_matrices(flat, 0.0, out.ctypes.data) == 0
         for i in range(fs.n_instances):
             assert (np.array(fs.instances[i].mat, np.float32) == out[i, :16]).all()
             assert (np.array(fs.instances[i].inv, np.float32) == out[i, 16:]).all()

@@ -43,7 +43,8 @@ class TrayMesh(C.Structure):
 class TrayInstance(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("geom_type", C.c_uint32), ("mesh_id", C.c_uint32), ("material_id", C.c_uint32),
                 ("geom_params", C.c_float * 4), ("emission", C.c_float * 4), ("mat", C.c_float * 16), ("inv", C.c_float * 16),
-                ("light_index", C.c_uint32), ("xf_first", C.c_uint32), ("xf_count", C.c_uint32), ("pad", C.c_uint32)]
+                ("light_index", C.c_uint32), ("xf_first", C.c_uint32), ("xf_count", C.c_uint32), ("animated", C.c_uint32),
+                ("emis_first", C.c_uint32), ("emis_count", C.c_uint32), ("pad", C.c_uint32 * 2)]
 
 
 class TrayKeyframe(C.Structure):
@@ -52,7 +53,11 @@ class TrayKeyframe(C.Structure):
 
 class TrayXformLevel(C.Structure):
     _fields_ = [("kf_first", C.c_uint32), ("kf_count", C.c_uint32), ("knot_first", C.c_uint32), ("knot_count", C.c_uint32),
-                ("degree", C.c_uint32)]
+                ("degree", C.c_uint32), ("pad", C.c_uint32 * 3), ("mat", C.c_float * 16), ("inv", C.c_float * 16)]
+
+
+class TrayColorKey(C.Structure):
+    _fields_ = [("color", C.c_float * 4), ("time", C.c_float), ("pad", C.c_float * 3)]
 
 
 class TrayMaterial(C.Structure):
@@ -99,6 +104,7 @@ class TrayFlatScene(C.Structure):
         ("n_xf_levels", C.c_uint32), ("xf_levels", _P(TrayXformLevel)),
         ("n_keyframes", C.c_uint32), ("keyframes", _P(TrayKeyframe)),
         ("n_knots", C.c_uint32), ("knots", _P(C.c_float)),
+        ("n_color_keys", C.c_uint32), ("color_keys", _P(TrayColorKey)), ("animated", C.c_uint32),
     ]
 
 
@@ -146,6 +152,7 @@ SYMBOLS = {
     "tray_debug_bsdf": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tray_last_error": (C.c_char_p, []),
     "tray_version": (C.c_char_p, []),
+    "tray_abi_sizeof": (C.c_uint32, [C.c_char_p]),
 }
 
 _lib = None

@@ -15,6 +15,7 @@
 #pragma once
 #include "../../../include/trayhip.h"
 #include "dev_math.h"
+#include "dev_anim.h"
 
 namespace tr {
 
@@ -49,6 +50,10 @@ struct DevScene {
     const float* __restrict__ filter_table;
     const float* __restrict__ filter_x;   // separable factors: table[y*16+x] == filter_x[x] * filter_y[y]
     const float* __restrict__ filter_y;
+    const TrayXformLevel* __restrict__ xf_levels;   // spline stacks of moving instances / camera (dev_anim.h)
+    const TrayKeyframe* __restrict__ keyframes;
+    const float* __restrict__ knots;
+    const TrayColorKey* __restrict__ color_keys;
     uint32_t n_instances, n_lights, min_depth, max_depth;
     uint32_t width, height, frame, film_rows;   // film_rows: 1 = row-binned film (separable, filter_h == 2)
     float filter_w, filter_h, inv_w, inv_h;
@@ -59,7 +64,20 @@ struct DevScene {
 struct Ray {
     f3 o, d;
     float min_t, max_t;
+    float time;   // ray.time (linalg/ray.rs:17): only read by the kernels built for moving scenes (ANIM)
 };
+
+// Transform of an instance at a ray's time as rows 0..2 of mat (x) and of inv (x + 12). Instance transforms are products
+// of TRS keyframes (AnimatedTransform::unanimated decomposes static ones too), so row 3 is (0,0,0,1) and the affine
+// point transform equals Transform * Point.
+TR_DEV void instance_xf_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, float* x) {
+    if (in->animated) {
+        eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { x[k] = in->mat[k]; x[12 + k] = in->inv[k]; }
+    }
+}
 
 struct HitRec {   // what traversal keeps for the closest candidate
     float t;
@@ -258,6 +276,7 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
 // Scene::intersect. Returns true on hit; rec = closest candidate (the last accepted one,
 // bvh.rs:93-98). any_hit: return at the first accepted candidate (OcclusionTester::occluded only
 // needs the boolean, light/mod.rs:30-37; the first accepted candidate is the same in both modes).
+template <bool ANIM>
 TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, HitRec& rec) {
     const TrayBvhNode* __restrict__ tree = sc.top_nodes;
     f3 o = ray.o, d = ray.d;
@@ -326,8 +345,16 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
             uint32_t i = sc.top_order[e & ~STK_KIND_MASK];
             const TrayInstance* __restrict__ in = sc.instances + i;
             if (in->kind == TRAY_INST_POINT_EMITTER) continue;   // emitter.rs:120
-            f3 lo_ = xf_point(in->inv, ray.o);
-            f3 ld = xf_vector(in->inv, ray.d);
+            f3 lo_, ld;
+            if (ANIM && in->animated) {   // transform.transform(ray.time) per visit (receiver.rs:30)
+                float x[24];
+                eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, ray.time, x);
+                lo_ = xf_point_affine(x + 12, ray.o);
+                ld = xf_vector(x + 12, ray.d);
+            } else {
+                lo_ = xf_point(in->inv, ray.o);
+                ld = xf_vector(in->inv, ray.d);
+            }
             uint32_t gt = in->geom_type;
             if (gt == TRAY_GEOM_MESH) {
                 const TrayMesh m = sc.meshes[in->mesh_id];
@@ -365,21 +392,33 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
 // Scene::intersect (scene.rs:148-150). The tile kernel calls this from exactly one site (every
 // lane traces one ray per step of its phase machine), so it is inlined there.
 struct TraceResult { HitRec rec; bool hit; };
+template <bool ANIM>
 TR_DEV TraceResult trace(const DevScene* __restrict__ scp, uint32_t* __restrict__ stack, Ray ray, bool any_hit) {
     const DevScene& sc = *scp;
     TraceResult r;
     r.rec.t = 0.0f; r.rec.inst = 0xffffffffu; r.rec.prim = 0u; r.rec.b1 = 0.0f; r.rec.b2 = 0.0f;
-    if (sc.n_instances <= TR_FLAT_MAX) r.hit = trace_flat(sc, stack, ray, any_hit, r.rec);
-    else r.hit = trace_bvh(sc, stack, ray, any_hit, r.rec);
+    // moving scenes always take BVH<Instance>: its boxes are the reference's swept bounds (animated_transform.rs:58-71),
+    // including the instances those bounds cut off, which the flat loop would not reproduce
+    if (!ANIM && sc.n_instances <= TR_FLAT_MAX) r.hit = trace_flat(sc, stack, ray, any_hit, r.rec);
+    else r.hit = trace_bvh<ANIM>(sc, stack, ray, any_hit, r.rec);
     return r;
 }
 
 // Rebuilds the DifferentialGeometry of the final candidate in object space and moves it to world
 // space (receiver.rs:36-42; DifferentialGeometry::{new,with_normal} differential_geometry.rs:32-64).
+template <bool ANIM>
 TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, float* uv_out = nullptr, f3* dp_dv_out = nullptr) {
     const TrayInstance* __restrict__ in = sc.instances + rec.inst;
-    f3 o = xf_point(in->inv, ray.o);
-    f3 d = xf_vector(in->inv, ray.d);
+    float x[24];
+    f3 o, d;
+    if (ANIM) {
+        instance_xf_at(sc, in, ray.time, x);
+        o = xf_point_affine(x + 12, ray.o);
+        d = xf_vector(x + 12, ray.d);
+    } else {
+        o = xf_point(in->inv, ray.o);
+        d = xf_vector(in->inv, ray.d);
+    }
     f3 p = o + d * rec.t;
     f3 n, ng, dp_du, dp_dv;
     float u = 0.0f, v = 0.0f;
@@ -442,25 +481,36 @@ TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, flo
         ng = normalized(mk(0.0f, 0.0f, 1.0f));
     }
     Hit h;
-    h.p = xf_point(in->mat, p);
-    h.n = xf_normal_t(in->inv, n);
-    h.ng = xf_normal_t(in->inv, ng);
-    h.dp_du = xf_vector(in->mat, dp_du);
+    if (ANIM) {
+        h.p = xf_point_affine(x, p);
+        h.n = xf_normal_t(x + 12, n);
+        h.ng = xf_normal_t(x + 12, ng);
+        h.dp_du = xf_vector(x, dp_du);
+        if (dp_dv_out) *dp_dv_out = xf_vector(x, dp_dv);
+    } else {
+        h.p = xf_point(in->mat, p);
+        h.n = xf_normal_t(in->inv, n);
+        h.ng = xf_normal_t(in->inv, ng);
+        h.dp_du = xf_vector(in->mat, dp_du);
+        if (dp_dv_out) *dp_dv_out = xf_vector(in->mat, dp_dv);
+    }
     h.inst = rec.inst;
     if (uv_out) { uv_out[0] = u; uv_out[1] = v; }
-    if (dp_dv_out) *dp_dv_out = xf_vector(in->mat, dp_dv);
     return h;
 }
 
 // Geometry normal of the final candidate only (what estimate_direct's BSDF half needs from the hit,
 // mod.rs:159): same arithmetic as finish_hit restricted to ng.
+template <bool ANIM>
 TR_DEV f3 finish_hit_ng(const DevScene& sc, const Ray& ray, const HitRec& rec) {
     const TrayInstance* __restrict__ in = sc.instances + rec.inst;
     uint32_t gt = in->geom_type;
     f3 ng;
+    float x[24];
+    if (ANIM) instance_xf_at(sc, in, ray.time, x);
     if (gt == TRAY_GEOM_SPHERE) {
-        f3 o = xf_point(in->inv, ray.o);
-        f3 d = xf_vector(in->inv, ray.d);
+        f3 o = ANIM ? xf_point_affine(x + 12, ray.o) : xf_point(in->inv, ray.o);
+        f3 d = ANIM ? xf_vector(x + 12, ray.d) : xf_vector(in->inv, ray.d);
         ng = normalized(o + d * rec.t);
     } else if (gt == TRAY_GEOM_MESH) {
         const float4* aq = reinterpret_cast<const float4*>(sc.tri_attrs + rec.prim);
@@ -472,7 +522,7 @@ TR_DEV f3 finish_hit_ng(const DevScene& sc, const Ray& ray, const HitRec& rec) {
     } else {
         ng = normalized(mk(0.0f, 0.0f, 1.0f));
     }
-    return xf_normal_t(in->inv, ng);
+    return ANIM ? xf_normal_t(x + 12, ng) : xf_normal_t(in->inv, ng);
 }
 
 // ---- Sampleable (object space) -------------------------------------------------------------

@@ -21,16 +21,27 @@
 
 namespace tr {
 
+template <bool ANIM>
 TR_DEV Ray camera_ray(const DevScene& sc, float px, float py, float time) {
     const TrayCamera& c = sc.camera;
     f3 q = xf_point(c.raster_to_cam, mk(px, py, 0.0f));
     f3 px_pos = mk(c.scaling[0], c.scaling[1], c.scaling[2]) * q;
     f3 d = normalized(px_pos);
-    (void)time;   // frame_time only selects the (unanimated) camera / instance transforms
+    // with a closed shutter (or nothing moving) frame_time is the same for every ray and only selects transforms
+    // the host evaluated already
+    const float frame_time = (c.shutter_close - c.shutter_open) * time + c.shutter_open;
     Ray r;
-    r.o = xf_point(c.cam_world, mk(0.0f, 0.0f, 0.0f));
-    r.d = xf_vector(c.cam_world, d);
+    if (ANIM && c.animated) {   // cam_world.transform(frame_time) * Ray (camera.rs:156)
+        float x[24];
+        eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, c.xf_first, c.xf_count, frame_time, x);
+        r.o = xf_point_affine(x, mk(0.0f, 0.0f, 0.0f));
+        r.d = xf_vector(x, d);
+    } else {
+        r.o = xf_point(c.cam_world, mk(0.0f, 0.0f, 0.0f));
+        r.d = xf_vector(c.cam_world, d);
+    }
     r.min_t = 0.0f; r.max_t = TR_INF;
+    r.time = frame_time;
     return r;
 }
 
@@ -44,10 +55,17 @@ TR_DEV void pixel_sample(uint32_t kp, uint32_t s, uint32_t spp, uint32_t px, uin
 
 TR_DEV float rr_draw(uint32_t ks, uint32_t bounce) { return (float)(draw(ks, SD_RR + bounce) >> 8) / 16777216.0f; }   // Rng::next_f32
 
-TR_DEV f3 inst_emission(const TrayInstance* __restrict__ in) { return mk(in->emission[0], in->emission[1], in->emission[2]); }
+// self.emission.color(time): the host stores color(shutter_open); keys are only present when the colour moves while the
+// shutter is open
+template <bool ANIM>
+TR_DEV f3 inst_emission(const DevScene& sc, const TrayInstance* __restrict__ in, float time) {
+    if (ANIM && in->emis_count >= 2u) return color_keys_at(sc.color_keys + in->emis_first, in->emis_count, time);
+    return mk(in->emission[0], in->emission[1], in->emission[2]);
+}
 // Emitter::radiance (emitter.rs:140-142)
-TR_DEV f3 emitter_radiance(const TrayInstance* __restrict__ in, f3 w, f3 n) {
-    return dot(w, n) > 0.0f ? inst_emission(in) : mk(0.0f, 0.0f, 0.0f);
+template <bool ANIM>
+TR_DEV f3 emitter_radiance(const DevScene& sc, const TrayInstance* __restrict__ in, f3 w, f3 n, float time) {
+    return dot(w, n) > 0.0f ? inst_emission<ANIM>(sc, in, time) : mk(0.0f, 0.0f, 0.0f);
 }
 
 enum : uint32_t {
@@ -64,6 +82,7 @@ struct Lane {
     uint32_t flags;
     uint32_t bounce;       // index of the path vertex being shaded
     uint32_t ks;           // sample key: scrambles and shuffle entries of the six LD arrays derive from it
+    float time;            // ray.time of the camera ray, inherited by every ray of the path (path.rs:110, mod.rs:154)
     f3 o, d;               // stage A ray: camera ray, or continuation from the previous vertex
     f3 throughput, illum;
     f3 first_ng;           // hit.dg.ng of the camera ray's hit (quirk Q1)
@@ -83,6 +102,7 @@ TR_DEV void lane_start_sample(Lane& ln, const Ray& cam_ray, uint32_t ks) {
     ln.bounce = 0u;
     ln.ks = ks;
     ln.o = cam_ray.o; ln.d = cam_ray.d;
+    ln.time = cam_ray.time;
     ln.throughput = mk(1.0f, 1.0f, 1.0f);
     ln.illum = mk(0.0f, 0.0f, 0.0f);
 }
@@ -102,31 +122,35 @@ TR_DEV Ray stage_a_ray(const Lane& ln) {
     r.o = ln.o; r.d = ln.d;
     r.min_t = ln.bounce == 0u ? 0.0f : 0.001f;   // camera ray (ray.rs:25-27) vs ray.min_t = 0.001 (path.rs:110)
     r.max_t = TR_INF;
+    r.time = ln.time;
     return r;
 }
 TR_DEV Ray stage_b_ray(const Lane& ln) {   // OcclusionTester::test_points (light/mod.rs:21-23): unnormalised segment (quirk Q4)
     Ray r;
     r.o = ln.bsdf.p; r.d = ln.aux_d; r.min_t = 0.001f; r.max_t = 0.999f;
+    r.time = ln.time;
     return r;
 }
 TR_DEV Ray stage_c_ray(const Lane& ln) {   // Ray::segment(p, w_i, 0.001, inf) (mod.rs:154)
     Ray r;
     r.o = ln.bsdf.p; r.d = ln.aux_d; r.min_t = 0.001f; r.max_t = TR_INF;
+    r.time = ln.time;
     return r;
 }
 
 // Stage A, after the ray hit: head of the loop body of Path::illumination (path.rs:69-79) and the light
 // sample of estimate_direct (mod.rs:106-127). Sets LF_SHADOW when an occlusion ray has to be traced.
+template <bool ANIM>
 TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counters& cnt) {
     cnt.vertices++;
     const Ray ray = stage_a_ray(ln);
-    Hit hit = finish_hit(sc, ray, rec);
+    Hit hit = finish_hit<ANIM>(sc, ray, rec);
     if (ln.bounce == 0u) ln.first_ng = hit.ng;
     const TrayInstance* __restrict__ inst = sc.instances + hit.inst;
     if (ln.bounce == 0u || (ln.flags & LF_SPECULAR)) {
         if (inst->kind != TRAY_INST_RECEIVER) {
             f3 w = -ln.d;
-            ln.illum = ln.illum + ln.throughput * emitter_radiance(inst, w, ln.first_ng);
+            ln.illum = ln.illum + ln.throughput * emitter_radiance<ANIM>(sc, inst, w, ln.first_ng, ln.time);
         }
     }
     ln.bsdf = make_bsdf(sc, hit);
@@ -143,23 +167,25 @@ TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counte
     const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
     // Light::sample_incident (emitter.rs:165-186)
     f3 p_w;
+    float x[24];   // ANIM: self.transform.transform(time) (emitter.rs:168,175)
+    if (ANIM) instance_xf_at(sc, light, ln.time, x);
     if (light->kind == TRAY_INST_POINT_EMITTER) {
-        f3 pos = xf_point(light->mat, mk(0.0f, 0.0f, 0.0f));
+        f3 pos = ANIM ? xf_point_affine(x, mk(0.0f, 0.0f, 0.0f)) : xf_point(light->mat, mk(0.0f, 0.0f, 0.0f));
         ln.wi_l = normalized(pos - ln.bsdf.p);
-        ln.li = inst_emission(light) / length_sqr(pos - ln.bsdf.p);
+        ln.li = inst_emission<ANIM>(sc, light, ln.time) / length_sqr(pos - ln.bsdf.p);
         ln.pdf_l = 1.0f;
         p_w = pos;
     } else {
         float l2x, l2y;
         lane_2d(sc, ln, SD_L2, l2x, l2y);
-        f3 p_l = xf_point(light->inv, ln.bsdf.p);
+        f3 p_l = ANIM ? xf_point_affine(x + 12, ln.bsdf.p) : xf_point(light->inv, ln.bsdf.p);
         f3 p_sampled, normal;
         geom_sample(light, p_l, l2x, l2y, p_sampled, normal);
         f3 w_il = normalized(p_sampled - p_l);
         ln.pdf_l = geom_pdf(light, p_l, w_il);
-        ln.li = emitter_radiance(light, -w_il, normal);
-        p_w = xf_point(light->mat, p_sampled);
-        ln.wi_l = xf_vector(light->mat, w_il);
+        ln.li = emitter_radiance<ANIM>(sc, light, -w_il, normal, ln.time);
+        p_w = ANIM ? xf_point_affine(x, p_sampled) : xf_point(light->mat, p_sampled);
+        ln.wi_l = ANIM ? xf_vector(x, w_il) : xf_vector(light->mat, w_il);
     }
     if (ln.pdf_l > 0.0f && !is_black(ln.li)) {
         ln.aux_d = p_w - ln.bsdf.p;
@@ -172,6 +198,7 @@ TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counte
 //   WANT_MIS    BSDF half of estimate_direct (mod.rs:141-153), may set LF_MIS (ray for stage C)
 //   WANT_PATH   path continuation (path.rs:84-110): next stage A ray, or LF_LAST
 // Returns the follow-up query.
+template <bool ANIM>
 TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
     const bool is_light = want == WANT_LIGHT, mis = want == WANT_MIS;
     const uint32_t flags = want == WANT_PATH ? BX_ALL : BX_NON_SPECULAR;
@@ -207,8 +234,16 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
             float w = 1.0f;
             if (!(h.sampled_type & BX_SPECULAR)) {
                 // Light::pdf (emitter.rs:193-203)
-                f3 p_l = xf_point(light->inv, ln.bsdf.p);
-                f3 wl = normalized(xf_vector(light->inv, w_i));
+                f3 p_l, wl;
+                if (ANIM) {
+                    float x[24];
+                    instance_xf_at(sc, light, ln.time, x);
+                    p_l = xf_point_affine(x + 12, ln.bsdf.p);
+                    wl = normalized(xf_vector(x + 12, w_i));
+                } else {
+                    p_l = xf_point(light->inv, ln.bsdf.p);
+                    wl = normalized(xf_vector(light->inv, w_i));
+                }
                 float pl = geom_pdf(light, p_l, wl);
                 if (pl == 0.0f) return WANT_PATH;   // `return direct_light` (mod.rs:146-148)
                 w = power_heuristic(1.0f, pdf, 1.0f, pl);
@@ -237,21 +272,23 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
 }
 
 // Stage B after the occlusion ray: all BSDF queries of the vertex
+template <bool ANIM>
 TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
     const bool delta = sc.instances[ln.light_inst].kind == TRAY_INST_POINT_EMITTER;
     uint32_t want = ((ln.flags & LF_SHADOW) && !occluded) ? WANT_LIGHT : (delta ? WANT_PATH : WANT_MIS);
 #pragma nounroll
-    for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) want = query_stage(sc, ln, want);   // LIGHT -> MIS -> PATH
+    for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) want = query_stage<ANIM>(sc, ln, want);   // LIGHT -> MIS -> PATH
 }
 
 // Stage C: tail of the BSDF half of estimate_direct (mod.rs:154-166), then path.rs:82 and the
 // bookkeeping for the next vertex. Returns false when the camera sample is finished.
+template <bool ANIM>
 TR_DEV bool vertex_end(const DevScene& sc, Lane& ln, bool mis_hit, const HitRec& rec) {
     if ((ln.flags & LF_MIS) && mis_hit && rec.inst == ln.light_inst) {   // same emitter object (mod.rs:157-160)
         const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
         const Ray r = stage_c_ray(ln);
-        f3 ng = finish_hit_ng(sc, r, rec);
-        f3 li2 = emitter_radiance(light, -ln.aux_d, ng);
+        f3 ng = finish_hit_ng<ANIM>(sc, r, rec);
+        f3 li2 = emitter_radiance<ANIM>(sc, light, -ln.aux_d, ng, ln.time);
         if (!is_black(li2)) ln.direct = ln.direct + ln.mis_f * li2 * ln.li.x * ln.li.y / ln.li.z;
     }
     ln.illum = ln.illum + ln.t_vertex * ln.direct;   // path.rs:82

@@ -198,6 +198,7 @@ __device__ __forceinline__ void film_splat_rows_global(const DevScene& sc, float
 
 // Work item w (0 <= w < n_work) maps to queue entry (w / chunk) * chunk_stride * chunk + (w % chunk):
 // contiguous ranges use chunk_stride = 1; multi-GPU sharding interleaves chunks round-robin.
+template <bool ANIM>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const DevScene scv, const uint2* __restrict__ tiles, uint32_t tile_count,
                                                          uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf,
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ counter,
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
                 if (s_next < spp) {
                     float t;
                     pixel_sample(kp, s_next, spp, px, py, sx, sy, t);
-                    lane_start_sample(ln, camera_ray(sc, sx, sy, t), key_sample(kp, s_next));
+                    lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), key_sample(kp, s_next));
                     s_next += TR_BLOCK / 64;
                     ++n_samples;
                     pending = true;
@@ -268,17 +269,17 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
                     if (want_ray) {
                         cnt.rays++;
                         const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
-                        tr_ = trace(scp, my_stack, r, stage == 1);
+                        tr_ = trace<ANIM>(scp, my_stack, r, stage == 1);
                     }
                 }
                 if (alive) {
                     if (stage == 0) {
-                        if (tr_.hit) vertex_begin(sc, ln, tr_.rec, cnt);
+                        if (tr_.hit) vertex_begin<ANIM>(sc, ln, tr_.rec, cnt);
                         else ln.flags &= ~LF_ALIVE;   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
                     } else if (stage == 1) {
-                        vertex_queries(sc, ln, tr_.hit);
+                        vertex_queries<ANIM>(sc, ln, tr_.hit);
                     } else {
-                        if (!vertex_end(sc, ln, tr_.hit, tr_.rec)) ln.flags &= ~LF_ALIVE;
+                        if (!vertex_end<ANIM>(sc, ln, tr_.hit, tr_.rec)) ln.flags &= ~LF_ALIVE;
                     }
                 }
             }
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
 }
 
 // ---- parity / debug kernels: the same device functions, one thread per item -------------------
+template <bool ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene scv, uint32_t n, const TrayRay* __restrict__ rays,
                                                               TrayHit* __restrict__ hits) {
     extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries, sized per scene at launch
@@ -323,15 +325,15 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene scv
     Ray r;
     r.o = mk(rays[i].o[0], rays[i].o[1], rays[i].o[2]);
     r.d = mk(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
-    r.min_t = rays[i].min_t; r.max_t = rays[i].max_t;
+    r.min_t = rays[i].min_t; r.max_t = rays[i].max_t; r.time = rays[i].time;
     TrayHit o;
     memset(&o, 0, sizeof o);
-    TraceResult tr_ = trace(scp, s_stack + threadIdx.x, r, false);
+    TraceResult tr_ = trace<ANIM>(scp, s_stack + threadIdx.x, r, false);
     const HitRec rec = tr_.rec;
     if (tr_.hit) {
         float uv[2];
         f3 dp_dv;
-        Hit h = finish_hit(sc, r, rec, uv, &dp_dv);
+        Hit h = finish_hit<ANIM>(sc, r, rec, uv, &dp_dv);
         o.t = rec.t; o.inst = rec.inst; o.prim = rec.prim;
         o.p[0] = h.p.x; o.p[1] = h.p.y; o.p[2] = h.p.z;
         o.n[0] = h.n.x; o.n[1] = h.n.y; o.n[2] = h.n.z;
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene scv
 
 // thread_work's inner loop body for individual (pixel, sample) items (multithreaded.rs:94-103),
 // driven through the same lane machine as the tile kernel
+template <bool ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevScene scv, uint32_t n, const uint32_t* __restrict__ px,
                                                                     const uint32_t* __restrict__ py, const uint32_t* __restrict__ si,
                                                                     uint32_t spp, uint32_t kf, float* __restrict__ out) {
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
     float sx, sy, t;
     pixel_sample(kp, si[i], spp, px[i], py[i], sx, sy, t);
     Lane ln;
-    lane_start_sample(ln, camera_ray(sc, sx, sy, t), key_sample(kp, si[i]));
+    lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), key_sample(kp, si[i]));
     uint32_t* const my_stack = s_stack + threadIdx.x;
     while (ln.flags & LF_ALIVE) {
 #pragma nounroll
@@ -374,16 +377,16 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
             if (want_ray) {
                 cnt.rays++;
                 const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
-                tr_ = trace(scp, my_stack, r, stage == 1);
+                tr_ = trace<ANIM>(scp, my_stack, r, stage == 1);
             }
             if (alive) {
                 if (stage == 0) {
-                    if (tr_.hit) vertex_begin(sc, ln, tr_.rec, cnt);
+                    if (tr_.hit) vertex_begin<ANIM>(sc, ln, tr_.rec, cnt);
                     else ln.flags &= ~LF_ALIVE;
                 } else if (stage == 1) {
-                    vertex_queries(sc, ln, tr_.hit);
+                    vertex_queries<ANIM>(sc, ln, tr_.hit);
                 } else {
-                    if (!vertex_end(sc, ln, tr_.hit, tr_.rec)) ln.flags &= ~LF_ALIVE;
+                    if (!vertex_end<ANIM>(sc, ln, tr_.hit, tr_.rec)) ln.flags &= ~LF_ALIVE;
                 }
             }
         }
@@ -441,6 +444,7 @@ struct TrayDeviceScene {
     uint32_t n_chunks = 0;
     uint32_t stack_bytes = 0;   // dynamic LDS of every kernel that traverses: stack depth x TR_BLOCK x 4
     bool wavefront = false;   // TRAYHIP_MODE=wave selects the stage-kernel schedule (wavefront.h)
+    bool animated = false;    // something moves while the shutter is open: the <ANIM = true> kernels run
 };
 
 static thread_local int g_device = 0;
@@ -513,9 +517,27 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         return TRAY_E_UNSUPPORTED;
     }
     if (f->max_depth > 15) { set_error("pathtracer max_depth > 15 is not supported"); return TRAY_E_UNSUPPORTED; }
-    if (f->camera.animated) { set_error("animated cameras are not supported yet (SURVEY 8f)"); return TRAY_E_UNSUPPORTED; }
+    auto stack_ok = [&](uint32_t first, uint32_t count, bool moving) {   // spline stacks the device evaluates per ray
+        if ((uint64_t)first + count > f->n_xf_levels) return false;
+        for (uint32_t l = 0; moving && l < count; ++l) {
+            const TrayXformLevel& lv = f->xf_levels[first + l];
+            if (lv.kf_count < 2) continue;
+            if (lv.degree > 3 || lv.knot_count != lv.kf_count + lv.degree + 1 || (uint64_t)lv.kf_first + lv.kf_count > f->n_keyframes ||
+                (uint64_t)lv.knot_first + lv.knot_count > f->n_knots) return false;
+        }
+        return true;
+    };
+    if (!stack_ok(f->camera.xf_first, f->camera.xf_count, f->camera.animated != 0)) {
+        set_error("camera keyframes: the device evaluates B-splines of degree <= 3 with consistent knot vectors"); return TRAY_E_UNSUPPORTED;
+    }
+    bool moving = f->camera.animated != 0;
     for (uint32_t i = 0; i < f->n_instances; ++i) {
         const TrayInstance& in = f->instances[i];
+        if (!stack_ok(in.xf_first, in.xf_count, in.animated != 0)) {
+            set_error("instance keyframes: the device evaluates B-splines of degree <= 3 with consistent knot vectors"); return TRAY_E_UNSUPPORTED;
+        }
+        if (in.emis_count && (uint64_t)in.emis_first + in.emis_count > f->n_color_keys) { set_error("instance references missing colour keys"); return TRAY_E_INVALID; }
+        moving = moving || in.animated != 0 || in.emis_count >= 2;
         if (in.kind != TRAY_INST_POINT_EMITTER && in.material_id >= f->n_materials) { set_error("instance references a missing material"); return TRAY_E_INVALID; }
         if (in.geom_type == TRAY_GEOM_MESH && in.mesh_id >= f->n_meshes) { set_error("instance references a missing mesh"); return TRAY_E_INVALID; }
     }
@@ -551,7 +573,12 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     UP(filter_table, &f->film.table[0], TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE)
     UP(filter_x, &f->film.table_x[0], TRAY_FILTER_TABLE_SIZE)
     UP(filter_y, &f->film.table_y[0], TRAY_FILTER_TABLE_SIZE)
+    UP(xf_levels, f->xf_levels, f->n_xf_levels)
+    UP(keyframes, f->keyframes, f->n_keyframes)
+    UP(knots, f->knots, f->n_knots)
+    UP(color_keys, f->color_keys, f->n_color_keys)
 #undef UP
+    s->animated = moving;
     if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
     s->n_materials = f->n_materials;
     d.n_instances = f->n_instances; d.n_lights = f->n_lights; d.min_depth = f->min_depth; d.max_depth = f->max_depth;
@@ -562,7 +589,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             for (int x = 0; x < TRAY_FILTER_TABLE_SIZE; ++x)
                 if (f->film.table[y * TRAY_FILTER_TABLE_SIZE + x] != f->film.table_x[x] * f->film.table_y[y]) { ok = false; break; }
         d.film_rows = (ok && !getenv("TRAYHIP_DIRECT_FILM")) ? 1u : 0u;
-        if (const char* m = getenv("TRAYHIP_MODE")) s->wavefront = std::string(m) == "wave";
+        if (const char* m = getenv("TRAYHIP_MODE")) s->wavefront = std::string(m) == "wave" && !s->animated;
     }
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
@@ -613,25 +640,30 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         for (uint32_t m = 0; m < f->n_meshes; ++m)
             mesh_depth = std::max(mesh_depth, depth_of(f->mesh_nodes + f->meshes[m].node_offset, f->meshes[m].node_count));
         uint32_t depth = mesh_depth + 1;
-        if (f->n_instances > TR_FLAT_MAX) depth += depth_of(f->top_nodes, f->n_top_nodes) + 4 + 1;
+        if (f->n_instances > TR_FLAT_MAX || s->animated) depth += depth_of(f->top_nodes, f->n_top_nodes) + 4 + 1;
         depth = std::max(depth, 4u);
         if (depth > 96) { tray_scene_destroy(s); set_error("BVH too deep for the LDS traversal stack (" + std::to_string(depth) + " levels)"); return TRAY_E_UNSUPPORTED; }
         s->stack_bytes = depth * TR_BLOCK * (uint32_t)sizeof(uint32_t);
         if (s->stack_bytes > 32u * 1024u) {   // past the default dynamic-LDS window: raise the per-kernel limit (160 KB LDS per CU)
             const int bytes = (int)s->stack_bytes;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_intersect), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_sample_radiance), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_intersect<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_intersect<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_sample_radiance<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_sample_radiance<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipGetLastError();
         }
     }
     int per_cu = 0, cus = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) cus = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles, TR_BLOCK, s->stack_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    hipError_t occ = s->animated ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles<true>, TR_BLOCK, s->stack_bytes)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles<false>, TR_BLOCK, s->stack_bytes);
+    if (occ != hipSuccess || per_cu < 1) per_cu = 1;
     if (cus < 1) cus = 256;
     s->n_blocks = cus * per_cu;
     *out = s;
@@ -744,8 +776,12 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     if (s->wavefront) return launch_wavefront(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
     int blocks = (int)std::min<uint32_t>((uint32_t)s->n_blocks, tile_count);
     HIP_CHECK(hipEventRecord(s->ev0, stream));
-    hipLaunchKernelGGL(k_path_tiles, dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev,
-                       s->d_counter, s->d_stats);
+    if (s->animated)
+        hipLaunchKernelGGL(k_path_tiles<true>, dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf,
+                           rgbw_dev, s->d_counter, s->d_stats);
+    else
+        hipLaunchKernelGGL(k_path_tiles<false>, dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf,
+                           rgbw_dev, s->d_counter, s->d_stats);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(s->ev1, stream));
     s->timing_valid = true;
@@ -801,7 +837,8 @@ int tray_debug_intersect(TrayDeviceScene* s, uint32_t n, const TrayRay* rays, Tr
     hipError_t e = hipMalloc(&d_h, n * sizeof(TrayHit));
     if (e == hipSuccess) e = hipMemcpy(d_r, rays, n * sizeof(TrayRay), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_debug_intersect, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_r, d_h);
+        if (s->animated) hipLaunchKernelGGL(k_debug_intersect<true>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_r, d_h);
+        else hipLaunchKernelGGL(k_debug_intersect<false>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_r, d_h);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(hits, d_h, n * sizeof(TrayHit), hipMemcpyDeviceToHost);
@@ -831,7 +868,10 @@ int tray_debug_sample_radiance(TrayDeviceScene* s, uint32_t n, const uint32_t* p
         uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
         kf = mix(kf ^ (uint32_t)(seed >> 32));
         kf = mix(kf + s->dev.frame);
-        hipLaunchKernelGGL(k_debug_sample_radiance, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
+        if (s->animated)
+            hipLaunchKernelGGL(k_debug_sample_radiance<true>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
+        else
+            hipLaunchKernelGGL(k_debug_sample_radiance<false>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(out, d_out, 8 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost);

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace(const DevScene scv, WfPoo
         r.o = ld3(pool, F_P, i); r.d = ld3(pool, F_AUX, i);
         r.min_t = 0.001f; r.max_t = STAGE == 1 ? 0.999f : TR_INF;
     }
-    TraceResult t = trace(scp, s_stack + threadIdx.x, r, STAGE == 1);
+    TraceResult t = trace<false>(scp, s_stack + threadIdx.x, r, STAGE == 1);
     if (STAGE == 1) {
         flags = t.hit ? (flags | WF_OCCLUDED) : (flags & ~WF_OCCLUDED);
     } else {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
     rec.b1 = pf(pool, F_REC_B1, i); rec.b2 = pf(pool, F_REC_B2, i);
     Counters cnt;
     cnt.rays = 0; cnt.vertices = 0;
-    vertex_begin(sc, ln, rec, cnt);
+    vertex_begin<false>(sc, ln, rec, cnt);
     pu(pool, F_FLAGS, i) = ln.flags | WF_INVERTEX;
     st3(pool, F_ILLUM, i, ln.illum);
     if (ln.bounce == 0u) st3(pool, F_NG, i, ln.first_ng);
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPoo
     ln.direct = ld3(pool, F_DIRECT, i);
     ln.o = mk(0.0f, 0.0f, 0.0f); ln.d = mk(0.0f, 0.0f, 0.0f);
     ln.aux_d = mk(0.0f, 0.0f, 0.0f); ln.mis_f = mk(0.0f, 0.0f, 0.0f);
-    vertex_queries(sc, ln, (flags & WF_OCCLUDED) != 0u);
+    vertex_queries<false>(sc, ln, (flags & WF_OCCLUDED) != 0u);
     pu(pool, F_FLAGS, i) = ln.flags;
     st3(pool, F_T, i, ln.throughput);
     st3(pool, F_DIRECT, i, ln.direct);
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
                 rec.t = pf(pool, F_REC_T, i); rec.inst = pu(pool, F_REC_INST, i); rec.prim = pu(pool, F_REC_PRIM, i);
                 rec.b1 = pf(pool, F_REC_B1, i); rec.b2 = pf(pool, F_REC_B2, i);
             }
-            const bool cont = vertex_end(sc, ln, (flags & WF_HIT_C) != 0u, rec);
+            const bool cont = vertex_end<false>(sc, ln, (flags & WF_HIT_C) != 0u, rec);
             st3(pool, F_ILLUM, i, ln.illum);
             pu(pool, F_BOUNCE, i) = ln.bounce;
             flags = ln.flags & ~(WF_INVERTEX | WF_HIT_A | WF_HIT_C | WF_OCCLUDED | LF_SHADOW | LF_MIS | LF_LAST);
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
             const uint32_t kp = key_pixel(kf, py * sc.width + px);
             float sx, sy, t;
             pixel_sample(kp, s_next, spp, px, py, sx, sy, t);
-            const Ray cam = camera_ray(sc, sx, sy, t);
+            const Ray cam = camera_ray<false>(sc, sx, sy, t);
             pu(pool, F_SNEXT, i) = s_next + TR_BLOCK / 64;
             pu(pool, F_BOUNCE, i) = 0u;
             pu(pool, F_KS, i) = key_sample(kp, s_next);

@@ -29,7 +29,18 @@ using namespace trayh;
 extern "C" {
 
 const char* tray_last_error(void) { return g_error.c_str(); }
-const char* tray_version(void) { return "trayhip 0.1 (abi 1, gfx950)"; }
+const char* tray_version(void) { return "trayhip 0.2 (abi 2, gfx950)"; }
+
+uint32_t tray_abi_sizeof(const char* name) {
+    if (!name) return 0;
+    const std::string n(name);
+#define TRAY_SZ(T) if (n == #T) return (uint32_t)sizeof(T);
+    TRAY_SZ(TrayBvhNode) TRAY_SZ(TrayTriVerts) TRAY_SZ(TrayTriAttrs) TRAY_SZ(TrayMesh) TRAY_SZ(TrayInstance) TRAY_SZ(TrayKeyframe)
+    TRAY_SZ(TrayXformLevel) TRAY_SZ(TrayColorKey) TRAY_SZ(TrayMaterial) TRAY_SZ(TrayMerlTable) TRAY_SZ(TrayCamera) TRAY_SZ(TrayFilm)
+    TRAY_SZ(TrayFlatScene) TRAY_SZ(TraySceneInfo) TRAY_SZ(TrayKernelTiming) TRAY_SZ(TrayRay) TRAY_SZ(TrayHit)
+#undef TRAY_SZ
+    return 0;
+}
 
 int tray_block_queue(uint32_t width, uint32_t height, uint32_t select_start, uint32_t select_count,
                      uint32_t* xy, uint32_t cap, uint32_t* n_out) {

@@ -262,6 +262,77 @@ struct Keyframe {
     }
 };
 
+inline float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }   // linalg/mod.rs:51-53
+
+// quaternion.rs:101-113
+inline Quat slerp(float t, const Quat& a, const Quat& b) {
+    float cos_theta = qdot(a, b);
+    Quat q;
+    if (cos_theta > 0.9995f) {
+        q.v = (1.0f - t) * a.v + t * b.v;
+        q.w = (1.0f - t) * a.w + t * b.w;
+        float len = std::sqrt(qdot(q, q));
+        q.v = V3(q.v.x / len, q.v.y / len, q.v.z / len);
+        q.w = q.w / len;
+    } else {
+        float theta = std::acos(clampf(cos_theta, -1.0f, 1.0f));
+        float theta_t = theta * t;
+        Quat perp;
+        perp.v = b.v - a.v * cos_theta;
+        perp.w = b.w - a.w * cos_theta;
+        float len = std::sqrt(qdot(perp, perp));
+        perp.v = V3(perp.v.x / len, perp.v.y / len, perp.v.z / len);
+        perp.w = perp.w / len;
+        float c = std::cos(theta_t), sn = std::sin(theta_t);
+        q.v = a.v * c + perp.v * sn;
+        q.w = a.w * c + perp.w * sn;
+    }
+    return q;
+}
+
+// bspline::Interpolate for Keyframe (keyframe.rs:66-73)
+inline Keyframe kf_interpolate(const Keyframe& a, const Keyframe& b, float t) {
+    Keyframe k;
+    k.translation = (1.0f - t) * a.translation + t * b.translation;
+    k.rotation = slerp(t, a.rotation, b.rotation);
+    k.scaling = (1.0f - t) * a.scaling + t * b.scaling;
+    return k;
+}
+
+// bspline 0.2.2 (crates.io; not vendored under /root/reference): BSpline::point = locate the knot span with an
+// upper-bound binary search, clamp it to [degree, n_knots - degree - 1], then iterative de Boor with
+// alpha = (t - knots[i-1]) / (knots[i+degree-k] - knots[i-1]). Restated from the published algorithm: parity unpinned.
+inline size_t bspline_span(const float* knots, size_t n_knots, size_t degree, float t) {
+    size_t first = 0;
+    long count = (long)n_knots;
+    while (count > 0) {   // first index with knots[i] > t
+        long step = count / 2;
+        size_t it = first + (size_t)step;
+        if (!(t < knots[it])) { first = it + 1; count -= step + 1; }
+        else count = step;
+    }
+    size_t hi = n_knots - degree - 1;
+    if (first == n_knots) return hi;
+    if (first == 0) return degree;
+    if (first >= hi) return hi;
+    return first;
+}
+template <class T, class Lerp>
+inline T bspline_point(const T* pts, const float* knots, size_t n_knots, size_t degree, float t, Lerp&& interpolate) {
+    size_t i_start = bspline_span(knots, n_knots, degree, t);
+    T tmp[8];   // degree <= 7 (checked by the loader)
+    for (size_t j = 0; j <= degree; ++j) tmp[j] = pts[j + i_start - degree - 1];
+    for (size_t lvl = 0; lvl < degree; ++lvl) {
+        size_t k = lvl + 1;
+        for (size_t j = 0; j < degree - lvl; ++j) {
+            size_t i = j + k + i_start - degree;
+            float alpha = (t - knots[i - 1]) / (knots[i + degree - k] - knots[i - 1]);
+            tmp[j] = interpolate(tmp[j], tmp[j + 1], alpha);
+        }
+    }
+    return tmp[0];
+}
+
 // Symmetric 3x3 eigen-decomposition (cyclic Jacobi, f64): a = V diag(d) V^T
 inline void jacobi_eig3(double a[3][3], double v[3][3], double d[3]) {
     for (int i = 0; i < 3; ++i)

@@ -55,11 +55,28 @@ struct AnimXform {
         for (auto& l : levels) if (l.kfs.size() > 1) return true;
         return false;
     }
-    // AnimatedTransform::transform for a stack of single-control-point splines
-    Xform static_transform() const {
+    // AnimatedTransform::transform (animated_transform.rs:40-56)
+    Xform transform(float time) const {
         Xform t = Xform::identity();
-        for (auto& l : levels) t = l.kfs[0].transform() * t;
+        for (auto& l : levels) {
+            if (l.kfs.size() == 1) { t = l.kfs[0].transform() * t; continue; }
+            size_t nk = l.knots.size();
+            float lo = l.knots[l.degree], hi = l.knots[nk - 1 - l.degree];   // BSpline::knot_domain
+            float t_val = clampf(time, lo, hi);
+            Keyframe k = bspline_point(l.kfs.data(), l.knots.data(), nk, l.degree, t_val, kf_interpolate);
+            t = k.transform() * t;
+        }
         return t;
+    }
+    // AnimatedTransform::animation_bounds (animated_transform.rs:58-71): 128 time samples, only when EVERY level is animated
+    BBox animation_bounds(const BBox& b, float start, float end) const {
+        if (!is_animated()) return transform(start).bbox(b);
+        BBox ret;
+        for (int i = 0; i < 128; ++i) {
+            float time = lerpf((float)i / 127.0f, start, end);
+            ret = ret.box_union(transform(time).bbox(b));
+        }
+        return ret;
     }
 };
 
@@ -87,6 +104,8 @@ struct HostCamera {
     AnimXform cam_world;
     float fov = 0;
     bool animated_fov = false;
+    std::vector<float> fovs, fov_knots;   // CameraFov::Animated(BSpline<f32>)
+    uint32_t fov_degree = 0;
     float shutter_size = 0.5f;
     uint32_t active_at = 0;
 };
@@ -120,6 +139,7 @@ struct TrayHostScene {
     std::vector<TrayXformLevel> f_levels;
     std::vector<TrayKeyframe> f_keyframes;
     std::vector<float> f_knots;
+    std::vector<TrayColorKey> f_color_keys;
 };
 
 namespace trayh {
@@ -267,7 +287,12 @@ static AnimXform load_keyframes(const Json& e) {   // scene.rs:825-850 + Animate
         if (!d->as_u64(u)) fail(TRAY_E_PARSE, "Curve degree must be a positive integer");
         l.degree = (uint32_t)u;
     }
-    if (l.kfs.empty()) fail(TRAY_E_PARSE, "keyframes need at least one control point");
+    // BSpline::new (bspline 0.2.2): panics restated as load errors; knots are sorted
+    if (l.kfs.size() <= l.degree) fail(TRAY_E_INVALID, "Too few control points for curve");
+    if (l.knots.size() != l.kfs.size() + l.degree + 1)
+        fail(TRAY_E_INVALID, "Invalid number of knots, got " + std::to_string(l.knots.size()) + ", expected " + std::to_string(l.kfs.size() + l.degree + 1));
+    if (l.degree > 7) fail(TRAY_E_UNSUPPORTED, "B-spline keyframes of degree > 7 are not supported");
+    std::sort(l.knots.begin(), l.knots.end());
     for (size_t i = 1; i < l.kfs.size(); ++i)   // shortest-arc flip, animated_transform.rs:26-31
         if (qdot(l.kfs[i - 1].rotation, l.kfs[i].rotation) < 0.0f) {
             l.kfs[i].rotation.v = -l.kfs[i].rotation.v;
@@ -379,11 +404,21 @@ static HostCamera load_camera(const Json& e) {   // scene.rs:251-293
         c.cam_world = AnimXform::unanimated(Xform::look_at(pos, target, up));
     }
     const Json& fov = need(e, "fov", "The camera must specify a field of view");
-    if (fov.is_array()) {
-        c.animated_fov = true;   // camera.rs:97-125, outside the hot-path scope
-        double d = 0;
-        if (fov.arr.empty() || !fov.arr[0].as_f64(d)) fail(TRAY_E_PARSE, "fovs must be a number");
-        c.fov = (float)d;
+    if (fov.is_array()) {   // Camera::animated_fov (camera.rs:97-125): BSpline<f32> sampled once per frame (camera.rs:130-141)
+        c.animated_fov = true;
+        const Json& kn = need(e, "fov_knots", "Animated field of view must specify spline knots");
+        if (!kn.is_array()) fail(TRAY_E_PARSE, "Fov spline knots must be an array");
+        unsigned long long deg;
+        if (!need(e, "fov_spline_degree", "Animated fov spline must have degree").as_u64(deg)) fail(TRAY_E_PARSE, "Animated fov spline degree must be a u64");
+        for (auto& v : fov.arr) { double d; if (!v.as_f64(d)) fail(TRAY_E_PARSE, "fovs must be a number"); c.fovs.push_back((float)d); }
+        for (auto& v : kn.arr) { double d; if (!v.as_f64(d)) fail(TRAY_E_PARSE, "fov knots must be a number"); c.fov_knots.push_back((float)d); }
+        c.fov_degree = (uint32_t)deg;
+        if (c.fovs.size() <= c.fov_degree) fail(TRAY_E_INVALID, "Too few control points for curve");
+        if (c.fov_knots.size() != c.fovs.size() + c.fov_degree + 1)
+            fail(TRAY_E_INVALID, "Invalid number of knots, got " + std::to_string(c.fov_knots.size()) + ", expected " + std::to_string(c.fovs.size() + c.fov_degree + 1));
+        if (c.fov_degree > 7) fail(TRAY_E_UNSUPPORTED, "B-spline keyframes of degree > 7 are not supported");
+        std::sort(c.fov_knots.begin(), c.fov_knots.end());
+        c.fov = c.fovs[0];
     } else {
         double d;
         if (!fov.as_f64(d)) fail(TRAY_E_PARSE, "Camera fov must be a number");
@@ -791,7 +826,6 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
     if (n_active == 0) fail(TRAY_E_INVALID, "no camera is active at the requested frame");
     cam_idx = n_active - 1;
     const HostCamera& cam = s.cameras[cam_idx];
-    if (cam.animated_fov) fail(TRAY_E_UNSUPPORTED, "animated camera fov is outside the hot-path scope (SURVEY 8f)");
     float shutter_open = start;
     float shutter_close = start + cam.shutter_size * (end - start);   // camera.rs:127-129
 
@@ -812,6 +846,11 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
             tl.kf_first = (uint32_t)s.f_keyframes.size(); tl.kf_count = (uint32_t)l.kfs.size();
             tl.knot_first = (uint32_t)s.f_knots.size(); tl.knot_count = (uint32_t)l.knots.size();
             tl.degree = l.degree;
+            if (l.kfs.size() == 1) {
+                Xform kt = l.kfs[0].transform();
+                std::memcpy(tl.mat, kt.mat.m, sizeof tl.mat);
+                std::memcpy(tl.inv, kt.inv.m, sizeof tl.inv);
+            }
             for (auto& k : l.kfs) {
                 TrayKeyframe tk{};
                 for (int i = 0; i < 3; ++i) { tk.translation[i] = k.translation[i]; tk.rotation[i] = k.rotation.v[i]; tk.scaling[i] = k.scaling[i]; }
@@ -843,17 +882,25 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
         Xform proj_div_inv = Xform::from_mat(proj_div).inverse();
         Xform r2c = proj_div_inv * raster_screen;   // evaluated per ray in the reference (camera.rs:152)
         std::memcpy(c.raster_to_cam, r2c.mat.m, sizeof c.raster_to_cam);
-        float tan_fov = std::tan(to_radians(cam.fov) / 2.0f);
+        float fov = cam.fov;
+        if (cam.animated_fov) {   // Camera::update_frame (camera.rs:130-141): the spline at the middle of the frame
+            size_t nk = cam.fov_knots.size();
+            float t_mid = clampf((start + end) / 2.0f, cam.fov_knots[cam.fov_degree], cam.fov_knots[nk - 1 - cam.fov_degree]);
+            fov = bspline_point(cam.fovs.data(), cam.fov_knots.data(), nk, cam.fov_degree, t_mid,
+                                [](float a, float b, float t) { return a * (1.0f - t) + b * t; });   // bspline's blanket Interpolate
+        }
+        float tan_fov = std::tan(to_radians(fov) / 2.0f);
         c.scaling[0] = tan_fov; c.scaling[1] = tan_fov; c.scaling[2] = 1.0f;
         c.shutter_open = shutter_open; c.shutter_close = shutter_close;
-        c.animated = cam.cam_world.any_animated() ? 1u : 0u;
-        Xform cw = cam.cam_world.static_transform();
+        c.animated = (cam.cam_world.any_animated() && shutter_open != shutter_close) ? 1u : 0u;
+        Xform cw = cam.cam_world.transform(shutter_open);
         std::memcpy(c.cam_world, cw.mat.m, sizeof c.cam_world);
         push_levels(cam.cam_world, c.xf_first, c.xf_count);
     }
 
     // Instances, lights, top-level BVH over the shutter interval (scene.rs:171-175; receiver.rs:55-57)
-    s.f_instances.clear(); s.f_lights.clear();
+    s.f_instances.clear(); s.f_lights.clear(); s.f_color_keys.clear();
+    bool any_animated = f.camera.animated != 0;
     std::vector<BBox> inst_bounds;
     for (size_t i = 0; i < s.instances.size(); ++i) {
         const HostInstance& hi = s.instances[i];
@@ -862,24 +909,32 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
         std::memcpy(ti.geom_params, hi.geom_params, sizeof ti.geom_params);
         ti.light_index = 0xffffffffu;
         if (hi.kind != TRAY_INST_RECEIVER) {
-            if (hi.emission.size() > 1 && shutter_open != shutter_close)
-                fail(TRAY_E_UNSUPPORTED, "animated emission with an open shutter is a SURVEY 8f 'next' row (per-ray AnimatedColor)");
             color_at(hi.emission, shutter_open, ti.emission);
+            if (hi.emission.size() > 1 && shutter_open != shutter_close) {   // Emitter::radiance(.., time) per ray (emitter.rs:139-141)
+                ti.emis_first = (uint32_t)s.f_color_keys.size(); ti.emis_count = (uint32_t)hi.emission.size();
+                for (auto& k : hi.emission) {
+                    TrayColorKey ck{};
+                    std::memcpy(ck.color, k.c, sizeof ck.color);
+                    ck.time = k.time;
+                    s.f_color_keys.push_back(ck);
+                }
+                any_animated = true;
+            }
             ti.light_index = (uint32_t)s.f_lights.size();
             s.f_lights.push_back((uint32_t)i);
         }
-        if (hi.xf.any_animated() && shutter_open != shutter_close)
-            fail(TRAY_E_UNSUPPORTED, "animated instance transforms with an open shutter are a SURVEY 8f 'next' row (per-ray spline evaluation)");
-        if (hi.xf.any_animated())
-            fail(TRAY_E_UNSUPPORTED, "B-spline keyframe evaluation (bspline 0.2.2) is a SURVEY 8f 'next' row");
-        Xform t = hi.xf.static_transform();
+        // with a closed shutter every ray of the frame has time == shutter_open: the stack is evaluated once, here
+        ti.animated = (hi.xf.any_animated() && shutter_open != shutter_close) ? 1u : 0u;
+        if (ti.animated) any_animated = true;
+        Xform t = hi.xf.transform(shutter_open);
         std::memcpy(ti.mat, t.mat.m, sizeof ti.mat);
         std::memcpy(ti.inv, t.inv.m, sizeof ti.inv);
         push_levels(hi.xf, ti.xf_first, ti.xf_count);
         s.f_instances.push_back(ti);
-        inst_bounds.push_back(t.bbox(geom_bounds(s, hi)));   // animation_bounds of an unanimated stack (animated_transform.rs:59-61)
+        // Receiver/Emitter::bounds (receiver.rs:55-57, emitter.rs:151-160): swept over the shutter interval
+        inst_bounds.push_back(hi.xf.animation_bounds(geom_bounds(s, hi), shutter_open, shutter_close));
     }
-    if (f.camera.animated) fail(TRAY_E_UNSUPPORTED, "animated cameras are a SURVEY 8f 'next' row");
+    f.animated = any_animated ? 1u : 0u;
     BvhBuild top = build_bvh(inst_bounds, 4);   // BVH::new(4, instances, ..) scene.rs:141
     s.f_top_nodes = top.nodes;
     s.f_top_order = top.ordered;
@@ -909,6 +964,7 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
     f.n_xf_levels = (uint32_t)s.f_levels.size(); f.xf_levels = s.f_levels.data();
     f.n_keyframes = (uint32_t)s.f_keyframes.size(); f.keyframes = s.f_keyframes.data();
     f.n_knots = (uint32_t)s.f_knots.size(); f.knots = s.f_knots.data();
+    f.n_color_keys = (uint32_t)s.f_color_keys.size(); f.color_keys = s.f_color_keys.data();
 }
 
 template <class F>

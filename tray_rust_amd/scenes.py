@@ -255,6 +255,66 @@ def write_dragon_assets(directory, film=(1920, 1080, 2048), grid=660, material="
     return write_scene(dragon_scene(*film, material=material), os.path.join(directory, "dragon.json")), n
 
 
+# ---- moving scenes (BASELINE.json configs[4] is scenes/tr15.json, whose 25 models and 5 BRDFs are not
+# distributed). These builders use the same JSON features tr15.json uses: "keyframes" (cubic B-splines of TRS control
+# points) on the camera, on objects and on groups, animated "emission" key lists, shutter_size, frames / scene_time.
+def _key(*transform):
+    return {"transform": list(transform)}
+
+
+def _clamped_knots(n_points, t0, t1, degree=3):
+    inner = n_points - degree - 1
+    return [t0] * (degree + 1) + [t0 + (t1 - t0) * (i + 1) / (inner + 1) for i in range(inner)] + [t1] * (degree + 1)
+
+
+def moving_box(width=160, height=120, samples=16, frames=8, scene_time=2.0, shutter_size=0.5):
+    """Cornell walls + every kind of motion the reference supports: a camera on a cubic spline, a sphere that translates,
+    rotates and scales, a cube mesh whose GROUP moves (static child under a moving parent), a disk light that slides and
+    changes colour, a point light fading in."""
+    d = cornell_box(width, height, samples)
+    d["film"].update({"frames": frames, "start_frame": 0, "end_frame": frames - 1, "scene_time": scene_time})
+    d["camera"] = {"fov": 30, "shutter_size": shutter_size, "keyframes": {
+        "control_points": [_key(_t(0, 12, -60)), _key(_ry(-2), _t(2, 13, -58)), _key(_ry(-5), _t(5, 14, -55)),
+                           _key(_ry(-7), _t(7, 13, -53)), _key(_ry(-8), _t(8, 12, -52))],
+        "knots": _clamped_knots(5, 0.0, scene_time)}}
+    d["materials"] += [{"type": "metal", "name": "metal", "refractive_index": [0.155265, 0.116723, 0.138381],
+                        "absorption_coefficient": [4.82835, 3.12225, 2.14696], "roughness": 0.2},
+                       {"type": "glass", "name": "glass", "reflect": [1, 1, 1], "transmit": [1, 1, 1], "eta": 1.52}]
+    walls = d["objects"][0]
+    cube = {"type": "mesh", "file": "models/cube.obj", "model": "Cube"}
+    ball = {"name": "ball", "type": "receiver", "material": "metal", "geometry": {"type": "sphere", "radius": 1.0},
+            "keyframes": {"control_points": [_key(_s(3.0), _t(-8, 3, 4)), _key(_s(3.5), _rx(40), _t(-4, 9, 2)),
+                                             _key(_s([4.0, 3.0, 4.0]), _rx(90), _ry(45), _t(2, 6, 0)), _key(_s(3.0), _rx(170), _t(7, 3, -2))],
+                          "knots": _clamped_knots(4, 0.0, scene_time)}}
+    spinner = {"type": "group", "name": "spinner",
+               "keyframes": {"control_points": [_key(_t(6, 0, 8)), _key(_ry(60), _t(5, 1, 7)), _key(_ry(120), _t(4, 2, 6)),
+                                                _key(_ry(180), _t(3, 1, 5)), _key(_ry(240), _t(2, 0, 4))],
+                             "knots": _clamped_knots(5, 0.0, scene_time)},
+               "objects": [{"name": "block", "type": "receiver", "material": "white_plastic", "geometry": dict(cube),
+                            "transform": [_s([3, 5, 3]), _t(0, 5, 0)]},
+                           {"name": "lens", "type": "receiver", "material": "glass", "geometry": {"type": "sphere", "radius": 2.0},
+                            "transform": [_t(0, 12.5, 0)]}]}
+    lamp = {"name": "light", "type": "emitter", "material": "white_wall", "emitter": "area",
+            "emission": [{"time": 0.0, "color": [1, 0.772549, 0.560784, 30]}, {"time": scene_time * 0.5, "color": [0.6, 0.8, 1.0, 55]},
+                         {"time": scene_time, "color": [1, 0.5, 0.4, 40]}],
+            "geometry": {"type": "disk", "radius": 3.5, "inner_radius": 0.0},
+            "keyframes": {"control_points": [_key(_rx(90), _t(-6, 23.8, 0)), _key(_rx(90), _t(-2, 23.8, 3)),
+                                             _key(_rx(90), _t(3, 23.8, 1)), _key(_rx(90), _t(6, 23.8, -2))],
+                          "knots": _clamped_knots(4, 0.0, scene_time)}}
+    spark = {"name": "spark", "type": "emitter", "emitter": "point",
+             "emission": [{"time": 0.0, "color": [1, 0.9, 0.8, 0]}, {"time": scene_time, "color": [1, 0.9, 0.8, 400]}],
+             "transform": [_t(-10, 18, -6)]}
+    d["objects"] = [walls, lamp, spark, ball, spinner]
+    return d
+
+
+def write_moving_box(directory, **kw):
+    os.makedirs(os.path.join(directory, "models"), exist_ok=True)
+    with open(os.path.join(directory, "models", "cube.obj"), "w") as f:
+        f.write(cube_obj())
+    return write_scene(moving_box(**kw), os.path.join(directory, "moving_box.json"))
+
+
 def write_scene(scene, path):
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
