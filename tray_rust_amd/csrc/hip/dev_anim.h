@@ -44,13 +44,15 @@ TR_DEV DevKey key_interpolate(const DevKey& a, const DevKey& b, float t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) r.q[i] = q[i] / len;
     } else {
-        float theta = acosf(clampf(cos_theta, -1.0f, 1.0f));
+        // acos / cos / sin through f64 and rounded once: the host libm the reference (and the oracle) calls is correctly
+        // rounded for almost every argument, ocml's f32 versions are 1-2 ulp; every ulp here moves a whole instance
+        float theta = (float)acos((double)clampf(cos_theta, -1.0f, 1.0f));
         float theta_t = theta * t;
         float perp[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) perp[i] = b.q[i] - a.q[i] * cos_theta;
         float len = sqrtf(quat_dot(perp, perp));
-        float c = cosf(theta_t), sn = sinf(theta_t);
+        float c = (float)cos((double)theta_t), sn = (float)sin((double)theta_t);
 #pragma unroll
         for (int i = 0; i < 4; ++i) r.q[i] = a.q[i] * c + (perp[i] / len) * sn;
     }
