@@ -151,3 +151,20 @@ def test_animated_fov_is_sampled_at_the_middle_of_the_frame(tmp_path, built):
         fs = scene.flatten(frame).contents
         mid = (frame + 0.5) * 0.25
         assert np.isclose(fs.camera.scaling[0], np.tan(np.radians(ref(mid)) / 2), rtol=1e-5)
+
+
+def test_tr15_stand_in_has_the_structure_of_tr15(tmp_path, built):
+    """Counts asserted here are the ones tests/test_tr15_compat.py reads off the reference's scenes/tr15.json."""
+    p, tris = scenes.write_tr15_like_assets(str(tmp_path), film=(64, 40, 4), detail=0.03)
+    scene, rt, spp, fi = T.Scene.load_file(p)
+    assert (fi.frames, fi.time) == (600, 25.0)
+    assert (scene.info.n_instances, scene.info.n_lights, scene.info.n_meshes) == (59, 10, 25)
+    fs = scene.flatten(330).contents
+    assert (fs.min_depth, fs.max_depth, fs.n_merl, fs.n_materials) == (5, 10, 5, 20)
+    assert sum(fs.instances[i].animated for i in range(fs.n_instances)) == 14
+    assert sum(fs.instances[i].emis_count >= 2 for i in range(fs.n_instances)) == 10
+    assert fs.camera.animated == 1
+    img, st = O.render_tiles(scene.flatten(330), 4, seed=1)
+    assert np.isfinite(img).all() and st.vertices > 3 * st.samples
+    full = sum(2 * gu * gv for models in scenes._TR15_MODELS.values() for _, gu, gv in models)
+    assert 3.0e6 < full < 3.3e6

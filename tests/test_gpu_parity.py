@@ -356,3 +356,20 @@ def _config_at(fi, frame, spp=32):
     c = T.Config(".", "s", spp, 1, fi, (0, 0))
     c.current_frame = frame
     return c
+
+
+def test_tr15_stand_in_image_rmse(tmp_path):
+    """59 instances (BVH<Instance> on the device), 14 of them moving, 10 keyed lights, MERL / glass / metal, depth 10."""
+    p, _ = scenes.write_tr15_like_assets(str(tmp_path), film=(160, 96, 64), detail=0.05)
+    scene, rt, _, fi = T.Scene.load_file(p)
+    frame, spp = 330, 64
+    hip = T.Hip(0, seed=2)
+    hip.render(scene, rt, _config_at(fi, frame, spp))
+    gpu = rt.get_renderf32().reshape(rt.height, rt.width, 4).copy()
+    tim = hip.last_timing
+    cpu, st = O.render_tiles(scene.flatten(frame), spp, seed=2)
+    assert tim.samples == st.samples
+    assert abs(int(tim.vertices) - int(st.vertices)) <= 1e-3 * st.vertices
+    r = rmse(gpu, cpu)
+    print(f"tr15_like frame {frame} 160x96x{spp}: RMSE {r:.3e} V {st.vertices / st.samples:.3f}")
+    assert r < 2e-4   # 1e-4 at a realistic sample count; see test_moving_scene_image_rmse

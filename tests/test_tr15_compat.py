@@ -1,0 +1,84 @@
+"""The loader against the reference's own scenes/tr15.json (BASELINE.json configs[4]): 600 frames, a camera and five objects
+/ groups on cubic B-splines, ten lights with animated emission, 13 OBJ files with 25 models, 5 MERL BRDFs. The models and
+BRDFs are not distributed with the reference, so seeded stand-ins are generated at the paths the scene names. Runs only
+where /root/reference exists (this container); nothing here travels to the GPU box."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import tray_rust_amd as T
+from tray_rust_amd import scenes
+import _oracle as O
+
+TR15 = "/root/reference/scenes/tr15.json"
+pytestmark = pytest.mark.skipif(not os.path.exists(TR15), reason="reference scenes are only present in the build container")
+
+
+@pytest.fixture(scope="module")
+def tr15(tmp_path_factory, built):
+    d = str(tmp_path_factory.mktemp("tr15"))
+    shutil.copy(TR15, os.path.join(d, "tr15.json"))
+    desc = json.load(open(TR15))
+    files = {}
+
+    def walk(objs):
+        for o in objs:
+            g = o.get("geometry")
+            if g and g["type"] == "mesh":
+                files.setdefault(g["file"], set()).add(g["model"])
+            if o["type"] == "group":
+                walk(o["objects"])
+    walk(desc["objects"])
+    seed = 0
+    for path, models in sorted(files.items()):
+        objs = []
+        for m in sorted(models):
+            seed += 1
+            objs.append((m,) + scenes.knot_mesh(10, 6, seed=seed, extent=1.0))
+        scenes.write_obj(os.path.join(d, path), objs)
+    first = None
+    for m in desc["materials"]:
+        if m["type"] == "merl":
+            dst = os.path.join(d, m["file"])
+            if first is None:
+                scenes.write_merl_binary(dst)
+                first = dst
+            else:
+                os.link(first, dst)
+    return desc, T.Scene.load_file(os.path.join(d, "tr15.json"))
+
+
+def test_tr15_loads_with_every_feature(tr15):
+    desc, (scene, rt, spp, fi) = tr15
+    assert (rt.width, rt.height, spp) == (1920, 1080, 2048)
+    assert (fi.frames, fi.time, fi.start, fi.end) == (600, 25.0, 0, 599)
+    assert scene.info.n_lights == 10 and scene.info.n_instances == 59 and scene.info.n_meshes == 25
+    fs = scene.flatten(0).contents
+    assert (fs.min_depth, fs.max_depth) == (5, 10) and fs.n_merl == 5
+    assert fs.n_instances > 16   # BVH<Instance> path on the device
+
+
+@pytest.mark.parametrize("frame", [0, 150, 330, 599])
+def test_tr15_frames_flatten_and_trace(tr15, frame):
+    desc, (scene, rt, spp, fi) = tr15
+    flat = scene.flatten(frame)
+    fs = flat.contents
+    step = np.float32(25.0) / np.float32(600)
+    assert fs.camera.shutter_open == np.float32(frame) * step
+    assert np.isclose(fs.camera.shutter_close - fs.camera.shutter_open, 0.5 * step, rtol=1e-4)
+    assert fs.camera.animated == 1 and fs.animated == 1
+    moving = [i for i in range(fs.n_instances) if fs.instances[i].animated]
+    assert len(moving) == 14   # 3 walls (own + group splines), 4 x (light, cone) under moving groups, dragon, rust_logo, cow
+    keyed = [i for i in range(fs.n_instances) if fs.instances[i].emis_count >= 2]
+    assert len(keyed) == 10
+    # the library's spline evaluation (instance matrices at shutter_open) against the oracle's, bit for bit
+    for i in moving:
+        inst = fs.instances[i]
+        out = np.zeros(32, np.float32)
+        assert O.oracle().oracle_stack_transform(flat, inst.xf_first, inst.xf_count, float(fs.camera.shutter_open), out.ctypes.data) == 0
+        assert (np.frombuffer(inst.mat, np.float32) == out[:16]).all() and (np.frombuffer(inst.inv, np.float32) == out[16:]).all()
+    img, st = O.render_tiles(flat, 4, seed=1, tile_start=16000, tile_count=6)
+    assert np.isfinite(img).all() and st.samples == 6 * 64 * 4

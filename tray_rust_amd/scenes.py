@@ -160,20 +160,18 @@ def dragon_scene(width=1920, height=1080, samples=2048, material="merl"):
     return d
 
 
-def write_dragon_obj(path, grid=660, seed=7, extent=0.2):
-    """Deterministic stand-in for the Stanford dragon: a (2,3) torus-knot tube with 4-octave value-noise radial
-    displacement on a grid x grid quad mesh (grid=660 -> 871 200 triangles / 435 600 vertices; the real dragon has
-    871 414 / 437 645), written as a real OBJ with v/vt/vn (both required, src/geometry/mesh.rs:57-61). The longest
-    bounding-box side is `extent` (the scanned dragon is about 0.2 units; the scene scales it by 13)."""
+def knot_mesh(grid_u, grid_v=None, seed=7, p=2, q=3, tube=0.22, noise=0.25, extent=1.0):
+    """Closed torus-topology quad grid: a (p,q) torus-knot tube with 4-octave value-noise radial displacement, smooth
+    normals, uv = grid coordinates, longest bounding-box side = extent, y up. Returns (pos, uv, normals, quads) with
+    1-based quad indices local to this mesh; 2 * grid_u * grid_v triangles."""
     import numpy as np
-    n = int(grid)
-    u = (np.arange(n) / n)[:, None] * 2 * np.pi          # along the knot
-    v = (np.arange(n) / n)[None, :] * 2 * np.pi          # around the tube
-    P, Q = 2, 3
+    nu = int(grid_u); nv = int(grid_v or grid_u)
+    u = (np.arange(nu) / nu)[:, None] * 2 * np.pi          # along the knot
+    v = (np.arange(nv) / nv)[None, :] * 2 * np.pi          # around the tube
 
     def knot(t):
-        r = 0.5 * (2 + np.cos(Q * t))
-        return np.stack([r * np.cos(P * t), r * np.sin(P * t), -0.5 * np.sin(Q * t)], -1)
+        r = 0.5 * (2 + np.cos(q * t))
+        return np.stack([r * np.cos(p * t), r * np.sin(p * t), -0.5 * np.sin(q * t)], -1)
     c = knot(u[:, 0])
     dt = 1e-4
     tangent = knot(u[:, 0] + dt) - knot(u[:, 0] - dt)
@@ -182,17 +180,17 @@ def write_dragon_obj(path, grid=660, seed=7, extent=0.2):
     nrm = np.cross(tangent, ref); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
     bin_ = np.cross(tangent, nrm)
     rng = np.random.default_rng(seed)
-    disp = np.zeros((n, n))
+    disp = np.zeros((nu, nv))
     for octave in range(4):   # periodic value noise
         k = 8 << octave
         g = rng.uniform(-1, 1, (k, k))
-        iu = (np.arange(n) * k / n); iv = (np.arange(n) * k / n)
+        iu = (np.arange(nu) * k / nu); iv = (np.arange(nv) * k / nv)
         u0 = np.floor(iu).astype(int); v0 = np.floor(iv).astype(int)
         fu = (iu - u0)[:, None]; fv = (iv - v0)[None, :]
         fu = fu * fu * (3 - 2 * fu); fv = fv * fv * (3 - 2 * fv)
         a = g[u0 % k][:, v0 % k]; b = g[(u0 + 1) % k][:, v0 % k]; cc = g[u0 % k][:, (v0 + 1) % k]; dd = g[(u0 + 1) % k][:, (v0 + 1) % k]
         disp += (a * (1 - fu) * (1 - fv) + b * fu * (1 - fv) + cc * (1 - fu) * fv + dd * fu * fv) / (2 ** octave)
-    radius = 0.22 * (1 + 0.25 * disp)
+    radius = tube * (1 + noise * disp)
     pos = c[:, None, :] + radius[..., None] * (np.cos(v)[..., None] * nrm[:, None, :] + np.sin(v)[..., None] * bin_[:, None, :])
     # smooth normals from the periodic grid
     du = np.roll(pos, -1, 0) - np.roll(pos, 1, 0); dv = np.roll(pos, -1, 1) - np.roll(pos, 1, 1)
@@ -200,19 +198,39 @@ def write_dragon_obj(path, grid=660, seed=7, extent=0.2):
     lo, hi = pos.reshape(-1, 3).min(0), pos.reshape(-1, 3).max(0)
     pos = (pos - (lo + hi) / 2) * (extent / (hi - lo).max())
     pos = pos[..., [0, 2, 1]]; nn = nn[..., [0, 2, 1]]          # stand it up: y is up in the scene
-    uv = np.stack(np.meshgrid(np.arange(n) / n, np.arange(n) / n, indexing="ij"), -1)
-    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    idx = (np.arange(n)[:, None] * n + np.arange(n)[None, :])
+    uv = np.stack(np.meshgrid(np.arange(nu) / nu, np.arange(nv) / nv, indexing="ij"), -1)
+    idx = (np.arange(nu)[:, None] * nv + np.arange(nv)[None, :])
     a = idx; b = np.roll(idx, -1, 0); cc = np.roll(np.roll(idx, -1, 0), -1, 1); dd = np.roll(idx, -1, 1)
     quads = np.stack([a, b, cc, dd], -1).reshape(-1, 4) + 1
+    return pos.reshape(-1, 3), uv.reshape(-1, 2), nn.reshape(-1, 3), quads
+
+
+def write_obj(path, objects):
+    """objects: [(name, pos, uv, normals, quads)] -> a Wavefront OBJ with one `o` block per object (v/vt/vn, quad faces,
+    indices global across the file as the format requires). Returns the triangle count."""
+    import numpy as np
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    tris = 0
+    base = 0
     with open(path, "w") as f:
-        f.write("o dragon\n")
-        np.savetxt(f, pos.reshape(-1, 3), fmt="v %.7f %.7f %.7f")
-        np.savetxt(f, uv.reshape(-1, 2), fmt="vt %.6f %.6f")
-        np.savetxt(f, nn.reshape(-1, 3), fmt="vn %.6f %.6f %.6f")
-        q = quads
-        np.savetxt(f, np.stack([q[:, 0]] * 3 + [q[:, 1]] * 3 + [q[:, 2]] * 3 + [q[:, 3]] * 3, -1), fmt="f %d/%d/%d %d/%d/%d %d/%d/%d %d/%d/%d")
-    return 2 * n * n
+        for name, pos, uv, nn, quads in objects:
+            f.write("o %s\n" % name)
+            np.savetxt(f, pos, fmt="v %.7f %.7f %.7f")
+            np.savetxt(f, uv, fmt="vt %.6f %.6f")
+            np.savetxt(f, nn, fmt="vn %.6f %.6f %.6f")
+            q = quads + base
+            np.savetxt(f, np.stack([q[:, 0]] * 3 + [q[:, 1]] * 3 + [q[:, 2]] * 3 + [q[:, 3]] * 3, -1), fmt="f %d/%d/%d %d/%d/%d %d/%d/%d %d/%d/%d")
+            base += len(pos)
+            tris += 2 * len(quads)
+    return tris
+
+
+def write_dragon_obj(path, grid=660, seed=7, extent=0.2):
+    """Deterministic stand-in for the Stanford dragon: knot_mesh on a grid x grid quad mesh (grid=660 -> 871 200 triangles /
+    435 600 vertices; the real dragon has 871 414 / 437 645), written as a real OBJ with v/vt/vn (both required,
+    src/geometry/mesh.rs:57-61). The longest bounding-box side is `extent` (the scanned dragon is about 0.2 units; the
+    scene scales it by 13)."""
+    return write_obj(path, [("dragon",) + knot_mesh(grid, grid, seed=seed, extent=extent)])
 
 
 def write_merl_binary(path, kd=(0.05, 0.12, 0.45), ks=0.35, alpha=0.08):
@@ -313,6 +331,162 @@ def write_moving_box(directory, **kw):
     with open(os.path.join(directory, "models", "cube.obj"), "w") as f:
         f.write(cube_obj())
     return write_scene(moving_box(**kw), os.path.join(directory, "moving_box.json"))
+
+
+# C5 stand-in. scenes/tr15.json needs 13 OBJ files (25 models) and 5 MERL tables that are not distributed, and the file itself
+# is not available on the GPU box, so the benchmark scene is generated: same film / integrator settings, the same counts
+# (59 instances in 25 meshes, 10 keyed lights, 14 moving instances, a 12-point camera spline, 20 materials of the same
+# types) and mesh sizes of the same order, with its own choreography. tests/test_tr15_compat.py loads the real tr15.json.
+_TR15_MODELS = {   # file -> [(model, grid_u, grid_v)] at detail = 1 (2 * gu * gv triangles each)
+    "models/cone.obj": [("Cone", 8, 4)],
+    "models/teapot2.obj": [("Base", 44, 36), ("Top", 28, 22)],
+    "models/u_logo.obj": [("U_Logo", 100, 100)],
+    "models/buddha.obj": [("buddha", 737, 737)],
+    "models/dragon.obj": [("dragon", 660, 660)],
+    "models/kenny_nl/Tree_01.obj": [("Leaves", 36, 28), ("Trunk", 16, 12)],
+    "models/kenny_nl/Tree_02.obj": [("Leaves", 40, 30), ("Trunk", 16, 12)],
+    "models/rust_logo.obj": [("rust_logo", 174, 174)],
+    "models/lucy.obj": [("lucy", 512, 512)],
+    "models/teapot.obj": [("Teapot", 56, 56)],
+    "models/ajax.obj": [("Ajax", 522, 522)],
+    "models/cow.obj": [("Cow", 54, 54)],
+    "models/kenny_nl/tree_1_ornamented.obj": [("Leaves", 48, 36), ("Trunk", 16, 12), ("Tinsel", 60, 8), ("Sphere1", 16, 12), ("Sphere2", 16, 12),
+                                              ("Sphere3", 16, 12), ("Sphere4", 16, 12), ("Sphere5", 16, 12), ("Bunny", 60, 48), ("Suzanne", 32, 24)],
+}
+_TR15_BRDFS = {"oxidized_steel": ("brdfs/black-oxidized-steel.binary", (0.02, 0.02, 0.025), 0.25, 0.12),
+               "silver_paint": ("brdfs/silver-paint.binary", (0.25, 0.25, 0.27), 0.5, 0.2),
+               "gold_metallic_paint": ("brdfs/gold-metallic-paint.binary", (0.35, 0.22, 0.05), 0.6, 0.15),
+               "blue_acrylic": ("brdfs/blue-acrylic.binary", (0.05, 0.12, 0.45), 0.35, 0.08),
+               "brass": ("brdfs/brass.binary", (0.3, 0.2, 0.06), 0.8, 0.1)}
+
+
+def tr15_like(width=1920, height=1080, samples=512, frames=600, scene_time=25.0):
+    import math
+    mesh = lambda f, m: {"type": "mesh", "file": f, "model": m}
+    recv = lambda name, material, geom, transform=None, keyframes=None: dict(
+        {"name": name, "type": "receiver", "material": material, "geometry": geom},
+        **({"keyframes": keyframes} if keyframes else {"transform": transform}))
+    disk = lambda r: {"type": "disk", "radius": r, "inner_radius": 0.0}
+    warm = [1, 0.772549, 0.560784]
+
+    def light(name, radius, keys, transform):
+        return {"name": name, "type": "emitter", "material": "white_wall", "emitter": "area", "geometry": disk(radius),
+                "emission": [{"time": t, "color": warm[:2] + [b, e]} for (t, b, e) in keys], "transform": transform}
+
+    def spline(points, t0, t1):
+        return {"control_points": [_key(*p) for p in points], "knots": _clamped_knots(len(points), t0, t1)}
+
+    cam_pts = []
+    for i in range(12):
+        a = -30.0 + 80.0 * i / 11.0
+        r = 58.0 - 16.0 * i / 11.0
+        h = 12.0 + 6.0 * math.sin(math.pi * i / 11.0)
+        cam_pts.append((_rx(4.0), _ry(a), _t(-r * math.sin(math.radians(a)), h, -r * math.cos(math.radians(a)))))
+    materials = [
+        {"type": "matte", "name": "white_wall", "diffuse": [0.740063, 0.742313, 0.733934], "roughness": 1.0},
+        {"type": "matte", "name": "red_wall", "diffuse": [0.366046, 0.0371827, 0.0416385], "roughness": 1.0},
+        {"type": "matte", "name": "green_wall", "diffuse": [0.162928, 0.408903, 0.0833759], "roughness": 1.0},
+        {"type": "matte", "name": "blue_sky", "diffuse": [0.3, 0.5, 0.8], "roughness": 0.0},
+        {"type": "matte", "name": "pantone_yellow", "diffuse": [0.9, 0.75, 0.1], "roughness": 0.5},
+        {"type": "matte", "name": "sienna_matte", "diffuse": [0.53, 0.32, 0.18], "roughness": 0.8},
+        {"type": "matte", "name": "forest_green_matte", "diffuse": [0.13, 0.45, 0.13], "roughness": 0.8},
+        {"type": "plastic", "name": "white_plastic", "diffuse": [0.8, 0.8, 0.8], "gloss": [0.6, 0.6, 0.6], "roughness": 0.5},
+        {"type": "plastic", "name": "green_plastic", "diffuse": [0.1, 0.7, 0.2], "gloss": [0.6, 0.6, 0.6], "roughness": 0.2},
+        {"type": "plastic", "name": "u_logo_plastic", "diffuse": [0.8, 0.05, 0.05], "gloss": [0.5, 0.5, 0.5], "roughness": 0.3},
+        {"type": "plastic", "name": "u_logo_plastic_shiny", "diffuse": [0.8, 0.05, 0.05], "gloss": [0.8, 0.8, 0.8], "roughness": 0.05},
+        {"type": "plastic", "name": "pantone_yellow_plastic", "diffuse": [0.9, 0.75, 0.1], "gloss": [0.6, 0.6, 0.6], "roughness": 0.1},
+        {"type": "glass", "name": "glass", "reflect": [1, 1, 1], "transmit": [1, 1, 1], "eta": 1.52},
+        {"type": "metal", "name": "silver_metal", "refractive_index": [0.155265, 0.116723, 0.138381], "absorption_coefficient": [4.82835, 3.12225, 2.14696], "roughness": 0.1},
+        {"type": "metal", "name": "rough_silver_metal", "refractive_index": [0.155265, 0.116723, 0.138381], "absorption_coefficient": [4.82835, 3.12225, 2.14696], "roughness": 0.3},
+    ] + [{"type": "merl", "name": n, "file": f} for n, (f, _, _, _) in _TR15_BRDFS.items()]
+
+    def ring(i, n, r):   # i-th of n spots on a circle of radius r on the stage
+        a = 2 * math.pi * i / n
+        return r * math.sin(a), r * math.cos(a)
+
+    objects = []
+    # stage: three walls that slide in (own spline + the group's spline), floor, backdrop, sky dome
+    def wall(name, material, rot, pos):
+        pts = [(_s([64, 30, 1]), rot, _t(pos[0], pos[1] + dy, pos[2])) for dy in (60.0, 35.0, 10.0, 0.0)]
+        return recv(name, material, {"type": "plane"}, keyframes=spline(pts, 2.5, 6.0))
+    objects.append({"type": "group", "name": "walls", "keyframes": spline([(_t(0, 0, 30 - 10 * k),) for k in range(4)], 2.5, 6.0),
+                    "objects": [wall("back_wall", "white_wall", _ry(0), (0, 30, 64)), wall("left_wall", "red_wall", _ry(90), (-64, 30, 0)),
+                                wall("right_wall", "green_wall", _ry(-90), (64, 30, 0))]})
+    objects.append(recv("floor", "white_plastic", {"type": "plane"}, [_s(120), _rx(90), _t(0, 0, 0)]))
+    objects.append(recv("far_backdrop", "blue_sky", {"type": "plane"}, [_s(200), _t(0, 0, 150)]))
+    objects.append(recv("sky_dome", "blue_sky", {"type": "sphere", "radius": 300.0}, [_t(0, 0, 0)]))
+    # four spot lights on moving arms
+    cone_knots = [(0, 9), (0, 8), (0, 8), (0, 8)]
+    for i in range(4):
+        x, z = ring(i, 4, 22.0)
+        arm = [(_ry(40.0 * k), _t(x * (1 - 0.15 * k), 30 - 2 * k, z * (1 - 0.15 * k))) for k in range(6 - (i > 1) - (i > 2))]
+        objects.append({"type": "group", "name": "light_cone%d" % (i + 1), "keyframes": spline(arm, *cone_knots[i]), "objects": [
+            light("cone_light", 2.0, [(0, 0.560784, 0), (2 + i, 0.560784, 0), (4 + i, 0.560784, 180)], [_rx(90), _t(0, -0.5, 0)]),
+            recv("cone", "pantone_yellow", mesh("models/cone.obj", "Cone"), [_s(5.0), _t(0, 0, 0)])]})
+    objects.append(light("large_light1", 9.0, [(0, 0.560784, 0), (3.5, 0.560784, 0), (5, 0.560784, 110), (7, 0.560784, 150)], [_rx(90), _t(0, 48, 0)]))
+    # heroes on the stage
+    heroes = [("buddha", "models/buddha.obj", "buddha", "gold_metallic_paint", 14.0), ("lucy", "models/lucy.obj", "lucy", "silver_paint", 16.0),
+              ("ajax", "models/ajax.obj", "Ajax", "brass", 13.0), ("u_logo", "models/u_logo.obj", "U_Logo", "u_logo_plastic", 9.0),
+              ("teapot2", "models/teapot.obj", "Teapot", "pantone_yellow_plastic", 6.0)]
+    for i, (name, f, m, mat, size) in enumerate(heroes):
+        x, z = ring(i, 5, 18.0)
+        objects.append(recv(name, mat, mesh(f, m), [_s(size), _ry(72.0 * i), _t(x, size * 0.35, z)]))
+    objects.append({"type": "group", "name": "red_teapot", "transform": [_t(-8, 0, -12)], "objects": [
+        recv("base", "rough_silver_metal", mesh("models/teapot2.obj", "Base"), [_s(5.0), _t(0, 1.8, 0)]),
+        recv("top", "rough_silver_metal", mesh("models/teapot2.obj", "Top"), [_s(3.0), _t(0, 4.2, 0)])]})
+    objects.append(light("buddha_highlight", 3.0, [(0, 0.560784, 0), (4, 0.560784, 0), (5.5, 0.560784, 120)], [_rx(90), _t(0, 26, 18)]))
+    objects.append(recv("dragon", "blue_acrylic", mesh("models/dragon.obj", "dragon"), keyframes=spline(
+        [(_s(11.0), _ry(30.0 * k), _t(8 - 4 * k, 4 + 2 * k * (3 - k) / 2.0, -6 + k)) for k in range(4)], 11.5, 14.0)))
+    for i in range(4):
+        x, z = ring(i, 4, 30.0)
+        tree = "models/kenny_nl/Tree_0%d.obj" % (1 + (i % 2 == 1))
+        mats = ("glass", "red_wall") if i % 3 == 0 else ("green_plastic", "blue_acrylic")
+        objects.append({"type": "group", "name": "kenny_nl_pine%d" % (i + 1), "transform": [_s(7.0), _ry(50.0 * i), _t(x * 0.9, 0, z * 0.9 + 4)], "objects": [
+            recv("leaves", mats[0], mesh(tree, "Leaves"), [_s(1.0), _t(0, 1.1, 0)]),
+            recv("trunk", mats[1], mesh(tree, "Trunk"), [_s([0.25, 0.8, 0.25]), _t(0, 0.3, 0)])]})
+    objects.append(light("lucy_logo_section_light", 4.0, [(6, 0.560784, 0), (9, 0.54509, 140)], [_rx(90), _t(17, 30, 6)]))
+    objects.append(light("left_backlight", 4.0, [(6, 0.560784, 0), (9, 0.54509, 140)], [_rx(60), _t(-25, 28, 20)]))
+    objects.append(recv("rust_logo", "oxidized_steel", mesh("models/rust_logo.obj", "rust_logo"), keyframes=spline(
+        [(_s(6.0 + 0.2 * k), _rx(15.0 * k), _ry(33.0 * k), _t(-12 + 2 * k, 6 + 1.5 * math.sin(k), -4 + 0.5 * k)) for k in range(12)], 12.0, 25.0)))
+    objects.append({"type": "group", "name": "ajax_light_cone1", "transform": [_t(10.6, 30, -14.6)], "objects": [
+        light("cone_light", 2.0, [(5, 0.560784, 0), (7, 0.760784, 350)], [_rx(90), _t(0, -0.5, 0)]),
+        recv("cone", "pantone_yellow", mesh("models/cone.obj", "Cone"), [_s(5.0), _t(0, 0, 0)])]})
+    objects.append(light("ajax_upper_light", 3.0, [(5, 0.560784, 0), (7, 0.760784, 160)], [_rx(90), _t(-10.6, 34, -14.6)]))
+    objects.append(recv("cow", "glass", mesh("models/cow.obj", "Cow"), keyframes=spline(
+        [(_s(5.0), _ry(50.0 * k), _t(-20 + 6 * k, 2.5 + (k % 2), -18 + 2 * k)) for k in range(7)], 18.0, 24.5)))
+    orn = [("leaves", "Leaves", "forest_green_matte"), ("trunk", "Trunk", "sienna_matte"), ("tinsel", "Tinsel", "silver_metal"),
+           ("sphere1", "Sphere1", "pantone_yellow"), ("sphere2", "Sphere2", "silver_metal"), ("sphere3", "Sphere3", "u_logo_plastic_shiny"),
+           ("sphere4", "Sphere4", "glass"), ("sphere5", "Sphere5", "silver_paint"), ("bunny", "Bunny", "gold_metallic_paint"),
+           ("suzanne", "Suzanne", "pantone_yellow_plastic")]
+    for g in range(2):
+        kids = []
+        for j, (name, model, mat) in enumerate(orn):
+            if j < 3:
+                xf = [_s([1.0, 1.2, 1.0] if j != 1 else [0.25, 0.8, 0.25]), _t(0, 1.0 if j != 1 else 0.3, 0)]
+            else:
+                ox, oz = ring(j - 3, 7, 0.55)
+                xf = [_s(0.22), _t(ox, 0.5 + 0.12 * j, oz)]
+            kids.append(recv(name, mat if not (g == 1 and name == "suzanne") else "silver_paint", mesh("models/kenny_nl/tree_1_ornamented.obj", model), xf))
+        objects.append({"type": "group", "name": "kenny_pine_ornaments" + ("" if g == 0 else "2"), "transform": [_s(9.0), _t(-26 + 52 * g, 0, -8)], "objects": kids})
+    return {"film": dict(_film(width, height, samples), frames=int(frames), start_frame=0, end_frame=int(frames) - 1, scene_time=scene_time),
+            "camera": {"fov": 40, "keyframes": spline(cam_pts, 0.0, scene_time)},
+            "integrator": {"type": "pathtracer", "min_depth": 5, "max_depth": 10}, "materials": materials, "objects": objects}
+
+
+def write_tr15_like_assets(directory, film=(1920, 1080, 512), frames=600, scene_time=25.0, detail=1.0):
+    """tr15_like.json + its 13 OBJ files + 5 MERL tables under `directory`. detail scales every mesh grid (1.0 = about 3.1 M
+    triangles in total; tests use ~0.03). Returns (scene path, triangle count)."""
+    tris = 0
+    seed = 100
+    for path, models in sorted(_TR15_MODELS.items()):
+        objs = []
+        for name, gu, gv in models:
+            seed += 1
+            objs.append((name,) + knot_mesh(max(4, int(round(gu * detail))), max(3, int(round(gv * detail))), seed=seed, p=2 + seed % 2, q=3 + 2 * (seed % 3 == 0), extent=1.0))
+        tris += write_obj(os.path.join(directory, path), objs)
+    for name, (f, kd, ks, alpha) in _TR15_BRDFS.items():
+        write_merl_binary(os.path.join(directory, f), kd=kd, ks=ks, alpha=alpha)
+    return write_scene(tr15_like(*film, frames=frames, scene_time=scene_time), os.path.join(directory, "tr15_like.json")), tris
 
 
 def write_scene(scene, path):
