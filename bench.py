@@ -28,7 +28,7 @@ WIDTH, HEIGHT, SPP = 1920, 1080, 1024
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E
 BYTES_PER_VERTEX = 368.0   # SURVEY 8(d) wavefront accounting
 BYTES_PER_PIXEL = 16.0
-WORKLOAD_CONFIG = {"cornell_box": 1, "smallpt": 2, "dragon": 3}
+WORKLOAD_CONFIG = {"cornell_box": 1, "smallpt": 2, "dragon": 3, "tr15_like": 4}
 
 
 def cpu_baseline(flat, spp, target_seconds=15.0):
@@ -62,9 +62,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=0, help="debug only: the reported config is 1024 spp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["cornell_box", "smallpt", "dragon"], default="cornell_box",
+    ap.add_argument("--workload", choices=["cornell_box", "smallpt", "dragon", "tr15_like"], default="cornell_box",
                     help="cornell_box = BASELINE.json configs[1] (the reported line); smallpt = configs[2] at 4096 spp; "
-                         "dragon = configs[3] stand-in (871 200 triangles + MERL) at 2048 spp")
+                         "dragon = configs[3] stand-in (871 200 triangles + MERL) at 2048 spp; tr15_like = configs[4] stand-in "
+                         "(59 instances, 3.1 M triangles, moving camera / objects / lights), one frame at 512 spp")
+    ap.add_argument("--frame", type=int, default=330, help="frame of a moving workload (tr15_like)")
     args = ap.parse_args()
 
     import torch
@@ -86,9 +88,12 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     tmp = tempfile.mkdtemp(prefix=f"traybench{rank}_")
-    want_spp = args.spp or {"cornell_box": SPP, "smallpt": 4096, "dragon": 2048}[args.workload]
+    want_spp = args.spp or {"cornell_box": SPP, "smallpt": 4096, "dragon": 2048, "tr15_like": 512}[args.workload]
+    frame = args.frame if args.workload == "tr15_like" else 0
     if args.workload == "dragon":
         scenes.write_dragon_assets(tmp, film=(WIDTH, HEIGHT, want_spp))
+    elif args.workload == "tr15_like":
+        scenes.write_tr15_like_assets(tmp, film=(WIDTH, HEIGHT, want_spp))
     else:
         scenes.write_assets(tmp, cornell=(WIDTH, HEIGHT, want_spp), small=(WIDTH, HEIGHT, want_spp))
     scene, rt, spp, frame_info = T.Scene.load_file(os.path.join(tmp, args.workload + ".json"))
@@ -101,10 +106,10 @@ def main():
         film.zero_()
         if distributed:
             multi.render_frame_sharded(   # tiles round-robin over ranks, then film::Image::add_pixels as one RCCL sum-reduce
-                lambda r, w, f: hip.render_shard_device(scene, 0, r, w, spp, f.data_ptr(), chunk_tiles=multi.DEFAULT_CHUNK_TILES, stream=stream),
+                lambda r, w, f: hip.render_shard_device(scene, frame, r, w, spp, f.data_ptr(), chunk_tiles=multi.DEFAULT_CHUNK_TILES, stream=stream),
                 film, rank, world, dst=0)
         else:
-            hip.render_device(scene, 0, (0, 0), spp, film.data_ptr(), stream=stream)
+            hip.render_device(scene, frame, (0, 0), spp, film.data_ptr(), stream=stream)
 
     def fence():
         if distributed:
@@ -145,7 +150,7 @@ def main():
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.workload == "cornell_box":
             try:
                 traffic = json.load(open(pmc)).get("k_path_tiles_hbm_bytes_per_launch")
             except Exception:
@@ -165,7 +170,7 @@ def main():
                          "note": "368 B per path vertex + 16 B per pixel (SURVEY 8d); the scene is cache resident, the kernel is VALU/divergence bound"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene.flatten(0), spp)
+            out["cpu_baseline"] = cpu_baseline(scene.flatten(frame), spp)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

@@ -9,7 +9,11 @@ spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 scene_name = sys.argv[3] if len(sys.argv) > 3 else "cornell_box"
 d = "/tmp/sc_small"
-if scene_name == "dragon":
+frame = 0
+if scene_name == "tr15_like":
+    scenes.write_tr15_like_assets(d, film=(1920, 1080, spp), detail=float(os.environ.get("TR15_DETAIL", "1.0")))
+    frame = int(os.environ.get("TR15_FRAME", "330"))
+elif scene_name == "dragon":
     scenes.write_dragon_assets(d, film=(1920, 1080, spp), extent=float(os.environ.get("DRAGON_EXTENT", "0.2")))
 else:
     scenes.write_assets(d, cornell=(1920, 1080, spp), small=(1920, 1080, spp))
@@ -17,6 +21,6 @@ scene, rt, spp, fi = T.Scene.load_file(f"{d}/{scene_name}.json")
 hip = T.Hip(0, seed=1)
 buf = torch.zeros(1080 * 1920 * 4, dtype=torch.float32, device="cuda")
 for rep in range(reps):
-    hip.render_device(scene, 0, (0, 0), spp, buf.data_ptr())
+    hip.render_device(scene, frame, (0, 0), spp, buf.data_ptr())
     tim = hip.timing(scene)
     print(f"{scene_name} 1080p {spp}spp: kernel ms {tim.render_ms:.2f} Msamples/s {tim.samples / tim.render_ms / 1e3:.2f} V {tim.vertices / tim.samples:.3f} rays/sample {tim.rays / tim.samples:.3f}", flush=True)
