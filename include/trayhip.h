@@ -96,11 +96,12 @@ typedef struct TrayInstance {
     uint32_t light_index; /* index in lights[] or 0xffffffff */
     uint32_t xf_first;    /* first TrayXformLevel of this instance's spline stack */
     uint32_t xf_count;    /* number of levels (object first, then group parents) */
-    uint32_t animated;    /* 1 => some level has more than one control point: evaluate the stack at ray.time
+    uint32_t animated;    /* 1 => some level varies while the shutter is open: evaluate the stack at ray.time
                            * (receiver.rs:30, emitter.rs:122,161,169,190) */
     uint32_t emis_first;  /* AnimatedColor keyframes in color_keys[] (film/animated_color.rs:45-49), sorted by time */
     uint32_t emis_count;
-    uint32_t pad[2];
+    uint32_t moving_slot; /* index among the animated instances of this frame (0xffffffff if not animated) */
+    uint32_t pad;
 } TrayInstance;
 
 /* TRS keyframe (src/linalg/keyframe.rs:13-17) */
@@ -118,8 +119,11 @@ typedef struct TrayXformLevel {
     uint32_t kf_first, kf_count;     /* control points in keyframes[] */
     uint32_t knot_first, knot_count; /* knots in knots[] (sorted ascending) */
     uint32_t degree;
-    uint32_t pad[3];
-    float mat[16];                   /* control_point.transform() when kf_count == 1 (keyframe.rs:60-63) */
+    uint32_t is_const;               /* 1 => the level has the same value for every ray of this frame: one control point, or
+                                      * the open shutter lies outside the knot domain, where transform() clamps the time
+                                      * (animated_transform.rs:49-50). mat/inv hold that value. */
+    uint32_t pad[2];
+    float mat[16];                   /* Keyframe::transform() of the constant level (keyframe.rs:60-63) */
     float inv[16];
 } TrayXformLevel;
 

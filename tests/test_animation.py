@@ -115,6 +115,26 @@ def test_frames_differ_and_motion_blurs(moving):
     assert (a == c).all()
 
 
+def test_levels_outside_their_knot_domain_are_constant_for_the_frame(tmp_path, built):
+    """transform() clamps the time to the knot domain (animated_transform.rs:49-50): a spline that ended before the shutter
+    opens is one matrix for the whole frame. The oracle keeps evaluating it per ray and must agree bit for bit."""
+    d = scenes.moving_box(48, 32, 4, frames=8, scene_time=2.0)
+    ball = [o for o in d["objects"] if o.get("name") == "ball"][0]
+    ball["keyframes"]["knots"] = scenes._clamped_knots(4, 0.0, 0.6)   # the ball stops at t = 0.6
+    scenes.write_moving_box(str(tmp_path))
+    scene, *_ = T.Scene.load_string(json.dumps(d), str(tmp_path))
+    for frame, moving in ((1, True), (2, True), (3, False), (6, False)):   # frame 2 spans 0.5 .. 0.625
+        flat = scene.flatten(frame)
+        fs = flat.contents
+        b = [fs.instances[i] for i in range(fs.n_instances) if fs.instances[i].geom_type == 0 and fs.instances[i].xf_count == 1][0]
+        assert bool(b.animated) == moving, frame
+        lv = fs.xf_levels[b.xf_first]
+        assert lv.kf_count == 4 and bool(lv.is_const) == (not moving)
+        a, _ = O.render_tiles(flat, 4, seed=3)
+        c, _ = O.render_tiles(flat, 4, seed=3, flags=O.FAITHFUL_XF)
+        assert (a == c).all()
+
+
 def test_closed_shutter_needs_no_per_ray_evaluation(tmp_path, built):
     p = scenes.write_moving_box(str(tmp_path), width=32, height=24, samples=4, shutter_size=0.0)
     scene, *_ = T.Scene.load_file(p)
@@ -161,7 +181,10 @@ def test_tr15_stand_in_has_the_structure_of_tr15(tmp_path, built):
     assert (scene.info.n_instances, scene.info.n_lights, scene.info.n_meshes) == (59, 10, 25)
     fs = scene.flatten(330).contents
     assert (fs.min_depth, fs.max_depth, fs.n_merl, fs.n_materials) == (5, 10, 5, 20)
-    assert sum(fs.instances[i].animated for i in range(fs.n_instances)) == 14
+    splined = [i for i in range(fs.n_instances)
+               if any(fs.xf_levels[fs.instances[i].xf_first + l].kf_count > 1 for l in range(fs.instances[i].xf_count))]
+    assert len(splined) == 14
+    assert sum(fs.instances[i].animated for i in range(fs.n_instances)) == 2   # dragon and rust_logo move at t = 13.75
     assert sum(fs.instances[i].emis_count >= 2 for i in range(fs.n_instances)) == 10
     assert fs.camera.animated == 1
     img, st = O.render_tiles(scene.flatten(330), 4, seed=1)

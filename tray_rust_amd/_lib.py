@@ -44,7 +44,7 @@ class TrayInstance(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("geom_type", C.c_uint32), ("mesh_id", C.c_uint32), ("material_id", C.c_uint32),
                 ("geom_params", C.c_float * 4), ("emission", C.c_float * 4), ("mat", C.c_float * 16), ("inv", C.c_float * 16),
                 ("light_index", C.c_uint32), ("xf_first", C.c_uint32), ("xf_count", C.c_uint32), ("animated", C.c_uint32),
-                ("emis_first", C.c_uint32), ("emis_count", C.c_uint32), ("pad", C.c_uint32 * 2)]
+                ("emis_first", C.c_uint32), ("emis_count", C.c_uint32), ("moving_slot", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class TrayKeyframe(C.Structure):
@@ -53,7 +53,7 @@ class TrayKeyframe(C.Structure):
 
 class TrayXformLevel(C.Structure):
     _fields_ = [("kf_first", C.c_uint32), ("kf_count", C.c_uint32), ("knot_first", C.c_uint32), ("knot_count", C.c_uint32),
-                ("degree", C.c_uint32), ("pad", C.c_uint32 * 3), ("mat", C.c_float * 16), ("inv", C.c_float * 16)]
+                ("degree", C.c_uint32), ("is_const", C.c_uint32), ("pad", C.c_uint32 * 2), ("mat", C.c_float * 16), ("inv", C.c_float * 16)]
 
 
 class TrayColorKey(C.Structure):

@@ -162,7 +162,7 @@ __device__ __noinline__ void eval_xform_stack(const TrayXformLevel* __restrict__
     for (uint32_t l = 0; l < xf_count; ++l) {
         const TrayXformLevel* __restrict__ lv = levels + xf_first + l;
         float km[16], ki[16];
-        if (lv->kf_count == 1u) {
+        if (lv->is_const != 0u) {   // one control point, or the open shutter misses the knot domain: evaluated on the host
 #pragma unroll
             for (int i = 0; i < 16; ++i) { km[i] = lv->mat[i]; ki[i] = lv->inv[i]; }
         } else {

@@ -54,6 +54,12 @@ struct DevScene {
     const TrayKeyframe* __restrict__ keyframes;
     const float* __restrict__ knots;
     const TrayColorKey* __restrict__ color_keys;
+    // Per-path transform cache of the moving instances (ANIM kernels): every ray of a path carries the camera ray's time, so
+    // each lane evaluates the spline stacks ONCE per camera sample and keeps mat/inv rows in HBM, laid out
+    // [moving_slot][24 floats][lane] so that a wave reads / writes 256 contiguous bytes per float.
+    float* __restrict__ xf_cache;              // nullptr: evaluate at every use (debug kernels)
+    const uint32_t* __restrict__ moving_ids;   // instance ids of the moving instances, by moving_slot
+    uint32_t n_moving, xf_cache_lanes;
     uint32_t n_instances, n_lights, min_depth, max_depth;
     uint32_t width, height, frame, film_rows;   // film_rows: 1 = row-binned film (separable, filter_h == 2)
     float filter_w, filter_h, inv_w, inv_h;
@@ -70,9 +76,41 @@ struct Ray {
 // Transform of an instance at a ray's time as rows 0..2 of mat (x) and of inv (x + 12). Instance transforms are products
 // of TRS keyframes (AnimatedTransform::unanimated decomposes static ones too), so row 3 is (0,0,0,1) and the affine
 // point transform equals Transform * Point.
+TR_DEV uint32_t xf_cache_lane() { return blockIdx.x * blockDim.x + threadIdx.x; }
+// start of a camera sample: evaluate every moving instance at the path's time into this lane's cache column
+TR_DEV void xf_cache_fill(const DevScene& sc, float time) {
+    if (!sc.xf_cache) return;
+    const uint32_t lane = xf_cache_lane(), lanes = sc.xf_cache_lanes;
+    for (uint32_t m = 0; m < sc.n_moving; ++m) {
+        const TrayInstance* __restrict__ in = sc.instances + sc.moving_ids[m];
+        float x[24];
+        eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
+        float* __restrict__ col = sc.xf_cache + (size_t)m * 24u * lanes + lane;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) col[(size_t)k * lanes] = x[k];
+    }
+}
+// rows of inv only (x + 12 .. x + 23 are written)
+TR_DEV void instance_inv_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, float* x) {
+    if (sc.xf_cache) {
+        const uint32_t lanes = sc.xf_cache_lanes;
+        const float* __restrict__ col = sc.xf_cache + ((size_t)in->moving_slot * 24u + 12u) * lanes + xf_cache_lane();
+#pragma unroll
+        for (int k = 0; k < 12; ++k) x[12 + k] = col[(size_t)k * lanes];
+    } else {
+        eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
+    }
+}
 TR_DEV void instance_xf_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, float* x) {
     if (in->animated) {
-        eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
+        if (sc.xf_cache) {
+            const uint32_t lanes = sc.xf_cache_lanes;
+            const float* __restrict__ col = sc.xf_cache + (size_t)in->moving_slot * 24u * lanes + xf_cache_lane();
+#pragma unroll
+            for (int k = 0; k < 24; ++k) x[k] = col[(size_t)k * lanes];
+        } else {
+            eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 12; ++k) { x[k] = in->mat[k]; x[12 + k] = in->inv[k]; }
@@ -348,7 +386,7 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
             f3 lo_, ld;
             if (ANIM && in->animated) {   // transform.transform(ray.time) per visit (receiver.rs:30)
                 float x[24];
-                eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, ray.time, x);
+                instance_inv_at(sc, in, ray.time, x);
                 lo_ = xf_point_affine(x + 12, ray.o);
                 ld = xf_vector(x + 12, ray.d);
             } else {

@@ -97,6 +97,7 @@ struct Lane {
     f3 t_vertex;           // throughput at this vertex, kept for `illum += throughput * direct`
 };
 
+// (the ANIM tile kernel calls xf_cache_fill(sc, cam_ray.time) right after this)
 TR_DEV void lane_start_sample(Lane& ln, const Ray& cam_ray, uint32_t ks) {
     ln.flags = LF_ALIVE;
     ln.bounce = 0u;

@@ -252,6 +252,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
                     float t;
                     pixel_sample(kp, s_next, spp, px, py, sx, sy, t);
                     lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), key_sample(kp, s_next));
+                    if (ANIM) xf_cache_fill(sc, ln.time);   // the path's transforms of the moving instances, once per camera sample
                     s_next += TR_BLOCK / 64;
                     ++n_samples;
                     pending = true;
@@ -445,6 +446,7 @@ struct TrayDeviceScene {
     uint32_t stack_bytes = 0;   // dynamic LDS of every kernel that traverses: stack depth x TR_BLOCK x 4
     bool wavefront = false;   // TRAYHIP_MODE=wave selects the stage-kernel schedule (wavefront.h)
     bool animated = false;    // something moves while the shutter is open: the <ANIM = true> kernels run
+    uint32_t deferred_n_moving = 0;
 };
 
 static thread_local int g_device = 0;
@@ -664,8 +666,27 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     hipError_t occ = s->animated ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles<true>, TR_BLOCK, s->stack_bytes)
                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles<false>, TR_BLOCK, s->stack_bytes);
     if (occ != hipSuccess || per_cu < 1) per_cu = 1;
+    s->deferred_n_moving = 0;
+    for (uint32_t i = 0; i < f->n_instances; ++i) if (f->instances[i].animated) s->deferred_n_moving++;
     if (cus < 1) cus = 256;
     s->n_blocks = cus * per_cu;
+    if (s->animated && s->deferred_n_moving > 0 && s->deferred_n_moving <= 64) {   // per-path transform cache (dev_geom.h)
+        std::vector<uint32_t> ids(s->deferred_n_moving, 0u);
+        for (uint32_t i = 0; i < f->n_instances; ++i)
+            if (f->instances[i].animated && f->instances[i].moving_slot < ids.size()) ids[f->instances[i].moving_slot] = i;
+        const uint32_t* d_ids = nullptr;
+        if (upload(s, ids.data(), ids.size(), &d_ids) != TRAY_OK) { tray_scene_destroy(s); return TRAY_E_NOMEM; }
+        const uint32_t lanes = (uint32_t)s->n_blocks * TR_BLOCK;
+        void* cache = nullptr;
+        if (hipMalloc(&cache, (size_t)s->deferred_n_moving * 24u * lanes * sizeof(float)) != hipSuccess) {
+            tray_scene_destroy(s); set_error("hipMalloc of the transform cache failed"); return TRAY_E_NOMEM;
+        }
+        s->allocs.push_back(cache);
+        s->dev.xf_cache = static_cast<float*>(cache);
+        s->dev.moving_ids = d_ids;
+        s->dev.n_moving = s->deferred_n_moving;
+        s->dev.xf_cache_lanes = lanes;
+    }
     *out = s;
     return TRAY_OK;
 }
@@ -837,7 +858,9 @@ int tray_debug_intersect(TrayDeviceScene* s, uint32_t n, const TrayRay* rays, Tr
     hipError_t e = hipMalloc(&d_h, n * sizeof(TrayHit));
     if (e == hipSuccess) e = hipMemcpy(d_r, rays, n * sizeof(TrayRay), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        if (s->animated) hipLaunchKernelGGL(k_debug_intersect<true>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_r, d_h);
+        DevScene nocache = s->dev;   // debug grids are sized by the item count, not by the cache: evaluate at every use
+        nocache.xf_cache = nullptr;
+        if (s->animated) hipLaunchKernelGGL(k_debug_intersect<true>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, nocache, n, d_r, d_h);
         else hipLaunchKernelGGL(k_debug_intersect<false>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_r, d_h);
         e = hipGetLastError();
     }
@@ -868,8 +891,10 @@ int tray_debug_sample_radiance(TrayDeviceScene* s, uint32_t n, const uint32_t* p
         uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
         kf = mix(kf ^ (uint32_t)(seed >> 32));
         kf = mix(kf + s->dev.frame);
+        DevScene nocache = s->dev;
+        nocache.xf_cache = nullptr;
         if (s->animated)
-            hipLaunchKernelGGL(k_debug_sample_radiance<true>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
+            hipLaunchKernelGGL(k_debug_sample_radiance<true>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, nocache, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
         else
             hipLaunchKernelGGL(k_debug_sample_radiance<false>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
         e = hipGetLastError();

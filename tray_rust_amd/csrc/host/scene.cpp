@@ -55,6 +55,30 @@ struct AnimXform {
         for (auto& l : levels) if (l.kfs.size() > 1) return true;
         return false;
     }
+    // A level whose value is the same for every time in [open, close]: a single control point, or a spline whose knot
+    // domain the interval does not enter (transform() clamps the time, animated_transform.rs:49-50)
+    static bool level_const_over(const SplineLevel& l, float open, float close, float& t_eval) {
+        t_eval = open;
+        if (l.kfs.size() == 1) return true;
+        float lo = l.knots[l.degree], hi = l.knots[l.knots.size() - 1 - l.degree];
+        if (open == close) { t_eval = clampf(open, lo, hi); return true; }
+        if (open >= hi) { t_eval = hi; return true; }
+        // frame_time = (close - open) * u + open (camera.rs:155) can round one ulp past `close`: keep a margin
+        float close_max = std::nextafter(std::nextafter(close, INFINITY), INFINITY);
+        if (close_max <= lo) { t_eval = lo; return true; }
+        return false;
+    }
+    bool varies_over(float open, float close) const {
+        float t;
+        for (auto& l : levels) if (!level_const_over(l, open, close, t)) return true;
+        return false;
+    }
+    static Xform level_transform(const SplineLevel& l, float time) {
+        if (l.kfs.size() == 1) return l.kfs[0].transform();
+        size_t nk = l.knots.size();
+        float t_val = clampf(time, l.knots[l.degree], l.knots[nk - 1 - l.degree]);
+        return bspline_point(l.kfs.data(), l.knots.data(), nk, l.degree, t_val, kf_interpolate).transform();
+    }
     // AnimatedTransform::transform (animated_transform.rs:40-56)
     Xform transform(float time) const {
         Xform t = Xform::identity();
@@ -846,8 +870,10 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
             tl.kf_first = (uint32_t)s.f_keyframes.size(); tl.kf_count = (uint32_t)l.kfs.size();
             tl.knot_first = (uint32_t)s.f_knots.size(); tl.knot_count = (uint32_t)l.knots.size();
             tl.degree = l.degree;
-            if (l.kfs.size() == 1) {
-                Xform kt = l.kfs[0].transform();
+            float t_eval;
+            if (AnimXform::level_const_over(l, shutter_open, shutter_close, t_eval)) {
+                Xform kt = AnimXform::level_transform(l, t_eval);
+                tl.is_const = 1;
                 std::memcpy(tl.mat, kt.mat.m, sizeof tl.mat);
                 std::memcpy(tl.inv, kt.inv.m, sizeof tl.inv);
             }
@@ -892,7 +918,7 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
         float tan_fov = std::tan(to_radians(fov) / 2.0f);
         c.scaling[0] = tan_fov; c.scaling[1] = tan_fov; c.scaling[2] = 1.0f;
         c.shutter_open = shutter_open; c.shutter_close = shutter_close;
-        c.animated = (cam.cam_world.any_animated() && shutter_open != shutter_close) ? 1u : 0u;
+        c.animated = cam.cam_world.varies_over(shutter_open, shutter_close) ? 1u : 0u;
         Xform cw = cam.cam_world.transform(shutter_open);
         std::memcpy(c.cam_world, cw.mat.m, sizeof c.cam_world);
         push_levels(cam.cam_world, c.xf_first, c.xf_count);
@@ -901,6 +927,7 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
     // Instances, lights, top-level BVH over the shutter interval (scene.rs:171-175; receiver.rs:55-57)
     s.f_instances.clear(); s.f_lights.clear(); s.f_color_keys.clear();
     bool any_animated = f.camera.animated != 0;
+    uint32_t n_moving = 0;
     std::vector<BBox> inst_bounds;
     for (size_t i = 0; i < s.instances.size(); ++i) {
         const HostInstance& hi = s.instances[i];
@@ -924,8 +951,9 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
             s.f_lights.push_back((uint32_t)i);
         }
         // with a closed shutter every ray of the frame has time == shutter_open: the stack is evaluated once, here
-        ti.animated = (hi.xf.any_animated() && shutter_open != shutter_close) ? 1u : 0u;
-        if (ti.animated) any_animated = true;
+        ti.animated = hi.xf.varies_over(shutter_open, shutter_close) ? 1u : 0u;
+        ti.moving_slot = 0xffffffffu;
+        if (ti.animated) { any_animated = true; ti.moving_slot = n_moving++; }
         Xform t = hi.xf.transform(shutter_open);
         std::memcpy(ti.mat, t.mat.m, sizeof ti.mat);
         std::memcpy(ti.inv, t.inv.m, sizeof ti.inv);
