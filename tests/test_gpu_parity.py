@@ -282,10 +282,13 @@ def test_dragon_image_rmse(dragon):
     assert r < 1e-4
 
 
+@pytest.mark.parametrize("trace", ["dyn", "slot"])
 @pytest.mark.parametrize("name", list(SCENES))
-def test_wavefront_schedule_matches_the_oracle(name, tmp_path, monkeypatch):
-    """TRAYHIP_MODE=wave: the stage-kernel schedule over the HBM path pool renders the same image."""
+def test_wavefront_schedule_matches_the_oracle(name, trace, tmp_path, monkeypatch):
+    """TRAYHIP_MODE=wave: the stage-kernel schedule over the HBM path pool renders the same image, with compacted ray
+    queues + persistent dynamic-fetch traversal (dyn, the default) or one thread per pool slot (slot)."""
     monkeypatch.setenv("TRAYHIP_MODE", "wave")
+    monkeypatch.setenv("TRAYHIP_WF_TRACE", trace)
     monkeypatch.setenv("TRAYHIP_WF_SLOTS", "65536")
     scene, rt, _, fi = load(SCENES[name](96, 64, 16), tmp_path)
     gpu, tim = gpu_render(scene, rt, 16, fi, seed=6)

@@ -13,6 +13,10 @@ frame = 0
 if scene_name == "tr15_like":
     scenes.write_tr15_like_assets(d, film=(1920, 1080, spp), detail=float(os.environ.get("TR15_DETAIL", "1.0")))
     frame = int(os.environ.get("TR15_FRAME", "330"))
+    if "TR15_SHUTTER" in os.environ:   # 0 = closed shutter: nothing moves within a frame, the static kernels run
+        import json
+        desc = json.load(open(f"{d}/tr15_like.json")); desc["camera"]["shutter_size"] = float(os.environ["TR15_SHUTTER"])
+        json.dump(desc, open(f"{d}/tr15_like.json", "w"))
 elif scene_name == "dragon":
     scenes.write_dragon_assets(d, film=(1920, 1080, spp), extent=float(os.environ.get("DRAGON_EXTENT", "0.2")))
 else:

@@ -23,6 +23,14 @@ for path in glob.glob(os.path.join(out_dir, "pmc_*", "**", "*kernel_trace.csv"),
         k = row["Kernel_Name"].split("(")[0]
         kernel_ns.setdefault(k, []).append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
 if counters:
+    per_kernel = []
+    for k, c in sorted(counters.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0.0)):
+        if c.get("SQ_ACTIVE_INST_VALU"):
+            per_kernel.append(f"# kernel {k}: wave_cycles {c.get('SQ_WAVE_CYCLES', 0):.4g} valu_insts {c.get('SQ_INSTS_VALU', 0):.4g} "
+                              f"lane_util {c.get('SQ_THREAD_CYCLES_VALU', 0) / (64 * c['SQ_ACTIVE_INST_VALU']):.3f} "
+                              f"wait_share {c.get('SQ_WAIT_ANY', 0) / max(c.get('SQ_WAVE_CYCLES', 1), 1):.3f} "
+                              f"total_ms {sum(kernel_ns.get(k, [0])) / 1e6 / max(1, len(glob.glob(os.path.join(out_dir, 'pmc_*')) ) // 2 or 1):.1f}")
+    open(os.path.join(dest, f"{tag}_per_kernel.txt"), "w").write("\n".join(per_kernel) + "\n")
     dominant = max(counters, key=lambda k: counters[k].get("SQ_WAVE_CYCLES", 0.0) + counters[k].get("FETCH_SIZE", 0.0))
     c = counters[dominant]
     lines = [f"# rocprofv3 --kernel-trace --pmc <set> -- python tools/bench_small.py 64 1 {workload}  ({workload} 1920x1080, 64 spp, one launch)",

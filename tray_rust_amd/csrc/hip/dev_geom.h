@@ -71,16 +71,17 @@ struct Ray {
     f3 o, d;
     float min_t, max_t;
     float time;   // ray.time (linalg/ray.rs:17): only read by the kernels built for moving scenes (ANIM)
+    uint32_t col; // column of the per-path transform cache that belongs to this ray's path (ANIM)
 };
 
 // Transform of an instance at a ray's time as rows 0..2 of mat (x) and of inv (x + 12). Instance transforms are products
 // of TRS keyframes (AnimatedTransform::unanimated decomposes static ones too), so row 3 is (0,0,0,1) and the affine
 // point transform equals Transform * Point.
-TR_DEV uint32_t xf_cache_lane() { return blockIdx.x * blockDim.x + threadIdx.x; }
-// start of a camera sample: evaluate every moving instance at the path's time into this lane's cache column
-TR_DEV void xf_cache_fill(const DevScene& sc, float time) {
+TR_DEV uint32_t xf_cache_lane() { return blockIdx.x * blockDim.x + threadIdx.x; }   // megakernel: one column per thread
+// start of a camera sample: evaluate every moving instance at the path's time into the path's cache column
+TR_DEV void xf_cache_fill(const DevScene& sc, float time, uint32_t lane) {
     if (!sc.xf_cache) return;
-    const uint32_t lane = xf_cache_lane(), lanes = sc.xf_cache_lanes;
+    const uint32_t lanes = sc.xf_cache_lanes;
     for (uint32_t m = 0; m < sc.n_moving; ++m) {
         const TrayInstance* __restrict__ in = sc.instances + sc.moving_ids[m];
         float x[24];
@@ -91,21 +92,21 @@ TR_DEV void xf_cache_fill(const DevScene& sc, float time) {
     }
 }
 // rows of inv only (x + 12 .. x + 23 are written)
-TR_DEV void instance_inv_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, float* x) {
+TR_DEV void instance_inv_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, uint32_t column, float* x) {
     if (sc.xf_cache) {
         const uint32_t lanes = sc.xf_cache_lanes;
-        const float* __restrict__ col = sc.xf_cache + ((size_t)in->moving_slot * 24u + 12u) * lanes + xf_cache_lane();
+        const float* __restrict__ col = sc.xf_cache + ((size_t)in->moving_slot * 24u + 12u) * lanes + column;
 #pragma unroll
         for (int k = 0; k < 12; ++k) x[12 + k] = col[(size_t)k * lanes];
     } else {
         eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
     }
 }
-TR_DEV void instance_xf_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, float* x) {
+TR_DEV void instance_xf_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, uint32_t column, float* x) {
     if (in->animated) {
         if (sc.xf_cache) {
             const uint32_t lanes = sc.xf_cache_lanes;
-            const float* __restrict__ col = sc.xf_cache + (size_t)in->moving_slot * 24u * lanes + xf_cache_lane();
+            const float* __restrict__ col = sc.xf_cache + (size_t)in->moving_slot * 24u * lanes + column;
 #pragma unroll
             for (int k = 0; k < 24; ++k) x[k] = col[(size_t)k * lanes];
         } else {
@@ -386,7 +387,7 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
             f3 lo_, ld;
             if (ANIM && in->animated) {   // transform.transform(ray.time) per visit (receiver.rs:30)
                 float x[24];
-                instance_inv_at(sc, in, ray.time, x);
+                instance_inv_at(sc, in, ray.time, ray.col, x);
                 lo_ = xf_point_affine(x + 12, ray.o);
                 ld = xf_vector(x + 12, ray.d);
             } else {
@@ -450,7 +451,7 @@ TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, flo
     float x[24];
     f3 o, d;
     if (ANIM) {
-        instance_xf_at(sc, in, ray.time, x);
+        instance_xf_at(sc, in, ray.time, ray.col, x);
         o = xf_point_affine(x + 12, ray.o);
         d = xf_vector(x + 12, ray.d);
     } else {
@@ -545,7 +546,7 @@ TR_DEV f3 finish_hit_ng(const DevScene& sc, const Ray& ray, const HitRec& rec) {
     uint32_t gt = in->geom_type;
     f3 ng;
     float x[24];
-    if (ANIM) instance_xf_at(sc, in, ray.time, x);
+    if (ANIM) instance_xf_at(sc, in, ray.time, ray.col, x);
     if (gt == TRAY_GEOM_SPHERE) {
         f3 o = ANIM ? xf_point_affine(x + 12, ray.o) : xf_point(in->inv, ray.o);
         f3 d = ANIM ? xf_vector(x + 12, ray.d) : xf_vector(in->inv, ray.d);

@@ -41,7 +41,7 @@ TR_DEV Ray camera_ray(const DevScene& sc, float px, float py, float time) {
         r.d = xf_vector(c.cam_world, d);
     }
     r.min_t = 0.0f; r.max_t = TR_INF;
-    r.time = frame_time;
+    r.time = frame_time; r.col = 0u;
     return r;
 }
 
@@ -83,6 +83,7 @@ struct Lane {
     uint32_t bounce;       // index of the path vertex being shaded
     uint32_t ks;           // sample key: scrambles and shuffle entries of the six LD arrays derive from it
     float time;            // ray.time of the camera ray, inherited by every ray of the path (path.rs:110, mod.rs:154)
+    uint32_t col;          // the path's column of the transform cache (ANIM): thread id (tile kernel) or pool slot (wavefront)
     f3 o, d;               // stage A ray: camera ray, or continuation from the previous vertex
     f3 throughput, illum;
     f3 first_ng;           // hit.dg.ng of the camera ray's hit (quirk Q1)
@@ -103,7 +104,7 @@ TR_DEV void lane_start_sample(Lane& ln, const Ray& cam_ray, uint32_t ks) {
     ln.bounce = 0u;
     ln.ks = ks;
     ln.o = cam_ray.o; ln.d = cam_ray.d;
-    ln.time = cam_ray.time;
+    ln.time = cam_ray.time; ln.col = 0u;
     ln.throughput = mk(1.0f, 1.0f, 1.0f);
     ln.illum = mk(0.0f, 0.0f, 0.0f);
 }
@@ -123,19 +124,19 @@ TR_DEV Ray stage_a_ray(const Lane& ln) {
     r.o = ln.o; r.d = ln.d;
     r.min_t = ln.bounce == 0u ? 0.0f : 0.001f;   // camera ray (ray.rs:25-27) vs ray.min_t = 0.001 (path.rs:110)
     r.max_t = TR_INF;
-    r.time = ln.time;
+    r.time = ln.time; r.col = ln.col;
     return r;
 }
 TR_DEV Ray stage_b_ray(const Lane& ln) {   // OcclusionTester::test_points (light/mod.rs:21-23): unnormalised segment (quirk Q4)
     Ray r;
     r.o = ln.bsdf.p; r.d = ln.aux_d; r.min_t = 0.001f; r.max_t = 0.999f;
-    r.time = ln.time;
+    r.time = ln.time; r.col = ln.col;
     return r;
 }
 TR_DEV Ray stage_c_ray(const Lane& ln) {   // Ray::segment(p, w_i, 0.001, inf) (mod.rs:154)
     Ray r;
     r.o = ln.bsdf.p; r.d = ln.aux_d; r.min_t = 0.001f; r.max_t = TR_INF;
-    r.time = ln.time;
+    r.time = ln.time; r.col = ln.col;
     return r;
 }
 
@@ -169,7 +170,7 @@ TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counte
     // Light::sample_incident (emitter.rs:165-186)
     f3 p_w;
     float x[24];   // ANIM: self.transform.transform(time) (emitter.rs:168,175)
-    if (ANIM) instance_xf_at(sc, light, ln.time, x);
+    if (ANIM) instance_xf_at(sc, light, ln.time, ln.col, x);
     if (light->kind == TRAY_INST_POINT_EMITTER) {
         f3 pos = ANIM ? xf_point_affine(x, mk(0.0f, 0.0f, 0.0f)) : xf_point(light->mat, mk(0.0f, 0.0f, 0.0f));
         ln.wi_l = normalized(pos - ln.bsdf.p);
@@ -238,7 +239,7 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
                 f3 p_l, wl;
                 if (ANIM) {
                     float x[24];
-                    instance_xf_at(sc, light, ln.time, x);
+                    instance_xf_at(sc, light, ln.time, ln.col, x);
                     p_l = xf_point_affine(x + 12, ln.bsdf.p);
                     wl = normalized(xf_vector(x + 12, w_i));
                 } else {

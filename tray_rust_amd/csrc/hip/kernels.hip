@@ -252,7 +252,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
                     float t;
                     pixel_sample(kp, s_next, spp, px, py, sx, sy, t);
                     lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), key_sample(kp, s_next));
-                    if (ANIM) xf_cache_fill(sc, ln.time);   // the path's transforms of the moving instances, once per camera sample
+                    if (ANIM) { ln.col = xf_cache_lane(); xf_cache_fill(sc, ln.time, ln.col); }   // the path's transforms of the moving instances, once per camera sample
                     s_next += TR_BLOCK / 64;
                     ++n_samples;
                     pending = true;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene scv
     Ray r;
     r.o = mk(rays[i].o[0], rays[i].o[1], rays[i].o[2]);
     r.d = mk(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
-    r.min_t = rays[i].min_t; r.max_t = rays[i].max_t; r.time = rays[i].time;
+    r.min_t = rays[i].min_t; r.max_t = rays[i].max_t; r.time = rays[i].time; r.col = 0u;
     TrayHit o;
     memset(&o, 0, sizeof o);
     TraceResult tr_ = trace<ANIM>(scp, s_stack + threadIdx.x, r, false);
@@ -447,6 +447,9 @@ struct TrayDeviceScene {
     bool wavefront = false;   // TRAYHIP_MODE=wave selects the stage-kernel schedule (wavefront.h)
     bool animated = false;    // something moves while the shutter is open: the <ANIM = true> kernels run
     uint32_t deferred_n_moving = 0;
+    uint32_t* d_queues = nullptr;     // wavefront schedule: ray queues A, B, C (n_slots each) + WF_QCTL_WORDS counters
+    uint32_t n_blocks_trace = 0;      // persistent grid of k_wf_trace_dyn
+    bool wf_dynamic = true;           // TRAYHIP_WF_TRACE=slot: one thread per pool slot instead (no compaction)
 };
 
 static thread_local int g_device = 0;
@@ -471,6 +474,41 @@ static int upload(TrayDeviceScene* s, const T* host, size_t n, const T** out) {
     else HIP_CHECK(hipMemset(d, 0, bytes));
     *out = static_cast<const T*>(d);
     return TRAY_OK;
+}
+
+#ifndef WF_SLOTS
+#define WF_SLOTS (4u << 20)
+#endif
+#define WF_POLL 16
+// one round of the wavefront schedule: advance -> trace A -> begin -> trace B -> query -> trace C
+template <bool ANIM>
+static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 tgrid, dim3 block, hipStream_t stream, const uint2* tiles, uint32_t tile_count, uint32_t chunk,
+                     uint32_t chunk_stride, uint32_t spp, uint32_t kf, float* rgbw_dev, uint32_t n_active, uint32_t* qa, uint32_t* qb, uint32_t* qc,
+                     uint32_t* qctl) {
+    if (s->wf_dynamic) {   // compacted ray queues + persistent traversal with dynamic fetch
+        hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
+                           spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, qa, qctl);
+        hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->stack_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats);
+        hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, qb, qctl);
+        hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->stack_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats);
+        hipLaunchKernelGGL(k_wf_query<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, qc, qctl);
+        hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->stack_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats);
+    } else {
+        uint32_t* const none = nullptr;
+        hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
+                           spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, none, none);
+        hipLaunchKernelGGL((k_wf_trace<0, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
+        hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, none, none);
+        hipLaunchKernelGGL((k_wf_trace<1, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
+        hipLaunchKernelGGL(k_wf_query<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, none, none);
+        hipLaunchKernelGGL((k_wf_trace<2, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
+    }
+}
+
+static uint32_t wf_slot_count() {
+    uint32_t n_slots = WF_SLOTS;
+    if (const char* e = getenv("TRAYHIP_WF_SLOTS")) n_slots = (uint32_t)std::max(256l, atol(e)) / TR_BLOCK * TR_BLOCK;
+    return n_slots;
 }
 
 extern "C" {
@@ -591,7 +629,10 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             for (int x = 0; x < TRAY_FILTER_TABLE_SIZE; ++x)
                 if (f->film.table[y * TRAY_FILTER_TABLE_SIZE + x] != f->film.table_x[x] * f->film.table_y[y]) { ok = false; break; }
         d.film_rows = (ok && !getenv("TRAYHIP_DIRECT_FILM")) ? 1u : 0u;
-        if (const char* m = getenv("TRAYHIP_MODE")) s->wavefront = std::string(m) == "wave" && !s->animated;
+        // schedule: the tile megakernel for scenes its flat instance loop covers, the wavefront stage kernels (compacted ray
+        // queues, persistent traversal with dynamic fetch) for scenes that go through BVH<Instance>; TRAYHIP_MODE overrides
+        s->wavefront = f->n_instances > TR_FLAT_MAX;
+        if (const char* m = getenv("TRAYHIP_MODE")) s->wavefront = std::string(m) == "wave";
     }
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
@@ -642,7 +683,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         for (uint32_t m = 0; m < f->n_meshes; ++m)
             mesh_depth = std::max(mesh_depth, depth_of(f->mesh_nodes + f->meshes[m].node_offset, f->meshes[m].node_count));
         uint32_t depth = mesh_depth + 1;
-        if (f->n_instances > TR_FLAT_MAX || s->animated) depth += depth_of(f->top_nodes, f->n_top_nodes) + 4 + 1;
+        if (f->n_instances > TR_FLAT_MAX || s->animated || s->wavefront) depth += depth_of(f->top_nodes, f->n_top_nodes) + 4 + 1;
         depth = std::max(depth, 4u);
         if (depth > 96) { tray_scene_destroy(s); set_error("BVH too deep for the LDS traversal stack (" + std::to_string(depth) + " levels)"); return TRAY_E_UNSUPPORTED; }
         s->stack_bytes = depth * TR_BLOCK * (uint32_t)sizeof(uint32_t);
@@ -650,9 +691,18 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             const int bytes = (int)s->stack_bytes;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_intersect<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_intersect<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_sample_radiance<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -676,7 +726,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             if (f->instances[i].animated && f->instances[i].moving_slot < ids.size()) ids[f->instances[i].moving_slot] = i;
         const uint32_t* d_ids = nullptr;
         if (upload(s, ids.data(), ids.size(), &d_ids) != TRAY_OK) { tray_scene_destroy(s); return TRAY_E_NOMEM; }
-        const uint32_t lanes = (uint32_t)s->n_blocks * TR_BLOCK;
+        const uint32_t lanes = s->wavefront ? wf_slot_count() : (uint32_t)s->n_blocks * TR_BLOCK;   // one column per pool slot / per thread
         void* cache = nullptr;
         if (hipMalloc(&cache, (size_t)s->deferred_n_moving * 24u * lanes * sizeof(float)) != hipSuccess) {
             tray_scene_destroy(s); set_error("hipMalloc of the transform cache failed"); return TRAY_E_NOMEM;
@@ -696,15 +746,10 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
 
 // Wavefront schedule: rounds of six stage kernels over the path pool until every tile is done.
 // The host only polls a "tiles done" word every WF_POLL rounds; kernels of finished chunks exit at once.
-#ifndef WF_SLOTS
-#define WF_SLOTS (4u << 20)
-#endif
-#define WF_POLL 16
 static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride,
                             uint32_t spp, uint32_t kf, float* rgbw_dev, hipStream_t stream) {
     if (!s->pool.data) {
-        uint32_t n_slots = WF_SLOTS;
-        if (const char* e = getenv("TRAYHIP_WF_SLOTS")) n_slots = (uint32_t)std::max(256l, atol(e)) / TR_BLOCK * TR_BLOCK;
+        uint32_t n_slots = wf_slot_count();
         s->n_chunks = n_slots / TR_BLOCK;
         void* p = nullptr;
         HIP_CHECK(hipMalloc(&p, (size_t)F_COUNT * n_slots * sizeof(float)));
@@ -717,6 +762,19 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
         HIP_CHECK(hipMemset(s->d_bins, 0, (size_t)s->n_chunks * ROWBIN_SIZE * sizeof(float)));
         HIP_CHECK(hipMalloc(&p, 2 * sizeof(uint32_t)));
         s->allocs.push_back(p); s->d_wf_counters = static_cast<uint32_t*>(p);
+        HIP_CHECK(hipMalloc(&p, (3 * (size_t)n_slots + WF_QCTL_WORDS) * sizeof(uint32_t)));   // ray queues A, B, C + their counters
+        s->allocs.push_back(p); s->d_queues = static_cast<uint32_t*>(p);
+        {
+            int per_cu = 0, cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+            hipError_t oe = s->animated ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, true>, TR_BLOCK, s->stack_bytes)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, false>, TR_BLOCK, s->stack_bytes);
+            if (oe != hipSuccess || per_cu < 1) per_cu = 1;
+            s->n_blocks_trace = (uint32_t)(cus * per_cu);
+            const char* e = getenv("TRAYHIP_WF_TRACE");
+            s->wf_dynamic = !(e && std::string(e) == "slot");
+        }
         HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s->h_done), sizeof(uint32_t), hipHostMallocDefault));
     }
     const uint32_t n_chunks = std::min(s->n_chunks, tile_count);
@@ -731,17 +789,15 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     const dim3 grid(n_chunks), block(TR_BLOCK);
     const uint2* tiles = s->d_tiles + tile_start;
     uint32_t launches = 0;
+    uint32_t* const qa = s->d_queues, * const qb = qa + s->pool.n_slots, * const qc = qb + s->pool.n_slots, * const qctl = qc + s->pool.n_slots;
+    const dim3 tgrid(std::min<uint32_t>(s->n_blocks_trace, n_chunks));
     // every chunk needs at most (spp/4 rounded up) samples x (max_depth + 2) rounds per tile, plus one round per tile switch
     const uint64_t tiles_per_chunk = (tile_count + n_chunks - 1) / n_chunks;
     const uint64_t max_rounds = tiles_per_chunk * (((uint64_t)spp + 3) / 4 * (s->dev.max_depth + 3) + 4) + 2 * WF_POLL;
     for (uint32_t round = 0;; ++round) {
-        hipLaunchKernelGGL(k_wf_advance, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
-                           spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats);
-        hipLaunchKernelGGL(k_wf_trace<0>, grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
-        hipLaunchKernelGGL(k_wf_begin, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats);
-        hipLaunchKernelGGL(k_wf_trace<1>, grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
-        hipLaunchKernelGGL(k_wf_query, grid, block, 0, stream, s->dev, s->pool, n_active);
-        hipLaunchKernelGGL(k_wf_trace<2>, grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
+        if (s->wf_dynamic) HIP_CHECK(hipMemsetAsync(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), stream));
+        if (s->animated) wf_round<true>(s, grid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qctl);
+        else wf_round<false>(s, grid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qctl);
         launches += 6;
         if (round % WF_POLL == WF_POLL - 1) {
             HIP_CHECK(hipGetLastError());

@@ -32,7 +32,8 @@ enum {
     F_P, F_N = F_P + 3, F_TAN = F_N + 3, F_BITAN = F_TAN + 3, F_MAT = F_BITAN + 3,
     F_WO, F_LINST = F_WO + 3, F_LI, F_WL = F_LI + 3, F_PDFL = F_WL + 3,
     F_AUX, F_DIRECT = F_AUX + 3, F_MISF = F_DIRECT + 3, F_TV = F_MISF + 3,
-    F_COUNT = F_TV + 3
+    F_TIME = F_TV + 3,   // ray.time of the path (moving scenes)
+    F_COUNT
 };
 
 struct WfPool {
@@ -62,7 +63,7 @@ TR_DEV void st_bsdf(const DevScene& sc, const WfPool& p, uint32_t i, const Bsdf&
 // STAGE 0: camera / continuation ray (closest hit) -> rec, WF_HIT_A
 // STAGE 1: occlusion ray of the light sample (any hit) -> WF_OCCLUDED
 // STAGE 2: BSDF-sampled ray of estimate_direct (closest hit) -> rec, WF_HIT_C
-template <int STAGE>
+template <int STAGE, bool ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace(const DevScene scv, WfPool pool, uint32_t n_active, DevStats* __restrict__ stats) {
     const DevScene* scp = &scv;
     extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries
@@ -81,7 +82,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace(const DevScene scv, WfPoo
         r.o = ld3(pool, F_P, i); r.d = ld3(pool, F_AUX, i);
         r.min_t = 0.001f; r.max_t = STAGE == 1 ? 0.999f : TR_INF;
     }
-    TraceResult t = trace<false>(scp, s_stack + threadIdx.x, r, STAGE == 1);
+    r.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; r.col = i;
+    TraceResult t = trace<ANIM>(scp, s_stack + threadIdx.x, r, STAGE == 1);
     if (STAGE == 1) {
         flags = t.hit ? (flags | WF_OCCLUDED) : (flags & ~WF_OCCLUDED);
     } else {
@@ -98,8 +100,206 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace(const DevScene scv, WfPoo
     if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].rays, (unsigned long long)__popcll(m));
 }
 
+// ---- ray queues: per-stage compaction of the slots that have a ray to trace --------------------
+// qctl[0..2] = entries in queue A / B / C, qctl[3..5] = consumer cursors; zeroed at the start of every round.
+// Producers append with one atomic per wave (ballot + prefix count); slots keep their place in the pool, only their
+// indices are compacted, so every stage still reads and writes pool fields at the slot's own address.
+#define WF_QCTL_WORDS 8
+TR_DEV void wf_enqueue(uint32_t* __restrict__ queue, uint32_t* __restrict__ count, bool want, uint32_t slot) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, (int)leader);
+    if (want) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
+}
+
+// Persistent-threads traversal with dynamic ray fetch: a wave keeps 64 rays in flight; a lane whose ray is finished takes
+// the next entry of the stage's queue instead of idling until the slowest ray of its wave is done (the tail is what
+// holds the lane utilisation of one-ray-per-lane kernels near 10 % on scenes that mix walls with million-triangle
+// meshes). One loop iteration = one step of the one-loop two-level traversal of trace_bvh (same visiting order, same
+// arithmetic); the per-lane stack lives in LDS as in every other traversing kernel.
+#ifndef WF_REFILL_MIN
+#define WF_REFILL_MIN 8
+#endif
+template <int STAGE, bool ANIM>
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, WfPool pool, const uint32_t* __restrict__ queue,
+                                                           uint32_t* __restrict__ qctl, DevStats* __restrict__ stats) {
+    const DevScene& sc = scv;
+    extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries
+    uint32_t* __restrict__ stack = s_stack + threadIdx.x;
+    const uint32_t n = qctl[STAGE];
+    uint32_t* __restrict__ cursor = qctl + 3 + STAGE;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool any_hit = STAGE == 1;
+    bool active = false, exhausted = false;
+    uint32_t slot = 0u, n_rays = 0u;
+    // traversal state (trace_bvh)
+    f3 wo = mk(0, 0, 0), wd = mk(0, 0, 0), o = wo, d = wd, inv_dir = wo;
+    bool nx = false, ny = false, nz = false, in_mesh = false, any = false;
+    float min_t = 0.0f, max_t = 0.0f, time = 0.0f;
+    int sp = 0;
+    uint32_t current = 0u, cur_inst = 0u, tri_base = 0u;
+    const TrayBvhNode* __restrict__ tree = sc.top_nodes;
+    const TrayTriVerts* __restrict__ tris = nullptr;
+    HitRec rec;
+    rec.t = 0.0f; rec.inst = 0xffffffffu; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
+    for (;;) {
+        // ---- refill idle lanes from the queue
+        if (!exhausted) {
+            const unsigned long long idle = __ballot(!active);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (n_idle >= WF_REFILL_MIN || n_idle == (uint32_t)__popcll(__ballot(1))) {
+                const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
+                uint32_t base = 0u;
+                if (lane == leader) base = atomicAdd(cursor, n_idle);
+                base = __shfl(base, (int)leader);
+                if (base + n_idle >= n) exhausted = true;
+                if (!active) {
+                    const uint32_t q = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                    if (q < n) {
+                        slot = queue[q];
+                        if (STAGE == 0) {
+                            wo = ld3(pool, F_O, slot); wd = ld3(pool, F_D, slot);
+                            min_t = pu(pool, F_BOUNCE, slot) == 0u ? 0.0f : 0.001f; max_t = TR_INF;
+                        } else {
+                            wo = ld3(pool, F_P, slot); wd = ld3(pool, F_AUX, slot);
+                            min_t = 0.001f; max_t = STAGE == 1 ? 0.999f : TR_INF;
+                        }
+                        if (ANIM) time = pf(pool, F_TIME, slot);
+                        o = wo; d = wd;
+                        inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
+                        tree = sc.top_nodes; current = 0u; sp = 0; in_mesh = false; any = false;
+                        rec.t = 0.0f; rec.inst = 0xffffffffu; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
+                        active = true;
+                        ++n_rays;
+                    }
+                }
+            }
+        }
+        if (!__any(active)) break;
+        // ---- one traversal step: node test (both levels) ...
+        bool finished = false, descend = !active;   // lanes without a ray sit the step out
+        if (active) {
+            const float4* nq = reinterpret_cast<const float4*>(tree + current);
+            float4 lo = nq[0], hi = nq[1];
+            uint32_t offset = __float_as_uint(hi.z);
+            uint32_t meta = __float_as_uint(hi.w);
+            uint32_t count = meta & 0xffffu, axis = (meta >> 16) & 0xffu;
+            if (bbox_hit(lo, hi, o, inv_dir, nx, ny, nz, min_t, max_t)) {
+                if (count == 0u) {
+                    bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
+                    uint32_t far_child = neg ? current + 1u : offset;
+                    current = neg ? offset : current + 1u;
+                    stack[sp * TR_BLOCK] = far_child;
+                    ++sp;
+                    descend = true;
+                } else if (in_mesh) {
+                    for (uint32_t k = 0; k < count; ++k) {
+                        float t, bb1, bb2;
+                        if (triangle_test(tris + offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
+                            max_t = t;
+                            rec.t = t; rec.inst = cur_inst; rec.prim = tri_base + offset + k; rec.b1 = bb1; rec.b2 = bb2;
+                            any = true;
+                            if (any_hit) { finished = true; break; }
+                        }
+                    }
+                } else {
+                    for (uint32_t k = count; k > 0u; --k) {
+                        stack[sp * TR_BLOCK] = STK_INSTANCE | (offset + k - 1u);
+                        ++sp;
+                    }
+                }
+            }
+        }
+        // ---- ... then pop until there is a node to test
+        if (!descend && !finished) {
+            bool have_node = false;
+            while (sp > 0) {
+                --sp;
+                uint32_t e = stack[sp * TR_BLOCK];
+                uint32_t kind = e & STK_KIND_MASK;
+                if (kind == STK_NODE) { current = e; have_node = true; break; }
+                if (kind == STK_EXIT_MESH) {
+                    in_mesh = false;
+                    tree = sc.top_nodes;
+                    o = wo; d = wd;
+                    inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
+                    continue;
+                }
+                uint32_t i = sc.top_order[e & ~STK_KIND_MASK];
+                const TrayInstance* __restrict__ in = sc.instances + i;
+                if (in->kind == TRAY_INST_POINT_EMITTER) continue;
+                f3 lo_, ld;
+                if (ANIM && in->animated) {   // the path's transform of a moving instance, from the per-slot cache
+                    float x[24];
+                    instance_inv_at(sc, in, time, slot, x);
+                    lo_ = xf_point_affine(x + 12, wo);
+                    ld = xf_vector(x + 12, wd);
+                } else {
+                    lo_ = xf_point(in->inv, wo);
+                    ld = xf_vector(in->inv, wd);
+                }
+                uint32_t gt = in->geom_type;
+                if (gt == TRAY_GEOM_MESH) {
+                    const TrayMesh m = sc.meshes[in->mesh_id];
+                    stack[sp * TR_BLOCK] = STK_EXIT_MESH;
+                    ++sp;
+                    in_mesh = true;
+                    cur_inst = i;
+                    tree = sc.mesh_nodes + m.node_offset;
+                    tris = sc.tri_verts + m.tri_offset;
+                    tri_base = m.tri_offset;
+                    o = lo_; d = ld;
+                    inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
+                    current = 0;
+                    have_node = true;
+                    break;
+                }
+                float t;
+                bool hit;
+                if (gt == TRAY_GEOM_RECT) hit = rect_test(in->geom_params[0], in->geom_params[1], lo_, ld, min_t, max_t, t);
+                else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(in->geom_params[0], lo_, ld, min_t, max_t, t);
+                else hit = disk_test(in->geom_params[0], in->geom_params[1], lo_, ld, min_t, max_t, t);
+                if (hit) {
+                    max_t = t;
+                    rec.t = t; rec.inst = i; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
+                    any = true;
+                    if (any_hit) { finished = true; break; }
+                }
+            }
+            if (!have_node) finished = true;
+        }
+        if (finished) {   // write the result to the ray's own slot
+            uint32_t flags = pu(pool, F_FLAGS, slot);
+            if (STAGE == 1) {
+                flags = any ? (flags | WF_OCCLUDED) : (flags & ~WF_OCCLUDED);
+            } else {
+                const uint32_t bit = STAGE == 0 ? WF_HIT_A : WF_HIT_C;
+                flags = any ? (flags | bit) : (flags & ~bit);
+                if (any) {
+                    pf(pool, F_REC_T, slot) = rec.t; pu(pool, F_REC_INST, slot) = rec.inst; pu(pool, F_REC_PRIM, slot) = rec.prim;
+                    pf(pool, F_REC_B1, slot) = rec.b1; pf(pool, F_REC_B2, slot) = rec.b2;
+                }
+            }
+            pu(pool, F_FLAGS, slot) = flags;
+            active = false;
+        }
+    }
+    // one counter update per wave
+    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
+    if (lane == 0u && n_rays) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].rays, (unsigned long long)n_rays);
+}
+
 // Stage A shading: vertex_begin for the slots whose ray hit, end of the sample for those that missed
-__global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPool pool, uint32_t n_active, DevStats* __restrict__ stats) {
+template <bool ANIM>
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPool pool, uint32_t n_active, DevStats* __restrict__ stats,
+                                                       uint32_t* __restrict__ queue_b, uint32_t* __restrict__ qctl) {
     const DevScene& sc = scv;
     const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
     if (i >= n_active) return;
@@ -120,7 +320,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
     rec.b1 = pf(pool, F_REC_B1, i); rec.b2 = pf(pool, F_REC_B2, i);
     Counters cnt;
     cnt.rays = 0; cnt.vertices = 0;
-    vertex_begin<false>(sc, ln, rec, cnt);
+    ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
+    vertex_begin<ANIM>(sc, ln, rec, cnt);
     pu(pool, F_FLAGS, i) = ln.flags | WF_INVERTEX;
     st3(pool, F_ILLUM, i, ln.illum);
     if (ln.bounce == 0u) st3(pool, F_NG, i, ln.first_ng);
@@ -133,10 +334,13 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
     st3(pool, F_TV, i, ln.t_vertex);
     const unsigned long long m = __ballot(1);
     if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].vertices, (unsigned long long)__popcll(m));
+    if (queue_b) wf_enqueue(queue_b, qctl + 1, (ln.flags & LF_SHADOW) != 0u, i);
 }
 
 // Stage B shading: the BSDF queries of the vertex (light half, BSDF half, continuation)
-__global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPool pool, uint32_t n_active) {
+template <bool ANIM>
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ queue_c,
+                                                       uint32_t* __restrict__ qctl) {
     const DevScene& sc = scv;
     const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
     if (i >= n_active) return;
@@ -153,21 +357,25 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPoo
     ln.direct = ld3(pool, F_DIRECT, i);
     ln.o = mk(0.0f, 0.0f, 0.0f); ln.d = mk(0.0f, 0.0f, 0.0f);
     ln.aux_d = mk(0.0f, 0.0f, 0.0f); ln.mis_f = mk(0.0f, 0.0f, 0.0f);
-    vertex_queries<false>(sc, ln, (flags & WF_OCCLUDED) != 0u);
+    ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
+    vertex_queries<ANIM>(sc, ln, (flags & WF_OCCLUDED) != 0u);
     pu(pool, F_FLAGS, i) = ln.flags;
     st3(pool, F_T, i, ln.throughput);
     st3(pool, F_DIRECT, i, ln.direct);
     if (!(ln.flags & LF_LAST)) { st3(pool, F_O, i, ln.o); st3(pool, F_D, i, ln.d); }
     if (ln.flags & LF_MIS) { st3(pool, F_AUX, i, ln.aux_d); st3(pool, F_MISF, i, ln.mis_f); st3(pool, F_LI, i, ln.li); }
+    if (queue_c) wf_enqueue(queue_c, qctl + 2, (ln.flags & LF_MIS) != 0u, i);
 }
 
 // Round head, one workgroup per chunk: vertex_end of the previous round, film splat of finished samples,
 // tile completion / switch, path regeneration.
+template <bool ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfPool pool, WfChunk* __restrict__ chunks,
                                                          float* __restrict__ bins, const uint2* __restrict__ tiles, uint32_t tile_count,
                                                          uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf,
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ tile_counter,
-                                                         uint32_t* __restrict__ tiles_done, DevStats* __restrict__ stats) {
+                                                         uint32_t* __restrict__ tiles_done, DevStats* __restrict__ stats,
+                                                         uint32_t* __restrict__ queue_a, uint32_t* __restrict__ qctl) {
     __shared__ float s_win[4 * WIN_PLANE];
     __shared__ float s_table[TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE];
     __shared__ float s_tx[TRAY_FILTER_TABLE_SIZE], s_ty[TRAY_FILTER_TABLE_SIZE];
@@ -204,7 +412,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
                 rec.t = pf(pool, F_REC_T, i); rec.inst = pu(pool, F_REC_INST, i); rec.prim = pu(pool, F_REC_PRIM, i);
                 rec.b1 = pf(pool, F_REC_B1, i); rec.b2 = pf(pool, F_REC_B2, i);
             }
-            const bool cont = vertex_end<false>(sc, ln, (flags & WF_HIT_C) != 0u, rec);
+            ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
+            const bool cont = vertex_end<ANIM>(sc, ln, (flags & WF_HIT_C) != 0u, rec);
             st3(pool, F_ILLUM, i, ln.illum);
             pu(pool, F_BOUNCE, i) = ln.bounce;
             flags = ln.flags & ~(WF_INVERTEX | WF_HIT_A | WF_HIT_C | WF_OCCLUDED | LF_SHADOW | LF_MIS | LF_LAST);
@@ -274,7 +483,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
             const uint32_t kp = key_pixel(kf, py * sc.width + px);
             float sx, sy, t;
             pixel_sample(kp, s_next, spp, px, py, sx, sy, t);
-            const Ray cam = camera_ray<false>(sc, sx, sy, t);
+            const Ray cam = camera_ray<ANIM>(sc, sx, sy, t);
+            if (ANIM) { pf(pool, F_TIME, i) = cam.time; xf_cache_fill(sc, cam.time, i); }
             pu(pool, F_SNEXT, i) = s_next + TR_BLOCK / 64;
             pu(pool, F_BOUNCE, i) = 0u;
             pu(pool, F_KS, i) = key_sample(kp, s_next);
@@ -287,6 +497,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
         }
     }
     pu(pool, F_FLAGS, i) = flags;
+    if (queue_a) wf_enqueue(queue_a, qctl, (flags & LF_ALIVE) != 0u, i);
 }
 
 }  // namespace tr
