@@ -91,9 +91,13 @@ TR_DEV void xf_cache_fill(const DevScene& sc, float time, uint32_t lane) {
         for (int k = 0; k < 24; ++k) col[(size_t)k * lanes] = x[k];
     }
 }
+// ANIM template values: 0 = nothing moves within the frame; 1 = moving instances are read from the per-path cache (tile and
+// wavefront kernels: no function call in their hot loops, a call would raise their register allocation to the callee's);
+// 2 = the spline stacks are evaluated at every use (debug kernels, whose grids are not sized by the cache)
 // rows of inv only (x + 12 .. x + 23 are written)
+template <int ANIM>
 TR_DEV void instance_inv_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, uint32_t column, float* x) {
-    if (sc.xf_cache) {
+    if (ANIM == 1) {
         const uint32_t lanes = sc.xf_cache_lanes;
         const float* __restrict__ col = sc.xf_cache + ((size_t)in->moving_slot * 24u + 12u) * lanes + column;
 #pragma unroll
@@ -102,9 +106,10 @@ TR_DEV void instance_inv_at(const DevScene& sc, const TrayInstance* __restrict__
         eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
     }
 }
+template <int ANIM>
 TR_DEV void instance_xf_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, uint32_t column, float* x) {
     if (in->animated) {
-        if (sc.xf_cache) {
+        if (ANIM == 1) {
             const uint32_t lanes = sc.xf_cache_lanes;
             const float* __restrict__ col = sc.xf_cache + (size_t)in->moving_slot * 24u * lanes + column;
 #pragma unroll
@@ -315,7 +320,7 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
 // Scene::intersect. Returns true on hit; rec = closest candidate (the last accepted one,
 // bvh.rs:93-98). any_hit: return at the first accepted candidate (OcclusionTester::occluded only
 // needs the boolean, light/mod.rs:30-37; the first accepted candidate is the same in both modes).
-template <bool ANIM>
+template <int ANIM>
 TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, HitRec& rec) {
     const TrayBvhNode* __restrict__ tree = sc.top_nodes;
     f3 o = ray.o, d = ray.d;
@@ -387,7 +392,7 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
             f3 lo_, ld;
             if (ANIM && in->animated) {   // transform.transform(ray.time) per visit (receiver.rs:30)
                 float x[24];
-                instance_inv_at(sc, in, ray.time, ray.col, x);
+                instance_inv_at<ANIM>(sc, in, ray.time, ray.col, x);
                 lo_ = xf_point_affine(x + 12, ray.o);
                 ld = xf_vector(x + 12, ray.d);
             } else {
@@ -431,7 +436,7 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
 // Scene::intersect (scene.rs:148-150). The tile kernel calls this from exactly one site (every
 // lane traces one ray per step of its phase machine), so it is inlined there.
 struct TraceResult { HitRec rec; bool hit; };
-template <bool ANIM>
+template <int ANIM>
 TR_DEV TraceResult trace(const DevScene* __restrict__ scp, uint32_t* __restrict__ stack, Ray ray, bool any_hit) {
     const DevScene& sc = *scp;
     TraceResult r;
@@ -445,13 +450,13 @@ TR_DEV TraceResult trace(const DevScene* __restrict__ scp, uint32_t* __restrict_
 
 // Rebuilds the DifferentialGeometry of the final candidate in object space and moves it to world
 // space (receiver.rs:36-42; DifferentialGeometry::{new,with_normal} differential_geometry.rs:32-64).
-template <bool ANIM>
+template <int ANIM>
 TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, float* uv_out = nullptr, f3* dp_dv_out = nullptr) {
     const TrayInstance* __restrict__ in = sc.instances + rec.inst;
     float x[24];
     f3 o, d;
     if (ANIM) {
-        instance_xf_at(sc, in, ray.time, ray.col, x);
+        instance_xf_at<ANIM>(sc, in, ray.time, ray.col, x);
         o = xf_point_affine(x + 12, ray.o);
         d = xf_vector(x + 12, ray.d);
     } else {
@@ -540,13 +545,13 @@ TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, flo
 
 // Geometry normal of the final candidate only (what estimate_direct's BSDF half needs from the hit,
 // mod.rs:159): same arithmetic as finish_hit restricted to ng.
-template <bool ANIM>
+template <int ANIM>
 TR_DEV f3 finish_hit_ng(const DevScene& sc, const Ray& ray, const HitRec& rec) {
     const TrayInstance* __restrict__ in = sc.instances + rec.inst;
     uint32_t gt = in->geom_type;
     f3 ng;
     float x[24];
-    if (ANIM) instance_xf_at(sc, in, ray.time, ray.col, x);
+    if (ANIM) instance_xf_at<ANIM>(sc, in, ray.time, ray.col, x);
     if (gt == TRAY_GEOM_SPHERE) {
         f3 o = ANIM ? xf_point_affine(x + 12, ray.o) : xf_point(in->inv, ray.o);
         f3 d = ANIM ? xf_vector(x + 12, ray.d) : xf_vector(in->inv, ray.d);

@@ -21,7 +21,7 @@
 
 namespace tr {
 
-template <bool ANIM>
+template <int ANIM>
 TR_DEV Ray camera_ray(const DevScene& sc, float px, float py, float time) {
     const TrayCamera& c = sc.camera;
     f3 q = xf_point(c.raster_to_cam, mk(px, py, 0.0f));
@@ -57,13 +57,13 @@ TR_DEV float rr_draw(uint32_t ks, uint32_t bounce) { return (float)(draw(ks, SD_
 
 // self.emission.color(time): the host stores color(shutter_open); keys are only present when the colour moves while the
 // shutter is open
-template <bool ANIM>
+template <int ANIM>
 TR_DEV f3 inst_emission(const DevScene& sc, const TrayInstance* __restrict__ in, float time) {
     if (ANIM && in->emis_count >= 2u) return color_keys_at(sc.color_keys + in->emis_first, in->emis_count, time);
     return mk(in->emission[0], in->emission[1], in->emission[2]);
 }
 // Emitter::radiance (emitter.rs:140-142)
-template <bool ANIM>
+template <int ANIM>
 TR_DEV f3 emitter_radiance(const DevScene& sc, const TrayInstance* __restrict__ in, f3 w, f3 n, float time) {
     return dot(w, n) > 0.0f ? inst_emission<ANIM>(sc, in, time) : mk(0.0f, 0.0f, 0.0f);
 }
@@ -142,7 +142,7 @@ TR_DEV Ray stage_c_ray(const Lane& ln) {   // Ray::segment(p, w_i, 0.001, inf) (
 
 // Stage A, after the ray hit: head of the loop body of Path::illumination (path.rs:69-79) and the light
 // sample of estimate_direct (mod.rs:106-127). Sets LF_SHADOW when an occlusion ray has to be traced.
-template <bool ANIM>
+template <int ANIM>
 TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counters& cnt) {
     cnt.vertices++;
     const Ray ray = stage_a_ray(ln);
@@ -170,7 +170,7 @@ TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counte
     // Light::sample_incident (emitter.rs:165-186)
     f3 p_w;
     float x[24];   // ANIM: self.transform.transform(time) (emitter.rs:168,175)
-    if (ANIM) instance_xf_at(sc, light, ln.time, ln.col, x);
+    if (ANIM) instance_xf_at<ANIM>(sc, light, ln.time, ln.col, x);
     if (light->kind == TRAY_INST_POINT_EMITTER) {
         f3 pos = ANIM ? xf_point_affine(x, mk(0.0f, 0.0f, 0.0f)) : xf_point(light->mat, mk(0.0f, 0.0f, 0.0f));
         ln.wi_l = normalized(pos - ln.bsdf.p);
@@ -200,7 +200,7 @@ TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counte
 //   WANT_MIS    BSDF half of estimate_direct (mod.rs:141-153), may set LF_MIS (ray for stage C)
 //   WANT_PATH   path continuation (path.rs:84-110): next stage A ray, or LF_LAST
 // Returns the follow-up query.
-template <bool ANIM>
+template <int ANIM>
 TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
     const bool is_light = want == WANT_LIGHT, mis = want == WANT_MIS;
     const uint32_t flags = want == WANT_PATH ? BX_ALL : BX_NON_SPECULAR;
@@ -239,7 +239,7 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
                 f3 p_l, wl;
                 if (ANIM) {
                     float x[24];
-                    instance_xf_at(sc, light, ln.time, ln.col, x);
+                    instance_xf_at<ANIM>(sc, light, ln.time, ln.col, x);
                     p_l = xf_point_affine(x + 12, ln.bsdf.p);
                     wl = normalized(xf_vector(x + 12, w_i));
                 } else {
@@ -274,7 +274,7 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
 }
 
 // Stage B after the occlusion ray: all BSDF queries of the vertex
-template <bool ANIM>
+template <int ANIM>
 TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
     const bool delta = sc.instances[ln.light_inst].kind == TRAY_INST_POINT_EMITTER;
     uint32_t want = ((ln.flags & LF_SHADOW) && !occluded) ? WANT_LIGHT : (delta ? WANT_PATH : WANT_MIS);
@@ -284,7 +284,7 @@ TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
 
 // Stage C: tail of the BSDF half of estimate_direct (mod.rs:154-166), then path.rs:82 and the
 // bookkeeping for the next vertex. Returns false when the camera sample is finished.
-template <bool ANIM>
+template <int ANIM>
 TR_DEV bool vertex_end(const DevScene& sc, Lane& ln, bool mis_hit, const HitRec& rec) {
     if ((ln.flags & LF_MIS) && mis_hit && rec.inst == ln.light_inst) {   // same emitter object (mod.rs:157-160)
         const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;

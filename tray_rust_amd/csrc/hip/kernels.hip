@@ -198,7 +198,7 @@ __device__ __forceinline__ void film_splat_rows_global(const DevScene& sc, float
 
 // Work item w (0 <= w < n_work) maps to queue entry (w / chunk) * chunk_stride * chunk + (w % chunk):
 // contiguous ranges use chunk_stride = 1; multi-GPU sharding interleaves chunks round-robin.
-template <bool ANIM>
+template <int ANIM>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const DevScene scv, const uint2* __restrict__ tiles, uint32_t tile_count,
                                                          uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf,
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ counter,
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
 }
 
 // ---- parity / debug kernels: the same device functions, one thread per item -------------------
-template <bool ANIM>
+template <int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene scv, uint32_t n, const TrayRay* __restrict__ rays,
                                                               TrayHit* __restrict__ hits) {
     extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries, sized per scene at launch
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene scv
 
 // thread_work's inner loop body for individual (pixel, sample) items (multithreaded.rs:94-103),
 // driven through the same lane machine as the tile kernel
-template <bool ANIM>
+template <int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevScene scv, uint32_t n, const uint32_t* __restrict__ px,
                                                                     const uint32_t* __restrict__ py, const uint32_t* __restrict__ si,
                                                                     uint32_t spp, uint32_t kf, float* __restrict__ out) {
@@ -481,22 +481,26 @@ static int upload(TrayDeviceScene* s, const T* host, size_t n, const T** out) {
 #endif
 #define WF_POLL 16
 // one round of the wavefront schedule: advance -> trace A -> begin -> trace B -> query -> trace C
-template <bool ANIM>
+template <int ANIM>
 static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 tgrid, dim3 block, hipStream_t stream, const uint2* tiles, uint32_t tile_count, uint32_t chunk,
                      uint32_t chunk_stride, uint32_t spp, uint32_t kf, float* rgbw_dev, uint32_t n_active, uint32_t* qa, uint32_t* qb, uint32_t* qc,
                      uint32_t* qctl) {
     if (s->wf_dynamic) {   // compacted ray queues + persistent traversal with dynamic fetch
+        uint32_t* const qr = qc + s->pool.n_slots + WF_QCTL_WORDS;
         hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
-                           spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, qa, qctl);
+                           spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, qa, qr, qctl);
+        hipLaunchKernelGGL(k_wf_regen<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
         hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->stack_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats);
         hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, qb, qctl);
         hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->stack_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats);
         hipLaunchKernelGGL(k_wf_query<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, qc, qctl);
         hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->stack_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats);
-    } else {
+    } else {   // one thread per pool slot in every stage; only the regeneration is compacted
         uint32_t* const none = nullptr;
+        uint32_t* const qr = qc + s->pool.n_slots + WF_QCTL_WORDS;
         hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
-                           spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, none, none);
+                           spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, qa, qr, qctl);
+        hipLaunchKernelGGL(k_wf_regen<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
         hipLaunchKernelGGL((k_wf_trace<0, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
         hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, none, none);
         hipLaunchKernelGGL((k_wf_trace<1, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
@@ -689,38 +693,41 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         s->stack_bytes = depth * TR_BLOCK * (uint32_t)sizeof(uint32_t);
         if (s->stack_bytes > 32u * 1024u) {   // past the default dynamic-LDS window: raise the per-kernel limit (160 KB LDS per CU)
             const int bytes = (int)s->stack_bytes;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_intersect<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_intersect<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_sample_radiance<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_sample_radiance<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_intersect<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_intersect<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_sample_radiance<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_sample_radiance<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipGetLastError();
         }
     }
     int per_cu = 0, cus = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) cus = prop.multiProcessorCount;
-    hipError_t occ = s->animated ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles<true>, TR_BLOCK, s->stack_bytes)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles<false>, TR_BLOCK, s->stack_bytes);
+    hipError_t occ = s->animated ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles<1>, TR_BLOCK, s->stack_bytes)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles<0>, TR_BLOCK, s->stack_bytes);
     if (occ != hipSuccess || per_cu < 1) per_cu = 1;
     s->deferred_n_moving = 0;
     for (uint32_t i = 0; i < f->n_instances; ++i) if (f->instances[i].animated) s->deferred_n_moving++;
     if (cus < 1) cus = 256;
     s->n_blocks = cus * per_cu;
-    if (s->animated && s->deferred_n_moving > 0 && s->deferred_n_moving <= 64) {   // per-path transform cache (dev_geom.h)
+    if (s->deferred_n_moving > 64) {
+        tray_scene_destroy(s); set_error("more than 64 instances move within one frame: the per-path transform cache does not cover that"); return TRAY_E_UNSUPPORTED;
+    }
+    if (s->animated && s->deferred_n_moving > 0) {   // per-path transform cache (dev_geom.h)
         std::vector<uint32_t> ids(s->deferred_n_moving, 0u);
         for (uint32_t i = 0; i < f->n_instances; ++i)
             if (f->instances[i].animated && f->instances[i].moving_slot < ids.size()) ids[f->instances[i].moving_slot] = i;
@@ -762,14 +769,14 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
         HIP_CHECK(hipMemset(s->d_bins, 0, (size_t)s->n_chunks * ROWBIN_SIZE * sizeof(float)));
         HIP_CHECK(hipMalloc(&p, 2 * sizeof(uint32_t)));
         s->allocs.push_back(p); s->d_wf_counters = static_cast<uint32_t*>(p);
-        HIP_CHECK(hipMalloc(&p, (3 * (size_t)n_slots + WF_QCTL_WORDS) * sizeof(uint32_t)));   // ray queues A, B, C + their counters
+        HIP_CHECK(hipMalloc(&p, (4 * (size_t)n_slots + WF_QCTL_WORDS) * sizeof(uint32_t)));   // ray queues A, B, C, their counters, regeneration queue
         s->allocs.push_back(p); s->d_queues = static_cast<uint32_t*>(p);
         {
             int per_cu = 0, cus = 256;
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-            hipError_t oe = s->animated ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, true>, TR_BLOCK, s->stack_bytes)
-                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, false>, TR_BLOCK, s->stack_bytes);
+            hipError_t oe = s->animated ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, 1>, TR_BLOCK, s->stack_bytes)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, 0>, TR_BLOCK, s->stack_bytes);
             if (oe != hipSuccess || per_cu < 1) per_cu = 1;
             s->n_blocks_trace = (uint32_t)(cus * per_cu);
             const char* e = getenv("TRAYHIP_WF_TRACE");
@@ -795,10 +802,10 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     const uint64_t tiles_per_chunk = (tile_count + n_chunks - 1) / n_chunks;
     const uint64_t max_rounds = tiles_per_chunk * (((uint64_t)spp + 3) / 4 * (s->dev.max_depth + 3) + 4) + 2 * WF_POLL;
     for (uint32_t round = 0;; ++round) {
-        if (s->wf_dynamic) HIP_CHECK(hipMemsetAsync(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), stream));
-        if (s->animated) wf_round<true>(s, grid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qctl);
-        else wf_round<false>(s, grid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qctl);
-        launches += 6;
+        HIP_CHECK(hipMemsetAsync(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), stream));
+        if (s->animated) wf_round<1>(s, grid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qctl);
+        else wf_round<0>(s, grid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qctl);
+        launches += 7;
         if (round % WF_POLL == WF_POLL - 1) {
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipMemcpyAsync(s->h_done, s->d_wf_counters + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -854,10 +861,10 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     int blocks = (int)std::min<uint32_t>((uint32_t)s->n_blocks, tile_count);
     HIP_CHECK(hipEventRecord(s->ev0, stream));
     if (s->animated)
-        hipLaunchKernelGGL(k_path_tiles<true>, dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf,
+        hipLaunchKernelGGL(k_path_tiles<1>, dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf,
                            rgbw_dev, s->d_counter, s->d_stats);
     else
-        hipLaunchKernelGGL(k_path_tiles<false>, dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf,
+        hipLaunchKernelGGL(k_path_tiles<0>, dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf,
                            rgbw_dev, s->d_counter, s->d_stats);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(s->ev1, stream));
@@ -916,8 +923,8 @@ int tray_debug_intersect(TrayDeviceScene* s, uint32_t n, const TrayRay* rays, Tr
     if (e == hipSuccess) {
         DevScene nocache = s->dev;   // debug grids are sized by the item count, not by the cache: evaluate at every use
         nocache.xf_cache = nullptr;
-        if (s->animated) hipLaunchKernelGGL(k_debug_intersect<true>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, nocache, n, d_r, d_h);
-        else hipLaunchKernelGGL(k_debug_intersect<false>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_r, d_h);
+        if (s->animated) hipLaunchKernelGGL(k_debug_intersect<2>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, nocache, n, d_r, d_h);
+        else hipLaunchKernelGGL(k_debug_intersect<0>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_r, d_h);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(hits, d_h, n * sizeof(TrayHit), hipMemcpyDeviceToHost);
@@ -950,9 +957,9 @@ int tray_debug_sample_radiance(TrayDeviceScene* s, uint32_t n, const uint32_t* p
         DevScene nocache = s->dev;
         nocache.xf_cache = nullptr;
         if (s->animated)
-            hipLaunchKernelGGL(k_debug_sample_radiance<true>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, nocache, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
+            hipLaunchKernelGGL(k_debug_sample_radiance<2>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, nocache, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
         else
-            hipLaunchKernelGGL(k_debug_sample_radiance<false>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
+            hipLaunchKernelGGL(k_debug_sample_radiance<0>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(out, d_out, 8 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost);

@@ -63,7 +63,7 @@ TR_DEV void st_bsdf(const DevScene& sc, const WfPool& p, uint32_t i, const Bsdf&
 // STAGE 0: camera / continuation ray (closest hit) -> rec, WF_HIT_A
 // STAGE 1: occlusion ray of the light sample (any hit) -> WF_OCCLUDED
 // STAGE 2: BSDF-sampled ray of estimate_direct (closest hit) -> rec, WF_HIT_C
-template <int STAGE, bool ANIM>
+template <int STAGE, int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace(const DevScene scv, WfPool pool, uint32_t n_active, DevStats* __restrict__ stats) {
     const DevScene* scp = &scv;
     extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries
@@ -124,7 +124,7 @@ TR_DEV void wf_enqueue(uint32_t* __restrict__ queue, uint32_t* __restrict__ coun
 #ifndef WF_REFILL_MIN
 #define WF_REFILL_MIN 8
 #endif
-template <int STAGE, bool ANIM>
+template <int STAGE, int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, WfPool pool, const uint32_t* __restrict__ queue,
                                                            uint32_t* __restrict__ qctl, DevStats* __restrict__ stats) {
     const DevScene& sc = scv;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
                 f3 lo_, ld;
                 if (ANIM && in->animated) {   // the path's transform of a moving instance, from the per-slot cache
                     float x[24];
-                    instance_inv_at(sc, in, time, slot, x);
+                    instance_inv_at<ANIM>(sc, in, time, slot, x);
                     lo_ = xf_point_affine(x + 12, wo);
                     ld = xf_vector(x + 12, wd);
                 } else {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
 }
 
 // Stage A shading: vertex_begin for the slots whose ray hit, end of the sample for those that missed
-template <bool ANIM>
+template <int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPool pool, uint32_t n_active, DevStats* __restrict__ stats,
                                                        uint32_t* __restrict__ queue_b, uint32_t* __restrict__ qctl) {
     const DevScene& sc = scv;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
 }
 
 // Stage B shading: the BSDF queries of the vertex (light half, BSDF half, continuation)
-template <bool ANIM>
+template <int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ queue_c,
                                                        uint32_t* __restrict__ qctl) {
     const DevScene& sc = scv;
@@ -367,15 +367,53 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPoo
     if (queue_c) wf_enqueue(queue_c, qctl + 2, (ln.flags & LF_MIS) != 0u, i);
 }
 
+// New camera sample for pool slot i of a chunk that works on tile `tile_idx` (multithreaded.rs:90-96)
+template <int ANIM>
+TR_DEV void wf_regenerate(const DevScene& sc, const WfPool& pool, uint32_t i, uint32_t tile_idx, const uint2* __restrict__ tiles, uint32_t chunk,
+                          uint32_t chunk_stride, uint32_t spp, uint32_t kf, DevStats* __restrict__ stats) {
+    const uint32_t lane = i & 63u;
+    const uint32_t s_next = pu(pool, F_SNEXT, i);
+    const uint2 tile = tiles[(tile_idx / chunk) * chunk_stride * chunk + (tile_idx % chunk)];
+    const uint32_t px = tile.x * 8u + (lane & 7u), py = tile.y * 8u + (lane >> 3);
+    const uint32_t kp = key_pixel(kf, py * sc.width + px);
+    float sx, sy, t;
+    pixel_sample(kp, s_next, spp, px, py, sx, sy, t);
+    const Ray cam = camera_ray<ANIM>(sc, sx, sy, t);
+    if (ANIM) { pf(pool, F_TIME, i) = cam.time; xf_cache_fill(sc, cam.time, i); }
+    pu(pool, F_SNEXT, i) = s_next + TR_BLOCK / 64;
+    pu(pool, F_BOUNCE, i) = 0u;
+    pu(pool, F_KS, i) = key_sample(kp, s_next);
+    pf(pool, F_SX, i) = sx; pf(pool, F_SY, i) = sy;
+    st3(pool, F_O, i, cam.o); st3(pool, F_D, i, cam.d);
+    st3(pool, F_T, i, mk(1.0f, 1.0f, 1.0f)); st3(pool, F_ILLUM, i, mk(0.0f, 0.0f, 0.0f));
+    const unsigned long long m = __ballot(1);
+    if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].samples, (unsigned long long)__popcll(m));
+}
+
+// Compacted regeneration: one thread per entry of queue R (slots whose sample finished and whose tile has samples left)
+template <int ANIM>
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_regen(const DevScene scv, WfPool pool, const WfChunk* __restrict__ chunks, const uint2* __restrict__ tiles,
+                                                       uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf, DevStats* __restrict__ stats,
+                                                       const uint32_t* __restrict__ queue_r, uint32_t* __restrict__ queue_a, uint32_t* __restrict__ qctl) {
+    const DevScene& sc = scv;
+    const uint32_t q = blockIdx.x * TR_BLOCK + threadIdx.x;
+    if (q >= qctl[6]) return;
+    const uint32_t i = queue_r[q];
+    wf_regenerate<ANIM>(sc, pool, i, chunks[i / TR_BLOCK].tile, tiles, chunk, chunk_stride, spp, kf, stats);
+    pu(pool, F_FLAGS, i) = LF_ALIVE;
+    wf_enqueue(queue_a, qctl, true, i);
+}
+
 // Round head, one workgroup per chunk: vertex_end of the previous round, film splat of finished samples,
 // tile completion / switch, path regeneration.
-template <bool ANIM>
+template <int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfPool pool, WfChunk* __restrict__ chunks,
                                                          float* __restrict__ bins, const uint2* __restrict__ tiles, uint32_t tile_count,
                                                          uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf,
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ tile_counter,
                                                          uint32_t* __restrict__ tiles_done, DevStats* __restrict__ stats,
-                                                         uint32_t* __restrict__ queue_a, uint32_t* __restrict__ qctl) {
+                                                         uint32_t* __restrict__ queue_a, uint32_t* __restrict__ queue_r,
+                                                         uint32_t* __restrict__ qctl) {
     __shared__ float s_win[4 * WIN_PLANE];
     __shared__ float s_table[TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE];
     __shared__ float s_tx[TRAY_FILTER_TABLE_SIZE], s_ty[TRAY_FILTER_TABLE_SIZE];
@@ -474,30 +512,12 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
         pu(pool, F_SNEXT, i) = sub;
     }
     if (tid == 0) { chunks[c].tile = s_tile; chunks[c].done = s_done; }
-    // ---- path regeneration (multithreaded.rs:90-96)
-    if (tile_idx != WF_TILE_IDLE && !(flags & LF_ALIVE)) {
-        const uint32_t s_next = pu(pool, F_SNEXT, i);
-        if (s_next < spp) {
-            const uint2 tile = tiles[(tile_idx / chunk) * chunk_stride * chunk + (tile_idx % chunk)];
-            const uint32_t px = tile.x * 8u + (lane & 7u), py = tile.y * 8u + (lane >> 3);
-            const uint32_t kp = key_pixel(kf, py * sc.width + px);
-            float sx, sy, t;
-            pixel_sample(kp, s_next, spp, px, py, sx, sy, t);
-            const Ray cam = camera_ray<ANIM>(sc, sx, sy, t);
-            if (ANIM) { pf(pool, F_TIME, i) = cam.time; xf_cache_fill(sc, cam.time, i); }
-            pu(pool, F_SNEXT, i) = s_next + TR_BLOCK / 64;
-            pu(pool, F_BOUNCE, i) = 0u;
-            pu(pool, F_KS, i) = key_sample(kp, s_next);
-            pf(pool, F_SX, i) = sx; pf(pool, F_SY, i) = sy;
-            st3(pool, F_O, i, cam.o); st3(pool, F_D, i, cam.d);
-            st3(pool, F_T, i, mk(1.0f, 1.0f, 1.0f)); st3(pool, F_ILLUM, i, mk(0.0f, 0.0f, 0.0f));
-            flags = LF_ALIVE;
-            const unsigned long long m = __ballot(1);
-            if (lane == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].samples, (unsigned long long)__popcll(m));
-        }
-    }
+    // ---- path regeneration (multithreaded.rs:90-96): inline, or (compacted schedule) deferred to k_wf_regen so that the
+    // camera rays and the per-path transforms of moving scenes are computed by full waves
+    const bool wants_sample = tile_idx != WF_TILE_IDLE && !(flags & LF_ALIVE) && pu(pool, F_SNEXT, i) < spp;
+    wf_enqueue(queue_r, qctl + 6, wants_sample, i);
     pu(pool, F_FLAGS, i) = flags;
-    if (queue_a) wf_enqueue(queue_a, qctl, (flags & LF_ALIVE) != 0u, i);
+    wf_enqueue(queue_a, qctl, (flags & LF_ALIVE) != 0u, i);
 }
 
 }  // namespace tr
