@@ -122,7 +122,7 @@ TR_DEV void wf_enqueue(uint32_t* __restrict__ queue, uint32_t* __restrict__ coun
 // meshes). One loop iteration = one step of the one-loop two-level traversal of trace_bvh (same visiting order, same
 // arithmetic); the per-lane stack lives in LDS as in every other traversing kernel.
 #ifndef WF_REFILL_MIN
-#define WF_REFILL_MIN 8
+#define WF_REFILL_MIN 24
 #endif
 template <int STAGE, int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, WfPool pool, const uint32_t* __restrict__ queue,
