@@ -64,3 +64,11 @@ def test_shard_lists_are_disjoint_and_balanced(built):
     assert sorted(sum(shards, [])) == list(range(n))
     sizes = [len(s) for s in shards]
     assert max(sizes) - min(sizes) <= 16
+
+
+def test_frames_shard_round_robin():
+    from tray_rust_amd import multi
+    world = 8
+    parts = [multi.shard_frames(0, 127, r, world) for r in range(world)]
+    assert sorted(sum(parts, [])) == list(range(128)) and all(len(p) == 16 for p in parts)
+    assert multi.shard_frames(5, 6, 3, 8) == [] and multi.shard_frames(5, 6, 1, 8) == [6]

@@ -34,3 +34,10 @@ def render_frame_sharded(render_shard, film, rank, world, dst=0):
     afterwards rank `dst` holds the whole frame."""
     render_shard(rank, world, film)
     return merge_film(film, dst)
+
+
+def shard_frames(start_frame, end_frame, rank, world):
+    """Frames [start_frame, end_frame] dealt round-robin over the ranks (BASELINE.json configs[4]: an animation shards by
+    frame first; frames are independent, src/main.rs:91-106, so no collective is needed -- each rank writes its own
+    frames). With fewer frames than ranks, shard the tiles of each frame instead (render_frame_sharded)."""
+    return list(range(int(start_frame) + int(rank), int(end_frame) + 1, int(world)))
