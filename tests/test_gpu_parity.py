@@ -271,14 +271,20 @@ def test_merl_bsdf(dragon):
     assert (a[:, 0:3] > 0).any()
 
 
-def test_dragon_image_rmse(dragon):
+@pytest.mark.parametrize("mode", ["mega", "wave"])
+def test_dragon_image_rmse(dragon, mode, monkeypatch):
+    """mega: tile kernel (flat instance loop + per-lane mesh traversal); wave: wavefront schedule, whose persistent
+    traversal expands both children of a node per step."""
+    monkeypatch.setenv("TRAYHIP_MODE", mode)
     scene, rt, spp, fi = dragon
+    scene.release_device()
     gpu, tim = gpu_render(scene, rt, 16, fi, seed=3)
+    scene.release_device()
     cpu, st = O.render_tiles(scene.flatten(0), 16, seed=3)
     assert tim.samples == st.samples
     assert abs(int(tim.vertices) - int(st.vertices)) <= 2e-4 * st.vertices
     r = rmse(gpu, cpu)
-    print(f"dragon(96) 160x120x16: RMSE {r:.3e} V {st.vertices / st.samples:.3f}")
+    print(f"dragon(96) 160x120x16 {mode}: RMSE {r:.3e} V {st.vertices / st.samples:.3f}")
     assert r < 1e-4
 
 

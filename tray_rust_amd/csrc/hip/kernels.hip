@@ -39,7 +39,7 @@ using namespace tr;
 #define WIN_STRIDE 24       // row stride in floats: 4 rows of 8 lanes land on 32 distinct banks
 #define WIN_PLANE (WIN_MAX * WIN_STRIDE)
 
-struct DevStats { unsigned long long samples, vertices, rays; };
+struct DevStats { unsigned long long samples, vertices, rays, trav[5]; };   // trav: traversal counters of builds with -DWF_TRACE_STATS
 
 // RenderTarget::write for one sample into the LDS window (render_target.rs:118-146).
 // win origin = (x0 - fpw, y0 - fph); ranges already clipped to the image.
@@ -905,7 +905,13 @@ int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t) {
     std::vector<DevStats> all(WF_STAT_SLOTS);
     HIP_CHECK(hipMemcpy(all.data(), s->d_stats, all.size() * sizeof(DevStats), hipMemcpyDeviceToHost));
     DevStats st{};
-    for (const DevStats& a : all) { st.samples += a.samples; st.vertices += a.vertices; st.rays += a.rays; }
+    for (const DevStats& a : all) {
+        st.samples += a.samples; st.vertices += a.vertices; st.rays += a.rays;
+        for (int k = 0; k < 5; ++k) st.trav[k] += a.trav[k];
+    }
+    if (getenv("TRAYHIP_STATS") && st.rays)
+        fprintf(stderr, "[trayhip] per ray: iterations %.2f  node visits %.2f  node expansions %.2f  instance entries %.2f  triangle tests %.2f\n",
+                (double)st.trav[0] / st.rays, (double)st.trav[1] / st.rays, (double)st.trav[2] / st.rays, (double)st.trav[3] / st.rays, (double)st.trav[4] / st.rays);
     t->launches = s->launches;
     t->samples = st.samples; t->vertices = st.vertices; t->rays = st.rays;
     return TRAY_OK;

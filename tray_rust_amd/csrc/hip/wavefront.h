@@ -124,6 +124,12 @@ TR_DEV void wf_enqueue(uint32_t* __restrict__ queue, uint32_t* __restrict__ coun
 #ifndef WF_REFILL_MIN
 #define WF_REFILL_MIN 24
 #endif
+#ifndef WF_NODE_STEPS
+#define WF_NODE_STEPS 8    // node steps per round of the while-while loop
+#endif
+#ifndef WF_NODE_MIN
+#define WF_NODE_MIN 16     // ... as long as this many lanes still have node work (or nobody waits for the leaf / pop phase)
+#endif
 template <int STAGE, int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, WfPool pool, const uint32_t* __restrict__ queue,
                                                            uint32_t* __restrict__ qctl, DevStats* __restrict__ stats) {
@@ -136,12 +142,20 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
     const bool any_hit = STAGE == 1;
     bool active = false, exhausted = false;
     uint32_t slot = 0u, n_rays = 0u;
+#ifdef WF_TRACE_STATS
+    uint32_t c_iter = 0u, c_visit = 0u, c_expand = 0u, c_inst = 0u, c_tri = 0u;
+#define WF_COUNT(x) (++(x))
+#else
+#define WF_COUNT(x) ((void)0)
+#endif
     // traversal state (trace_bvh)
     f3 wo = mk(0, 0, 0), wd = mk(0, 0, 0), o = wo, d = wd, inv_dir = wo;
     bool nx = false, ny = false, nz = false, in_mesh = false, any = false;
     float min_t = 0.0f, max_t = 0.0f, time = 0.0f;
     int sp = 0;
-    uint32_t current = 0u, cur_inst = 0u, tri_base = 0u;
+    uint32_t node_a = 0u, node_b = 0xffffffffu, cur_inst = 0u, tri_base = 0u, cur_offset = 0u, cur_count = 0u;
+    enum : uint32_t { TM_NODE = 0u, TM_LEAF = 1u, TM_POP = 2u, WF_NO_NODE = 0xffffffffu };
+    uint32_t mode = TM_NODE;
     const TrayBvhNode* __restrict__ tree = sc.top_nodes;
     const TrayTriVerts* __restrict__ tris = nullptr;
     HitRec rec;
@@ -172,7 +186,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
                         o = wo; d = wd;
                         inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                         nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
-                        tree = sc.top_nodes; current = 0u; sp = 0; in_mesh = false; any = false;
+                        tree = sc.top_nodes; node_a = 0u; node_b = WF_NO_NODE; sp = 0; in_mesh = false; any = false; mode = TM_NODE;
                         rec.t = 0.0f; rec.inst = 0xffffffffu; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
                         active = true;
                         ++n_rays;
@@ -181,49 +195,80 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
             }
         }
         if (!__any(active)) break;
-        // ---- one traversal step: node test (both levels) ...
-        bool finished = false, descend = !active;   // lanes without a ray sit the step out
-        if (active) {
-            const float4* nq = reinterpret_cast<const float4*>(tree + current);
-            float4 lo = nq[0], hi = nq[1];
-            uint32_t offset = __float_as_uint(hi.z);
-            uint32_t meta = __float_as_uint(hi.w);
-            uint32_t count = meta & 0xffffu, axis = (meta >> 16) & 0xffu;
-            if (bbox_hit(lo, hi, o, inv_dir, nx, ny, nz, min_t, max_t)) {
-                if (count == 0u) {
-                    bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
-                    uint32_t far_child = neg ? current + 1u : offset;
-                    current = neg ? offset : current + 1u;
-                    stack[sp * TR_BLOCK] = far_child;
-                    ++sp;
-                    descend = true;
-                } else if (in_mesh) {
-                    for (uint32_t k = 0; k < count; ++k) {
-                        float t, bb1, bb2;
-                        if (triangle_test(tris + offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
-                            max_t = t;
-                            rec.t = t; rec.inst = cur_inst; rec.prim = tri_base + offset + k; rec.b1 = bb1; rec.b2 = bb2;
-                            any = true;
-                            if (any_hit) { finished = true; break; }
-                        }
+        // ---- traversal, while-while form. A lane is in one of three modes:
+        //   TM_NODE  has one or two nodes to test: a popped node (the box test the reference runs when it reaches a node,
+        //            with the ray's current max_t) or BOTH children of a node whose box was hit. Fetching the children
+        //            together means a child whose box is missed never costs a dependent fetch of its own; the far child is
+        //            pushed only if its box is hit now (a box missed with the current max_t is missed with any later, smaller
+        //            one) and is re-tested when popped, so the accepted candidates and their order are exactly the
+        //            reference's (bvh.rs:89-127).
+        //   TM_LEAF  reached a leaf: triangles of a BVH<Triangle> leaf, or the instances of a BVH<Instance> leaf
+        //   TM_POP   needs the next stack entry (instance entry, primitive tests, leaving a mesh)
+        // The node phase repeats while enough lanes have node work, so the (much longer) leaf / pop code runs once per
+        // several node steps instead of once per step for whichever few lanes happen to need it.
+        bool finished = false;
+#pragma nounroll
+        for (int it = 0; it < WF_NODE_STEPS; ++it) {
+            const bool in_node = active && mode == TM_NODE;
+            const uint32_t n_node = (uint32_t)__popcll(__ballot(in_node));
+            if (n_node == 0u) break;
+            if (it > 0 && n_node < WF_NODE_MIN && __any(active && mode != TM_NODE)) break;
+            if (in_node) {
+                WF_COUNT(c_iter);
+                const bool two = node_b != WF_NO_NODE;
+                const float4* qa = reinterpret_cast<const float4*>(tree + node_a);
+                const float4* qb = reinterpret_cast<const float4*>(tree + (two ? node_b : node_a));
+                const float4 alo = qa[0], ahi = qa[1], blo = qb[0], bhi = qb[1];
+                const bool ha = bbox_hit(alo, ahi, o, inv_dir, nx, ny, nz, min_t, max_t);
+                const bool hb = two && bbox_hit(blo, bhi, o, inv_dir, nx, ny, nz, min_t, max_t);
+                if (two) WF_COUNT(c_expand); else WF_COUNT(c_visit);
+                if (ha || hb) {
+                    if (ha && hb) { stack[sp * TR_BLOCK] = node_b; ++sp; }
+                    const uint32_t cur = ha ? node_a : node_b;
+                    cur_offset = __float_as_uint(ha ? ahi.z : bhi.z);
+                    const uint32_t meta = __float_as_uint(ha ? ahi.w : bhi.w);
+                    cur_count = meta & 0xffffu;
+                    if (cur_count == 0u) {   // interior: near child first by the sign of the split axis (bvh.rs:105-119)
+                        const uint32_t axis = (meta >> 16) & 0xffu;
+                        const bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
+                        node_a = neg ? cur_offset : cur + 1u;
+                        node_b = neg ? cur + 1u : cur_offset;
+                    } else {
+                        mode = TM_LEAF;
                     }
                 } else {
-                    for (uint32_t k = count; k > 0u; --k) {
-                        stack[sp * TR_BLOCK] = STK_INSTANCE | (offset + k - 1u);
-                        ++sp;
-                    }
+                    mode = TM_POP;
                 }
             }
         }
-        // ---- ... then pop until there is a node to test
-        if (!descend && !finished) {
+        if (active && mode == TM_LEAF) {
+            if (in_mesh) {   // BVH<Triangle> leaf (<= 16 triangles), tested in order
+                for (uint32_t k = 0; k < cur_count; ++k) {
+                    float t, bb1, bb2;
+                    WF_COUNT(c_tri);
+                    if (triangle_test(tris + cur_offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
+                        max_t = t;
+                        rec.t = t; rec.inst = cur_inst; rec.prim = tri_base + cur_offset + k; rec.b1 = bb1; rec.b2 = bb2;
+                        any = true;
+                        if (any_hit) { finished = true; break; }
+                    }
+                }
+            } else {   // BVH<Instance> leaf (<= 4 instances): queue them so that pops come in leaf order
+                for (uint32_t k = cur_count; k > 0u; --k) {
+                    stack[sp * TR_BLOCK] = STK_INSTANCE | (cur_offset + k - 1u);
+                    ++sp;
+                }
+            }
+            mode = TM_POP;
+        }
+        if (active && mode == TM_POP && !finished) {
             bool have_node = false;
             while (sp > 0) {
                 --sp;
                 uint32_t e = stack[sp * TR_BLOCK];
                 uint32_t kind = e & STK_KIND_MASK;
-                if (kind == STK_NODE) { current = e; have_node = true; break; }
-                if (kind == STK_EXIT_MESH) {
+                if (kind == STK_NODE) { node_a = e; node_b = WF_NO_NODE; have_node = true; break; }
+                if (kind == STK_EXIT_MESH) {   // back to world space and the top-level tree
                     in_mesh = false;
                     tree = sc.top_nodes;
                     o = wo; d = wd;
@@ -231,9 +276,11 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
                     nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
                     continue;
                 }
+                // Instance::intersect (receiver.rs:29-35): world ray -> object ray by `inv`, direction not renormalised
                 uint32_t i = sc.top_order[e & ~STK_KIND_MASK];
                 const TrayInstance* __restrict__ in = sc.instances + i;
-                if (in->kind == TRAY_INST_POINT_EMITTER) continue;
+                if (in->kind == TRAY_INST_POINT_EMITTER) continue;   // emitter.rs:120
+                WF_COUNT(c_inst);
                 f3 lo_, ld;
                 if (ANIM && in->animated) {   // the path's transform of a moving instance, from the per-slot cache
                     float x[24];
@@ -257,7 +304,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
                     o = lo_; d = ld;
                     inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                     nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
-                    current = 0;
+                    node_a = 0u; node_b = WF_NO_NODE;
                     have_node = true;
                     break;
                 }
@@ -273,7 +320,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
                     if (any_hit) { finished = true; break; }
                 }
             }
-            if (!have_node) finished = true;
+            if (have_node) mode = TM_NODE;
+            else finished = true;
         }
         if (finished) {   // write the result to the ray's own slot
             uint32_t flags = pu(pool, F_FLAGS, slot);
@@ -294,6 +342,15 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
     // one counter update per wave
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
     if (lane == 0u && n_rays) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].rays, (unsigned long long)n_rays);
+#ifdef WF_TRACE_STATS
+    uint32_t cs[5] = {c_iter, c_visit, c_expand, c_inst, c_tri};
+    for (int k = 0; k < 5; ++k) {
+        uint32_t v = cs[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0u && v) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].trav[k], (unsigned long long)v);
+    }
+#endif
+#undef WF_COUNT
 }
 
 // Stage A shading: vertex_begin for the slots whose ray hit, end of the sample for those that missed
