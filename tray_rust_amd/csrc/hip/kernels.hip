@@ -167,6 +167,9 @@ __device__ __forceinline__ void film_splat_global(const DevScene& sc, float* __r
         }
     }
 }
+// bins: the chunk's row bins in global memory (LDS_BINS = false, workgroup-scope atomics) or this round's partial sums in
+// LDS (true: ds_add_f32; the caller adds them to the global bins once per round)
+template <bool LDS_BINS>
 __device__ __forceinline__ void film_splat_rows_global(const DevScene& sc, float* __restrict__ bins, const float* __restrict__ s_tx,
                                                        float* __restrict__ rgbw, const float* __restrict__ s_table,
                                                        int x0, int y0, int py_l, float sx, float sy, f3 c) {
@@ -187,10 +190,11 @@ __device__ __forceinline__ void film_splat_rows_global(const DevScene& sc, float
         int fx_idx = min((int)(fx * (float)TRAY_FILTER_TABLE_SIZE), TRAY_FILTER_TABLE_SIZE - 1);
         float wx = s_tx[fx_idx];
         float* __restrict__ o = row + (ix - wx0) * 4;
-        wg_add(o + 0, wx * c.x);
-        wg_add(o + 1, wx * c.y);
-        wg_add(o + 2, wx * c.z);
-        wg_add(o + 3, wx);
+        if (LDS_BINS) {
+            atomicAdd(o + 0, wx * c.x); atomicAdd(o + 1, wx * c.y); atomicAdd(o + 2, wx * c.z); atomicAdd(o + 3, wx);
+        } else {
+            wg_add(o + 0, wx * c.x); wg_add(o + 1, wx * c.y); wg_add(o + 2, wx * c.z); wg_add(o + 3, wx);
+        }
     }
 }
 

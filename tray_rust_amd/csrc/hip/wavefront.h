@@ -475,6 +475,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
     __shared__ float s_table[TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE];
     __shared__ float s_tx[TRAY_FILTER_TABLE_SIZE], s_ty[TRAY_FILTER_TABLE_SIZE];
     __shared__ uint32_t s_tile, s_done, s_fin;
+    __shared__ float s_bins[ROWBIN_SIZE];   // this round's contribution to the chunk's row bins
     const DevScene& sc = scv;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, sub = tid >> 6;
     const uint32_t c = blockIdx.x;
@@ -483,6 +484,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
     if (tid == 0) { s_tile = chunks[c].tile; s_done = chunks[c].done; s_fin = 0u; }
     s_table[tid] = sc.filter_table[tid];
     if (tid < TRAY_FILTER_TABLE_SIZE) { s_tx[tid] = sc.filter_x[tid]; s_ty[tid] = sc.filter_y[tid]; }
+    for (uint32_t k = tid; k < ROWBIN_SIZE; k += TR_BLOCK) s_bins[k] = 0.0f;
     __syncthreads();
     uint32_t tile_idx = s_tile;
     if (tile_idx == WF_TILE_IDLE) return;
@@ -519,15 +521,21 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
             const f3 il = ld3(pool, F_ILLUM, i);
             const f3 col = mk(clampf(il.x, 0.0f, 1.0f), clampf(il.y, 0.0f, 1.0f), clampf(il.z, 0.0f, 1.0f));   // quirk Q3
             const float sx = pf(pool, F_SX, i), sy = pf(pool, F_SY, i);
-            if (film_rows) film_splat_rows_global(sc, my_bins, s_tx, rgbw, s_table, x0, y0, (int)(lane >> 3), sx, sy, col);
+            if (film_rows) film_splat_rows_global<true>(sc, s_bins, s_tx, rgbw, s_table, x0, y0, (int)(lane >> 3), sx, sy, col);
             else film_splat_global(sc, rgbw, s_table, x0, y0, sx, sy, col);
             flags &= ~WF_FINISHED;
             atomicAdd(&s_fin, 1u);
         }
         __syncthreads();
+        if (film_rows && s_fin != 0u) {   // the chunk owns its bins: plain read-modify-write, coalesced
+            for (uint32_t k = tid; k < ROWBIN_SIZE; k += TR_BLOCK) {
+                const float v = s_bins[k];
+                if (v != 0.0f) my_bins[k] += v;
+            }
+        }
         // ---- tile complete: spread the row bins over the window, flush it, take the next tile
         const uint32_t done = s_done + s_fin;
-        __syncthreads();   // everybody has read s_done / s_fin before thread 0 rewrites them
+        __syncthreads();   // everybody has read s_done / s_fin before thread 0 rewrites them; the bins are up to date
         if (done == 64u * spp) {
             if (film_rows) {
                 for (uint32_t k = tid; k < 4 * WIN_PLANE; k += TR_BLOCK) s_win[k] = 0.0f;
