@@ -382,3 +382,49 @@ def test_tr15_stand_in_image_rmse(tmp_path):
     r = rmse(gpu, cpu)
     print(f"tr15_like frame {frame} 160x96x{spp}: RMSE {r:.3e} V {st.vertices / st.samples:.3f}")
     assert r < 2e-4   # 1e-4 at a realistic sample count; see test_moving_scene_image_rmse
+
+
+@pytest.mark.parametrize("filt", [{"type": "gaussian", "width": 1.5, "height": 1.5, "alpha": 2.0},
+                                  {"type": "gaussian", "width": 2.0, "height": 2.0, "alpha": 1.0},
+                                  {"type": "mitchell_netravali", "width": 1.0, "height": 2.0, "b": 0.2, "c": 0.4}])
+def test_other_reconstruction_filters(filt, tmp_path):
+    """Gaussian (film/filter/gaussian.rs) and non-default footprints: widths other than 2 take the verbatim
+    RenderTarget::write path instead of the row-binned film."""
+    d = scenes.cornell_box(96, 64, 16)
+    d["film"]["filter"] = filt
+    scene, rt, _, fi = load(d, tmp_path)
+    gpu, tim = gpu_render(scene, rt, 16, fi, seed=8)
+    cpu, st = O.render_tiles(scene.flatten(0), 16, seed=8)
+    assert tim.samples == st.samples
+    assert np.abs(gpu[..., 3] - cpu[..., 3]).max() < 1e-3 * cpu[..., 3].max()
+    assert rmse(gpu, cpu) < 1e-4
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_full_size_frame_through_strided_tiles(name, tmp_path):
+    """BASELINE.json's film size (1920x1080): every 64th tile of the Morton queue rendered by the GPU (shard 0 of 64, one tile
+    per chunk) against the oracle rendering the same tiles; then the whole frame for the size-independent counters."""
+    import torch
+    scene, rt, _, fi = load(SCENES[name](1920, 1080, 64), tmp_path)
+    flat = scene.flatten(0)
+    dev = scene.device_scene(0, 0)
+    part = torch.zeros(1920 * 1080 * 4, dtype=torch.float32, device="cuda")
+    T.check(T.lib().tray_render_shard_device(dev, 0, 64, 1, 64, 7, C.c_void_p(part.data_ptr()), None))
+    torch.cuda.synchronize()
+    gpu = part.cpu().numpy().reshape(1080, 1920, 4)
+    cpu, st = O.render_tiles(flat, 64, seed=7, stride=64)
+    assert st.samples == 507 * 64 * 64   # ceil(32400 / 64) tiles
+    touched = cpu[..., 3] > 0
+    assert (touched == (gpu[..., 3] > 0)).all()
+    assert np.abs(gpu[..., 3] - cpu[..., 3]).max() < 1e-3 * cpu[..., 3].max()
+    d = (rgb(gpu) - rgb(cpu))[touched]
+    assert float(np.sqrt(np.mean(d ** 2))) < 1e-4
+    # whole frame at 16 spp: exact sample count, vertices per sample as the oracle's tile sample predicts
+    rt.clear()
+    hip = T.Hip(0, seed=7)
+    hip.render(scene, rt, T.Config(".", "s", 16, 1, fi, (0, 0)))
+    tim = hip.last_timing
+    assert tim.samples == 1920 * 1080 * 16
+    img = rt.get_renderf32().reshape(1080, 1920, 4)
+    assert np.isfinite(img).all() and (img[..., 3] > 0).all()
+    assert abs(tim.vertices / tim.samples - st.vertices / st.samples) < 0.02 * st.vertices / st.samples
