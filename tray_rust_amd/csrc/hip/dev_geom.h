@@ -62,6 +62,7 @@ struct DevScene {
     uint32_t n_moving, xf_cache_lanes;
     uint32_t n_instances, n_lights, min_depth, max_depth;
     uint32_t width, height, frame, film_rows;   // film_rows: 1 = row-binned film (separable, filter_h == 2)
+    uint32_t coop_offset;   // word offset of the cooperative leaf test's LDS area behind the traversal stacks (0 = none)
     float filter_w, filter_h, inv_w, inv_h;
     int32_t fpw, fph;
     TrayCamera camera;
@@ -267,6 +268,88 @@ TR_DEV bool mesh_traverse(const DevScene& sc, uint32_t* __restrict__ stack, cons
     return any;
 }
 
+// Meshes of at most TR_COOP_MAX_TRIS triangles (the reference's cube.obj: 12) in the flat instance loop. Their BVH<Triangle>
+// is a dozen nodes deep enough that per-lane traversal costs a wave ~2000 instructions per instance however few of its lanes
+// hold a ray that passes the root box (measured: the two cubes were 32 % of the cornell_box kernel). Instead, after the
+// root box test (the reference's first test), the lanes of a wave share a brute-force test of ALL the mesh's triangles: the
+// n rays that pass are staged in LDS and every ray is tested by FOUR lanes, each taking a quarter of the triangles in leaf
+// order, so one pass of ceil(T/4) triangle tests serves 16 rays. The reference's sequential rule (a candidate is accepted
+// when t <= the closest t so far, mesh.rs:168 / bvh.rs:93-98) makes the survivor the valid candidate of minimal t, the last
+// one among equal t: each lane applies the rule to its triangles, a quad reduction applies it across the quarters.
+// Versus BVH traversal this differs only where the flat instance loop already does: candidates the reference's inner slab
+// tests drop by rounding (rays within an ulp of a leaf box edge) and the order among exactly tied t.
+#define TR_COOP_MAX_TRIS 16
+#define TR_COOP_WORDS 768   // per wave: ray o, d, min_t, max_t (8 x 64) + result t, k, b1, b2 (4 x 64)
+TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float* __restrict__ w_lds, bool participate, f3 o, f3 d, float min_t,
+                           float& max_t, uint32_t& prim, float& b1, float& b2) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const float4* nq = reinterpret_cast<const float4*>(sc.mesh_nodes + m.node_offset);
+    const float4 lo = nq[0], hi = nq[1];
+    const uint32_t offset = 0u, T = m.tri_count;
+    const TrayTriVerts* __restrict__ tris = sc.tri_verts + m.tri_offset;
+    const f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const bool need = participate && bbox_hit(lo, hi, o, inv_dir, d.x < 0.0f, d.y < 0.0f, d.z < 0.0f, min_t, max_t);
+    const unsigned long long mask = __ballot(need);
+    if (mask == 0ull) return false;
+    const uint32_t n = (uint32_t)__popcll(mask);
+    if (n > 32u) {   // most of the wave needs the test: one ray per lane does as well
+        bool any = false;
+        if (need)
+            for (uint32_t k = 0; k < T; ++k) {
+                float t, bb1, bb2;
+                if (triangle_test(tris + k, o, d, min_t, max_t, t, bb1, bb2)) { max_t = t; prim = m.tri_offset + offset + k; b1 = bb1; b2 = bb2; any = true; }
+            }
+        return any;
+    }
+    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (need) {
+        w_lds[0 * 64 + rank] = o.x; w_lds[1 * 64 + rank] = o.y; w_lds[2 * 64 + rank] = o.z;
+        w_lds[3 * 64 + rank] = d.x; w_lds[4 * 64 + rank] = d.y; w_lds[5 * 64 + rank] = d.z;
+        w_lds[6 * 64 + rank] = min_t; w_lds[7 * 64 + rank] = max_t;
+        w_lds[9 * 64 + rank] = -1.0f;   // no candidate yet
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t per = (T + 3u) >> 2, g = lane & 3u;
+    for (uint32_t base = 0; base < n; base += 16u) {
+        const uint32_t r = base + (lane >> 2);
+        float ct = 0.0f, cb1 = 0.0f, cb2 = 0.0f, ck = -1.0f;
+        if (r < n) {
+            const f3 ro = mk(w_lds[0 * 64 + r], w_lds[1 * 64 + r], w_lds[2 * 64 + r]);
+            const f3 rd = mk(w_lds[3 * 64 + r], w_lds[4 * 64 + r], w_lds[5 * 64 + r]);
+            const float rmin = w_lds[6 * 64 + r];
+            float cur = w_lds[7 * 64 + r];
+            for (uint32_t j = 0; j < per; ++j) {
+                const uint32_t k = g * per + j;
+                if (k < T) {
+                    float t, bb1, bb2;
+                    if (triangle_test(tris + k, ro, rd, rmin, cur, t, bb1, bb2)) { cur = t; ct = t; cb1 = bb1; cb2 = bb2; ck = (float)k; }
+                }
+            }
+        }
+        // quad reduction in triangle order: the later quarter wins ties (all four lanes of a quad are active together)
+#pragma unroll
+        for (int step = 1; step <= 2; step <<= 1) {
+            const float ot = __shfl_xor(ct, step), ok = __shfl_xor(ck, step), ob1 = __shfl_xor(cb1, step), ob2 = __shfl_xor(cb2, step);
+            const bool take = ok >= 0.0f && (ck < 0.0f || ot < ct || (!(ct < ot) && ok > ck));
+            if (take) { ct = ot; ck = ok; cb1 = ob1; cb2 = ob2; }
+        }
+        if (r < n && g == 0u && ck >= 0.0f) {
+            w_lds[8 * 64 + r] = ct; w_lds[9 * 64 + r] = ck; w_lds[10 * 64 + r] = cb1; w_lds[11 * 64 + r] = cb2;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool hit = false;
+    if (need) {
+        const float ck = w_lds[9 * 64 + rank];
+        if (ck >= 0.0f) {
+            max_t = w_lds[8 * 64 + rank]; prim = m.tri_offset + offset + (uint32_t)ck;
+            b1 = w_lds[10 * 64 + rank]; b2 = w_lds[11 * 64 + rank];
+            hit = true;
+        }
+    }
+    return hit;
+}
+
 // Scene::intersect for scenes with a handful of instances: every lane tests the instances in scene
 // order inside one wave-uniform loop. The instance index is uniform, so the transform and the geometry
 // parameters are scalar loads and the primitive type never diverges; only BVH<Triangle> traversal is
@@ -276,10 +359,10 @@ TR_DEV bool mesh_traverse(const DevScene& sc, uint32_t* __restrict__ stack, cons
 #ifndef TR_FLAT_MAX
 #define TR_FLAT_MAX 16
 #endif
-TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, HitRec& rec) {
+TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, bool active, HitRec& rec) {
     const float min_t = ray.min_t;
     float max_t = ray.max_t;
-    bool any = false, done = false;
+    bool any = false, done = !active;   // lanes without a ray run along: the cooperative leaf test uses their ALUs
     const uint32_t n = sc.n_instances;
     for (uint32_t i = 0; i < n; ++i) {
         // the instance index is wave-uniform: read the record through the constant address space so the
@@ -293,24 +376,28 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
         for (int k = 0; k < 16; ++k) inv[k] = in->inv[k];
         const float gp0 = in->geom_params[0], gp1 = in->geom_params[1];
         const uint32_t mesh_id = in->mesh_id;
-        if (!done) {
-            // Instance::intersect (receiver.rs:29-35): world ray -> object ray by `inv`, direction not renormalised
-            f3 o = xf_point(inv, ray.o);
-            f3 d = xf_vector(inv, ray.d);
-            float t = max_t;
-            bool hit;
-            uint32_t prim = 0u;
-            float b1 = 0.0f, b2 = 0.0f;
+        // Instance::intersect (receiver.rs:29-35): world ray -> object ray by `inv`, direction not renormalised
+        const f3 o = xf_point(inv, ray.o);
+        const f3 d = xf_vector(inv, ray.d);
+        float t = max_t;
+        bool hit = false;
+        uint32_t prim = 0u;
+        float b1 = 0.0f, b2 = 0.0f;
+        if (gt == TRAY_GEOM_MESH && sc.coop_offset != 0u && sc.meshes[mesh_id].tri_count <= TR_COOP_MAX_TRIS) {
+            // small mesh: the whole wave enters, lanes without a pending ray only lend their ALUs
+            volatile float* w_lds = reinterpret_cast<volatile float*>(stack - threadIdx.x + sc.coop_offset) + (threadIdx.x >> 6) * TR_COOP_WORDS;
+            hit = mesh_leaf_coop(sc, sc.meshes[mesh_id], w_lds, !done, o, d, min_t, t, prim, b1, b2);
+        } else if (!done) {
             if (gt == TRAY_GEOM_RECT) hit = rect_test(gp0, gp1, o, d, min_t, max_t, t);
             else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(gp0, o, d, min_t, max_t, t);
             else if (gt == TRAY_GEOM_MESH) hit = mesh_traverse(sc, stack, sc.meshes[mesh_id], o, d, min_t, t, any_hit, prim, b1, b2);
             else hit = disk_test(gp0, gp1, o, d, min_t, max_t, t);
-            if (hit) {
-                max_t = t;
-                rec.t = t; rec.inst = i; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
-                any = true;
-                done = any_hit;
-            }
+        }
+        if (hit) {
+            max_t = t;
+            rec.t = t; rec.inst = i; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
+            any = true;
+            done = any_hit;
         }
         if (__all(done)) break;
     }
@@ -436,15 +523,16 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
 // Scene::intersect (scene.rs:148-150). The tile kernel calls this from exactly one site (every
 // lane traces one ray per step of its phase machine), so it is inlined there.
 struct TraceResult { HitRec rec; bool hit; };
+// Called by ALL lanes of a wave that has at least one ray; `active` = this lane has one.
 template <int ANIM>
-TR_DEV TraceResult trace(const DevScene* __restrict__ scp, uint32_t* __restrict__ stack, Ray ray, bool any_hit) {
+TR_DEV TraceResult trace(const DevScene* __restrict__ scp, uint32_t* __restrict__ stack, Ray ray, bool any_hit, bool active) {
     const DevScene& sc = *scp;
     TraceResult r;
     r.rec.t = 0.0f; r.rec.inst = 0xffffffffu; r.rec.prim = 0u; r.rec.b1 = 0.0f; r.rec.b2 = 0.0f;
     // moving scenes always take BVH<Instance>: its boxes are the reference's swept bounds (animated_transform.rs:58-71),
     // including the instances those bounds cut off, which the flat loop would not reproduce
-    if (!ANIM && sc.n_instances <= TR_FLAT_MAX) r.hit = trace_flat(sc, stack, ray, any_hit, r.rec);
-    else r.hit = trace_bvh<ANIM>(sc, stack, ray, any_hit, r.rec);
+    if (!ANIM && sc.n_instances <= TR_FLAT_MAX) r.hit = trace_flat(sc, stack, ray, any_hit, active, r.rec);
+    else r.hit = active ? trace_bvh<ANIM>(sc, stack, ray, any_hit, r.rec) : false;
     return r;
 }
 

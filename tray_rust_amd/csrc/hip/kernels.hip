@@ -39,7 +39,7 @@ using namespace tr;
 #define WIN_STRIDE 24       // row stride in floats: 4 rows of 8 lanes land on 32 distinct banks
 #define WIN_PLANE (WIN_MAX * WIN_STRIDE)
 
-struct DevStats { unsigned long long samples, vertices, rays, trav[5]; };   // trav: traversal counters of builds with -DWF_TRACE_STATS
+struct DevStats { unsigned long long samples, vertices, rays, trav[18]; };   // trav[stage * 6 + k]: traversal counters of builds with -DWF_TRACE_STATS
 
 // RenderTarget::write for one sample into the LDS window (render_target.rs:118-146).
 // win origin = (x0 - fpw, y0 - fph); ranges already clipped to the image.
@@ -270,12 +270,10 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
                 TraceResult tr_;
                 tr_.hit = false;
                 tr_.rec.t = 0.0f; tr_.rec.inst = 0xffffffffu; tr_.rec.prim = 0u; tr_.rec.b1 = 0.0f; tr_.rec.b2 = 0.0f;
-                if (__any(want_ray)) {
-                    if (want_ray) {
-                        cnt.rays++;
-                        const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
-                        tr_ = trace<ANIM>(scp, my_stack, r, stage == 1);
-                    }
+                if (__any(want_ray)) {   // the whole wave enters the traversal code (dev_geom.h: cooperative leaf test)
+                    if (want_ray) cnt.rays++;
+                    const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
+                    tr_ = trace<ANIM>(scp, my_stack, r, stage == 1, want_ray);
                 }
                 if (alive) {
                     if (stage == 0) {
@@ -325,15 +323,17 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene scv
     extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries, sized per scene at launch
     const DevScene& sc = scv;
     const DevScene* const scp = &scv;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = idx < n;   // the whole wave stays for the traversal (cooperative leaf test)
+    const uint32_t i = in_range ? idx : 0u;
     Ray r;
     r.o = mk(rays[i].o[0], rays[i].o[1], rays[i].o[2]);
     r.d = mk(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
     r.min_t = rays[i].min_t; r.max_t = rays[i].max_t; r.time = rays[i].time; r.col = 0u;
     TrayHit o;
     memset(&o, 0, sizeof o);
-    TraceResult tr_ = trace<ANIM>(scp, s_stack + threadIdx.x, r, false);
+    TraceResult tr_ = trace<ANIM>(scp, s_stack + threadIdx.x, r, false, in_range);
+    if (!in_range) return;
     const HitRec rec = tr_.rec;
     if (tr_.hit) {
         float uv[2];
@@ -361,8 +361,9 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
     extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries, sized per scene at launch
     const DevScene& sc = scv;
     const DevScene* const scp = &scv;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = idx < n;   // the whole wave steps together (cooperative leaf test inside the traversal)
+    const uint32_t i = in_range ? idx : 0u;
     Counters cnt;
     cnt.rays = 0; cnt.vertices = 0;
     const uint32_t kp = key_pixel(kf, py[i] * sc.width + px[i]);
@@ -370,8 +371,9 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
     pixel_sample(kp, si[i], spp, px[i], py[i], sx, sy, t);
     Lane ln;
     lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), key_sample(kp, si[i]));
+    if (!in_range) ln.flags = 0u;
     uint32_t* const my_stack = s_stack + threadIdx.x;
-    while (ln.flags & LF_ALIVE) {
+    while (__any(ln.flags & LF_ALIVE)) {
 #pragma nounroll
         for (int stage = 0; stage < 3; ++stage) {
             const bool alive = (ln.flags & LF_ALIVE) != 0u;
@@ -379,10 +381,10 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
             TraceResult tr_;
             tr_.hit = false;
             tr_.rec.t = 0.0f; tr_.rec.inst = 0xffffffffu; tr_.rec.prim = 0u; tr_.rec.b1 = 0.0f; tr_.rec.b2 = 0.0f;
-            if (want_ray) {
-                cnt.rays++;
+            if (__any(want_ray)) {
+                if (want_ray) cnt.rays++;
                 const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
-                tr_ = trace<ANIM>(scp, my_stack, r, stage == 1);
+                tr_ = trace<ANIM>(scp, my_stack, r, stage == 1, want_ray);
             }
             if (alive) {
                 if (stage == 0) {
@@ -396,6 +398,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
             }
         }
     }
+    if (!in_range) return;
     f3 c = lane_result(ln);
     float* o = out + (size_t)i * 8;
     o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = sx; o[4] = sy; o[5] = (float)cnt.vertices; o[6] = (float)cnt.rays; o[7] = 0.0f;
@@ -695,6 +698,13 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         depth = std::max(depth, 4u);
         if (depth > 96) { tray_scene_destroy(s); set_error("BVH too deep for the LDS traversal stack (" + std::to_string(depth) + " levels)"); return TRAY_E_UNSUPPORTED; }
         s->stack_bytes = depth * TR_BLOCK * (uint32_t)sizeof(uint32_t);
+        // cooperative test of small meshes (dev_geom.h: mesh_leaf_coop) in the flat instance loop: per-wave LDS behind the stacks
+        bool single_leaf = false;
+        for (uint32_t m = 0; m < f->n_meshes; ++m) single_leaf = single_leaf || f->meshes[m].tri_count <= TR_COOP_MAX_TRIS;
+        if (single_leaf && !s->wavefront && !s->animated && f->n_instances <= TR_FLAT_MAX && !getenv("TRAYHIP_NO_COOP")) {
+            s->dev.coop_offset = depth * TR_BLOCK;
+            s->stack_bytes += (TR_BLOCK / 64) * TR_COOP_WORDS * (uint32_t)sizeof(float);
+        }
         if (s->stack_bytes > 32u * 1024u) {   // past the default dynamic-LDS window: raise the per-kernel limit (160 KB LDS per CU)
             const int bytes = (int)s->stack_bytes;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -911,11 +921,15 @@ int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t) {
     DevStats st{};
     for (const DevStats& a : all) {
         st.samples += a.samples; st.vertices += a.vertices; st.rays += a.rays;
-        for (int k = 0; k < 5; ++k) st.trav[k] += a.trav[k];
+        for (int k = 0; k < 18; ++k) st.trav[k] += a.trav[k];
     }
     if (getenv("TRAYHIP_STATS") && st.rays)
-        fprintf(stderr, "[trayhip] per ray: iterations %.2f  node visits %.2f  node expansions %.2f  instance entries %.2f  triangle tests %.2f\n",
-                (double)st.trav[0] / st.rays, (double)st.trav[1] / st.rays, (double)st.trav[2] / st.rays, (double)st.trav[3] / st.rays, (double)st.trav[4] / st.rays);
+        for (int g = 0; g < 3; ++g) {
+            const unsigned long long* t = st.trav + g * 6;
+            if (!t[5]) continue;
+            fprintf(stderr, "[trayhip] stage %c: %llu rays; per ray: node steps %.2f  single-node visits %.2f  two-child expansions %.2f  instance entries %.2f  triangle tests %.2f\n",
+                    "ABC"[g], t[5], (double)t[0] / t[5], (double)t[1] / t[5], (double)t[2] / t[5], (double)t[3] / t[5], (double)t[4] / t[5]);
+        }
     t->launches = s->launches;
     t->samples = st.samples; t->vertices = st.vertices; t->rays = st.rays;
     return TRAY_OK;

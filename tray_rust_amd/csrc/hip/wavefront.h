@@ -68,13 +68,12 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace(const DevScene scv, WfPoo
     const DevScene* scp = &scv;
     extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries
     const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
-    if (i >= n_active) return;
+    if (i >= n_active) return;   // n_active is a multiple of the workgroup size: whole waves leave
     uint32_t flags = pu(pool, F_FLAGS, i);
     const uint32_t need = STAGE == 0 ? LF_ALIVE : (STAGE == 1 ? (LF_ALIVE | WF_INVERTEX | LF_SHADOW) : (LF_ALIVE | WF_INVERTEX | LF_MIS));
     const bool want = (flags & need) == need;
     if (!__any(want)) return;
-    if (!want) return;
-    Ray r;
+    Ray r;   // lanes without a ray keep the wave company (cooperative leaf test)
     if (STAGE == 0) {
         r.o = ld3(pool, F_O, i); r.d = ld3(pool, F_D, i);
         r.min_t = pu(pool, F_BOUNCE, i) == 0u ? 0.0f : 0.001f; r.max_t = TR_INF;
@@ -83,7 +82,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace(const DevScene scv, WfPoo
         r.min_t = 0.001f; r.max_t = STAGE == 1 ? 0.999f : TR_INF;
     }
     r.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; r.col = i;
-    TraceResult t = trace<ANIM>(scp, s_stack + threadIdx.x, r, STAGE == 1);
+    TraceResult t = trace<ANIM>(scp, s_stack + threadIdx.x, r, STAGE == 1, want);
+    if (!want) return;
     if (STAGE == 1) {
         flags = t.hit ? (flags | WF_OCCLUDED) : (flags & ~WF_OCCLUDED);
     } else {
@@ -343,12 +343,13 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
     if (lane == 0u && n_rays) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].rays, (unsigned long long)n_rays);
 #ifdef WF_TRACE_STATS
-    uint32_t cs[5] = {c_iter, c_visit, c_expand, c_inst, c_tri};
+    uint32_t cs[6] = {c_iter, c_visit, c_expand, c_inst, c_tri, 0u};
     for (int k = 0; k < 5; ++k) {
         uint32_t v = cs[k];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0u && v) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].trav[k], (unsigned long long)v);
+        if (lane == 0u && v) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].trav[STAGE * 6 + k], (unsigned long long)v);
     }
+    if (lane == 0u && n_rays) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].trav[STAGE * 6 + 5], (unsigned long long)n_rays);
 #endif
 #undef WF_COUNT
 }
