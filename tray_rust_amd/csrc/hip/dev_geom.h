@@ -292,15 +292,6 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float*
     const unsigned long long mask = __ballot(need);
     if (mask == 0ull) return false;
     const uint32_t n = (uint32_t)__popcll(mask);
-    if (n > 32u) {   // most of the wave needs the test: one ray per lane does as well
-        bool any = false;
-        if (need)
-            for (uint32_t k = 0; k < T; ++k) {
-                float t, bb1, bb2;
-                if (triangle_test(tris + k, o, d, min_t, max_t, t, bb1, bb2)) { max_t = t; prim = m.tri_offset + offset + k; b1 = bb1; b2 = bb2; any = true; }
-            }
-        return any;
-    }
     const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     if (need) {
         w_lds[0 * 64 + rank] = o.x; w_lds[1 * 64 + rank] = o.y; w_lds[2 * 64 + rank] = o.z;
