@@ -200,7 +200,7 @@ TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counte
 //   WANT_MIS    BSDF half of estimate_direct (mod.rs:141-153), may set LF_MIS (ray for stage C)
 //   WANT_PATH   path continuation (path.rs:84-110): next stage A ray, or LF_LAST
 // Returns the follow-up query.
-template <int ANIM>
+template <int ANIM, int FEAT>
 TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
     const bool is_light = want == WANT_LIGHT, mis = want == WANT_MIS;
     const uint32_t flags = want == WANT_PATH ? BX_ALL : BX_NON_SPECULAR;
@@ -214,10 +214,10 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
         float u0, u1;
         lane_2d(sc, ln, mis ? SD_B2 : SD_P2, u0, u1);
         float one_d = lane_1d(sc, ln, mis ? SD_B1 : SD_P1);
-        h = bsdf_sample_head(ln.bsdf, ln.w_o, flags, u0, u1, one_d);
+        h = bsdf_sample_head<FEAT>(ln.bsdf, ln.w_o, flags, u0, u1, one_d);
     }
-    if (h.need_eval) h.f = bsdf_eval(ln.bsdf, ln.w_o, h.wi_world, flags);
-    if (h.need_pdf) h.pdf = bsdf_pdf(ln.bsdf, ln.w_o, h.wi_world, flags);
+    if (h.need_eval) h.f = bsdf_eval<FEAT>(ln.bsdf, ln.w_o, h.wi_world, flags);
+    if (h.need_pdf) h.pdf = bsdf_pdf<FEAT>(ln.bsdf, ln.w_o, h.wi_world, flags);
     const f3 f = h.f, w_i = h.wi_world;
     const float pdf = h.pdf;
     if (is_light) {
@@ -274,12 +274,12 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
 }
 
 // Stage B after the occlusion ray: all BSDF queries of the vertex
-template <int ANIM>
+template <int ANIM, int FEAT>
 TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
     const bool delta = sc.instances[ln.light_inst].kind == TRAY_INST_POINT_EMITTER;
     uint32_t want = ((ln.flags & LF_SHADOW) && !occluded) ? WANT_LIGHT : (delta ? WANT_PATH : WANT_MIS);
 #pragma nounroll
-    for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) want = query_stage<ANIM>(sc, ln, want);   // LIGHT -> MIS -> PATH
+    for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) want = query_stage<ANIM, FEAT>(sc, ln, want);   // LIGHT -> MIS -> PATH
 }
 
 // Stage C: tail of the BSDF half of estimate_direct (mod.rs:154-166), then path.rs:82 and the

@@ -202,7 +202,7 @@ __device__ __forceinline__ void film_splat_rows_global(const DevScene& sc, float
 
 // Work item w (0 <= w < n_work) maps to queue entry (w / chunk) * chunk_stride * chunk + (w % chunk):
 // contiguous ranges use chunk_stride = 1; multi-GPU sharding interleaves chunks round-robin.
-template <int ANIM>
+template <int ANIM, int FEAT>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const DevScene scv, const uint2* __restrict__ tiles, uint32_t tile_count,
                                                          uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf,
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ counter,
@@ -224,6 +224,10 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
     Counters cnt;
     cnt.rays = 0; cnt.vertices = 0;
     uint32_t n_samples = 0;
+#ifdef TR_STAGE_CLOCKS
+    unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long clk_t = clock64();
+#endif
     for (;;) {
         __syncthreads();   // previous tile fully flushed
         if (tid == 0) s_tile = atomicAdd(counter, 1u);
@@ -263,6 +267,12 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
                 }
             }
             if (!__any(ln.flags & LF_ALIVE)) break;
+#ifdef TR_STAGE_CLOCKS
+#define TR_CLK(slot) do { const long long now_ = clock64(); clk[slot] += (unsigned long long)(now_ - clk_t); clk_t = now_; } while (0)
+            TR_CLK(6);   // regeneration + film splat
+#else
+#define TR_CLK(slot) ((void)0)
+#endif
 #pragma nounroll
             for (int stage = 0; stage < 3; ++stage) {
                 const bool alive = (ln.flags & LF_ALIVE) != 0u;
@@ -275,16 +285,18 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
                     const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
                     tr_ = trace<ANIM>(scp, my_stack, r, stage == 1, want_ray);
                 }
+                TR_CLK(stage);   // trace A / B / C
                 if (alive) {
                     if (stage == 0) {
                         if (tr_.hit) vertex_begin<ANIM>(sc, ln, tr_.rec, cnt);
                         else ln.flags &= ~LF_ALIVE;   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
                     } else if (stage == 1) {
-                        vertex_queries<ANIM>(sc, ln, tr_.hit);
+                        vertex_queries<ANIM, FEAT>(sc, ln, tr_.hit);
                     } else {
                         if (!vertex_end<ANIM>(sc, ln, tr_.hit, tr_.rec)) ln.flags &= ~LF_ALIVE;
                     }
                 }
+                TR_CLK(3 + stage);   // vertex_begin / queries / vertex_end
             }
         }
         __syncthreads();
@@ -313,8 +325,13 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
         atomicAdd(&stats->samples, (unsigned long long)n_samples);
         atomicAdd(&stats->vertices, (unsigned long long)cnt.vertices);
         atomicAdd(&stats->rays, (unsigned long long)cnt.rays);
+#ifdef TR_STAGE_CLOCKS
+        if ((tid & 63u) == 0u)
+            for (int k = 0; k < 7; ++k) atomicAdd(&stats->trav[k], clk[k]);
+#endif
     }
 }
+#undef TR_CLK
 
 // ---- parity / debug kernels: the same device functions, one thread per item -------------------
 template <int ANIM>
@@ -391,7 +408,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
                     if (tr_.hit) vertex_begin<ANIM>(sc, ln, tr_.rec, cnt);
                     else ln.flags &= ~LF_ALIVE;
                 } else if (stage == 1) {
-                    vertex_queries<ANIM>(sc, ln, tr_.hit);
+                    vertex_queries<ANIM, FEAT_ALL>(sc, ln, tr_.hit);
                 } else {
                     if (!vertex_end<ANIM>(sc, ln, tr_.hit, tr_.rec)) ln.flags &= ~LF_ALIVE;
                 }
@@ -417,8 +434,8 @@ __global__ __launch_bounds__(64) void k_debug_bsdf(const DevScene scv, uint32_t 
     uint32_t flags = flags_sel == 0 ? BX_ALL : BX_NON_SPECULAR;
     f3 wo = mk(dirs[6 * i], dirs[6 * i + 1], dirs[6 * i + 2]), wi = mk(dirs[6 * i + 3], dirs[6 * i + 4], dirs[6 * i + 5]);
     float* o = out + (size_t)i * 12;
-    f3 e = bsdf_eval(b, wo, wi, flags);
-    o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = bsdf_pdf(b, wo, wi, flags);
+    f3 e = bsdf_eval<FEAT_ALL>(b, wo, wi, flags);
+    o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = bsdf_pdf<FEAT_ALL>(b, wo, wi, flags);
     f3 swi;
     float spdf;
     uint32_t st;
@@ -454,6 +471,7 @@ struct TrayDeviceScene {
     bool wavefront = false;   // TRAYHIP_MODE=wave selects the stage-kernel schedule (wavefront.h)
     bool animated = false;    // something moves while the shutter is open: the <ANIM = true> kernels run
     uint32_t deferred_n_moving = 0;
+    int feat = FEAT_ALL;              // lobe kinds of the scene's materials that need the large kernels (dev_bsdf.h)
     uint32_t* d_queues = nullptr;     // wavefront schedule: ray queues A, B, C (n_slots each) + WF_QCTL_WORDS counters
     uint32_t n_blocks_trace = 0;      // persistent grid of k_wf_trace_dyn
     bool wf_dynamic = true;           // TRAYHIP_WF_TRACE=slot: one thread per pool slot instead (no compaction)
@@ -488,7 +506,7 @@ static int upload(TrayDeviceScene* s, const T* host, size_t n, const T** out) {
 #endif
 #define WF_POLL 16
 // one round of the wavefront schedule: advance -> trace A -> begin -> trace B -> query -> trace C
-template <int ANIM>
+template <int ANIM, int FEAT>
 static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 tgrid, dim3 block, hipStream_t stream, const uint2* tiles, uint32_t tile_count, uint32_t chunk,
                      uint32_t chunk_stride, uint32_t spp, uint32_t kf, float* rgbw_dev, uint32_t n_active, uint32_t* qa, uint32_t* qb, uint32_t* qc,
                      uint32_t* qctl) {
@@ -500,7 +518,7 @@ static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 tgrid, dim3 block, hipS
         hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->stack_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats);
         hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, qb, qctl);
         hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->stack_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats);
-        hipLaunchKernelGGL(k_wf_query<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, qc, qctl);
+        hipLaunchKernelGGL((k_wf_query<ANIM, FEAT>), grid, block, 0, stream, s->dev, s->pool, n_active, qc, qctl);
         hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->stack_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats);
     } else {   // one thread per pool slot in every stage; only the regeneration is compacted
         uint32_t* const none = nullptr;
@@ -511,7 +529,7 @@ static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 tgrid, dim3 block, hipS
         hipLaunchKernelGGL((k_wf_trace<0, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
         hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, none, none);
         hipLaunchKernelGGL((k_wf_trace<1, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
-        hipLaunchKernelGGL(k_wf_query<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, none, none);
+        hipLaunchKernelGGL((k_wf_query<ANIM, FEAT>), grid, block, 0, stream, s->dev, s->pool, n_active, none, none);
         hipLaunchKernelGGL((k_wf_trace<2, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
     }
 }
@@ -618,6 +636,16 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         if (f->materials[i].kind == TRAY_MAT_MERL && f->materials[i].table >= f->n_merl) { rc = TRAY_E_INVALID; set_error("material references a missing MERL table"); }
         else mats[i] = lower_material(f->materials[i], f->merl_tables);
     }
+    {   // smallest kernel feature set that covers the materials
+        int feat = FEAT_NONE;
+        for (const DevMaterial& dm : mats)
+            for (uint32_t l = 0; l < dm.n_lobes && l < 2u; ++l) {
+                if (dm.lobe[l].kind == LB_MERL) feat |= FEAT_MERL;
+                if (dm.lobe[l].kind == LB_MF_TRANS) feat |= FEAT_MF_TRANS;
+            }
+        s->feat = (feat & FEAT_MF_TRANS) ? FEAT_ALL : feat;
+        if (getenv("TRAYHIP_FEAT_ALL")) s->feat = FEAT_ALL;
+    }
     UP(materials, mats.data(), f->n_materials)
     UP(merl_data, f->merl_data, f->n_merl_floats)
     UP(lights, f->lights, f->n_lights)
@@ -707,8 +735,10 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         }
         if (s->stack_bytes > 32u * 1024u) {   // past the default dynamic-LDS window: raise the per-kernel limit (160 KB LDS per CU)
             const int bytes = (int)s->stack_bytes;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_MERL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -731,8 +761,8 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     int per_cu = 0, cus = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) cus = prop.multiProcessorCount;
-    hipError_t occ = s->animated ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles<1>, TR_BLOCK, s->stack_bytes)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles<0>, TR_BLOCK, s->stack_bytes);
+    hipError_t occ = s->animated ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles<1, FEAT_ALL>, TR_BLOCK, s->stack_bytes)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles<0, FEAT_ALL>, TR_BLOCK, s->stack_bytes);
     if (occ != hipSuccess || per_cu < 1) per_cu = 1;
     s->deferred_n_moving = 0;
     for (uint32_t i = 0; i < f->n_instances; ++i) if (f->instances[i].animated) s->deferred_n_moving++;
@@ -817,8 +847,12 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     const uint64_t max_rounds = tiles_per_chunk * (((uint64_t)spp + 3) / 4 * (s->dev.max_depth + 3) + 4) + 2 * WF_POLL;
     for (uint32_t round = 0;; ++round) {
         HIP_CHECK(hipMemsetAsync(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), stream));
-        if (s->animated) wf_round<1>(s, grid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qctl);
-        else wf_round<0>(s, grid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qctl);
+#define WF_ROUND(A, F) wf_round<A, F>(s, grid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qctl)
+        if (s->animated) WF_ROUND(1, FEAT_ALL);
+        else if (s->feat == FEAT_NONE) WF_ROUND(0, FEAT_NONE);
+        else if (s->feat == FEAT_MERL) WF_ROUND(0, FEAT_MERL);
+        else WF_ROUND(0, FEAT_ALL);
+#undef WF_ROUND
         launches += 7;
         if (round % WF_POLL == WF_POLL - 1) {
             HIP_CHECK(hipGetLastError());
@@ -874,12 +908,13 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     if (s->wavefront) return launch_wavefront(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
     int blocks = (int)std::min<uint32_t>((uint32_t)s->n_blocks, tile_count);
     HIP_CHECK(hipEventRecord(s->ev0, stream));
-    if (s->animated)
-        hipLaunchKernelGGL(k_path_tiles<1>, dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf,
-                           rgbw_dev, s->d_counter, s->d_stats);
-    else
-        hipLaunchKernelGGL(k_path_tiles<0>, dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf,
-                           rgbw_dev, s->d_counter, s->d_stats);
+#define PATH_TILES(A, F) hipLaunchKernelGGL((k_path_tiles<A, F>), dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, \
+                                            chunk_stride, spp, kf, rgbw_dev, s->d_counter, s->d_stats)
+    if (s->animated) PATH_TILES(1, FEAT_ALL);
+    else if (s->feat == FEAT_NONE) PATH_TILES(0, FEAT_NONE);
+    else if (s->feat == FEAT_MERL) PATH_TILES(0, FEAT_MERL);
+    else PATH_TILES(0, FEAT_ALL);
+#undef PATH_TILES
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(s->ev1, stream));
     s->timing_valid = true;
@@ -923,6 +958,14 @@ int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t) {
         st.samples += a.samples; st.vertices += a.vertices; st.rays += a.rays;
         for (int k = 0; k < 18; ++k) st.trav[k] += a.trav[k];
     }
+#ifdef TR_STAGE_CLOCKS
+    if (getenv("TRAYHIP_STATS") && st.trav[0]) {
+        double tot = 0;
+        for (int k = 0; k < 7; ++k) tot += (double)st.trav[k];
+        const char* names[7] = {"trace A", "trace B", "trace C", "vertex_begin", "queries", "vertex_end", "regen+film"};
+        for (int k = 0; k < 7; ++k) fprintf(stderr, "[trayhip] %-12s %5.1f %% of wave cycles\n", names[k], 100.0 * (double)st.trav[k] / tot);
+    }
+#else
     if (getenv("TRAYHIP_STATS") && st.rays)
         for (int g = 0; g < 3; ++g) {
             const unsigned long long* t = st.trav + g * 6;
@@ -930,6 +973,7 @@ int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t) {
             fprintf(stderr, "[trayhip] stage %c: %llu rays; per ray: node steps %.2f  single-node visits %.2f  two-child expansions %.2f  instance entries %.2f  triangle tests %.2f\n",
                     "ABC"[g], t[5], (double)t[0] / t[5], (double)t[1] / t[5], (double)t[2] / t[5], (double)t[3] / t[5], (double)t[4] / t[5]);
         }
+#endif
     t->launches = s->launches;
     t->samples = st.samples; t->vertices = st.vertices; t->rays = st.rays;
     return TRAY_OK;

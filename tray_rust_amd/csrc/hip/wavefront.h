@@ -396,7 +396,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
 }
 
 // Stage B shading: the BSDF queries of the vertex (light half, BSDF half, continuation)
-template <int ANIM>
+template <int ANIM, int FEAT>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ queue_c,
                                                        uint32_t* __restrict__ qctl) {
     const DevScene& sc = scv;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPoo
     ln.o = mk(0.0f, 0.0f, 0.0f); ln.d = mk(0.0f, 0.0f, 0.0f);
     ln.aux_d = mk(0.0f, 0.0f, 0.0f); ln.mis_f = mk(0.0f, 0.0f, 0.0f);
     ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
-    vertex_queries<ANIM>(sc, ln, (flags & WF_OCCLUDED) != 0u);
+    vertex_queries<ANIM, FEAT>(sc, ln, (flags & WF_OCCLUDED) != 0u);
     pu(pool, F_FLAGS, i) = ln.flags;
     st3(pool, F_T, i, ln.throughput);
     st3(pool, F_DIRECT, i, ln.direct);
