@@ -151,8 +151,9 @@ TR_DEV f3 merl_eval(const float* __restrict__ brdf, f3 w_oi, f3 w_ii) {
 // FEAT: which of the two register-hungry lobe kinds the scene's materials contain. The kernels that hold BSDF code are
 // instantiated per feature set and tray_scene_create picks the smallest one that covers the scene: leaving the MERL table
 // lookup and the microfacet-transmission code out of the single eval / pdf site cuts the tile kernel's scratch from 740 to
-// 592 B per lane (cornell_box 454 -> 494, smallpt 385 -> 426 Msamples/s at 64 spp).
-enum : int { FEAT_NONE = 0, FEAT_MERL = 1, FEAT_MF_TRANS = 2, FEAT_ALL = 3 };
+// 592 B per lane (cornell_box 454 -> 484, smallpt 385 -> 421 Msamples/s at 64 spp), leaving out the specular lobes and the
+// conductor Fresnel term as well to 508 B (cornell_box 545).
+enum : int { FEAT_NONE = 0, FEAT_MERL = 1, FEAT_MF_TRANS = 2, FEAT_SPEC = 4, FEAT_ALL = 7 };   // FEAT_SPEC: specular lobes and conductor Fresnel
 template <int FEAT>
 TR_DEV f3 lobe_eval(const Bsdf& b, const Lobe& l, f3 w_o, f3 w_i) {
     switch (l.kind) {
@@ -176,7 +177,7 @@ TR_DEV f3 lobe_eval(const Bsdf& b, const Lobe& l, f3 w_o, f3 w_i) {
             w_h = normalized(w_h);
             float d = beckmann_d(l.width, w_h);
             f3 f;
-            if (l.kind == LB_TS_DIEL) { float fr = fresnel_dielectric(l.eta_t, dot(w_i, w_h)); f = mk(fr, fr, fr); }
+            if (!(FEAT & FEAT_SPEC) || l.kind == LB_TS_DIEL) { float fr = fresnel_dielectric(l.eta_t, dot(w_i, w_h)); f = mk(fr, fr, fr); }
             else f = fresnel_conductor(mk(b.mat->eta[0], b.mat->eta[1], b.mat->eta[2]), mk(b.mat->k[0], b.mat->k[1], b.mat->k[2]), dot(w_i, w_h));
             float g = beckmann_g1(l.width, w_i) * beckmann_g1(l.width, w_o);
             return l.color * f * d * g / (4.0f * cos_ti * cos_to);
@@ -226,6 +227,7 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
     switch (l.kind) {
         case LB_SPEC_REFL_DIEL:
         case LB_SPEC_REFL_COND: {
+            if (!(FEAT & FEAT_SPEC)) { w_i = zero; pdf = 0.0f; return zero; }   // no such lobe in this scene (checked by the host)
             w_i = mk(-w_o.x, -w_o.y, w_o.z);
             if (w_i.z != 0.0f) {
                 f3 f;
@@ -238,6 +240,7 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
             return zero;
         }
         case LB_SPEC_TRANS: {
+            if (!(FEAT & FEAT_SPEC)) { w_i = zero; pdf = 0.0f; return zero; }
             bool entering = cos_theta(w_o) > 0.0f;
             float ei = entering ? 1.0f : l.eta_t, et = entering ? l.eta_t : 1.0f;
             f3 n = entering ? mk(0.0f, 0.0f, 1.0f) : mk(0.0f, 0.0f, -1.0f);

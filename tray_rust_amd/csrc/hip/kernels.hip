@@ -640,8 +640,10 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         int feat = FEAT_NONE;
         for (const DevMaterial& dm : mats)
             for (uint32_t l = 0; l < dm.n_lobes && l < 2u; ++l) {
-                if (dm.lobe[l].kind == LB_MERL) feat |= FEAT_MERL;
-                if (dm.lobe[l].kind == LB_MF_TRANS) feat |= FEAT_MF_TRANS;
+                const uint32_t k = dm.lobe[l].kind;
+                if (k == LB_MERL) feat |= FEAT_MERL;
+                if (k == LB_MF_TRANS) feat |= FEAT_MF_TRANS;
+                if (k == LB_SPEC_REFL_DIEL || k == LB_SPEC_REFL_COND || k == LB_SPEC_TRANS || k == LB_TS_COND) feat |= FEAT_SPEC;
             }
         s->feat = (feat & FEAT_MF_TRANS) ? FEAT_ALL : feat;
         if (getenv("TRAYHIP_FEAT_ALL")) s->feat = FEAT_ALL;
@@ -737,6 +739,8 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             const int bytes = (int)s->stack_bytes;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_MERL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_SPEC>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_MERL | FEAT_SPEC>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -851,6 +855,8 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
         if (s->animated) WF_ROUND(1, FEAT_ALL);
         else if (s->feat == FEAT_NONE) WF_ROUND(0, FEAT_NONE);
         else if (s->feat == FEAT_MERL) WF_ROUND(0, FEAT_MERL);
+        else if (s->feat == FEAT_SPEC) WF_ROUND(0, FEAT_SPEC);
+        else if (s->feat == (FEAT_MERL | FEAT_SPEC)) WF_ROUND(0, FEAT_MERL | FEAT_SPEC);
         else WF_ROUND(0, FEAT_ALL);
 #undef WF_ROUND
         launches += 7;
@@ -913,6 +919,8 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     if (s->animated) PATH_TILES(1, FEAT_ALL);
     else if (s->feat == FEAT_NONE) PATH_TILES(0, FEAT_NONE);
     else if (s->feat == FEAT_MERL) PATH_TILES(0, FEAT_MERL);
+    else if (s->feat == FEAT_SPEC) PATH_TILES(0, FEAT_SPEC);
+    else if (s->feat == (FEAT_MERL | FEAT_SPEC)) PATH_TILES(0, FEAT_MERL | FEAT_SPEC);
     else PATH_TILES(0, FEAT_ALL);
 #undef PATH_TILES
     HIP_CHECK(hipGetLastError());
