@@ -31,7 +31,7 @@ BYTES_PER_PIXEL = 16.0
 WORKLOAD_CONFIG = {"cornell_box": 1, "smallpt": 2, "dragon": 3, "tr15_like": 4}
 
 
-def cpu_baseline(flat, spp, target_seconds=15.0):
+def cpu_baseline(flat, spp, target_seconds=8.0):
     """Oracle ('port' of the reference incl. the per-intersection transform rebuild of geometry/receiver.rs:30) on all host
     cores over every k-th tile of the Morton queue. The per-sample cost of the path tracer does not depend on the sample
     count, so the sample runs at min(spp, 64) spp over MANY tiles (>= 16 per thread): with one expensive tile per thread
