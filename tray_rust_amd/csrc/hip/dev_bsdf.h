@@ -293,9 +293,10 @@ TR_DEV f3 from_shading(const Bsdf& b, f3 v) {   // bsdf.rs:57-61
     return mk(b.bitan.x * v.x + b.tan.x * v.y + b.n.x * v.z, b.bitan.y * v.x + b.tan.y * v.y + b.n.y * v.z,
               b.bitan.z * v.x + b.tan.z * v.y + b.n.z * v.z);
 }
+// The *_sh variants take w_o / w_i already in (normalised) shading space: BSDF::eval, ::pdf and ::sample each start with the
+// same to_shading + normalized of the same vectors (bsdf.rs:67-68,86,115-116); the vertex step computes them once.
 template <int FEAT>
-TR_DEV f3 bsdf_eval(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {   // bsdf.rs:66-79
-    f3 w_o = normalized(to_shading(b, wo_world)), w_i = normalized(to_shading(b, wi_world));
+TR_DEV f3 bsdf_eval_sh(const Bsdf& b, f3 w_o, f3 w_i, uint32_t flags) {   // bsdf.rs:66-79
     if (w_o.z * w_i.z > 0.0f) flags &= ~(uint32_t)BX_TRANSMISSION; else flags &= ~(uint32_t)BX_REFLECTION;
     f3 sum = mk(0.0f, 0.0f, 0.0f);
     const int n = (int)b.mat->n_lobes;
@@ -307,8 +308,11 @@ TR_DEV f3 bsdf_eval(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {  
     return sum;
 }
 template <int FEAT>
-TR_DEV float bsdf_pdf(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {   // bsdf.rs:114-125
-    f3 w_o = normalized(to_shading(b, wo_world)), w_i = normalized(to_shading(b, wi_world));
+TR_DEV f3 bsdf_eval(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {
+    return bsdf_eval_sh<FEAT>(b, normalized(to_shading(b, wo_world)), normalized(to_shading(b, wi_world)), flags);
+}
+template <int FEAT>
+TR_DEV float bsdf_pdf_sh(const Bsdf& b, f3 w_o, f3 w_i, uint32_t flags) {   // bsdf.rs:114-125
     float pdf_val = 0.0f;
     int n_comps = 0;
     const int n = (int)b.mat->n_lobes;
@@ -318,6 +322,10 @@ TR_DEV float bsdf_pdf(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {
         if (lobe_matches(l.type, flags)) { pdf_val = pdf_val + lobe_pdf<FEAT>(l, w_o, w_i); ++n_comps; }
     }
     return n_comps > 0 ? pdf_val / (float)n_comps : 0.0f;
+}
+template <int FEAT>
+TR_DEV float bsdf_pdf(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {
+    return bsdf_pdf_sh<FEAT>(b, normalized(to_shading(b, wo_world)), normalized(to_shading(b, wi_world)), flags);
 }
 // Head of BSDF::sample (bsdf.rs:85-102): choose the lobe, sample its direction. Outputs the world
 // direction, the lobe's own pdf, f for specular lobes, the sampled type bits (0 = nothing sampled)
@@ -329,7 +337,7 @@ struct SampleHead {
     bool need_eval, need_pdf;
 };
 template <int FEAT>
-TR_DEV SampleHead bsdf_sample_head(const Bsdf& b, f3 wo_world, uint32_t flags, float u0, float u1, float one_d) {
+TR_DEV SampleHead bsdf_sample_head_sh(const Bsdf& b, f3 w_o, uint32_t flags, float u0, float u1, float one_d) {
     const f3 zero = mk(0.0f, 0.0f, 0.0f);
     SampleHead h;
     h.wi_world = zero; h.f = zero; h.pdf = 0.0f; h.sampled_type = 0u; h.need_eval = false; h.need_pdf = false;
@@ -343,7 +351,6 @@ TR_DEV SampleHead bsdf_sample_head(const Bsdf& b, f3 wo_world, uint32_t flags, f
     if (comp > n_matching - 1) comp = n_matching - 1;
     int li = (m0 && comp == 0) ? 0 : 1;   // matching_at(comp): the comp-th matching lobe
     const Lobe l = load_lobe(b.mat, li);
-    f3 w_o = normalized(to_shading(b, wo_world));
     f3 w_i;
     float pdf_v;
     f3 f = lobe_sample<FEAT>(b, l, w_o, u0, u1, w_i, pdf_v);
@@ -354,6 +361,10 @@ TR_DEV SampleHead bsdf_sample_head(const Bsdf& b, f3 wo_world, uint32_t flags, f
     h.need_pdf = !specular && n_matching > 1;
     h.need_eval = !specular;
     return h;
+}
+template <int FEAT>
+TR_DEV SampleHead bsdf_sample_head(const Bsdf& b, f3 wo_world, uint32_t flags, float u0, float u1, float one_d) {
+    return bsdf_sample_head_sh<FEAT>(b, normalized(to_shading(b, wo_world)), flags, u0, u1, one_d);
 }
 // Whole BSDF::sample (used by the BSDF debug kernel; the tile kernel shares one eval / pdf site
 // between the light and the BSDF halves of estimate_direct and the path continuation, dev_integrator.h)

@@ -207,6 +207,7 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
     const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
     const bool delta = light->kind == TRAY_INST_POINT_EMITTER;
     SampleHead h;
+    const f3 wo_sh = normalized(to_shading(ln.bsdf, ln.w_o));   // shared by sample / eval / pdf (same value each computes)
     if (is_light) {
         h.wi_world = ln.wi_l; h.f = mk(0.0f, 0.0f, 0.0f); h.pdf = 0.0f; h.sampled_type = 0u;
         h.need_eval = true; h.need_pdf = !delta;
@@ -214,10 +215,13 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
         float u0, u1;
         lane_2d(sc, ln, mis ? SD_B2 : SD_P2, u0, u1);
         float one_d = lane_1d(sc, ln, mis ? SD_B1 : SD_P1);
-        h = bsdf_sample_head<FEAT>(ln.bsdf, ln.w_o, flags, u0, u1, one_d);
+        h = bsdf_sample_head_sh<FEAT>(ln.bsdf, wo_sh, flags, u0, u1, one_d);
     }
-    if (h.need_eval) h.f = bsdf_eval<FEAT>(ln.bsdf, ln.w_o, h.wi_world, flags);
-    if (h.need_pdf) h.pdf = bsdf_pdf<FEAT>(ln.bsdf, ln.w_o, h.wi_world, flags);
+    if (h.need_eval || h.need_pdf) {
+        const f3 wi_sh = normalized(to_shading(ln.bsdf, h.wi_world));
+        if (h.need_eval) h.f = bsdf_eval_sh<FEAT>(ln.bsdf, wo_sh, wi_sh, flags);
+        if (h.need_pdf) h.pdf = bsdf_pdf_sh<FEAT>(ln.bsdf, wo_sh, wi_sh, flags);
+    }
     const f3 f = h.f, w_i = h.wi_world;
     const float pdf = h.pdf;
     if (is_light) {
