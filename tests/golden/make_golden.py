@@ -33,3 +33,19 @@ for name, build in (("cornell_box", scenes.cornell_box), ("smallpt", scenes.smal
         np.savez_compressed(os.path.join(HERE, f"{name}_48x32_16spp_seed9.npz"), rgbw=img, vertices=st.vertices, rays=st.rays,
                             px=px, py=py, si=si, radiance=rad)
         print(name, img.shape, st.vertices, st.rays)
+
+# moving scene (frame 3 of moving_box: camera, sphere, group and light on splines, keyed emission) and the small-grid
+# dragon stand-in (mesh BVH + MERL table): these write their own assets
+for name, writer, frame in (("moving_box", lambda d: scenes.write_moving_box(d, width=48, height=32, samples=16), 3),
+                            ("dragon40", lambda d: scenes.write_dragon_assets(d, film=(48, 32, 16), grid=40, extent=1.0)[0], 0)):
+    with tempfile.TemporaryDirectory() as d:
+        scene, *_ = T.Scene.load_file(writer(d))
+        flat = scene.flatten(frame)
+        img, st = O.render_tiles(flat, 16, seed=9)
+        rng = np.random.default_rng(42)
+        n = 512
+        px = rng.integers(0, 48, n).astype(np.uint32); py = rng.integers(0, 32, n).astype(np.uint32); si = rng.integers(0, 16, n).astype(np.uint32)
+        rad = O.sample_radiance(flat, px, py, si, 16, seed=9)
+        np.savez_compressed(os.path.join(HERE, f"{name}_48x32_16spp_seed9.npz"), rgbw=img, vertices=st.vertices, rays=st.rays,
+                            px=px, py=py, si=si, radiance=rad, frame=frame)
+        print(name, img.shape, st.vertices, st.rays)
