@@ -7,8 +7,11 @@
 //   chunk     : 256 consecutive slots = one workgroup = one 8x8 tile at a time (slot k <-> pixel k & 63,
 //               samples (k >> 6), +4, ... exactly like k_path_tiles), pulled from the Morton queue with a
 //               global atomic counter (block_queue.rs:52-59) when the previous tile of the chunk is complete
-//   per round : k_wf_advance (vertex_end of the previous round, film splat of finished samples, tile switch,
-//               path regeneration) -> k_wf_trace<A> -> k_wf_begin -> k_wf_trace<B> -> k_wf_query -> k_wf_trace<C>
+//   per round : k_wf_advance (stage C shading of the few vertices that traced a BSDF-sampled light ray, film splat of finished
+//               samples, tile switch, queues A and R) -> k_wf_regen (new camera samples for queue R: camera ray, spline stacks
+//               of moving instances into the per-slot cache, queue A) -> k_wf_trace_dyn<A> -> k_wf_begin (queue B) ->
+//               k_wf_trace_dyn<B> -> k_wf_query (BSDF queries; vertex_end unless a stage C ray is pending; queue C) ->
+//               k_wf_trace_dyn<C>. TRAYHIP_WF_TRACE=slot runs one thread per slot in the trace stages instead (k_wf_trace).
 //   film      : per-chunk row bins in global memory (workgroup-private, L2 resident), resolved through an LDS
 //               window and flushed with global f32 atomics once per tile (same arithmetic as k_path_tiles)
 //
@@ -417,11 +420,24 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPoo
     ln.aux_d = mk(0.0f, 0.0f, 0.0f); ln.mis_f = mk(0.0f, 0.0f, 0.0f);
     ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
     vertex_queries<ANIM, FEAT>(sc, ln, (flags & WF_OCCLUDED) != 0u);
-    pu(pool, F_FLAGS, i) = ln.flags;
     st3(pool, F_T, i, ln.throughput);
-    st3(pool, F_DIRECT, i, ln.direct);
     if (!(ln.flags & LF_LAST)) { st3(pool, F_O, i, ln.o); st3(pool, F_D, i, ln.d); }
-    if (ln.flags & LF_MIS) { st3(pool, F_AUX, i, ln.aux_d); st3(pool, F_MISF, i, ln.mis_f); st3(pool, F_LI, i, ln.li); }
+    if (ln.flags & LF_MIS) {   // the vertex ends in k_wf_advance, after stage C has traced the BSDF-sampled light ray
+        pu(pool, F_FLAGS, i) = ln.flags;
+        st3(pool, F_DIRECT, i, ln.direct);
+        st3(pool, F_AUX, i, ln.aux_d); st3(pool, F_MISF, i, ln.mis_f); st3(pool, F_LI, i, ln.li);
+    } else {   // no stage C ray (the usual case): vertex_end here, while the vertex is in registers
+        ln.illum = ld3(pool, F_ILLUM, i);
+        ln.t_vertex = ld3(pool, F_TV, i);
+        HitRec none;
+        none.t = 0.0f; none.inst = 0xffffffffu; none.prim = 0u; none.b1 = 0.0f; none.b2 = 0.0f;
+        const bool cont = vertex_end<ANIM>(sc, ln, false, none);
+        st3(pool, F_ILLUM, i, ln.illum);
+        pu(pool, F_BOUNCE, i) = ln.bounce;
+        uint32_t f2 = ln.flags & ~(WF_INVERTEX | WF_HIT_A | WF_HIT_C | WF_OCCLUDED | LF_SHADOW | LF_MIS | LF_LAST);
+        if (!cont) f2 = (f2 & ~LF_ALIVE) | WF_FINISHED;
+        pu(pool, F_FLAGS, i) = f2;
+    }
     if (queue_c) wf_enqueue(queue_c, qctl + 2, (ln.flags & LF_MIS) != 0u, i);
 }
 
