@@ -62,3 +62,19 @@ def test_device_calls_fail_loudly_without_gpu(assets):
     scene, rt, spp, fi = T.Scene.load_file(os.path.join(assets, "cornell_box.json"))
     with pytest.raises(T.TrayError):
         T.Hip(0).render(scene, rt, T.Config(".", "x", spp, 1, fi))
+
+
+def test_product_does_not_depend_on_the_oracle(built):
+    """oracle/ is test infrastructure: the shipped library must not link it and the package must not import it."""
+    import re
+    import subprocess
+    from tray_rust_amd import _lib as L
+    needed = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-d", L.LIB_PATH], capture_output=True, text=True).stdout
+    libs = re.findall(r"\(NEEDED\)\s+Shared library: \[(.*?)\]", needed)
+    assert libs and not any("oracle" in l for l in libs), libs
+    pkg = os.path.dirname(os.path.abspath(L.__file__))
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".h", ".cpp", ".hip")):
+                text = open(os.path.join(root, f), errors="replace").read()
+                assert "liboracle" not in text and "oracle/" not in text.replace("the oracle/", ""), os.path.join(root, f)

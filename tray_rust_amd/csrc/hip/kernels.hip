@@ -448,7 +448,6 @@ __global__ __launch_bounds__(64) void k_debug_bsdf(const DevScene scv, uint32_t 
 struct TrayDeviceScene {
     int device = 0;
     DevScene dev{};
-    DevScene* d_dev = nullptr;   // the same struct in device memory (kernels read it through scalar loads)
     std::vector<void*> allocs;
     uint2* d_tiles = nullptr;      // full Morton queue
     uint32_t n_tiles = 0;
@@ -698,12 +697,6 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     s->d_counter = const_cast<uint32_t*>(d_counter);
     s->d_stats = const_cast<DevStats*>(d_stats);
     if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
-    {
-        const DevScene* d_dev = nullptr;
-        rc = upload(s, &s->dev, 1, &d_dev);
-        s->d_dev = const_cast<DevScene*>(d_dev);
-        if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
-    }
     if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
         tray_scene_destroy(s); set_error("hipEventCreate failed"); return TRAY_E_DEVICE;
     }
@@ -998,9 +991,8 @@ int tray_debug_intersect(TrayDeviceScene* s, uint32_t n, const TrayRay* rays, Tr
     hipError_t e = hipMalloc(&d_h, n * sizeof(TrayHit));
     if (e == hipSuccess) e = hipMemcpy(d_r, rays, n * sizeof(TrayRay), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        DevScene nocache = s->dev;   // debug grids are sized by the item count, not by the cache: evaluate at every use
-        nocache.xf_cache = nullptr;
-        if (s->animated) hipLaunchKernelGGL(k_debug_intersect<2>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, nocache, n, d_r, d_h);
+        // ANIM = 2: debug grids are sized by the item count, not by the transform cache, so the spline stacks are evaluated at every use
+        if (s->animated) hipLaunchKernelGGL(k_debug_intersect<2>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_r, d_h);
         else hipLaunchKernelGGL(k_debug_intersect<0>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_r, d_h);
         e = hipGetLastError();
     }
@@ -1031,10 +1023,8 @@ int tray_debug_sample_radiance(TrayDeviceScene* s, uint32_t n, const uint32_t* p
         uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
         kf = mix(kf ^ (uint32_t)(seed >> 32));
         kf = mix(kf + s->dev.frame);
-        DevScene nocache = s->dev;
-        nocache.xf_cache = nullptr;
         if (s->animated)
-            hipLaunchKernelGGL(k_debug_sample_radiance<2>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, nocache, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
+            hipLaunchKernelGGL(k_debug_sample_radiance<2>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
         else
             hipLaunchKernelGGL(k_debug_sample_radiance<0>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
         e = hipGetLastError();

@@ -213,7 +213,6 @@ static bool load_color(const Json& e, float c[4]) {   // scene.rs:698-718
         for (int i = 0; i < 4; ++i) c[i] = c[i] * v[3];
     return true;
 }
-static float luminance(const float c[4]) { return 0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2]; }   // color.rs:43-45
 
 static bool load_animated_color(const Json& e, std::vector<ColorKey>& out) {   // scene.rs:722-747
     if (!e.is_array() || e.arr.empty()) return false;
