@@ -17,6 +17,9 @@ if scene_name == "tr15_like":
         import json
         desc = json.load(open(f"{d}/tr15_like.json")); desc["camera"]["shutter_size"] = float(os.environ["TR15_SHUTTER"])
         json.dump(desc, open(f"{d}/tr15_like.json", "w"))
+elif scene_name == "moving_box":
+    scenes.write_moving_box(d, width=1920, height=1080, samples=spp)
+    frame = int(os.environ.get("MOVING_FRAME", "3"))
 elif scene_name == "dragon":
     scenes.write_dragon_assets(d, film=(1920, 1080, spp), extent=float(os.environ.get("DRAGON_EXTENT", "0.2")))
 else:

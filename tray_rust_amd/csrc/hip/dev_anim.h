@@ -5,14 +5,19 @@
 //   AnimatedColor::color            film/animated_color.rs:52-78
 //   BSpline::point                  bspline 0.2.2 (crates.io, not vendored by the reference): upper-bound span search
 //                                   clamped to [degree, n_knots - degree - 1], iterative de Boor
-// eval_xform_stack is the only function of the device code that is NOT inlined: it runs once per (ray, moving instance)
-// visit, needs ~100 registers for the 4x4 products and the general inverse, and must not raise the register budget of
-// the traversal loop it is called from. It returns rows 0..2 of mat and of inv (row 3 of a TRS product is (0,0,0,1)).
+// eval_xform_stack returns rows 0..2 of mat and of inv (row 3 of a TRS product is (0,0,0,1)). It needs ~100 registers for
+// the 4x4 products and the general inverse, so the hot loops never contain it: they read the per-path cache that the start
+// of a camera sample fills (dev_geom.h). It is inlined there (a call gives the calling kernel the callee's full register
+// allocation: measured 112 vs 128 Msamples/s on the moving_box scene).
 #pragma once
 #include "../../../include/trayhip.h"
 #include "dev_math.h"
 
 namespace tr {
+
+#ifndef TR_ANIM_EVAL
+#define TR_ANIM_EVAL __device__ __forceinline__
+#endif
 
 struct DevKey {
     f3 t;
@@ -154,7 +159,7 @@ TR_DEV void key_transform(const DevKey& k, float* __restrict__ mat, float* __res
 }
 
 // AnimatedTransform::transform(time). out24 = rows 0..2 of mat, then rows 0..2 of inv.
-__device__ __noinline__ void eval_xform_stack(const TrayXformLevel* __restrict__ levels, const TrayKeyframe* __restrict__ kfs,
+TR_ANIM_EVAL void eval_xform_stack(const TrayXformLevel* __restrict__ levels, const TrayKeyframe* __restrict__ kfs,
                                               const float* __restrict__ knots, uint32_t xf_first, uint32_t xf_count, float time,
                                               float* out24) {
     float mat[16], inv[16];

@@ -737,6 +737,10 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_MERL | FEAT_SPEC>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<1, FEAT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<1, FEAT_SPEC>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL | FEAT_SPEC>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -846,12 +850,12 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     for (uint32_t round = 0;; ++round) {
         HIP_CHECK(hipMemsetAsync(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), stream));
 #define WF_ROUND(A, F) wf_round<A, F>(s, grid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qctl)
-        if (s->animated) WF_ROUND(1, FEAT_ALL);
-        else if (s->feat == FEAT_NONE) WF_ROUND(0, FEAT_NONE);
-        else if (s->feat == FEAT_MERL) WF_ROUND(0, FEAT_MERL);
-        else if (s->feat == FEAT_SPEC) WF_ROUND(0, FEAT_SPEC);
-        else if (s->feat == (FEAT_MERL | FEAT_SPEC)) WF_ROUND(0, FEAT_MERL | FEAT_SPEC);
-        else WF_ROUND(0, FEAT_ALL);
+#define WF_ROUND_F(A) do { if (s->feat == FEAT_NONE) WF_ROUND(A, FEAT_NONE); else if (s->feat == FEAT_MERL) WF_ROUND(A, FEAT_MERL); \
+                          else if (s->feat == FEAT_SPEC) WF_ROUND(A, FEAT_SPEC); else if (s->feat == (FEAT_MERL | FEAT_SPEC)) WF_ROUND(A, FEAT_MERL | FEAT_SPEC); \
+                          else WF_ROUND(A, FEAT_ALL); } while (0)
+        if (s->animated) WF_ROUND_F(1);
+        else WF_ROUND_F(0);
+#undef WF_ROUND_F
 #undef WF_ROUND
         launches += 7;
         if (round % WF_POLL == WF_POLL - 1) {
@@ -910,12 +914,12 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     HIP_CHECK(hipEventRecord(s->ev0, stream));
 #define PATH_TILES(A, F) hipLaunchKernelGGL((k_path_tiles<A, F>), dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, \
                                             chunk_stride, spp, kf, rgbw_dev, s->d_counter, s->d_stats)
-    if (s->animated) PATH_TILES(1, FEAT_ALL);
-    else if (s->feat == FEAT_NONE) PATH_TILES(0, FEAT_NONE);
-    else if (s->feat == FEAT_MERL) PATH_TILES(0, FEAT_MERL);
-    else if (s->feat == FEAT_SPEC) PATH_TILES(0, FEAT_SPEC);
-    else if (s->feat == (FEAT_MERL | FEAT_SPEC)) PATH_TILES(0, FEAT_MERL | FEAT_SPEC);
-    else PATH_TILES(0, FEAT_ALL);
+#define PATH_TILES_F(A) do { if (s->feat == FEAT_NONE) PATH_TILES(A, FEAT_NONE); else if (s->feat == FEAT_MERL) PATH_TILES(A, FEAT_MERL); \
+                             else if (s->feat == FEAT_SPEC) PATH_TILES(A, FEAT_SPEC); else if (s->feat == (FEAT_MERL | FEAT_SPEC)) PATH_TILES(A, FEAT_MERL | FEAT_SPEC); \
+                             else PATH_TILES(A, FEAT_ALL); } while (0)
+    if (s->animated) PATH_TILES_F(1);
+    else PATH_TILES_F(0);
+#undef PATH_TILES_F
 #undef PATH_TILES
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(s->ev1, stream));
