@@ -9,7 +9,10 @@ import shutil
 import numpy as np
 import pytest
 
+import ctypes as C
+
 import tray_rust_amd as T
+from tray_rust_amd import _lib as L
 from tray_rust_amd import scenes
 import _oracle as O
 
@@ -88,3 +91,76 @@ def test_tr15_frames_flatten_and_trace(tr15, frame, n_moving):
         assert (np.frombuffer(inst.mat, np.float32) == out[:16]).all() and (np.frombuffer(inst.inv, np.float32) == out[16:]).all()
     img, st = O.render_tiles(flat, 4, seed=1, tile_start=16000, tile_count=6)
     assert np.isfinite(img).all() and st.samples == 6 * 64 * 4
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "smallpt", "logo_with_friends", "suzanne_scene", "logo_shadow"])
+def test_every_bundled_reference_scene_loads_and_renders(name, tmp_path, built):
+    """All scene files the reference ships (besides tr15.json above): the reference's own JSON, its own models where it
+    ships them (cube.obj), generated stand-ins for the models and BRDF tables it does not distribute."""
+    src_dir = os.path.dirname(TR15)
+    d = str(tmp_path)
+    shutil.copy(os.path.join(src_dir, name + ".json"), os.path.join(d, name + ".json"))
+    desc = json.load(open(os.path.join(src_dir, name + ".json")))
+    files = {}
+
+    def walk(objs):
+        for o in objs:
+            g = o.get("geometry")
+            if g and g["type"] == "mesh":
+                files.setdefault(g["file"], set()).add(g["model"])
+            if o["type"] == "group":
+                walk(o["objects"])
+    walk(desc["objects"])
+    seed = 50
+    for path, models in sorted(files.items()):
+        dst = os.path.join(d, path)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        if os.path.exists(os.path.join(src_dir, path)):
+            shutil.copy(os.path.join(src_dir, path), dst)
+            continue
+        objs = []
+        for m in sorted(models):
+            seed += 1
+            objs.append((m,) + scenes.knot_mesh(10, 6, seed=seed, extent=1.0))
+        scenes.write_obj(dst, objs)
+    first = None
+    for m in desc["materials"]:
+        if m["type"] == "merl":
+            dst = os.path.join(d, m["file"])
+            if first is None:
+                scenes.write_merl_binary(dst)
+                first = dst
+            elif not os.path.exists(dst):
+                os.link(first, dst)
+    scene, rt, spp, fi = T.Scene.load_file(os.path.join(d, name + ".json"))
+    assert (rt.width, rt.height, spp) == (desc["film"]["width"], desc["film"]["height"], desc["film"]["samples"])
+    flat = scene.flatten(0)
+    fs = flat.contents
+    assert fs.n_lights >= 1 and fs.animated == 0
+    n_tiles = (rt.width // 8) * (rt.height // 8)
+    img, st = O.render_tiles(flat, 4, seed=1, tile_start=n_tiles // 2, tile_count=4)
+    assert np.isfinite(img).all() and st.samples == 4 * 64 * 4
+
+
+def test_generated_cube_and_scenes_equal_the_reference_files(tmp_path, built):
+    """scenes.cube_obj() / cornell_box() / smallpt() restate scenes/models/cube.obj, cornell_box.json and smallpt.json (those
+    files do not exist on the GPU box): the flattened scenes must be identical, bit for bit."""
+    src_dir = os.path.dirname(TR15)
+    ref_dir, gen_dir = str(tmp_path / "ref"), str(tmp_path / "gen")
+    os.makedirs(os.path.join(ref_dir, "models")); os.makedirs(gen_dir)
+    shutil.copy(os.path.join(src_dir, "models", "cube.obj"), os.path.join(ref_dir, "models", "cube.obj"))
+    for name, build in (("cornell_box", scenes.cornell_box), ("smallpt", scenes.smallpt)):
+        desc = json.load(open(os.path.join(src_dir, name + ".json")))
+        shutil.copy(os.path.join(src_dir, name + ".json"), os.path.join(ref_dir, name + ".json"))
+        scenes.write_assets(gen_dir, cornell=(desc["film"]["width"], desc["film"]["height"], desc["film"]["samples"]),
+                            small=(desc["film"]["width"], desc["film"]["height"], desc["film"]["samples"]))
+        a = T.Scene.load_file(os.path.join(ref_dir, name + ".json"))[0]
+        b = T.Scene.load_file(os.path.join(gen_dir, name + ".json"))[0]
+        fa, fb = a.flatten(0).contents, b.flatten(0).contents
+        assert (fa.n_instances, fa.n_tris, fa.n_mesh_nodes, fa.n_materials, fa.n_lights) == (fb.n_instances, fb.n_tris, fb.n_mesh_nodes, fb.n_materials, fb.n_lights)
+        for field, n, size in (("instances", fa.n_instances, C.sizeof(L.TrayInstance)), ("tri_verts", fa.n_tris, 48), ("tri_attrs", fa.n_tris, 64),
+                               ("mesh_nodes", fa.n_mesh_nodes, 32), ("top_nodes", fa.n_top_nodes, 32), ("materials", fa.n_materials, C.sizeof(L.TrayMaterial))):
+            ba = C.string_at(C.cast(getattr(fa, field), C.c_void_p), n * size)
+            bb = C.string_at(C.cast(getattr(fb, field), C.c_void_p), n * size)
+            assert ba == bb, (name, field)
+        assert bytes(fa.camera) == bytes(fb.camera) and bytes(fa.film) == bytes(fb.film)
