@@ -714,14 +714,42 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             }
             return best;
         };
+        std::vector<uint32_t> mesh_depths(f->n_meshes, 0u);
         uint32_t mesh_depth = 0;
-        for (uint32_t m = 0; m < f->n_meshes; ++m)
-            mesh_depth = std::max(mesh_depth, depth_of(f->mesh_nodes + f->meshes[m].node_offset, f->meshes[m].node_count));
-        uint32_t depth = mesh_depth + 1;
-        if (f->n_instances > TR_FLAT_MAX || s->animated || s->wavefront) depth += depth_of(f->top_nodes, f->n_top_nodes) + 4 + 1;
+        for (uint32_t m = 0; m < f->n_meshes; ++m) {
+            mesh_depths[m] = depth_of(f->mesh_nodes + f->meshes[m].node_offset, f->meshes[m].node_count);
+            mesh_depth = std::max(mesh_depth, mesh_depths[m]);
+        }
+        uint32_t depth = mesh_depth + 1;   // per-lane BVH<Triangle> traversal: one pending far child per level
+        if (f->n_instances > TR_FLAT_MAX || s->animated || s->wavefront) {
+            // two-level traversal: exact worst case over the instances. While instance j of a BVH<Instance> leaf at depth d is
+            // traversed the stack holds the pending far children of the top-level path (d - 1), the leaf's later instances,
+            // the exit-mesh sentinel and the pending far children inside the mesh (its depth - 1).
+            uint32_t worst = 0;
+            std::vector<std::pair<uint32_t, uint32_t>> st;
+            if (f->n_top_nodes) st.push_back({0u, 1u});
+            while (!st.empty()) {
+                auto [idx, dep] = st.back();
+                st.pop_back();
+                if (idx >= f->n_top_nodes) continue;
+                const TrayBvhNode& nd = f->top_nodes[idx];
+                if (nd.count == 0) { st.push_back({idx + 1, dep + 1}); st.push_back({nd.offset, dep + 1}); continue; }
+                for (uint32_t j = 0; j < nd.count; ++j) {
+                    uint32_t need = (dep - 1) + (nd.count - 1 - j);
+                    if (nd.offset + j < f->n_top_order) {
+                        const TrayInstance& in = f->instances[f->top_order[nd.offset + j]];
+                        if (in.geom_type == TRAY_GEOM_MESH && in.mesh_id < f->n_meshes) need += 1 + (mesh_depths[in.mesh_id] > 0 ? mesh_depths[in.mesh_id] - 1 : 0);
+                    }
+                    worst = std::max(worst, need);
+                }
+                worst = std::max(worst, dep - 1 + nd.count);   // right after the leaf queued its instances
+            }
+            depth = std::max(depth, worst + 1);   // + 1 spare entry
+        }
         depth = std::max(depth, 4u);
         if (depth > 96) { tray_scene_destroy(s); set_error("BVH too deep for the LDS traversal stack (" + std::to_string(depth) + " levels)"); return TRAY_E_UNSUPPORTED; }
         s->stack_bytes = depth * TR_BLOCK * (uint32_t)sizeof(uint32_t);
+        if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] traversal stack: %u entries per lane (deepest BVH<Triangle> %u)\n", depth, mesh_depth);
         // cooperative test of small meshes (dev_geom.h: mesh_leaf_coop) in the flat instance loop: per-wave LDS behind the stacks
         bool single_leaf = false;
         for (uint32_t m = 0; m < f->n_meshes; ++m) single_leaf = single_leaf || f->meshes[m].tri_count <= TR_COOP_MAX_TRIS;
