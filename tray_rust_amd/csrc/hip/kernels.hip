@@ -473,6 +473,8 @@ struct TrayDeviceScene {
     int feat = FEAT_ALL;              // lobe kinds of the scene's materials that need the large kernels (dev_bsdf.h)
     uint32_t* d_queues = nullptr;     // wavefront schedule: ray queues A, B, C (n_slots each) + WF_QCTL_WORDS counters
     uint32_t n_blocks_trace = 0;      // persistent grid of k_wf_trace_dyn
+    uint32_t trace_lds_depth = 0, trace_lds_bytes = 0;   // LDS part of the dynamic-fetch kernel's stacks; deeper entries go to d_stack_overflow
+    uint32_t* d_stack_overflow = nullptr;
     bool wf_dynamic = true;           // TRAYHIP_WF_TRACE=slot: one thread per pool slot instead (no compaction)
 };
 
@@ -514,11 +516,11 @@ static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 tgrid, dim3 block, hipS
         hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
                            spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, qa, qr, qctl);
         hipLaunchKernelGGL(k_wf_regen<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
-        hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->stack_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats);
+        hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
         hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, qb, qctl);
-        hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->stack_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats);
+        hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
         hipLaunchKernelGGL((k_wf_query<ANIM, FEAT>), grid, block, 0, stream, s->dev, s->pool, n_active, qc, qctl);
-        hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->stack_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats);
+        hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
     } else {   // one thread per pool slot in every stage; only the regeneration is compacted
         uint32_t* const none = nullptr;
         uint32_t* const qr = qc + s->pool.n_slots + WF_QCTL_WORDS;
@@ -849,10 +851,20 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             int per_cu = 0, cus = 256;
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-            hipError_t oe = s->animated ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, 1>, TR_BLOCK, s->stack_bytes)
-                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, 0>, TR_BLOCK, s->stack_bytes);
+            // LDS stack entries per lane such that WF_TRACE_WAVES workgroups (4 waves each = one wave per SIMD) fit in the CU's 160 KB
+            const uint32_t full_depth = s->stack_bytes / (TR_BLOCK * (uint32_t)sizeof(uint32_t));
+            uint32_t lds_depth = std::min<uint32_t>(full_depth, (160u * 1024u / WF_TRACE_WAVES) / (TR_BLOCK * (uint32_t)sizeof(uint32_t)));
+            if (const char* e = getenv("TRAYHIP_WF_LDS_DEPTH")) lds_depth = std::min<uint32_t>(full_depth, (uint32_t)std::max(1, atoi(e)));
+            s->trace_lds_depth = lds_depth;
+            s->trace_lds_bytes = lds_depth * TR_BLOCK * (uint32_t)sizeof(uint32_t);
+            hipError_t oe = s->animated ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, 1>, TR_BLOCK, s->trace_lds_bytes)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, 0>, TR_BLOCK, s->trace_lds_bytes);
             if (oe != hipSuccess || per_cu < 1) per_cu = 1;
             s->n_blocks_trace = (uint32_t)(cus * per_cu);
+            const size_t ovf_entries = (size_t)(full_depth - lds_depth + 1u) * s->n_blocks_trace * TR_BLOCK;
+            HIP_CHECK(hipMalloc(&p, ovf_entries * sizeof(uint32_t)));
+            s->allocs.push_back(p); s->d_stack_overflow = static_cast<uint32_t*>(p);
+            if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] dynamic-fetch traversal: %u of %u stack entries in LDS, %d workgroups per CU\n", lds_depth, full_depth, per_cu);
             const char* e = getenv("TRAYHIP_WF_TRACE");
             s->wf_dynamic = !(e && std::string(e) == "slot");
         }

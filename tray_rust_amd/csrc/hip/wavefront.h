@@ -127,6 +127,9 @@ TR_DEV void wf_enqueue(uint32_t* __restrict__ queue, uint32_t* __restrict__ coun
 #ifndef WF_REFILL_MIN
 #define WF_REFILL_MIN 24
 #endif
+#ifndef WF_TRACE_WAVES
+#define WF_TRACE_WAVES 4   // waves per SIMD the traversal kernel is compiled for
+#endif
 #ifndef WF_NODE_STEPS
 #define WF_NODE_STEPS 8    // node steps per round of the while-while loop
 #endif
@@ -134,11 +137,18 @@ TR_DEV void wf_enqueue(uint32_t* __restrict__ queue, uint32_t* __restrict__ coun
 #define WF_NODE_MIN 16     // ... as long as this many lanes still have node work (or nobody waits for the leaf / pop phase)
 #endif
 template <int STAGE, int ANIM>
-__global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, WfPool pool, const uint32_t* __restrict__ queue,
-                                                           uint32_t* __restrict__ qctl, DevStats* __restrict__ stats) {
+__global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const DevScene scv, WfPool pool, const uint32_t* __restrict__ queue,
+                                                           uint32_t* __restrict__ qctl, DevStats* __restrict__ stats, uint32_t lds_depth,
+                                                           uint32_t* __restrict__ overflow) {
     const DevScene& sc = scv;
     extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries
     uint32_t* __restrict__ stack = s_stack + threadIdx.x;
+    // entries past lds_depth live in a per-thread column of `overflow` (HBM): the LDS part is sized for the occupancy the
+    // kernel is compiled for, the rarely reached deep levels of the largest meshes must not cost every workgroup its LDS
+    const uint32_t ovf_stride = gridDim.x * TR_BLOCK;
+    uint32_t* __restrict__ ovf = overflow + (blockIdx.x * TR_BLOCK + threadIdx.x);
+#define WF_PUSH(v) do { const uint32_t v_ = (v); if ((uint32_t)sp < lds_depth) stack[sp * TR_BLOCK] = v_; else ovf[(size_t)((uint32_t)sp - lds_depth) * ovf_stride] = v_; ++sp; } while (0)
+#define WF_POP() (--sp, (uint32_t)sp < lds_depth ? stack[sp * TR_BLOCK] : ovf[(size_t)((uint32_t)sp - lds_depth) * ovf_stride])
     const uint32_t n = qctl[STAGE];
     uint32_t* __restrict__ cursor = qctl + 3 + STAGE;
     const uint32_t lane = threadIdx.x & 63u;
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
                 const bool hb = two && bbox_hit(blo, bhi, o, inv_dir, nx, ny, nz, min_t, max_t);
                 if (two) WF_COUNT(c_expand); else WF_COUNT(c_visit);
                 if (ha || hb) {
-                    if (ha && hb) { stack[sp * TR_BLOCK] = node_b; ++sp; }
+                    if (ha && hb) WF_PUSH(node_b);
                     const uint32_t cur = ha ? node_a : node_b;
                     cur_offset = __float_as_uint(ha ? ahi.z : bhi.z);
                     const uint32_t meta = __float_as_uint(ha ? ahi.w : bhi.w);
@@ -258,8 +268,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
                 }
             } else {   // BVH<Instance> leaf (<= 4 instances): queue them so that pops come in leaf order
                 for (uint32_t k = cur_count; k > 0u; --k) {
-                    stack[sp * TR_BLOCK] = STK_INSTANCE | (cur_offset + k - 1u);
-                    ++sp;
+                    WF_PUSH(STK_INSTANCE | (cur_offset + k - 1u));
                 }
             }
             mode = TM_POP;
@@ -267,8 +276,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
         if (active && mode == TM_POP && !finished) {
             bool have_node = false;
             while (sp > 0) {
-                --sp;
-                uint32_t e = stack[sp * TR_BLOCK];
+                uint32_t e = WF_POP();
                 uint32_t kind = e & STK_KIND_MASK;
                 if (kind == STK_NODE) { node_a = e; node_b = WF_NO_NODE; have_node = true; break; }
                 if (kind == STK_EXIT_MESH) {   // back to world space and the top-level tree
@@ -297,8 +305,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
                 uint32_t gt = in->geom_type;
                 if (gt == TRAY_GEOM_MESH) {
                     const TrayMesh m = sc.meshes[in->mesh_id];
-                    stack[sp * TR_BLOCK] = STK_EXIT_MESH;
-                    ++sp;
+                    WF_PUSH(STK_EXIT_MESH);
                     in_mesh = true;
                     cur_inst = i;
                     tree = sc.mesh_nodes + m.node_offset;
@@ -355,6 +362,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_dyn(const DevScene scv, W
     if (lane == 0u && n_rays) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].trav[STAGE * 6 + 5], (unsigned long long)n_rays);
 #endif
 #undef WF_COUNT
+#undef WF_PUSH
+#undef WF_POP
 }
 
 // Stage A shading: vertex_begin for the slots whose ray hit, end of the sample for those that missed
