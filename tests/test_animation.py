@@ -191,3 +191,61 @@ def test_tr15_stand_in_has_the_structure_of_tr15(tmp_path, built):
     assert np.isfinite(img).all() and st.vertices > 3 * st.samples
     full = sum(2 * gu * gv for models in scenes._TR15_MODELS.values() for _, gu, gv in models)
     assert 3.0e6 < full < 3.3e6
+
+
+def test_moving_point_light_integrates_over_the_shutter(tmp_path, built):
+    """A Lambertian floor under a point light that slides along x while the shutter is open (linear B-spline, shutter_size 1):
+    the pixel under the camera sees rho/pi * I * mean over t of cos / r^2 with t uniform over the shutter interval -- pins the time
+    sampling (camera.rs:155), the per-ray spline evaluation (emitter.rs:168) and the keyed emission (animated_color.rs:52-78)."""
+    d = scenes.cornell_box(8, 8, 4)
+    d["film"].update({"frames": 1, "scene_time": 1.0})
+    d["integrator"] = {"type": "pathtracer", "min_depth": 0, "max_depth": 0}
+    d["materials"] = [{"type": "matte", "name": "m", "diffuse": [0.5, 0.5, 0.5], "roughness": 0.0}]
+    tr = lambda x: {"transform": [{"type": "translate", "translation": [x, 4.0, 0.0]}]}
+    d["objects"] = [
+        {"name": "floor", "type": "receiver", "material": "m", "geometry": {"type": "rectangle", "width": 400, "height": 400},
+         "transform": [{"type": "rotate_x", "rotation": -90}]},
+        {"name": "spark", "type": "emitter", "emitter": "point",
+         "emission": [{"time": 0.0, "color": [1, 1, 1, 10]}, {"time": 1.0, "color": [1, 1, 1, 30]}],   # stays below the per-sample clamp (Q3)
+         "keyframes": {"control_points": [tr(-6.0), tr(6.0)], "knots": [0, 0, 1, 1], "degree": 1}},
+    ]
+    d["camera"] = {"fov": 1.0, "shutter_size": 1.0, "transform": [{"type": "rotate_x", "rotation": 90}, {"type": "translate", "translation": [0, 5, 0]}]}
+    scenes.write_assets(str(tmp_path))
+    scene, *_ = T.Scene.load_string(json.dumps(d), str(tmp_path))
+    flat = scene.flatten(0)
+    fs = flat.contents
+    assert (fs.camera.shutter_open, fs.camera.shutter_close) == (0.0, 1.0) and fs.animated == 1
+    n = 8192
+    px = np.full(n, 4, np.uint32); py = np.full(n, 4, np.uint32); si = np.arange(n, dtype=np.uint32)
+    out = O.sample_radiance(flat, px, py, si, n, seed=3)
+    assert (out[:, 5] == 1).all()
+    t = (np.arange(200000) + 0.5) / 200000
+    x = -6.0 + 12.0 * t
+    r2 = x * x + 16.0
+    intensity = 10.0 + 20.0 * t
+    expect = 0.5 / np.pi * np.mean(intensity * (4.0 / np.sqrt(r2)) / r2)
+    got = out[:, 0].mean()
+    assert abs(got - expect) < 0.01 * expect, (got, expect)   # (0,2)-sequence time samples: far below 1 % at 8192 samples
+
+
+def test_moving_emitter_covers_a_ray_for_the_right_share_of_the_shutter(tmp_path, built):
+    """A unit sphere emitter crosses the (almost parallel) camera rays of one pixel at constant speed: it covers them for 1/3 of
+    the open shutter, so the pixel averages emission / 3 (Emitter::intersect with transform(ray.time), emitter.rs:118-137)."""
+    d = scenes.cornell_box(8, 8, 4)
+    d["film"].update({"frames": 1, "scene_time": 1.0})
+    d["integrator"] = {"type": "pathtracer", "min_depth": 0, "max_depth": 0}
+    d["materials"] = [{"type": "matte", "name": "m", "diffuse": [0.0, 0.0, 0.0], "roughness": 0.0}]
+    tr = lambda x: {"transform": [{"type": "translate", "translation": [x, 2.0, 0.0]}]}
+    d["objects"] = [{"name": "ball", "type": "emitter", "emitter": "area", "material": "m", "emission": [1, 1, 1, 0.75],
+                     "geometry": {"type": "sphere", "radius": 1.0},
+                     "keyframes": {"control_points": [tr(-3.0), tr(3.0)], "knots": [0, 0, 1, 1], "degree": 1}}]
+    d["camera"] = {"fov": 0.5, "shutter_size": 1.0, "transform": [{"type": "rotate_x", "rotation": 90}, {"type": "translate", "translation": [0, 50, 0]}]}
+    scenes.write_assets(str(tmp_path))
+    scene, *_ = T.Scene.load_string(json.dumps(d), str(tmp_path))
+    flat = scene.flatten(0)
+    n = 8192
+    px = np.full(n, 4, np.uint32); py = np.full(n, 4, np.uint32); si = np.arange(n, dtype=np.uint32)
+    out = O.sample_radiance(flat, px, py, si, n, seed=5)
+    hit = out[:, 5] == 1
+    assert abs(hit.mean() - 1.0 / 3.0) < 0.01
+    assert np.allclose(out[hit, 0], 0.75) and (out[~hit, 0] == 0).all()
