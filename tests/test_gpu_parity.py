@@ -13,6 +13,7 @@ import tray_rust_amd as T
 from tray_rust_amd import _lib as L
 from tray_rust_amd import scenes
 import _oracle as O
+import _scenes_extra as X
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -446,3 +447,19 @@ def test_gpu_matches_the_golden_of_the_moving_and_mesh_scenes(name, tmp_path):
     # test_moving_scene_image_rmse); the static mesh scene holds the 1e-4 bar
     assert rmse(gpu, g["rgbw"]) < (3e-4 if name == "moving_box" else 1e-4)
     assert abs(int(hip.last_timing.vertices) - int(g["vertices"])) <= 5
+
+
+@pytest.mark.parametrize("build", [X.sliding_point_light, X.crossing_emitter])
+def test_closed_form_moving_scenes_per_sample(build, tmp_path):
+    """The two scenes tests/test_animation.py checks against closed forms: per-sample radiance of the kernels vs the oracle
+    (moving point light with keyed emission; moving area emitter seen directly)."""
+    scene, *_ = load(build(), tmp_path)
+    flat = scene.flatten(0)
+    n = 8192
+    px = np.full(n, 4, np.uint32); py = np.full(n, 4, np.uint32); si = np.arange(n, dtype=np.uint32)
+    a = O.sample_radiance(flat, px, py, si, n, seed=3)
+    b = gpu_radiance(scene, px, py, si, n, 3)
+    assert (a[:, 5] == b[:, 5]).mean() > 0.999
+    same = a[:, 5] == b[:, 5]
+    assert np.abs(a[same, :3] - b[same, :3]).max() < 2e-5
+    assert abs(a[:, 0].mean() - b[:, 0].mean()) < 1e-3 * max(a[:, 0].mean(), 1e-6)
