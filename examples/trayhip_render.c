@@ -1,0 +1,53 @@
+/* Minimal C host for libtrayhip.so: what `tray_rust <scene> -o out.ppm` does between Scene::load_file and the image
+ * write (src/main.rs:56-109), through the C ABI only -- the calls the Rust `exec::Hip` of INTEGRATION.md makes.
+ *
+ *   cc -O2 -Iinclude examples/trayhip_render.c -Ltray_rust_amd -ltrayhip -Wl,-rpath,$PWD/tray_rust_amd -o trayhip_render
+ *   ./trayhip_render scene.json out.ppm [frame] [seed]
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include "trayhip.h"
+
+static int fail(const char* what, int rc) {
+    fprintf(stderr, "%s failed (%d): %s\n", what, rc, tray_last_error());
+    return 1;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) { fprintf(stderr, "usage: %s scene.json out.ppm [frame] [seed]\n", argv[0]); return 2; }
+    const uint32_t frame = argc > 3 ? (uint32_t)atoi(argv[3]) : 0u;
+    const uint64_t seed = argc > 4 ? (uint64_t)atoll(argv[4]) : 1u;
+    TrayHostScene* host = NULL;
+    int rc = tray_scene_load_file(argv[1], &host);
+    if (rc != TRAY_OK) return fail("tray_scene_load_file", rc);
+    TraySceneInfo info;
+    rc = tray_host_scene_info(host, &info);
+    if (rc != TRAY_OK) return fail("tray_host_scene_info", rc);
+    const TrayFlatScene* flat = NULL;
+    rc = tray_host_scene_flatten(host, frame, &flat);          /* Scene::update_frame */
+    if (rc != TRAY_OK) return fail("tray_host_scene_flatten", rc);
+    rc = tray_init(0);
+    if (rc != TRAY_OK) return fail("tray_init", rc);            /* no GPU, no render: there is no CPU fallback */
+    TrayDeviceScene* dev = NULL;
+    rc = tray_scene_create(flat, &dev);
+    if (rc != TRAY_OK) return fail("tray_scene_create", rc);
+    const size_t n = (size_t)info.width * info.height;
+    float* rgbw = (float*)calloc(n * 4, sizeof(float));
+    unsigned char* rgb8 = (unsigned char*)malloc(n * 3);
+    rc = tray_render_tiles(dev, 0, 0, tray_round_spp(info.spp), seed, rgbw);   /* Exec::render over the whole block queue */
+    if (rc != TRAY_OK) return fail("tray_render_tiles", rc);
+    TrayKernelTiming tim;
+    if (tray_last_timing(dev, &tim) == TRAY_OK)
+        printf("Frame %u: rendering took %.4fs (%.1f Msamples/s)\n", frame, tim.render_ms * 1e-3, (double)tim.samples / tim.render_ms * 1e-3);
+    rc = tray_resolve_srgb8(rgbw, info.width, info.height, rgb8);              /* RenderTarget::get_render */
+    if (rc != TRAY_OK) return fail("tray_resolve_srgb8", rc);
+    FILE* f = fopen(argv[2], "wb");
+    if (!f) { perror(argv[2]); return 1; }
+    fprintf(f, "P6\n%u %u\n255\n", info.width, info.height);
+    fwrite(rgb8, 3, n, f);
+    fclose(f);
+    tray_scene_destroy(dev);
+    tray_host_scene_free(host);
+    free(rgbw); free(rgb8);
+    return 0;
+}

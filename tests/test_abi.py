@@ -78,3 +78,43 @@ def test_product_does_not_depend_on_the_oracle(built):
             if f.endswith((".py", ".hpp", ".h", ".cpp", ".hip")):
                 text = open(os.path.join(root, f), errors="replace").read()
                 assert "liboracle" not in text and "oracle/" not in text.replace("the oracle/", ""), os.path.join(root, f)
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(tmp_path), "trayhip_render")
+    libdir = os.path.join(root, "tray_rust_amd")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "trayhip_render.c"),
+                    "-L" + libdir, "-ltrayhip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    return exe
+
+
+def test_plain_c_host_compiles_and_fails_loudly_without_a_gpu(assets, tmp_path):
+    """include/trayhip.h is a C header; examples/trayhip_render.c drives the whole boundary from C. Without a GPU the render must
+    stop with the library's error, not fall back to anything."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe, os.path.join(assets, "cornell_box.json"), os.path.join(str(tmp_path), "o.ppm")], capture_output=True, text=True)
+    assert r.returncode == 1 and "tray_init failed" in r.stderr
+    assert not os.path.exists(os.path.join(str(tmp_path), "o.ppm"))
+
+
+@pytest.mark.gpu
+def test_plain_c_host_renders(tmp_path):
+    import subprocess
+    import numpy as np
+    from tray_rust_amd import scenes
+    exe = _build_c_example(tmp_path)
+    scenes.write_assets(str(tmp_path), cornell=(64, 48, 16))
+    out = os.path.join(str(tmp_path), "o.ppm")
+    r = subprocess.run([exe, os.path.join(str(tmp_path), "cornell_box.json"), out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "rendering took" in r.stdout
+    data = open(out, "rb").read()
+    assert data.startswith(b"P6\n64 48\n255\n")
+    px = np.frombuffer(data[len(b"P6\n64 48\n255\n"):], np.uint8)
+    assert px.size == 64 * 48 * 3 and px.max() > 100
