@@ -5,6 +5,7 @@
 // ties, but matching the reference's tree keeps even those identical.
 #pragma once
 #include <algorithm>
+#include <future>
 #include <memory>
 #include <stdexcept>
 #include <vector>
@@ -57,12 +58,14 @@ inline size_t partition_ref(GeomInfo* a, size_t n, Pred pred) {
     return split;
 }
 
-inline std::unique_ptr<BuildNode> make_leaf(GeomInfo* info, size_t n, std::vector<uint32_t>& ordered, const BBox& bounds) {
+// A leaf covers a contiguous range of the (partitioned in place) info array, and the reference appends leaves to
+// ordered_geom in depth-first order, i.e. in the order of those ranges: geom_offset is the range's start, ordered_geom
+// is the final info order. That makes sibling subtrees independent, so large ones are built on separate threads.
+inline std::unique_ptr<BuildNode> make_leaf(GeomInfo* info, size_t n, const GeomInfo* base, const BBox& bounds) {
     auto node = std::make_unique<BuildNode>();
     node->bounds = bounds;
-    node->geom_offset = (uint32_t)ordered.size();
+    node->geom_offset = (uint32_t)(info - base);
     node->ngeom = (uint32_t)n;
-    for (size_t i = 0; i < n; ++i) ordered.push_back(info[i].idx);
     return node;
 }
 
@@ -75,21 +78,33 @@ inline std::unique_ptr<BuildNode> make_interior(std::unique_ptr<BuildNode> l, st
     return node;
 }
 
-inline std::unique_ptr<BuildNode> build(GeomInfo* info, size_t ngeom, std::vector<uint32_t>& ordered,
-                                        size_t& total_nodes, size_t max_geom) {
-    ++total_nodes;
+inline std::unique_ptr<BuildNode> build(GeomInfo* info, size_t ngeom, const GeomInfo* base, size_t max_geom, int par_levels);
+
+// build both halves of a split; the left one on its own thread while the range is large and levels remain
+inline std::unique_ptr<BuildNode> build_children(GeomInfo* info, size_t ngeom, size_t mid, const GeomInfo* base, size_t max_geom, int par_levels, int axis) {
+    std::unique_ptr<BuildNode> l, r;
+    if (par_levels > 0 && ngeom >= 65536) {
+        auto fl = std::async(std::launch::async, [=] { return build(info, mid, base, max_geom, par_levels - 1); });
+        r = build(info + mid, ngeom - mid, base, max_geom, par_levels - 1);
+        l = fl.get();
+    } else {
+        l = build(info, mid, base, max_geom, 0);
+        r = build(info + mid, ngeom - mid, base, max_geom, 0);
+    }
+    return make_interior(std::move(l), std::move(r), axis);
+}
+
+inline std::unique_ptr<BuildNode> build(GeomInfo* info, size_t ngeom, const GeomInfo* base, size_t max_geom, int par_levels) {
     BBox bounds;
     for (size_t i = 0; i < ngeom; ++i) bounds = bounds.box_union(info[i].bounds);
-    if (ngeom == 1) return make_leaf(info, ngeom, ordered, bounds);
+    if (ngeom == 1) return make_leaf(info, ngeom, base, bounds);
     BBox centroids;
     for (size_t i = 0; i < ngeom; ++i) centroids = centroids.point_union(info[i].center);
     int axis = centroids.max_extent();
     size_t mid = ngeom / 2;
     if (std::fabs(centroids.mx[axis] - centroids.mn[axis]) < kEps) {   // bvh.rs:155-165
-        if (ngeom < max_geom) return make_leaf(info, ngeom, ordered, bounds);
-        auto l = build(info, mid, ordered, total_nodes, max_geom);
-        auto r = build(info + mid, ngeom - mid, ordered, total_nodes, max_geom);
-        return make_interior(std::move(l), std::move(r), axis);
+        if (ngeom < max_geom) return make_leaf(info, ngeom, base, bounds);
+        return build_children(info, ngeom, mid, base, max_geom, par_levels, axis);
     }
     if (ngeom < 5) {
         // slice::sort_by is a stable merge sort
@@ -124,13 +139,11 @@ inline std::unique_ptr<BuildNode> build(GeomInfo* info, size_t ngeom, std::vecto
         if (ngeom > max_geom || min_cost < (float)ngeom) {
             mid = partition_ref(info, ngeom, [&](const GeomInfo& g) { return bucket_of(g) <= min_bucket; });
         } else {
-            return make_leaf(info, ngeom, ordered, bounds);
+            return make_leaf(info, ngeom, base, bounds);
         }
     }
     if (mid == 0 || mid == ngeom) throw std::runtime_error("BVH build: degenerate split (reference asserts mid != 0 && mid != len)");
-    auto l = build(info, mid, ordered, total_nodes, max_geom);
-    auto r = build(info + mid, ngeom - mid, ordered, total_nodes, max_geom);
-    return make_interior(std::move(l), std::move(r), axis);
+    return build_children(info, ngeom, mid, base, max_geom, par_levels, axis);
 }
 
 inline uint32_t flatten(const BuildNode& n, std::vector<TrayBvhNode>& out) {
@@ -160,10 +173,10 @@ inline BvhBuild build_bvh(const std::vector<BBox>& bounds, size_t max_geom) {
     std::vector<detail::GeomInfo> info(bounds.size());
     for (size_t i = 0; i < bounds.size(); ++i) info[i] = {(uint32_t)i, bounds[i].center(), bounds[i]};
     BvhBuild out;
-    out.ordered.reserve(bounds.size());
-    size_t total = 0;
-    auto root = detail::build(info.data(), info.size(), out.ordered, total, max_geom);
-    out.nodes.reserve(total);
+    auto root = detail::build(info.data(), info.size(), info.data(), max_geom, 4);
+    out.ordered.resize(info.size());
+    for (size_t i = 0; i < info.size(); ++i) out.ordered[i] = info[i].idx;
+    out.nodes.reserve(2 * info.size());
     detail::flatten(*root, out.nodes);
     return out;
 }

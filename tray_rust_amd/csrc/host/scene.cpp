@@ -2,6 +2,8 @@
 // toolchain exists in the build image). It keeps the reference's JSON schema, turns
 // the reference's panics into error codes, and lowers the loaded scene to the TrayFlatScene POD that
 // both the HIP tile worker and the CPU oracle consume.
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -10,6 +12,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/trayhip.h"
@@ -108,6 +111,7 @@ struct ColorKey { float c[4]; float time; };
 
 struct HostMesh {
     std::string key;   // file + '\n' + model
+    std::string file, model;   // build_meshes() fills bvh / verts / attrs after the whole scene is parsed
     BvhBuild bvh;
     std::vector<TrayTriVerts> verts;   // leaf order
     std::vector<TrayTriAttrs> attrs;
@@ -643,23 +647,28 @@ static uint32_t get_mesh(TrayHostScene& s, const std::string& file, const std::s
     std::string key = file + "\n" + model;
     for (size_t i = 0; i < s.meshes.size(); ++i)
         if (s.meshes[i].key == key) return (uint32_t)i;
-    std::vector<ObjModel> models = parse_obj(file);
+    HostMesh hm;
+    hm.key = key; hm.file = file; hm.model = model;
+    s.meshes.push_back(std::move(hm));
+    return (uint32_t)s.meshes.size() - 1;
+}
+
+// Mesh::load_obj + BVH::unanimated for one (file, model) request (mesh.rs:44-78)
+static void build_mesh(HostMesh& hm, const std::vector<ObjModel>& models) {
     const ObjModel* found = nullptr;
     for (auto& m : models) {
         if (m.normals.empty() || m.texcoords.empty()) continue;   // mesh.rs:57-61: skipped
-        if (m.name == model) { found = &m; break; }
+        if (m.name == hm.model) { found = &m; break; }
     }
-    if (!found) fail(TRAY_E_INVALID, "Requested model '" + model + "' was not found in \"" + file + "\"");
+    if (!found) fail(TRAY_E_INVALID, "Requested model '" + hm.model + "' was not found in \"" + hm.file + "\"");
     const ObjModel& m = *found;
     size_t ntri = m.indices.size() / 3, nvert = m.positions.size() / 3;
     if (m.normals.size() / 3 != nvert || m.texcoords.size() / 2 != nvert)
-        fail(TRAY_E_PARSE, "model '" + model + "' mixes vertices with and without normals/texcoords");
+        fail(TRAY_E_PARSE, "model '" + hm.model + "' mixes vertices with and without normals/texcoords");
     std::vector<BBox> bounds(ntri);
     auto P = [&](uint32_t i) { return V3(m.positions[3 * i], m.positions[3 * i + 1], m.positions[3 * i + 2]); };
     for (size_t t = 0; t < ntri; ++t)   // Triangle::bounds, mesh.rs:129-133
         bounds[t] = BBox(P(m.indices[3 * t]), P(m.indices[3 * t])).point_union(P(m.indices[3 * t + 1])).point_union(P(m.indices[3 * t + 2]));
-    HostMesh hm;
-    hm.key = key;
     hm.bvh = build_bvh(bounds, 16);   // BVH::unanimated(16, triangles), mesh.rs:44
     hm.verts.resize(ntri);
     hm.attrs.resize(ntri);
@@ -679,8 +688,40 @@ static uint32_t get_mesh(TrayHostScene& s, const std::string& file, const std::s
             ta.ta[k] = m.texcoords[2 * ia + k]; ta.tb[k] = m.texcoords[2 * ib + k]; ta.tc[k] = m.texcoords[2 * ic + k];
         }
     }
-    s.meshes.push_back(std::move(hm));
-    return (uint32_t)s.meshes.size() - 1;
+}
+
+// Every OBJ file is parsed once (the reference caches per file too, scene.rs:604-625) and the meshes are built on all host
+// cores: the results do not depend on the schedule, each mesh is built from its own model alone.
+static void build_meshes(TrayHostScene& s) {
+    std::vector<std::string> files;
+    for (auto& hm : s.meshes)
+        if (std::find(files.begin(), files.end(), hm.file) == files.end()) files.push_back(hm.file);
+    std::vector<std::vector<ObjModel>> parsed(files.size());
+    struct Err { int code = TRAY_OK; std::string msg; };
+    std::vector<Err> file_err(files.size()), mesh_err(s.meshes.size());
+    auto run = [](size_t n, auto&& job) {
+        unsigned hw = std::thread::hardware_concurrency();
+        size_t workers = std::max<size_t>(1, std::min<size_t>(n, hw ? hw : 1));
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        for (size_t w = 0; w < workers; ++w)
+            pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) job(i); });
+        for (auto& t : pool) t.join();
+    };
+    run(files.size(), [&](size_t i) {
+        try { parsed[i] = parse_obj(files[i]); }
+        catch (const LoadError& e) { file_err[i].code = e.code; file_err[i].msg = e.what(); }
+        catch (const std::exception& e) { file_err[i].code = TRAY_E_PARSE; file_err[i].msg = e.what(); }
+    });
+    run(s.meshes.size(), [&](size_t i) {
+        size_t fi = (size_t)(std::find(files.begin(), files.end(), s.meshes[i].file) - files.begin());
+        if (file_err[fi].code != TRAY_OK) { mesh_err[i] = file_err[fi]; return; }
+        try { build_mesh(s.meshes[i], parsed[fi]); }
+        catch (const LoadError& e) { mesh_err[i].code = e.code; mesh_err[i].msg = e.what(); }
+        catch (const std::exception& e) { mesh_err[i].code = TRAY_E_PARSE; mesh_err[i].msg = e.what(); }
+    });
+    for (auto& e : mesh_err)   // the first failing request in scene order, as a sequential load would report it
+        if (e.code != TRAY_OK) fail(e.code, e.msg);
 }
 
 // ------------------------------------------------------------------ objects (scene.rs:515-654)
@@ -801,6 +842,7 @@ static TrayHostScene* load_scene(const std::string& text, const std::string& bas
     }
     load_materials(*s, need(data, "materials", "An array of materials is required"), base);
     load_objects(*s, need(data, "objects", "The scene must specify a list of objects"), base, s->instances);
+    build_meshes(*s);
     if (s->instances.empty()) fail(TRAY_E_INVALID, "Aborting: the scene does not have any objects!");
     return s.release();
 }
