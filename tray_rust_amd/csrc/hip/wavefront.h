@@ -511,10 +511,10 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
     s_table[tid] = sc.filter_table[tid];
     if (tid < TRAY_FILTER_TABLE_SIZE) { s_tx[tid] = sc.filter_x[tid]; s_ty[tid] = sc.filter_y[tid]; }
     for (uint32_t k = tid; k < ROWBIN_SIZE; k += TR_BLOCK) s_bins[k] = 0.0f;
+    uint32_t flags = pu(pool, F_FLAGS, i);   // issued before the barrier: this kernel is a chain of dependent loads (95 % of its wave cycles wait)
     __syncthreads();
     uint32_t tile_idx = s_tile;
     if (tile_idx == WF_TILE_IDLE) return;
-    uint32_t flags = pu(pool, F_FLAGS, i);
     const bool film_rows = sc.film_rows != 0u;
     if (tile_idx != WF_TILE_NEED) {
         const uint2 tile = tiles[(tile_idx / chunk) * chunk_stride * chunk + (tile_idx % chunk)];
