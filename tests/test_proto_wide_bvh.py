@@ -1,0 +1,45 @@
+"""Design prototype for the next device traversal (oracle/proto_wide_bvh.hpp, CPU only): a 4-wide collapse of the reference's
+binary BVH<Triangle> with a pop-time re-test returns the SAME hit records as the binary traversal, with fewer dependent node
+fetches. Nothing in the product uses it yet (Next / C5)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import tray_rust_amd as T
+from tray_rust_amd import scenes
+import _oracle as O
+
+
+def both(flat, rays):
+    o = O.oracle()
+    o.oracle_proto_wide_bvh.restype = C.c_int
+    o.oracle_proto_wide_bvh.argtypes = [C.POINTER(T._lib.TrayFlatScene), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    a = np.zeros(len(rays), dtype=O.HIT_DTYPE); b = np.zeros(len(rays), dtype=O.HIT_DTYPE)
+    cnt = np.zeros(4, np.uint64)
+    assert o.oracle_proto_wide_bvh(flat, len(rays), rays.ctypes.data, a.ctypes.data, b.ctypes.data, cnt.ctypes.data) == 0
+    return a, b, cnt
+
+
+@pytest.mark.parametrize("grid", [24, 120])
+def test_wide_collapse_returns_the_same_hits(grid, tmp_path, built):
+    p, _ = scenes.write_dragon_assets(str(tmp_path), film=(160, 120, 4), grid=grid, extent=1.0)
+    scene, *_ = T.Scene.load_file(p)
+    flat = scene.flatten(0)
+    rng = np.random.default_rng(grid)
+    rays = O.camera_rays(flat, rng.uniform(0, [160, 120], (40000, 2)))
+    n = 40000   # rays from inside the box towards the mesh: deep traversals, grazing hits, shadow-like segments
+    o = rng.uniform([-14, 1, -18], [14, 23, 19], (n, 3)); tgt = rng.normal([8.5, 3.7, 1.5], 4.0, (n, 3)); d = tgt - o
+    seg = rng.uniform(0, 1, n) < 0.5
+    d[~seg] /= np.linalg.norm(d[~seg], axis=1, keepdims=True)
+    inner = np.concatenate([o, d, np.full((n, 1), 0.001), np.where(seg, 0.999, np.inf)[:, None], np.zeros((n, 1))], axis=1).astype(np.float32)
+    rays = np.concatenate([rays, inner])
+    a, b, cnt = both(flat, rays)
+    ref = O.intersect(flat, rays)
+    assert a.tobytes() == ref.tobytes()            # the counting binary traversal is the oracle's
+    assert a.tobytes() == b.tobytes()              # 4-wide collapse: identical records, bit for bit
+    assert (a["inst"] == 6).mean() > 0.05
+    assert cnt[2] == cnt[3]                        # the same leaves are visited
+    ratio = float(cnt[1]) / float(cnt[0])
+    print(f"grid {grid}: dependent fetches per ray binary {cnt[0] / len(rays):.2f} wide {cnt[1] / len(rays):.2f} (x{ratio:.2f})")
+    assert ratio < 0.75
