@@ -63,6 +63,8 @@ struct DevScene {
     uint32_t n_instances, n_lights, min_depth, max_depth;
     uint32_t width, height, frame, film_rows;   // film_rows: 1 = row-binned film (separable, filter_h == 2)
     uint32_t coop_offset;   // word offset of the cooperative leaf test's LDS area behind the traversal stacks (0 = none)
+    const float* __restrict__ wide_nodes;          // 4-wide collapse of every BVH<Triangle>, 32 floats per node (wavefront_wide.h); may be null
+    const uint32_t* __restrict__ mesh_wide_root;   // per mesh: index of its root's wide node
     float filter_w, filter_h, inv_w, inv_h;
     int32_t fpw, fph;
     TrayCamera camera;

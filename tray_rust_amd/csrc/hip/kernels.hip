@@ -199,6 +199,7 @@ __device__ __forceinline__ void film_splat_rows_global(const DevScene& sc, float
 }
 
 #include "wavefront.h"
+#include "wavefront_wide.h"
 
 // Work item w (0 <= w < n_work) maps to queue entry (w / chunk) * chunk_stride * chunk + (w % chunk):
 // contiguous ranges use chunk_stride = 1; multi-GPU sharding interleaves chunks round-robin.
@@ -476,6 +477,8 @@ struct TrayDeviceScene {
     uint32_t trace_lds_depth = 0, trace_lds_bytes = 0;   // LDS part of the dynamic-fetch kernel's stacks; deeper entries go to d_stack_overflow
     uint32_t* d_stack_overflow = nullptr;
     bool wf_dynamic = true;           // TRAYHIP_WF_TRACE=slot: one thread per pool slot instead (no compaction)
+    bool wf_wide = false;             // TRAYHIP_WF_WIDE=1: k_wf_trace_wide (4-wide BVH<Triangle>, wavefront_wide.h)
+    uint32_t wide_lds_words = 0, wide_lds_bytes = 0;
 };
 
 static thread_local int g_device = 0;
@@ -502,6 +505,40 @@ static int upload(TrayDeviceScene* s, const T* host, size_t n, const T** out) {
     return TRAY_OK;
 }
 
+// 4-wide collapse of one BVH<Triangle> (wavefront_wide.h): the wide node of a binary interior node holds its grandchildren, a
+// child that is a leaf stays one slot; slots in binary order [L.first, L.second, R.first, R.second]. 32 floats per node:
+// bminx[4] bminy[4] bminz[4] bmaxx[4] bmaxy[4] bmaxz[4] ref[4] meta pad[3]. ref: 0xffffffff empty, bit 31 = leaf
+// (count << 24 | first triangle of the mesh), else the index of the child's wide node.
+static uint32_t build_wide_nodes(const TrayBvhNode* tree, uint32_t n, std::vector<float>& out) {
+    const uint32_t self = (uint32_t)(out.size() / 32);
+    out.resize(out.size() + 32, 0.0f);
+    const TrayBvhNode& N = tree[n];
+    const uint32_t kids[2] = {n + 1u, N.offset};
+    uint32_t axes[2] = {0u, 0u}, slot_node[4] = {0u, 0u, 0u, 0u};
+    bool used[4] = {false, false, false, false};
+    for (int c = 0; c < 2; ++c) {
+        const TrayBvhNode& K = tree[kids[c]];
+        if (K.count > 0) { slot_node[2 * c] = kids[c]; used[2 * c] = true; }
+        else { axes[c] = K.axis; slot_node[2 * c] = kids[c] + 1u; slot_node[2 * c + 1] = K.offset; used[2 * c] = used[2 * c + 1] = true; }
+    }
+    for (int sidx = 0; sidx < 4; ++sidx) {
+        uint32_t ref = 0xffffffffu;
+        float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
+        if (used[sidx]) {
+            const TrayBvhNode& S = tree[slot_node[sidx]];
+            for (int k = 0; k < 3; ++k) { bmin[k] = S.bmin[k]; bmax[k] = S.bmax[k]; }
+            if (S.count > 0) ref = 0x80000000u | ((uint32_t)S.count << 24) | S.offset;
+            else ref = build_wide_nodes(tree, slot_node[sidx], out);
+        }
+        float* w = out.data() + (size_t)self * 32;   // (re-derive: the vector may have grown)
+        for (int k = 0; k < 3; ++k) { w[4 * k + sidx] = bmin[k]; w[12 + 4 * k + sidx] = bmax[k]; }
+        std::memcpy(w + 24 + sidx, &ref, sizeof ref);
+    }
+    const uint32_t meta = (uint32_t)N.axis | (axes[0] << 2) | (axes[1] << 4);
+    std::memcpy(out.data() + (size_t)self * 32 + 28, &meta, sizeof meta);
+    return self;
+}
+
 #ifndef WF_SLOTS
 #define WF_SLOTS (8u << 20)   // path pool slots (2.2 GB of pool at 66 fields): measured 36.6 / 45.2 / 53.1 Msamples/s at 2 / 4 / 8 M on the C5
 #endif                        // stand-in: every stage kernel ends with the tail of its slowest rays, fewer and larger rounds pay it less often
@@ -516,11 +553,14 @@ static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 tgrid, dim3 block, hipS
         hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
                            spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, qa, qr, qctl);
         hipLaunchKernelGGL(k_wf_regen<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
-        hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
+        if (s->wf_wide) hipLaunchKernelGGL((k_wf_trace_wide<0, ANIM>), tgrid, block, s->wide_lds_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats, s->wide_lds_words, s->d_stack_overflow);
+        else hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
         hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, qb, qctl);
-        hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
+        if (s->wf_wide) hipLaunchKernelGGL((k_wf_trace_wide<1, ANIM>), tgrid, block, s->wide_lds_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats, s->wide_lds_words, s->d_stack_overflow);
+        else hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
         hipLaunchKernelGGL((k_wf_query<ANIM, FEAT>), grid, block, 0, stream, s->dev, s->pool, n_active, qc, qctl);
-        hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
+        if (s->wf_wide) hipLaunchKernelGGL((k_wf_trace_wide<2, ANIM>), tgrid, block, s->wide_lds_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats, s->wide_lds_words, s->d_stack_overflow);
+        else hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
     } else {   // one thread per pool slot in every stage; only the regeneration is compacted
         uint32_t* const none = nullptr;
         uint32_t* const qr = qc + s->pool.n_slots + WF_QCTL_WORDS;
@@ -662,6 +702,24 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     UP(color_keys, f->color_keys, f->n_color_keys)
 #undef UP
     s->animated = moving;
+    if (getenv("TRAYHIP_WF_WIDE") && std::string(getenv("TRAYHIP_WF_WIDE")) == "1") {   // 4-wide BVH<Triangle> for the dynamic-fetch traversal
+        std::vector<float> wide;
+        std::vector<uint32_t> roots(f->n_meshes, 0xffffffffu);
+        bool ok = true;
+        for (uint32_t m = 0; m < f->n_meshes && ok; ++m) {
+            const TrayBvhNode* tree = f->mesh_nodes + f->meshes[m].node_offset;
+            if (f->meshes[m].tri_count >= (1u << 24)) ok = false;
+            else if (f->meshes[m].node_count && tree[0].count == 0) roots[m] = build_wide_nodes(tree, 0u, wide);
+        }
+        if (ok && rc == TRAY_OK) {
+            const float* d_wide = nullptr;
+            const uint32_t* d_roots = nullptr;
+            rc = upload(s, wide.data(), wide.size(), &d_wide);
+            if (rc == TRAY_OK) rc = upload(s, roots.data(), roots.size(), &d_roots);
+            d.wide_nodes = d_wide; d.mesh_wide_root = d_roots;
+            s->wf_wide = rc == TRAY_OK;
+        }
+    }
     if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
     s->n_materials = f->n_materials;
     d.n_instances = f->n_instances; d.n_lights = f->n_lights; d.min_depth = f->min_depth; d.max_depth = f->max_depth;
@@ -864,6 +922,13 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             const size_t ovf_entries = (size_t)(full_depth - lds_depth + 1u) * s->n_blocks_trace * TR_BLOCK;
             HIP_CHECK(hipMalloc(&p, ovf_entries * sizeof(uint32_t)));
             s->allocs.push_back(p); s->d_stack_overflow = static_cast<uint32_t*>(p);
+            if (s->wf_wide) {   // two-word entries, up to three pending per wide level: 32 words in LDS, the rest in HBM
+                s->wide_lds_words = 32u;
+                s->wide_lds_bytes = s->wide_lds_words * TR_BLOCK * (uint32_t)sizeof(uint32_t);
+                const size_t words = (size_t)(8u * full_depth + 64u) * s->n_blocks_trace * TR_BLOCK;
+                HIP_CHECK(hipMalloc(&p, words * sizeof(uint32_t)));
+                s->allocs.push_back(p); s->d_stack_overflow = static_cast<uint32_t*>(p);
+            }
             if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] dynamic-fetch traversal: %u of %u stack entries in LDS, %d workgroups per CU\n", lds_depth, full_depth, per_cu);
             const char* e = getenv("TRAYHIP_WF_TRACE");
             s->wf_dynamic = !(e && std::string(e) == "slot");
