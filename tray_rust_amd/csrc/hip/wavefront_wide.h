@@ -4,7 +4,7 @@
 // slot), 128 B = one fetch instead of up to three dependent ones. Exactness: every slot is tested when its wide node is
 // reached, pushed with its entry distance tmin, and re-tested as `tmin < max_t` when popped -- the only clause of
 // BBox::fast_intersect that depends on max_t -- so the accepted candidates and their order are the binary traversal's
-// (checked bit for bit on the CPU by oracle/proto_wide_bvh.hpp + tests/test_proto_wide_bvh.py; 0.36x the dependent fetches).
+// (checked bit for bit on the CPU by the prototype that tests/test_proto_wide_bvh.py exercises; 0.36x the dependent fetches).
 // The top level (BVH<Instance>) keeps the two-children step of k_wf_trace_dyn. Stack entries are two words (ref, tmin).
 #pragma once
 
