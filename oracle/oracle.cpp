@@ -424,12 +424,14 @@ int oracle_intersect(const TrayFlatScene* fs, uint32_t n, const TrayRay* rays, T
 // Design prototype (proto_wide_bvh.hpp): the same rays through binary BVH<Triangle> traversal and through its 4-wide collapse.
 // hits_binary / hits_wide get the full hit records; counters = {binary node+leaf fetches, wide node+leaf fetches, binary leaf
 // visits, wide leaf visits}.
-int oracle_proto_wide_bvh(const TrayFlatScene* fs, uint32_t n, const TrayRay* rays, TrayHit* hits_binary, TrayHit* hits_wide, unsigned long long* counters) {
+int oracle_proto_wide_bvh(const TrayFlatScene* fs, uint32_t n, const TrayRay* rays, TrayHit* hits_binary, TrayHit* hits_wide, unsigned long long* counters,
+                          int qbits) {   // qbits > 0: the wide pass uses slot boxes quantised to that many bits per coordinate
     if (!fs || !rays || !hits_binary || !hits_wide || !counters) return -1;
     std::vector<WideBvh> wide(fs->n_meshes);
     for (uint32_t m = 0; m < fs->n_meshes; ++m) {
         const TrayBvhNode* tree = fs->mesh_nodes + fs->meshes[m].node_offset;
         if (tree[0].count == 0) wide_build(tree, 0, wide[m]);
+        if (qbits > 0) quantise_wide(wide[m], qbits);
     }
     ProtoCounters pc;
     for (int pass = 0; pass < 2; ++pass) {

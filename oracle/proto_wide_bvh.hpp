@@ -27,6 +27,34 @@ struct WideBvh {
 };
 struct ProtoCounters { unsigned long long binary_fetches = 0, wide_fetches = 0, leaf_visits_binary = 0, leaf_visits_wide = 0; };
 
+// Third question: what does it cost to store the slot boxes QUANTISED (qbits per coordinate, relative to the union of the four
+// slots, rounded outwards)? The dequantised box contains the exact one, so no visit is lost; the extra visits (and the rare
+// candidate the exact box would have culled by rounding) are what the test measures. quantise_wide() rewrites a WideBvh in place.
+inline void quantise_wide(WideBvh& wb, int qbits) {
+    const float levels = (float)((1u << qbits) - 1u);
+    for (WideNode& w : wb.nodes) {
+        float lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};
+        for (int s = 0; s < 4; ++s)
+            if (w.kind[s])
+                for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], w.bmin[s][k]); hi[k] = std::fmax(hi[k], w.bmax[s][k]); }
+        for (int k = 0; k < 3; ++k) {
+            float scale = (hi[k] - lo[k]) / levels;
+            if (!(scale > 0.0f)) scale = 1e-30f;
+            for (int s = 0; s < 4; ++s) {
+                if (!w.kind[s]) continue;
+                float qmin = std::floor((w.bmin[s][k] - lo[k]) / scale), qmax = std::ceil((w.bmax[s][k] - lo[k]) / scale);
+                qmin = std::fmax(0.0f, std::fmin(levels, qmin)); qmax = std::fmax(0.0f, std::fmin(levels, qmax));
+                float dmin = lo[k] + qmin * scale, dmax = lo[k] + qmax * scale;
+                while (dmin > w.bmin[s][k] && qmin > 0.0f) { qmin -= 1.0f; dmin = lo[k] + qmin * scale; }   // rounding of the dequantisation itself
+                while (dmax < w.bmax[s][k] && qmax < levels) { qmax += 1.0f; dmax = lo[k] + qmax * scale; }
+                if (dmin > w.bmin[s][k]) dmin = w.bmin[s][k];
+                if (dmax < w.bmax[s][k]) dmax = w.bmax[s][k];
+                w.bmin[s][k] = dmin; w.bmax[s][k] = dmax;
+            }
+        }
+    }
+}
+
 inline uint32_t wide_build(const TrayBvhNode* tree, uint32_t n, WideBvh& out) {
     uint32_t self = (uint32_t)out.nodes.size();
     out.nodes.push_back(WideNode{});

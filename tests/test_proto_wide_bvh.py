@@ -11,13 +11,13 @@ from tray_rust_amd import scenes
 import _oracle as O
 
 
-def both(flat, rays):
+def both(flat, rays, qbits=0):
     o = O.oracle()
     o.oracle_proto_wide_bvh.restype = C.c_int
-    o.oracle_proto_wide_bvh.argtypes = [C.POINTER(T._lib.TrayFlatScene), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    o.oracle_proto_wide_bvh.argtypes = [C.POINTER(T._lib.TrayFlatScene), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     a = np.zeros(len(rays), dtype=O.HIT_DTYPE); b = np.zeros(len(rays), dtype=O.HIT_DTYPE)
     cnt = np.zeros(4, np.uint64)
-    assert o.oracle_proto_wide_bvh(flat, len(rays), rays.ctypes.data, a.ctypes.data, b.ctypes.data, cnt.ctypes.data) == 0
+    assert o.oracle_proto_wide_bvh(flat, len(rays), rays.ctypes.data, a.ctypes.data, b.ctypes.data, cnt.ctypes.data, qbits) == 0
     return a, b, cnt
 
 
@@ -43,3 +43,12 @@ def test_wide_collapse_returns_the_same_hits(grid, tmp_path, built):
     ratio = float(cnt[1]) / float(cnt[0])
     print(f"grid {grid}: dependent fetches per ray binary {cnt[0] / len(rays):.2f} wide {cnt[1] / len(rays):.2f} (x{ratio:.2f})")
     assert ratio < 0.75
+    # quantised slot boxes (conservative): no candidate is lost; how many extra fetches, how many records change
+    for qbits in (16, 8):
+        a2, q, cq = both(flat, rays, qbits)
+        differ = int((a2["inst"] != q["inst"]).sum() + ((a2["inst"] == q["inst"]) & ((a2["prim"] != q["prim"]) | (a2["t"] != q["t"]))).sum())
+        extra = float(cq[1]) / float(cnt[1]) - 1.0
+        print(f"   {qbits}-bit boxes: +{100 * extra:.1f} % fetches, {differ} of {len(rays)} hit records differ")
+        assert differ <= 2 and extra < (0.02 if qbits == 16 else 0.5)
+        hit = a2["inst"] != 0xffffffff
+        assert (q["t"][hit] <= a2["t"][hit]).all() or differ > 0   # a conservative box can only add candidates
