@@ -107,6 +107,10 @@ struct PathSamples {
     float rr(uint32_t bounce) const { return (float)(draw(ks, SD_RR + bounce) >> 8) / (float)(1u << 24); }   // Rng::next_f32
 };
 
+// Schedule analysis hook (tools/simulate_query_compaction.py): which BSDF queries each path vertex needed
+struct VertexLog { std::vector<uint8_t>* sink = nullptr; bool light = false, mis = false; };
+thread_local VertexLog g_vlog;
+
 // Integrator::estimate_direct (integrator/mod.rs:122-169)
 Colorf estimate_direct(const SceneView& sv, Vec3 w_o, Vec3 p, const BSDF& bsdf, const float l2[2], const float b2[2], float b1,
                        uint32_t light_inst, int flags, float time) {
@@ -120,6 +124,7 @@ Colorf estimate_direct(const SceneView& sv, Vec3 w_o, Vec3 p, const BSDF& bsdf, 
         Hit tmp;
         unoccluded = !scene_intersect(sv, r, tmp);
     }
+    g_vlog.light = unoccluded; g_vlog.mis = !delta;
     if (unoccluded) {
         Colorf f = bsdf.eval(w_o, ls.w_i, flags);
         if (!f.is_black()) {
@@ -188,6 +193,8 @@ Colorf path_illumination(const SceneView& sv, const Ray& r, const Hit& hit, cons
         if (li_idx > fs.n_lights - 1) li_idx = fs.n_lights - 1;
         Colorf li = estimate_direct(sv, w_o, current_hit.p, bsdf, l2, b2, b1, fs.lights[li_idx], BX_NON_SPECULAR, ray.time);
         illum = illum + path_throughput * li;
+        if (g_vlog.sink)   // material (5 bits) | light query ran (32) | BSDF-half query ran (64)
+            g_vlog.sink->push_back((uint8_t)((inst.material_id & 31u) | (g_vlog.light ? 32u : 0u) | (g_vlog.mis ? 64u : 0u)));
 
         ps.two_d(2, bounce, p2[0], p2[1]);
         float p1 = ps.one_d(2, bounce);
@@ -418,6 +425,27 @@ int oracle_intersect(const TrayFlatScene* fs, uint32_t n, const TrayRay* rays, T
             o.t = r.max_t; o.inst = 0xffffffffu;
         }
     }
+    return 0;
+}
+
+// Schedule analysis: for n camera samples, the per-vertex query codes (see VertexLog) of each path, up to 16 vertices per sample;
+// counts[i] = number of vertices (0 = the camera ray missed)
+int oracle_path_profile(const TrayFlatScene* fs, uint32_t n, const uint32_t* px, const uint32_t* py, const uint32_t* si, uint32_t spp, uint64_t seed,
+                        uint8_t* codes, uint8_t* counts) {
+    if (!fs || !px || !py || !si || !codes || !counts) return -1;
+    SceneView sv{fs, 0, nullptr};
+    const uint32_t kf = key_frame(seed, fs->frame);
+    std::vector<uint8_t> log;
+    g_vlog.sink = &log;
+    for (uint32_t i = 0; i < n; ++i) {
+        log.clear();
+        float sx, sy;
+        trace_sample(sv, kf, px[i], py[i], si[i], spp, sx, sy);
+        const size_t m = std::min<size_t>(log.size(), 16);
+        counts[i] = (uint8_t)m;
+        std::memcpy(codes + (size_t)i * 16, log.data(), m);
+    }
+    g_vlog.sink = nullptr;
     return 0;
 }
 

@@ -1,0 +1,70 @@
+"""CPU-side schedule analysis for the tile kernel's BSDF query stage (Next / C2): replays the wave-synchronous schedule of
+k_path_tiles on per-vertex query logs taken from the oracle and counts, per wave step, how many passes through the single BSDF
+eval / pdf site are needed
+    today           3 if any lane has a light-half query, else 2 (each lane runs its own LIGHT -> MIS -> PATH sequence)
+    compacted       ceil(jobs / 64): (lane, query) jobs spread over the lanes of the wave
+    + material sort sum over materials of ceil(jobs_m / 64)
+and the share of lanes that do useful work in those passes.  usage: python tools/simulate_query_compaction.py [scene] [spp] [tiles]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import tray_rust_amd as T
+from tray_rust_amd import scenes
+import _oracle as O
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cornell_box"
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+n_tiles = int(sys.argv[3]) if len(sys.argv) > 3 else 48
+d = "/tmp/sim_qc"
+scenes.write_assets(d, cornell=(1920, 1080, spp), small=(1920, 1080, spp))
+scene, *_ = T.Scene.load_file(f"{d}/{name}.json")
+flat = scene.flatten(0)
+o = O.oracle()
+o.oracle_path_profile.restype = C.c_int
+o.oracle_path_profile.argtypes = [C.POINTER(T._lib.TrayFlatScene), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+rng = np.random.default_rng(1)
+tiles = [(int(rng.integers(40, 200)), int(rng.integers(20, 115))) for _ in range(n_tiles)]   # tiles that see the box
+tot = {"steps": 0, "today": 0, "compact": 0, "sorted": 0, "jobs": 0, "alive": 0}
+for tx, ty in tiles:
+    px = np.repeat(np.arange(64) % 8 + tx * 8, spp).astype(np.uint32)
+    py = np.repeat(np.arange(64) // 8 + ty * 8, spp).astype(np.uint32)
+    si = np.tile(np.arange(spp), 64).astype(np.uint32)
+    codes = np.zeros((64 * spp, 16), np.uint8); counts = np.zeros(64 * spp, np.uint8)
+    assert o.oracle_path_profile(flat, len(px), px.ctypes.data, py.ctypes.data, si.ctypes.data, spp, 1, codes.ctypes.data, counts.ctypes.data) == 0
+    codes = codes.reshape(64, spp, 16); counts = counts.reshape(64, spp)
+    for wave in range(4):   # wave w takes samples w, w + 4, ... of every pixel (lane = pixel)
+        sample = np.full(64, wave); vertex = np.zeros(64, int)
+        while True:
+            live = sample < spp
+            if not live.any():
+                break
+            jobs_by_mat = {}
+            n_light = n_alive = 0
+            for lane in np.nonzero(live)[0]:
+                s = sample[lane]
+                if vertex[lane] < counts[lane, s]:
+                    c = int(codes[lane, s, vertex[lane]])
+                    j = 1 + (1 if c & 32 else 0) + (1 if c & 64 else 0)
+                    jobs_by_mat[c & 31] = jobs_by_mat.get(c & 31, 0) + j
+                    n_light += 1 if c & 32 else 0
+                    n_alive += 1
+                    vertex[lane] += 1
+                    if vertex[lane] >= counts[lane, s]:
+                        sample[lane] += 4; vertex[lane] = 0
+                else:   # camera miss: the lane only traced stage A this step
+                    sample[lane] += 4; vertex[lane] = 0
+            if n_alive == 0:
+                continue
+            jobs = sum(jobs_by_mat.values())
+            tot["steps"] += 1; tot["alive"] += n_alive; tot["jobs"] += jobs
+            tot["today"] += 3 if n_light else 2
+            tot["compact"] += -(-jobs // 64)
+            tot["sorted"] += sum(-(-j // 64) for j in jobs_by_mat.values())
+s = tot["steps"]
+print(f"{name} {spp} spp, {n_tiles} tiles: {s} wave steps, {tot['alive'] / s:.1f} lanes with a vertex per step, {tot['jobs'] / s:.1f} query jobs per step")
+for k in ("today", "compact", "sorted"):
+    print(f"  {k:8s} {tot[k] / s:.2f} passes per step, useful lanes {100 * tot['jobs'] / (64 * tot[k]):.0f} %")
