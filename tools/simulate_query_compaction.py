@@ -4,6 +4,7 @@ eval / pdf site are needed
     today           3 if any lane has a light-half query, else 2 (each lane runs its own LIGHT -> MIS -> PATH sequence)
     compacted       ceil(jobs / 64): (lane, query) jobs spread over the lanes of the wave
     + material sort sum over materials of ceil(jobs_m / 64)
+    + kind sort     the same per material KIND (matte, plastic, ...: what selects the code path of the eval site)
 and the share of lanes that do useful work in those passes.  usage: python tools/simulate_query_compaction.py [scene] [spp] [tiles]"""
 import ctypes as C
 import os
@@ -28,7 +29,10 @@ o.oracle_path_profile.restype = C.c_int
 o.oracle_path_profile.argtypes = [C.POINTER(T._lib.TrayFlatScene), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
 rng = np.random.default_rng(1)
 tiles = [(int(rng.integers(40, 200)), int(rng.integers(20, 115))) for _ in range(n_tiles)]   # tiles that see the box
-tot = {"steps": 0, "today": 0, "compact": 0, "sorted": 0, "jobs": 0, "alive": 0}
+tot = {"steps": 0, "today": 0, "compact": 0, "sorted": 0, "by_kind": 0, "jobs": 0, "alive": 0, "mixed": 0, "mixed_kind": 0}
+kind_of = [flat.contents.materials[m].kind for m in range(flat.contents.n_materials)]
+per_kind = {}
+per_mat = {}
 for tx, ty in tiles:
     px = np.repeat(np.arange(64) % 8 + tx * 8, spp).astype(np.uint32)
     py = np.repeat(np.arange(64) // 8 + ty * 8, spp).astype(np.uint32)
@@ -64,7 +68,27 @@ for tx, ty in tiles:
             tot["today"] += 3 if n_light else 2
             tot["compact"] += -(-jobs // 64)
             tot["sorted"] += sum(-(-j // 64) for j in jobs_by_mat.values())
+            tot["mixed"] += 1 if len(jobs_by_mat) > 1 else 0
+            by_kind = {}
+            for m, j in jobs_by_mat.items():
+                by_kind[kind_of[m]] = by_kind.get(kind_of[m], 0) + j
+            tot["by_kind"] += sum(-(-j // 64) for j in by_kind.values())
+            tot["mixed_kind"] += 1 if len(by_kind) > 1 else 0
+            for k, j in by_kind.items():
+                a = per_kind.setdefault(k, [0, 0])
+                a[0] += j; a[1] += -(-j // 64)
+            for m, j in jobs_by_mat.items():
+                a = per_mat.setdefault(m, [0, 0])
+                a[0] += j; a[1] += -(-j // 64)
 s = tot["steps"]
 print(f"{name} {spp} spp, {n_tiles} tiles: {s} wave steps, {tot['alive'] / s:.1f} lanes with a vertex per step, {tot['jobs'] / s:.1f} query jobs per step")
-for k in ("today", "compact", "sorted"):
+print(f"  steps with more than one material among the live lanes: {100 * tot['mixed'] / s:.0f} %")
+fs = flat.contents
+kinds = {0: "matte", 1: "plastic", 2: "metal", 3: "glass", 4: "rough_glass", 5: "specular_metal", 6: "merl"}
+for m, (j, p) in sorted(per_mat.items()):
+    print(f"  material {m} ({kinds.get(fs.materials[m].kind, '?')}): {100 * j / tot['jobs']:.0f} % of the jobs, {p / s:.2f} material-pure passes per step")
+print(f"  steps with more than one material KIND (= code path of the eval site): {100 * tot['mixed_kind'] / s:.0f} %")
+for k, (j, p) in sorted(per_kind.items()):
+    print(f"  kind {kinds.get(k, '?')}: {100 * j / tot['jobs']:.0f} % of the jobs, {p / s:.2f} kind-pure passes per step")
+for k in ("today", "compact", "sorted", "by_kind"):
     print(f"  {k:8s} {tot[k] / s:.2f} passes per step, useful lanes {100 * tot['jobs'] / (64 * tot[k]):.0f} %")
