@@ -462,6 +462,7 @@ struct TrayDeviceScene {
     uint32_t n_materials = 0;
     // wavefront mode (lazily allocated)
     WfPool pool{nullptr, 0};
+    bool wf_ready = false;               // every buffer below exists (a failed allocation leaves this false for good)
     WfChunk* d_chunks = nullptr;
     float* d_bins = nullptr;
     uint32_t* d_wf_counters = nullptr;   // [0] tile counter, [1] tiles done
@@ -819,32 +820,21 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         }
         if (s->stack_bytes > 32u * 1024u) {   // past the default dynamic-LDS window: raise the per-kernel limit (160 KB LDS per CU)
             const int bytes = (int)s->stack_bytes;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_MERL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_SPEC>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_MERL | FEAT_SPEC>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<1, FEAT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<1, FEAT_SPEC>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL | FEAT_SPEC>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wf_trace_dyn<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_intersect<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_intersect<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_sample_radiance<0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_sample_radiance<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            const void* const traversing[] = {   // every kernel that is launched with s->stack_bytes (or its LDS part)
+                reinterpret_cast<const void*>(k_path_tiles<0, FEAT_NONE>), reinterpret_cast<const void*>(k_path_tiles<0, FEAT_MERL>),
+                reinterpret_cast<const void*>(k_path_tiles<0, FEAT_SPEC>), reinterpret_cast<const void*>(k_path_tiles<0, FEAT_MERL | FEAT_SPEC>),
+                reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL>),
+                reinterpret_cast<const void*>(k_path_tiles<1, FEAT_NONE>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL>),
+                reinterpret_cast<const void*>(k_path_tiles<1, FEAT_SPEC>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL | FEAT_SPEC>),
+                reinterpret_cast<const void*>(k_wf_trace<0, 0>), reinterpret_cast<const void*>(k_wf_trace<0, 1>),
+                reinterpret_cast<const void*>(k_wf_trace<1, 0>), reinterpret_cast<const void*>(k_wf_trace<1, 1>),
+                reinterpret_cast<const void*>(k_wf_trace<2, 0>), reinterpret_cast<const void*>(k_wf_trace<2, 1>),
+                reinterpret_cast<const void*>(k_wf_trace_dyn<0, 0>), reinterpret_cast<const void*>(k_wf_trace_dyn<0, 1>),
+                reinterpret_cast<const void*>(k_wf_trace_dyn<1, 0>), reinterpret_cast<const void*>(k_wf_trace_dyn<1, 1>),
+                reinterpret_cast<const void*>(k_wf_trace_dyn<2, 0>), reinterpret_cast<const void*>(k_wf_trace_dyn<2, 1>),
+                reinterpret_cast<const void*>(k_debug_intersect<0>), reinterpret_cast<const void*>(k_debug_intersect<2>),
+                reinterpret_cast<const void*>(k_debug_sample_radiance<0>), reinterpret_cast<const void*>(k_debug_sample_radiance<2>)};
+            for (const void* k : traversing) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipGetLastError();
         }
     }
@@ -889,7 +879,8 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
 // The host only polls a "tiles done" word every WF_POLL rounds; kernels of finished chunks exit at once.
 static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride,
                             uint32_t spp, uint32_t kf, float* rgbw_dev, hipStream_t stream) {
-    if (!s->pool.data) {
+    if (!s->wf_ready) {
+        if (s->pool.data) { set_error("the wavefront buffers of this scene could not be allocated by an earlier call"); return TRAY_E_NOMEM; }
         uint32_t n_slots = wf_slot_count(s);
         s->n_chunks = n_slots / TR_BLOCK;
         void* p = nullptr;
@@ -934,6 +925,7 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             s->wf_dynamic = !(e && std::string(e) == "slot");
         }
         HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s->h_done), sizeof(uint32_t), hipHostMallocDefault));
+        s->wf_ready = true;
     }
     const uint32_t n_chunks = std::min(s->n_chunks, tile_count);
     const uint32_t n_active = n_chunks * TR_BLOCK;
@@ -1156,9 +1148,7 @@ int tray_debug_bsdf(TrayDeviceScene* s, uint32_t material_id, uint32_t flags, ui
     fake.material_id = material_id;
     TrayInstance* d_fake = nullptr;
     float *d_dirs = nullptr, *d_u = nullptr, *d_out = nullptr;
-    DevScene* d_tmp = nullptr;
     HIP_CHECK(hipMalloc(&d_fake, sizeof fake));
-    HIP_CHECK(hipMalloc(&d_tmp, sizeof(DevScene)));
     hipError_t e = hipMalloc(&d_dirs, 6 * (size_t)n * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&d_u, 3 * (size_t)n * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&d_out, 12 * (size_t)n * sizeof(float));
@@ -1168,14 +1158,10 @@ int tray_debug_bsdf(TrayDeviceScene* s, uint32_t material_id, uint32_t flags, ui
     if (e == hipSuccess) {
         DevScene tmp = s->dev;
         tmp.instances = d_fake;
-        e = hipMemcpy(d_tmp, &tmp, sizeof tmp, hipMemcpyHostToDevice);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_debug_bsdf, dim3((n + 63) / 64), dim3(64), 0, 0, tmp, flags, n, d_dirs, d_u, d_out);
-            e = hipGetLastError();
-        }
+        hipLaunchKernelGGL(k_debug_bsdf, dim3((n + 63) / 64), dim3(64), 0, 0, tmp, flags, n, d_dirs, d_u, d_out);
+        e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(out, d_out, 12 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
-    (void)hipFree(d_tmp);
     (void)hipFree(d_fake); (void)hipFree(d_dirs); (void)hipFree(d_u); (void)hipFree(d_out);
     if (e != hipSuccess) { set_error(std::string("tray_debug_bsdf: ") + hipGetErrorString(e)); return TRAY_E_DEVICE; }
     return TRAY_OK;
