@@ -31,7 +31,10 @@ bool proto_mesh_intersect(const SceneView& sv, const TrayMesh& m, Ray& ray, Hit&
         }
     };
     const TrayBvhNode* tree = fs.mesh_nodes + m.node_offset;
-    if (sv.flags & ORC_PROTO_WIDE) {
+    if ((sv.flags & ORC_PROTO_WIDE) && sv.packed) {
+        const size_t mi = (size_t)(&m - fs.meshes);
+        packed_traverse(tree, sv.packed->words + sv.packed->mesh_first[mi], sv.packed->quantised, sv.packed->mesh_root[mi], ray, leaf, sv.proto);
+    } else if (sv.flags & ORC_PROTO_WIDE) {
         wide_traverse(tree, sv.wide[&m - fs.meshes], ray, leaf, sv.proto);
     } else {   // bvh_traverse with counters
         Vec3 inv_dir(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
@@ -465,6 +468,37 @@ int oracle_proto_wide_bvh(const TrayFlatScene* fs, uint32_t n, const TrayRay* ra
     for (int pass = 0; pass < 2; ++pass) {
         SceneView sv{fs, pass ? ORC_PROTO_WIDE : 0, nullptr};
         sv.wide = wide.data(); sv.proto = &pc;
+        TrayHit* hits = pass ? hits_wide : hits_binary;
+        for (uint32_t i = 0; i < n; ++i) {
+            Ray r;
+            r.o = Vec3(rays[i].o[0], rays[i].o[1], rays[i].o[2]);
+            r.d = Vec3(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
+            r.min_t = rays[i].min_t; r.max_t = rays[i].max_t; r.time = rays[i].time;
+            Hit h;
+            TrayHit& o = hits[i];
+            std::memset(&o, 0, sizeof o);
+            if (scene_intersect(sv, r, h)) {
+                o.t = r.max_t; o.inst = h.inst; o.prim = h.prim;
+                for (int k = 0; k < 3; ++k) { o.p[k] = h.p[k]; o.n[k] = h.n[k]; o.ng[k] = h.ng[k]; o.dp_du[k] = h.dp_du[k]; o.dp_dv[k] = h.dp_dv[k]; }
+                o.u = h.u; o.v = h.v;
+            } else {
+                o.t = r.max_t; o.inst = 0xffffffffu;
+            }
+        }
+    }
+    counters[0] = pc.binary_fetches; counters[1] = pc.wide_fetches; counters[2] = pc.leaf_visits_binary; counters[3] = pc.leaf_visits_wide;
+    return 0;
+}
+
+// The same comparison with the wide pass walking the PRODUCT's packed nodes (tray_debug_wide_nodes) the way the device kernel does
+int oracle_proto_packed_wide(const TrayFlatScene* fs, uint32_t n, const TrayRay* rays, TrayHit* hits_binary, TrayHit* hits_wide, unsigned long long* counters,
+                             const uint32_t* words, const uint64_t* mesh_first, const uint32_t* mesh_root, int quantised) {
+    if (!fs || !rays || !hits_binary || !hits_wide || !counters || !words || !mesh_first || !mesh_root) return -1;
+    PackedWide pk{words, mesh_first, mesh_root, quantised};
+    ProtoCounters pc;
+    for (int pass = 0; pass < 2; ++pass) {
+        SceneView sv{fs, pass ? ORC_PROTO_WIDE : 0, nullptr};
+        sv.proto = &pc; sv.packed = pass ? &pk : nullptr;
         TrayHit* hits = pass ? hits_wide : hits_binary;
         for (uint32_t i = 0; i < n; ++i) {
             Ray r;

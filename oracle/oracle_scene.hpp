@@ -13,6 +13,7 @@ namespace orc {
 enum { ORC_FAITHFUL_XF = 1, ORC_BRUTE_FORCE = 2, ORC_PROTO_WIDE = 4 };   // ORC_PROTO_WIDE: proto_wide_bvh.hpp (design prototype)
 struct WideBvh;
 struct ProtoCounters;
+struct PackedWide;
 
 struct Stats { uint64_t samples = 0, vertices = 0, rays = 0; };
 
@@ -242,6 +243,7 @@ struct SceneView {
     Stats* stats;
     const WideBvh* wide = nullptr;       // per mesh, ORC_PROTO_WIDE only
     ProtoCounters* proto = nullptr;
+    const PackedWide* packed = nullptr;  // the product's packed wide nodes (tray_debug_wide_nodes), ORC_PROTO_WIDE only
     // AnimatedTransform::transform (animated_transform.rs:40-56) from the TRS keyframes of the spline stack
     Transform stack_transform(uint32_t xf_first, uint32_t xf_count, float time) const {
         Transform t = Transform::identity();

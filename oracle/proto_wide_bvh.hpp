@@ -10,6 +10,7 @@
 // `tmin < max_t` (the only clause of BBox::fast_intersect that involves max_t). The tests of the skipped intermediate nodes L
 // and R are implied: a box that contains a hit box is hit (every step of the slab test is monotone in the box).
 #pragma once
+#include <cstring>
 #include <vector>
 
 #include "oracle_scene.hpp"
@@ -147,6 +148,85 @@ inline void wide_traverse(const TrayBvhNode* tree, const WideBvh& wb, Ray& ray, 
             }
             current = e.ref; have = true;
             break;
+        }
+        if (!have) break;
+    }
+}
+
+// Fourth question: does the PRODUCT's packed node buffer (tray_debug_wide_nodes: what the device reads) reproduce the binary
+// traversal when it is walked the way the device kernel walks it (hip/wavefront_wide.h: all four slots tested when the node is
+// reached, the first hit slot in visiting order entered directly, the later ones pushed with their entry distance and re-tested
+// as `tmin < max_t` when popped)? The decode below restates the device's arithmetic: one rounded multiply and one rounded add
+// per quantised coordinate (this file is compiled with -ffp-contract=off like the library).
+struct PackedWide {
+    const uint32_t* words = nullptr;   // all meshes, concatenated
+    const uint64_t* mesh_first = nullptr;   // first word of each mesh
+    const uint32_t* mesh_root = nullptr;    // wide node of each mesh's root (0xffffffff: the root is a leaf)
+    int quantised = 0;
+};
+inline float packed_f(uint32_t w) { float f; std::memcpy(&f, &w, sizeof f); return f; }
+inline float packed_dequant(float lo, uint32_t word, int s, float scale) {
+    const float step = (float)((word >> (8 * s)) & 0xffu) * scale;
+    return lo + step;
+}
+
+template <class LeafFn>
+inline void packed_traverse(const TrayBvhNode* tree, const uint32_t* words, int quantised, uint32_t root, Ray& ray, LeafFn&& leaf, ProtoCounters* pc) {
+    Vec3 inv_dir(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    int neg_dir[3] = {ray.d.x < 0.0f, ray.d.y < 0.0f, ray.d.z < 0.0f};
+    if (pc) pc->wide_fetches++;   // the root record
+    if (!bbox_fast_intersect(tree[0], ray, inv_dir, neg_dir)) return;
+    if (tree[0].count > 0) { if (pc) pc->leaf_visits_wide++; leaf(tree[0].offset, (uint32_t)tree[0].count); return; }
+    struct Entry { uint32_t ref; float tmin; };
+    Entry stack[192];
+    int sp = 0;
+    uint32_t current = root;
+    auto visit_leaf = [&](uint32_t ref) {
+        if (pc) { pc->wide_fetches++; pc->leaf_visits_wide++; }
+        leaf(ref & 0xffffffu, (ref >> 24) & 0x1fu);
+    };
+    for (;;) {
+        if (pc) pc->wide_fetches++;
+        float bmin[4][3], bmax[4][3];
+        uint32_t ref[4], meta;
+        if (quantised) {
+            const uint32_t* w = words + (size_t)current * 16u;
+            const float lo[3] = {packed_f(w[0]), packed_f(w[1]), packed_f(w[2])}, sc[3] = {packed_f(w[3]), packed_f(w[4]), packed_f(w[5])};
+            for (int s = 0; s < 4; ++s) {
+                ref[s] = w[12 + s];
+                for (int k = 0; k < 3; ++k) { bmin[s][k] = packed_dequant(lo[k], w[6 + k], s, sc[k]); bmax[s][k] = packed_dequant(lo[k], w[9 + k], s, sc[k]); }
+            }
+            meta = (w[3] & 3u) | ((w[4] & 3u) << 2) | ((w[5] & 3u) << 4);
+        } else {
+            const uint32_t* w = words + (size_t)current * 32u;
+            for (int s = 0; s < 4; ++s) {
+                ref[s] = w[24 + s];
+                for (int k = 0; k < 3; ++k) { bmin[s][k] = packed_f(w[4 * k + s]); bmax[s][k] = packed_f(w[12 + 4 * k + s]); }
+            }
+            meta = w[28];
+        }
+        bool hit[4];
+        float tmin[4] = {0, 0, 0, 0};
+        for (int s = 0; s < 4; ++s) hit[s] = ref[s] != 0xffffffffu && slab_tmin(bmin[s], bmax[s], ray, inv_dir, neg_dir, tmin[s]);
+        const bool neg_top = neg_dir[meta & 3u] != 0, neg_l = neg_dir[(meta >> 2) & 3u] != 0, neg_r = neg_dir[(meta >> 4) & 3u] != 0;
+        const int near_l = (ref[1] != 0xffffffffu && neg_l) ? 1 : 0, near_r = (ref[3] != 0xffffffffu && neg_r) ? 1 : 0;
+        int ord[4];
+        if (!neg_top) { ord[0] = near_l; ord[1] = 1 - near_l; ord[2] = 2 + near_r; ord[3] = 3 - near_r; }
+        else { ord[0] = 2 + near_r; ord[1] = 3 - near_r; ord[2] = near_l; ord[3] = 1 - near_l; }
+        int kfirst = 4;
+        for (int k = 3; k >= 0; --k) if (hit[ord[k]]) kfirst = k;
+        for (int k = 3; k >= 1; --k) if (hit[ord[k]] && k > kfirst) stack[sp++] = Entry{ref[ord[k]], tmin[ord[k]]};
+        bool have = false;
+        if (kfirst < 4) {
+            const uint32_t r = ref[ord[kfirst]];
+            if (r & 0x80000000u) visit_leaf(r);
+            else { current = r; have = true; }
+        }
+        while (!have && sp > 0) {
+            const Entry e = stack[--sp];
+            if (!(e.tmin < ray.max_t)) continue;
+            if (e.ref & 0x80000000u) { visit_leaf(e.ref); continue; }
+            current = e.ref; have = true;
         }
         if (!have) break;
     }

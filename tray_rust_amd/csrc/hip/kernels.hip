@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../../include/trayhip.h"
+#include "../host/wide_nodes.hpp"
 #include "dev_integrator.h"
 
 namespace trayh { void set_error(const std::string& msg); }
@@ -506,39 +507,7 @@ static int upload(TrayDeviceScene* s, const T* host, size_t n, const T** out) {
     return TRAY_OK;
 }
 
-// 4-wide collapse of one BVH<Triangle> (wavefront_wide.h): the wide node of a binary interior node holds its grandchildren, a
-// child that is a leaf stays one slot; slots in binary order [L.first, L.second, R.first, R.second]. 32 floats per node:
-// bminx[4] bminy[4] bminz[4] bmaxx[4] bmaxy[4] bmaxz[4] ref[4] meta pad[3]. ref: 0xffffffff empty, bit 31 = leaf
-// (count << 24 | first triangle of the mesh), else the index of the child's wide node.
-static uint32_t build_wide_nodes(const TrayBvhNode* tree, uint32_t n, std::vector<float>& out) {
-    const uint32_t self = (uint32_t)(out.size() / 32);
-    out.resize(out.size() + 32, 0.0f);
-    const TrayBvhNode& N = tree[n];
-    const uint32_t kids[2] = {n + 1u, N.offset};
-    uint32_t axes[2] = {0u, 0u}, slot_node[4] = {0u, 0u, 0u, 0u};
-    bool used[4] = {false, false, false, false};
-    for (int c = 0; c < 2; ++c) {
-        const TrayBvhNode& K = tree[kids[c]];
-        if (K.count > 0) { slot_node[2 * c] = kids[c]; used[2 * c] = true; }
-        else { axes[c] = K.axis; slot_node[2 * c] = kids[c] + 1u; slot_node[2 * c + 1] = K.offset; used[2 * c] = used[2 * c + 1] = true; }
-    }
-    for (int sidx = 0; sidx < 4; ++sidx) {
-        uint32_t ref = 0xffffffffu;
-        float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
-        if (used[sidx]) {
-            const TrayBvhNode& S = tree[slot_node[sidx]];
-            for (int k = 0; k < 3; ++k) { bmin[k] = S.bmin[k]; bmax[k] = S.bmax[k]; }
-            if (S.count > 0) ref = 0x80000000u | ((uint32_t)S.count << 24) | S.offset;
-            else ref = build_wide_nodes(tree, slot_node[sidx], out);
-        }
-        float* w = out.data() + (size_t)self * 32;   // (re-derive: the vector may have grown)
-        for (int k = 0; k < 3; ++k) { w[4 * k + sidx] = bmin[k]; w[12 + 4 * k + sidx] = bmax[k]; }
-        std::memcpy(w + 24 + sidx, &ref, sizeof ref);
-    }
-    const uint32_t meta = (uint32_t)N.axis | (axes[0] << 2) | (axes[1] << 4);
-    std::memcpy(out.data() + (size_t)self * 32 + 28, &meta, sizeof meta);
-    return self;
-}
+using tray::build_wide_nodes;   // host/wide_nodes.hpp
 
 #ifndef WF_SLOTS
 #define WF_SLOTS (8u << 20)   // path pool slots (2.2 GB of pool at 66 fields): measured 36.6 / 45.2 / 53.1 Msamples/s at 2 / 4 / 8 M on the C5
@@ -704,20 +673,31 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
 #undef UP
     s->animated = moving;
     if (getenv("TRAYHIP_WF_WIDE") && std::string(getenv("TRAYHIP_WF_WIDE")) == "1") {   // 4-wide BVH<Triangle> for the dynamic-fetch traversal
+#ifdef TR_QWIDE   // variant build (make EXTRA_HIPFLAGS=-DTR_QWIDE): 64-B nodes with 8-bit boxes rounded outwards (host/wide_nodes.hpp)
+        std::vector<uint32_t> wide;
+#else
         std::vector<float> wide;
+#endif
         std::vector<uint32_t> roots(f->n_meshes, 0xffffffffu);
         bool ok = true;
         for (uint32_t m = 0; m < f->n_meshes && ok; ++m) {
             const TrayBvhNode* tree = f->mesh_nodes + f->meshes[m].node_offset;
             if (f->meshes[m].tri_count >= (1u << 24)) ok = false;
-            else if (f->meshes[m].node_count && tree[0].count == 0) roots[m] = build_wide_nodes(tree, 0u, wide);
+            else if (f->meshes[m].node_count && tree[0].count == 0) {
+#ifdef TR_QWIDE
+                roots[m] = tray::build_qwide_nodes(tree, 0u, wide);
+                ok = roots[m] != tray::WIDE_EMPTY;
+#else
+                roots[m] = build_wide_nodes(tree, 0u, wide);
+#endif
+            }
         }
         if (ok && rc == TRAY_OK) {
-            const float* d_wide = nullptr;
+            const decltype(wide)::value_type* d_wide = nullptr;
             const uint32_t* d_roots = nullptr;
             rc = upload(s, wide.data(), wide.size(), &d_wide);
             if (rc == TRAY_OK) rc = upload(s, roots.data(), roots.size(), &d_roots);
-            d.wide_nodes = d_wide; d.mesh_wide_root = d_roots;
+            d.wide_nodes = reinterpret_cast<const float*>(d_wide); d.mesh_wide_root = d_roots;
             s->wf_wide = rc == TRAY_OK;
         }
     }

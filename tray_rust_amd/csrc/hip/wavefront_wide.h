@@ -29,6 +29,12 @@ TR_DEV bool bbox_hit_tmin(float bminx, float bminy, float bminz, float bmaxx, fl
     return tmin < max_t && tmax > min_t;
 }
 
+// coordinate of slot `s` of a quantised node (host/wide_nodes.hpp: qwide_dequant -- one rounded multiply, one rounded add)
+TR_DEV float qwide_dequant(float lo, uint32_t word, uint32_t s, float scale) {
+    const float step = (float)((word >> (8u * s)) & 0xffu) * scale;
+    return lo + step;
+}
+
 template <int STAGE, int ANIM>
 __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_wide(const DevScene scv, WfPool pool, const uint32_t* __restrict__ queue,
                                                            uint32_t* __restrict__ qctl, DevStats* __restrict__ stats, uint32_t lds_depth,
@@ -61,7 +67,9 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_wide(cons
     int sp = 0;
     uint32_t node_a = 0u, node_b = 0xffffffffu, cur_inst = 0u, tri_base = 0u, cur_offset = 0u, cur_count = 0u, wnode = 0u;
     enum : uint32_t { TM_NODE = 0u, TM_LEAF = 1u, TM_POP = 2u, TM_WNODE = 3u, WF_NO_NODE = 0xffffffffu };
+#ifndef TR_QWIDE
     const float4* __restrict__ wide = reinterpret_cast<const float4*>(sc.wide_nodes);
+#endif
     const uint32_t no_tmin = __float_as_uint(-TR_INF);   // entries of the top level carry no entry distance
     uint32_t mode = TM_NODE;
     const TrayBvhNode* __restrict__ tree = sc.top_nodes;
@@ -124,15 +132,32 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_wide(cons
             if (in_node && mode == TM_WNODE) {
                 // 4-wide node of a BVH<Triangle> (collapse of two binary levels, wavefront_wide.h): one 128-B fetch, four slab tests
                 WF_COUNT(c_iter); WF_COUNT(c_expand);
+                float t0, t1, t2, t3;
+#ifdef TR_QWIDE   // 64-B node, 8-bit slot boxes rounded outwards (host/wide_nodes.hpp): the dequantised box contains the exact one
+                const uint4* q = reinterpret_cast<const uint4*>(sc.wide_nodes) + (size_t)wnode * 4u;
+                const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+                const float lox = __uint_as_float(w0.x), loy = __uint_as_float(w0.y), loz = __uint_as_float(w0.z);
+                const float qsx = __uint_as_float(w0.w), qsy = __uint_as_float(w1.x), qsz = __uint_as_float(w1.y);   // (axis bits included: the host quantised with exactly these)
+                const uint32_t r0 = w3.x, r1 = w3.y, r2 = w3.z, r3 = w3.w;
+                const uint32_t meta = (w0.w & 3u) | ((w1.x & 3u) << 2) | ((w1.y & 3u) << 4);
+#define QW_HIT(S, T) bbox_hit_tmin(qwide_dequant(lox, w1.z, S, qsx), qwide_dequant(loy, w1.w, S, qsy), qwide_dequant(loz, w2.x, S, qsz), \
+                                   qwide_dequant(lox, w2.y, S, qsx), qwide_dequant(loy, w2.z, S, qsy), qwide_dequant(loz, w2.w, S, qsz), \
+                                   o, inv_dir, nx, ny, nz, min_t, max_t, T)
+                const bool h0 = r0 != 0xffffffffu && QW_HIT(0u, t0);
+                const bool h1 = r1 != 0xffffffffu && QW_HIT(1u, t1);
+                const bool h2 = r2 != 0xffffffffu && QW_HIT(2u, t2);
+                const bool h3 = r3 != 0xffffffffu && QW_HIT(3u, t3);
+#undef QW_HIT
+#else
                 const float4* q = wide + (size_t)wnode * 8u;
                 const float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5], rf = q[6], mt = q[7];
                 const uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
                 const uint32_t meta = __float_as_uint(mt.x);
-                float t0, t1, t2, t3;
                 const bool h0 = r0 != 0xffffffffu && bbox_hit_tmin(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, o, inv_dir, nx, ny, nz, min_t, max_t, t0);
                 const bool h1 = r1 != 0xffffffffu && bbox_hit_tmin(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, o, inv_dir, nx, ny, nz, min_t, max_t, t1);
                 const bool h2 = r2 != 0xffffffffu && bbox_hit_tmin(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, o, inv_dir, nx, ny, nz, min_t, max_t, t2);
                 const bool h3 = r3 != 0xffffffffu && bbox_hit_tmin(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, o, inv_dir, nx, ny, nz, min_t, max_t, t3);
+#endif
                 // reference visiting order of the slots: near child of the collapsed node first, inside a child its near child first
                 const uint32_t ax_top = meta & 3u, ax_l = (meta >> 2) & 3u, ax_r = (meta >> 4) & 3u;
                 const bool neg_top = ax_top == 0u ? nx : (ax_top == 1u ? ny : nz);
