@@ -24,6 +24,7 @@
 
 #include "../../../include/trayhip.h"
 #include "../host/wide_nodes.hpp"
+#include "../host/validate.hpp"
 #include "dev_integrator.h"
 
 namespace trayh { void set_error(const std::string& msg); }
@@ -585,6 +586,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     *out = nullptr;
     if (f->abi_version != TRAY_ABI_VERSION) { set_error("tray_scene_create: ABI version mismatch"); return TRAY_E_INVALID; }
     if (f->n_lights == 0) { set_error("At least one light is required"); return TRAY_E_INVALID; }   // multithreaded.rs:39
+    if (const std::string bad = tray::validate_flat_scene(f); !bad.empty()) { set_error("tray_scene_create: inconsistent scene: " + bad); return TRAY_E_INVALID; }
     if (f->film.width % 8 != 0 || f->film.height % 8 != 0 || f->film.width == 0 || f->film.height == 0) {
         set_error("Image dimensions not evenly divided by blocks of (8, 8)");
         return TRAY_E_INVALID;

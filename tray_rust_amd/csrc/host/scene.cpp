@@ -17,6 +17,7 @@
 
 #include "../../../include/trayhip.h"
 #include "bvh.hpp"
+#include "validate.hpp"
 #include "json.hpp"
 #include "linalg.hpp"
 
@@ -1098,7 +1099,11 @@ int tray_host_scene_flatten(TrayHostScene* s, uint32_t frame, const TrayFlatScen
     if (!s || !out) { set_error("tray_host_scene_flatten: null argument"); return TRAY_E_INVALID; }
     *out = nullptr;
     int rc = guarded([&] { flatten(*s, frame); });
-    if (rc == TRAY_OK) *out = &s->flat;
+    if (rc == TRAY_OK) {   // the loader's own output goes through the check tray_scene_create applies to any caller's scene
+        const std::string bad = tray::validate_flat_scene(&s->flat);
+        if (!bad.empty()) { set_error("internal error: the flattened scene is inconsistent: " + bad); return TRAY_E_INVALID; }
+        *out = &s->flat;
+    }
     return rc;
 }
 

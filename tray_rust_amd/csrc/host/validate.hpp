@@ -1,0 +1,96 @@
+// Structural validation of a TrayFlatScene before anything of it is uploaded: every index the device kernels follow without a
+// bounds check (BVH child / leaf ranges, ordered-instance lists, light list, mesh and triangle ranges, MERL tables, spline
+// stacks, emission keys) must stay inside its array. tray_host_scene_flatten() always produces valid scenes; this is for callers
+// that build or patch the POD themselves through the C ABI. Returns "" when the scene is consistent, else what is wrong.
+#pragma once
+#include <cstdint>
+#include <string>
+
+#include "../../../include/trayhip.h"
+
+namespace tray {
+
+// one flattened BVH2: n nodes, leaves refer to [offset, offset + count) of `n_prims` ordered primitives, at most `max_leaf` each
+inline std::string validate_bvh(const TrayBvhNode* nodes, uint64_t n, uint64_t n_prims, uint32_t max_leaf, const char* what) {
+    if (n == 0) return "";
+    if (!nodes) return std::string(what) + ": null node array";
+    for (uint64_t i = 0; i < n; ++i) {
+        const TrayBvhNode& nd = nodes[i];
+        if (nd.count > 0) {
+            if (nd.count > max_leaf || (uint64_t)nd.offset + nd.count > n_prims)
+                return std::string(what) + ": leaf " + std::to_string(i) + " refers to primitives outside the ordered list";
+        } else {
+            // interior: first child is the next node, second child `offset` lies behind the whole first subtree
+            if (i + 1 >= n || nd.offset <= i + 1 || nd.offset >= n || nd.axis > 2)
+                return std::string(what) + ": interior node " + std::to_string(i) + " has a child outside the node array";
+        }
+    }
+    return "";
+}
+
+inline std::string validate_flat_scene(const TrayFlatScene* f) {
+    auto need = [](const void* p, uint64_t n) { return n == 0 || p != nullptr; };
+    if (!need(f->instances, f->n_instances) || !need(f->top_nodes, f->n_top_nodes) || !need(f->top_order, f->n_top_order) ||
+        !need(f->meshes, f->n_meshes) || !need(f->mesh_nodes, f->n_mesh_nodes) || !need(f->tri_verts, f->n_tris) ||
+        !need(f->tri_attrs, f->n_tris) || !need(f->materials, f->n_materials) || !need(f->merl_tables, f->n_merl) ||
+        !need(f->merl_data, f->n_merl_floats) || !need(f->lights, f->n_lights) || !need(f->xf_levels, f->n_xf_levels) ||
+        !need(f->keyframes, f->n_keyframes) || !need(f->knots, f->n_knots) || !need(f->color_keys, f->n_color_keys))
+        return "an array with a non-zero count is null";
+    if (f->n_instances == 0) return "the scene has no instances";
+    if (f->min_depth > f->max_depth) return "integrator min_depth > max_depth";
+    // BVH<Instance>
+    if (f->n_top_nodes == 0) return "the top-level BVH is empty";
+    if (std::string e = validate_bvh(f->top_nodes, f->n_top_nodes, f->n_top_order, 4u, "BVH<Instance>"); !e.empty()) return e;
+    for (uint32_t i = 0; i < f->n_top_order; ++i)
+        if (f->top_order[i] >= f->n_instances) return "top_order refers to a missing instance";
+    // meshes and their BVH<Triangle>
+    for (uint32_t m = 0; m < f->n_meshes; ++m) {
+        const TrayMesh& me = f->meshes[m];
+        if ((uint64_t)me.node_offset + me.node_count > f->n_mesh_nodes || (uint64_t)me.tri_offset + me.tri_count > f->n_tris)
+            return "mesh " + std::to_string(m) + " refers to nodes or triangles outside the arrays";
+        if (me.node_count == 0 || me.tri_count == 0) return "mesh " + std::to_string(m) + " is empty";
+        if (std::string e = validate_bvh(f->mesh_nodes + me.node_offset, me.node_count, me.tri_count, 16u, "BVH<Triangle>"); !e.empty())
+            return "mesh " + std::to_string(m) + ": " + e;
+    }
+    // materials and MERL tables
+    for (uint32_t t = 0; t < f->n_merl; ++t) {
+        const TrayMerlTable& mt = f->merl_tables[t];
+        const uint64_t floats = (uint64_t)mt.n_theta_h * mt.n_theta_d * mt.n_phi_d * 3u;
+        if (mt.n_theta_h == 0 || mt.n_theta_d == 0 || mt.n_phi_d == 0 || mt.offset > f->n_merl_floats || floats > f->n_merl_floats - mt.offset)
+            return "MERL table " + std::to_string(t) + " lies outside merl_data";
+    }
+    for (uint32_t i = 0; i < f->n_materials; ++i) {
+        const TrayMaterial& ma = f->materials[i];
+        if (ma.kind > TRAY_MAT_MERL) return "material " + std::to_string(i) + " has an unknown kind";
+        if (ma.kind == TRAY_MAT_MERL && ma.table >= f->n_merl) return "material references a missing MERL table";
+    }
+    // instances
+    auto stack_in_range = [&](uint32_t first, uint32_t count) { return (uint64_t)first + count <= f->n_xf_levels; };
+    for (uint32_t i = 0; i < f->n_instances; ++i) {
+        const TrayInstance& in = f->instances[i];
+        const std::string who = "instance " + std::to_string(i);
+        if (in.kind > TRAY_INST_POINT_EMITTER) return who + " has an unknown kind";
+        if (in.kind == TRAY_INST_POINT_EMITTER) {
+            if (in.geom_type != TRAY_GEOM_NONE) return who + ": a point emitter has no geometry";
+        } else {
+            if (in.geom_type > TRAY_GEOM_MESH) return who + " has an unknown geometry type";
+            if (in.material_id >= f->n_materials) return "instance references a missing material";
+            if (in.geom_type == TRAY_GEOM_MESH && in.mesh_id >= f->n_meshes) return "instance references a missing mesh";
+            if (in.kind == TRAY_INST_AREA_EMITTER && in.geom_type == TRAY_GEOM_MESH) return who + ": area lights are spheres, disks or rectangles (scene.rs:584-654)";
+        }
+        if (!stack_in_range(in.xf_first, in.xf_count)) return who + " refers to spline levels outside xf_levels";
+        if (in.emis_count && (uint64_t)in.emis_first + in.emis_count > f->n_color_keys) return "instance references missing colour keys";
+        if (in.kind != TRAY_INST_RECEIVER && (in.light_index >= f->n_lights || f->lights[in.light_index] != i)) return who + " is an emitter that the light list does not hold";
+    }
+    if (!stack_in_range(f->camera.xf_first, f->camera.xf_count)) return "the camera refers to spline levels outside xf_levels";
+    for (uint32_t l = 0; l < f->n_lights; ++l)
+        if (f->lights[l] >= f->n_instances || f->instances[f->lights[l]].kind == TRAY_INST_RECEIVER) return "light " + std::to_string(l) + " is not an emitter instance";
+    for (uint32_t l = 0; l < f->n_xf_levels; ++l) {
+        const TrayXformLevel& lv = f->xf_levels[l];
+        if (lv.kf_count == 0 || (uint64_t)lv.kf_first + lv.kf_count > f->n_keyframes || (uint64_t)lv.knot_first + lv.knot_count > f->n_knots)
+            return "spline level " + std::to_string(l) + " refers to keyframes or knots outside the arrays";
+    }
+    return "";
+}
+
+}  // namespace tray
