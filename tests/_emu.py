@@ -1,0 +1,61 @@
+"""Host emulation of the DEVICE source (tests/emu): the files hipcc compiles for gfx950, compiled by g++ behind a shim with
+one-lane waves. Test infrastructure only; lets the CPU suite run per-lane device code (traversal kernels, debug kernels)
+against the oracle without a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from tray_rust_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+HIP_DIR = os.path.join(ROOT, "tray_rust_amd", "csrc", "hip")
+_libs = {}
+
+
+def _stale(so, deps):
+    return not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps)
+
+
+def emu(qwide=False):
+    """libtrayemu.so (exact 128-B wide nodes) or libtrayemu_qwide.so (-DTR_QWIDE: the staged 64-B quantised nodes)"""
+    if qwide not in _libs:
+        so = os.path.join(EMU_DIR, "libtrayemu_qwide.so" if qwide else "libtrayemu.so")
+        deps = [os.path.join(EMU_DIR, f) for f in ("emu_kernels.cpp", "hip_emu.h")]
+        deps += [os.path.join(HIP_DIR, f) for f in os.listdir(HIP_DIR) if f.endswith((".h", ".hip"))]
+        deps += [os.path.join(ROOT, "tray_rust_amd", "csrc", "host", "wide_nodes.hpp"), os.path.join(ROOT, "include", "trayhip.h")]
+        if _stale(so, deps):
+            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-shared", "-o", so,
+                   os.path.join(EMU_DIR, "emu_kernels.cpp")] + (["-DTR_QWIDE"] if qwide else [])
+            subprocess.run(cmd, check=True)
+        h = C.CDLL(so)
+        FS = C.POINTER(L.TrayFlatScene)
+        h.emu_is_qwide.restype = C.c_int
+        h.emu_debug_intersect.restype = C.c_int
+        h.emu_debug_intersect.argtypes = [FS, C.c_uint32, C.c_void_p, C.c_void_p]
+        h.emu_wf_trace.restype = C.c_int
+        h.emu_wf_trace.argtypes = [FS, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6
+        assert h.emu_is_qwide() == int(qwide)
+        _libs[qwide] = h
+    return _libs[qwide]
+
+
+def debug_intersect(flat, rays, hit_dtype):
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 9)
+    hits = np.zeros(len(rays), dtype=hit_dtype)
+    assert emu().emu_debug_intersect(flat, len(rays), rays.ctypes.data, hits.ctypes.data) == 0
+    return hits
+
+
+def wf_trace(flat, rays, kernel, stage, lds_depth=0, blocks=3, qwide=False):
+    """kernel 0 = k_wf_trace_dyn, 1 = k_wf_trace_wide; returns (hit, t, inst, prim)"""
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 9)
+    n = len(rays)
+    hit = np.zeros(n, np.uint32); t = np.zeros(n, np.float32); inst = np.zeros(n, np.uint32); prim = np.zeros(n, np.uint32)
+    b1 = np.zeros(n, np.float32); b2 = np.zeros(n, np.float32)
+    rc = emu(qwide).emu_wf_trace(flat, kernel, stage, n, rays.ctypes.data, lds_depth, blocks, hit.ctypes.data, t.ctypes.data,
+                                 inst.ctypes.data, prim.ctypes.data, b1.ctypes.data, b2.ctypes.data)
+    assert rc == 0, rc
+    return hit.astype(bool), t, inst, prim

@@ -1,0 +1,140 @@
+// TEST INFRASTRUCTURE ONLY: the device source of libtrayhip.so compiled for the host (hip_emu.h) and driven one thread at a
+// time. Entry points mirror what the library does around the same kernels (scene upload, pool fields, queues, launch geometry).
+#include "hip_emu.h"
+
+uint32_t s_stack[1 << 16];                    // `extern __shared__ uint32_t s_stack[]` of the kernels in the global namespace
+namespace tr { uint32_t s_stack[1 << 16]; }   // ... and of those in namespace tr (wavefront.h)
+
+#include "../../tray_rust_amd/csrc/hip/kernels.hip"
+
+namespace trayh { void set_error(const std::string&) {} }
+
+namespace {
+
+struct EmuScene {
+    DevScene d{};
+    std::vector<DevMaterial> mats;
+    std::vector<uint32_t> wide_words, wide_roots;
+    uint32_t depth = 0;   // traversal stack entries per lane, as tray_scene_create sizes them (two-level worst case, generous)
+};
+
+uint32_t bvh_depth(const TrayBvhNode* nodes, uint32_t n) {
+    uint32_t best = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> st;
+    if (n) st.push_back({0u, 1u});
+    while (!st.empty()) {
+        auto [idx, dep] = st.back();
+        st.pop_back();
+        best = std::max(best, dep);
+        if (idx < n && nodes[idx].count == 0) { st.push_back({idx + 1, dep + 1}); st.push_back({nodes[idx].offset, dep + 1}); }
+    }
+    return best;
+}
+
+void make_scene(const TrayFlatScene* f, int wide_format, EmuScene& e) {
+    DevScene& d = e.d;
+    d.instances = f->instances; d.top_nodes = f->top_nodes; d.top_order = f->top_order; d.meshes = f->meshes;
+    d.mesh_nodes = f->mesh_nodes; d.tri_verts = f->tri_verts; d.tri_attrs = f->tri_attrs;
+    e.mats.resize(f->n_materials);
+    for (uint32_t i = 0; i < f->n_materials; ++i) e.mats[i] = lower_material(f->materials[i], f->merl_tables);
+    d.materials = e.mats.data(); d.merl_data = f->merl_data; d.lights = f->lights;
+    d.filter_table = f->film.table; d.filter_x = f->film.table_x; d.filter_y = f->film.table_y;
+    d.xf_levels = f->xf_levels; d.keyframes = f->keyframes; d.knots = f->knots; d.color_keys = f->color_keys;
+    d.xf_cache = nullptr; d.moving_ids = nullptr; d.n_moving = 0; d.xf_cache_lanes = 0;
+    d.n_instances = f->n_instances; d.n_lights = f->n_lights; d.min_depth = f->min_depth; d.max_depth = f->max_depth;
+    d.width = f->film.width; d.height = f->film.height; d.frame = f->frame; d.film_rows = 0; d.coop_offset = 0;
+    d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
+    d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
+    d.camera = f->camera;
+    uint32_t mesh_depth = 0;
+    for (uint32_t m = 0; m < f->n_meshes; ++m) mesh_depth = std::max(mesh_depth, bvh_depth(f->mesh_nodes + f->meshes[m].node_offset, f->meshes[m].node_count));
+    e.depth = mesh_depth + bvh_depth(f->top_nodes, f->n_top_nodes) + 8u;
+    e.wide_roots.assign(f->n_meshes, 0xffffffffu);
+    if (wide_format) {
+        for (uint32_t m = 0; m < f->n_meshes; ++m) {
+            const TrayBvhNode* tree = f->mesh_nodes + f->meshes[m].node_offset;
+            if (!f->meshes[m].node_count || tree[0].count != 0) continue;
+#ifdef TR_QWIDE
+            e.wide_roots[m] = tray::build_qwide_nodes(tree, 0u, e.wide_words);
+#else
+            std::vector<float> tmp(e.wide_words.size());
+            std::memcpy(tmp.data(), e.wide_words.data(), tmp.size() * 4);
+            e.wide_roots[m] = tray::build_wide_nodes(tree, 0u, tmp);
+            e.wide_words.resize(tmp.size());
+            std::memcpy(e.wide_words.data(), tmp.data(), tmp.size() * 4);
+#endif
+        }
+        d.wide_nodes = reinterpret_cast<const float*>(e.wide_words.data());
+        d.mesh_wide_root = e.wide_roots.data();
+    }
+}
+
+template <class K>
+void launch(uint32_t blocks, uint32_t threads, K&& kernel) {
+    gridDim.x = blocks; blockDim.x = threads;
+    for (uint32_t b = 0; b < blocks; ++b)
+        for (uint32_t t = 0; t < threads; ++t) { blockIdx.x = b; threadIdx.x = t; kernel(); }
+}
+
+}  // namespace
+
+extern "C" {
+
+int emu_is_qwide(void) {
+#ifdef TR_QWIDE
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+// k_debug_intersect<0> on n rays (what tray_debug_intersect launches)
+int emu_debug_intersect(const TrayFlatScene* f, uint32_t n, const TrayRay* rays, TrayHit* hits) {
+    EmuScene e;
+    make_scene(f, 0, e);
+    if (e.depth * TR_BLOCK > sizeof(::s_stack) / 4) return -2;
+    launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_intersect<0>(e.d, n, rays, hits); });
+    return 0;
+}
+
+// One stage of the wavefront traversal over n rays, through the pool fields and the queue the stage kernels use:
+//   kernel 0 = k_wf_trace_dyn, 1 = k_wf_trace_wide (the node format this file was compiled for); stage 0 = A (closest hit from
+//   F_O / F_D), 1 = B (any hit on the segment F_P + t F_AUX, t in (0.001, 0.999)), 2 = C (closest hit from F_P along F_AUX).
+// lds_depth < full depth exercises the HBM overflow part of the stacks. Output per ray: hit flag, t, inst, prim, b1, b2.
+int emu_wf_trace(const TrayFlatScene* f, int kernel, int stage, uint32_t n, const TrayRay* rays, uint32_t lds_depth, uint32_t blocks,
+                 uint32_t* hit, float* t, uint32_t* inst, uint32_t* prim, float* b1, float* b2) {
+    EmuScene e;
+    make_scene(f, kernel == 1, e);
+    const uint32_t n_slots = (n + TR_BLOCK - 1) / TR_BLOCK * TR_BLOCK;
+    std::vector<float> pool_data((size_t)F_COUNT * n_slots, 0.0f);
+    WfPool pool{pool_data.data(), n_slots};
+    std::vector<uint32_t> queue(n_slots), qctl(WF_QCTL_WORDS, 0u);
+    for (uint32_t i = 0; i < n; ++i) {
+        queue[i] = n - 1u - i;   // any permutation: slots keep their place, only indices travel
+        const uint32_t s = queue[i];
+        const f3 o = mk(rays[s].o[0], rays[s].o[1], rays[s].o[2]), dd = mk(rays[s].d[0], rays[s].d[1], rays[s].d[2]);
+        if (stage == 0) { st3(pool, F_O, s, o); st3(pool, F_D, s, dd); pu(pool, F_BOUNCE, s) = rays[s].min_t == 0.0f ? 0u : 1u; }
+        else { st3(pool, F_P, s, o); st3(pool, F_AUX, s, dd); }
+        pu(pool, F_FLAGS, s) = LF_ALIVE;
+    }
+    qctl[stage] = n;
+    const uint32_t full = kernel == 1 ? 2u * e.depth + 8u : e.depth;
+    if (lds_depth == 0 || lds_depth > full) lds_depth = full;
+    if ((size_t)lds_depth * TR_BLOCK > sizeof(tr::s_stack) / 4) return -2;
+    std::vector<uint32_t> overflow((size_t)(8u * e.depth + 64u) * blocks * TR_BLOCK, 0u);
+    std::vector<DevStats> stats(WF_STAT_SLOTS);
+    std::memset(stats.data(), 0, stats.size() * sizeof(DevStats));
+#define EMU_TRACE(K, S) launch(blocks, TR_BLOCK, [&] { K<S, 0>(e.d, pool, queue.data(), qctl.data(), stats.data(), lds_depth, overflow.data()); })
+    if (kernel == 0) { if (stage == 0) EMU_TRACE(k_wf_trace_dyn, 0); else if (stage == 1) EMU_TRACE(k_wf_trace_dyn, 1); else EMU_TRACE(k_wf_trace_dyn, 2); }
+    else { if (stage == 0) EMU_TRACE(k_wf_trace_wide, 0); else if (stage == 1) EMU_TRACE(k_wf_trace_wide, 1); else EMU_TRACE(k_wf_trace_wide, 2); }
+#undef EMU_TRACE
+    for (uint32_t s = 0; s < n; ++s) {
+        const uint32_t fl = pu(pool, F_FLAGS, s);
+        hit[s] = stage == 0 ? (fl & WF_HIT_A) != 0u : (stage == 1 ? (fl & WF_OCCLUDED) != 0u : (fl & WF_HIT_C) != 0u);
+        t[s] = pf(pool, F_REC_T, s); inst[s] = pu(pool, F_REC_INST, s); prim[s] = pu(pool, F_REC_PRIM, s);
+        b1[s] = pf(pool, F_REC_B1, s); b2[s] = pf(pool, F_REC_B2, s);
+    }
+    return 0;
+}
+
+}  // extern "C"

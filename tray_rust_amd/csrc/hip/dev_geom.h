@@ -576,7 +576,7 @@ TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, flo
         f3 ta = mk(a2.y, a2.z, 0.0f), tb = mk(a2.w, a3.x, 0.0f), tc = mk(a3.y, a3.z, 0.0f);
         float b1 = rec.b1, b2 = rec.b2;
         float b0 = 1.0f - b1 - b2;
-        n = normalized(b0 * na + b1 * nb + b2 * nc);
+        n = normalized(normalized(b0 * na + b1 * nb + b2 * nc));   // normalised in mesh.rs:172 AND in DifferentialGeometry::with_normal (differential_geometry.rs:51)
         ng = n;
         f3 texcoord = b0 * ta + b1 * tb + b2 * tc;
         u = texcoord.x; v = texcoord.y;
@@ -643,7 +643,7 @@ TR_DEV f3 finish_hit_ng(const DevScene& sc, const Ray& ray, const HitRec& rec) {
         f3 na = mk(a0.x, a0.y, a0.z), nb = mk(a0.w, a1.x, a1.y), nc = mk(a1.z, a1.w, a2.x);
         float b1 = rec.b1, b2 = rec.b2;
         float b0 = 1.0f - b1 - b2;
-        ng = normalized(b0 * na + b1 * nb + b2 * nc);
+        ng = normalized(normalized(b0 * na + b1 * nb + b2 * nc));   // twice, as in finish_hit
     } else {
         ng = normalized(mk(0.0f, 0.0f, 1.0f));
     }

@@ -3,7 +3,9 @@
 // Arithmetic order follows the reference expression by expression (file:line cited per function);
 // the translation unit is compiled with -ffp-contract=off so nothing is fused that rustc would not fuse.
 #pragma once
+#ifndef TR_HOST_EMU   // (tests/emu/hip_emu.h stands in for the runtime header when the device code is compiled for the host)
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace tr {

@@ -9,7 +9,9 @@
 //   * the film lives in LDS while the tile is rendered: a 17x17 RGBW window (tile + 4 px filter halo)
 //     updated with ds_add_f32 (RenderTarget::write, render_target.rs:77-165), flushed once per tile
 //     with global f32 atomics into the caller's RGBW buffer.
+#ifndef TR_HOST_EMU   // tests/emu compiles the device code of this file for the host (single-lane semantics) behind its own shim
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include <cstdio>
@@ -447,6 +449,7 @@ __global__ __launch_bounds__(64) void k_debug_bsdf(const DevScene scv, uint32_t 
 }
 
 // ================================================================== host side of the device ABI
+#ifndef TR_HOST_EMU
 
 struct TrayDeviceScene {
     int device = 0;
@@ -1150,3 +1153,4 @@ int tray_debug_bsdf(TrayDeviceScene* s, uint32_t material_id, uint32_t flags, ui
 }
 
 }  // extern "C"
+#endif  // TR_HOST_EMU
