@@ -27,7 +27,7 @@ def emu(qwide=False):
         deps += [os.path.join(HIP_DIR, f) for f in os.listdir(HIP_DIR) if f.endswith((".h", ".hip"))]
         deps += [os.path.join(ROOT, "tray_rust_amd", "csrc", "host", "wide_nodes.hpp"), os.path.join(ROOT, "include", "trayhip.h")]
         if _stale(so, deps):
-            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-shared", "-o", so,
+            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-attributes", "-shared", "-o", so,
                    os.path.join(EMU_DIR, "emu_kernels.cpp")] + (["-DTR_QWIDE"] if qwide else [])
             subprocess.run(cmd, check=True)
         h = C.CDLL(so)
@@ -37,6 +37,10 @@ def emu(qwide=False):
         h.emu_debug_intersect.argtypes = [FS, C.c_uint32, C.c_void_p, C.c_void_p]
         h.emu_wf_trace.restype = C.c_int
         h.emu_wf_trace.argtypes = [FS, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6
+        h.emu_debug_sample_radiance.restype = C.c_int
+        h.emu_debug_sample_radiance.argtypes = [FS, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+        h.emu_debug_bsdf.restype = C.c_int
+        h.emu_debug_bsdf.argtypes = [FS, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         assert h.emu_is_qwide() == int(qwide)
         _libs[qwide] = h
     return _libs[qwide]
@@ -59,3 +63,17 @@ def wf_trace(flat, rays, kernel, stage, lds_depth=0, blocks=3, qwide=False):
                                  inst.ctypes.data, prim.ctypes.data, b1.ctypes.data, b2.ctypes.data)
     assert rc == 0, rc
     return hit.astype(bool), t, inst, prim
+
+
+def sample_radiance(flat, px, py, si, spp, seed):
+    px = np.ascontiguousarray(px, np.uint32); py = np.ascontiguousarray(py, np.uint32); si = np.ascontiguousarray(si, np.uint32)
+    out = np.zeros((len(px), 8), np.float32)
+    assert emu().emu_debug_sample_radiance(flat, len(px), px.ctypes.data, py.ctypes.data, si.ctypes.data, spp, seed, out.ctypes.data) == 0
+    return out
+
+
+def bsdf(flat, material_id, flags_sel, dirs, u3):
+    dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 6); u3 = np.ascontiguousarray(u3, np.float32).reshape(-1, 3)
+    out = np.zeros((len(dirs), 12), np.float32)
+    assert emu().emu_debug_bsdf(flat, material_id, flags_sel, len(dirs), dirs.ctypes.data, u3.ctypes.data, out.ctypes.data) == 0
+    return out

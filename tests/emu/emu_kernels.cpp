@@ -97,6 +97,37 @@ int emu_debug_intersect(const TrayFlatScene* f, uint32_t n, const TrayRay* rays,
     return 0;
 }
 
+// k_debug_sample_radiance<0 | 2> for n (pixel, sample) items (what tray_debug_sample_radiance launches; ANIM = 2 evaluates the
+// spline stacks at every use, as the library does for its debug kernels on moving scenes)
+int emu_debug_sample_radiance(const TrayFlatScene* f, uint32_t n, const uint32_t* px, const uint32_t* py, const uint32_t* si, uint32_t spp,
+                              uint64_t seed, float* out) {
+    EmuScene e;
+    make_scene(f, 0, e);
+    if (e.depth * TR_BLOCK > sizeof(::s_stack) / 4) return -2;
+    auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };   // key_frame, as launch_tiles computes it
+    uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
+    kf = mix(kf ^ (uint32_t)(seed >> 32));
+    kf = mix(kf + e.d.frame);
+    bool moving = f->camera.animated != 0;
+    for (uint32_t i = 0; i < f->n_instances; ++i) moving = moving || f->instances[i].animated != 0 || f->instances[i].emis_count >= 2;
+    if (moving) launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_sample_radiance<2>(e.d, n, px, py, si, spp, kf, out); });
+    else launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_sample_radiance<0>(e.d, n, px, py, si, spp, kf, out); });
+    return 0;
+}
+
+// k_debug_bsdf: BSDF::eval / pdf / sample of one material on the canonical frame (what tray_debug_bsdf launches)
+int emu_debug_bsdf(const TrayFlatScene* f, uint32_t material_id, uint32_t flags, uint32_t n, const float* dirs, const float* u3, float* out) {
+    if (material_id >= f->n_materials) return -1;
+    EmuScene e;
+    make_scene(f, 0, e);
+    TrayInstance fake;
+    std::memset(&fake, 0, sizeof fake);
+    fake.material_id = material_id;
+    e.d.instances = &fake;
+    launch((n + 63) / 64, 64, [&] { k_debug_bsdf(e.d, flags, n, dirs, u3, out); });
+    return 0;
+}
+
 // One stage of the wavefront traversal over n rays, through the pool fields and the queue the stage kernels use:
 //   kernel 0 = k_wf_trace_dyn, 1 = k_wf_trace_wide (the node format this file was compiled for); stage 0 = A (closest hit from
 //   F_O / F_D), 1 = B (any hit on the segment F_P + t F_AUX, t in (0.001, 0.999)), 2 = C (closest hit from F_P along F_AUX).
