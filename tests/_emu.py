@@ -41,6 +41,8 @@ def emu(qwide=False):
         h.emu_debug_sample_radiance.argtypes = [FS, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
         h.emu_debug_bsdf.restype = C.c_int
         h.emu_debug_bsdf.argtypes = [FS, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        h.emu_render_tiles.restype = C.c_int
+        h.emu_render_tiles.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
         assert h.emu_is_qwide() == int(qwide)
         _libs[qwide] = h
     return _libs[qwide]
@@ -77,3 +79,14 @@ def bsdf(flat, material_id, flags_sel, dirs, u3):
     out = np.zeros((len(dirs), 12), np.float32)
     assert emu().emu_debug_bsdf(flat, material_id, flags_sel, len(dirs), dirs.ctypes.data, u3.ctypes.data, out.ctypes.data) == 0
     return out
+
+
+def render_tiles(flat, tiles_xy, spp, seed, blocks=1, coop=-1, film_rows=-1):
+    """k_path_tiles over the given tiles as a SIMT emulation (fibers); returns (rgbw image, (samples, vertices, rays, feat))"""
+    fs = flat.contents
+    tiles_xy = np.ascontiguousarray(tiles_xy, np.uint32).reshape(-1, 2)
+    img = np.zeros((fs.film.height, fs.film.width, 4), np.float32)
+    stats = np.zeros(4, np.uint64)
+    rc = emu().emu_render_tiles(flat, tiles_xy.ctypes.data, len(tiles_xy), spp, seed, img.ctypes.data, blocks, coop, film_rows, stats.ctypes.data)
+    assert rc == 0, f"emu_render_tiles: {rc}"
+    return img, tuple(int(x) for x in stats)

@@ -2,9 +2,6 @@
 // time. Entry points mirror what the library does around the same kernels (scene upload, pool fields, queues, launch geometry).
 #include "hip_emu.h"
 
-uint32_t s_stack[1 << 16];                    // `extern __shared__ uint32_t s_stack[]` of the kernels in the global namespace
-namespace tr { uint32_t s_stack[1 << 16]; }   // ... and of those in namespace tr (wavefront.h)
-
 #include "../../tray_rust_amd/csrc/hip/kernels.hip"
 
 namespace trayh { void set_error(const std::string&) {} }
@@ -69,11 +66,33 @@ void make_scene(const TrayFlatScene* f, int wide_format, EmuScene& e) {
     }
 }
 
-template <class K>
-void launch(uint32_t blocks, uint32_t threads, K&& kernel) {
-    gridDim.x = blocks; blockDim.x = threads;
-    for (uint32_t b = 0; b < blocks; ++b)
-        for (uint32_t t = 0; t < threads; ++t) { blockIdx.x = b; threadIdx.x = t; kernel(); }
+using hip_emu::launch;
+using hip_emu::launch_simt;
+
+// what tray_scene_create decides per scene: lobe feature set of the kernels, row-binned film, cooperative small-mesh test
+int feature_set(const EmuScene& e) {
+    int feat = FEAT_NONE;
+    for (const DevMaterial& dm : e.mats)
+        for (uint32_t l = 0; l < dm.n_lobes && l < 2u; ++l) {
+            const uint32_t k = dm.lobe[l].kind;
+            if (k == LB_MERL) feat |= FEAT_MERL;
+            if (k == LB_MF_TRANS) feat |= FEAT_MF_TRANS;
+            if (k == LB_SPEC_REFL_DIEL || k == LB_SPEC_REFL_COND || k == LB_SPEC_TRANS || k == LB_TS_COND) feat |= FEAT_SPEC;
+        }
+    return (feat & FEAT_MF_TRANS) ? FEAT_ALL : feat;
+}
+bool film_rows_ok(const TrayFlatScene* f) {
+    bool ok = f->film.separable != 0 && f->film.filter_h == 2.0f && f->film.inv_h == 0.5f && f->film.filter_pixel_h == 4;
+    for (int y = 0; ok && y < TRAY_FILTER_TABLE_SIZE; ++y)
+        for (int x = 0; x < TRAY_FILTER_TABLE_SIZE; ++x)
+            if (f->film.table[y * TRAY_FILTER_TABLE_SIZE + x] != f->film.table_x[x] * f->film.table_y[y]) { ok = false; break; }
+    return ok;
+}
+uint32_t key_frame_host(uint64_t seed, uint32_t frame) {   // as launch_tiles computes it
+    auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
+    uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
+    kf = mix(kf ^ (uint32_t)(seed >> 32));
+    return mix(kf + frame);
 }
 
 }  // namespace
@@ -92,7 +111,6 @@ int emu_is_qwide(void) {
 int emu_debug_intersect(const TrayFlatScene* f, uint32_t n, const TrayRay* rays, TrayHit* hits) {
     EmuScene e;
     make_scene(f, 0, e);
-    if (e.depth * TR_BLOCK > sizeof(::s_stack) / 4) return -2;
     launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_intersect<0>(e.d, n, rays, hits); });
     return 0;
 }
@@ -103,11 +121,7 @@ int emu_debug_sample_radiance(const TrayFlatScene* f, uint32_t n, const uint32_t
                               uint64_t seed, float* out) {
     EmuScene e;
     make_scene(f, 0, e);
-    if (e.depth * TR_BLOCK > sizeof(::s_stack) / 4) return -2;
-    auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };   // key_frame, as launch_tiles computes it
-    uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
-    kf = mix(kf ^ (uint32_t)(seed >> 32));
-    kf = mix(kf + e.d.frame);
+    const uint32_t kf = key_frame_host(seed, e.d.frame);
     bool moving = f->camera.animated != 0;
     for (uint32_t i = 0; i < f->n_instances; ++i) moving = moving || f->instances[i].animated != 0 || f->instances[i].emis_count >= 2;
     if (moving) launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_sample_radiance<2>(e.d, n, px, py, si, spp, kf, out); });
@@ -151,7 +165,6 @@ int emu_wf_trace(const TrayFlatScene* f, int kernel, int stage, uint32_t n, cons
     qctl[stage] = n;
     const uint32_t full = kernel == 1 ? 2u * e.depth + 8u : e.depth;
     if (lds_depth == 0 || lds_depth > full) lds_depth = full;
-    if ((size_t)lds_depth * TR_BLOCK > sizeof(tr::s_stack) / 4) return -2;
     std::vector<uint32_t> overflow((size_t)(8u * e.depth + 64u) * blocks * TR_BLOCK, 0u);
     std::vector<DevStats> stats(WF_STAT_SLOTS);
     std::memset(stats.data(), 0, stats.size() * sizeof(DevStats));
@@ -166,6 +179,41 @@ int emu_wf_trace(const TrayFlatScene* f, int kernel, int stage, uint32_t n, cons
         b1[s] = pf(pool, F_REC_B1, s); b2[s] = pf(pool, F_REC_B2, s);
     }
     return 0;
+}
+
+// The tile worker itself: k_path_tiles<0, FEAT> over `tile_count` tiles of the given Morton queue, launched the way
+// launch_tiles does (feature set, row-binned film and cooperative small-mesh test chosen as tray_scene_create chooses them),
+// as a SIMT emulation: 256 fibers per workgroup, wave intrinsics and barriers are rendezvous. rgbw is accumulated into.
+// coop / film_rows: -1 = as the library decides, 0 = off. Returns 0, or -3 if a rendezvous could not complete.
+int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t tile_count, uint32_t spp, uint64_t seed, float* rgbw,
+                     uint32_t blocks, int coop, int film_rows, unsigned long long* stats_out) {
+    EmuScene e;
+    make_scene(f, 0, e);
+    bool moving = f->camera.animated != 0;
+    for (uint32_t i = 0; i < f->n_instances; ++i) moving = moving || f->instances[i].animated != 0 || f->instances[i].emis_count >= 2;
+    if (moving || f->n_instances > TR_FLAT_MAX) return -4;   // the library runs other kernels for those
+    e.d.film_rows = (film_rows != 0 && film_rows_ok(f)) ? 1u : 0u;
+    uint32_t stack_words = e.depth * TR_BLOCK;
+    bool small_mesh = false;
+    for (uint32_t m = 0; m < f->n_meshes; ++m) small_mesh = small_mesh || f->meshes[m].tri_count <= TR_COOP_MAX_TRIS;
+    if (coop != 0 && small_mesh) { e.d.coop_offset = stack_words; stack_words += (TR_BLOCK / 64) * TR_COOP_WORDS; }
+    std::vector<uint2> tiles(tile_count);
+    for (uint32_t i = 0; i < tile_count; ++i) tiles[i] = make_uint2(tiles_xy[2 * i], tiles_xy[2 * i + 1]);
+    uint32_t counter = 0;
+    DevStats stats;
+    std::memset(&stats, 0, sizeof stats);
+    const uint32_t kf = key_frame_host(seed, e.d.frame);
+    const int feat = feature_set(e);
+    int rc;
+#define EMU_TILES(F) rc = launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<0, F>(e.d, tiles.data(), tile_count, tile_count ? tile_count : 1u, 1u, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
+    if (feat == FEAT_NONE) EMU_TILES(FEAT_NONE);
+    else if (feat == FEAT_MERL) EMU_TILES(FEAT_MERL);
+    else if (feat == FEAT_SPEC) EMU_TILES(FEAT_SPEC);
+    else if (feat == (FEAT_MERL | FEAT_SPEC)) EMU_TILES(FEAT_MERL | FEAT_SPEC);
+    else EMU_TILES(FEAT_ALL);
+#undef EMU_TILES
+    if (stats_out) { stats_out[0] = stats.samples; stats_out[1] = stats.vertices; stats_out[2] = stats.rays; stats_out[3] = (unsigned long long)feat; }
+    return rc;
 }
 
 }  // extern "C"

@@ -177,3 +177,49 @@ def test_bsdf_eval_pdf_sample_of_the_device_code(kind, tmp_path, built):
         a = O.bsdf(flat, mid, flags, dirs, u3)
         b = E.bsdf(flat, mid, flags, dirs, u3)
         assert np.array_equal(a, b, equal_nan=True), (kind, flags, np.abs(a - b).max())
+
+
+# ---- whole kernels as SIMT emulations: 256 fibers per workgroup, wave intrinsics and barriers are rendezvous (hip_emu.h)
+
+def rgb(img):
+    return img[..., :3] / np.maximum(img[..., 3:], 1e-20)
+
+
+def tile_queue(width, height):
+    return np.array(T.BlockQueue((width, height), (8, 8)).blocks, np.uint32).reshape(-1, 2)
+
+
+@pytest.mark.parametrize("name,coop,film_rows,blocks", [("cornell_box", -1, -1, 1), ("cornell_box", 0, -1, 2), ("cornell_box", -1, 0, 1),
+                                                        ("smallpt", -1, -1, 2), ("dragon", -1, -1, 1)])
+def test_tile_megakernel_emulated_as_simt(name, coop, film_rows, blocks, tmp_path, built):
+    """k_path_tiles itself -- persistent workgroups pulling tiles, wave-synchronous stages, path regeneration, the cooperative
+    small-mesh test (cornell_box's cubes), the row-binned LDS film -- run as fibers on the host: the same samples, path vertices
+    and rays as the oracle, and the same image up to the order of the film's f32 sums."""
+    w, h, spp = 32, 24, 8
+    d = str(tmp_path)
+    scenes.write_assets(d, cornell=(w, h, spp), small=(w, h, spp))
+    if name == "dragon":
+        scenes.write_dragon_assets(d, film=(w, h, spp), grid=16, extent=1.0)
+    scene, *_ = T.Scene.load_file(str(tmp_path / (name + ".json")))
+    flat = scene.flatten(0)
+    img, (samples, vertices, rays, feat) = E.render_tiles(flat, tile_queue(w, h), spp, 7, blocks=blocks, coop=coop, film_rows=film_rows)
+    ref, st = O.render_tiles(flat, spp, seed=7)
+    assert (samples, vertices, rays) == (st.samples, st.vertices, st.rays)
+    assert feat == {"cornell_box": 0, "smallpt": 4, "dragon": 1}[name]            # the feature set tray_scene_create would pick
+    assert np.abs(img[..., 3] - ref[..., 3]).max() < 1e-4 * ref[..., 3].max()
+    assert np.abs(rgb(img) - rgb(ref)).max() < 2e-5
+    assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6
+
+
+def test_tile_megakernel_partial_queue_and_idle_workgroups(tmp_path, built):
+    """skip(start).take(count) of the tile queue (block_queue.rs:39-41) and more workgroups than tiles"""
+    w, h, spp = 32, 24, 4
+    scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
+    scene, *_ = T.Scene.load_file(str(tmp_path / "cornell_box.json"))
+    flat = scene.flatten(0)
+    q = tile_queue(w, h)
+    a, sa = E.render_tiles(flat, q[:5], spp, 3, blocks=1)
+    b, sb = E.render_tiles(flat, q[5:], spp, 3, blocks=9)
+    full, sf = E.render_tiles(flat, q, spp, 3, blocks=2)
+    assert sa[0] + sb[0] == sf[0] == w * h * spp and sa[1] + sb[1] == sf[1]
+    assert np.abs((a + b) - full).max() < 1e-4 * full.max()

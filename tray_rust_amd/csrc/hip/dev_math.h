@@ -11,6 +11,9 @@
 namespace tr {
 
 #define TR_DEV __device__ __forceinline__
+#ifndef TR_HOST_EMU
+#define TR_DYN_LDS(T, name) extern __shared__ T name[]   // the workgroup's dynamic LDS (tests/emu supplies its own definition)
+#endif
 
 static constexpr float kPi = 3.14159265358979323846f;
 static constexpr float kInvPi = 0.318309886183790671538f;

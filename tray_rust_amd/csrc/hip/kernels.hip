@@ -216,7 +216,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
     __shared__ float s_table[TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE];
     __shared__ float s_rowbin[ROWBIN_SIZE];
     __shared__ float s_tx[TRAY_FILTER_TABLE_SIZE], s_ty[TRAY_FILTER_TABLE_SIZE];
-    extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries, sized per scene at launch
+    TR_DYN_LDS(uint32_t, s_stack);   // stack_depth x TR_BLOCK entries, sized per scene at launch
     __shared__ uint32_t s_tile;
     const DevScene& sc = scv;
     const DevScene* const scp = &scv;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
 template <int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_debug_intersect(const DevScene scv, uint32_t n, const TrayRay* __restrict__ rays,
                                                               TrayHit* __restrict__ hits) {
-    extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries, sized per scene at launch
+    TR_DYN_LDS(uint32_t, s_stack);   // stack_depth x TR_BLOCK entries, sized per scene at launch
     const DevScene& sc = scv;
     const DevScene* const scp = &scv;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -380,7 +380,7 @@ template <int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevScene scv, uint32_t n, const uint32_t* __restrict__ px,
                                                                     const uint32_t* __restrict__ py, const uint32_t* __restrict__ si,
                                                                     uint32_t spp, uint32_t kf, float* __restrict__ out) {
-    extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries, sized per scene at launch
+    TR_DYN_LDS(uint32_t, s_stack);   // stack_depth x TR_BLOCK entries, sized per scene at launch
     const DevScene& sc = scv;
     const DevScene* const scp = &scv;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;

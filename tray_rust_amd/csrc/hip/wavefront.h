@@ -69,7 +69,7 @@ TR_DEV void st_bsdf(const DevScene& sc, const WfPool& p, uint32_t i, const Bsdf&
 template <int STAGE, int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace(const DevScene scv, WfPool pool, uint32_t n_active, DevStats* __restrict__ stats) {
     const DevScene* scp = &scv;
-    extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries
+    TR_DYN_LDS(uint32_t, s_stack);   // stack_depth x TR_BLOCK entries
     const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
     if (i >= n_active) return;   // n_active is a multiple of the workgroup size: whole waves leave
     uint32_t flags = pu(pool, F_FLAGS, i);
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                                                            uint32_t* __restrict__ qctl, DevStats* __restrict__ stats, uint32_t lds_depth,
                                                            uint32_t* __restrict__ overflow) {
     const DevScene& sc = scv;
-    extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries
+    TR_DYN_LDS(uint32_t, s_stack);   // stack_depth x TR_BLOCK entries
     uint32_t* __restrict__ stack = s_stack + threadIdx.x;
     // entries past lds_depth live in a per-thread column of `overflow` (HBM): the LDS part is sized for the occupancy the
     // kernel is compiled for, the rarely reached deep levels of the largest meshes must not cost every workgroup its LDS

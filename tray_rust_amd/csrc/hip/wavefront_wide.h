@@ -40,7 +40,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_wide(cons
                                                            uint32_t* __restrict__ qctl, DevStats* __restrict__ stats, uint32_t lds_depth,
                                                            uint32_t* __restrict__ overflow) {
     const DevScene& sc = scv;
-    extern __shared__ uint32_t s_stack[];   // stack_depth x TR_BLOCK entries
+    TR_DYN_LDS(uint32_t, s_stack);   // stack_depth x TR_BLOCK entries
     uint32_t* __restrict__ stack = s_stack + threadIdx.x;
     // entries past lds_depth live in a per-thread column of `overflow` (HBM): the LDS part is sized for the occupancy the
     // kernel is compiled for, the rarely reached deep levels of the largest meshes must not cost every workgroup its LDS
