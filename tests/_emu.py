@@ -43,6 +43,8 @@ def emu(qwide=False):
         h.emu_debug_bsdf.argtypes = [FS, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         h.emu_render_tiles.restype = C.c_int
         h.emu_render_tiles.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+        h.emu_render_wavefront.restype = C.c_int
+        h.emu_render_wavefront.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         assert h.emu_is_qwide() == int(qwide)
         _libs[qwide] = h
     return _libs[qwide]
@@ -89,4 +91,16 @@ def render_tiles(flat, tiles_xy, spp, seed, blocks=1, coop=-1, film_rows=-1):
     stats = np.zeros(4, np.uint64)
     rc = emu().emu_render_tiles(flat, tiles_xy.ctypes.data, len(tiles_xy), spp, seed, img.ctypes.data, blocks, coop, film_rows, stats.ctypes.data)
     assert rc == 0, f"emu_render_tiles: {rc}"
+    return img, tuple(int(x) for x in stats)
+
+
+def render_wavefront(flat, tiles_xy, spp, seed, trace=0, n_chunks=4, trace_blocks=2, lds_depth=0, qwide=False):
+    """the wavefront schedule (7 stage kernels per round) as SIMT emulations; returns (rgbw image, (samples, vertices, rays, rounds))"""
+    fs = flat.contents
+    tiles_xy = np.ascontiguousarray(tiles_xy, np.uint32).reshape(-1, 2)
+    img = np.zeros((fs.film.height, fs.film.width, 4), np.float32)
+    stats = np.zeros(4, np.uint64)
+    rc = emu(qwide).emu_render_wavefront(flat, tiles_xy.ctypes.data, len(tiles_xy), spp, seed, img.ctypes.data, trace, n_chunks, trace_blocks,
+                                         lds_depth, stats.ctypes.data)
+    assert rc == 0, f"emu_render_wavefront: {rc}"
     return img, tuple(int(x) for x in stats)

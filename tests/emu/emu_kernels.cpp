@@ -216,4 +216,92 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
     return rc;
 }
 
+// The wavefront schedule (launch_wavefront + wf_round of kernels.hip): rounds of k_wf_advance -> k_wf_regen -> trace A ->
+// k_wf_begin -> trace B -> k_wf_query -> trace C over an HBM-style path pool until every tile is done. All kernels run as SIMT
+// emulations. trace: 0 = k_wf_trace_dyn (default of the library), 1 = k_wf_trace_wide (node format of this build), 2 = k_wf_trace
+// (one thread per slot, TRAYHIP_WF_TRACE=slot). Moving scenes run the ANIM = 1 kernels with the per-slot transform cache.
+// n_chunks = 256-slot chunks of the pool (<= tile_count); lds_depth as in emu_wf_trace.
+int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t tile_count, uint32_t spp, uint64_t seed, float* rgbw,
+                         int trace, uint32_t n_chunks, uint32_t trace_blocks, uint32_t lds_depth, unsigned long long* stats_out) {
+    EmuScene e;
+    make_scene(f, trace == 1, e);
+    bool moving = f->camera.animated != 0;
+    uint32_t n_moving = 0;
+    for (uint32_t i = 0; i < f->n_instances; ++i) {
+        moving = moving || f->instances[i].animated != 0 || f->instances[i].emis_count >= 2;
+        if (f->instances[i].animated) ++n_moving;
+    }
+    e.d.film_rows = film_rows_ok(f) ? 1u : 0u;
+    n_chunks = std::max(1u, std::min(n_chunks, tile_count));
+    const uint32_t n_slots = n_chunks * TR_BLOCK, n_active = n_slots;
+    std::vector<float> pool_data((size_t)F_COUNT * n_slots, 0.0f);
+    WfPool pool{pool_data.data(), n_slots};
+    std::vector<uint32_t> moving_ids(std::max(n_moving, 1u), 0u);
+    std::vector<float> xf_cache;
+    if (moving && n_moving) {   // per-path transform cache, one column per pool slot (tray_scene_create)
+        for (uint32_t i = 0; i < f->n_instances; ++i)
+            if (f->instances[i].animated && f->instances[i].moving_slot < n_moving) moving_ids[f->instances[i].moving_slot] = i;
+        xf_cache.assign((size_t)n_moving * 24u * n_slots, 0.0f);
+        e.d.xf_cache = xf_cache.data(); e.d.moving_ids = moving_ids.data(); e.d.n_moving = n_moving; e.d.xf_cache_lanes = n_slots;
+    }
+    std::vector<WfChunk> chunks(n_chunks, WfChunk{WF_TILE_NEED, 0u});
+    std::vector<float> bins((size_t)n_chunks * ROWBIN_SIZE, 0.0f);
+    std::vector<uint32_t> queues(4 * (size_t)n_slots + WF_QCTL_WORDS, 0u);
+    uint32_t* const qa = queues.data(), * const qb = qa + n_slots, * const qc = qb + n_slots, * const qctl = qc + n_slots, * const qr = qc + n_slots + WF_QCTL_WORDS;
+    uint32_t counters[2] = {0u, 0u};
+    std::vector<DevStats> stats(WF_STAT_SLOTS);
+    std::memset(stats.data(), 0, stats.size() * sizeof(DevStats));
+    std::vector<uint2> tiles(tile_count);
+    for (uint32_t i = 0; i < tile_count; ++i) tiles[i] = make_uint2(tiles_xy[2 * i], tiles_xy[2 * i + 1]);
+    const uint32_t kf = key_frame_host(seed, e.d.frame);
+    const uint32_t full = trace == 1 ? 2u * e.depth + 8u : e.depth;
+    if (lds_depth == 0 || lds_depth > full) lds_depth = full;
+    trace_blocks = std::max(1u, std::min(trace_blocks, n_chunks));
+    std::vector<uint32_t> overflow((size_t)(8u * e.depth + 64u) * trace_blocks * TR_BLOCK, 0u);
+    const size_t slot_lds = (size_t)e.depth * TR_BLOCK * 4, dyn_lds = (size_t)lds_depth * TR_BLOCK * 4;
+    const int feat = feature_set(e);
+    const uint64_t max_rounds = (uint64_t)((tile_count + n_chunks - 1) / n_chunks) * (((uint64_t)spp + 3) / 4 * (e.d.max_depth + 3) + 4) + 32;
+    int rc = 0;
+    uint64_t rounds = 0;
+#define EMU_K(...) do { if (rc == 0) rc = launch_simt(__VA_ARGS__); } while (0)
+#define EMU_ROUND(A, F)                                                                                                                     \
+    do {                                                                                                                                    \
+        EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_advance<A>(e.d, pool, chunks.data(), bins.data(), tiles.data(), tile_count, tile_count, 1u, spp, kf, rgbw, \
+                                                         counters, counters + 1, stats.data(), qa, qr, qctl); });                          \
+        EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_regen<A>(e.d, pool, chunks.data(), tiles.data(), tile_count, 1u, spp, kf, stats.data(), qr, qa, qctl); }); \
+        EMU_TRACE_STAGE(0, A, qa);                                                                                                          \
+        EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_begin<A>(e.d, pool, n_active, stats.data(), trace == 2 ? nullptr : qb, trace == 2 ? nullptr : qctl); }); \
+        EMU_TRACE_STAGE(1, A, qb);                                                                                                          \
+        EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query<A, F>(e.d, pool, n_active, trace == 2 ? nullptr : qc, trace == 2 ? nullptr : qctl); });  \
+        EMU_TRACE_STAGE(2, A, qc);                                                                                                          \
+    } while (0)
+#define EMU_TRACE_STAGE(S, A, Q)                                                                                                            \
+    do {                                                                                                                                    \
+        if (trace == 0) EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data()); }, dyn_lds); \
+        else if (trace == 1) EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_wide<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data()); }, dyn_lds); \
+        else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_trace<S, A>(e.d, pool, n_active, stats.data()); }, slot_lds);                             \
+    } while (0)
+#define EMU_ROUND_F(A)                                                                                                                      \
+    do {                                                                                                                                    \
+        if (feat == FEAT_NONE) EMU_ROUND(A, FEAT_NONE); else if (feat == FEAT_MERL) EMU_ROUND(A, FEAT_MERL);                                \
+        else if (feat == FEAT_SPEC) EMU_ROUND(A, FEAT_SPEC); else if (feat == (FEAT_MERL | FEAT_SPEC)) EMU_ROUND(A, FEAT_MERL | FEAT_SPEC);  \
+        else EMU_ROUND(A, FEAT_ALL);                                                                                                        \
+    } while (0)
+    while (rc == 0 && counters[1] < tile_count) {
+        std::memset(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t));
+        if (moving) EMU_ROUND_F(1); else EMU_ROUND_F(0);
+        if (++rounds > max_rounds) rc = -5;   // "wavefront schedule did not terminate"
+    }
+#undef EMU_ROUND_F
+#undef EMU_TRACE_STAGE
+#undef EMU_ROUND
+#undef EMU_K
+    if (stats_out) {
+        DevStats st{};
+        for (const DevStats& a : stats) { st.samples += a.samples; st.vertices += a.vertices; st.rays += a.rays; }
+        stats_out[0] = st.samples; stats_out[1] = st.vertices; stats_out[2] = st.rays; stats_out[3] = rounds;
+    }
+    return rc;
+}
+
 }  // extern "C"

@@ -223,3 +223,36 @@ def test_tile_megakernel_partial_queue_and_idle_workgroups(tmp_path, built):
     full, sf = E.render_tiles(flat, q, spp, 3, blocks=2)
     assert sa[0] + sb[0] == sf[0] == w * h * spp and sa[1] + sb[1] == sf[1]
     assert np.abs((a + b) - full).max() < 1e-4 * full.max()
+
+
+WF_CASES = [("cornell_box", 0, 0, False), ("cornell_box", 0, 2, False), ("moving_box", 3, 0, False), ("moving_box", 3, 2, False),
+            ("tr15_like", 330, 0, False), ("tr15_like", 330, 1, False), ("tr15_like", 330, 1, True)]
+
+
+@pytest.mark.parametrize("name,frame,trace,qwide", WF_CASES, ids=[f"{n}-{['dyn', 'wide', 'slot'][t]}{'-quantised' if q else ''}" for n, _, t, q in WF_CASES])
+def test_wavefront_schedule_emulated_as_simt(name, frame, trace, qwide, tmp_path, built):
+    """The whole wavefront schedule -- k_wf_advance (film row bins, tile switch), k_wf_regen (camera samples, the per-path transform
+    cache of moving scenes), the three traversal kernels in each of their forms, k_wf_begin, k_wf_query, ray queues -- round
+    after round until every tile is done, as fibers on the host: the oracle's samples, vertices, rays and image."""
+    w, h, spp = 32, 24, 8
+    d = str(tmp_path)
+    if name == "tr15_like":
+        scenes.write_tr15_like_assets(d, film=(w, h, spp), detail=0.02)     # 59 instances, splines, keyed lights, MERL
+    elif name == "moving_box":
+        scenes.write_moving_box(d, width=w, height=h, samples=spp)
+    else:
+        scenes.write_assets(d, cornell=(w, h, spp), small=(w, h, spp))
+    scene, *_ = T.Scene.load_file(str(tmp_path / (name + ".json")))
+    flat = scene.flatten(frame)
+    img, (samples, vertices, rays, rounds) = E.render_wavefront(flat, tile_queue(w, h), spp, 5, trace=trace, n_chunks=5, trace_blocks=2,
+                                                                lds_depth=0 if trace == 2 else 4, qwide=qwide)
+    ref, st = O.render_tiles(flat, spp, seed=5)
+    assert samples == st.samples == w * h * spp
+    moving = bool(flat.contents.animated)
+    if moving:   # slerp's transcendental in f64 on the device side: a handful of paths may take another turn
+        assert abs(vertices - st.vertices) <= 2e-3 * st.vertices and abs(rays - st.rays) <= 2e-3 * st.rays
+    else:
+        assert (vertices, rays) == (st.vertices, st.rays)
+    assert rgb(ref).max() > 0.05
+    assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < (2e-3 if moving else 2e-6)
+    assert np.abs(img[..., 3] - ref[..., 3]).max() < 1e-4 * ref[..., 3].max()
