@@ -129,6 +129,50 @@ int emu_debug_sample_radiance(const TrayFlatScene* f, uint32_t n, const uint32_t
     return 0;
 }
 
+// Debugging aid: the loop of k_debug_sample_radiance<0> for ONE sample with the lane state printed after every vertex
+int emu_trace_sample(const TrayFlatScene* f, uint32_t px, uint32_t py, uint32_t si, uint32_t spp, uint64_t seed) {
+    EmuScene e;
+    make_scene(f, 0, e);
+    const uint32_t kf = key_frame_host(seed, e.d.frame);
+    hip_emu::launch(1, 1, [&] {
+        const DevScene& sc = e.d;
+        TR_DYN_LDS(uint32_t, s_stack);
+        Counters cnt; cnt.rays = 0; cnt.vertices = 0;
+        const uint32_t kp = key_pixel(kf, py * sc.width + px);
+        float sx, sy, t;
+        pixel_sample(kp, si, spp, px, py, sx, sy, t);
+        Lane ln;
+        lane_start_sample(ln, camera_ray<0>(sc, sx, sy, t), key_sample(kp, si));
+        while (ln.flags & LF_ALIVE) {
+            for (int stage = 0; stage < 3; ++stage) {
+                const bool alive = (ln.flags & LF_ALIVE) != 0u;
+                const bool want_ray = alive && (stage == 0 || (stage == 1 && (ln.flags & LF_SHADOW)) || (stage == 2 && (ln.flags & LF_MIS)));
+                TraceResult tr_; tr_.hit = false; tr_.rec.t = 0.0f; tr_.rec.inst = 0xffffffffu; tr_.rec.prim = 0u; tr_.rec.b1 = 0.0f; tr_.rec.b2 = 0.0f;
+                if (want_ray) { const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln)); tr_ = trace<0>(&e.d, s_stack, r, stage == 1, want_ray); }
+                if (!alive) continue;
+                if (stage == 0) { if (tr_.hit) vertex_begin<0>(sc, ln, tr_.rec, cnt); else ln.flags &= ~LF_ALIVE; if (tr_.hit) std::fprintf(stderr, "device  bounce %u inst %u", ln.bounce, tr_.rec.inst); }
+                else if (stage == 1) {
+                    std::fprintf(stderr, "\ndevice    light sample: pdf %.9g li %.9g %.9g %.9g shadow-ray %d occluded %d w_i %.9g %.9g %.9g\n", ln.pdf_l, ln.li.x, ln.li.y, ln.li.z,
+                                 (int)((ln.flags & LF_SHADOW) != 0), (int)tr_.hit, ln.wi_l.x, ln.wi_l.y, ln.wi_l.z);
+                    vertex_queries<0, FEAT_ALL>(sc, ln, tr_.hit);
+                    std::fprintf(stderr, "device    after queries: direct %.9g %.9g %.9g mis %d (cos, w, pdf) %.9g %.9g %.9g f %.9g %.9g %.9g\n", ln.direct.x, ln.direct.y, ln.direct.z,
+                                 (int)((ln.flags & LF_MIS) != 0), ln.li.x, ln.li.y, ln.li.z, ln.mis_f.x, ln.mis_f.y, ln.mis_f.z);
+                }
+                else {
+                    const f3 tv = ln.t_vertex;
+                    const uint32_t b = ln.bounce;
+                    const bool cont = vertex_end<0>(sc, ln, tr_.hit, tr_.rec);
+                    std::fprintf(stderr, " li %.9g %.9g %.9g  throughput %.9g %.9g %.9g  illum %.9g %.9g %.9g\n", ln.direct.x, ln.direct.y, ln.direct.z, tv.x, tv.y, tv.z,
+                                 ln.illum.x, ln.illum.y, ln.illum.z);
+                    (void)b;
+                    if (!cont) ln.flags &= ~LF_ALIVE;
+                }
+            }
+        }
+    });
+    return 0;
+}
+
 // k_debug_bsdf: BSDF::eval / pdf / sample of one material on the canonical frame (what tray_debug_bsdf launches)
 int emu_debug_bsdf(const TrayFlatScene* f, uint32_t material_id, uint32_t flags, uint32_t n, const float* dirs, const float* u3, float* out) {
     if (material_id >= f->n_materials) return -1;
