@@ -111,6 +111,8 @@ struct PathSamples {
 };
 
 // Schedule analysis hook (tools/simulate_query_compaction.py): which BSDF queries each path vertex needed
+// ORACLE_TRACE=1 (set before the first call): per-vertex lines on stderr, to line a sample up against tests/emu's emu_trace_sample
+static bool oracle_trace() { static const bool on = getenv("ORACLE_TRACE") != nullptr; return on; }
 struct VertexLog { std::vector<uint8_t>* sink = nullptr; bool light = false, mis = false; };
 thread_local VertexLog g_vlog;
 
@@ -128,7 +130,7 @@ Colorf estimate_direct(const SceneView& sv, Vec3 w_o, Vec3 p, const BSDF& bsdf, 
         unoccluded = !scene_intersect(sv, r, tmp);
     }
     g_vlog.light = unoccluded; g_vlog.mis = !delta;
-    if (getenv("ORACLE_TRACE")) fprintf(stderr, "oracle    light sample: pdf %.9g li %.9g %.9g %.9g unoccluded %d w_i %.9g %.9g %.9g\n", ls.pdf, ls.li.r, ls.li.g, ls.li.b, (int)unoccluded, ls.w_i.x, ls.w_i.y, ls.w_i.z);
+    if (oracle_trace()) fprintf(stderr, "oracle    light sample: pdf %.9g li %.9g %.9g %.9g unoccluded %d w_i %.9g %.9g %.9g\n", ls.pdf, ls.li.r, ls.li.g, ls.li.b, (int)unoccluded, ls.w_i.x, ls.w_i.y, ls.w_i.z);
     if (unoccluded) {
         Colorf f = bsdf.eval(w_o, ls.w_i, flags);
         if (!f.is_black()) {
@@ -138,7 +140,7 @@ Colorf estimate_direct(const SceneView& sv, Vec3 w_o, Vec3 p, const BSDF& bsdf, 
                 float pdf_bsdf = bsdf.pdf(w_o, ls.w_i, flags);
                 float w = power_heuristic(1.0f, ls.pdf, 1.0f, pdf_bsdf);
                 direct_light = f * ls.li * std::fabs(dot(ls.w_i, bsdf.n)) * w / ls.pdf;
-                if (getenv("ORACLE_TRACE")) fprintf(stderr, "oracle    light half: f %.9g %.9g %.9g pdf_bsdf %.9g w %.9g -> %.9g %.9g %.9g\n", f.r, f.g, f.b, pdf_bsdf, w, direct_light.r, direct_light.g, direct_light.b);
+                if (oracle_trace()) fprintf(stderr, "oracle    light half: f %.9g %.9g %.9g pdf_bsdf %.9g w %.9g -> %.9g %.9g %.9g\n", f.r, f.g, f.b, pdf_bsdf, w, direct_light.r, direct_light.g, direct_light.b);
             }
         }
     }
@@ -162,7 +164,7 @@ Colorf estimate_direct(const SceneView& sv, Vec3 w_o, Vec3 p, const BSDF& bsdf, 
                 if (h.inst == light_inst)   // same emitter object (mod.rs:157-160)
                     li = emitter_radiance(sv, light, -w_i, h.ng, time);
             }
-            if (getenv("ORACLE_TRACE")) fprintf(stderr, "oracle    bsdf half: pdf_bsdf %.9g w %.9g f %.9g %.9g %.9g li %.9g %.9g %.9g\n", pdf_bsdf, w, f.r, f.g, f.b, li.r, li.g, li.b);
+            if (oracle_trace()) fprintf(stderr, "oracle    bsdf half: pdf_bsdf %.9g w %.9g f %.9g %.9g %.9g li %.9g %.9g %.9g\n", pdf_bsdf, w, f.r, f.g, f.b, li.r, li.g, li.b);
             if (!li.is_black()) direct_light = direct_light + f * li * std::fabs(dot(w_i, bsdf.n)) * w / pdf_bsdf;
         }
     }
@@ -199,7 +201,7 @@ Colorf path_illumination(const SceneView& sv, const Ray& r, const Hit& hit, cons
         if (li_idx > fs.n_lights - 1) li_idx = fs.n_lights - 1;
         Colorf li = estimate_direct(sv, w_o, current_hit.p, bsdf, l2, b2, b1, fs.lights[li_idx], BX_NON_SPECULAR, ray.time);
         illum = illum + path_throughput * li;
-        if (getenv("ORACLE_TRACE")) fprintf(stderr, "oracle  bounce %u inst %u mat %u li %.9g %.9g %.9g  throughput %.9g %.9g %.9g  illum %.9g %.9g %.9g\n", bounce, current_hit.inst,
+        if (oracle_trace()) fprintf(stderr, "oracle  bounce %u inst %u mat %u li %.9g %.9g %.9g  throughput %.9g %.9g %.9g  illum %.9g %.9g %.9g\n", bounce, current_hit.inst,
                                             inst.material_id, li.r, li.g, li.b, path_throughput.r, path_throughput.g, path_throughput.b, illum.r, illum.g, illum.b);
         if (g_vlog.sink)   // material (5 bits) | light query ran (32) | BSDF-half query ran (64)
             g_vlog.sink->push_back((uint8_t)((inst.material_id & 31u) | (g_vlog.light ? 32u : 0u) | (g_vlog.mis ? 64u : 0u)));
