@@ -225,19 +225,27 @@ def test_tile_megakernel_partial_queue_and_idle_workgroups(tmp_path, built):
     assert np.abs((a + b) - full).max() < 1e-4 * full.max()
 
 
+@pytest.fixture(scope="module")
+def tr15_dir(tmp_path_factory):
+    import pathlib
+    d = tmp_path_factory.mktemp("emu_tr15_small")
+    scenes.write_tr15_like_assets(str(d), film=(32, 24, 8), detail=0.02)
+    return pathlib.Path(str(d))
+
+
 WF_CASES = [("cornell_box", 0, 0, False), ("cornell_box", 0, 2, False), ("moving_box", 3, 0, False), ("moving_box", 3, 2, False),
             ("tr15_like", 330, 0, False), ("tr15_like", 330, 1, False), ("tr15_like", 330, 1, True)]
 
 
 @pytest.mark.parametrize("name,frame,trace,qwide", WF_CASES, ids=[f"{n}-{['dyn', 'wide', 'slot'][t]}{'-quantised' if q else ''}" for n, _, t, q in WF_CASES])
-def test_wavefront_schedule_emulated_as_simt(name, frame, trace, qwide, tmp_path, built):
+def test_wavefront_schedule_emulated_as_simt(name, frame, trace, qwide, tmp_path, tr15_dir, built):
     """The whole wavefront schedule -- k_wf_advance (film row bins, tile switch), k_wf_regen (camera samples, the per-path transform
     cache of moving scenes), the three traversal kernels in each of their forms, k_wf_begin, k_wf_query, ray queues -- round
     after round until every tile is done, as fibers on the host: the oracle's samples, vertices, rays and image."""
     w, h, spp = 32, 24, 8
     d = str(tmp_path)
     if name == "tr15_like":
-        scenes.write_tr15_like_assets(d, film=(w, h, spp), detail=0.02)     # 59 instances, splines, keyed lights, MERL
+        tmp_path = tr15_dir                                                  # 59 instances, splines, keyed lights, MERL
     elif name == "moving_box":
         scenes.write_moving_box(d, width=w, height=h, samples=spp)
     else:
