@@ -19,16 +19,19 @@ def _stale(so, deps):
     return not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps)
 
 
-def emu(qwide=False):
-    """libtrayemu.so (exact 128-B wide nodes) or libtrayemu_qwide.so (-DTR_QWIDE: the staged 64-B quantised nodes)"""
-    if qwide not in _libs:
-        so = os.path.join(EMU_DIR, "libtrayemu_qwide.so" if qwide else "libtrayemu.so")
+def emu(qwide=False, defines=()):
+    """libtrayemu.so (exact 128-B wide nodes), libtrayemu_qwide.so (-DTR_QWIDE: the staged 64-B quantised nodes), or a build with
+    other staged variant macros, e.g. defines=("TR_ALIGNED_QUERIES",)"""
+    defines = tuple(sorted(set(defines) | ({"TR_QWIDE"} if qwide else set())))
+    key = defines
+    if key not in _libs:
+        so = os.path.join(EMU_DIR, "libtrayemu" + "".join("_" + d.lower() for d in defines).replace("_tr_", "_") + ".so")
         deps = [os.path.join(EMU_DIR, f) for f in ("emu_kernels.cpp", "hip_emu.h")]
         deps += [os.path.join(HIP_DIR, f) for f in os.listdir(HIP_DIR) if f.endswith((".h", ".hip"))]
         deps += [os.path.join(ROOT, "tray_rust_amd", "csrc", "host", "wide_nodes.hpp"), os.path.join(ROOT, "include", "trayhip.h")]
         if _stale(so, deps):
             cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-attributes", "-shared", "-o", so,
-                   os.path.join(EMU_DIR, "emu_kernels.cpp")] + (["-DTR_QWIDE"] if qwide else [])
+                   os.path.join(EMU_DIR, "emu_kernels.cpp")] + ["-D" + d for d in defines]
             subprocess.run(cmd, check=True)
         h = C.CDLL(so)
         FS = C.POINTER(L.TrayFlatScene)
@@ -45,9 +48,9 @@ def emu(qwide=False):
         h.emu_render_tiles.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
         h.emu_render_wavefront.restype = C.c_int
         h.emu_render_wavefront.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
-        assert h.emu_is_qwide() == int(qwide)
-        _libs[qwide] = h
-    return _libs[qwide]
+        assert h.emu_is_qwide() == int("TR_QWIDE" in defines)
+        _libs[key] = h
+    return _libs[key]
 
 
 def debug_intersect(flat, rays, hit_dtype):
@@ -69,10 +72,10 @@ def wf_trace(flat, rays, kernel, stage, lds_depth=0, blocks=3, qwide=False):
     return hit.astype(bool), t, inst, prim
 
 
-def sample_radiance(flat, px, py, si, spp, seed):
+def sample_radiance(flat, px, py, si, spp, seed, defines=()):
     px = np.ascontiguousarray(px, np.uint32); py = np.ascontiguousarray(py, np.uint32); si = np.ascontiguousarray(si, np.uint32)
     out = np.zeros((len(px), 8), np.float32)
-    assert emu().emu_debug_sample_radiance(flat, len(px), px.ctypes.data, py.ctypes.data, si.ctypes.data, spp, seed, out.ctypes.data) == 0
+    assert emu(defines=defines).emu_debug_sample_radiance(flat, len(px), px.ctypes.data, py.ctypes.data, si.ctypes.data, spp, seed, out.ctypes.data) == 0
     return out
 
 
@@ -83,24 +86,24 @@ def bsdf(flat, material_id, flags_sel, dirs, u3):
     return out
 
 
-def render_tiles(flat, tiles_xy, spp, seed, blocks=1, coop=-1, film_rows=-1):
+def render_tiles(flat, tiles_xy, spp, seed, blocks=1, coop=-1, film_rows=-1, defines=()):
     """k_path_tiles over the given tiles as a SIMT emulation (fibers); returns (rgbw image, (samples, vertices, rays, feat))"""
     fs = flat.contents
     tiles_xy = np.ascontiguousarray(tiles_xy, np.uint32).reshape(-1, 2)
     img = np.zeros((fs.film.height, fs.film.width, 4), np.float32)
     stats = np.zeros(4, np.uint64)
-    rc = emu().emu_render_tiles(flat, tiles_xy.ctypes.data, len(tiles_xy), spp, seed, img.ctypes.data, blocks, coop, film_rows, stats.ctypes.data)
+    rc = emu(defines=defines).emu_render_tiles(flat, tiles_xy.ctypes.data, len(tiles_xy), spp, seed, img.ctypes.data, blocks, coop, film_rows, stats.ctypes.data)
     assert rc == 0, f"emu_render_tiles: {rc}"
     return img, tuple(int(x) for x in stats)
 
 
-def render_wavefront(flat, tiles_xy, spp, seed, trace=0, n_chunks=4, trace_blocks=2, lds_depth=0, qwide=False):
+def render_wavefront(flat, tiles_xy, spp, seed, trace=0, n_chunks=4, trace_blocks=2, lds_depth=0, qwide=False, defines=()):
     """the wavefront schedule (7 stage kernels per round) as SIMT emulations; returns (rgbw image, (samples, vertices, rays, rounds))"""
     fs = flat.contents
     tiles_xy = np.ascontiguousarray(tiles_xy, np.uint32).reshape(-1, 2)
     img = np.zeros((fs.film.height, fs.film.width, 4), np.float32)
     stats = np.zeros(4, np.uint64)
-    rc = emu(qwide).emu_render_wavefront(flat, tiles_xy.ctypes.data, len(tiles_xy), spp, seed, img.ctypes.data, trace, n_chunks, trace_blocks,
+    rc = emu(qwide, defines).emu_render_wavefront(flat, tiles_xy.ctypes.data, len(tiles_xy), spp, seed, img.ctypes.data, trace, n_chunks, trace_blocks,
                                          lds_depth, stats.ctypes.data)
     assert rc == 0, f"emu_render_wavefront: {rc}"
     return img, tuple(int(x) for x in stats)

@@ -29,7 +29,7 @@ o.oracle_path_profile.restype = C.c_int
 o.oracle_path_profile.argtypes = [C.POINTER(T._lib.TrayFlatScene), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
 rng = np.random.default_rng(1)
 tiles = [(int(rng.integers(40, 200)), int(rng.integers(20, 115))) for _ in range(n_tiles)]   # tiles that see the box
-tot = {"steps": 0, "today": 0, "compact": 0, "sorted": 0, "by_kind": 0, "jobs": 0, "alive": 0, "mixed": 0, "mixed_kind": 0}
+tot = {"steps": 0, "units_today": 0, "units_aligned": 0, "passes_aligned": 0, "today": 0, "compact": 0, "sorted": 0, "by_kind": 0, "jobs": 0, "alive": 0, "mixed": 0, "mixed_kind": 0}
 kind_of = [flat.contents.materials[m].kind for m in range(flat.contents.n_materials)]
 per_kind = {}
 per_mat = {}
@@ -48,6 +48,7 @@ for tx, ty in tiles:
                 break
             jobs_by_mat = {}
             n_light = n_alive = 0
+            kinds_in_pass = [set(), set(), set()]   # query kinds (LIGHT / MIS / PATH) that pass p of today's schedule has to run
             for lane in np.nonzero(live)[0]:
                 s = sample[lane]
                 if vertex[lane] < counts[lane, s]:
@@ -55,6 +56,9 @@ for tx, ty in tiles:
                     j = 1 + (1 if c & 32 else 0) + (1 if c & 64 else 0)
                     jobs_by_mat[c & 31] = jobs_by_mat.get(c & 31, 0) + j
                     n_light += 1 if c & 32 else 0
+                    seq = (["L"] if c & 32 else []) + (["M"] if c & 64 else []) + ["P"]   # the lane's own LIGHT -> MIS -> PATH sequence
+                    for p_, k_ in enumerate(seq):
+                        kinds_in_pass[p_].add(k_)
                     n_alive += 1
                     vertex[lane] += 1
                     if vertex[lane] >= counts[lane, s]:
@@ -66,6 +70,9 @@ for tx, ty in tiles:
             jobs = sum(jobs_by_mat.values())
             tot["steps"] += 1; tot["alive"] += n_alive; tot["jobs"] += jobs
             tot["today"] += 3 if n_light else 2
+            tot["units_today"] += sum(len(k) for k in kinds_in_pass)            # a pass runs the head / epilogue code of every kind present in it
+            tot["units_aligned"] += len(set().union(*kinds_in_pass))           # -DTR_ALIGNED_QUERIES: pass k serves kind k only
+            tot["passes_aligned"] += len(set().union(*kinds_in_pass))
             tot["compact"] += -(-jobs // 64)
             tot["sorted"] += sum(-(-j // 64) for j in jobs_by_mat.values())
             tot["mixed"] += 1 if len(jobs_by_mat) > 1 else 0
@@ -90,5 +97,7 @@ for m, (j, p) in sorted(per_mat.items()):
 print(f"  steps with more than one material KIND (= code path of the eval site): {100 * tot['mixed_kind'] / s:.0f} %")
 for k, (j, p) in sorted(per_kind.items()):
     print(f"  kind {kinds.get(k, '?')}: {100 * j / tot['jobs']:.0f} % of the jobs, {p / s:.2f} kind-pure passes per step")
+print(f"  query kinds run per step (each = that kind's sample head / epilogue once for the wave): today {tot['units_today'] / s:.2f} in {tot['today'] / s:.2f} passes, "
+      f"aligned schedule (-DTR_ALIGNED_QUERIES) {tot['units_aligned'] / s:.2f} in {tot['passes_aligned'] / s:.2f} passes")
 for k in ("today", "compact", "sorted", "by_kind"):
     print(f"  {k:8s} {tot[k] / s:.2f} passes per step, useful lanes {100 * tot['jobs'] / (64 * tot[k]):.0f} %")

@@ -282,8 +282,15 @@ template <int ANIM, int FEAT>
 TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
     const bool delta = sc.instances[ln.light_inst].kind == TRAY_INST_POINT_EMITTER;
     uint32_t want = ((ln.flags & LF_SHADOW) && !occluded) ? WANT_LIGHT : (delta ? WANT_PATH : WANT_MIS);
+#ifdef TR_ALIGNED_QUERIES   // staged variant (Next / C2): pass k serves only the lanes whose pending query is of kind k, so a pass runs one
+                           // kind's head and epilogue instead of up to two (the lanes' own sequences, hence the results, are unchanged)
+#pragma nounroll
+    for (uint32_t kind = WANT_LIGHT; kind <= WANT_PATH; ++kind)
+        if (want == kind) want = query_stage<ANIM, FEAT>(sc, ln, want);
+#else
 #pragma nounroll
     for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) want = query_stage<ANIM, FEAT>(sc, ln, want);   // LIGHT -> MIS -> PATH
+#endif
 }
 
 // Stage C: tail of the BSDF half of estimate_direct (mod.rs:154-166), then path.rs:82 and the
