@@ -36,9 +36,6 @@ using namespace tr;
 #ifndef TR_MIN_WAVES
 #define TR_MIN_WAVES 3
 #endif
-#ifndef TR_REGEN_MIN
-#define TR_REGEN_MIN 8
-#endif
 #define WIN_MAX 17          // 8 + 2*4 + 1 window columns/rows
 #define WIN_STRIDE 24       // row stride in floats: 4 rows of 8 lanes land on 32 distinct banks
 #define WIN_PLANE (WIN_MAX * WIN_STRIDE)
