@@ -2,6 +2,69 @@
 // time. Entry points mirror what the library does around the same kernels (scene upload, pool fields, queues, launch geometry).
 #include "hip_emu.h"
 
+#ifdef TR_EMU_PROFILE   // divergence profile: see hip_emu.h; block barriers are ignored (they separate tiles, not stages)
+#include <dlfcn.h>
+#include <map>
+#include <unordered_map>
+#define NOINSTR __attribute__((no_instrument_function))
+namespace hip_emu {
+struct ProfAgg { uint64_t lane_calls = 0, wave_calls = 0, lanes = 0, segments = 0; };
+struct ProfState {
+    std::unordered_map<void*, uint32_t> lane;                 // calls of the running lane in its current segment
+    std::unordered_map<void*, std::pair<uint32_t, uint64_t>> wave[MAX_THREADS / WAVE];   // fn -> (max over lanes, sum over lanes) in the wave's segment
+    std::unordered_map<void*, uint32_t> wave_lanes[MAX_THREADS / WAVE];
+    std::unordered_map<void*, ProfAgg> total;
+    bool on = false;
+};
+static ProfState g_prof;
+NOINSTR inline ProfState& prof() { return g_prof; }
+NOINSTR void prof_lane_done(uint32_t wave) {
+    ProfState& p = prof();
+    if (!p.on) return;
+    for (auto& kv : p.lane) {
+        auto& w = p.wave[wave][kv.first];
+        w.first = std::max(w.first, kv.second); w.second += kv.second;
+        p.wave_lanes[wave][kv.first] += 1;
+    }
+    p.lane.clear();
+}
+NOINSTR void prof_wave_done(uint32_t wave) {
+    ProfState& p = prof();
+    if (!p.on) return;
+    for (auto& kv : p.wave[wave]) {
+        ProfAgg& a = p.total[kv.first];
+        a.wave_calls += kv.second.first; a.lane_calls += kv.second.second; a.lanes += p.wave_lanes[wave][kv.first]; a.segments += 1;
+    }
+    p.wave[wave].clear(); p.wave_lanes[wave].clear();
+}
+}  // namespace hip_emu
+extern "C" {
+NOINSTR void __cyg_profile_func_enter(void* fn, void*) { hip_emu::ProfState& p = hip_emu::prof(); if (p.on && hip_emu::block().simt) ++p.lane[reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(fn) << 3) | (hip_emu::prof_phase & 7u))]; }
+NOINSTR void __cyg_profile_func_exit(void*, void*) {}
+NOINSTR void emu_profile_start(void) { hip_emu::ProfState& p = hip_emu::prof(); p.total.clear(); p.on = true; }
+// writes "lane_calls wave_calls lanes segments symbol" lines; returns the number of functions
+NOINSTR int emu_profile_dump(const char* path) {
+    hip_emu::ProfState& p = hip_emu::prof();
+    p.on = false;
+    FILE* f = std::fopen(path, "w");
+    if (!f) return -1;
+    std::unordered_map<void*, hip_emu::ProfAgg> by_fn;   // the phases of a function, added up
+    for (auto& kv : p.total) {
+        hip_emu::ProfAgg& a = by_fn[reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(kv.first) >> 3)];
+        a.lane_calls += kv.second.lane_calls; a.wave_calls += kv.second.wave_calls; a.lanes += kv.second.lanes; a.segments += kv.second.segments;
+    }
+    for (auto& kv : by_fn) {
+        Dl_info info;
+        const char* name = (dladdr(kv.first, &info) && info.dli_sname) ? info.dli_sname : "?";
+        std::fprintf(f, "%llu %llu %llu %llu %s\n", (unsigned long long)kv.second.lane_calls, (unsigned long long)kv.second.wave_calls,
+                     (unsigned long long)kv.second.lanes, (unsigned long long)kv.second.segments, name);
+    }
+    std::fclose(f);
+    return (int)by_fn.size();
+}
+}
+#endif
+
 #include "../../tray_rust_amd/csrc/hip/kernels.hip"
 
 namespace trayh { void set_error(const std::string&) {} }

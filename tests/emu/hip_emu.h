@@ -33,6 +33,12 @@
 #define __shared__ static
 #define __launch_bounds__(...)
 #define TR_DYN_LDS(T, name) T* const name = reinterpret_cast<T*>(hip_emu::dyn_lds())
+#ifdef TR_EMU_PROFILE
+namespace hip_emu { static uint32_t prof_phase = 0; }
+#define TR_EMU_PHASE(k) (hip_emu::prof_phase = (uint32_t)(k))   // calls made in different phases of a segment are not executed together
+#else
+#define TR_EMU_PHASE(k) ((void)0)
+#endif
 
 using std::isfinite; using std::isinf; using std::isnan; using std::max; using std::min;   // global in HIP device code
 
@@ -78,6 +84,18 @@ struct Block {
 inline Block& block() { static Block b; return b; }
 inline void* dyn_lds() { return block().lds.data(); }
 
+// ---- divergence profile (builds with -DTR_EMU_PROFILE -finstrument-functions, tools/divergence_profile.py): between two
+// rendezvous a lane runs one SEGMENT; a function the lanes of a wave call in the same segment would be executed together on
+// the device, as often as the lane that calls it most often. prof_lane_done() closes the calling lane's segment,
+// prof_wave_done() the wave's.
+#ifdef TR_EMU_PROFILE
+void prof_lane_done(uint32_t wave);
+void prof_wave_done(uint32_t wave);
+#else
+inline void prof_lane_done(uint32_t) {}
+inline void prof_wave_done(uint32_t) {}
+#endif
+
 inline void yield() { Block& b = block(); swapcontext(&b.fibers[b.current].ctx, &b.sched); }
 
 // all live lanes of the calling lane's wave contribute `mine`; returns after every one of them has arrived
@@ -90,7 +108,8 @@ inline void wave_exchange(uint64_t mine, uint64_t* all, uint64_t& present) {
     if (w.arrived == 0) w.present[buf] = 0;
     w.slots[buf][lane] = mine;
     w.present[buf] |= 1ull << lane;
-    if (++w.arrived == w.live) { w.arrived = 0; ++w.gen; ++b.progress; }
+    prof_lane_done(tid / WAVE);
+    if (++w.arrived == w.live) { w.arrived = 0; ++w.gen; ++b.progress; prof_wave_done(tid / WAVE); }
     else while (w.gen == my_gen) yield();
     std::memcpy(all, w.slots[buf], sizeof w.slots[buf]);
     present = w.present[buf];
@@ -98,6 +117,7 @@ inline void wave_exchange(uint64_t mine, uint64_t* all, uint64_t& present) {
 inline void block_barrier() {
     Block& b = block();
     const uint64_t my_gen = b.gen;
+    prof_lane_done(threadIdx.x / WAVE);
     if (++b.arrived == b.live) { b.arrived = 0; ++b.gen; ++b.progress; }
     else while (b.gen == my_gen) yield();
 }
@@ -105,6 +125,8 @@ inline void fiber_exit() {   // a thread that leaves the kernel no longer takes 
     Block& b = block();
     Wave& w = b.waves[threadIdx.x / WAVE];
     --w.live; --b.live; ++b.progress;
+    prof_lane_done(threadIdx.x / WAVE);
+    if (w.live == 0 || w.arrived == w.live) prof_wave_done(threadIdx.x / WAVE);
     if (w.live > 0 && w.arrived == w.live) { w.arrived = 0; ++w.gen; }
     if (b.live > 0 && b.arrived == b.live) { b.arrived = 0; ++b.gen; }
     b.fibers[b.current].done = true;

@@ -285,8 +285,17 @@ TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
 #ifdef TR_ALIGNED_QUERIES   // staged variant (Next / C2): pass k serves only the lanes whose pending query is of kind k, so a pass runs one
                            // kind's head and epilogue instead of up to two (the lanes' own sequences, hence the results, are unchanged)
 #pragma nounroll
-    for (uint32_t kind = WANT_LIGHT; kind <= WANT_PATH; ++kind)
+    for (uint32_t kind = WANT_LIGHT; kind <= WANT_PATH; ++kind) {
+        TR_EMU_PHASE(kind);
         if (want == kind) want = query_stage<ANIM, FEAT>(sc, ln, want);
+    }
+    TR_EMU_PHASE(0);
+#elif defined(TR_EMU_PROFILE)   // divergence-profile build of tests/emu: the default schedule, its passes numbered
+    for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) {
+        TR_EMU_PHASE(pass + 1);
+        want = query_stage<ANIM, FEAT>(sc, ln, want);
+    }
+    TR_EMU_PHASE(0);
 #else
 #pragma nounroll
     for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) want = query_stage<ANIM, FEAT>(sc, ln, want);   // LIGHT -> MIS -> PATH

@@ -13,6 +13,7 @@ namespace tr {
 #define TR_DEV __device__ __forceinline__
 #ifndef TR_HOST_EMU
 #define TR_DYN_LDS(T, name) extern __shared__ T name[]   // the workgroup's dynamic LDS (tests/emu supplies its own definition)
+#define TR_EMU_PHASE(k) ((void)0)   // numbers the passes of a loop whose iterations the lanes of a wave execute together; read by the host emulation's divergence profile only
 #endif
 
 static constexpr float kPi = 3.14159265358979323846f;
