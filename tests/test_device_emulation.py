@@ -325,3 +325,17 @@ def test_staged_variant_aligned_queries_changes_no_bit(name, tmp_path, built):
     assert sa == sb and a.tobytes() == b.tobytes()
     c, sc = E.render_wavefront(flat, tile_queue(w, h), spp, 4, trace=2, defines=V)
     assert sc[:3] == sa[:3] and float(np.sqrt(np.mean((rgb(c) - rgb(a)) ** 2))) < 2e-6
+
+
+def test_staged_variant_eager_loads_changes_no_bit(tmp_path, built):
+    """-DTR_WF_EAGER_LOADS (Next / C5: k_wf_advance requests every pool field it may need together with the flags
+    instead of in three dependent rounds): the wavefront schedule's image and counts are the default build's bit for bit."""
+    w, h, spp = 32, 24, 8
+    scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
+    scenes.write_moving_box(str(tmp_path), width=w, height=h, samples=spp)
+    for name, frame in (("smallpt", 0), ("moving_box", 3)):
+        scene, *_ = T.Scene.load_file(str(tmp_path / (name + ".json")))
+        flat = scene.flatten(frame)
+        a, sa = E.render_wavefront(flat, tile_queue(w, h), spp, 6, trace=0, n_chunks=5)
+        b, sb = E.render_wavefront(flat, tile_queue(w, h), spp, 6, trace=0, n_chunks=5, defines=("TR_WF_EAGER_LOADS",))
+        assert sa == sb and a.tobytes() == b.tobytes(), name
