@@ -298,12 +298,22 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
     make_scene(f, 0, e);
     bool moving = f->camera.animated != 0;
     for (uint32_t i = 0; i < f->n_instances; ++i) moving = moving || f->instances[i].animated != 0 || f->instances[i].emis_count >= 2;
-    if (moving || f->n_instances > TR_FLAT_MAX) return -4;   // the library runs other kernels for those
+    if (f->n_instances > TR_FLAT_MAX && !moving) return -4;   // the library runs the wavefront schedule for those
+    uint32_t n_moving = 0;
+    for (uint32_t i = 0; i < f->n_instances; ++i) if (f->instances[i].animated) ++n_moving;
+    std::vector<uint32_t> moving_ids(std::max(n_moving, 1u), 0u);
+    std::vector<float> xf_cache;
+    if (moving && n_moving) {   // per-path transform cache, one column per thread of the grid (tray_scene_create)
+        for (uint32_t i = 0; i < f->n_instances; ++i)
+            if (f->instances[i].animated && f->instances[i].moving_slot < n_moving) moving_ids[f->instances[i].moving_slot] = i;
+        xf_cache.assign((size_t)n_moving * 24u * blocks * TR_BLOCK, 0.0f);
+        e.d.xf_cache = xf_cache.data(); e.d.moving_ids = moving_ids.data(); e.d.n_moving = n_moving; e.d.xf_cache_lanes = blocks * TR_BLOCK;
+    }
     e.d.film_rows = (film_rows != 0 && film_rows_ok(f)) ? 1u : 0u;
     uint32_t stack_words = e.depth * TR_BLOCK;
     bool small_mesh = false;
     for (uint32_t m = 0; m < f->n_meshes; ++m) small_mesh = small_mesh || f->meshes[m].tri_count <= TR_COOP_MAX_TRIS;
-    if (coop != 0 && small_mesh) { e.d.coop_offset = stack_words; stack_words += (TR_BLOCK / 64) * TR_COOP_WORDS; }
+    if (coop != 0 && small_mesh && !moving) { e.d.coop_offset = stack_words; stack_words += (TR_BLOCK / 64) * TR_COOP_WORDS; }
     std::vector<uint2> tiles(tile_count);
     for (uint32_t i = 0; i < tile_count; ++i) tiles[i] = make_uint2(tiles_xy[2 * i], tiles_xy[2 * i + 1]);
     uint32_t counter = 0;
@@ -312,7 +322,9 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
     const uint32_t kf = key_frame_host(seed, e.d.frame);
     const int feat = feature_set(e);
     int rc;
-#define EMU_TILES(F) rc = launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<0, F>(e.d, tiles.data(), tile_count, tile_count ? tile_count : 1u, 1u, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
+#define EMU_TILES(F)                                                                                                                                              \
+    rc = moving ? launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<1, F>(e.d, tiles.data(), tile_count, tile_count ? tile_count : 1u, 1u, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4) \
+                : launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<0, F>(e.d, tiles.data(), tile_count, tile_count ? tile_count : 1u, 1u, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
     if (feat == FEAT_NONE) EMU_TILES(FEAT_NONE);
     else if (feat == FEAT_MERL) EMU_TILES(FEAT_MERL);
     else if (feat == FEAT_SPEC) EMU_TILES(FEAT_SPEC);

@@ -339,3 +339,17 @@ def test_staged_variant_eager_loads_changes_no_bit(tmp_path, built):
         a, sa = E.render_wavefront(flat, tile_queue(w, h), spp, 6, trace=0, n_chunks=5)
         b, sb = E.render_wavefront(flat, tile_queue(w, h), spp, 6, trace=0, n_chunks=5, defines=("TR_WF_EAGER_LOADS",))
         assert sa == sb and a.tobytes() == b.tobytes(), name
+
+
+def test_tile_megakernel_of_moving_scenes_emulated_as_simt(tmp_path, built):
+    """k_path_tiles<ANIM = 1>: the spline stacks of the moving instances are evaluated once per camera sample into the per-thread
+    transform cache (xf_cache_fill) and read back by traversal, hit finishing and light sampling"""
+    w, h, spp = 32, 24, 8
+    scenes.write_moving_box(str(tmp_path), width=w, height=h, samples=spp)
+    scene, *_ = T.Scene.load_file(str(tmp_path / "moving_box.json"))
+    flat = scene.flatten(3)
+    assert flat.contents.animated and flat.contents.n_instances <= 16
+    img, (samples, vertices, rays, _) = E.render_tiles(flat, tile_queue(w, h), spp, 2, blocks=2)
+    ref, st = O.render_tiles(flat, spp, seed=2)
+    assert samples == st.samples and abs(vertices - st.vertices) <= 2e-3 * st.vertices and abs(rays - st.rays) <= 2e-3 * st.rays
+    assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-3 and np.abs(img[..., 3] - ref[..., 3]).max() < 1e-4 * ref[..., 3].max()
