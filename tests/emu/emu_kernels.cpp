@@ -75,6 +75,7 @@ struct EmuScene {
     DevScene d{};
     std::vector<DevMaterial> mats;
     std::vector<uint32_t> wide_words, wide_roots;
+    std::vector<TrayBvhNode> inst_leaf;
     uint32_t depth = 0;   // traversal stack entries per lane, as tray_scene_create sizes them (two-level worst case, generous)
 };
 
@@ -106,6 +107,12 @@ void make_scene(const TrayFlatScene* f, int wide_format, EmuScene& e) {
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
     d.camera = f->camera;
+#ifdef TR_EXACT_FLAT
+    e.inst_leaf.assign(f->n_instances, TrayBvhNode{});
+    for (uint32_t nd = 0; nd < f->n_top_nodes; ++nd)
+        for (uint32_t k = 0; k < f->top_nodes[nd].count; ++k) e.inst_leaf[f->top_order[f->top_nodes[nd].offset + k]] = f->top_nodes[nd];
+    d.inst_leaf = e.inst_leaf.data();
+#endif
     uint32_t mesh_depth = 0;
     for (uint32_t m = 0; m < f->n_meshes; ++m) mesh_depth = std::max(mesh_depth, bvh_depth(f->mesh_nodes + f->meshes[m].node_offset, f->meshes[m].node_count));
     e.depth = mesh_depth + bvh_depth(f->top_nodes, f->n_top_nodes) + 8u;

@@ -353,3 +353,29 @@ def test_tile_megakernel_of_moving_scenes_emulated_as_simt(tmp_path, built):
     ref, st = O.render_tiles(flat, spp, seed=2)
     assert samples == st.samples and abs(vertices - st.vertices) <= 2e-3 * st.vertices and abs(rays - st.rays) <= 2e-3 * st.rays
     assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-3 and np.abs(img[..., 3] - ref[..., 3]).max() < 1e-4 * ref[..., 3].max()
+
+
+def test_staged_variant_exact_flat_loop_closes_the_deviation_class(tmp_path, built):
+    """-DTR_EXACT_FLAT: the flat instance loop also tests the box of the instance's BVH<Instance> leaf, as the
+    reference's traversal does on the way to it. The two samples of the 300-scene sweep that differ in the default build (seeds
+    148 and 323: an occlusion ray grazing the wall it starts on) come out bit-identical, and so does everything else."""
+    import _random_scenes as R
+    V = ("TR_EXACT_FLAT",)
+    d = str(tmp_path)
+    for seed, (x, y, s_) in ((148, (32, 18, 6)), (323, (28, 5, 0))):
+        scene, *_ = T.Scene.load_file(R.write_random_scene(d, seed))
+        flat = scene.flatten(0)
+        rng = np.random.default_rng(seed)
+        n = 1500
+        px = rng.integers(0, 64, n).astype(np.uint32); py = rng.integers(0, 48, n).astype(np.uint32); si = rng.integers(0, 8, n).astype(np.uint32)
+        px[0], py[0], si[0] = x, y, s_
+        a = O.sample_radiance(flat, px, py, si, 8, seed=seed + 1)
+        assert a.tobytes() != E.sample_radiance(flat, px, py, si, 8, seed + 1).tobytes()          # the default build drops that sample's light
+        assert a.tobytes() == E.sample_radiance(flat, px, py, si, 8, seed + 1, defines=V).tobytes()
+    w, h, spp = 32, 24, 8
+    scenes.write_assets(d, cornell=(w, h, spp), small=(w, h, spp))
+    scene, *_ = T.Scene.load_file(str(tmp_path / "cornell_box.json"))
+    flat = scene.flatten(0)
+    img, st = E.render_tiles(flat, tile_queue(w, h), spp, 7, defines=V)      # with the cooperative small-mesh test behind the box test
+    ref, ost = O.render_tiles(flat, spp, seed=7)
+    assert st[:3] == (ost.samples, ost.vertices, ost.rays) and float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6

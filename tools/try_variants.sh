@@ -4,13 +4,14 @@
 #   qwide    -DTR_QWIDE            64-B quantised 4-wide BVH<Triangle> nodes in the wavefront traversal (needs TRAYHIP_WF_WIDE=1)
 #   aq       -DTR_ALIGNED_QUERIES  BSDF query passes aligned by query kind (tile kernel and k_wf_query)
 #   eager    -DTR_WF_EAGER_LOADS   k_wf_advance requests all its pool fields in one round
-#   build:   for v in qwide:-DTR_QWIDE aq:-DTR_ALIGNED_QUERIES eager:-DTR_WF_EAGER_LOADS; do make -C tray_rust_amd/csrc OUT=../libtrayhip_${v%%:*}.so KOBJ=hip/kernels_${v%%:*}.o EXTRA_HIPFLAGS=${v##*:}; done
+#   exact    -DTR_EXACT_FLAT       the flat instance loop tests the BVH<Instance> leaf box too (closes the deviation class; costs a slab test per instance)
+#   build:   tools/build_variants.sh
 #   run:     gpurun --timeout 1200 -- 'bash tools/try_variants.sh'
 # 1. the GPU parity suite against each variant library, 2. the four workloads at 64 spp, default library vs variant (Msamples/s).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$ROOT/gpurun_out/variants; mkdir -p "$OUT"
 cd "$ROOT"
-for v in aq qwide eager; do
+for v in aq qwide eager exact; do
   V=$ROOT/tray_rust_amd/libtrayhip_$v.so
   [ -f "$V" ] || { echo "variant $v not built (see the header of this script)"; continue; }
   EXTRA=""; [ $v = qwide ] && EXTRA="TRAYHIP_WF_WIDE=1"
@@ -20,6 +21,7 @@ done
 for wl in cornell_box smallpt dragon tr15_like; do
   echo "== $wl default"; timeout 300 python tools/bench_small.py 64 2 $wl 2>&1 | tail -2 | tee "$OUT/${wl}_default.log"
   echo "== $wl aq";      TRAYHIP_LIB=$ROOT/tray_rust_amd/libtrayhip_aq.so timeout 300 python tools/bench_small.py 64 2 $wl 2>&1 | tail -2 | tee "$OUT/${wl}_aq.log"
+  [ $wl != tr15_like ] && { echo "== $wl exact"; TRAYHIP_LIB=$ROOT/tray_rust_amd/libtrayhip_exact.so timeout 300 python tools/bench_small.py 64 2 $wl 2>&1 | tail -2 | tee "$OUT/${wl}_exact.log"; }
 done
 for wl in tr15_like; do
   echo "== $wl eager";   TRAYHIP_LIB=$ROOT/tray_rust_amd/libtrayhip_eager.so timeout 300 python tools/bench_small.py 64 2 $wl 2>&1 | tail -2 | tee "$OUT/${wl}_eager.log"

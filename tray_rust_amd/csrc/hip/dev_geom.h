@@ -65,6 +65,9 @@ struct DevScene {
     uint32_t coop_offset;   // word offset of the cooperative leaf test's LDS area behind the traversal stacks (0 = none)
     const float* __restrict__ wide_nodes;          // 4-wide collapse of every BVH<Triangle>, 32 floats per node (wavefront_wide.h); may be null
     const uint32_t* __restrict__ mesh_wide_root;   // per mesh: index of its root's wide node
+#ifdef TR_EXACT_FLAT
+    const TrayBvhNode* __restrict__ inst_leaf;     // per instance: the BVH<Instance> leaf node that holds it (staged variant, trace_flat)
+#endif
     float filter_w, filter_h, inv_w, inv_h;
     int32_t fpw, fph;
     TrayCamera camera;
@@ -357,6 +360,12 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
     float max_t = ray.max_t;
     bool any = false, done = !active;   // lanes without a ray run along: the cooperative leaf test uses their ALUs
     const uint32_t n = sc.n_instances;
+#ifdef TR_EXACT_FLAT   // staged variant: the reference reaches an instance only through the box of its BVH<Instance> leaf (bvh.rs:89-98); a box
+                       // that contains a hit box is hit, so testing the leaf's box here reproduces every drop of that traversal -- the
+                       // grazing rays along zero-thickness boxes that make up the flat loop's deviation class
+    const f3 w_inv_dir = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    const bool wnx = ray.d.x < 0.0f, wny = ray.d.y < 0.0f, wnz = ray.d.z < 0.0f;
+#endif
     for (uint32_t i = 0; i < n; ++i) {
         // the instance index is wave-uniform: read the record through the constant address space so the
         // transform and the geometry parameters arrive as scalar loads (SGPRs), not 64 identical lane loads
@@ -376,11 +385,19 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
         bool hit = false;
         uint32_t prim = 0u;
         float b1 = 0.0f, b2 = 0.0f;
+#ifdef TR_EXACT_FLAT
+        typedef const __attribute__((address_space(4))) float* ConstBox;   // (scalar loads, like the instance record)
+        ConstBox lb = (ConstBox)(sc.inst_leaf + i);
+        const float4 leaf_lo = make_float4(lb[0], lb[1], lb[2], lb[3]), leaf_hi = make_float4(lb[4], lb[5], lb[6], lb[7]);
+        const bool wanted = !done && bbox_hit(leaf_lo, leaf_hi, ray.o, w_inv_dir, wnx, wny, wnz, min_t, max_t);
+#else
+        const bool wanted = !done;
+#endif
         if (gt == TRAY_GEOM_MESH && sc.coop_offset != 0u && sc.meshes[mesh_id].tri_count <= TR_COOP_MAX_TRIS) {
             // small mesh: the whole wave enters, lanes without a pending ray only lend their ALUs
             volatile float* w_lds = reinterpret_cast<volatile float*>(stack - threadIdx.x + sc.coop_offset) + (threadIdx.x >> 6) * TR_COOP_WORDS;
-            hit = mesh_leaf_coop(sc, sc.meshes[mesh_id], w_lds, !done, o, d, min_t, t, prim, b1, b2);
-        } else if (!done) {
+            hit = mesh_leaf_coop(sc, sc.meshes[mesh_id], w_lds, wanted, o, d, min_t, t, prim, b1, b2);
+        } else if (wanted) {
             if (gt == TRAY_GEOM_RECT) hit = rect_test(gp0, gp1, o, d, min_t, max_t, t);
             else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(gp0, o, d, min_t, max_t, t);
             else if (gt == TRAY_GEOM_MESH) hit = mesh_traverse(sc, stack, sc.meshes[mesh_id], o, d, min_t, t, any_hit, prim, b1, b2);

@@ -703,6 +703,17 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             s->wf_wide = rc == TRAY_OK;
         }
     }
+#ifdef TR_EXACT_FLAT   // variant build: the BVH<Instance> leaf of every instance, for the leaf-box test of the flat loop (dev_geom.h)
+    if (rc == TRAY_OK) {
+        std::vector<TrayBvhNode> leaf(f->n_instances);
+        std::memset(leaf.data(), 0, leaf.size() * sizeof(TrayBvhNode));
+        for (uint32_t nd = 0; nd < f->n_top_nodes; ++nd)
+            for (uint32_t k = 0; k < f->top_nodes[nd].count; ++k) leaf[f->top_order[f->top_nodes[nd].offset + k]] = f->top_nodes[nd];
+        const TrayBvhNode* d_leaf = nullptr;
+        rc = upload(s, leaf.data(), leaf.size(), &d_leaf);
+        d.inst_leaf = d_leaf;
+    }
+#endif
     if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
     s->n_materials = f->n_materials;
     d.n_instances = f->n_instances; d.n_lights = f->n_lights; d.min_depth = f->min_depth; d.max_depth = f->max_depth;
