@@ -379,3 +379,19 @@ def test_staged_variant_exact_flat_loop_closes_the_deviation_class(tmp_path, bui
     img, st = E.render_tiles(flat, tile_queue(w, h), spp, 7, defines=V)      # with the cooperative small-mesh test behind the box test
     ref, ost = O.render_tiles(flat, spp, seed=7)
     assert st[:3] == (ost.samples, ost.vertices, ost.rays) and float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6
+
+
+def test_staged_variant_two_children_mesh_step_changes_no_bit(tmp_path, built):
+    """-DTR_MESH_TWO_CHILDREN (Next / C4: mesh_traverse of the tile kernel with the node step of k_wf_trace_dyn)"""
+    w, h, spp = 32, 24, 8
+    scenes.write_dragon_assets(str(tmp_path), film=(w, h, spp), grid=32, extent=1.0)
+    scene, *_ = T.Scene.load_file(str(tmp_path / "dragon.json"))
+    flat = scene.flatten(0)
+    V = ("TR_MESH_TWO_CHILDREN",)
+    rng = np.random.default_rng(3)
+    n = 5000
+    px = rng.integers(0, w, n).astype(np.uint32); py = rng.integers(0, h, n).astype(np.uint32); si = rng.integers(0, spp, n).astype(np.uint32)
+    assert O.sample_radiance(flat, px, py, si, spp, seed=8).tobytes() == E.sample_radiance(flat, px, py, si, spp, 8, defines=V).tobytes()
+    a, sa = E.render_tiles(flat, tile_queue(w, h), spp, 8)
+    b, sb = E.render_tiles(flat, tile_queue(w, h), spp, 8, defines=V)
+    assert sa == sb and a.tobytes() == b.tobytes()

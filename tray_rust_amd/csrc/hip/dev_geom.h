@@ -242,8 +242,45 @@ TR_DEV bool mesh_traverse(const DevScene& sc, uint32_t* __restrict__ stack, cons
     f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
     int sp = 0;
-    uint32_t current = 0;
     bool any = false;
+#ifdef TR_MESH_TWO_CHILDREN   // staged variant (Next / C4): the node step of k_wf_trace_dyn -- both children of a hit node are fetched and
+                              // tested together, the far one is pushed only if its box is hit now and is re-tested when popped, so the accepted
+                              // candidates and their order are the reference's (bvh.rs:89-127) in about 0.65x the dependent iterations
+    const uint32_t no_node = 0xffffffffu;
+    uint32_t node_a = 0u, node_b = no_node;
+    for (;;) {
+        const bool two = node_b != no_node;
+        const float4* qa = reinterpret_cast<const float4*>(tree + node_a);
+        const float4* qb = reinterpret_cast<const float4*>(tree + (two ? node_b : node_a));
+        const float4 alo = qa[0], ahi = qa[1], blo = qb[0], bhi = qb[1];
+        const bool ha = bbox_hit(alo, ahi, o, inv_dir, nx, ny, nz, min_t, max_t);
+        const bool hb = two && bbox_hit(blo, bhi, o, inv_dir, nx, ny, nz, min_t, max_t);
+        if (ha || hb) {
+            if (ha && hb) { stack[sp * TR_BLOCK] = node_b; ++sp; }
+            const uint32_t cur = ha ? node_a : node_b;
+            const uint32_t offset = __float_as_uint(ha ? ahi.z : bhi.z);
+            const uint32_t meta = __float_as_uint(ha ? ahi.w : bhi.w);
+            const uint32_t count = meta & 0xffffu, axis = (meta >> 16) & 0xffu;
+            if (count == 0u) {
+                const bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
+                node_a = neg ? offset : cur + 1u;
+                node_b = neg ? cur + 1u : offset;
+                continue;
+            }
+            for (uint32_t k = 0; k < count; ++k) {
+                float t, bb1, bb2;
+                if (triangle_test(tris + offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
+                    max_t = t; prim = m.tri_offset + offset + k; b1 = bb1; b2 = bb2; any = true;
+                    if (any_hit) return true;
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        node_a = stack[sp * TR_BLOCK]; node_b = no_node;
+    }
+#else
+    uint32_t current = 0;
     for (;;) {
         const float4* nq = reinterpret_cast<const float4*>(tree + current);
         float4 lo = nq[0], hi = nq[1];
@@ -270,6 +307,7 @@ TR_DEV bool mesh_traverse(const DevScene& sc, uint32_t* __restrict__ stack, cons
         --sp;
         current = stack[sp * TR_BLOCK];
     }
+#endif
     return any;
 }
 
