@@ -45,7 +45,7 @@ def emu(qwide=False, defines=()):
         h.emu_debug_bsdf.restype = C.c_int
         h.emu_debug_bsdf.argtypes = [FS, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         h.emu_render_tiles.restype = C.c_int
-        h.emu_render_tiles.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+        h.emu_render_tiles.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         h.emu_render_wavefront.restype = C.c_int
         h.emu_render_wavefront.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         assert h.emu_is_qwide() == int("TR_QWIDE" in defines)
@@ -86,13 +86,13 @@ def bsdf(flat, material_id, flags_sel, dirs, u3):
     return out
 
 
-def render_tiles(flat, tiles_xy, spp, seed, blocks=1, coop=-1, film_rows=-1, defines=()):
+def render_tiles(flat, tiles_xy, spp, seed, blocks=1, coop=-1, film_rows=-1, defines=(), shard=(0, 0, 1)):
     """k_path_tiles over the given tiles as a SIMT emulation (fibers); returns (rgbw image, (samples, vertices, rays, feat))"""
     fs = flat.contents
     tiles_xy = np.ascontiguousarray(tiles_xy, np.uint32).reshape(-1, 2)
     img = np.zeros((fs.film.height, fs.film.width, 4), np.float32)
     stats = np.zeros(4, np.uint64)
-    rc = emu(defines=defines).emu_render_tiles(flat, tiles_xy.ctypes.data, len(tiles_xy), spp, seed, img.ctypes.data, blocks, coop, film_rows, stats.ctypes.data)
+    rc = emu(defines=defines).emu_render_tiles(flat, tiles_xy.ctypes.data, len(tiles_xy), spp, seed, img.ctypes.data, blocks, coop, film_rows, stats.ctypes.data, *shard)
     assert rc == 0, f"emu_render_tiles: {rc}"
     return img, tuple(int(x) for x in stats)
 

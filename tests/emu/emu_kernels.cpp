@@ -299,8 +299,10 @@ int emu_wf_trace(const TrayFlatScene* f, int kernel, int stage, uint32_t n, cons
 // launch_tiles does (feature set, row-binned film and cooperative small-mesh test chosen as tray_scene_create chooses them),
 // as a SIMT emulation: 256 fibers per workgroup, wave intrinsics and barriers are rendezvous. rgbw is accumulated into.
 // coop / film_rows: -1 = as the library decides, 0 = off. Returns 0, or -3 if a rendezvous could not complete.
+// shard / n_shards / chunk_tiles: the launch tray_render_shard_device makes for one rank (chunks shard, shard + n_shards, ... of chunk_tiles
+// tiles each); n_shards = 0 renders the whole queue given.
 int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t tile_count, uint32_t spp, uint64_t seed, float* rgbw,
-                     uint32_t blocks, int coop, int film_rows, unsigned long long* stats_out) {
+                     uint32_t blocks, int coop, int film_rows, unsigned long long* stats_out, uint32_t shard, uint32_t n_shards, uint32_t chunk_tiles) {
     EmuScene e;
     make_scene(f, 0, e);
     bool moving = f->camera.animated != 0;
@@ -323,6 +325,17 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
     if (coop != 0 && small_mesh && !moving) { e.d.coop_offset = stack_words; stack_words += (TR_BLOCK / 64) * TR_COOP_WORDS; }
     std::vector<uint2> tiles(tile_count);
     for (uint32_t i = 0; i < tile_count; ++i) tiles[i] = make_uint2(tiles_xy[2 * i], tiles_xy[2 * i + 1]);
+    // work-item mapping of launch_tiles: item w -> queue entry (w / chunk) * chunk_stride * chunk + (w % chunk), from tile_start on
+    uint32_t tile_start = 0, work = tile_count, chunk = tile_count ? tile_count : 1u, chunk_stride = 1u;
+    if (n_shards) {   // tray_render_shard_device
+        const uint32_t n_chunks = (tile_count + chunk_tiles - 1) / chunk_tiles;
+        const uint32_t my_chunks = shard < n_chunks ? (n_chunks - shard + n_shards - 1) / n_shards : 0;
+        if (my_chunks == 0) { if (stats_out) stats_out[0] = stats_out[1] = stats_out[2] = stats_out[3] = 0; return 0; }
+        const uint32_t last_chunk = shard + (my_chunks - 1) * n_shards;
+        uint32_t tail = tile_count - last_chunk * chunk_tiles;
+        if (tail > chunk_tiles) tail = chunk_tiles;
+        tile_start = shard * chunk_tiles; work = (my_chunks - 1) * chunk_tiles + tail; chunk = chunk_tiles; chunk_stride = n_shards;
+    }
     uint32_t counter = 0;
     DevStats stats;
     std::memset(&stats, 0, sizeof stats);
@@ -330,8 +343,8 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
     const int feat = feature_set(e);
     int rc;
 #define EMU_TILES(F)                                                                                                                                              \
-    rc = moving ? launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<1, F>(e.d, tiles.data(), tile_count, tile_count ? tile_count : 1u, 1u, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4) \
-                : launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<0, F>(e.d, tiles.data(), tile_count, tile_count ? tile_count : 1u, 1u, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
+    rc = moving ? launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<1, F>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4) \
+                : launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<0, F>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
     if (feat == FEAT_NONE) EMU_TILES(FEAT_NONE);
     else if (feat == FEAT_MERL) EMU_TILES(FEAT_MERL);
     else if (feat == FEAT_SPEC) EMU_TILES(FEAT_SPEC);

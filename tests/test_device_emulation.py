@@ -395,3 +395,30 @@ def test_staged_variant_two_children_mesh_step_changes_no_bit(tmp_path, built):
     a, sa = E.render_tiles(flat, tile_queue(w, h), spp, 8)
     b, sb = E.render_tiles(flat, tile_queue(w, h), spp, 8, defines=V)
     assert sa == sb and a.tobytes() == b.tobytes()
+
+
+def test_sharded_launches_of_the_tile_kernel_partition_the_frame(tmp_path, built):
+    """tray_render_shard_device's launch (chunks shard, shard + n, ... of the Morton queue; work item -> queue entry mapping inside
+    k_path_tiles) for 3 ranks with 5-tile chunks: the shards render exactly the tiles tray_shard_tiles enumerates and add up to
+    the whole frame -- the multi-GPU data path minus the RCCL sum."""
+    from tray_rust_amd import multi
+    w, h, spp = 48, 32, 4
+    scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
+    scene, *_ = T.Scene.load_file(str(tmp_path / "cornell_box.json"))
+    flat = scene.flatten(0)
+    q = tile_queue(w, h)
+    full, sf = E.render_tiles(flat, q, spp, 9, blocks=2)
+    total = np.zeros_like(full)
+    samples = 0
+    for rank in range(3):
+        part, sp_ = E.render_tiles(flat, q, spp, 9, blocks=2, shard=(rank, 3, 5))
+        mine = multi.shard_tiles(len(q), rank, 3, 5)
+        assert sp_[0] == len(mine) * 64 * spp
+        touched = np.zeros((h, w), bool)
+        for t in mine:
+            x, y = int(q[t][0]), int(q[t][1])
+            touched[max(0, y * 8 - 4):y * 8 + 13, max(0, x * 8 - 4):x * 8 + 13] = True     # tile + filter halo
+        assert not part[~touched].any()
+        total += part; samples += sp_[0]
+    assert samples == sf[0] == w * h * spp
+    assert np.abs(total - full).max() < 1e-4 * full.max()

@@ -40,7 +40,7 @@ subprocess.run(["g++", "-O1", "-fno-inline", "-finstrument-functions", "-finstru
 lib = C.CDLL(so)
 FS = C.POINTER(T._lib.TrayFlatScene)
 lib.emu_render_tiles.restype = C.c_int
-lib.emu_render_tiles.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+lib.emu_render_tiles.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
 lib.emu_render_wavefront.restype = C.c_int
 lib.emu_render_wavefront.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
 lib.emu_profile_dump.argtypes = [C.c_char_p]
@@ -58,7 +58,7 @@ lib.emu_profile_start()
 if args.wavefront:
     rc = lib.emu_render_wavefront(flat, tiles.ctypes.data, len(tiles), spp, 1, img.ctypes.data, 0, 8, 2, 0, stats.ctypes.data)
 else:
-    rc = lib.emu_render_tiles(flat, tiles.ctypes.data, len(tiles), spp, 1, img.ctypes.data, 1, -1, -1, stats.ctypes.data)
+    rc = lib.emu_render_tiles(flat, tiles.ctypes.data, len(tiles), spp, 1, img.ctypes.data, 1, -1, -1, stats.ctypes.data, 0, 0, 1)
 assert rc == 0, rc
 dump = os.path.join(d, "profile.txt")
 assert lib.emu_profile_dump(dump.encode()) > 0
