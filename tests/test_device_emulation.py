@@ -422,3 +422,21 @@ def test_sharded_launches_of_the_tile_kernel_partition_the_frame(tmp_path, built
         total += part; samples += sp_[0]
     assert samples == sf[0] == w * h * spp
     assert np.abs(total - full).max() < 1e-4 * full.max()
+
+
+@pytest.mark.parametrize("w,h,spp,max_depth", [(8, 8, 1, 0), (16, 8, 2, 1), (8, 16, 1, 5), (24, 8, 4, 0)])
+def test_smallest_films_sample_counts_and_depths(w, h, spp, max_depth, tmp_path, built):
+    """Edge sizes: one-tile films, 1 / 2 samples per pixel (waves of the tile kernel without a sample, pool slots without one),
+    max_depth 0 (the path ends at its first vertex) -- both schedules against the oracle."""
+    import json
+    scenes.write_assets(str(tmp_path))
+    for make in (scenes.cornell_box, scenes.smallpt):
+        desc = make(w, h, spp)
+        desc["integrator"] = {"type": "pathtracer", "min_depth": 0, "max_depth": max_depth}
+        json.dump(desc, open(tmp_path / "x.json", "w"))
+        scene, *_ = T.Scene.load_file(str(tmp_path / "x.json"))
+        flat = scene.flatten(0)
+        ref, st = O.render_tiles(flat, spp, seed=3)
+        for img, s_ in (E.render_tiles(flat, tile_queue(w, h), spp, 3, blocks=2), E.render_wavefront(flat, tile_queue(w, h), spp, 3, trace=0, n_chunks=2)):
+            assert s_[:3] == (st.samples, st.vertices, st.rays)
+            assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6
