@@ -1,0 +1,51 @@
+"""Torch-free A/B of library builds in seconds: renders prepared scenes through the C ABI and prints Msamples/s from the library's
+own HIP events (tray_last_timing). One process per library (TRAYHIP_LIB is read at import):
+    python tools/mini_ab.py prepare <dir>                 # writes the scenes once
+    TRAYHIP_LIB=... python tools/mini_ab.py run <dir> <label> cornell_box:64 dragon:32 tr15_like:16 ...
+Also prints the pixel RMSE of each render against the first library's result stored in <dir> (parity of the variant on the GPU)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import tray_rust_amd as T
+from tray_rust_amd import scenes
+
+W, H = 1920, 1080
+mode, d = sys.argv[1], sys.argv[2]
+if mode == "prepare":
+    scenes.write_assets(d, cornell=(W, H, 64), small=(W, H, 64))
+    scenes.write_dragon_assets(d, film=(W, H, 32), grid=220, extent=0.2)          # 96 800 triangles: loads in a second
+    scenes.write_tr15_like_assets(os.path.join(d, "tr15"), film=(W, H, 16), detail=0.15)   # own directory: it brings its own models/
+    sys.exit(0)
+label = sys.argv[3]
+hip = T.Hip(device=0, seed=1)
+for item in sys.argv[4:]:
+    name, spp = item.split(":")
+    spp = int(spp)
+    frame = 330 if name == "tr15_like" else 0
+    t0 = time.time()
+    scene, rt, _, fi = T.Scene.load_file(os.path.join(d, "tr15" if name == "tr15_like" else "", name + ".json"))
+    if frame:
+        fi = T.FrameInfo(fi.frames, fi.time, frame, frame)   # Config.current_frame = frame_info.start
+    best = 0.0
+    for rep in range(2):
+        rt.clear()
+        sys.stdout = open(os.devnull, "w")
+        try:
+            hip.render(scene, rt, T.Config(d, name, spp, 1, fi, (0, 0)))
+        finally:
+            sys.stdout = sys.__stdout__
+        t = hip.last_timing
+        best = max(best, t.samples / (t.render_ms * 1e-3) / 1e6)
+    img = rt.get_renderf32().reshape(H, W, 4)
+    rgb = img[..., :3] / np.maximum(img[..., 3:], 1e-20)
+    ref_path = os.path.join(d, f"ref_{name}.npy")
+    if os.path.exists(ref_path):
+        ref = np.load(ref_path)
+        r = float(np.sqrt(np.mean((rgb - ref) ** 2)))
+    else:
+        np.save(ref_path, rgb); r = 0.0
+    print(f"{label:8s} {name:12s} {spp:3d} spp  {best:8.1f} Msamples/s  launches {t.launches:4d}  RMSE vs first {r:.2e}  (load+render {time.time() - t0:.1f}s)", flush=True)
