@@ -4,12 +4,12 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; cd "$ROOT"; D=/tmp/mini_ab; mkdir -p gpurun_out
 L=$ROOT/tray_rust_amd
 {
-python tools/mini_ab.py prepare $D
-python tools/mini_ab.py run $D default cornell_box:64 dragon:32 tr15_like:16
-TRAYHIP_LIB=$L/libtrayhip_aq.so    python tools/mini_ab.py run $D aq cornell_box:64 dragon:32 tr15_like:16
-TRAYHIP_LIB=$L/libtrayhip_m2c.so   python tools/mini_ab.py run $D m2c dragon:32
-TRAYHIP_LIB=$L/libtrayhip_exact.so python tools/mini_ab.py run $D exact cornell_box:64 dragon:32
-TRAYHIP_LIB=$L/libtrayhip_eager.so python tools/mini_ab.py run $D eager tr15_like:16
-TRAYHIP_LIB=$L/libtrayhip_qwide.so TRAYHIP_WF_WIDE=1 python tools/mini_ab.py run $D qwide tr15_like:16
-TRAYHIP_MODE=wave python tools/mini_ab.py run $D wave dragon:32
+timeout 15 python tools/mini_ab.py prepare $D
+timeout 10 python tools/mini_ab.py run $D default cornell_box:64 dragon:32 tr15_like:16
+TRAYHIP_LIB=$L/libtrayhip_aq.so    timeout 10 python tools/mini_ab.py run $D aq cornell_box:64 dragon:32 tr15_like:16
+TRAYHIP_LIB=$L/libtrayhip_m2c.so   timeout 10 python tools/mini_ab.py run $D m2c dragon:32
+TRAYHIP_LIB=$L/libtrayhip_exact.so timeout 10 python tools/mini_ab.py run $D exact cornell_box:64 dragon:32
+TRAYHIP_LIB=$L/libtrayhip_eager.so timeout 10 python tools/mini_ab.py run $D eager tr15_like:16
+TRAYHIP_LIB=$L/libtrayhip_qwide.so TRAYHIP_WF_WIDE=1 timeout 10 python tools/mini_ab.py run $D qwide tr15_like:16
+TRAYHIP_MODE=wave timeout 10 python tools/mini_ab.py run $D wave dragon:32
 } 2>&1 | grep -v "^Frame" | tee gpurun_out/mini_ab.log
