@@ -21,7 +21,7 @@ def _stale(so, deps):
 
 def emu(qwide=False, defines=()):
     """libtrayemu.so (exact 128-B wide nodes), libtrayemu_qwide.so (-DTR_QWIDE: the staged 64-B quantised nodes), or a build with
-    other staged variant macros, e.g. defines=("TR_ALIGNED_QUERIES",)"""
+    other staged variant macros, e.g. defines=("TR_MESH_TWO_CHILDREN",)"""
     defines = tuple(sorted(set(defines) | ({"TR_QWIDE"} if qwide else set())))
     key = defines
     if key not in _libs:

@@ -306,41 +306,6 @@ def test_random_scene_sweep_of_the_per_sample_path(tmp_path, built):
     assert off <= 3, f"{off} of {total} samples differ"
 
 
-@pytest.mark.parametrize("name", ["cornell_box", "smallpt"])
-def test_staged_variant_aligned_queries_changes_no_bit(name, tmp_path, built):
-    """-DTR_ALIGNED_QUERIES (Next / C2: pass k of the BSDF query stage serves only the lanes whose pending query is of
-    kind k) reorders work inside a wave and nothing else: same per-sample records as the oracle, and the tile kernel's image is
-    the default build's bit for bit."""
-    w, h, spp = 32, 24, 8
-    scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
-    scene, *_ = T.Scene.load_file(str(tmp_path / (name + ".json")))
-    flat = scene.flatten(0)
-    V = ("TR_ALIGNED_QUERIES",)
-    rng = np.random.default_rng(2)
-    n = 4000
-    px = rng.integers(0, w, n).astype(np.uint32); py = rng.integers(0, h, n).astype(np.uint32); si = rng.integers(0, spp, n).astype(np.uint32)
-    assert O.sample_radiance(flat, px, py, si, spp, seed=4).tobytes() == E.sample_radiance(flat, px, py, si, spp, 4, defines=V).tobytes()
-    a, sa = E.render_tiles(flat, tile_queue(w, h), spp, 4)
-    b, sb = E.render_tiles(flat, tile_queue(w, h), spp, 4, defines=V)
-    assert sa == sb and a.tobytes() == b.tobytes()
-    c, sc = E.render_wavefront(flat, tile_queue(w, h), spp, 4, trace=2, defines=V)
-    assert sc[:3] == sa[:3] and float(np.sqrt(np.mean((rgb(c) - rgb(a)) ** 2))) < 2e-6
-
-
-def test_staged_variant_eager_loads_changes_no_bit(tmp_path, built):
-    """-DTR_WF_EAGER_LOADS (Next / C5: k_wf_advance requests every pool field it may need together with the flags
-    instead of in three dependent rounds): the wavefront schedule's image and counts are the default build's bit for bit."""
-    w, h, spp = 32, 24, 8
-    scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
-    scenes.write_moving_box(str(tmp_path), width=w, height=h, samples=spp)
-    for name, frame in (("smallpt", 0), ("moving_box", 3)):
-        scene, *_ = T.Scene.load_file(str(tmp_path / (name + ".json")))
-        flat = scene.flatten(frame)
-        a, sa = E.render_wavefront(flat, tile_queue(w, h), spp, 6, trace=0, n_chunks=5)
-        b, sb = E.render_wavefront(flat, tile_queue(w, h), spp, 6, trace=0, n_chunks=5, defines=("TR_WF_EAGER_LOADS",))
-        assert sa == sb and a.tobytes() == b.tobytes(), name
-
-
 def test_tile_megakernel_of_moving_scenes_emulated_as_simt(tmp_path, built):
     """k_path_tiles<ANIM = 1>: the spline stacks of the moving instances are evaluated once per camera sample into the per-thread
     transform cache (xf_cache_fill) and read back by traversal, hit finishing and light sampling"""

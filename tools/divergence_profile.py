@@ -8,7 +8,7 @@ it most. Per function the table gives
     bytes                 size of its x86 body at -O1 without inlining -- a rough stand-in for its instruction count
     share                 wave calls x bytes, normalised: where the wave's issue slots go, to first order
 It sees structure (who runs what together, how full the wave is), not timing.
-usage: python tools/divergence_profile.py [cornell_box|smallpt|dragon] [--wavefront] [--define TR_ALIGNED_QUERIES]"""
+usage: python tools/divergence_profile.py [cornell_box|smallpt|dragon] [--wavefront] [--define TR_MESH_TWO_CHILDREN]"""
 import argparse
 import ctypes as C
 import os

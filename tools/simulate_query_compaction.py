@@ -71,7 +71,7 @@ for tx, ty in tiles:
             tot["steps"] += 1; tot["alive"] += n_alive; tot["jobs"] += jobs
             tot["today"] += 3 if n_light else 2
             tot["units_today"] += sum(len(k) for k in kinds_in_pass)            # a pass runs the head / epilogue code of every kind present in it
-            tot["units_aligned"] += len(set().union(*kinds_in_pass))           # -DTR_ALIGNED_QUERIES: pass k serves kind k only
+            tot["units_aligned"] += len(set().union(*kinds_in_pass))           # aligned schedule: pass k serves kind k only
             tot["passes_aligned"] += len(set().union(*kinds_in_pass))
             tot["compact"] += -(-jobs // 64)
             tot["sorted"] += sum(-(-j // 64) for j in jobs_by_mat.values())
@@ -98,6 +98,6 @@ print(f"  steps with more than one material KIND (= code path of the eval site):
 for k, (j, p) in sorted(per_kind.items()):
     print(f"  kind {kinds.get(k, '?')}: {100 * j / tot['jobs']:.0f} % of the jobs, {p / s:.2f} kind-pure passes per step")
 print(f"  query kinds run per step (each = that kind's sample head / epilogue once for the wave): today {tot['units_today'] / s:.2f} in {tot['today'] / s:.2f} passes, "
-      f"aligned schedule (-DTR_ALIGNED_QUERIES) {tot['units_aligned'] / s:.2f} in {tot['passes_aligned'] / s:.2f} passes")
+      f"aligned schedule (pass k serves query kind k; measured on the GPU in round 1: no effect) {tot['units_aligned'] / s:.2f} in {tot['passes_aligned'] / s:.2f} passes")
 for k in ("today", "compact", "sorted", "by_kind"):
     print(f"  {k:8s} {tot[k] / s:.2f} passes per step, useful lanes {100 * tot['jobs'] / (64 * tot[k]):.0f} %")

@@ -282,15 +282,7 @@ template <int ANIM, int FEAT>
 TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
     const bool delta = sc.instances[ln.light_inst].kind == TRAY_INST_POINT_EMITTER;
     uint32_t want = ((ln.flags & LF_SHADOW) && !occluded) ? WANT_LIGHT : (delta ? WANT_PATH : WANT_MIS);
-#ifdef TR_ALIGNED_QUERIES   // staged variant (Next / C2): pass k serves only the lanes whose pending query is of kind k, so a pass runs one
-                           // kind's head and epilogue instead of up to two (the lanes' own sequences, hence the results, are unchanged)
-#pragma nounroll
-    for (uint32_t kind = WANT_LIGHT; kind <= WANT_PATH; ++kind) {
-        TR_EMU_PHASE(kind);
-        if (want == kind) want = query_stage<ANIM, FEAT>(sc, ln, want);
-    }
-    TR_EMU_PHASE(0);
-#elif defined(TR_EMU_PROFILE)   // divergence-profile build of tests/emu: the default schedule, its passes numbered
+#if defined(TR_EMU_PROFILE)   // divergence-profile build of tests/emu: the default schedule, its passes numbered
     for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) {
         TR_EMU_PHASE(pass + 1);
         want = query_stage<ANIM, FEAT>(sc, ln, want);

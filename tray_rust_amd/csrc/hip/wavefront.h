@@ -512,17 +512,6 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
     if (tid < TRAY_FILTER_TABLE_SIZE) { s_tx[tid] = sc.filter_x[tid]; s_ty[tid] = sc.filter_y[tid]; }
     for (uint32_t k = tid; k < ROWBIN_SIZE; k += TR_BLOCK) s_bins[k] = 0.0f;
     uint32_t flags = pu(pool, F_FLAGS, i);   // issued before the barrier: this kernel is a chain of dependent loads (95 % of its wave cycles wait)
-#ifdef TR_WF_EAGER_LOADS   // staged variant (Next / C5): every pool field the kernel may need is requested here, together with the
-                           // flags -- 31 words per slot, ~1 GB per launch at 8 M slots -- instead of in three dependent rounds
-                           // (flags -> vertex and MIS fields -> illum / sample position of finished samples). Same values, same arithmetic.
-    const uint32_t e_bounce = pu(pool, F_BOUNCE, i), e_linst = pu(pool, F_LINST, i);
-    const f3 e_illum = ld3(pool, F_ILLUM, i), e_direct = ld3(pool, F_DIRECT, i), e_tv = ld3(pool, F_TV, i);
-    const float e_sx = pf(pool, F_SX, i), e_sy = pf(pool, F_SY, i);
-    const f3 e_p = ld3(pool, F_P, i), e_aux = ld3(pool, F_AUX, i), e_misf = ld3(pool, F_MISF, i), e_li = ld3(pool, F_LI, i);
-    const float e_rt = pf(pool, F_REC_T, i), e_rb1 = pf(pool, F_REC_B1, i), e_rb2 = pf(pool, F_REC_B2, i);
-    const uint32_t e_rinst = pu(pool, F_REC_INST, i), e_rprim = pu(pool, F_REC_PRIM, i);
-    const float e_time = ANIM ? pf(pool, F_TIME, i) : 0.0f;
-#endif
     __syncthreads();
     uint32_t tile_idx = s_tile;
     if (tile_idx == WF_TILE_IDLE) return;
@@ -531,22 +520,11 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
         const uint2 tile = tiles[(tile_idx / chunk) * chunk_stride * chunk + (tile_idx % chunk)];
         const int x0 = (int)tile.x * 8, y0 = (int)tile.y * 8;
         // ---- stage C shading of the previous round
-#ifdef TR_WF_EAGER_LOADS
-        f3 fin_illum = e_illum;
-#endif
         if ((flags & (LF_ALIVE | WF_INVERTEX)) == (LF_ALIVE | WF_INVERTEX)) {
             Lane ln;
             ln.flags = flags;
             HitRec rec;
             rec.t = 0.0f; rec.inst = 0xffffffffu; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
-#ifdef TR_WF_EAGER_LOADS
-            ln.bounce = e_bounce; ln.illum = e_illum; ln.direct = e_direct; ln.t_vertex = e_tv; ln.light_inst = e_linst;
-            if (flags & LF_MIS) {
-                ln.bsdf.p = e_p; ln.aux_d = e_aux; ln.mis_f = e_misf; ln.li = e_li;
-                rec.t = e_rt; rec.inst = e_rinst; rec.prim = e_rprim; rec.b1 = e_rb1; rec.b2 = e_rb2;
-            }
-            ln.time = e_time; ln.col = i;
-#else
             ln.bounce = pu(pool, F_BOUNCE, i);
             ln.illum = ld3(pool, F_ILLUM, i);
             ln.direct = ld3(pool, F_DIRECT, i);
@@ -558,11 +536,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
                 rec.b1 = pf(pool, F_REC_B1, i); rec.b2 = pf(pool, F_REC_B2, i);
             }
             ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
-#endif
             const bool cont = vertex_end<ANIM>(sc, ln, (flags & WF_HIT_C) != 0u, rec);
-#ifdef TR_WF_EAGER_LOADS
-            fin_illum = ln.illum;
-#endif
             st3(pool, F_ILLUM, i, ln.illum);
             pu(pool, F_BOUNCE, i) = ln.bounce;
             flags = ln.flags & ~(WF_INVERTEX | WF_HIT_A | WF_HIT_C | WF_OCCLUDED | LF_SHADOW | LF_MIS | LF_LAST);
@@ -570,13 +544,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
         }
         // ---- RenderTarget::write of the samples that finished (here or in k_wf_begin)
         if (flags & WF_FINISHED) {
-#ifdef TR_WF_EAGER_LOADS
-            const f3 il = fin_illum;   // what vertex_end just stored, or (sample finished in k_wf_begin) what the pool held
-            const float sx = e_sx, sy = e_sy;
-#else
             const f3 il = ld3(pool, F_ILLUM, i);
             const float sx = pf(pool, F_SX, i), sy = pf(pool, F_SY, i);
-#endif
             const f3 col = mk(clampf(il.x, 0.0f, 1.0f), clampf(il.y, 0.0f, 1.0f), clampf(il.z, 0.0f, 1.0f));   // quirk Q3
             if (film_rows) film_splat_rows_global<true>(sc, s_bins, s_tx, rgbw, s_table, x0, y0, (int)(lane >> 3), sx, sy, col);
             else film_splat_global(sc, rgbw, s_table, x0, y0, sx, sy, col);
