@@ -96,7 +96,18 @@ struct Lane {
     f3 direct;             // direct_light of estimate_direct
     f3 mis_f;              // f of the BSDF half (stage C)
     f3 t_vertex;           // throughput at this vertex, kept for `illum += throughput * direct`
+#ifdef TR_STAGE_CLOCKS   // instrumented builds only: wave clocks of the parts of a BSDF query (set by k_path_tiles, null elsewhere)
+    unsigned long long* qclk = nullptr;   // [0] sample head / light setup, [1] eval + pdf site, [2] epilogue of the query kind
+    long long qt = 0;
+#endif
 };
+#ifdef TR_STAGE_CLOCKS
+#define TR_QCLK_START(ln) do { if ((ln).qclk) (ln).qt = clock64(); } while (0)
+#define TR_QCLK(ln, k) do { if ((ln).qclk) { const long long n_ = clock64(); (ln).qclk[k] += (unsigned long long)(n_ - (ln).qt); (ln).qt = n_; } } while (0)
+#else
+#define TR_QCLK_START(ln) ((void)0)
+#define TR_QCLK(ln, k) ((void)0)
+#endif
 
 // (the ANIM tile kernel calls xf_cache_fill(sc, cam_ray.time) right after this)
 TR_DEV void lane_start_sample(Lane& ln, const Ray& cam_ray, uint32_t ks) {
@@ -207,6 +218,7 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
     const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
     const bool delta = light->kind == TRAY_INST_POINT_EMITTER;
     SampleHead h;
+    TR_QCLK_START(ln);
     const f3 wo_sh = normalized(to_shading(ln.bsdf, ln.w_o));   // shared by sample / eval / pdf (same value each computes)
     if (is_light) {
         h.wi_world = ln.wi_l; h.f = mk(0.0f, 0.0f, 0.0f); h.pdf = 0.0f; h.sampled_type = 0u;
@@ -217,11 +229,13 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
         float one_d = lane_1d(sc, ln, mis ? SD_B1 : SD_P1);
         h = bsdf_sample_head_sh<FEAT>(ln.bsdf, wo_sh, flags, u0, u1, one_d);
     }
+    TR_QCLK(ln, 0);
     if (h.need_eval || h.need_pdf) {
         const f3 wi_sh = normalized(to_shading(ln.bsdf, h.wi_world));
         if (h.need_eval) h.f = bsdf_eval_sh<FEAT>(ln.bsdf, wo_sh, wi_sh, flags);
         if (h.need_pdf) h.pdf = bsdf_pdf_sh<FEAT>(ln.bsdf, wo_sh, wi_sh, flags);
     }
+    TR_QCLK(ln, 1);
     const f3 f = h.f, w_i = h.wi_world;
     const float pdf = h.pdf;
     if (is_light) {
@@ -290,7 +304,10 @@ TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
     TR_EMU_PHASE(0);
 #else
 #pragma nounroll
-    for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) want = query_stage<ANIM, FEAT>(sc, ln, want);   // LIGHT -> MIS -> PATH
+    for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) {   // LIGHT -> MIS -> PATH
+        want = query_stage<ANIM, FEAT>(sc, ln, want);
+        TR_QCLK(ln, 2);
+    }
 #endif
 }
 

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
     cnt.rays = 0; cnt.vertices = 0;
     uint32_t n_samples = 0;
 #ifdef TR_STAGE_CLOCKS
-    unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long clk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 0..6 stages, 8..10 parts of the BSDF queries (dev_integrator.h: TR_QCLK)
     long long clk_t = clock64();
 #endif
     for (;;) {
@@ -250,6 +250,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
         Lane ln;
         ln.flags = 0u;
         ln.illum = mk(0.0f, 0.0f, 0.0f);
+#ifdef TR_STAGE_CLOCKS
+        ln.qclk = clk + 8;
+#endif
         for (;;) {   // one path vertex per live lane and step
             if (!(ln.flags & LF_ALIVE)) {
                 // the previous sample of this lane is finished: RenderTarget::write it, start the next one
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
         atomicAdd(&stats->rays, (unsigned long long)cnt.rays);
 #ifdef TR_STAGE_CLOCKS
         if ((tid & 63u) == 0u)
-            for (int k = 0; k < 7; ++k) atomicAdd(&stats->trav[k], clk[k]);
+            for (int k = 0; k < 11; ++k) atomicAdd(&stats->trav[k], clk[k]);
 #endif
     }
 }
@@ -1060,6 +1063,8 @@ int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t) {
         for (int k = 0; k < 7; ++k) tot += (double)st.trav[k];
         const char* names[7] = {"trace A", "trace B", "trace C", "vertex_begin", "queries", "vertex_end", "regen+film"};
         for (int k = 0; k < 7; ++k) fprintf(stderr, "[trayhip] %-12s %5.1f %% of wave cycles\n", names[k], 100.0 * (double)st.trav[k] / tot);
+        const char* parts[3] = {"sample head / light setup", "eval + pdf site", "epilogue of the query kind"};
+        for (int k = 0; k < 3; ++k) fprintf(stderr, "[trayhip]   queries: %-28s %5.1f %% of wave cycles\n", parts[k], 100.0 * (double)st.trav[8 + k] / tot);
     }
 #else
     if (getenv("TRAYHIP_STATS") && st.rays)
