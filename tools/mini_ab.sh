@@ -10,4 +10,6 @@ TRAYHIP_LIB=$L/libtrayhip_m2c.so   timeout 10 python tools/mini_ab.py run $D m2c
 TRAYHIP_LIB=$L/libtrayhip_exact.so timeout 10 python tools/mini_ab.py run $D exact cornell_box:64 dragon:32
 TRAYHIP_LIB=$L/libtrayhip_qwide.so TRAYHIP_WF_WIDE=1 timeout 10 python tools/mini_ab.py run $D qwide tr15_like:16
 TRAYHIP_MODE=wave timeout 10 python tools/mini_ab.py run $D wave dragon:32
+# where the wave cycles go (instrumented build: stages of the tile kernel, parts of the BSDF queries)
+[ -f $L/libtrayhip_clk.so ] && TRAYHIP_LIB=$L/libtrayhip_clk.so TRAYHIP_STATS=1 timeout 10 python tools/mini_ab.py run $D clk cornell_box:64 dragon:32
 } 2>&1 | grep -v "^Frame" | tee gpurun_out/mini_ab.log
