@@ -144,9 +144,9 @@ class Scene:
         if self._dev is not None and (self._dev_frame != frame or (device is not None and device != self._dev_device)):
             self.release_device()
         if self._dev is None:
+            flat = self.flatten(frame)   # host work first: a scene that cannot be flattened fails here, with or without a GPU
             if device is not None:
                 check(lib().tray_init(int(device)))
-            flat = self.flatten(frame)
             d = C.c_void_p()
             check(lib().tray_scene_create(flat, C.byref(d)))
             self._dev, self._dev_frame, self._dev_device = d, frame, device
