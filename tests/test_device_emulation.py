@@ -405,3 +405,20 @@ def test_smallest_films_sample_counts_and_depths(w, h, spp, max_depth, tmp_path,
         for img, s_ in (E.render_tiles(flat, tile_queue(w, h), spp, 3, blocks=2), E.render_wavefront(flat, tile_queue(w, h), spp, 3, trace=0, n_chunks=2)):
             assert s_[:3] == (st.samples, st.vertices, st.rays)
             assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6
+
+
+def test_staged_variant_lazy_rectangle_test_changes_no_bit(tmp_path, built):
+    """-DTR_RECT_LAZY (Next / C2: the flat loop computes the x / y rows of a rectangle instance's object-space ray only when
+    t is in range): same expressions, same bits."""
+    w, h, spp = 32, 24, 8
+    scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
+    scene, *_ = T.Scene.load_file(str(tmp_path / "cornell_box.json"))
+    flat = scene.flatten(0)
+    V = ("TR_RECT_LAZY",)
+    a, sa = E.render_tiles(flat, tile_queue(w, h), spp, 4)
+    b, sb = E.render_tiles(flat, tile_queue(w, h), spp, 4, defines=V)
+    assert sa == sb and a.tobytes() == b.tobytes()
+    rng = np.random.default_rng(5)
+    n = 4000
+    px = rng.integers(0, w, n).astype(np.uint32); py = rng.integers(0, h, n).astype(np.uint32); si = rng.integers(0, spp, n).astype(np.uint32)
+    assert O.sample_radiance(flat, px, py, si, spp, seed=4).tobytes() == E.sample_radiance(flat, px, py, si, spp, 4, defines=V).tobytes()

@@ -209,6 +209,27 @@ TR_DEV bool rect_test(float width, float height, f3 o, f3 d, float min_t, float 
     if (p.x >= -hw && p.x <= hw && p.y >= -hh && p.y <= hh) { t_out = t; return true; }
     return false;
 }
+#ifdef TR_RECT_LAZY
+// staged variant: Instance::intersect + Rectangle::intersect on the WORLD ray with the z row of `inv` first -- the x / y rows of the
+// object-space origin and direction are only computed when t is in range. Same expressions as xf_point / xf_vector / rect_test.
+TR_DEV bool rect_test_lazy(const float* __restrict__ m, float width, float height, f3 wo, f3 wd, float min_t, float max_t, float& t_out) {
+    const float dz = m[8] * wd.x + m[9] * wd.y + m[10] * wd.z;
+    if (fabsf(dz) < 1e-8f) return false;
+    const float w = m[12] * wo.x + m[13] * wo.y + m[14] * wo.z + m[15];
+    const bool div = fabsf(w - 1.0f) < kEps;   // quirk Q5
+    float oz = m[8] * wo.x + m[9] * wo.y + m[10] * wo.z + m[11];
+    if (div) oz = oz / w;
+    const float t = -oz / dz;
+    if (t < min_t || t > max_t) return false;
+    float ox = m[0] * wo.x + m[1] * wo.y + m[2] * wo.z + m[3], oy = m[4] * wo.x + m[5] * wo.y + m[6] * wo.z + m[7];
+    if (div) { ox = ox / w; oy = oy / w; }
+    const float dx = m[0] * wd.x + m[1] * wd.y + m[2] * wd.z, dy = m[4] * wd.x + m[5] * wd.y + m[6] * wd.z;
+    const float px = ox + dx * t, py = oy + dy * t;
+    const float hw = width / 2.0f, hh = height / 2.0f;
+    if (px >= -hw && px <= hw && py >= -hh && py <= hh) { t_out = t; return true; }
+    return false;
+}
+#endif
 TR_DEV bool disk_test(float radius, float inner_radius, f3 o, f3 d, float min_t, float max_t, float& t_out) {   // disk.rs:42-66
     if (fabsf(d.z) == 0.0f) return false;
     float t = -o.z / d.z;
@@ -417,8 +438,13 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
         const float gp0 = in->geom_params[0], gp1 = in->geom_params[1];
         const uint32_t mesh_id = in->mesh_id;
         // Instance::intersect (receiver.rs:29-35): world ray -> object ray by `inv`, direction not renormalised
+#ifdef TR_RECT_LAZY
+        f3 o = ray.o, d = ray.d;
+        if (gt != TRAY_GEOM_RECT) { o = xf_point(inv, ray.o); d = xf_vector(inv, ray.d); }
+#else
         const f3 o = xf_point(inv, ray.o);
         const f3 d = xf_vector(inv, ray.d);
+#endif
         float t = max_t;
         bool hit = false;
         uint32_t prim = 0u;
@@ -436,7 +462,11 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
             volatile float* w_lds = reinterpret_cast<volatile float*>(stack - threadIdx.x + sc.coop_offset) + (threadIdx.x >> 6) * TR_COOP_WORDS;
             hit = mesh_leaf_coop(sc, sc.meshes[mesh_id], w_lds, wanted, o, d, min_t, t, prim, b1, b2);
         } else if (wanted) {
+#ifdef TR_RECT_LAZY
+            if (gt == TRAY_GEOM_RECT) hit = rect_test_lazy(inv, gp0, gp1, o, d, min_t, max_t, t);
+#else
             if (gt == TRAY_GEOM_RECT) hit = rect_test(gp0, gp1, o, d, min_t, max_t, t);
+#endif
             else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(gp0, o, d, min_t, max_t, t);
             else if (gt == TRAY_GEOM_MESH) hit = mesh_traverse(sc, stack, sc.meshes[mesh_id], o, d, min_t, t, any_hit, prim, b1, b2);
             else hit = disk_test(gp0, gp1, o, d, min_t, max_t, t);
