@@ -422,3 +422,22 @@ def test_staged_variant_lazy_rectangle_test_changes_no_bit(tmp_path, built):
     n = 4000
     px = rng.integers(0, w, n).astype(np.uint32); py = rng.integers(0, h, n).astype(np.uint32); si = rng.integers(0, spp, n).astype(np.uint32)
     assert O.sample_radiance(flat, px, py, si, spp, seed=4).tobytes() == E.sample_radiance(flat, px, py, si, spp, 4, defines=V).tobytes()
+
+
+def test_staged_variant_smaller_lane_state_changes_no_bit(tmp_path, built):
+    """-DTR_REMAT_WO -DTR_REMAT_BITAN -DTR_NO_LANE_O (Next / C2): three fields of the per-lane path state are recomputed
+    or shared instead of kept across the traversals (w_o = -d, bitan = cross(tan, n), ray origin = bsdf.p), which takes the tile
+    kernel's scratch from 516 to 388 B per lane (tools/spill_report.sh). Same expressions, same bits, in both schedules."""
+    w, h, spp = 32, 24, 8
+    scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
+    scenes.write_moving_box(str(tmp_path), width=w, height=h, samples=spp)
+    V = ("TR_REMAT_WO", "TR_REMAT_BITAN", "TR_NO_LANE_O")
+    for name, frame in (("cornell_box", 0), ("smallpt", 0), ("moving_box", 3)):
+        scene, *_ = T.Scene.load_file(str(tmp_path / (name + ".json")))
+        flat = scene.flatten(frame)
+        a, sa = E.render_tiles(flat, tile_queue(w, h), spp, 4, blocks=2)
+        b, sb = E.render_tiles(flat, tile_queue(w, h), spp, 4, blocks=2, defines=V)
+        assert sa == sb and a.tobytes() == b.tobytes(), name
+        c, sc = E.render_wavefront(flat, tile_queue(w, h), spp, 4, trace=0)
+        d_, sd = E.render_wavefront(flat, tile_queue(w, h), spp, 4, trace=0, defines=V)
+        assert sc == sd and c.tobytes() == d_.tobytes(), name

@@ -84,11 +84,19 @@ struct Lane {
     uint32_t ks;           // sample key: scrambles and shuffle entries of the six LD arrays derive from it
     float time;            // ray.time of the camera ray, inherited by every ray of the path (path.rs:110, mod.rs:154)
     uint32_t col;          // the path's column of the transform cache (ANIM): thread id (tile kernel) or pool slot (wavefront)
+#ifdef TR_NO_LANE_O   // staged variant: the stage A ray starts at the previous vertex (bsdf.p) -- or at the camera, parked in bsdf.p until the first hit
+    f3 d;
+#define LN_O(ln) ((ln).bsdf.p)
+#else
     f3 o, d;               // stage A ray: camera ray, or continuation from the previous vertex
+#define LN_O(ln) ((ln).o)
+#endif
     f3 throughput, illum;
     f3 first_ng;           // hit.dg.ng of the camera ray's hit (quirk Q1)
     Bsdf bsdf;             // shading context of the current vertex (BSDF::new)
+#ifndef TR_REMAT_WO   // staged variant: w_o is -d until the PATH query writes the next ray's direction, so it need not be kept
     f3 w_o;
+#endif
     uint32_t light_inst;
     f3 li, wi_l;           // light sample (stage B)           | stage C: li = (|cos|, mis weight, pdf_bsdf)
     float pdf_l;
@@ -114,7 +122,7 @@ TR_DEV void lane_start_sample(Lane& ln, const Ray& cam_ray, uint32_t ks) {
     ln.flags = LF_ALIVE;
     ln.bounce = 0u;
     ln.ks = ks;
-    ln.o = cam_ray.o; ln.d = cam_ray.d;
+    LN_O(ln) = cam_ray.o; ln.d = cam_ray.d;
     ln.time = cam_ray.time; ln.col = 0u;
     ln.throughput = mk(1.0f, 1.0f, 1.0f);
     ln.illum = mk(0.0f, 0.0f, 0.0f);
@@ -132,7 +140,7 @@ TR_DEV float lane_1d(const DevScene& sc, const Lane& ln, uint32_t dim) {
 
 TR_DEV Ray stage_a_ray(const Lane& ln) {
     Ray r;
-    r.o = ln.o; r.d = ln.d;
+    r.o = LN_O(ln); r.d = ln.d;
     r.min_t = ln.bounce == 0u ? 0.0f : 0.001f;   // camera ray (ray.rs:25-27) vs ray.min_t = 0.001 (path.rs:110)
     r.max_t = TR_INF;
     r.time = ln.time; r.col = ln.col;
@@ -167,7 +175,9 @@ TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counte
         }
     }
     ln.bsdf = make_bsdf(sc, hit);
+#ifndef TR_REMAT_WO
     ln.w_o = -ln.d;
+#endif
     ln.direct = mk(0.0f, 0.0f, 0.0f);
     ln.t_vertex = ln.throughput;
     ln.flags &= ~(LF_SHADOW | LF_MIS | LF_LAST);
@@ -219,7 +229,11 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
     const bool delta = light->kind == TRAY_INST_POINT_EMITTER;
     SampleHead h;
     TR_QCLK_START(ln);
-    const f3 wo_sh = normalized(to_shading(ln.bsdf, ln.w_o));   // shared by sample / eval / pdf (same value each computes)
+#ifdef TR_REMAT_WO
+    const f3 wo_sh = normalized(to_shading(ln.bsdf, -ln.d));
+#else
+    const f3 wo_sh = normalized(to_shading(ln.bsdf, ln.w_o));
+#endif   // (wo_sh is shared by sample / eval / pdf: the same value each of them computes)
     if (is_light) {
         h.wi_world = ln.wi_l; h.f = mk(0.0f, 0.0f, 0.0f); h.pdf = 0.0f; h.sampled_type = 0u;
         h.need_eval = true; h.need_pdf = !delta;
@@ -286,7 +300,9 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
         ln.throughput = ln.throughput / cont_prob;
     }
     if (ln.bounce == sc.max_depth) { ln.flags |= LF_LAST; return WANT_NONE; }
+#ifndef TR_NO_LANE_O
     ln.o = ln.bsdf.p;
+#endif
     ln.d = normalized(w_i);
     return WANT_NONE;
 }

@@ -52,12 +52,20 @@ TR_DEV f3 ld3(const WfPool& p, int f, uint32_t i) { return mk(pf(p, f, i), pf(p,
 TR_DEV void st3(const WfPool& p, int f, uint32_t i, f3 v) { pf(p, f, i) = v.x; pf(p, f + 1, i) = v.y; pf(p, f + 2, i) = v.z; }
 
 TR_DEV void ld_bsdf(const DevScene& sc, const WfPool& p, uint32_t i, Bsdf& b) {
-    b.p = ld3(p, F_P, i); b.n = ld3(p, F_N, i); b.tan = ld3(p, F_TAN, i); b.bitan = ld3(p, F_BITAN, i);
+    b.p = ld3(p, F_P, i); b.n = ld3(p, F_N, i); b.tan = ld3(p, F_TAN, i);
+#ifndef TR_REMAT_BITAN
+    b.bitan = ld3(p, F_BITAN, i);
+#endif
+
     b.mat = sc.materials + pu(p, F_MAT, i);
     b.merl_data = sc.merl_data;
 }
 TR_DEV void st_bsdf(const DevScene& sc, const WfPool& p, uint32_t i, const Bsdf& b) {
-    st3(p, F_P, i, b.p); st3(p, F_N, i, b.n); st3(p, F_TAN, i, b.tan); st3(p, F_BITAN, i, b.bitan);
+    st3(p, F_P, i, b.p); st3(p, F_N, i, b.n); st3(p, F_TAN, i, b.tan);
+#ifndef TR_REMAT_BITAN
+    st3(p, F_BITAN, i, b.bitan);
+#endif
+
     pu(p, F_MAT, i) = (uint32_t)(b.mat - sc.materials);
 }
 
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
     Lane ln;
     ln.flags = flags;
     ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
-    ln.o = ld3(pool, F_O, i); ln.d = ld3(pool, F_D, i);
+    LN_O(ln) = ld3(pool, F_O, i); ln.d = ld3(pool, F_D, i);
     ln.throughput = ld3(pool, F_T, i); ln.illum = ld3(pool, F_ILLUM, i);
     ln.first_ng = ld3(pool, F_NG, i);
     HitRec rec;
@@ -396,7 +404,11 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
     st3(pool, F_ILLUM, i, ln.illum);
     if (ln.bounce == 0u) st3(pool, F_NG, i, ln.first_ng);
     st_bsdf(sc, pool, i, ln.bsdf);
+#ifdef TR_REMAT_WO
+    st3(pool, F_WO, i, -ln.d);
+#else
     st3(pool, F_WO, i, ln.w_o);
+#endif
     pu(pool, F_LINST, i) = ln.light_inst;
     st3(pool, F_LI, i, ln.li); st3(pool, F_WL, i, ln.wi_l); pf(pool, F_PDFL, i) = ln.pdf_l;
     if (ln.flags & LF_SHADOW) st3(pool, F_AUX, i, ln.aux_d);
@@ -421,16 +433,24 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPoo
     ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
     ln.throughput = ld3(pool, F_T, i);
     ld_bsdf(sc, pool, i, ln.bsdf);
+#ifndef TR_REMAT_WO
     ln.w_o = ld3(pool, F_WO, i);
+#endif
     ln.light_inst = pu(pool, F_LINST, i);
     ln.li = ld3(pool, F_LI, i); ln.wi_l = ld3(pool, F_WL, i); ln.pdf_l = pf(pool, F_PDFL, i);
     ln.direct = ld3(pool, F_DIRECT, i);
-    ln.o = mk(0.0f, 0.0f, 0.0f); ln.d = mk(0.0f, 0.0f, 0.0f);
+#ifndef TR_NO_LANE_O
+    ln.o = mk(0.0f, 0.0f, 0.0f);
+#endif
+    ln.d = mk(0.0f, 0.0f, 0.0f);
+#ifdef TR_REMAT_WO
+    ln.d = -ld3(pool, F_WO, i);   // (-d is the outgoing direction until the PATH query replaces d)
+#endif
     ln.aux_d = mk(0.0f, 0.0f, 0.0f); ln.mis_f = mk(0.0f, 0.0f, 0.0f);
     ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
     vertex_queries<ANIM, FEAT>(sc, ln, (flags & WF_OCCLUDED) != 0u);
     st3(pool, F_T, i, ln.throughput);
-    if (!(ln.flags & LF_LAST)) { st3(pool, F_O, i, ln.o); st3(pool, F_D, i, ln.d); }
+    if (!(ln.flags & LF_LAST)) { st3(pool, F_O, i, LN_O(ln)); st3(pool, F_D, i, ln.d); }
     if (ln.flags & LF_MIS) {   // the vertex ends in k_wf_advance, after stage C has traced the BSDF-sampled light ray
         pu(pool, F_FLAGS, i) = ln.flags;
         st3(pool, F_DIRECT, i, ln.direct);
