@@ -425,13 +425,14 @@ def test_staged_variant_lazy_rectangle_test_changes_no_bit(tmp_path, built):
 
 
 def test_staged_variant_smaller_lane_state_changes_no_bit(tmp_path, built):
-    """-DTR_REMAT_WO -DTR_REMAT_BITAN -DTR_NO_LANE_O (Next / C2): three fields of the per-lane path state are recomputed
-    or shared instead of kept across the traversals (w_o = -d, bitan = cross(tan, n), ray origin = bsdf.p), which takes the tile
-    kernel's scratch from 516 to 388 B per lane (tools/spill_report.sh). Same expressions, same bits, in both schedules."""
+    """-DTR_REMAT_WO -DTR_REMAT_BITAN -DTR_NO_LANE_O -DTR_SHARE_WIL (Next / C2): four fields of the per-lane path state are
+    recomputed or shared instead of kept across the traversals (w_o = -d, bitan = cross(tan, n), ray origin = bsdf.p, wi_l and mis_f
+    in one slot), which takes the tile kernel's scratch from 516 to 364 B per lane (tools/spill_report.sh). Same expressions, same
+    bits, in both schedules."""
     w, h, spp = 32, 24, 8
     scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
     scenes.write_moving_box(str(tmp_path), width=w, height=h, samples=spp)
-    V = ("TR_REMAT_WO", "TR_REMAT_BITAN", "TR_NO_LANE_O")
+    V = ("TR_REMAT_WO", "TR_REMAT_BITAN", "TR_NO_LANE_O", "TR_SHARE_WIL")
     for name, frame in (("cornell_box", 0), ("smallpt", 0), ("moving_box", 3)):
         scene, *_ = T.Scene.load_file(str(tmp_path / (name + ".json")))
         flat = scene.flatten(frame)

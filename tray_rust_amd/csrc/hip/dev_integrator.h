@@ -98,11 +98,19 @@ struct Lane {
     f3 w_o;
 #endif
     uint32_t light_inst;
+#ifdef TR_SHARE_WIL   // staged variant: wi_l (written in vertex_begin, last read by the LIGHT query) and mis_f (written by the MIS query, which
+                      // follows it) never live at the same time
+    f3 li;
+    union { f3 wi_l; f3 mis_f; };
+#else
     f3 li, wi_l;           // light sample (stage B)           | stage C: li = (|cos|, mis weight, pdf_bsdf)
+#endif
     float pdf_l;
     f3 aux_d;              // stage B: occlusion segment p_w - p | stage C: BSDF-sampled direction
     f3 direct;             // direct_light of estimate_direct
+#ifndef TR_SHARE_WIL
     f3 mis_f;              // f of the BSDF half (stage C)
+#endif
     f3 t_vertex;           // throughput at this vertex, kept for `illum += throughput * direct`
 #ifdef TR_STAGE_CLOCKS   // instrumented builds only: wave clocks of the parts of a BSDF query (set by k_path_tiles, null elsewhere)
     unsigned long long* qclk = nullptr;   // [0] sample head / light setup, [1] eval + pdf site, [2] epilogue of the query kind

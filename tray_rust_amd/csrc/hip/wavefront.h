@@ -437,6 +437,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPoo
     ln.w_o = ld3(pool, F_WO, i);
 #endif
     ln.light_inst = pu(pool, F_LINST, i);
+    ln.aux_d = mk(0.0f, 0.0f, 0.0f); ln.mis_f = mk(0.0f, 0.0f, 0.0f);   // (before wi_l is loaded: the two may share storage, TR_SHARE_WIL)
     ln.li = ld3(pool, F_LI, i); ln.wi_l = ld3(pool, F_WL, i); ln.pdf_l = pf(pool, F_PDFL, i);
     ln.direct = ld3(pool, F_DIRECT, i);
 #ifndef TR_NO_LANE_O
@@ -446,7 +447,6 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPoo
 #ifdef TR_REMAT_WO
     ln.d = -ld3(pool, F_WO, i);   // (-d is the outgoing direction until the PATH query replaces d)
 #endif
-    ln.aux_d = mk(0.0f, 0.0f, 0.0f); ln.mis_f = mk(0.0f, 0.0f, 0.0f);
     ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
     vertex_queries<ANIM, FEAT>(sc, ln, (flags & WF_OCCLUDED) != 0u);
     st3(pool, F_T, i, ln.throughput);
