@@ -442,3 +442,20 @@ def test_staged_variant_smaller_lane_state_changes_no_bit(tmp_path, built):
         c, sc = E.render_wavefront(flat, tile_queue(w, h), spp, 4, trace=0)
         d_, sd = E.render_wavefront(flat, tile_queue(w, h), spp, 4, trace=0, defines=V)
         assert sc == sd and c.tobytes() == d_.tobytes(), name
+
+
+def test_staged_variant_wave_level_statistics(tmp_path, built):
+    """-DTR_WAVE_COUNTERS (Next / C2): the tile kernel's samples / vertices / rays statistics as wave totals (ballot +
+    popcount, held in scalar registers) instead of three per-lane counters that live across the whole kernel. Same totals; the
+    image differs only by the order of the film's f32 sums (one more rendezvous per step reorders the emulated lanes)."""
+    w, h, spp = 32, 24, 8
+    scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
+    scenes.write_dragon_assets(str(tmp_path), film=(w, h, spp), grid=24, extent=1.0)
+    for name in ("cornell_box", "smallpt", "dragon"):
+        scene, *_ = T.Scene.load_file(str(tmp_path / (name + ".json")))
+        flat = scene.flatten(0)
+        a, sa = E.render_tiles(flat, tile_queue(w, h), spp, 4, blocks=2)
+        b, sb = E.render_tiles(flat, tile_queue(w, h), spp, 4, blocks=2, defines=("TR_WAVE_COUNTERS",))
+        ref, st = O.render_tiles(flat, spp, seed=4)
+        assert sa[:3] == sb[:3] == (st.samples, st.vertices, st.rays), name
+        assert np.abs(a - b).max() < 2e-6 * a.max()

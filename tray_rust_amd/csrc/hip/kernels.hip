@@ -226,6 +226,10 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
     Counters cnt;
     cnt.rays = 0; cnt.vertices = 0;
     uint32_t n_samples = 0;
+#ifdef TR_WAVE_COUNTERS   // staged variant: the three statistics counters as wave totals (ballot + popcount, wave-uniform: SGPRs) instead of three
+                          // VGPRs that live across the whole kernel
+    uint32_t w_samples = 0u, w_vertices = 0u, w_rays = 0u;
+#endif
 #ifdef TR_STAGE_CLOCKS
     unsigned long long clk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 0..6 stages, 8..10 parts of the BSDF queries (dev_integrator.h: TR_QCLK)
     long long clk_t = clock64();
@@ -254,6 +258,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
         ln.qclk = clk + 8;
 #endif
         for (;;) {   // one path vertex per live lane and step
+#ifdef TR_WAVE_COUNTERS
+            bool started = false;
+#endif
             if (!(ln.flags & LF_ALIVE)) {
                 // the previous sample of this lane is finished: RenderTarget::write it, start the next one
                 if (pending) {
@@ -267,10 +274,17 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
                     lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), key_sample(kp, s_next));
                     if (ANIM) { ln.col = xf_cache_lane(); xf_cache_fill(sc, ln.time, ln.col); }   // the path's transforms of the moving instances, once per camera sample
                     s_next += TR_BLOCK / 64;
+#ifdef TR_WAVE_COUNTERS
+                    started = true;
+#else
                     ++n_samples;
+#endif
                     pending = true;
                 }
             }
+#ifdef TR_WAVE_COUNTERS
+            w_samples += (uint32_t)__popcll(__ballot(started));
+#endif
             if (!__any(ln.flags & LF_ALIVE)) break;
 #ifdef TR_STAGE_CLOCKS
 #define TR_CLK(slot) do { const long long now_ = clock64(); clk[slot] += (unsigned long long)(now_ - clk_t); clk_t = now_; } while (0)
@@ -285,12 +299,21 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
                 TraceResult tr_;
                 tr_.hit = false;
                 tr_.rec.t = 0.0f; tr_.rec.inst = 0xffffffffu; tr_.rec.prim = 0u; tr_.rec.b1 = 0.0f; tr_.rec.b2 = 0.0f;
+#ifdef TR_WAVE_COUNTERS
+                const unsigned long long wr_ = __ballot(want_ray);
+                w_rays += (uint32_t)__popcll(wr_);
+                if (wr_ != 0ull) {
+#else
                 if (__any(want_ray)) {   // the whole wave enters the traversal code (dev_geom.h: cooperative leaf test)
                     if (want_ray) cnt.rays++;
+#endif
                     const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
                     tr_ = trace<ANIM>(scp, my_stack, r, stage == 1, want_ray);
                 }
                 TR_CLK(stage);   // trace A / B / C
+#ifdef TR_WAVE_COUNTERS
+                if (stage == 0) w_vertices += (uint32_t)__popcll(__ballot(alive && tr_.hit));
+#endif
                 if (alive) {
                     if (stage == 0) {
                         if (tr_.hit) vertex_begin<ANIM>(sc, ln, tr_.rec, cnt);
@@ -327,9 +350,17 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
         }
     }
     if (stats) {
+#ifdef TR_WAVE_COUNTERS
+        if (lane == 0u) {
+            atomicAdd(&stats->samples, (unsigned long long)w_samples);
+            atomicAdd(&stats->vertices, (unsigned long long)w_vertices);
+            atomicAdd(&stats->rays, (unsigned long long)w_rays);
+        }
+#else
         atomicAdd(&stats->samples, (unsigned long long)n_samples);
         atomicAdd(&stats->vertices, (unsigned long long)cnt.vertices);
         atomicAdd(&stats->rays, (unsigned long long)cnt.rays);
+#endif
 #ifdef TR_STAGE_CLOCKS
         if ((tid & 63u) == 0u)
             for (int k = 0; k < 11; ++k) atomicAdd(&stats->trav[k], clk[k]);
