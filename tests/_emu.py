@@ -19,19 +19,40 @@ def _stale(so, deps):
     return not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps)
 
 
+def _target(defines):
+    so = os.path.join(EMU_DIR, "libtrayemu" + "".join("_" + d.lower() for d in defines).replace("_tr_", "_") + ".so")
+    deps = [os.path.join(EMU_DIR, f) for f in ("emu_kernels.cpp", "hip_emu.h")]
+    deps += [os.path.join(HIP_DIR, f) for f in os.listdir(HIP_DIR) if f.endswith((".h", ".hip"))]
+    deps += [os.path.join(ROOT, "tray_rust_amd", "csrc", "host", "wide_nodes.hpp"), os.path.join(ROOT, "include", "trayhip.h")]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-attributes", "-shared", "-o", so,
+           os.path.join(EMU_DIR, "emu_kernels.cpp")] + ["-D" + d for d in defines]
+    return so, deps, cmd
+
+
+def _norm(qwide, defines):
+    return tuple(sorted(set(defines) | ({"TR_QWIDE"} if qwide else set())))
+
+
+def prebuild(define_sets):
+    """compile the stale ones of several builds side by side (each takes ~25 s; the suite uses five)"""
+    procs = []
+    for defines in define_sets:
+        so, deps, cmd = _target(_norm(False, defines))
+        if _stale(so, deps):
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("host emulation build failed: " + " ".join(cmd))
+
+
 def emu(qwide=False, defines=()):
     """libtrayemu.so (exact 128-B wide nodes), libtrayemu_qwide.so (-DTR_QWIDE: the staged 64-B quantised nodes), or a build with
     other staged variant macros, e.g. defines=("TR_MESH_TWO_CHILDREN",)"""
-    defines = tuple(sorted(set(defines) | ({"TR_QWIDE"} if qwide else set())))
+    defines = _norm(qwide, defines)
     key = defines
     if key not in _libs:
-        so = os.path.join(EMU_DIR, "libtrayemu" + "".join("_" + d.lower() for d in defines).replace("_tr_", "_") + ".so")
-        deps = [os.path.join(EMU_DIR, f) for f in ("emu_kernels.cpp", "hip_emu.h")]
-        deps += [os.path.join(HIP_DIR, f) for f in os.listdir(HIP_DIR) if f.endswith((".h", ".hip"))]
-        deps += [os.path.join(ROOT, "tray_rust_amd", "csrc", "host", "wide_nodes.hpp"), os.path.join(ROOT, "include", "trayhip.h")]
+        so, deps, cmd = _target(defines)
         if _stale(so, deps):
-            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-attributes", "-shared", "-o", so,
-                   os.path.join(EMU_DIR, "emu_kernels.cpp")] + ["-D" + d for d in defines]
             subprocess.run(cmd, check=True)
         h = C.CDLL(so)
         FS = C.POINTER(L.TrayFlatScene)

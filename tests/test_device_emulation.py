@@ -15,6 +15,14 @@ import _oracle as O
 from test_proto_wide_bvh import mixed_rays
 
 BOX = ([-14, 1, -18], [14, 23, 19])
+# the staged variants that must not change a bit, in ONE build (a host build per variant is ~25 s of g++ each)
+SAME_BITS = ("TR_MESH_TWO_CHILDREN", "TR_RECT_LAZY", "TR_REMAT_WO", "TR_REMAT_BITAN", "TR_NO_LANE_O", "TR_SHARE_WIL")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emulation_builds(built):
+    E.prebuild([(), ("TR_QWIDE",), SAME_BITS, ("TR_WAVE_COUNTERS",), ("TR_EXACT_FLAT",)])
+
 
 
 @pytest.fixture(scope="module")
@@ -352,7 +360,7 @@ def test_staged_variant_two_children_mesh_step_changes_no_bit(tmp_path, built):
     scenes.write_dragon_assets(str(tmp_path), film=(w, h, spp), grid=32, extent=1.0)
     scene, *_ = T.Scene.load_file(str(tmp_path / "dragon.json"))
     flat = scene.flatten(0)
-    V = ("TR_MESH_TWO_CHILDREN",)
+    V = SAME_BITS
     rng = np.random.default_rng(3)
     n = 5000
     px = rng.integers(0, w, n).astype(np.uint32); py = rng.integers(0, h, n).astype(np.uint32); si = rng.integers(0, spp, n).astype(np.uint32)
@@ -414,7 +422,7 @@ def test_staged_variant_lazy_rectangle_test_changes_no_bit(tmp_path, built):
     scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
     scene, *_ = T.Scene.load_file(str(tmp_path / "cornell_box.json"))
     flat = scene.flatten(0)
-    V = ("TR_RECT_LAZY",)
+    V = SAME_BITS
     a, sa = E.render_tiles(flat, tile_queue(w, h), spp, 4)
     b, sb = E.render_tiles(flat, tile_queue(w, h), spp, 4, defines=V)
     assert sa == sb and a.tobytes() == b.tobytes()
@@ -432,7 +440,7 @@ def test_staged_variant_smaller_lane_state_changes_no_bit(tmp_path, built):
     w, h, spp = 32, 24, 8
     scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
     scenes.write_moving_box(str(tmp_path), width=w, height=h, samples=spp)
-    V = ("TR_REMAT_WO", "TR_REMAT_BITAN", "TR_NO_LANE_O", "TR_SHARE_WIL")
+    V = SAME_BITS
     for name, frame in (("cornell_box", 0), ("smallpt", 0), ("moving_box", 3)):
         scene, *_ = T.Scene.load_file(str(tmp_path / (name + ".json")))
         flat = scene.flatten(frame)
