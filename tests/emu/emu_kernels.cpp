@@ -106,7 +106,11 @@ void make_scene(const TrayFlatScene* f, int wide_format, EmuScene& e) {
     d.width = f->film.width; d.height = f->film.height; d.frame = f->frame; d.film_rows = 0; d.coop_offset = 0;
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
+#ifdef TR_CAMERA_PTR
+    d.camera_p = &f->camera;
+#else
     d.camera = f->camera;
+#endif
 #ifdef TR_EXACT_FLAT
     e.inst_leaf.assign(f->n_instances, TrayBvhNode{});
     for (uint32_t nd = 0; nd < f->n_top_nodes; ++nd)

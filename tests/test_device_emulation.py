@@ -16,7 +16,7 @@ from test_proto_wide_bvh import mixed_rays
 
 BOX = ([-14, 1, -18], [14, 23, 19])
 # the staged variants that must not change a bit, in ONE build (a host build per variant is ~25 s of g++ each)
-SAME_BITS = ("TR_MESH_TWO_CHILDREN", "TR_RECT_LAZY", "TR_REMAT_WO", "TR_REMAT_BITAN", "TR_NO_LANE_O", "TR_SHARE_WIL")
+SAME_BITS = ("TR_MESH_TWO_CHILDREN", "TR_RECT_LAZY", "TR_REMAT_WO", "TR_REMAT_BITAN", "TR_NO_LANE_O", "TR_SHARE_WIL", "TR_CAMERA_PTR")
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -433,10 +433,11 @@ def test_staged_variant_lazy_rectangle_test_changes_no_bit(tmp_path, built):
 
 
 def test_staged_variant_smaller_lane_state_changes_no_bit(tmp_path, built):
-    """-DTR_REMAT_WO -DTR_REMAT_BITAN -DTR_NO_LANE_O -DTR_SHARE_WIL (Next / C2): four fields of the per-lane path state are
-    recomputed or shared instead of kept across the traversals (w_o = -d, bitan = cross(tan, n), ray origin = bsdf.p, wi_l and mis_f
-    in one slot), which takes the tile kernel's scratch from 516 to 364 B per lane (tools/spill_report.sh). Same expressions, same
-    bits, in both schedules."""
+    """-DTR_REMAT_WO -DTR_REMAT_BITAN -DTR_NO_LANE_O -DTR_SHARE_WIL -DTR_CAMERA_PTR (Next / C2): four fields of the per-lane
+    path state are recomputed or shared instead of kept across the traversals (w_o = -d, bitan = cross(tan, n), ray origin = bsdf.p,
+    wi_l and mis_f in one slot) and the camera sits behind a pointer instead of in scalar registers; with the wave-level statistics
+    that takes the tile kernel's scratch from 516 to 160 B per lane (tools/spill_report.sh). Same expressions, same bits, in both
+    schedules, static and moving (animated camera)."""
     w, h, spp = 32, 24, 8
     scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
     scenes.write_moving_box(str(tmp_path), width=w, height=h, samples=spp)

@@ -70,7 +70,12 @@ struct DevScene {
 #endif
     float filter_w, filter_h, inv_w, inv_h;
     int32_t fpw, fph;
+#ifdef TR_CAMERA_PTR   // staged variant: the camera (44 words, read only where a camera sample starts) behind a pointer instead of by value,
+                       // where it held scalar registers for the whole kernel (193 -> 140 SGPRs spilled to VGPR lanes in k_path_tiles)
+    const TrayCamera* __restrict__ camera_p;
+#else
     TrayCamera camera;
+#endif
 };
 
 struct Ray {

@@ -23,7 +23,11 @@ namespace tr {
 
 template <int ANIM>
 TR_DEV Ray camera_ray(const DevScene& sc, float px, float py, float time) {
+#ifdef TR_CAMERA_PTR
+    const TrayCamera& c = *sc.camera_p;
+#else
     const TrayCamera& c = sc.camera;
+#endif
     f3 q = xf_point(c.raster_to_cam, mk(px, py, 0.0f));
     f3 px_pos = mk(c.scaling[0], c.scaling[1], c.scaling[2]) * q;
     f3 d = normalized(px_pos);

@@ -765,7 +765,16 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     }
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
+#ifdef TR_CAMERA_PTR
+    {
+        const TrayCamera* d_cam = nullptr;
+        rc = upload(s, &f->camera, 1, &d_cam);
+        d.camera_p = d_cam;
+        if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
+    }
+#else
     d.camera = f->camera;
+#endif
     // Morton tile queue (BlockQueue::new)
     uint32_t n_tiles = 0;
     rc = tray_block_queue(d.width, d.height, 0, 0, nullptr, 0, &n_tiles);
