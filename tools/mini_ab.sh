@@ -8,6 +8,7 @@ timeout 15 python tools/mini_ab.py prepare $D
 timeout 10 python tools/mini_ab.py run $D default cornell_box:64 dragon:32 tr15_like:16
 TRAYHIP_LIB=$L/libtrayhip_m2c.so   timeout 10 python tools/mini_ab.py run $D m2c dragon:32
 TRAYHIP_LIB=$L/libtrayhip_state.so timeout 10 python tools/mini_ab.py run $D state cornell_box:64 dragon:32 tr15_like:16
+TRAYHIP_LIB=$L/libtrayhip_wq3.so    timeout 10 python tools/mini_ab.py run $D wq3 tr15_like:16
 TRAYHIP_LIB=$L/libtrayhip_state2.so timeout 10 python tools/mini_ab.py run $D state2 cornell_box:64 dragon:32
 TRAYHIP_LIB=$L/libtrayhip_lazy.so  timeout 10 python tools/mini_ab.py run $D lazy cornell_box:64 dragon:32
 TRAYHIP_LIB=$L/libtrayhip_exact.so timeout 10 python tools/mini_ab.py run $D exact cornell_box:64 dragon:32

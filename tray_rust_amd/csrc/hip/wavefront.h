@@ -421,7 +421,12 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
 
 // Stage B shading: the BSDF queries of the vertex (light half, BSDF half, continuation)
 template <int ANIM, int FEAT>
-__global__ __launch_bounds__(TR_BLOCK) void k_wf_query(const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ queue_c,
+#ifdef WF_QUERY_WAVES   // staged variant: compile the shading kernel of the wavefront schedule for this many waves per SIMD (default: whatever 239 VGPRs allow, 2)
+__global__ __launch_bounds__(TR_BLOCK, WF_QUERY_WAVES) void k_wf_query(
+#else
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_query(
+#endif
+    const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ queue_c,
                                                        uint32_t* __restrict__ qctl) {
     const DevScene& sc = scv;
     const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
