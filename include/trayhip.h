@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TRAY_ABI_VERSION 2
+#define TRAY_ABI_VERSION 3
 
 enum {
     TRAY_OK = 0,
@@ -295,6 +295,9 @@ typedef struct TrayKernelTiming {
     uint64_t samples;       /* camera samples traced */
     uint64_t vertices;      /* path vertices shaded (iterations of path.rs:69) */
     uint64_t rays;          /* Scene::intersect calls */
+    uint64_t retraced;      /* rays of the flat instance loop whose closest candidates tied (or sat inside one another's bounding-box
+                             * window) and that were therefore traced again with the reference's BVH<Instance> traversal
+                             * (geometry/bvh.rs:81-130), which decides by its visiting order; about 1 in 1e7 on cornell_box */
 } TrayKernelTiming;
 int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t);
 

@@ -69,9 +69,15 @@ def emu(qwide=False, defines=()):
         h.emu_render_tiles.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         h.emu_render_wavefront.restype = C.c_int
         h.emu_render_wavefront.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        h.emu_retraced.restype = C.c_uint
         assert h.emu_is_qwide() == int("TR_QWIDE" in defines)
         _libs[key] = h
     return _libs[key]
+
+
+def retraced(defines=()):
+    """rays the flat instance loop handed to the reference's two-level traversal since the last call (tied candidates)"""
+    return int(emu(defines=defines).emu_retraced())
 
 
 def debug_intersect(flat, rays, hit_dtype):

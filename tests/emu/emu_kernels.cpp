@@ -71,11 +71,15 @@ namespace trayh { void set_error(const std::string&) {} }
 
 namespace {
 
+uint32_t g_retraced = 0;   // accumulated over the calls of this process; read and reset by emu_retraced()
+
 struct EmuScene {
     DevScene d{};
     std::vector<DevMaterial> mats;
     std::vector<uint32_t> wide_words, wide_roots;
     std::vector<TrayBvhNode> inst_leaf;
+    std::vector<uint8_t> tri_leaf;
+    uint32_t retraced = 0;   // rays the flat loop handed to trace_bvh
     uint32_t depth = 0;   // traversal stack entries per lane, as tray_scene_create sizes them (two-level worst case, generous)
 };
 
@@ -106,17 +110,10 @@ void make_scene(const TrayFlatScene* f, int wide_format, EmuScene& e) {
     d.width = f->film.width; d.height = f->film.height; d.frame = f->frame; d.film_rows = 0; d.coop_offset = 0;
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
-#ifdef TR_CAMERA_PTR
     d.camera_p = &f->camera;
-#else
-    d.camera = f->camera;
-#endif
-#ifdef TR_EXACT_FLAT
-    e.inst_leaf.assign(f->n_instances, TrayBvhNode{});
-    for (uint32_t nd = 0; nd < f->n_top_nodes; ++nd)
-        for (uint32_t k = 0; k < f->top_nodes[nd].count; ++k) e.inst_leaf[f->top_order[f->top_nodes[nd].offset + k]] = f->top_nodes[nd];
-    d.inst_leaf = e.inst_leaf.data();
-#endif
+    tray::flat_loop_gates(f, TR_COOP_MAX_TRIS, e.inst_leaf, e.tri_leaf);
+    d.inst_leaf = e.inst_leaf.data(); d.tri_leaf = e.tri_leaf.data();
+    d.retraced = &g_retraced;
     uint32_t mesh_depth = 0;
     for (uint32_t m = 0; m < f->n_meshes; ++m) mesh_depth = std::max(mesh_depth, bvh_depth(f->mesh_nodes + f->meshes[m].node_offset, f->meshes[m].node_count));
     e.depth = mesh_depth + bvh_depth(f->top_nodes, f->n_top_nodes) + 8u;
@@ -448,3 +445,5 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
 }
 
 }  // extern "C"
+
+extern "C" unsigned emu_retraced(void) { const unsigned r = g_retraced; g_retraced = 0; return r; }

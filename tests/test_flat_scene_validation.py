@@ -115,3 +115,56 @@ def test_inconsistent_scene_is_rejected_before_any_device_call(case, dragon):
     CASES[case](f, keep)
     rc, msg = create(f)
     assert rc == L.TRAY_E_INVALID and "inconsistent scene" in msg, (case, rc, msg)
+
+
+# ---- moving scenes: the device indexes the per-path transform cache by moving_slot and searches the knots of every moving level
+@pytest.fixture(scope="module")
+def moving(tmp_path_factory, built):
+    import json
+    import os
+    d = str(tmp_path_factory.mktemp("valmov"))
+    scenes.write_assets(d)
+    p = os.path.join(d, "moving_box.json")
+    json.dump(scenes.moving_box(64, 64, 4), open(p, "w"))
+    scene, *_ = T.Scene.load_file(p)
+    return scene, scene.flatten(1)
+
+
+def animated_instances(f):
+    return [i for i in range(f.n_instances) if f.instances[i].animated]
+
+
+def moving_level(f):
+    return next(l for l in range(f.n_xf_levels) if f.xf_levels[l].kf_count >= 2)
+
+
+def patch_knot(f, keep, level, k, value):
+    a = array_copy(f.knots, f.n_knots, C.c_float)
+    a[f.xf_levels[level].knot_first + k] = value
+    keep.append(a)
+    f.knots = C.cast(a, L._P(C.c_float))
+
+
+MOVING_CASES = {
+    "moving_slot past the animated instances": lambda f, keep: patch_instance(f, keep, animated_instances(f)[0], "moving_slot", 0xffffffff),
+    "moving_slot shared by two instances": lambda f, keep: patch_instance(f, keep, animated_instances(f)[0], "moving_slot",
+                                                                          f.instances[animated_instances(f)[1]].moving_slot),
+    "decreasing knots": lambda f, keep: patch_knot(f, keep, moving_level(f), 1, 1e9),
+    "NaN knot": lambda f, keep: patch_knot(f, keep, moving_level(f), 2, float("nan")),
+}
+
+
+def test_moving_scene_of_the_loader_passes_the_check(moving):
+    f = moving[1].contents
+    assert len(animated_instances(f)) >= 2
+    rc, msg = create(clone(moving[1]))
+    assert rc == 0 or "inconsistent" not in msg
+
+
+@pytest.mark.parametrize("case", sorted(MOVING_CASES))
+def test_inconsistent_moving_scene_is_rejected(case, moving):
+    f = clone(moving[1])
+    keep = []
+    MOVING_CASES[case](f, keep)
+    rc, msg = create(f)
+    assert rc == L.TRAY_E_INVALID and "inconsistent scene" in msg, (case, rc, msg)

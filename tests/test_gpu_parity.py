@@ -370,9 +370,9 @@ def _config_at(fi, frame, spp=32):
 
 def test_tr15_stand_in_image_rmse(tmp_path):
     """59 instances (BVH<Instance> on the device), 14 of them moving, 10 keyed lights, MERL / glass / metal, depth 10."""
-    p, _ = scenes.write_tr15_like_assets(str(tmp_path), film=(160, 96, 64), detail=0.05)
+    p, _ = scenes.write_tr15_like_assets(str(tmp_path), film=(160, 96, 256), detail=0.05)
     scene, rt, _, fi = T.Scene.load_file(p)
-    frame, spp = 330, 64
+    frame, spp = 330, 256   # (at 64 spp the few paths that per-ray slerp flips leave 1.5e-4; the error falls as 1 / sqrt(spp))
     hip = T.Hip(0, seed=2)
     hip.render(scene, rt, _config_at(fi, frame, spp))
     gpu = rt.get_renderf32().reshape(rt.height, rt.width, 4).copy()
@@ -382,7 +382,7 @@ def test_tr15_stand_in_image_rmse(tmp_path):
     assert abs(int(tim.vertices) - int(st.vertices)) <= 1e-3 * st.vertices
     r = rmse(gpu, cpu)
     print(f"tr15_like frame {frame} 160x96x{spp}: RMSE {r:.3e} V {st.vertices / st.samples:.3f}")
-    assert r < 2e-4   # 1e-4 at a realistic sample count; see test_moving_scene_image_rmse
+    assert r < 1e-4
 
 
 @pytest.mark.parametrize("filt", [{"type": "gaussian", "width": 1.5, "height": 1.5, "alpha": 2.0},
@@ -443,9 +443,18 @@ def test_gpu_matches_the_golden_of_the_moving_and_mesh_scenes(name, tmp_path):
     hip = T.Hip(0, seed=9)
     hip.render(scene, rt, _config_at(fi, frame, 16))
     gpu = rt.get_renderf32().reshape(32, 48, 4)
-    # moving_box: 1536 pixels x 16 spp and per-ray libm inside slerp -> a flipped path moves the RMSE by ~1e-4 (see
-    # test_moving_scene_image_rmse); the static mesh scene holds the 1e-4 bar
-    assert rmse(gpu, g["rgbw"]) < (3e-4 if name == "moving_box" else 1e-4)
+    if name == "moving_box":
+        # 1536 pixels x 16 spp and per-ray libm inside slerp: ONE flipped path moves the RMSE of this small fixture by ~1e-4 (see
+        # test_moving_scene_image_rmse), so the 1e-4 bar is held on the same frame at 256 spp (second fixture)
+        assert abs(int(hip.last_timing.vertices) - int(g["vertices"])) <= 5
+        g = np.load(os.path.join(GOLDEN, "moving_box_48x32_256spp_seed9.npz"))
+        scene, rt, _, fi = T.Scene.load_file(scenes.write_moving_box(d, width=48, height=32, samples=256))
+        hip.render(scene, rt, _config_at(fi, frame, 256))
+        gpu = rt.get_renderf32().reshape(32, 48, 4)
+        assert rmse(gpu, g["rgbw"]) < 1e-4
+        assert abs(int(hip.last_timing.vertices) - int(g["vertices"])) <= 5e-4 * int(g["vertices"])
+        return
+    assert rmse(gpu, g["rgbw"]) < 1e-4
     assert abs(int(hip.last_timing.vertices) - int(g["vertices"])) <= 5
 
 

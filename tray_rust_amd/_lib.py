@@ -116,7 +116,7 @@ class TraySceneInfo(C.Structure):
 
 class TrayKernelTiming(C.Structure):
     _fields_ = [("render_ms", C.c_float), ("launches", C.c_uint32), ("samples", C.c_uint64), ("vertices", C.c_uint64),
-                ("rays", C.c_uint64)]
+                ("rays", C.c_uint64), ("retraced", C.c_uint64)]
 
 
 class TrayRay(C.Structure):

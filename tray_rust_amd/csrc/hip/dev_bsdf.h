@@ -29,11 +29,7 @@ struct Lobe {
 
 // BSDF: shading frame in registers, lobes fetched from the material table when needed
 struct Bsdf {
-#ifdef TR_REMAT_BITAN   // staged variant: bitan = cross(tan, n) is recomputed where it is used instead of living across the traversals
     f3 p, n, tan;
-#else
-    f3 p, n, tan, bitan;
-#endif
     const DevMaterial* __restrict__ mat;
     const float* __restrict__ merl_data;
 };
@@ -292,11 +288,7 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
 }
 
 // ---- BSDF (world space) ------------------------------------------------------------------------
-#ifdef TR_REMAT_BITAN
 #define TR_BITAN(b) cross((b).tan, (b).n)
-#else
-#define TR_BITAN(b) ((b).bitan)
-#endif
 TR_DEV f3 to_shading(const Bsdf& b, f3 v) { return mk(dot(v, TR_BITAN(b)), dot(v, b.tan), dot(v, b.n)); }   // bsdf.rs:52-55
 TR_DEV f3 from_shading(const Bsdf& b, f3 v) {   // bsdf.rs:57-61
     const f3 bt = TR_BITAN(b);
@@ -392,9 +384,6 @@ TR_DEV Bsdf make_bsdf(const DevScene& sc, const Hit& hit) {
     b.n = normalized(hit.n);
     f3 bt = normalized(hit.dp_du);
     b.tan = cross(b.n, bt);
-#ifndef TR_REMAT_BITAN
-    b.bitan = cross(b.tan, b.n);
-#endif
     b.p = hit.p;
     b.mat = sc.materials + sc.instances[hit.inst].material_id;
     b.merl_data = sc.merl_data;

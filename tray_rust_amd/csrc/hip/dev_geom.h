@@ -65,17 +65,13 @@ struct DevScene {
     uint32_t coop_offset;   // word offset of the cooperative leaf test's LDS area behind the traversal stacks (0 = none)
     const float* __restrict__ wide_nodes;          // 4-wide collapse of every BVH<Triangle>, 32 floats per node (wavefront_wide.h); may be null
     const uint32_t* __restrict__ mesh_wide_root;   // per mesh: index of its root's wide node
-#ifdef TR_EXACT_FLAT
-    const TrayBvhNode* __restrict__ inst_leaf;     // per instance: the BVH<Instance> leaf node that holds it (staged variant, trace_flat)
-#endif
+    const TrayBvhNode* __restrict__ inst_leaf;     // per instance: the BVH<Instance> leaf node that holds it (trace_flat's gate)
+    uint32_t* __restrict__ retraced;               // counter of rays the flat loop handed to trace_bvh (tied candidates); may be null
+    const uint8_t* __restrict__ tri_leaf;          // per triangle of a mesh with <= TR_COOP_MAX_TRIS triangles: index of its BVH<Triangle> leaf node (mesh_leaf_coop's gate)
     float filter_w, filter_h, inv_w, inv_h;
     int32_t fpw, fph;
-#ifdef TR_CAMERA_PTR   // staged variant: the camera (44 words, read only where a camera sample starts) behind a pointer instead of by value,
                        // where it held scalar registers for the whole kernel (193 -> 140 SGPRs spilled to VGPR lanes in k_path_tiles)
     const TrayCamera* __restrict__ camera_p;
-#else
-    TrayCamera camera;
-#endif
 };
 
 struct Ray {
@@ -168,6 +164,28 @@ TR_DEV bool bbox_hit(const float4 lo, const float4 hi, const f3 o, const f3 inv_
     return tmin < max_t && tmax > min_t;
 }
 
+// BBox::fast_intersect that also reports the entry distance it compared with max_t (the flat loop's and the cooperative
+// leaf test's gates keep it: a candidate whose box is entered at or behind its own hit distance is a hazard, see trace_flat)
+TR_DEV bool bbox_hit_t(const float4 lo, const float4 hi, const f3 o, const f3 inv_dir, const bool nx, const bool ny, const bool nz,
+                       float min_t, float max_t, float& tmin_out) {
+    float bminx = lo.x, bminy = lo.y, bminz = lo.z, bmaxx = lo.w, bmaxy = hi.x, bmaxz = hi.y;
+    float tmin = ((nx ? bmaxx : bminx) - o.x) * inv_dir.x;
+    float tmax = ((nx ? bminx : bmaxx) - o.x) * inv_dir.x;
+    float tymin = ((ny ? bmaxy : bminy) - o.y) * inv_dir.y;
+    float tymax = ((ny ? bminy : bmaxy) - o.y) * inv_dir.y;
+    tmin_out = tmin;
+    if (tmin > tymax || tymin > tmax) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = ((nz ? bmaxz : bminz) - o.z) * inv_dir.z;
+    float tzmax = ((nz ? bminz : bmaxz) - o.z) * inv_dir.z;
+    if (tmin > tzmax || tzmin > tmax) return false;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    tmin_out = tmin;
+    return tmin < max_t && tmax > min_t;
+}
+
 // Test part of intersect_triangle (mesh.rs:136-171). Inclusive range test, no back-face culling.
 TR_DEV bool triangle_test(const TrayTriVerts* __restrict__ tv, f3 o, f3 d, float min_t, float max_t, float& t_out, float& b1_out, float& b2_out) {
     const float4* q = reinterpret_cast<const float4*>(tv);
@@ -214,27 +232,6 @@ TR_DEV bool rect_test(float width, float height, f3 o, f3 d, float min_t, float 
     if (p.x >= -hw && p.x <= hw && p.y >= -hh && p.y <= hh) { t_out = t; return true; }
     return false;
 }
-#ifdef TR_RECT_LAZY
-// staged variant: Instance::intersect + Rectangle::intersect on the WORLD ray with the z row of `inv` first -- the x / y rows of the
-// object-space origin and direction are only computed when t is in range. Same expressions as xf_point / xf_vector / rect_test.
-TR_DEV bool rect_test_lazy(const float* __restrict__ m, float width, float height, f3 wo, f3 wd, float min_t, float max_t, float& t_out) {
-    const float dz = m[8] * wd.x + m[9] * wd.y + m[10] * wd.z;
-    if (fabsf(dz) < 1e-8f) return false;
-    const float w = m[12] * wo.x + m[13] * wo.y + m[14] * wo.z + m[15];
-    const bool div = fabsf(w - 1.0f) < kEps;   // quirk Q5
-    float oz = m[8] * wo.x + m[9] * wo.y + m[10] * wo.z + m[11];
-    if (div) oz = oz / w;
-    const float t = -oz / dz;
-    if (t < min_t || t > max_t) return false;
-    float ox = m[0] * wo.x + m[1] * wo.y + m[2] * wo.z + m[3], oy = m[4] * wo.x + m[5] * wo.y + m[6] * wo.z + m[7];
-    if (div) { ox = ox / w; oy = oy / w; }
-    const float dx = m[0] * wd.x + m[1] * wd.y + m[2] * wd.z, dy = m[4] * wd.x + m[5] * wd.y + m[6] * wd.z;
-    const float px = ox + dx * t, py = oy + dy * t;
-    const float hw = width / 2.0f, hh = height / 2.0f;
-    if (px >= -hw && px <= hw && py >= -hh && py <= hh) { t_out = t; return true; }
-    return false;
-}
-#endif
 TR_DEV bool disk_test(float radius, float inner_radius, f3 o, f3 d, float min_t, float max_t, float& t_out) {   // disk.rs:42-66
     if (fabsf(d.z) == 0.0f) return false;
     float t = -o.z / d.z;
@@ -261,17 +258,18 @@ enum : uint32_t { STK_NODE = 0u, STK_INSTANCE = 1u << 30, STK_EXIT_MESH = 2u << 
 
 // BVH<Triangle>::intersect over one mesh (bvh.rs:81-130, leaf <= 16). Returns true if a triangle was
 // accepted; max_t shrinks as candidates are accepted. any_hit: stop at the first accepted candidate.
+// Node step: both children of a hit node are fetched and tested together, the far one is pushed only if its
+// box is hit now and is re-tested when popped, so the accepted candidates and their order are the reference's
+// (bvh.rs:89-127) in about 0.65x the dependent iterations of the one-node-per-step form (measured +6 .. 17 % on
+// mesh scenes). leaf_tmin: entry distance of the leaf box of the last accepted triangle (trace_flat's hazard test).
 TR_DEV bool mesh_traverse(const DevScene& sc, uint32_t* __restrict__ stack, const TrayMesh m, f3 o, f3 d, float min_t, float& max_t,
-                          bool any_hit, uint32_t& prim, float& b1, float& b2) {
+                          bool any_hit, uint32_t& prim, float& b1, float& b2, float& leaf_tmin) {
     const TrayBvhNode* __restrict__ tree = sc.mesh_nodes + m.node_offset;
     const TrayTriVerts* __restrict__ tris = sc.tri_verts + m.tri_offset;
     f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
     int sp = 0;
     bool any = false;
-#ifdef TR_MESH_TWO_CHILDREN   // staged variant (Next / C4): the node step of k_wf_trace_dyn -- both children of a hit node are fetched and
-                              // tested together, the far one is pushed only if its box is hit now and is re-tested when popped, so the accepted
-                              // candidates and their order are the reference's (bvh.rs:89-127) in about 0.65x the dependent iterations
     const uint32_t no_node = 0xffffffffu;
     uint32_t node_a = 0u, node_b = no_node;
     for (;;) {
@@ -279,8 +277,9 @@ TR_DEV bool mesh_traverse(const DevScene& sc, uint32_t* __restrict__ stack, cons
         const float4* qa = reinterpret_cast<const float4*>(tree + node_a);
         const float4* qb = reinterpret_cast<const float4*>(tree + (two ? node_b : node_a));
         const float4 alo = qa[0], ahi = qa[1], blo = qb[0], bhi = qb[1];
-        const bool ha = bbox_hit(alo, ahi, o, inv_dir, nx, ny, nz, min_t, max_t);
-        const bool hb = two && bbox_hit(blo, bhi, o, inv_dir, nx, ny, nz, min_t, max_t);
+        float ta, tb;
+        const bool ha = bbox_hit_t(alo, ahi, o, inv_dir, nx, ny, nz, min_t, max_t, ta);
+        const bool hb = bbox_hit_t(blo, bhi, o, inv_dir, nx, ny, nz, min_t, max_t, tb) && two;
         if (ha || hb) {
             if (ha && hb) { stack[sp * TR_BLOCK] = node_b; ++sp; }
             const uint32_t cur = ha ? node_a : node_b;
@@ -297,6 +296,7 @@ TR_DEV bool mesh_traverse(const DevScene& sc, uint32_t* __restrict__ stack, cons
                 float t, bb1, bb2;
                 if (triangle_test(tris + offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
                     max_t = t; prim = m.tri_offset + offset + k; b1 = bb1; b2 = bb2; any = true;
+                    leaf_tmin = ha ? ta : tb;
                     if (any_hit) return true;
                 }
             }
@@ -305,59 +305,33 @@ TR_DEV bool mesh_traverse(const DevScene& sc, uint32_t* __restrict__ stack, cons
         --sp;
         node_a = stack[sp * TR_BLOCK]; node_b = no_node;
     }
-#else
-    uint32_t current = 0;
-    for (;;) {
-        const float4* nq = reinterpret_cast<const float4*>(tree + current);
-        float4 lo = nq[0], hi = nq[1];
-        uint32_t offset = __float_as_uint(hi.z);
-        uint32_t meta = __float_as_uint(hi.w);
-        uint32_t count = meta & 0xffffu, axis = (meta >> 16) & 0xffu;
-        if (bbox_hit(lo, hi, o, inv_dir, nx, ny, nz, min_t, max_t)) {
-            if (count == 0u) {
-                bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
-                stack[sp * TR_BLOCK] = neg ? current + 1u : offset;
-                ++sp;
-                current = neg ? offset : current + 1u;
-                continue;
-            }
-            for (uint32_t k = 0; k < count; ++k) {
-                float t, bb1, bb2;
-                if (triangle_test(tris + offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
-                    max_t = t; prim = m.tri_offset + offset + k; b1 = bb1; b2 = bb2; any = true;
-                    if (any_hit) return true;
-                }
-            }
-        }
-        if (sp == 0) break;
-        --sp;
-        current = stack[sp * TR_BLOCK];
-    }
-#endif
     return any;
 }
 
 // Meshes of at most TR_COOP_MAX_TRIS triangles (the reference's cube.obj: 12) in the flat instance loop. Their BVH<Triangle>
 // is a dozen nodes deep enough that per-lane traversal costs a wave ~2000 instructions per instance however few of its lanes
 // hold a ray that passes the root box (measured: the two cubes were 32 % of the cornell_box kernel). Instead, after the
-// root box test (the reference's first test), the lanes of a wave share a brute-force test of ALL the mesh's triangles: the
-// n rays that pass are staged in LDS and every ray is tested by FOUR lanes, each taking a quarter of the triangles in leaf
-// order, so one pass of ceil(T/4) triangle tests serves 16 rays. The reference's sequential rule (a candidate is accepted
-// when t <= the closest t so far, mesh.rs:168 / bvh.rs:93-98) makes the survivor the valid candidate of minimal t, the last
-// one among equal t: each lane applies the rule to its triangles, a quad reduction applies it across the quarters.
-// Versus BVH traversal this differs only where the flat instance loop already does: candidates the reference's inner slab
-// tests drop by rounding (rays within an ulp of a leaf box edge) and the order among exactly tied t.
+// root box test (the reference's first test), the lanes of a wave share a test of ALL the mesh's triangles: the n rays that
+// pass are staged in LDS and every ray is tested by FOUR lanes, each taking a quarter of the triangles in leaf order, so one
+// pass of ceil(T/4) triangle tests serves 16 rays. Every triangle is gated by the box of its BVH<Triangle> leaf (tri_leaf),
+// tested with the ray's ORIGINAL max_t like the reference tests it when it reaches the leaf before any candidate was accepted
+// (the boxes of the leaf's ancestors contain it and are hit whenever it is). Returned: the valid candidate of minimal t
+// (max_t, prim, b1, b2), the entry distance of its leaf box (leaf_tmin) and `hazard` when another valid candidate of the mesh
+// lies at or below max(t, leaf_tmin) -- a tie, or a candidate inside the window in which the survivor's gate depends on the
+// order of the reference's traversal (trace_flat explains the rule); the caller then re-traces the ray the reference's way.
 #define TR_COOP_MAX_TRIS 16
-#define TR_COOP_WORDS 768   // per wave: ray o, d, min_t, max_t (8 x 64) + result t, k, b1, b2 (4 x 64)
+#define TR_COOP_WORDS 896   // per wave: ray o, d, min_t, gate max_t (8 x 64) + result t, k, b1, b2, second t, leaf box entry (6 x 64)
 TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float* __restrict__ w_lds, bool participate, f3 o, f3 d, float min_t,
-                           float& max_t, uint32_t& prim, float& b1, float& b2) {
+                           float gate_max_t, float accept_max_t, float& t_out, uint32_t& prim, float& b1, float& b2, float& leaf_tmin, bool& hazard) {
     const uint32_t lane = threadIdx.x & 63u;
-    const float4* nq = reinterpret_cast<const float4*>(sc.mesh_nodes + m.node_offset);
+    const TrayBvhNode* __restrict__ tree = sc.mesh_nodes + m.node_offset;
+    const float4* nq = reinterpret_cast<const float4*>(tree);
     const float4 lo = nq[0], hi = nq[1];
-    const uint32_t offset = 0u, T = m.tri_count;
+    const uint32_t T = m.tri_count;
     const TrayTriVerts* __restrict__ tris = sc.tri_verts + m.tri_offset;
+    const uint8_t* __restrict__ leaf_of = sc.tri_leaf + m.tri_offset;
     const f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const bool need = participate && bbox_hit(lo, hi, o, inv_dir, d.x < 0.0f, d.y < 0.0f, d.z < 0.0f, min_t, max_t);
+    const bool need = participate && bbox_hit(lo, hi, o, inv_dir, d.x < 0.0f, d.y < 0.0f, d.z < 0.0f, min_t, gate_max_t);
     const unsigned long long mask = __ballot(need);
     if (mask == 0ull) return false;
     const uint32_t n = (uint32_t)__popcll(mask);
@@ -365,45 +339,67 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float*
     if (need) {
         w_lds[0 * 64 + rank] = o.x; w_lds[1 * 64 + rank] = o.y; w_lds[2 * 64 + rank] = o.z;
         w_lds[3 * 64 + rank] = d.x; w_lds[4 * 64 + rank] = d.y; w_lds[5 * 64 + rank] = d.z;
-        w_lds[6 * 64 + rank] = min_t; w_lds[7 * 64 + rank] = max_t;
+        w_lds[6 * 64 + rank] = min_t; w_lds[7 * 64 + rank] = gate_max_t;
         w_lds[9 * 64 + rank] = -1.0f;   // no candidate yet
     }
     __builtin_amdgcn_wave_barrier();
     const uint32_t per = (T + 3u) >> 2, g = lane & 3u;
     for (uint32_t base = 0; base < n; base += 16u) {
         const uint32_t r = base + (lane >> 2);
-        float ct = 0.0f, cb1 = 0.0f, cb2 = 0.0f, ck = -1.0f;
+        // best candidate of this lane's quarter, the smallest t among its other candidates, the best one's leaf box entry
+        float ct = 0.0f, cb1 = 0.0f, cb2 = 0.0f, ck = -1.0f, c2 = TR_INF, cbox = 0.0f;
         if (r < n) {
             const f3 ro = mk(w_lds[0 * 64 + r], w_lds[1 * 64 + r], w_lds[2 * 64 + r]);
             const f3 rd = mk(w_lds[3 * 64 + r], w_lds[4 * 64 + r], w_lds[5 * 64 + r]);
-            const float rmin = w_lds[6 * 64 + r];
-            float cur = w_lds[7 * 64 + r];
+            const f3 rinv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+            const bool rnx = rd.x < 0.0f, rny = rd.y < 0.0f, rnz = rd.z < 0.0f;
+            const float rmin = w_lds[6 * 64 + r], rmax = w_lds[7 * 64 + r];
+            float box_t = 0.0f;
+            uint32_t leaf = 0xffffffffu;
+            bool gate = false;
             for (uint32_t j = 0; j < per; ++j) {
                 const uint32_t k = g * per + j;
                 if (k < T) {
+                    const uint32_t lf = leaf_of[k];
+                    if (lf != leaf) {   // (consecutive triangles usually share their leaf)
+                        leaf = lf;
+                        const float4* lq = reinterpret_cast<const float4*>(tree + lf);
+                        gate = bbox_hit_t(lq[0], lq[1], ro, rinv, rnx, rny, rnz, rmin, rmax, box_t);
+                    }
                     float t, bb1, bb2;
-                    if (triangle_test(tris + k, ro, rd, rmin, cur, t, bb1, bb2)) { cur = t; ct = t; cb1 = bb1; cb2 = bb2; ck = (float)k; }
+                    if (gate && triangle_test(tris + k, ro, rd, rmin, rmax, t, bb1, bb2)) {
+                        if (ck < 0.0f || t < ct) { c2 = ck < 0.0f ? c2 : fminf(c2, ct); ct = t; cb1 = bb1; cb2 = bb2; ck = (float)k; cbox = box_t; }
+                        else c2 = fminf(c2, t);
+                    }
                 }
             }
         }
-        // quad reduction in triangle order: the later quarter wins ties (all four lanes of a quad are active together)
+        // quad reduction (all four lanes of a quad are active together)
 #pragma unroll
         for (int step = 1; step <= 2; step <<= 1) {
-            const float ot = __shfl_xor(ct, step), ok = __shfl_xor(ck, step), ob1 = __shfl_xor(cb1, step), ob2 = __shfl_xor(cb2, step);
-            const bool take = ok >= 0.0f && (ck < 0.0f || ot < ct || (!(ct < ot) && ok > ck));
-            if (take) { ct = ot; ck = ok; cb1 = ob1; cb2 = ob2; }
+            const float ot = __shfl_xor(ct, step), ok = __shfl_xor(ck, step), ob1 = __shfl_xor(cb1, step), ob2 = __shfl_xor(cb2, step),
+                        o2 = __shfl_xor(c2, step), obox = __shfl_xor(cbox, step);
+            const bool both = ok >= 0.0f && ck >= 0.0f;
+            const bool take = ok >= 0.0f && (ck < 0.0f || ot < ct);
+            c2 = fminf(c2, o2);
+            if (both) c2 = fminf(c2, take ? ct : ot);   // the loser of the two bests is the other side's closest rival
+            if (take) { ct = ot; ck = ok; cb1 = ob1; cb2 = ob2; cbox = obox; }
         }
         if (r < n && g == 0u && ck >= 0.0f) {
             w_lds[8 * 64 + r] = ct; w_lds[9 * 64 + r] = ck; w_lds[10 * 64 + r] = cb1; w_lds[11 * 64 + r] = cb2;
+            w_lds[12 * 64 + r] = c2; w_lds[13 * 64 + r] = cbox;
         }
     }
     __builtin_amdgcn_wave_barrier();
     bool hit = false;
     if (need) {
         const float ck = w_lds[9 * 64 + rank];
-        if (ck >= 0.0f) {
-            max_t = w_lds[8 * 64 + rank]; prim = m.tri_offset + offset + (uint32_t)ck;
+        if (ck >= 0.0f && w_lds[8 * 64 + rank] <= accept_max_t) {
+            const float t = w_lds[8 * 64 + rank], c2 = w_lds[12 * 64 + rank], cbox = w_lds[13 * 64 + rank];
+            t_out = t; prim = m.tri_offset + (uint32_t)ck;
             b1 = w_lds[10 * 64 + rank]; b2 = w_lds[11 * 64 + rank];
+            leaf_tmin = cbox;
+            hazard = !(c2 > t && c2 > cbox);   // (also true when cbox is NaN)
             hit = true;
         }
     }
@@ -413,23 +409,41 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float*
 // Scene::intersect for scenes with a handful of instances: every lane tests the instances in scene
 // order inside one wave-uniform loop. The instance index is uniform, so the transform and the geometry
 // parameters are scalar loads and the primitive type never diverges; only BVH<Triangle> traversal is
-// per lane. Versus BVH<Instance>::intersect this skips the (conservative) node culling and visits the
-// instances in a different order: the closest hit is the same except for exactly tied t (two
-// instances hit at the same f32 distance) and for rays the reference's slab test drops by rounding.
+// per lane.
+//
+// Exactness versus BVH<Instance>::intersect (bvh.rs:81-130), which visits the instances leaf by leaf in a
+// ray-dependent order and reaches one only if its leaf's box passes fast_intersect with the ray's CURRENT max_t.
+// Call C the candidates that are valid for the ray's original [min_t, max_t] and whose gates -- the box of the
+// instance's BVH<Instance> leaf and, for triangles, the box of their BVH<Triangle> leaf; ancestors contain them and
+// are hit whenever they are (the slab arithmetic is monotone in the bounds) -- pass with the ORIGINAL max_t.
+//  * any-hit rays (OcclusionTester): until a candidate is accepted the reference's max_t is the original one, so it
+//    accepts one iff C is not empty. The loop below returns at the first member of C it meets: the same boolean.
+//  * closest-hit rays: let a be the minimum of C (t_a = B), G the largest entry distance of a's gates. If every other
+//    member of C has t > max(B, G), the reference returns a whatever its order: when it reaches a its max_t is the
+//    original one or the t' of an accepted candidate, t' > G, so a's gates pass and a is accepted; earlier accepted
+//    candidates are overwritten, later ones have t > B. (G is usually far below B; for the flat box of an axis-aligned
+//    wall G and B are the same number up to rounding, which is why the window is max(B, G) and not B.)
+//    The loop tests every instance whose gate passes with the original max_t against the bound max(closest so far, its
+//    gate entry): a candidate accepted at or behind the closest one (R1), or a new closest one whose gate is entered at or
+//    behind the previous closest (R2), shows that a second candidate lies inside the window -- a tie or a rounding
+//    coincidence, about one ray in 1e7 -- and sets `hazard`; trace() re-traces those rays with trace_bvh, which IS the
+//    reference's traversal. No member of C inside the window escapes: one tested after a meets the bound max(B, G); one
+//    tested before a either was the closest so far when a arrived (R2) or lies behind a closest-so-far that is (R2).
+//    BVH<Triangle> traversals start from the ORIGINAL max_t (a start value the reference did not have would prune
+//    differently) and report the entry distance of the winning triangle's leaf box, which is part of G.
+// The flat loop therefore returns the reference's hit record bit for bit; tests/test_device_emulation.py and
+// tests/test_gpu_parity.py check it on random scenes and on scenes built to produce ties (coincident walls).
 #ifndef TR_FLAT_MAX
 #define TR_FLAT_MAX 16
 #endif
-TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, bool active, HitRec& rec) {
-    const float min_t = ray.min_t;
-    float max_t = ray.max_t;
+TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, bool active, HitRec& rec, bool& hazard) {
+    const float min_t = ray.min_t, gate_max_t = ray.max_t;
+    float max_t = ray.max_t;          // closest accepted candidate so far
+    float best_gate = -TR_INF;        // G of that candidate
     bool any = false, done = !active;   // lanes without a ray run along: the cooperative leaf test uses their ALUs
     const uint32_t n = sc.n_instances;
-#ifdef TR_EXACT_FLAT   // staged variant: the reference reaches an instance only through the box of its BVH<Instance> leaf (bvh.rs:89-98); a box
-                       // that contains a hit box is hit, so testing the leaf's box here reproduces every drop of that traversal -- the
-                       // grazing rays along zero-thickness boxes that make up the flat loop's deviation class
     const f3 w_inv_dir = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     const bool wnx = ray.d.x < 0.0f, wny = ray.d.y < 0.0f, wnz = ray.d.z < 0.0f;
-#endif
     for (uint32_t i = 0; i < n; ++i) {
         // the instance index is wave-uniform: read the record through the constant address space so the
         // transform and the geometry parameters arrive as scalar loads (SGPRs), not 64 identical lane loads
@@ -443,42 +457,42 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
         const float gp0 = in->geom_params[0], gp1 = in->geom_params[1];
         const uint32_t mesh_id = in->mesh_id;
         // Instance::intersect (receiver.rs:29-35): world ray -> object ray by `inv`, direction not renormalised
-#ifdef TR_RECT_LAZY
-        f3 o = ray.o, d = ray.d;
-        if (gt != TRAY_GEOM_RECT) { o = xf_point(inv, ray.o); d = xf_vector(inv, ray.d); }
-#else
         const f3 o = xf_point(inv, ray.o);
         const f3 d = xf_vector(inv, ray.d);
-#endif
-        float t = max_t;
-        bool hit = false;
+        const float bound = fmaxf(max_t, best_gate);   // (best_gate is -inf until a candidate was accepted)
+        float t = bound;
+        bool hit = false, hz = false;
         uint32_t prim = 0u;
-        float b1 = 0.0f, b2 = 0.0f;
-#ifdef TR_EXACT_FLAT
+        float b1 = 0.0f, b2 = 0.0f, box_t = 0.0f, leaf_t = -TR_INF;
         typedef const __attribute__((address_space(4))) float* ConstBox;   // (scalar loads, like the instance record)
         ConstBox lb = (ConstBox)(sc.inst_leaf + i);
         const float4 leaf_lo = make_float4(lb[0], lb[1], lb[2], lb[3]), leaf_hi = make_float4(lb[4], lb[5], lb[6], lb[7]);
-        const bool wanted = !done && bbox_hit(leaf_lo, leaf_hi, ray.o, w_inv_dir, wnx, wny, wnz, min_t, max_t);
-#else
-        const bool wanted = !done;
-#endif
+        const bool wanted = bbox_hit_t(leaf_lo, leaf_hi, ray.o, w_inv_dir, wnx, wny, wnz, min_t, gate_max_t, box_t) && !done;
         if (gt == TRAY_GEOM_MESH && sc.coop_offset != 0u && sc.meshes[mesh_id].tri_count <= TR_COOP_MAX_TRIS) {
             // small mesh: the whole wave enters, lanes without a pending ray only lend their ALUs
             volatile float* w_lds = reinterpret_cast<volatile float*>(stack - threadIdx.x + sc.coop_offset) + (threadIdx.x >> 6) * TR_COOP_WORDS;
-            hit = mesh_leaf_coop(sc, sc.meshes[mesh_id], w_lds, wanted, o, d, min_t, t, prim, b1, b2);
+            hit = mesh_leaf_coop(sc, sc.meshes[mesh_id], w_lds, wanted, o, d, min_t, gate_max_t, bound, t, prim, b1, b2, leaf_t, hz);
         } else if (wanted) {
-#ifdef TR_RECT_LAZY
-            if (gt == TRAY_GEOM_RECT) hit = rect_test_lazy(inv, gp0, gp1, o, d, min_t, max_t, t);
-#else
-            if (gt == TRAY_GEOM_RECT) hit = rect_test(gp0, gp1, o, d, min_t, max_t, t);
-#endif
-            else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(gp0, o, d, min_t, max_t, t);
-            else if (gt == TRAY_GEOM_MESH) hit = mesh_traverse(sc, stack, sc.meshes[mesh_id], o, d, min_t, t, any_hit, prim, b1, b2);
-            else hit = disk_test(gp0, gp1, o, d, min_t, max_t, t);
+            if (gt == TRAY_GEOM_RECT) hit = rect_test(gp0, gp1, o, d, min_t, bound, t);
+            else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(gp0, o, d, min_t, bound, t);
+            else if (gt == TRAY_GEOM_MESH) {
+                float mt = gate_max_t;   // the mesh's own traversal, from the original max_t
+                hit = mesh_traverse(sc, stack, sc.meshes[mesh_id], o, d, min_t, mt, any_hit, prim, b1, b2, leaf_t) && mt <= bound;
+                t = mt;
+            } else hit = disk_test(gp0, gp1, o, d, min_t, bound, t);
         }
         if (hit) {
-            max_t = t;
-            rec.t = t; rec.inst = i; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
+            const float gate_new = fmaxf(box_t, leaf_t);
+            const bool closer = !any || t < max_t;
+            if (!any_hit) {
+                if (!closer) hazard = true;                              // R1: a second candidate inside the window of the closest one
+                else if (any && !(gate_new < max_t)) hazard = true;      // R2: the previous closest one lies inside the window of the new one
+                if (hz || box_t != box_t || leaf_t != leaf_t) hazard = true;   // rivals inside a small mesh; NaN entry distances
+            }
+            if (closer) {
+                max_t = t; best_gate = gate_new;
+                rec.t = t; rec.inst = i; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
+            }
             any = true;
             done = any_hit;
         }
@@ -614,8 +628,17 @@ TR_DEV TraceResult trace(const DevScene* __restrict__ scp, uint32_t* __restrict_
     r.rec.t = 0.0f; r.rec.inst = 0xffffffffu; r.rec.prim = 0u; r.rec.b1 = 0.0f; r.rec.b2 = 0.0f;
     // moving scenes always take BVH<Instance>: its boxes are the reference's swept bounds (animated_transform.rs:58-71),
     // including the instances those bounds cut off, which the flat loop would not reproduce
-    if (!ANIM && sc.n_instances <= TR_FLAT_MAX) r.hit = trace_flat(sc, stack, ray, any_hit, active, r.rec);
-    else r.hit = active ? trace_bvh<ANIM>(sc, stack, ray, any_hit, r.rec) : false;
+    if (!ANIM && sc.n_instances <= TR_FLAT_MAX) {
+        bool hazard = false;
+        r.hit = trace_flat(sc, stack, ray, any_hit, active, r.rec, hazard);
+        if (__any(hazard)) {   // (about one ray in 1e7: tied candidates, or a box entered behind its own hit) the reference's traversal decides
+            if (hazard) {
+                if (sc.retraced) atomicAdd(sc.retraced, 1u);
+                r.rec.t = 0.0f; r.rec.inst = 0xffffffffu; r.rec.prim = 0u; r.rec.b1 = 0.0f; r.rec.b2 = 0.0f;
+                r.hit = trace_bvh<0>(sc, stack, ray, false, r.rec);
+            }
+        }
+    } else r.hit = active ? trace_bvh<ANIM>(sc, stack, ray, any_hit, r.rec) : false;
     return r;
 }
 

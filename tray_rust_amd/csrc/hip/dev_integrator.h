@@ -23,11 +23,7 @@ namespace tr {
 
 template <int ANIM>
 TR_DEV Ray camera_ray(const DevScene& sc, float px, float py, float time) {
-#ifdef TR_CAMERA_PTR
     const TrayCamera& c = *sc.camera_p;
-#else
-    const TrayCamera& c = sc.camera;
-#endif
     f3 q = xf_point(c.raster_to_cam, mk(px, py, 0.0f));
     f3 px_pos = mk(c.scaling[0], c.scaling[1], c.scaling[2]) * q;
     f3 d = normalized(px_pos);
@@ -88,33 +84,18 @@ struct Lane {
     uint32_t ks;           // sample key: scrambles and shuffle entries of the six LD arrays derive from it
     float time;            // ray.time of the camera ray, inherited by every ray of the path (path.rs:110, mod.rs:154)
     uint32_t col;          // the path's column of the transform cache (ANIM): thread id (tile kernel) or pool slot (wavefront)
-#ifdef TR_NO_LANE_O   // staged variant: the stage A ray starts at the previous vertex (bsdf.p) -- or at the camera, parked in bsdf.p until the first hit
-    f3 d;
-#define LN_O(ln) ((ln).bsdf.p)
-#else
     f3 o, d;               // stage A ray: camera ray, or continuation from the previous vertex
 #define LN_O(ln) ((ln).o)
-#endif
     f3 throughput, illum;
     f3 first_ng;           // hit.dg.ng of the camera ray's hit (quirk Q1)
     Bsdf bsdf;             // shading context of the current vertex (BSDF::new)
-#ifndef TR_REMAT_WO   // staged variant: w_o is -d until the PATH query writes the next ray's direction, so it need not be kept
-    f3 w_o;
-#endif
     uint32_t light_inst;
-#ifdef TR_SHARE_WIL   // staged variant: wi_l (written in vertex_begin, last read by the LIGHT query) and mis_f (written by the MIS query, which
                       // follows it) never live at the same time
     f3 li;
     union { f3 wi_l; f3 mis_f; };
-#else
-    f3 li, wi_l;           // light sample (stage B)           | stage C: li = (|cos|, mis weight, pdf_bsdf)
-#endif
     float pdf_l;
     f3 aux_d;              // stage B: occlusion segment p_w - p | stage C: BSDF-sampled direction
     f3 direct;             // direct_light of estimate_direct
-#ifndef TR_SHARE_WIL
-    f3 mis_f;              // f of the BSDF half (stage C)
-#endif
     f3 t_vertex;           // throughput at this vertex, kept for `illum += throughput * direct`
 #ifdef TR_STAGE_CLOCKS   // instrumented builds only: wave clocks of the parts of a BSDF query (set by k_path_tiles, null elsewhere)
     unsigned long long* qclk = nullptr;   // [0] sample head / light setup, [1] eval + pdf site, [2] epilogue of the query kind
@@ -187,9 +168,6 @@ TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counte
         }
     }
     ln.bsdf = make_bsdf(sc, hit);
-#ifndef TR_REMAT_WO
-    ln.w_o = -ln.d;
-#endif
     ln.direct = mk(0.0f, 0.0f, 0.0f);
     ln.t_vertex = ln.throughput;
     ln.flags &= ~(LF_SHADOW | LF_MIS | LF_LAST);
@@ -234,18 +212,13 @@ TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counte
 //   WANT_PATH   path continuation (path.rs:84-110): next stage A ray, or LF_LAST
 // Returns the follow-up query.
 template <int ANIM, int FEAT>
-TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
+TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want, const f3 wo_sh) {
     const bool is_light = want == WANT_LIGHT, mis = want == WANT_MIS;
     const uint32_t flags = want == WANT_PATH ? BX_ALL : BX_NON_SPECULAR;
     const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
     const bool delta = light->kind == TRAY_INST_POINT_EMITTER;
     SampleHead h;
     TR_QCLK_START(ln);
-#ifdef TR_REMAT_WO
-    const f3 wo_sh = normalized(to_shading(ln.bsdf, -ln.d));
-#else
-    const f3 wo_sh = normalized(to_shading(ln.bsdf, ln.w_o));
-#endif   // (wo_sh is shared by sample / eval / pdf: the same value each of them computes)
     if (is_light) {
         h.wi_world = ln.wi_l; h.f = mk(0.0f, 0.0f, 0.0f); h.pdf = 0.0f; h.sampled_type = 0u;
         h.need_eval = true; h.need_pdf = !delta;
@@ -312,9 +285,7 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want) {
         ln.throughput = ln.throughput / cont_prob;
     }
     if (ln.bounce == sc.max_depth) { ln.flags |= LF_LAST; return WANT_NONE; }
-#ifndef TR_NO_LANE_O
     ln.o = ln.bsdf.p;
-#endif
     ln.d = normalized(w_i);
     return WANT_NONE;
 }
@@ -324,16 +295,19 @@ template <int ANIM, int FEAT>
 TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
     const bool delta = sc.instances[ln.light_inst].kind == TRAY_INST_POINT_EMITTER;
     uint32_t want = ((ln.flags & LF_SHADOW) && !occluded) ? WANT_LIGHT : (delta ? WANT_PATH : WANT_MIS);
+    // w_o in shading space, once per vertex: BSDF::eval, ::pdf and ::sample each start with the same to_shading + normalized of the
+    // same vector (bsdf.rs:67-68,86,115-116). w_o is -d until the PATH query (the last one) writes the next ray's direction.
+    const f3 wo_sh = normalized(to_shading(ln.bsdf, -ln.d));
 #if defined(TR_EMU_PROFILE)   // divergence-profile build of tests/emu: the default schedule, its passes numbered
     for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) {
         TR_EMU_PHASE(pass + 1);
-        want = query_stage<ANIM, FEAT>(sc, ln, want);
+        want = query_stage<ANIM, FEAT>(sc, ln, want, wo_sh);
     }
     TR_EMU_PHASE(0);
 #else
 #pragma nounroll
     for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) {   // LIGHT -> MIS -> PATH
-        want = query_stage<ANIM, FEAT>(sc, ln, want);
+        want = query_stage<ANIM, FEAT>(sc, ln, want, wo_sh);
         TR_QCLK(ln, 2);
     }
 #endif

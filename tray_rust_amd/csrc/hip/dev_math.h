@@ -51,7 +51,9 @@ TR_DEV f3 xf_point(const float* __restrict__ m, f3 p) {
     r.y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
     r.z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
     float w = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
-    if (fabsf(w - 1.0f) < kEps) r = r / w;   // quirk Q5: divides only when w is (almost) one
+    // quirk Q5: divides only when w is (almost) one. x / 1.0f == x for every x, so the (three IEEE) divides are skipped when w is
+    // exactly one -- the case of every affine instance transform (row 3 = 0 0 0 1): same bits, ~45 FMA-equivalents less per call
+    if (w != 1.0f && fabsf(w - 1.0f) < kEps) r = r / w;
     return r;
 }
 TR_DEV f3 xf_vector(const float* __restrict__ m, f3 v) {   // transform.rs:165-172,218-229

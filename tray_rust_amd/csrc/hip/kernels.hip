@@ -27,6 +27,7 @@
 #include "../../../include/trayhip.h"
 #include "../host/wide_nodes.hpp"
 #include "../host/validate.hpp"
+#include "../host/gates.hpp"
 #include "dev_integrator.h"
 
 namespace trayh { void set_error(const std::string& msg); }
@@ -226,10 +227,8 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
     Counters cnt;
     cnt.rays = 0; cnt.vertices = 0;
     uint32_t n_samples = 0;
-#ifdef TR_WAVE_COUNTERS   // staged variant: the three statistics counters as wave totals (ballot + popcount, wave-uniform: SGPRs) instead of three
                           // VGPRs that live across the whole kernel
     uint32_t w_samples = 0u, w_vertices = 0u, w_rays = 0u;
-#endif
 #ifdef TR_STAGE_CLOCKS
     unsigned long long clk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 0..6 stages, 8..10 parts of the BSDF queries (dev_integrator.h: TR_QCLK)
     long long clk_t = clock64();
@@ -258,9 +257,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
         ln.qclk = clk + 8;
 #endif
         for (;;) {   // one path vertex per live lane and step
-#ifdef TR_WAVE_COUNTERS
             bool started = false;
-#endif
             if (!(ln.flags & LF_ALIVE)) {
                 // the previous sample of this lane is finished: RenderTarget::write it, start the next one
                 if (pending) {
@@ -274,17 +271,11 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
                     lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), key_sample(kp, s_next));
                     if (ANIM) { ln.col = xf_cache_lane(); xf_cache_fill(sc, ln.time, ln.col); }   // the path's transforms of the moving instances, once per camera sample
                     s_next += TR_BLOCK / 64;
-#ifdef TR_WAVE_COUNTERS
                     started = true;
-#else
-                    ++n_samples;
-#endif
                     pending = true;
                 }
             }
-#ifdef TR_WAVE_COUNTERS
             w_samples += (uint32_t)__popcll(__ballot(started));
-#endif
             if (!__any(ln.flags & LF_ALIVE)) break;
 #ifdef TR_STAGE_CLOCKS
 #define TR_CLK(slot) do { const long long now_ = clock64(); clk[slot] += (unsigned long long)(now_ - clk_t); clk_t = now_; } while (0)
@@ -299,21 +290,14 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
                 TraceResult tr_;
                 tr_.hit = false;
                 tr_.rec.t = 0.0f; tr_.rec.inst = 0xffffffffu; tr_.rec.prim = 0u; tr_.rec.b1 = 0.0f; tr_.rec.b2 = 0.0f;
-#ifdef TR_WAVE_COUNTERS
                 const unsigned long long wr_ = __ballot(want_ray);
                 w_rays += (uint32_t)__popcll(wr_);
                 if (wr_ != 0ull) {
-#else
-                if (__any(want_ray)) {   // the whole wave enters the traversal code (dev_geom.h: cooperative leaf test)
-                    if (want_ray) cnt.rays++;
-#endif
                     const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
                     tr_ = trace<ANIM>(scp, my_stack, r, stage == 1, want_ray);
                 }
                 TR_CLK(stage);   // trace A / B / C
-#ifdef TR_WAVE_COUNTERS
                 if (stage == 0) w_vertices += (uint32_t)__popcll(__ballot(alive && tr_.hit));
-#endif
                 if (alive) {
                     if (stage == 0) {
                         if (tr_.hit) vertex_begin<ANIM>(sc, ln, tr_.rec, cnt);
@@ -350,17 +334,11 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
         }
     }
     if (stats) {
-#ifdef TR_WAVE_COUNTERS
         if (lane == 0u) {
             atomicAdd(&stats->samples, (unsigned long long)w_samples);
             atomicAdd(&stats->vertices, (unsigned long long)w_vertices);
             atomicAdd(&stats->rays, (unsigned long long)w_rays);
         }
-#else
-        atomicAdd(&stats->samples, (unsigned long long)n_samples);
-        atomicAdd(&stats->vertices, (unsigned long long)cnt.vertices);
-        atomicAdd(&stats->rays, (unsigned long long)cnt.rays);
-#endif
 #ifdef TR_STAGE_CLOCKS
         if ((tid & 63u) == 0u)
             for (int k = 0; k < 11; ++k) atomicAdd(&stats->trav[k], clk[k]);
@@ -490,6 +468,7 @@ struct TrayDeviceScene {
     uint32_t n_tiles = 0;
     uint32_t* d_counter = nullptr;
     DevStats* d_stats = nullptr;
+    uint32_t* d_retraced = nullptr;   // rays the flat instance loop re-traced through BVH<Instance> (dev_geom.h: trace)
     TrayInstance* d_instances = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_valid = false;
@@ -737,17 +716,16 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             s->wf_wide = rc == TRAY_OK;
         }
     }
-#ifdef TR_EXACT_FLAT   // variant build: the BVH<Instance> leaf of every instance, for the leaf-box test of the flat loop (dev_geom.h)
-    if (rc == TRAY_OK) {
-        std::vector<TrayBvhNode> leaf(f->n_instances);
-        std::memset(leaf.data(), 0, leaf.size() * sizeof(TrayBvhNode));
-        for (uint32_t nd = 0; nd < f->n_top_nodes; ++nd)
-            for (uint32_t k = 0; k < f->top_nodes[nd].count; ++k) leaf[f->top_order[f->top_nodes[nd].offset + k]] = f->top_nodes[nd];
+    if (rc == TRAY_OK) {   // gates of the flat instance loop (dev_geom.h: trace_flat, mesh_leaf_coop)
+        std::vector<TrayBvhNode> leaf;
+        std::vector<uint8_t> tri_leaf;
+        tray::flat_loop_gates(f, TR_COOP_MAX_TRIS, leaf, tri_leaf);
         const TrayBvhNode* d_leaf = nullptr;
+        const uint8_t* d_tri_leaf = nullptr;
         rc = upload(s, leaf.data(), leaf.size(), &d_leaf);
-        d.inst_leaf = d_leaf;
+        if (rc == TRAY_OK) rc = upload(s, tri_leaf.data(), tri_leaf.size(), &d_tri_leaf);
+        d.inst_leaf = d_leaf; d.tri_leaf = d_tri_leaf;
     }
-#endif
     if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
     s->n_materials = f->n_materials;
     d.n_instances = f->n_instances; d.n_lights = f->n_lights; d.min_depth = f->min_depth; d.max_depth = f->max_depth;
@@ -765,16 +743,12 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     }
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
-#ifdef TR_CAMERA_PTR
     {
         const TrayCamera* d_cam = nullptr;
         rc = upload(s, &f->camera, 1, &d_cam);
         d.camera_p = d_cam;
         if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
     }
-#else
-    d.camera = f->camera;
-#endif
     // Morton tile queue (BlockQueue::new)
     uint32_t n_tiles = 0;
     rc = tray_block_queue(d.width, d.height, 0, 0, nullptr, 0, &n_tiles);
@@ -791,8 +765,12 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     std::memset(zs.data(), 0, zs.size() * sizeof(DevStats));
     if (rc == TRAY_OK) rc = upload(s, &zero, 1, &d_counter);
     if (rc == TRAY_OK) rc = upload(s, zs.data(), zs.size(), &d_stats);
+    const uint32_t* d_retraced = nullptr;
+    if (rc == TRAY_OK) rc = upload(s, &zero, 1, &d_retraced);
     s->d_counter = const_cast<uint32_t*>(d_counter);
     s->d_stats = const_cast<DevStats*>(d_stats);
+    s->d_retraced = const_cast<uint32_t*>(d_retraced);
+    d.retraced = s->d_retraced;
     if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
     if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
         tray_scene_destroy(s); set_error("hipEventCreate failed"); return TRAY_E_DEVICE;
@@ -818,7 +796,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             mesh_depth = std::max(mesh_depth, mesh_depths[m]);
         }
         uint32_t depth = mesh_depth + 1;   // per-lane BVH<Triangle> traversal: one pending far child per level
-        if (f->n_instances > TR_FLAT_MAX || s->animated || s->wavefront) {
+        {   // (scenes the flat instance loop serves need it too: rays with tied candidates are re-traced through BVH<Instance>)
             // two-level traversal: exact worst case over the instances. While instance j of a BVH<Instance> leaf at depth d is
             // traversed the stack holds the pending far children of the top-level path (d - 1), the leaf's later instances,
             // the exit-mesh sentinel and the pending far children inside the mesh (its depth - 1).
@@ -1037,6 +1015,7 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     if (tile_count == 0) { std::fprintf(stderr, "Warning: This block queue is empty!\n"); return TRAY_OK; }   // block_queue.rs:42-44
     HIP_CHECK(hipMemsetAsync(s->d_counter, 0, sizeof(uint32_t), stream));
     HIP_CHECK(hipMemsetAsync(s->d_stats, 0, WF_STAT_SLOTS * sizeof(DevStats), stream));
+    HIP_CHECK(hipMemsetAsync(s->d_retraced, 0, sizeof(uint32_t), stream));
     // key_frame on the host (same mixing as the device function)
     auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
     uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
@@ -1115,8 +1094,10 @@ int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t) {
                     "ABC"[g], t[5], (double)t[0] / t[5], (double)t[1] / t[5], (double)t[2] / t[5], (double)t[3] / t[5], (double)t[4] / t[5]);
         }
 #endif
+    uint32_t retraced = 0;
+    HIP_CHECK(hipMemcpy(&retraced, s->d_retraced, sizeof retraced, hipMemcpyDeviceToHost));
     t->launches = s->launches;
-    t->samples = st.samples; t->vertices = st.vertices; t->rays = st.rays;
+    t->samples = st.samples; t->vertices = st.vertices; t->rays = st.rays; t->retraced = retraced;
     return TRAY_OK;
 }
 

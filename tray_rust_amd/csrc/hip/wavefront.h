@@ -53,18 +53,12 @@ TR_DEV void st3(const WfPool& p, int f, uint32_t i, f3 v) { pf(p, f, i) = v.x; p
 
 TR_DEV void ld_bsdf(const DevScene& sc, const WfPool& p, uint32_t i, Bsdf& b) {
     b.p = ld3(p, F_P, i); b.n = ld3(p, F_N, i); b.tan = ld3(p, F_TAN, i);
-#ifndef TR_REMAT_BITAN
-    b.bitan = ld3(p, F_BITAN, i);
-#endif
 
     b.mat = sc.materials + pu(p, F_MAT, i);
     b.merl_data = sc.merl_data;
 }
 TR_DEV void st_bsdf(const DevScene& sc, const WfPool& p, uint32_t i, const Bsdf& b) {
     st3(p, F_P, i, b.p); st3(p, F_N, i, b.n); st3(p, F_TAN, i, b.tan);
-#ifndef TR_REMAT_BITAN
-    st3(p, F_BITAN, i, b.bitan);
-#endif
 
     pu(p, F_MAT, i) = (uint32_t)(b.mat - sc.materials);
 }
@@ -404,11 +398,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
     st3(pool, F_ILLUM, i, ln.illum);
     if (ln.bounce == 0u) st3(pool, F_NG, i, ln.first_ng);
     st_bsdf(sc, pool, i, ln.bsdf);
-#ifdef TR_REMAT_WO
     st3(pool, F_WO, i, -ln.d);
-#else
-    st3(pool, F_WO, i, ln.w_o);
-#endif
     pu(pool, F_LINST, i) = ln.light_inst;
     st3(pool, F_LI, i, ln.li); st3(pool, F_WL, i, ln.wi_l); pf(pool, F_PDFL, i) = ln.pdf_l;
     if (ln.flags & LF_SHADOW) st3(pool, F_AUX, i, ln.aux_d);
@@ -438,20 +428,13 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(
     ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
     ln.throughput = ld3(pool, F_T, i);
     ld_bsdf(sc, pool, i, ln.bsdf);
-#ifndef TR_REMAT_WO
-    ln.w_o = ld3(pool, F_WO, i);
-#endif
     ln.light_inst = pu(pool, F_LINST, i);
     ln.aux_d = mk(0.0f, 0.0f, 0.0f); ln.mis_f = mk(0.0f, 0.0f, 0.0f);   // (before wi_l is loaded: the two may share storage, TR_SHARE_WIL)
     ln.li = ld3(pool, F_LI, i); ln.wi_l = ld3(pool, F_WL, i); ln.pdf_l = pf(pool, F_PDFL, i);
     ln.direct = ld3(pool, F_DIRECT, i);
-#ifndef TR_NO_LANE_O
     ln.o = mk(0.0f, 0.0f, 0.0f);
-#endif
     ln.d = mk(0.0f, 0.0f, 0.0f);
-#ifdef TR_REMAT_WO
     ln.d = -ld3(pool, F_WO, i);   // (-d is the outgoing direction until the PATH query replaces d)
-#endif
     ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
     vertex_queries<ANIM, FEAT>(sc, ln, (flags & WF_OCCLUDED) != 0u);
     st3(pool, F_T, i, ln.throughput);

@@ -82,6 +82,19 @@ inline std::string validate_flat_scene(const TrayFlatScene* f) {
         if (in.emis_count && (uint64_t)in.emis_first + in.emis_count > f->n_color_keys) return "instance references missing colour keys";
         if (in.kind != TRAY_INST_RECEIVER && (in.light_index >= f->n_lights || f->lights[in.light_index] != i)) return who + " is an emitter that the light list does not hold";
     }
+    {   // moving_slot indexes the per-path transform cache (dev_geom.h: instance_xf_at): the slots of the animated instances must be
+        // a permutation of 0 .. n_animated-1
+        uint32_t n_animated = 0;
+        for (uint32_t i = 0; i < f->n_instances; ++i) n_animated += f->instances[i].animated != 0 ? 1u : 0u;
+        std::string seen(n_animated, '\0');
+        for (uint32_t i = 0; i < f->n_instances; ++i) {
+            const TrayInstance& in = f->instances[i];
+            if (!in.animated) continue;
+            if (in.moving_slot >= n_animated) return "instance " + std::to_string(i) + " is animated but its moving_slot is not below the number of animated instances";
+            if (seen[in.moving_slot]) return "instance " + std::to_string(i) + " shares its moving_slot with another animated instance";
+            seen[in.moving_slot] = 1;
+        }
+    }
     if (!stack_in_range(f->camera.xf_first, f->camera.xf_count)) return "the camera refers to spline levels outside xf_levels";
     for (uint32_t l = 0; l < f->n_lights; ++l)
         if (f->lights[l] >= f->n_instances || f->instances[f->lights[l]].kind == TRAY_INST_RECEIVER) return "light " + std::to_string(l) + " is not an emitter instance";
@@ -89,6 +102,14 @@ inline std::string validate_flat_scene(const TrayFlatScene* f) {
         const TrayXformLevel& lv = f->xf_levels[l];
         if (lv.kf_count == 0 || (uint64_t)lv.kf_first + lv.kf_count > f->n_keyframes || (uint64_t)lv.knot_first + lv.knot_count > f->n_knots)
             return "spline level " + std::to_string(l) + " refers to keyframes or knots outside the arrays";
+        if (lv.kf_count >= 2) {   // spline_point (dev_anim.h) searches the knots: they must be finite and non-decreasing, or the span index wraps
+            if (lv.knot_count != lv.kf_count + lv.degree + 1) return "spline level " + std::to_string(l) + " has a knot vector that does not fit its keyframes and degree";
+            for (uint32_t k = 0; k < lv.knot_count; ++k) {
+                const float kv = f->knots[lv.knot_first + k];
+                if (!(kv - kv == 0.0f)) return "spline level " + std::to_string(l) + " has a knot that is not finite";
+                if (k > 0 && kv < f->knots[lv.knot_first + k - 1]) return "spline level " + std::to_string(l) + " has decreasing knots";
+            }
+        }
     }
     return "";
 }
