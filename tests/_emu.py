@@ -23,7 +23,7 @@ def _target(defines):
     so = os.path.join(EMU_DIR, "libtrayemu" + "".join("_" + d.lower() for d in defines).replace("_tr_", "_") + ".so")
     deps = [os.path.join(EMU_DIR, f) for f in ("emu_kernels.cpp", "hip_emu.h")]
     deps += [os.path.join(HIP_DIR, f) for f in os.listdir(HIP_DIR) if f.endswith((".h", ".hip"))]
-    deps += [os.path.join(ROOT, "tray_rust_amd", "csrc", "host", "wide_nodes.hpp"), os.path.join(ROOT, "include", "trayhip.h")]
+    deps += [os.path.join(ROOT, "tray_rust_amd", "csrc", "host", "wide_nodes.hpp"), os.path.join(ROOT, "tray_rust_amd", "csrc", "host", "gates.hpp"), os.path.join(ROOT, "include", "trayhip.h")]
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-attributes", "-shared", "-o", so,
            os.path.join(EMU_DIR, "emu_kernels.cpp")] + ["-D" + d for d in defines]
     return so, deps, cmd

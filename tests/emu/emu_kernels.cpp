@@ -77,7 +77,8 @@ struct EmuScene {
     DevScene d{};
     std::vector<DevMaterial> mats;
     std::vector<uint32_t> wide_words, wide_roots;
-    std::vector<TrayBvhNode> inst_leaf;
+    std::vector<tray::FlatLeaf> flat_leaves;
+    std::vector<tray::FlatInst> flat_insts;
     std::vector<uint8_t> tri_leaf;
     uint32_t retraced = 0;   // rays the flat loop handed to trace_bvh
     uint32_t depth = 0;   // traversal stack entries per lane, as tray_scene_create sizes them (two-level worst case, generous)
@@ -111,8 +112,8 @@ void make_scene(const TrayFlatScene* f, int wide_format, EmuScene& e) {
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
     d.camera_p = &f->camera;
-    tray::flat_loop_gates(f, TR_COOP_MAX_TRIS, e.inst_leaf, e.tri_leaf);
-    d.inst_leaf = e.inst_leaf.data(); d.tri_leaf = e.tri_leaf.data();
+    tray::flat_loop_gates(f, TR_COOP_MAX_TRIS, e.flat_leaves, e.flat_insts, e.tri_leaf);
+    d.flat_leaves = e.flat_leaves.data(); d.flat_insts = e.flat_insts.data(); d.n_flat_leaves = (uint32_t)e.flat_leaves.size(); d.tri_leaf = e.tri_leaf.data();
     d.retraced = &g_retraced;
     uint32_t mesh_depth = 0;
     for (uint32_t m = 0; m < f->n_meshes; ++m) mesh_depth = std::max(mesh_depth, bvh_depth(f->mesh_nodes + f->meshes[m].node_offset, f->meshes[m].node_count));

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Static register / scratch / LDS report of the kernels inside the built libtrayhip.so (no GPU needed), as text and as
+# profiles/static_registers_latest.json (read by bench.py for the compute view of the roofline).   tools/static_registers.sh [lib]
+set -e
+cd "$(dirname "$0")/.."
+LIB=${1:-tray_rust_amd/libtrayhip.so}
+T=$(mktemp -d)
+/opt/rocm/lib/llvm/bin/llvm-objcopy -O binary --only-section=.hip_fatbin "$LIB" $T/f.bin
+/opt/rocm/lib/llvm/bin/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$T/f.bin --output=$T/k.co --unbundle
+/opt/rocm/lib/llvm/bin/llvm-readelf --notes $T/k.co | awk -v hash="$(tools/device_code_hash.sh $LIB)" '
+  /\.name:/ {name=$2}
+  /\.private_segment_fixed_size:/ {scr=$2}
+  /\.sgpr_spill_count:/ {ss=$2}
+  /\.group_segment_fixed_size:/ {lds=$2}
+  /\.sgpr_count:/ {sg=$2}
+  /\.vgpr_count:/ {v=$2}
+  /\.vgpr_spill_count:/ {sp=$2; if (name ~ /k_path_tilesILi0ELi0E/) { printf "{\"device_code_hash\": \"%s\", \"kernel\": \"k_path_tiles<0,0>\", \"vgprs\": %d, \"spilled_vgprs\": %d, \"scratch_bytes_per_lane\": %d, \"sgprs\": %d, \"sgprs_spilled_to_vgpr_lanes\": %d, \"static_lds_bytes\": %d, \"waves_per_simd_by_vgprs\": %d}\n", hash, v, sp, scr, sg, ss, lds, (v <= 64 ? 8 : (v <= 72 ? 7 : (v <= 80 ? 6 : (v <= 96 ? 5 : (v <= 128 ? 4 : (v <= 168 ? 3 : (v <= 256 ? 2 : 1))))))) > "profiles/static_registers_latest.json" }
+    if (name ~ /k_path_tiles|k_wf_/) printf "%-60s vgprs %3d  spilled %3d  scratch %4d B  sgprs %3d (%3d spilled to lanes)  lds %d\n", substr(name,1,60), v, sp, scr, sg, ss, lds}'
+cat profiles/static_registers_latest.json
+rm -rf $T

@@ -16,6 +16,7 @@
 #include "../../../include/trayhip.h"
 #include "dev_math.h"
 #include "dev_anim.h"
+#include "../host/gates.hpp"
 
 namespace tr {
 
@@ -65,7 +66,9 @@ struct DevScene {
     uint32_t coop_offset;   // word offset of the cooperative leaf test's LDS area behind the traversal stacks (0 = none)
     const float* __restrict__ wide_nodes;          // 4-wide collapse of every BVH<Triangle>, 32 floats per node (wavefront_wide.h); may be null
     const uint32_t* __restrict__ mesh_wide_root;   // per mesh: index of its root's wide node
-    const TrayBvhNode* __restrict__ inst_leaf;     // per instance: the BVH<Instance> leaf node that holds it (trace_flat's gate)
+    const tray::FlatLeaf* __restrict__ flat_leaves;   // the flat instance loop's view of the scene: BVH<Instance> leaves ...
+    const tray::FlatInst* __restrict__ flat_insts;    // ... and their instances, one 128-B record each (host/gates.hpp)
+    uint32_t n_flat_leaves, pad_flat;
     uint32_t* __restrict__ retraced;               // counter of rays the flat loop handed to trace_bvh (tied candidates); may be null
     const uint8_t* __restrict__ tri_leaf;          // per triangle of a mesh with <= TR_COOP_MAX_TRIS triangles: index of its BVH<Triangle> leaf node (mesh_leaf_coop's gate)
     float filter_w, filter_h, inv_w, inv_h;
@@ -313,14 +316,16 @@ TR_DEV bool mesh_traverse(const DevScene& sc, uint32_t* __restrict__ stack, cons
 // hold a ray that passes the root box (measured: the two cubes were 32 % of the cornell_box kernel). Instead, after the
 // root box test (the reference's first test), the lanes of a wave share a test of ALL the mesh's triangles: the n rays that
 // pass are staged in LDS and every ray is tested by FOUR lanes, each taking a quarter of the triangles in leaf order, so one
-// pass of ceil(T/4) triangle tests serves 16 rays. Every triangle is gated by the box of its BVH<Triangle> leaf (tri_leaf),
-// tested with the ray's ORIGINAL max_t like the reference tests it when it reaches the leaf before any candidate was accepted
-// (the boxes of the leaf's ancestors contain it and are hit whenever it is). Returned: the valid candidate of minimal t
-// (max_t, prim, b1, b2), the entry distance of its leaf box (leaf_tmin) and `hazard` when another valid candidate of the mesh
-// lies at or below max(t, leaf_tmin) -- a tie, or a candidate inside the window in which the survivor's gate depends on the
-// order of the reference's traversal (trace_flat explains the rule); the caller then re-traces the ray the reference's way.
+// pass of ceil(T/4) triangle tests serves 16 rays. Returned: the valid triangle of minimal t over ALL triangles (t_out, prim,
+// b1, b2), the entry distance of its BVH<Triangle> leaf's box (leaf_tmin) and `hazard`. The reference reaches a triangle only
+// through its leaf's box (ancestors contain it and are hit whenever it is); that gate is tested for the SURVIVOR only, with the
+// ray's original max_t as the reference tests it before any candidate was accepted: if it passes, the survivor is also the
+// minimum of the gated candidates (a subset). `hazard` is set when it fails (only rounding at a flat leaf box produces that), or
+// when another valid triangle lies at or below max(t, leaf_tmin) -- a tie, or a rival inside the window in which the survivor's
+// gate depends on the order of the reference's traversal (trace_flat explains the rule; testing ungated rivals only adds
+// caution); the caller then re-traces the ray the reference's way.
 #define TR_COOP_MAX_TRIS 16
-#define TR_COOP_WORDS 896   // per wave: ray o, d, min_t, gate max_t (8 x 64) + result t, k, b1, b2, second t, leaf box entry (6 x 64)
+#define TR_COOP_WORDS 832   // per wave: ray o, d, min_t, gate max_t (8 x 64) + result t, k, b1, b2, second t (5 x 64)
 TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float* __restrict__ w_lds, bool participate, f3 o, f3 d, float min_t,
                            float gate_max_t, float accept_max_t, float& t_out, uint32_t& prim, float& b1, float& b2, float& leaf_tmin, bool& hazard) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -329,9 +334,9 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float*
     const float4 lo = nq[0], hi = nq[1];
     const uint32_t T = m.tri_count;
     const TrayTriVerts* __restrict__ tris = sc.tri_verts + m.tri_offset;
-    const uint8_t* __restrict__ leaf_of = sc.tri_leaf + m.tri_offset;
     const f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const bool need = participate && bbox_hit(lo, hi, o, inv_dir, d.x < 0.0f, d.y < 0.0f, d.z < 0.0f, min_t, gate_max_t);
+    const bool dnx = d.x < 0.0f, dny = d.y < 0.0f, dnz = d.z < 0.0f;
+    const bool need = participate && bbox_hit(lo, hi, o, inv_dir, dnx, dny, dnz, min_t, gate_max_t);
     const unsigned long long mask = __ballot(need);
     if (mask == 0ull) return false;
     const uint32_t n = (uint32_t)__popcll(mask);
@@ -346,29 +351,18 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float*
     const uint32_t per = (T + 3u) >> 2, g = lane & 3u;
     for (uint32_t base = 0; base < n; base += 16u) {
         const uint32_t r = base + (lane >> 2);
-        // best candidate of this lane's quarter, the smallest t among its other candidates, the best one's leaf box entry
-        float ct = 0.0f, cb1 = 0.0f, cb2 = 0.0f, ck = -1.0f, c2 = TR_INF, cbox = 0.0f;
+        // best candidate of this lane's quarter and the smallest t among its other candidates
+        float ct = 0.0f, cb1 = 0.0f, cb2 = 0.0f, ck = -1.0f, c2 = TR_INF;
         if (r < n) {
             const f3 ro = mk(w_lds[0 * 64 + r], w_lds[1 * 64 + r], w_lds[2 * 64 + r]);
             const f3 rd = mk(w_lds[3 * 64 + r], w_lds[4 * 64 + r], w_lds[5 * 64 + r]);
-            const f3 rinv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-            const bool rnx = rd.x < 0.0f, rny = rd.y < 0.0f, rnz = rd.z < 0.0f;
             const float rmin = w_lds[6 * 64 + r], rmax = w_lds[7 * 64 + r];
-            float box_t = 0.0f;
-            uint32_t leaf = 0xffffffffu;
-            bool gate = false;
             for (uint32_t j = 0; j < per; ++j) {
                 const uint32_t k = g * per + j;
                 if (k < T) {
-                    const uint32_t lf = leaf_of[k];
-                    if (lf != leaf) {   // (consecutive triangles usually share their leaf)
-                        leaf = lf;
-                        const float4* lq = reinterpret_cast<const float4*>(tree + lf);
-                        gate = bbox_hit_t(lq[0], lq[1], ro, rinv, rnx, rny, rnz, rmin, rmax, box_t);
-                    }
                     float t, bb1, bb2;
-                    if (gate && triangle_test(tris + k, ro, rd, rmin, rmax, t, bb1, bb2)) {
-                        if (ck < 0.0f || t < ct) { c2 = ck < 0.0f ? c2 : fminf(c2, ct); ct = t; cb1 = bb1; cb2 = bb2; ck = (float)k; cbox = box_t; }
+                    if (triangle_test(tris + k, ro, rd, rmin, rmax, t, bb1, bb2)) {
+                        if (ck < 0.0f || t < ct) { c2 = ck < 0.0f ? c2 : fminf(c2, ct); ct = t; cb1 = bb1; cb2 = bb2; ck = (float)k; }
                         else c2 = fminf(c2, t);
                     }
                 }
@@ -378,16 +372,15 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float*
 #pragma unroll
         for (int step = 1; step <= 2; step <<= 1) {
             const float ot = __shfl_xor(ct, step), ok = __shfl_xor(ck, step), ob1 = __shfl_xor(cb1, step), ob2 = __shfl_xor(cb2, step),
-                        o2 = __shfl_xor(c2, step), obox = __shfl_xor(cbox, step);
+                        o2 = __shfl_xor(c2, step);
             const bool both = ok >= 0.0f && ck >= 0.0f;
             const bool take = ok >= 0.0f && (ck < 0.0f || ot < ct);
             c2 = fminf(c2, o2);
             if (both) c2 = fminf(c2, take ? ct : ot);   // the loser of the two bests is the other side's closest rival
-            if (take) { ct = ot; ck = ok; cb1 = ob1; cb2 = ob2; cbox = obox; }
+            if (take) { ct = ot; ck = ok; cb1 = ob1; cb2 = ob2; }
         }
         if (r < n && g == 0u && ck >= 0.0f) {
-            w_lds[8 * 64 + r] = ct; w_lds[9 * 64 + r] = ck; w_lds[10 * 64 + r] = cb1; w_lds[11 * 64 + r] = cb2;
-            w_lds[12 * 64 + r] = c2; w_lds[13 * 64 + r] = cbox;
+            w_lds[8 * 64 + r] = ct; w_lds[9 * 64 + r] = ck; w_lds[10 * 64 + r] = cb1; w_lds[11 * 64 + r] = cb2; w_lds[12 * 64 + r] = c2;
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -395,19 +388,24 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float*
     if (need) {
         const float ck = w_lds[9 * 64 + rank];
         if (ck >= 0.0f && w_lds[8 * 64 + rank] <= accept_max_t) {
-            const float t = w_lds[8 * 64 + rank], c2 = w_lds[12 * 64 + rank], cbox = w_lds[13 * 64 + rank];
-            t_out = t; prim = m.tri_offset + (uint32_t)ck;
+            const float t = w_lds[8 * 64 + rank], c2 = w_lds[12 * 64 + rank];
+            const uint32_t k = (uint32_t)ck;
+            // the survivor's gate: the box of its BVH<Triangle> leaf, with the ray's original max_t
+            const float4* lq = reinterpret_cast<const float4*>(tree + sc.tri_leaf[m.tri_offset + k]);
+            float cbox;
+            const bool gate = bbox_hit_t(lq[0], lq[1], o, inv_dir, dnx, dny, dnz, min_t, gate_max_t, cbox);
+            t_out = t; prim = m.tri_offset + k;
             b1 = w_lds[10 * 64 + rank]; b2 = w_lds[11 * 64 + rank];
             leaf_tmin = cbox;
-            hazard = !(c2 > t && c2 > cbox);   // (also true when cbox is NaN)
+            hazard = !gate || !(c2 > t && c2 > cbox);   // (also true when cbox is NaN)
             hit = true;
         }
     }
     return hit;
 }
 
-// Scene::intersect for scenes with a handful of instances: every lane tests the instances in scene
-// order inside one wave-uniform loop. The instance index is uniform, so the transform and the geometry
+// Scene::intersect for scenes with a handful of instances: every lane tests the instances, BVH<Instance> leaf by leaf
+// (host/gates.hpp), inside one wave-uniform loop. The instance index is uniform, so the transform and the geometry
 // parameters are scalar loads and the primitive type never diverges; only BVH<Triangle> traversal is
 // per lane.
 //
@@ -436,65 +434,92 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float*
 #ifndef TR_FLAT_MAX
 #define TR_FLAT_MAX 16
 #endif
+// conservative cull by the instance's own (inflated) world box: rejects only when a slab comparison says so, a NaN passes
+TR_DEV bool own_box_pass(const float* __restrict__ lo, const float* __restrict__ hi, const f3 o, const f3 inv_dir, const bool nx, const bool ny, const bool nz,
+                         float min_t, float max_t) {
+    float tmin = ((nx ? hi[0] : lo[0]) - o.x) * inv_dir.x;
+    float tmax = ((nx ? lo[0] : hi[0]) - o.x) * inv_dir.x;
+    const float tymin = ((ny ? hi[1] : lo[1]) - o.y) * inv_dir.y;
+    const float tymax = ((ny ? lo[1] : hi[1]) - o.y) * inv_dir.y;
+    const float tzmin = ((nz ? hi[2] : lo[2]) - o.z) * inv_dir.z;
+    const float tzmax = ((nz ? lo[2] : hi[2]) - o.z) * inv_dir.z;
+    if (tymin > tmin) tmin = tymin;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tymax < tmax) tmax = tymax;
+    if (tzmax < tmax) tmax = tzmax;
+    return !(tmin > tmax) && !(tmin >= max_t) && !(tmax <= min_t);
+}
 TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, bool active, HitRec& rec, bool& hazard) {
     const float min_t = ray.min_t, gate_max_t = ray.max_t;
     float max_t = ray.max_t;          // closest accepted candidate so far
     float best_gate = -TR_INF;        // G of that candidate
     bool any = false, done = !active;   // lanes without a ray run along: the cooperative leaf test uses their ALUs
-    const uint32_t n = sc.n_instances;
     const f3 w_inv_dir = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     const bool wnx = ray.d.x < 0.0f, wny = ray.d.y < 0.0f, wnz = ray.d.z < 0.0f;
-    for (uint32_t i = 0; i < n; ++i) {
-        // the instance index is wave-uniform: read the record through the constant address space so the
-        // transform and the geometry parameters arrive as scalar loads (SGPRs), not 64 identical lane loads
-        typedef const __attribute__((address_space(4))) TrayInstance* ConstInst;
-        ConstInst in = (ConstInst)(sc.instances + i);
-        const uint32_t kind = in->kind, gt = in->geom_type;
-        if (kind == TRAY_INST_POINT_EMITTER) continue;   // emitter.rs:120
-        float inv[16];
+    // the leaf and instance indices are wave-uniform: the records are read through the constant address space so that boxes,
+    // transforms and geometry parameters arrive as scalar loads (SGPRs), not 64 identical lane loads
+    typedef const __attribute__((address_space(4))) tray::FlatLeaf* ConstLeaf;
+    typedef const __attribute__((address_space(4))) tray::FlatInst* ConstInst;
+    const uint32_t n_leaves = sc.n_flat_leaves;
+    for (uint32_t l = 0; l < n_leaves; ++l) {
+        ConstLeaf lf = (ConstLeaf)(sc.flat_leaves + l);
+        const float4 leaf_lo = make_float4(lf->bmin[0], lf->bmin[1], lf->bmin[2], lf->bmax[0]), leaf_hi = make_float4(lf->bmax[1], lf->bmax[2], 0.0f, 0.0f);
+        const uint32_t first = lf->first, count = lf->count;
+        float box_t = 0.0f;
+        // the gate of every instance of this leaf: its box with the ORIGINAL max_t (bvh.rs:89-98)
+        const bool gate = bbox_hit_t(leaf_lo, leaf_hi, ray.o, w_inv_dir, wnx, wny, wnz, min_t, gate_max_t, box_t) && !done;
+        if (!__any(gate)) continue;
+        for (uint32_t k = 0; k < count; ++k) {
+            ConstInst in = (ConstInst)(sc.flat_insts + first + k);
+            float own_lo[3], own_hi[3];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) inv[k] = in->inv[k];
-        const float gp0 = in->geom_params[0], gp1 = in->geom_params[1];
-        const uint32_t mesh_id = in->mesh_id;
-        // Instance::intersect (receiver.rs:29-35): world ray -> object ray by `inv`, direction not renormalised
-        const f3 o = xf_point(inv, ray.o);
-        const f3 d = xf_vector(inv, ray.d);
-        const float bound = fmaxf(max_t, best_gate);   // (best_gate is -inf until a candidate was accepted)
-        float t = bound;
-        bool hit = false, hz = false;
-        uint32_t prim = 0u;
-        float b1 = 0.0f, b2 = 0.0f, box_t = 0.0f, leaf_t = -TR_INF;
-        typedef const __attribute__((address_space(4))) float* ConstBox;   // (scalar loads, like the instance record)
-        ConstBox lb = (ConstBox)(sc.inst_leaf + i);
-        const float4 leaf_lo = make_float4(lb[0], lb[1], lb[2], lb[3]), leaf_hi = make_float4(lb[4], lb[5], lb[6], lb[7]);
-        const bool wanted = bbox_hit_t(leaf_lo, leaf_hi, ray.o, w_inv_dir, wnx, wny, wnz, min_t, gate_max_t, box_t) && !done;
-        if (gt == TRAY_GEOM_MESH && sc.coop_offset != 0u && sc.meshes[mesh_id].tri_count <= TR_COOP_MAX_TRIS) {
-            // small mesh: the whole wave enters, lanes without a pending ray only lend their ALUs
-            volatile float* w_lds = reinterpret_cast<volatile float*>(stack - threadIdx.x + sc.coop_offset) + (threadIdx.x >> 6) * TR_COOP_WORDS;
-            hit = mesh_leaf_coop(sc, sc.meshes[mesh_id], w_lds, wanted, o, d, min_t, gate_max_t, bound, t, prim, b1, b2, leaf_t, hz);
-        } else if (wanted) {
-            if (gt == TRAY_GEOM_RECT) hit = rect_test(gp0, gp1, o, d, min_t, bound, t);
-            else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(gp0, o, d, min_t, bound, t);
-            else if (gt == TRAY_GEOM_MESH) {
-                float mt = gate_max_t;   // the mesh's own traversal, from the original max_t
-                hit = mesh_traverse(sc, stack, sc.meshes[mesh_id], o, d, min_t, mt, any_hit, prim, b1, b2, leaf_t) && mt <= bound;
-                t = mt;
-            } else hit = disk_test(gp0, gp1, o, d, min_t, bound, t);
-        }
-        if (hit) {
-            const float gate_new = fmaxf(box_t, leaf_t);
-            const bool closer = !any || t < max_t;
-            if (!any_hit) {
-                if (!closer) hazard = true;                              // R1: a second candidate inside the window of the closest one
-                else if (any && !(gate_new < max_t)) hazard = true;      // R2: the previous closest one lies inside the window of the new one
-                if (hz || box_t != box_t || leaf_t != leaf_t) hazard = true;   // rivals inside a small mesh; NaN entry distances
+            for (int c = 0; c < 3; ++c) { own_lo[c] = in->lo[c]; own_hi[c] = in->hi[c]; }
+            // occlusion segments are short and end at the light: most instances lie outside the segment's reach for every lane of the
+            // wave, and the own-box cull skips them wholesale (measured: trace B 17.3 -> 15.3 % of the tile kernel's wave cycles);
+            // unbounded rays pass most boxes, the cull would only cost them its slab test
+            const bool wanted = gate && !done && (!any_hit || own_box_pass(own_lo, own_hi, ray.o, w_inv_dir, wnx, wny, wnz, min_t, gate_max_t));
+            if (!__any(wanted)) continue;   // nobody's ray comes near this instance
+            const uint32_t gt = in->geom_type, mesh_id = in->mesh_id, inst_id = in->inst;
+            float inv[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) inv[c] = in->inv[c];
+            const float gp0 = in->gp0, gp1 = in->gp1;
+            // Instance::intersect (receiver.rs:29-35): world ray -> object ray by `inv`, direction not renormalised
+            const f3 o = xf_point(inv, ray.o);
+            const f3 d = xf_vector(inv, ray.d);
+            const float bound = fmaxf(max_t, best_gate);   // (best_gate is -inf until a candidate was accepted)
+            float t = bound;
+            bool hit = false, hz = false;
+            uint32_t prim = 0u;
+            float b1 = 0.0f, b2 = 0.0f, leaf_t = -TR_INF;
+            if (gt == TRAY_GEOM_MESH && sc.coop_offset != 0u && sc.meshes[mesh_id].tri_count <= TR_COOP_MAX_TRIS) {
+                // small mesh: the whole wave enters, lanes without a pending ray only lend their ALUs
+                volatile float* w_lds = reinterpret_cast<volatile float*>(stack - threadIdx.x + sc.coop_offset) + (threadIdx.x >> 6) * TR_COOP_WORDS;
+                hit = mesh_leaf_coop(sc, sc.meshes[mesh_id], w_lds, wanted, o, d, min_t, gate_max_t, bound, t, prim, b1, b2, leaf_t, hz);
+            } else if (wanted) {
+                if (gt == TRAY_GEOM_RECT) hit = rect_test(gp0, gp1, o, d, min_t, bound, t);
+                else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(gp0, o, d, min_t, bound, t);
+                else if (gt == TRAY_GEOM_MESH) {
+                    float mt = gate_max_t;   // the mesh's own traversal, from the original max_t
+                    hit = mesh_traverse(sc, stack, sc.meshes[mesh_id], o, d, min_t, mt, any_hit, prim, b1, b2, leaf_t) && mt <= bound;
+                    t = mt;
+                } else hit = disk_test(gp0, gp1, o, d, min_t, bound, t);
             }
-            if (closer) {
-                max_t = t; best_gate = gate_new;
-                rec.t = t; rec.inst = i; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
+            if (hit) {
+                const float gate_new = fmaxf(box_t, leaf_t);
+                const bool closer = !any || t < max_t;
+                if (!any_hit) {
+                    if (!closer) hazard = true;                              // R1: a second candidate inside the window of the closest one
+                    else if (any && !(gate_new < max_t)) hazard = true;      // R2: the previous closest one lies inside the window of the new one
+                    if (hz || box_t != box_t || leaf_t != leaf_t) hazard = true;   // rivals inside a small mesh; NaN entry distances
+                }
+                if (closer) {
+                    max_t = t; best_gate = gate_new;
+                    rec.t = t; rec.inst = inst_id; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
+                }
+                any = true;
+                done = any_hit;
             }
-            any = true;
-            done = any_hit;
         }
         if (__all(done)) break;
     }

@@ -27,7 +27,6 @@
 #include "../../../include/trayhip.h"
 #include "../host/wide_nodes.hpp"
 #include "../host/validate.hpp"
-#include "../host/gates.hpp"
 #include "dev_integrator.h"
 
 namespace trayh { void set_error(const std::string& msg); }
@@ -716,15 +715,18 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             s->wf_wide = rc == TRAY_OK;
         }
     }
-    if (rc == TRAY_OK) {   // gates of the flat instance loop (dev_geom.h: trace_flat, mesh_leaf_coop)
-        std::vector<TrayBvhNode> leaf;
+    if (rc == TRAY_OK) {   // the flat instance loop's records and gates (host/gates.hpp; dev_geom.h: trace_flat, mesh_leaf_coop)
+        std::vector<tray::FlatLeaf> leaves;
+        std::vector<tray::FlatInst> insts;
         std::vector<uint8_t> tri_leaf;
-        tray::flat_loop_gates(f, TR_COOP_MAX_TRIS, leaf, tri_leaf);
-        const TrayBvhNode* d_leaf = nullptr;
+        tray::flat_loop_gates(f, TR_COOP_MAX_TRIS, leaves, insts, tri_leaf);
+        const tray::FlatLeaf* d_leaves = nullptr;
+        const tray::FlatInst* d_insts = nullptr;
         const uint8_t* d_tri_leaf = nullptr;
-        rc = upload(s, leaf.data(), leaf.size(), &d_leaf);
+        rc = upload(s, leaves.data(), leaves.size(), &d_leaves);
+        if (rc == TRAY_OK) rc = upload(s, insts.data(), insts.size(), &d_insts);
         if (rc == TRAY_OK) rc = upload(s, tri_leaf.data(), tri_leaf.size(), &d_tri_leaf);
-        d.inst_leaf = d_leaf; d.tri_leaf = d_tri_leaf;
+        d.flat_leaves = d_leaves; d.flat_insts = d_insts; d.n_flat_leaves = (uint32_t)leaves.size(); d.tri_leaf = d_tri_leaf;
     }
     if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
     s->n_materials = f->n_materials;
