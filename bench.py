@@ -123,9 +123,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world != args.gpus and args.gpus > 1:
+        if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+            raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world}")
+        # started plainly (`python bench.py --gpus N`): become the launcher of N ranks, one per GPU, on this node
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     distributed = world > 1
     torch.cuda.set_device(local_rank)
     if distributed:

@@ -301,6 +301,22 @@ typedef struct TrayKernelTiming {
 } TrayKernelTiming;
 int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t);
 
+/* ---- one frame on several GPUs of this process ------------------------------------------------------
+ * The reference's distributed mode hands every worker a slice of the block queue and sums the returned RGBW blocks on the
+ * master (src/exec/distrib/master.rs:91-93,124-163; film::Image::add_blocks, src/film/image.rs:36-50). Here the workers are
+ * the GPUs of one node: tray_multi_create deep-copies the scene to each listed device and creates one RCCL communicator per
+ * device (ncclCommInitAll); tray_render_frame_multi renders shard d of n_dev on device d (tray_render_shard_device, 16-tile
+ * chunks round-robin, one host thread and one stream per device), sums the per-device films onto the first device with ONE
+ * ncclReduce(sum) over xGMI and adds the result into rgbw_host (width*height*4 f32, get_renderf32 layout). A Rust
+ * exec::Hip that owns a whole node calls these three instead of spawning worker processes. RCCL is loaded with dlopen
+ * (librccl.so) when the first TrayMultiScene is created: a build or a box without it still serves the single-GPU calls. */
+typedef struct TrayMultiScene TrayMultiScene;
+int tray_multi_create(const TrayFlatScene* f, int n_dev, const int* dev_ids, TrayMultiScene** out);
+int tray_render_frame_multi(TrayMultiScene* m, uint32_t spp, uint64_t seed, float* rgbw_host);
+/* per-device timings of the last tray_render_frame_multi (n_dev entries) and the duration of the reduce (ms) */
+int tray_multi_timing(TrayMultiScene* m, TrayKernelTiming* per_device, float* reduce_ms);
+void tray_multi_destroy(TrayMultiScene* m);
+
 /* ---- parity / debug entry points (same device code as the renderer, one thread per item) ---- */
 
 typedef struct TrayRay { float o[3]; float d[3]; float min_t, max_t, time; } TrayRay;   /* ray.rs:9-22 */

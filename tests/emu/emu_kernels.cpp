@@ -401,6 +401,11 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     std::vector<uint32_t> overflow((size_t)(8u * e.depth + 64u) * trace_blocks * TR_BLOCK, 0u);
     const size_t slot_lds = (size_t)e.depth * TR_BLOCK * 4, dyn_lds = (size_t)lds_depth * TR_BLOCK * 4;
     const int feat = feature_set(e);
+    // the material sort of the shading stage (default of the library for the compacted schedule; trace == 2 is the slot form without queues)
+    const bool sorted = trace != 2 && !getenv("TRAYHIP_WF_SORT_OFF");
+    std::vector<uint32_t> kind_queues((size_t)WF_MAT_KINDS * n_slots, 0u);
+    uint32_t kinds_present = 0;
+    for (const DevMaterial& dm : e.mats) kinds_present |= 1u << dm.mat_kind;
     const uint64_t max_rounds = (uint64_t)((tile_count + n_chunks - 1) / n_chunks) * (((uint64_t)spp + 3) / 4 * (e.d.max_depth + 3) + 4) + 32;
     int rc = 0;
     uint64_t rounds = 0;
@@ -411,11 +416,15 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
                                                          counters, counters + 1, stats.data(), qa, qr, qctl); });                          \
         EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_regen<A>(e.d, pool, chunks.data(), tiles.data(), tile_count, 1u, spp, kf, stats.data(), qr, qa, qctl); }); \
         EMU_TRACE_STAGE(0, A, qa);                                                                                                          \
-        EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_begin<A>(e.d, pool, n_active, stats.data(), trace == 2 ? nullptr : qb, trace == 2 ? nullptr : qctl); }); \
+        EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_begin<A>(e.d, pool, n_active, stats.data(), trace == 2 ? nullptr : qb, trace == 2 ? nullptr : qctl, sorted ? kind_queues.data() : nullptr); }); \
         EMU_TRACE_STAGE(1, A, qb);                                                                                                          \
-        EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query<A, F>(e.d, pool, n_active, trace == 2 ? nullptr : qc, trace == 2 ? nullptr : qctl); });  \
+        if (sorted) {   /* wf_round of kernels.hip: one kind-pure shading launch per material kind of the scene */                        \
+            EMU_QUERY_KIND(A, TRAY_MAT_MATTE); EMU_QUERY_KIND(A, TRAY_MAT_PLASTIC); EMU_QUERY_KIND(A, TRAY_MAT_METAL); EMU_QUERY_KIND(A, TRAY_MAT_GLASS); \
+            EMU_QUERY_KIND(A, TRAY_MAT_ROUGH_GLASS); EMU_QUERY_KIND(A, TRAY_MAT_SPECULAR_METAL); EMU_QUERY_KIND(A, TRAY_MAT_MERL);          \
+        } else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query<A, F>(e.d, pool, n_active, trace == 2 ? nullptr : qc, trace == 2 ? nullptr : qctl); });  \
         EMU_TRACE_STAGE(2, A, qc);                                                                                                          \
     } while (0)
+#define EMU_QUERY_KIND(A, K) do { if (kinds_present & (1u << K)) EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query_kind<A, K>(e.d, pool, kind_queues.data(), qc, qctl); }); } while (0)
 #define EMU_TRACE_STAGE(S, A, Q)                                                                                                            \
     do {                                                                                                                                    \
         if (trace == 0) EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data()); }, dyn_lds); \
@@ -435,6 +444,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     }
 #undef EMU_ROUND_F
 #undef EMU_TRACE_STAGE
+#undef EMU_QUERY_KIND
 #undef EMU_ROUND
 #undef EMU_K
     if (stats_out) {

@@ -472,3 +472,17 @@ def test_closed_form_moving_scenes_per_sample(build, tmp_path):
     same = a[:, 5] == b[:, 5]
     assert np.abs(a[same, :3] - b[same, :3]).max() < 2e-5
     assert abs(a[:, 0].mean() - b[:, 0].mean()) < 1e-3 * max(a[:, 0].mean(), 1e-6)
+
+
+def test_frame_on_all_gpus_of_the_process_through_the_c_abi(tmp_path):
+    """tray_multi_create / tray_render_frame_multi: shard per device, ONE ncclReduce(sum) inside the library (RCCL loaded with
+    dlopen), result added into the host film. With one GPU the communicator has one rank; with more the test also runs on two."""
+    import torch
+    scene, rt, _, fi = load(scenes.cornell_box(160, 96, 16), tmp_path)
+    whole, tim = gpu_render(scene, rt, 16, fi, seed=5)
+    for n_dev in sorted({1, min(2, torch.cuda.device_count())}):
+        rt.clear()
+        per, reduce_ms = T.Hip(0, seed=5).render_multi(scene, rt, T.Config(".", "s", 16, 1, fi, (0, 0)), list(range(n_dev)))
+        got = rt.get_renderf32().reshape(96, 160, 4)
+        assert np.allclose(got, whole, rtol=0, atol=1e-4 * whole.max()), n_dev
+        assert sum(int(p.samples) for p in per) == tim.samples and reduce_ms >= 0.0

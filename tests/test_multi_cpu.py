@@ -72,3 +72,51 @@ def test_frames_shard_round_robin():
     parts = [multi.shard_frames(0, 127, r, world) for r in range(world)]
     assert sorted(sum(parts, [])) == list(range(128)) and all(len(p) == 16 for p in parts)
     assert multi.shard_frames(5, 6, 3, 8) == [] and multi.shard_frames(5, 6, 1, 8) == [6]
+
+
+# ---- the same two-rank flow with the REAL per-rank renderer (tray_render_shard_device) and RCCL: needs two GPUs ----
+def _gpu_worker(rank, world, port, scene_path, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import tray_rust_amd as T
+    from tray_rust_amd import multi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    scene, rt, spp, fi = T.Scene.load_file(scene_path)
+    hip = T.Hip(device=rank, seed=11)
+    film = torch.zeros(rt.width * rt.height * 4, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    multi.render_frame_sharded(lambda r, w, f: hip.render_shard_device(scene, 0, r, w, T.round_spp(spp), f.data_ptr(), chunk_tiles=3, stream=stream),
+                               film, rank, world, dst=0)
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.save(out_path, film.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_gpu_ranks_shard_and_rccl_reduce(tmp_path):
+    """bench.py's N > 1 path on hardware: one process per GPU, tray_render_shard_device per rank, ONE RCCL sum-reduce to rank 0.
+    Runs where the box has two GPUs (the driver's 8-GPU node); skipped on the 1-GPU boxes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    import tray_rust_amd as T
+    from tray_rust_amd import scenes
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    scenes.write_assets(str(tmp_path))
+    scene_path = os.path.join(str(tmp_path), "s.json")
+    json.dump(scenes.cornell_box(160, 96, 16), open(scene_path, "w"))
+    out_path = os.path.join(str(tmp_path), "merged.npy")
+    mp.spawn(_gpu_worker, args=(2, 29500 + os.getpid() % 2000, scene_path, out_path), nprocs=2, join=True)
+    merged = np.load(out_path).reshape(96, 160, 4)
+    scene, *_ = T.Scene.load_file(scene_path)
+    whole, _ = O.render_tiles(scene.flatten(0), 16, seed=11)
+    rgb = lambda i: i[..., :3] / np.maximum(i[..., 3:], 1e-20)
+    assert (merged[..., 3] > 0).all() and float(np.sqrt(np.mean((rgb(merged) - rgb(whole)) ** 2))) < 1e-4

@@ -203,6 +203,24 @@ class Hip:
                                              C.c_void_p(int(rgbw_ptr)), C.c_void_p(int(stream)) if stream else None))
         return dev
 
+    def render_multi(self, scene, rt, config, devices):
+        """One frame on several GPUs of this process: tiles sharded round-robin over `devices`, the per-device films summed onto
+        the first one by RCCL inside the library (tray_render_frame_multi; the master's Image::add_blocks merge,
+        exec/distrib/master.rs:124-163, film/image.rs:36-50), the result added into rt. Returns (per-device timings, reduce ms)."""
+        spp = round_spp(config.spp)
+        flat = scene.flatten(config.current_frame)
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        m = C.c_void_p()
+        check(lib().tray_multi_create(flat, len(devices), ids, C.byref(m)))
+        try:
+            check(lib().tray_render_frame_multi(m, spp, self.seed, rt.pixels.ctypes.data))
+            per = (_lib.TrayKernelTiming * len(devices))()
+            ms = C.c_float()
+            check(lib().tray_multi_timing(m, per, C.byref(ms)))
+        finally:
+            lib().tray_multi_destroy(m)
+        return list(per), float(ms.value)
+
     def timing(self, scene):
         t = _lib.TrayKernelTiming()
         check(lib().tray_last_timing(scene.device_scene(scene._dev_frame, self.device), C.byref(t)))

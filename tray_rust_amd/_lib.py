@@ -145,6 +145,10 @@ SYMBOLS = {
     "tray_render_tiles_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "tray_render_shard_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "tray_shard_tiles": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_uint32), C.c_uint32, _P(C.c_uint32)]),
+    "tray_multi_create": (C.c_int, [_P(TrayFlatScene), C.c_int, _P(C.c_int), _P(C.c_void_p)]),
+    "tray_render_frame_multi": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]),
+    "tray_multi_timing": (C.c_int, [C.c_void_p, _P(TrayKernelTiming), _P(C.c_float)]),
+    "tray_multi_destroy": (None, [C.c_void_p]),
     "tray_render_tiles": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),
     "tray_last_timing": (C.c_int, [C.c_void_p, _P(TrayKernelTiming)]),
     "tray_debug_intersect": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),

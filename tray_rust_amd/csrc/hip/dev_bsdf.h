@@ -154,11 +154,31 @@ TR_DEV f3 merl_eval(const float* __restrict__ brdf, f3 w_oi, f3 w_ii) {
 // 592 B per lane (cornell_box 454 -> 484, smallpt 385 -> 421 Msamples/s at 64 spp), leaving out the specular lobes and the
 // conductor Fresnel term as well to 508 B (cornell_box 545).
 enum : int { FEAT_NONE = 0, FEAT_MERL = 1, FEAT_MF_TRANS = 2, FEAT_SPEC = 4, FEAT_ALL = 7 };   // FEAT_SPEC: specular lobes and conductor Fresnel
-template <int FEAT>
+// KM: bit per lobe kind (1 << LB_*) that can occur at all. The kind-pure shading kernels of the wavefront schedule (wavefront.h:
+// k_wf_query_kind, fed by the material sort of k_wf_begin) are instantiated with the lobes of ONE material kind, so every other
+// case of the switches below is dead code there; everywhere else KM_ALL keeps them all.
+enum : uint32_t { KM_ALL = 0x1ffu };
+#define LOBE_ON(k) ((KM >> (k)) & 1u)
+// lobes a material kind (TRAY_MAT_*) lowers to (lower_material below), and the FEAT set its code needs
+TR_DEV constexpr uint32_t km_of_material(int mk) {
+    return mk == TRAY_MAT_MATTE ? (1u << LB_LAMBERTIAN) | (1u << LB_OREN_NAYAR)
+         : mk == TRAY_MAT_PLASTIC ? (1u << LB_LAMBERTIAN) | (1u << LB_TS_DIEL)
+         : mk == TRAY_MAT_METAL ? (1u << LB_TS_COND)
+         : mk == TRAY_MAT_GLASS ? (1u << LB_SPEC_REFL_DIEL) | (1u << LB_SPEC_TRANS)
+         : mk == TRAY_MAT_ROUGH_GLASS ? (1u << LB_TS_DIEL) | (1u << LB_MF_TRANS)
+         : mk == TRAY_MAT_SPECULAR_METAL ? (1u << LB_SPEC_REFL_COND)
+         : (1u << LB_MERL);
+}
+TR_DEV constexpr int feat_of_material(int mk) {
+    return mk == TRAY_MAT_METAL || mk == TRAY_MAT_GLASS || mk == TRAY_MAT_SPECULAR_METAL ? FEAT_SPEC
+         : mk == TRAY_MAT_ROUGH_GLASS ? FEAT_MF_TRANS : mk == TRAY_MAT_MERL ? FEAT_MERL : FEAT_NONE;
+}
+template <int FEAT, uint32_t KM = KM_ALL>
 TR_DEV f3 lobe_eval(const Bsdf& b, const Lobe& l, f3 w_o, f3 w_i) {
     switch (l.kind) {
-        case LB_LAMBERTIAN: return l.color * kInvPi;
+        case LB_LAMBERTIAN: return LOBE_ON(LB_LAMBERTIAN) ? l.color * kInvPi : mk(0.0f, 0.0f, 0.0f);
         case LB_OREN_NAYAR: {
+            if (!LOBE_ON(LB_OREN_NAYAR)) return mk(0.0f, 0.0f, 0.0f);
             float sin_o = sin_theta(w_o), sin_i = sin_theta(w_i);
             float max_cos = 0.0f;
             if (sin_i > 1e-4f && sin_o > 1e-4f)
@@ -170,6 +190,7 @@ TR_DEV f3 lobe_eval(const Bsdf& b, const Lobe& l, f3 w_o, f3 w_i) {
         }
         case LB_TS_DIEL:
         case LB_TS_COND: {
+            if (!LOBE_ON(LB_TS_DIEL) && !LOBE_ON(LB_TS_COND)) return mk(0.0f, 0.0f, 0.0f);
             float cos_to = fabsf(cos_theta(w_o)), cos_ti = fabsf(cos_theta(w_i));
             if (cos_to == 0.0f || cos_ti == 0.0f) return mk(0.0f, 0.0f, 0.0f);
             f3 w_h = w_i + w_o;
@@ -177,13 +198,13 @@ TR_DEV f3 lobe_eval(const Bsdf& b, const Lobe& l, f3 w_o, f3 w_i) {
             w_h = normalized(w_h);
             float d = beckmann_d(l.width, w_h);
             f3 f;
-            if (!(FEAT & FEAT_SPEC) || l.kind == LB_TS_DIEL) { float fr = fresnel_dielectric(l.eta_t, dot(w_i, w_h)); f = mk(fr, fr, fr); }
+            if (!(FEAT & FEAT_SPEC) || !LOBE_ON(LB_TS_COND) || (LOBE_ON(LB_TS_DIEL) && l.kind == LB_TS_DIEL)) { float fr = fresnel_dielectric(l.eta_t, dot(w_i, w_h)); f = mk(fr, fr, fr); }
             else f = fresnel_conductor(mk(b.mat->eta[0], b.mat->eta[1], b.mat->eta[2]), mk(b.mat->k[0], b.mat->k[1], b.mat->k[2]), dot(w_i, w_h));
             float g = beckmann_g1(l.width, w_i) * beckmann_g1(l.width, w_o);
             return l.color * f * d * g / (4.0f * cos_ti * cos_to);
         }
         case LB_MF_TRANS: {
-            if (!(FEAT & FEAT_MF_TRANS)) return mk(0.0f, 0.0f, 0.0f);   // no such lobe in this scene (checked by the host)
+            if (!(FEAT & FEAT_MF_TRANS) || !LOBE_ON(LB_MF_TRANS)) return mk(0.0f, 0.0f, 0.0f);   // no such lobe in this scene (checked by the host)
             if (same_hemisphere(w_o, w_i)) return mk(0.0f, 0.0f, 0.0f);
             float cos_to = cos_theta(w_o), cos_ti = cos_theta(w_i);
             if (cos_to == 0.0f || cos_ti == 0.0f) return mk(0.0f, 0.0f, 0.0f);
@@ -198,19 +219,19 @@ TR_DEV f3 lobe_eval(const Bsdf& b, const Lobe& l, f3 w_o, f3 w_i) {
             f3 f = mk(fr, fr, fr);
             return l.color * (fabsf(wi_dot_h) / (fabsf(w_i.z) * fabsf(w_o.z))) * (f * g * d) * jac;
         }
-        case LB_MERL: return (FEAT & FEAT_MERL) ? merl_eval(b.merl_data + b.mat->merl_offset, w_o, w_i) : mk(0.0f, 0.0f, 0.0f);
+        case LB_MERL: return ((FEAT & FEAT_MERL) && LOBE_ON(LB_MERL)) ? merl_eval(b.merl_data + b.mat->merl_offset, w_o, w_i) : mk(0.0f, 0.0f, 0.0f);
         default: return mk(0.0f, 0.0f, 0.0f);   // specular lobes evaluate to black
     }
 }
-template <int FEAT>
+template <int FEAT, uint32_t KM = KM_ALL>
 TR_DEV float lobe_pdf(const Lobe& l, f3 w_o, f3 w_i) {
-    if (l.kind == LB_TS_DIEL || l.kind == LB_TS_COND) {
+    if ((LOBE_ON(LB_TS_DIEL) || LOBE_ON(LB_TS_COND)) && (l.kind == LB_TS_DIEL || l.kind == LB_TS_COND)) {
         if (!same_hemisphere(w_o, w_i)) return 0.0f;
         f3 w_h = normalized(w_o + w_i);
         float jac = 1.0f / (4.0f * fabsf(dot(w_o, w_h)));
         return beckmann_pdf(l.width, w_h) * jac;
     }
-    if ((FEAT & FEAT_MF_TRANS) && l.kind == LB_MF_TRANS) {
+    if ((FEAT & FEAT_MF_TRANS) && LOBE_ON(LB_MF_TRANS) && l.kind == LB_MF_TRANS) {
         if (same_hemisphere(w_o, w_i)) return 0.0f;
         float e0, e1;
         mt_eta(l.eta_t, w_o, e0, e1);
@@ -221,17 +242,17 @@ TR_DEV float lobe_pdf(const Lobe& l, f3 w_o, f3 w_i) {
 }
 // BxDF::sample. For specular lobes returns f; for the others only the direction and the lobe's own pdf
 // are produced: BSDF::sample (bsdf.rs:103-109) replaces f by BSDF::eval for every non-specular lobe.
-template <int FEAT>
+template <int FEAT, uint32_t KM = KM_ALL>
 TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, f3& w_i, float& pdf) {
     const f3 zero = mk(0.0f, 0.0f, 0.0f);
     switch (l.kind) {
         case LB_SPEC_REFL_DIEL:
         case LB_SPEC_REFL_COND: {
-            if (!(FEAT & FEAT_SPEC)) { w_i = zero; pdf = 0.0f; return zero; }   // no such lobe in this scene (checked by the host)
+            if (!(FEAT & FEAT_SPEC) || (!LOBE_ON(LB_SPEC_REFL_DIEL) && !LOBE_ON(LB_SPEC_REFL_COND))) { w_i = zero; pdf = 0.0f; return zero; }   // no such lobe in this scene (checked by the host)
             w_i = mk(-w_o.x, -w_o.y, w_o.z);
             if (w_i.z != 0.0f) {
                 f3 f;
-                if (l.kind == LB_SPEC_REFL_DIEL) { float fr = fresnel_dielectric(l.eta_t, cos_theta(w_o)); f = mk(fr, fr, fr); }
+                if (!LOBE_ON(LB_SPEC_REFL_COND) || (LOBE_ON(LB_SPEC_REFL_DIEL) && l.kind == LB_SPEC_REFL_DIEL)) { float fr = fresnel_dielectric(l.eta_t, cos_theta(w_o)); f = mk(fr, fr, fr); }
                 else f = fresnel_conductor(mk(b.mat->eta[0], b.mat->eta[1], b.mat->eta[2]), mk(b.mat->k[0], b.mat->k[1], b.mat->k[2]), cos_theta(w_o));
                 pdf = 1.0f;
                 return f * l.color / fabsf(cos_theta(w_i));
@@ -240,7 +261,7 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
             return zero;
         }
         case LB_SPEC_TRANS: {
-            if (!(FEAT & FEAT_SPEC)) { w_i = zero; pdf = 0.0f; return zero; }
+            if (!(FEAT & FEAT_SPEC) || !LOBE_ON(LB_SPEC_TRANS)) { w_i = zero; pdf = 0.0f; return zero; }
             bool entering = cos_theta(w_o) > 0.0f;
             float ei = entering ? 1.0f : l.eta_t, et = entering ? l.eta_t : 1.0f;
             f3 n = entering ? mk(0.0f, 0.0f, 1.0f) : mk(0.0f, 0.0f, -1.0f);
@@ -254,16 +275,17 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
         }
         case LB_TS_DIEL:
         case LB_TS_COND: {
+            if (!LOBE_ON(LB_TS_DIEL) && !LOBE_ON(LB_TS_COND)) { w_i = zero; pdf = 0.0f; return zero; }
             if (w_o.z == 0.0f) { w_i = zero; pdf = 0.0f; return zero; }
             f3 w_h = beckmann_sample(l.width, u0, u1);
             if (!same_hemisphere(w_o, w_h)) w_h = -w_h;
             w_i = reflect(w_o, w_h);
             if (!same_hemisphere(w_o, w_i)) { w_i = zero; pdf = 0.0f; return zero; }
-            pdf = lobe_pdf<FEAT>(l, w_o, w_i);
+            pdf = lobe_pdf<FEAT, KM>(l, w_o, w_i);
             return zero;
         }
         case LB_MF_TRANS: {
-            if (!(FEAT & FEAT_MF_TRANS)) { w_i = zero; pdf = 0.0f; return zero; }
+            if (!(FEAT & FEAT_MF_TRANS) || !LOBE_ON(LB_MF_TRANS)) { w_i = zero; pdf = 0.0f; return zero; }
             f3 w_h = beckmann_sample(l.width, u0, u1);
             if (!same_hemisphere(w_o, w_h)) w_h = -w_h;
             float e0, e1;
@@ -272,16 +294,17 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
             if (refract(w_o, w_h, e0 / e1, wi)) {
                 if (same_hemisphere(w_o, wi)) { w_i = zero; pdf = 0.0f; return zero; }
                 w_i = wi;
-                pdf = lobe_pdf<FEAT>(l, w_o, w_i);
+                pdf = lobe_pdf<FEAT, KM>(l, w_o, w_i);
                 return zero;
             }
             w_i = zero; pdf = 0.0f;
             return zero;
         }
         default: {   // cosine hemisphere (bxdf/mod.rs:102-109)
+            if (!LOBE_ON(LB_LAMBERTIAN) && !LOBE_ON(LB_OREN_NAYAR) && !LOBE_ON(LB_MERL)) { w_i = zero; pdf = 0.0f; return zero; }
             w_i = cos_sample_hemisphere(u0, u1);
             if (w_o.z < 0.0f) w_i.z *= -1.0f;
-            pdf = lobe_pdf<FEAT>(l, w_o, w_i);
+            pdf = lobe_pdf<FEAT, KM>(l, w_o, w_i);
             return zero;
         }
     }
@@ -297,7 +320,7 @@ TR_DEV f3 from_shading(const Bsdf& b, f3 v) {   // bsdf.rs:57-61
 }
 // The *_sh variants take w_o / w_i already in (normalised) shading space: BSDF::eval, ::pdf and ::sample each start with the
 // same to_shading + normalized of the same vectors (bsdf.rs:67-68,86,115-116); the vertex step computes them once.
-template <int FEAT>
+template <int FEAT, uint32_t KM = KM_ALL>
 TR_DEV f3 bsdf_eval_sh(const Bsdf& b, f3 w_o, f3 w_i, uint32_t flags) {   // bsdf.rs:66-79
     if (w_o.z * w_i.z > 0.0f) flags &= ~(uint32_t)BX_TRANSMISSION; else flags &= ~(uint32_t)BX_REFLECTION;
     f3 sum = mk(0.0f, 0.0f, 0.0f);
@@ -305,7 +328,7 @@ TR_DEV f3 bsdf_eval_sh(const Bsdf& b, f3 w_o, f3 w_i, uint32_t flags) {   // bsd
 #pragma nounroll
     for (int i = 0; i < n; ++i) {
         Lobe l = load_lobe(b.mat, i);
-        if (lobe_matches(l.type, flags)) sum = sum + lobe_eval<FEAT>(b, l, w_o, w_i);
+        if (lobe_matches(l.type, flags)) sum = sum + lobe_eval<FEAT, KM>(b, l, w_o, w_i);
     }
     return sum;
 }
@@ -313,7 +336,7 @@ template <int FEAT>
 TR_DEV f3 bsdf_eval(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {
     return bsdf_eval_sh<FEAT>(b, normalized(to_shading(b, wo_world)), normalized(to_shading(b, wi_world)), flags);
 }
-template <int FEAT>
+template <int FEAT, uint32_t KM = KM_ALL>
 TR_DEV float bsdf_pdf_sh(const Bsdf& b, f3 w_o, f3 w_i, uint32_t flags) {   // bsdf.rs:114-125
     float pdf_val = 0.0f;
     int n_comps = 0;
@@ -321,7 +344,7 @@ TR_DEV float bsdf_pdf_sh(const Bsdf& b, f3 w_o, f3 w_i, uint32_t flags) {   // b
 #pragma nounroll
     for (int i = 0; i < n; ++i) {
         Lobe l = load_lobe(b.mat, i);
-        if (lobe_matches(l.type, flags)) { pdf_val = pdf_val + lobe_pdf<FEAT>(l, w_o, w_i); ++n_comps; }
+        if (lobe_matches(l.type, flags)) { pdf_val = pdf_val + lobe_pdf<FEAT, KM>(l, w_o, w_i); ++n_comps; }
     }
     return n_comps > 0 ? pdf_val / (float)n_comps : 0.0f;
 }
@@ -338,7 +361,7 @@ struct SampleHead {
     uint32_t sampled_type;
     bool need_eval, need_pdf;
 };
-template <int FEAT>
+template <int FEAT, uint32_t KM = KM_ALL>
 TR_DEV SampleHead bsdf_sample_head_sh(const Bsdf& b, f3 w_o, uint32_t flags, float u0, float u1, float one_d) {
     const f3 zero = mk(0.0f, 0.0f, 0.0f);
     SampleHead h;
@@ -355,7 +378,7 @@ TR_DEV SampleHead bsdf_sample_head_sh(const Bsdf& b, f3 w_o, uint32_t flags, flo
     const Lobe l = load_lobe(b.mat, li);
     f3 w_i;
     float pdf_v;
-    f3 f = lobe_sample<FEAT>(b, l, w_o, u0, u1, w_i, pdf_v);
+    f3 f = lobe_sample<FEAT, KM>(b, l, w_o, u0, u1, w_i, pdf_v);
     if (length_sqr(w_i) == 0.0f) return h;
     h.wi_world = normalized(from_shading(b, w_i));
     bool specular = (l.type & BX_SPECULAR) != 0u;
@@ -405,6 +428,7 @@ inline DevMaterial lower_material(const TrayMaterial& m, const TrayMerlTable* ta
     };
     const float white[3] = {1.0f, 1.0f, 1.0f};
     for (int i = 0; i < 3; ++i) { d.eta[i] = m.c0[i]; d.k[i] = m.c1[i]; }
+    d.mat_kind = m.kind <= TRAY_MAT_MERL ? m.kind : (uint32_t)TRAY_MAT_MERL;
     auto beckmann = [](float w) { return w > 0.000001f ? w : 0.000001f; };   // Beckmann::new (f32::max)
     switch (m.kind) {
         case TRAY_MAT_MATTE:   // matte.rs:52-65, oren_nayar.rs:26-34

@@ -30,7 +30,7 @@ struct DevLobe {
 };
 struct DevMaterial {
     uint32_t n_lobes;
-    uint32_t pad0;
+    uint32_t mat_kind;      // TRAY_MAT_*: the key of the wavefront schedule's material sort
     uint64_t merl_offset;   // float offset into merl_data
     DevLobe lobe[2];
     float eta[4];           // conductor eta (rgb)

@@ -211,7 +211,7 @@ TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counte
 //   WANT_MIS    BSDF half of estimate_direct (mod.rs:141-153), may set LF_MIS (ray for stage C)
 //   WANT_PATH   path continuation (path.rs:84-110): next stage A ray, or LF_LAST
 // Returns the follow-up query.
-template <int ANIM, int FEAT>
+template <int ANIM, int FEAT, uint32_t KM = KM_ALL>
 TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want, const f3 wo_sh) {
     const bool is_light = want == WANT_LIGHT, mis = want == WANT_MIS;
     const uint32_t flags = want == WANT_PATH ? BX_ALL : BX_NON_SPECULAR;
@@ -226,13 +226,13 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want, const f
         float u0, u1;
         lane_2d(sc, ln, mis ? SD_B2 : SD_P2, u0, u1);
         float one_d = lane_1d(sc, ln, mis ? SD_B1 : SD_P1);
-        h = bsdf_sample_head_sh<FEAT>(ln.bsdf, wo_sh, flags, u0, u1, one_d);
+        h = bsdf_sample_head_sh<FEAT, KM>(ln.bsdf, wo_sh, flags, u0, u1, one_d);
     }
     TR_QCLK(ln, 0);
     if (h.need_eval || h.need_pdf) {
         const f3 wi_sh = normalized(to_shading(ln.bsdf, h.wi_world));
-        if (h.need_eval) h.f = bsdf_eval_sh<FEAT>(ln.bsdf, wo_sh, wi_sh, flags);
-        if (h.need_pdf) h.pdf = bsdf_pdf_sh<FEAT>(ln.bsdf, wo_sh, wi_sh, flags);
+        if (h.need_eval) h.f = bsdf_eval_sh<FEAT, KM>(ln.bsdf, wo_sh, wi_sh, flags);
+        if (h.need_pdf) h.pdf = bsdf_pdf_sh<FEAT, KM>(ln.bsdf, wo_sh, wi_sh, flags);
     }
     TR_QCLK(ln, 1);
     const f3 f = h.f, w_i = h.wi_world;
@@ -291,7 +291,7 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want, const f
 }
 
 // Stage B after the occlusion ray: all BSDF queries of the vertex
-template <int ANIM, int FEAT>
+template <int ANIM, int FEAT, uint32_t KM = KM_ALL>
 TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
     const bool delta = sc.instances[ln.light_inst].kind == TRAY_INST_POINT_EMITTER;
     uint32_t want = ((ln.flags & LF_SHADOW) && !occluded) ? WANT_LIGHT : (delta ? WANT_PATH : WANT_MIS);
@@ -301,13 +301,13 @@ TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
 #if defined(TR_EMU_PROFILE)   // divergence-profile build of tests/emu: the default schedule, its passes numbered
     for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) {
         TR_EMU_PHASE(pass + 1);
-        want = query_stage<ANIM, FEAT>(sc, ln, want, wo_sh);
+        want = query_stage<ANIM, FEAT, KM>(sc, ln, want, wo_sh);
     }
     TR_EMU_PHASE(0);
 #else
 #pragma nounroll
     for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) {   // LIGHT -> MIS -> PATH
-        want = query_stage<ANIM, FEAT>(sc, ln, want, wo_sh);
+        want = query_stage<ANIM, FEAT, KM>(sc, ln, want, wo_sh);
         TR_QCLK(ln, 2);
     }
 #endif

@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
+#include <dlfcn.h>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -492,6 +494,9 @@ struct TrayDeviceScene {
     uint32_t trace_lds_depth = 0, trace_lds_bytes = 0;   // LDS part of the dynamic-fetch kernel's stacks; deeper entries go to d_stack_overflow
     uint32_t* d_stack_overflow = nullptr;
     bool wf_dynamic = true;           // TRAYHIP_WF_TRACE=slot: one thread per pool slot instead (no compaction)
+    bool wf_sort = true;              // material sort of the shading stage (k_wf_begin's LDS counting sort -> k_wf_query_kind); TRAYHIP_WF_SORT=0: off
+    uint32_t* d_kind_queues = nullptr;   // WF_MAT_KINDS x n_slots slot indices
+    uint32_t mat_kinds_present = 0;   // bit per TRAY_MAT_* kind among the scene's materials
     bool wf_wide = false;             // TRAYHIP_WF_WIDE=1: k_wf_trace_wide (4-wide BVH<Triangle>, wavefront_wide.h)
     uint32_t wide_lds_words = 0, wide_lds_bytes = 0;
 };
@@ -538,10 +543,16 @@ static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 tgrid, dim3 block, hipS
         hipLaunchKernelGGL(k_wf_regen<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
         if (s->wf_wide) hipLaunchKernelGGL((k_wf_trace_wide<0, ANIM>), tgrid, block, s->wide_lds_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats, s->wide_lds_words, s->d_stack_overflow);
         else hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
-        hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, qb, qctl);
+        uint32_t* const kq = s->wf_sort ? s->d_kind_queues : nullptr;
+        hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, qb, qctl, kq);
         if (s->wf_wide) hipLaunchKernelGGL((k_wf_trace_wide<1, ANIM>), tgrid, block, s->wide_lds_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats, s->wide_lds_words, s->d_stack_overflow);
         else hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
-        hipLaunchKernelGGL((k_wf_query<ANIM, FEAT>), grid, block, 0, stream, s->dev, s->pool, n_active, qc, qctl);
+        if (kq) {   // kind-pure shading over the sorted queues: one launch per material kind the scene contains
+#define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), grid, block, 0, stream, s->dev, s->pool, kq, qc, qctl)
+            WF_QUERY_KIND(TRAY_MAT_MATTE); WF_QUERY_KIND(TRAY_MAT_PLASTIC); WF_QUERY_KIND(TRAY_MAT_METAL); WF_QUERY_KIND(TRAY_MAT_GLASS);
+            WF_QUERY_KIND(TRAY_MAT_ROUGH_GLASS); WF_QUERY_KIND(TRAY_MAT_SPECULAR_METAL); WF_QUERY_KIND(TRAY_MAT_MERL);
+#undef WF_QUERY_KIND
+        } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT>), grid, block, 0, stream, s->dev, s->pool, n_active, qc, qctl);
         if (s->wf_wide) hipLaunchKernelGGL((k_wf_trace_wide<2, ANIM>), tgrid, block, s->wide_lds_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats, s->wide_lds_words, s->d_stack_overflow);
         else hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
     } else {   // one thread per pool slot in every stage; only the regeneration is compacted
@@ -551,7 +562,7 @@ static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 tgrid, dim3 block, hipS
                            spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, qa, qr, qctl);
         hipLaunchKernelGGL(k_wf_regen<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
         hipLaunchKernelGGL((k_wf_trace<0, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
-        hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, none, none);
+        hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, none, none, none);
         hipLaunchKernelGGL((k_wf_trace<1, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
         hipLaunchKernelGGL((k_wf_query<ANIM, FEAT>), grid, block, 0, stream, s->dev, s->pool, n_active, none, none);
         hipLaunchKernelGGL((k_wf_trace<2, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
@@ -674,6 +685,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         s->feat = (feat & FEAT_MF_TRANS) ? FEAT_ALL : feat;
         if (getenv("TRAYHIP_FEAT_ALL")) s->feat = FEAT_ALL;
     }
+    for (const DevMaterial& dm : mats) s->mat_kinds_present |= 1u << dm.mat_kind;
     UP(materials, mats.data(), f->n_materials)
     UP(merl_data, f->merl_data, f->n_merl_floats)
     UP(lights, f->lights, f->n_lights)
@@ -912,6 +924,11 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
         s->allocs.push_back(p); s->d_wf_counters = static_cast<uint32_t*>(p);
         HIP_CHECK(hipMalloc(&p, (4 * (size_t)n_slots + WF_QCTL_WORDS) * sizeof(uint32_t)));   // ray queues A, B, C, their counters, regeneration queue
         s->allocs.push_back(p); s->d_queues = static_cast<uint32_t*>(p);
+        if (const char* e = getenv("TRAYHIP_WF_SORT")) s->wf_sort = std::string(e) != "0";
+        if (s->wf_sort) {   // shading queues of the material sort (slot indices), one per material kind
+            HIP_CHECK(hipMalloc(&p, (size_t)WF_MAT_KINDS * n_slots * sizeof(uint32_t)));
+            s->allocs.push_back(p); s->d_kind_queues = static_cast<uint32_t*>(p);
+        }
         {
             int per_cu = 0, cus = 256;
             hipDeviceProp_t prop;
@@ -1062,6 +1079,158 @@ int tray_render_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_cou
     (void)hipFree(d);
     if (e != hipSuccess) { set_error(std::string("tray_render_tiles: ") + hipGetErrorString(e)); return TRAY_E_DEVICE; }
     return rc;
+}
+
+// ---- several GPUs of this process: shard + RCCL sum-reduce inside the library ----------------------------------------------
+namespace {
+struct Rccl {   // the six entry points, resolved from librccl.so on first use
+    void* lib = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool load(std::string& err) {
+        if (lib) return true;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("librccl.so could not be loaded: ") + dlerror(); return false; }
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        Reduce = reinterpret_cast<decltype(Reduce)>(dlsym(lib, "ncclReduce"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Reduce || !GetErrorString) { err = "librccl.so lacks an expected entry point"; lib = nullptr; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+}  // namespace
+
+struct TrayMultiScene {
+    int n_dev = 0;
+    std::vector<int> dev_ids;
+    std::vector<TrayDeviceScene*> scenes;
+    std::vector<float*> films;          // one full-frame RGBW buffer per device
+    std::vector<hipStream_t> streams;
+    std::vector<void*> comms;           // ncclComm_t
+    size_t n_floats = 0;
+    float reduce_ms = 0.0f;
+    hipEvent_t r0 = nullptr, r1 = nullptr;   // around the reduce, on the first device's stream
+};
+
+void tray_multi_destroy(TrayMultiScene* m) {
+    if (!m) return;
+    for (int d = 0; d < (int)m->scenes.size(); ++d) {
+        (void)hipSetDevice(m->dev_ids[d]);
+        if (d < (int)m->comms.size() && m->comms[d] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comms[d]);
+        if (d < (int)m->films.size() && m->films[d]) (void)hipFree(m->films[d]);
+        if (d < (int)m->streams.size() && m->streams[d]) (void)hipStreamDestroy(m->streams[d]);
+        if (d == 0) { if (m->r0) (void)hipEventDestroy(m->r0); if (m->r1) (void)hipEventDestroy(m->r1); }
+        tray_scene_destroy(m->scenes[d]);
+    }
+    delete m;
+}
+
+int tray_multi_create(const TrayFlatScene* f, int n_dev, const int* dev_ids, TrayMultiScene** out) {
+    if (!f || !out || !dev_ids || n_dev < 1) { set_error("tray_multi_create: null argument or no device"); return TRAY_E_INVALID; }
+    *out = nullptr;
+    int have = 0;
+    HIP_CHECK(hipGetDeviceCount(&have));
+    for (int d = 0; d < n_dev; ++d) {
+        if (dev_ids[d] < 0 || dev_ids[d] >= have) { set_error("tray_multi_create: no such HIP device " + std::to_string(dev_ids[d])); return TRAY_E_INVALID; }
+        for (int e = 0; e < d; ++e) if (dev_ids[e] == dev_ids[d]) { set_error("tray_multi_create: a device is listed twice"); return TRAY_E_INVALID; }
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        std::string err;
+        if (!g_rccl.load(err)) { set_error("tray_multi_create: " + err); return TRAY_E_UNSUPPORTED; }
+    }
+    TrayMultiScene* m = new TrayMultiScene();
+    m->n_dev = n_dev;
+    m->dev_ids.assign(dev_ids, dev_ids + n_dev);
+    m->n_floats = (size_t)f->film.width * f->film.height * 4;
+    const int before = g_device;
+    int rc = TRAY_OK;
+    for (int d = 0; d < n_dev && rc == TRAY_OK; ++d) {
+        rc = tray_init(dev_ids[d]);
+        TrayDeviceScene* s = nullptr;
+        if (rc == TRAY_OK) rc = tray_scene_create(f, &s);
+        if (rc != TRAY_OK) break;
+        m->scenes.push_back(s);
+        float* film = nullptr;
+        hipStream_t st = nullptr;
+        if (hipMalloc(&film, m->n_floats * sizeof(float)) != hipSuccess || hipStreamCreate(&st) != hipSuccess) { set_error("tray_multi_create: film / stream allocation failed"); rc = TRAY_E_NOMEM; }
+        m->films.push_back(film); m->streams.push_back(st);
+    }
+    if (rc == TRAY_OK) {
+        m->comms.assign(n_dev, nullptr);
+        const int nr = g_rccl.CommInitAll(m->comms.data(), n_dev, dev_ids);
+        if (nr != 0) { set_error(std::string("ncclCommInitAll failed: ") + g_rccl.GetErrorString(nr)); rc = TRAY_E_DEVICE; }
+    }
+    if (rc == TRAY_OK) {
+        (void)hipSetDevice(dev_ids[0]);
+        if (hipEventCreate(&m->r0) != hipSuccess || hipEventCreate(&m->r1) != hipSuccess) { set_error("hipEventCreate failed"); rc = TRAY_E_DEVICE; }
+    }
+    (void)tray_init(before);
+    if (rc != TRAY_OK) { tray_multi_destroy(m); return rc; }
+    *out = m;
+    return TRAY_OK;
+}
+
+int tray_render_frame_multi(TrayMultiScene* m, uint32_t spp, uint64_t seed, float* rgbw_host) {
+    if (!m || !rgbw_host) { set_error("tray_render_frame_multi: null argument"); return TRAY_E_INVALID; }
+    // one host thread per device: the wavefront schedule polls its stream, and the launches of different devices must overlap
+    std::vector<int> rcs(m->n_dev, TRAY_OK);
+    std::vector<std::string> errs(m->n_dev);
+    std::vector<std::thread> workers;
+    for (int d = 0; d < m->n_dev; ++d)
+        workers.emplace_back([&, d] {
+            if (hipSetDevice(m->dev_ids[d]) != hipSuccess || hipMemsetAsync(m->films[d], 0, m->n_floats * sizeof(float), m->streams[d]) != hipSuccess) {
+                rcs[d] = TRAY_E_DEVICE; errs[d] = "hipSetDevice / hipMemsetAsync failed"; return;
+            }
+            rcs[d] = tray_render_shard_device(m->scenes[d], (uint32_t)d, (uint32_t)m->n_dev, 16u, spp, seed, m->films[d], m->streams[d]);
+            if (rcs[d] != TRAY_OK) errs[d] = tray_last_error();
+        });
+    for (std::thread& w : workers) w.join();
+    for (int d = 0; d < m->n_dev; ++d)
+        if (rcs[d] != TRAY_OK) { set_error("tray_render_frame_multi: device " + std::to_string(m->dev_ids[d]) + ": " + errs[d]); return rcs[d]; }
+    // film::Image::add_blocks on the master == one sum-reduce onto the first device (in place on the root)
+    HIP_CHECK(hipSetDevice(m->dev_ids[0]));
+    HIP_CHECK(hipEventRecord(m->r0, m->streams[0]));
+    int nr = g_rccl.GroupStart();
+    for (int d = 0; d < m->n_dev && nr == 0; ++d) {
+        (void)hipSetDevice(m->dev_ids[d]);
+        nr = g_rccl.Reduce(m->films[d], m->films[d], m->n_floats, /*ncclFloat*/ 7, /*ncclSum*/ 0, /*root*/ 0, m->comms[d], m->streams[d]);
+    }
+    const int ne = g_rccl.GroupEnd();
+    if (nr == 0) nr = ne;
+    if (nr != 0) { set_error(std::string("ncclReduce failed: ") + g_rccl.GetErrorString(nr)); return TRAY_E_DEVICE; }
+    HIP_CHECK(hipSetDevice(m->dev_ids[0]));
+    HIP_CHECK(hipEventRecord(m->r1, m->streams[0]));
+    for (int d = 0; d < m->n_dev; ++d) { HIP_CHECK(hipSetDevice(m->dev_ids[d])); HIP_CHECK(hipStreamSynchronize(m->streams[d])); }
+    HIP_CHECK(hipSetDevice(m->dev_ids[0]));
+    HIP_CHECK(hipEventElapsedTime(&m->reduce_ms, m->r0, m->r1));
+    std::vector<float> tmp(m->n_floats);
+    HIP_CHECK(hipMemcpy(tmp.data(), m->films[0], m->n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < m->n_floats; ++i) rgbw_host[i] += tmp[i];
+    return TRAY_OK;
+}
+
+int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t);
+int tray_multi_timing(TrayMultiScene* m, TrayKernelTiming* per_device, float* reduce_ms) {
+    if (!m || !per_device) { set_error("tray_multi_timing: null argument"); return TRAY_E_INVALID; }
+    for (int d = 0; d < m->n_dev; ++d) {
+        const int rc = tray_last_timing(m->scenes[d], per_device + d);
+        if (rc != TRAY_OK) return rc;
+    }
+    if (reduce_ms) *reduce_ms = m->reduce_ms;
+    return TRAY_OK;
 }
 
 int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t) {

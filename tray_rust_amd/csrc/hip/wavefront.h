@@ -109,7 +109,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace(const DevScene scv, WfPoo
 // qctl[0..2] = entries in queue A / B / C, qctl[3..5] = consumer cursors; zeroed at the start of every round.
 // Producers append with one atomic per wave (ballot + prefix count); slots keep their place in the pool, only their
 // indices are compacted, so every stage still reads and writes pool fields at the slot's own address.
-#define WF_QCTL_WORDS 8
+#define WF_QCTL_WORDS 16   // [7] unused, [8 + k] = entries of the shading queue of material kind k (the material sort of k_wf_begin)
+#define WF_MAT_KINDS 7     // TRAY_MAT_*
 TR_DEV void wf_enqueue(uint32_t* __restrict__ queue, uint32_t* __restrict__ count, bool want, uint32_t slot) {
     const unsigned long long m = __ballot(want);
     if (m == 0ull) return;
@@ -368,75 +369,86 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
 #undef WF_POP
 }
 
-// Stage A shading: vertex_begin for the slots whose ray hit, end of the sample for those that missed
+// Stage A shading: vertex_begin for the slots whose ray hit, end of the sample for those that missed.
+// Material sort (north_star: "material sort in LDS"): when kind_queues is given, the vertices this workgroup just set up are
+// counted per material kind in LDS (one ds_add_rtn per vertex gives its rank inside the workgroup's share), the workgroup
+// reserves a range in each kind's global queue with ONE atomic per kind present, and the slot INDICES are written there -- a
+// counting sort of 256 jobs, nothing but indices moves. k_wf_query_kind<kind> then shades each queue with full waves of one
+// material kind and only that kind's lobe code compiled in, instead of one thread per pool slot running every kind's code.
 template <int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPool pool, uint32_t n_active, DevStats* __restrict__ stats,
-                                                       uint32_t* __restrict__ queue_b, uint32_t* __restrict__ qctl) {
+                                                       uint32_t* __restrict__ queue_b, uint32_t* __restrict__ qctl, uint32_t* __restrict__ kind_queues) {
+    __shared__ uint32_t s_cnt[8], s_base[8];
     const DevScene& sc = scv;
-    const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
-    if (i >= n_active) return;
-    uint32_t flags = pu(pool, F_FLAGS, i);
-    if (!(flags & LF_ALIVE)) return;
-    if (!(flags & WF_HIT_A)) {   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
-        pu(pool, F_FLAGS, i) = (flags & ~(LF_ALIVE | WF_INVERTEX)) | WF_FINISHED;
-        return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t i = blockIdx.x * TR_BLOCK + tid;
+    if (kind_queues) {
+        if (tid < 8u) s_cnt[tid] = 0u;
+        __syncthreads();
     }
-    Lane ln;
-    ln.flags = flags;
-    ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
-    LN_O(ln) = ld3(pool, F_O, i); ln.d = ld3(pool, F_D, i);
-    ln.throughput = ld3(pool, F_T, i); ln.illum = ld3(pool, F_ILLUM, i);
-    ln.first_ng = ld3(pool, F_NG, i);
-    HitRec rec;
-    rec.t = pf(pool, F_REC_T, i); rec.inst = pu(pool, F_REC_INST, i); rec.prim = pu(pool, F_REC_PRIM, i);
-    rec.b1 = pf(pool, F_REC_B1, i); rec.b2 = pf(pool, F_REC_B2, i);
-    Counters cnt;
-    cnt.rays = 0; cnt.vertices = 0;
-    ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
-    vertex_begin<ANIM>(sc, ln, rec, cnt);
-    pu(pool, F_FLAGS, i) = ln.flags | WF_INVERTEX;
-    st3(pool, F_ILLUM, i, ln.illum);
-    if (ln.bounce == 0u) st3(pool, F_NG, i, ln.first_ng);
-    st_bsdf(sc, pool, i, ln.bsdf);
-    st3(pool, F_WO, i, -ln.d);
-    pu(pool, F_LINST, i) = ln.light_inst;
-    st3(pool, F_LI, i, ln.li); st3(pool, F_WL, i, ln.wi_l); pf(pool, F_PDFL, i) = ln.pdf_l;
-    if (ln.flags & LF_SHADOW) st3(pool, F_AUX, i, ln.aux_d);
-    st3(pool, F_DIRECT, i, ln.direct);
-    st3(pool, F_TV, i, ln.t_vertex);
-    const unsigned long long m = __ballot(1);
-    if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].vertices, (unsigned long long)__popcll(m));
-    if (queue_b) wf_enqueue(queue_b, qctl + 1, (ln.flags & LF_SHADOW) != 0u, i);
+    uint32_t kind = WF_MAT_KINDS;   // no vertex from this slot
+    uint32_t flags = i < n_active ? pu(pool, F_FLAGS, i) : 0u;
+    if ((flags & LF_ALIVE) && !(flags & WF_HIT_A)) {   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
+        pu(pool, F_FLAGS, i) = (flags & ~(LF_ALIVE | WF_INVERTEX)) | WF_FINISHED;
+    } else if (flags & LF_ALIVE) {
+        Lane ln;
+        ln.flags = flags;
+        ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
+        LN_O(ln) = ld3(pool, F_O, i); ln.d = ld3(pool, F_D, i);
+        ln.throughput = ld3(pool, F_T, i); ln.illum = ld3(pool, F_ILLUM, i);
+        ln.first_ng = ld3(pool, F_NG, i);
+        HitRec rec;
+        rec.t = pf(pool, F_REC_T, i); rec.inst = pu(pool, F_REC_INST, i); rec.prim = pu(pool, F_REC_PRIM, i);
+        rec.b1 = pf(pool, F_REC_B1, i); rec.b2 = pf(pool, F_REC_B2, i);
+        Counters cnt;
+        cnt.rays = 0; cnt.vertices = 0;
+        ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
+        vertex_begin<ANIM>(sc, ln, rec, cnt);
+        pu(pool, F_FLAGS, i) = ln.flags | WF_INVERTEX;
+        st3(pool, F_ILLUM, i, ln.illum);
+        if (ln.bounce == 0u) st3(pool, F_NG, i, ln.first_ng);
+        st_bsdf(sc, pool, i, ln.bsdf);
+        st3(pool, F_WO, i, -ln.d);
+        pu(pool, F_LINST, i) = ln.light_inst;
+        st3(pool, F_LI, i, ln.li); st3(pool, F_WL, i, ln.wi_l); pf(pool, F_PDFL, i) = ln.pdf_l;
+        if (ln.flags & LF_SHADOW) st3(pool, F_AUX, i, ln.aux_d);
+        st3(pool, F_DIRECT, i, ln.direct);
+        st3(pool, F_TV, i, ln.t_vertex);
+        flags = ln.flags;
+        kind = ln.bsdf.mat->mat_kind;
+    } else flags = 0u;
+    {   // one counter update per wave (all lanes of the wave are here: nobody has returned)
+        const unsigned long long m = __ballot(kind < WF_MAT_KINDS);
+        if (m != 0ull && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u)
+            atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].vertices, (unsigned long long)__popcll(m));
+    }
+    if (queue_b) wf_enqueue(queue_b, qctl + 1, kind < WF_MAT_KINDS && (flags & LF_SHADOW) != 0u, i);
+    if (kind_queues) {
+        uint32_t rank = 0u;
+        if (kind < WF_MAT_KINDS) rank = atomicAdd(&s_cnt[kind], 1u);
+        __syncthreads();
+        if (tid < WF_MAT_KINDS && s_cnt[tid]) s_base[tid] = atomicAdd(qctl + 8 + tid, s_cnt[tid]);
+        __syncthreads();
+        if (kind < WF_MAT_KINDS) kind_queues[(size_t)kind * pool.n_slots + s_base[kind] + rank] = i;
+    }
 }
 
-// Stage B shading: the BSDF queries of the vertex (light half, BSDF half, continuation)
-template <int ANIM, int FEAT>
-#ifdef WF_QUERY_WAVES   // staged variant: compile the shading kernel of the wavefront schedule for this many waves per SIMD (default: whatever 239 VGPRs allow, 2)
-__global__ __launch_bounds__(TR_BLOCK, WF_QUERY_WAVES) void k_wf_query(
-#else
-__global__ __launch_bounds__(TR_BLOCK) void k_wf_query(
-#endif
-    const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ queue_c,
-                                                       uint32_t* __restrict__ qctl) {
-    const DevScene& sc = scv;
-    const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
-    if (i >= n_active) return;
-    const uint32_t flags = pu(pool, F_FLAGS, i);
-    if ((flags & (LF_ALIVE | WF_INVERTEX)) != (LF_ALIVE | WF_INVERTEX)) return;
+// Stage B shading of pool slot i: the BSDF queries of the vertex (light half, BSDF half, continuation)
+template <int ANIM, int FEAT, uint32_t KM>
+TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, uint32_t flags, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl) {
     Lane ln;
     ln.flags = flags;
     ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
     ln.throughput = ld3(pool, F_T, i);
     ld_bsdf(sc, pool, i, ln.bsdf);
     ln.light_inst = pu(pool, F_LINST, i);
-    ln.aux_d = mk(0.0f, 0.0f, 0.0f); ln.mis_f = mk(0.0f, 0.0f, 0.0f);   // (before wi_l is loaded: the two may share storage, TR_SHARE_WIL)
+    ln.aux_d = mk(0.0f, 0.0f, 0.0f); ln.mis_f = mk(0.0f, 0.0f, 0.0f);   // (before wi_l is loaded: the two share storage)
     ln.li = ld3(pool, F_LI, i); ln.wi_l = ld3(pool, F_WL, i); ln.pdf_l = pf(pool, F_PDFL, i);
     ln.direct = ld3(pool, F_DIRECT, i);
     ln.o = mk(0.0f, 0.0f, 0.0f);
-    ln.d = mk(0.0f, 0.0f, 0.0f);
     ln.d = -ld3(pool, F_WO, i);   // (-d is the outgoing direction until the PATH query replaces d)
     ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
-    vertex_queries<ANIM, FEAT>(sc, ln, (flags & WF_OCCLUDED) != 0u);
+    vertex_queries<ANIM, FEAT, KM>(sc, ln, (flags & WF_OCCLUDED) != 0u);
     st3(pool, F_T, i, ln.throughput);
     if (!(ln.flags & LF_LAST)) { st3(pool, F_O, i, LN_O(ln)); st3(pool, F_D, i, ln.d); }
     if (ln.flags & LF_MIS) {   // the vertex ends in k_wf_advance, after stage C has traced the BSDF-sampled light ray
@@ -456,6 +468,35 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(
         pu(pool, F_FLAGS, i) = f2;
     }
     if (queue_c) wf_enqueue(queue_c, qctl + 2, (ln.flags & LF_MIS) != 0u, i);
+}
+
+// one thread per pool slot, every material kind's code (TRAYHIP_WF_SORT=0, or the slot form of the schedule)
+template <int ANIM, int FEAT>
+#ifdef WF_QUERY_WAVES   // staged knob: compile the shading kernel of the wavefront schedule for this many waves per SIMD (default: whatever 239 VGPRs allow, 2)
+__global__ __launch_bounds__(TR_BLOCK, WF_QUERY_WAVES) void k_wf_query(
+#else
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_query(
+#endif
+    const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl) {
+    const DevScene& sc = scv;
+    const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
+    if (i >= n_active) return;
+    const uint32_t flags = pu(pool, F_FLAGS, i);
+    if ((flags & (LF_ALIVE | WF_INVERTEX)) != (LF_ALIVE | WF_INVERTEX)) return;
+    wf_query_slot<ANIM, FEAT, KM_ALL>(sc, pool, i, flags, queue_c, qctl);
+}
+
+// kind-pure shading: one thread per entry of material kind MK's queue (filled by k_wf_begin's counting sort); only the lobes that
+// kind lowers to are compiled in (dev_bsdf.h: km_of_material), so the kernels are small (matte 2 lobes' code instead of 9) and
+// every lane of a wave runs the same material's code
+template <int ANIM, int MK>
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_query_kind(const DevScene scv, WfPool pool, const uint32_t* __restrict__ kind_queues,
+                                                            uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl) {
+    const DevScene& sc = scv;
+    const uint32_t q = blockIdx.x * TR_BLOCK + threadIdx.x;
+    if (q >= qctl[8 + MK]) return;
+    const uint32_t i = kind_queues[(size_t)MK * pool.n_slots + q];
+    wf_query_slot<ANIM, feat_of_material(MK), km_of_material(MK)>(sc, pool, i, pu(pool, F_FLAGS, i), queue_c, qctl);
 }
 
 // New camera sample for pool slot i of a chunk that works on tile `tile_idx` (multithreaded.rs:90-96)

@@ -30,7 +30,7 @@ using namespace trayh;
 extern "C" {
 
 const char* tray_last_error(void) { return g_error.c_str(); }
-const char* tray_version(void) { return "trayhip 0.2 (abi 2, gfx950)"; }
+const char* tray_version(void) { return "trayhip 0.3 (abi 3, gfx950)"; }
 
 uint32_t tray_abi_sizeof(const char* name) {
     if (!name) return 0;
