@@ -139,8 +139,24 @@ enum {
     TRAY_MAT_ROUGH_GLASS = 4, TRAY_MAT_SPECULAR_METAL = 5, TRAY_MAT_MERL = 6
 };
 
-/* Closed lowering of the reference's Material trait objects (src/material/ *.rs); every texture
- * parameter is a constant (texture/mod.rs:43-76), scalars read from colour textures are luminance.
+/* Image textures (src/texture/image.rs:9-47, animated_image.rs:7-58; loader scene.rs:317-394). A texture is one frame (type
+ * "image") or >= 2 keyed frames ("animated_image", "movie": lerp between the two frames around ray.time, the first / last frame
+ * outside the keys). Frames are RGBA8 as image::DynamicImage::get_pixel presents them (row 0 on top; grey -> l,l,l,255). */
+typedef struct TrayTexture {
+    uint32_t first_frame, n_frames;   /* in tex_frames[] */
+} TrayTexture;
+typedef struct TrayTexFrame {
+    float time;                        /* keyframe time (0 for a plain image) */
+    uint32_t width, height;
+    uint32_t pad;
+    uint64_t offset;                   /* byte offset of the frame's width*height*4 bytes in tex_data */
+} TrayTexFrame;
+#define TRAY_NO_TEXTURE 0xffffffffu
+
+/* Closed lowering of the reference's Material trait objects (src/material/ *.rs). Every parameter is a Texture in the
+ * reference (texture/mod.rs:15-20): here a constant (c0 / c1 / f0 / f1; scalars read from constant colours are their
+ * luminance, texture/mod.rs:70-72) or, when the matching tex_* field is not TRAY_NO_TEXTURE, an image texture sampled at the
+ * hit's (u, v, time) -- sample_color for colour parameters, sample_f32 (red channel) for scalar ones.
  *   MATTE          c0 = diffuse,            f0 = roughness            (matte.rs:52-65)
  *   PLASTIC        c0 = diffuse, c1 = gloss, f0 = roughness           (plastic.rs:59-88)
  *   METAL          c0 = eta, c1 = k,        f0 = roughness            (metal.rs:56-67)
@@ -154,6 +170,7 @@ typedef struct TrayMaterial {
     float f0, f1;
     float c0[4];
     float c1[4];
+    uint32_t tex_c0, tex_c1, tex_f0, tex_f1;   /* texture ids or TRAY_NO_TEXTURE */
 } TrayMaterial;
 
 /* MERL table header: 90*90*180 RGB-interleaved f32, already scaled (material/merl.rs:60-82) */
@@ -212,6 +229,9 @@ typedef struct TrayFlatScene {
     uint32_t n_knots;       const float* knots;
     uint32_t n_color_keys;  const TrayColorKey* color_keys;
     uint32_t animated;      /* 1 if the camera, any instance transform or any emission varies over the open shutter */
+    uint32_t n_textures;    const TrayTexture* textures;
+    uint32_t n_tex_frames;  const TrayTexFrame* tex_frames;
+    uint64_t n_tex_bytes;   const uint8_t* tex_data;            /* RGBA8 texels of all frames */
 } TrayFlatScene;
 
 /* ---------------------------------------------------------------- host side: loader (scene.rs) */

@@ -682,6 +682,17 @@ void oracle_path_samples(uint64_t seed, uint32_t frame, uint32_t width, uint32_t
     }
 }
 // Mitchell-Netravali / film: splat one sample (x, y, rgb) of tile (tx, ty) into rgbw
+// Texture::sample_color / sample_f32 of texture `tex` at n (u, v, time) triples -> n x (r, g, b, a, f32)
+int oracle_texture_sample(const TrayFlatScene* fs, uint32_t tex, uint32_t n, const float* uvt, float* out) {
+    if (!fs || tex >= fs->n_textures) return 1;
+    for (uint32_t i = 0; i < n; ++i) {
+        const Colorf c = texture_sample_color(*fs, tex, uvt[3 * i], uvt[3 * i + 1], uvt[3 * i + 2]);
+        out[5 * i] = c.r; out[5 * i + 1] = c.g; out[5 * i + 2] = c.b; out[5 * i + 3] = c.a;
+        out[5 * i + 4] = texture_sample_f32(*fs, tex, uvt[3 * i], uvt[3 * i + 1], uvt[3 * i + 2]);
+    }
+    return 0;
+}
+
 void oracle_film_write(const TrayFlatScene* fs, uint32_t n, const float* samples5, uint32_t tile_x, uint32_t tile_y, float* rgbw) {
     std::vector<ImageSample> v(n);
     for (uint32_t i = 0; i < n; ++i) { v[i].x = samples5[5 * i]; v[i].y = samples5[5 * i + 1]; v[i].c = Colorf(samples5[5 * i + 2], samples5[5 * i + 3], samples5[5 * i + 4]); }

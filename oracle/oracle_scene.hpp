@@ -793,12 +793,76 @@ struct BSDF {
     }
 };
 
-// Material::bsdf for the seven materials (src/material/*.rs)
+// ---- image textures (src/texture/mod.rs:22-40, image.rs:9-47, animated_image.rs:7-58) --------------------------------
+// `x as u32` of Rust: saturating, NaN -> 0
+inline uint32_t f32_as_u32(float x) { return x > 0.0f ? (x >= 4294967296.0f ? 0xffffffffu : (uint32_t)x) : 0u; }
+inline Colorf tex_get_color(const TrayFlatScene& fs, const TrayTexFrame& fr, uint32_t x, uint32_t y) {   // Image::get_color
+    x = x > fr.width - 1 ? fr.width - 1 : x;   // clamp(x, 0, dims.0 - 1) on u32
+    y = y > fr.height - 1 ? fr.height - 1 : y;
+    const uint8_t* px = fs.tex_data + fr.offset + ((size_t)y * fr.width + x) * 4;
+    return Colorf((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f, (float)px[3] / 255.0f);
+}
+// bilinear_interpolate (texture/mod.rs:22-40): the four texels around (x, y), NOT centred on texel centres
+template <class T, class Get>
+inline T tex_bilinear(float x, float y, Get get) {
+    const uint32_t x0 = f32_as_u32(x), y0 = f32_as_u32(y);
+    const T s00 = get(x0, y0), s10 = get(x0 + 1u, y0), s01 = get(x0, y0 + 1u), s11 = get(x0 + 1u, y0 + 1u);
+    const float sx = x - (float)x0, sy = y - (float)y0;
+    return s00 * (1.0f - sx) * (1.0f - sy) + s10 * sx * (1.0f - sy) + s01 * (1.0f - sx) * sy + s11 * sx * sy;
+}
+inline Colorf image_sample_color(const TrayFlatScene& fs, const TrayTexFrame& fr, float u, float v) {
+    const float x = u * (float)fr.width, y = v * (float)fr.height;
+    return tex_bilinear<Colorf>(x, y, [&](uint32_t px, uint32_t py) { return tex_get_color(fs, fr, px, py); });
+}
+inline float image_sample_f32(const TrayFlatScene& fs, const TrayTexFrame& fr, float u, float v) {   // get_float: data[0] / 255
+    const float x = u * (float)fr.width, y = v * (float)fr.height;
+    return tex_bilinear<float>(x, y, [&](uint32_t px, uint32_t py) { return tex_get_color(fs, fr, px, py).r; });
+}
+// AnimatedImage::active_keyframes (binary_search_by on the frame times)
+inline void active_keyframes(const TrayTexFrame* fr, uint32_t n, float time, uint32_t& lo, bool& two) {
+    uint32_t a = 0, b = n;   // first index with fr[i].time >= time, or an exact match
+    two = false;
+    while (a < b) {
+        const uint32_t mid = a + (b - a) / 2;
+        if (fr[mid].time == time) { lo = mid; return; }
+        if (fr[mid].time < time) a = mid + 1; else b = mid;
+    }
+    if (a == n) lo = n - 1;
+    else if (a == 0) lo = 0;
+    else { lo = a - 1; two = true; }
+}
+inline Colorf texture_sample_color(const TrayFlatScene& fs, uint32_t tex, float u, float v, float time) {
+    const TrayTexture& t = fs.textures[tex];
+    const TrayTexFrame* fr = fs.tex_frames + t.first_frame;
+    if (t.n_frames < 2) return image_sample_color(fs, fr[0], u, v);
+    uint32_t lo; bool two;
+    active_keyframes(fr, t.n_frames, time, lo, two);
+    if (!two) return image_sample_color(fs, fr[lo], u, v);
+    const float x = (time - fr[lo].time) / (fr[lo + 1].time - fr[lo].time);
+    return image_sample_color(fs, fr[lo], u, v) * (1.0f - x) + image_sample_color(fs, fr[lo + 1], u, v) * x;   // linalg::lerp
+}
+inline float texture_sample_f32(const TrayFlatScene& fs, uint32_t tex, float u, float v, float time) {
+    const TrayTexture& t = fs.textures[tex];
+    const TrayTexFrame* fr = fs.tex_frames + t.first_frame;
+    if (t.n_frames < 2) return image_sample_f32(fs, fr[0], u, v);
+    uint32_t lo; bool two;
+    active_keyframes(fr, t.n_frames, time, lo, two);
+    if (!two) return image_sample_f32(fs, fr[lo], u, v);
+    const float x = (time - fr[lo].time) / (fr[lo + 1].time - fr[lo].time);
+    return image_sample_f32(fs, fr[lo], u, v) * (1.0f - x) + image_sample_f32(fs, fr[lo + 1], u, v) * x;
+}
+
+// Material::bsdf for the seven materials (src/material/*.rs): every parameter is texture.sample_color / sample_f32 at
+// (hit.dg.u, hit.dg.v, hit.dg.time) (e.g. matte.rs:55-56); constants are ConstantColor / ConstantScalar
 inline BSDF material_bsdf(const TrayFlatScene& fs, const Hit& hit) {
-    const TrayMaterial& m = fs.materials[fs.instances[hit.inst].material_id];
+    TrayMaterial m = fs.materials[fs.instances[hit.inst].material_id];
     BSDF b;
     b.set_frame(hit);
     Colorf c0(m.c0[0], m.c0[1], m.c0[2], m.c0[3]), c1(m.c1[0], m.c1[1], m.c1[2], m.c1[3]);
+    if (m.tex_c0 != TRAY_NO_TEXTURE) c0 = texture_sample_color(fs, m.tex_c0, hit.u, hit.v, hit.time);
+    if (m.tex_c1 != TRAY_NO_TEXTURE) c1 = texture_sample_color(fs, m.tex_c1, hit.u, hit.v, hit.time);
+    if (m.tex_f0 != TRAY_NO_TEXTURE) m.f0 = texture_sample_f32(fs, m.tex_f0, hit.u, hit.v, hit.time);
+    if (m.tex_f1 != TRAY_NO_TEXTURE) m.f1 = texture_sample_f32(fs, m.tex_f1, hit.u, hit.v, hit.time);
     auto dielectric = [](float ei, float et) { Fresnel f{}; f.kind = FR_DIELECTRIC; f.eta_i = ei; f.eta_t = et; return f; };
     auto conductor = [](Colorf eta, Colorf k) { Fresnel f{}; f.kind = FR_CONDUCTOR; f.eta = eta; f.k = k; return f; };
     switch (m.kind) {

@@ -77,6 +77,8 @@ def oracle():
         o.oracle_pixel_sample.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         o.oracle_path_samples.restype = None
         o.oracle_path_samples.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        o.oracle_texture_sample.restype = C.c_int
+        o.oracle_texture_sample.argtypes = [FS, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         o.oracle_film_write.restype = None
         o.oracle_film_write.argtypes = [FS, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         _o = o
@@ -103,6 +105,15 @@ def sample_radiance(flat, px, py, si, spp, seed=1, flags=0):
     rc = oracle().oracle_sample_radiance(flat, len(px), px.ctypes.data, py.ctypes.data, si.ctypes.data, spp, seed, out.ctypes.data, flags)
     if rc != 0:
         raise RuntimeError("oracle_sample_radiance failed")
+    return out
+
+
+def texture_sample(flat, tex, uvt):
+    """Texture::sample_color and ::sample_f32 at (u, v, time) rows -> (n, 5): r, g, b, a, f32"""
+    uvt = np.ascontiguousarray(uvt, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros((len(uvt), 5), np.float32)
+    if oracle().oracle_texture_sample(flat, tex, len(uvt), uvt.ctypes.data, out.ctypes.data) != 0:
+        raise RuntimeError("oracle_texture_sample failed")
     return out
 
 

@@ -104,6 +104,7 @@ void make_scene(const TrayFlatScene* f, int wide_format, EmuScene& e) {
     e.mats.resize(f->n_materials);
     for (uint32_t i = 0; i < f->n_materials; ++i) e.mats[i] = lower_material(f->materials[i], f->merl_tables);
     d.materials = e.mats.data(); d.merl_data = f->merl_data; d.lights = f->lights;
+    d.textures = f->n_textures ? f->textures : nullptr; d.tex_frames = f->tex_frames; d.tex_data = f->tex_data;
     d.filter_table = f->film.table; d.filter_x = f->film.table_x; d.filter_y = f->film.table_y;
     d.xf_levels = f->xf_levels; d.keyframes = f->keyframes; d.knots = f->knots; d.color_keys = f->color_keys;
     d.xf_cache = nullptr; d.moving_ids = nullptr; d.n_moving = 0; d.xf_cache_lanes = 0;
@@ -151,6 +152,7 @@ int feature_set(const EmuScene& e) {
             if (k == LB_MF_TRANS) feat |= FEAT_MF_TRANS;
             if (k == LB_SPEC_REFL_DIEL || k == LB_SPEC_REFL_COND || k == LB_SPEC_TRANS || k == LB_TS_COND) feat |= FEAT_SPEC;
         }
+    for (const DevMaterial& dm : e.mats) if (dm.textured) return FEAT_ALL | FEAT_TEX;
     return (feat & FEAT_MF_TRANS) ? FEAT_ALL : feat;
 }
 bool film_rows_ok(const TrayFlatScene* f) {
@@ -195,6 +197,7 @@ int emu_debug_sample_radiance(const TrayFlatScene* f, uint32_t n, const uint32_t
     make_scene(f, 0, e);
     const uint32_t kf = key_frame_host(seed, e.d.frame);
     bool moving = f->camera.animated != 0;
+    for (uint32_t t_ = 0; t_ < f->n_textures; ++t_) moving = moving || f->textures[t_].n_frames >= 2u;   // animated_image needs ray.time (tray_scene_create)
     for (uint32_t i = 0; i < f->n_instances; ++i) moving = moving || f->instances[i].animated != 0 || f->instances[i].emis_count >= 2;
     if (moving) launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_sample_radiance<2>(e.d, n, px, py, si, spp, kf, out); });
     else launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_sample_radiance<0>(e.d, n, px, py, si, spp, kf, out); });
@@ -308,6 +311,7 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
     EmuScene e;
     make_scene(f, 0, e);
     bool moving = f->camera.animated != 0;
+    for (uint32_t t_ = 0; t_ < f->n_textures; ++t_) moving = moving || f->textures[t_].n_frames >= 2u;   // animated_image needs ray.time (tray_scene_create)
     for (uint32_t i = 0; i < f->n_instances; ++i) moving = moving || f->instances[i].animated != 0 || f->instances[i].emis_count >= 2;
     if (f->n_instances > TR_FLAT_MAX && !moving) return -4;   // the library runs the wavefront schedule for those
     uint32_t n_moving = 0;
@@ -351,6 +355,7 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
     else if (feat == FEAT_MERL) EMU_TILES(FEAT_MERL);
     else if (feat == FEAT_SPEC) EMU_TILES(FEAT_SPEC);
     else if (feat == (FEAT_MERL | FEAT_SPEC)) EMU_TILES(FEAT_MERL | FEAT_SPEC);
+    else if (feat == (FEAT_ALL | FEAT_TEX)) EMU_TILES(FEAT_ALL | FEAT_TEX);
     else EMU_TILES(FEAT_ALL);
 #undef EMU_TILES
     if (stats_out) { stats_out[0] = stats.samples; stats_out[1] = stats.vertices; stats_out[2] = stats.rays; stats_out[3] = (unsigned long long)feat; }
@@ -367,6 +372,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     EmuScene e;
     make_scene(f, trace == 1, e);
     bool moving = f->camera.animated != 0;
+    for (uint32_t t_ = 0; t_ < f->n_textures; ++t_) moving = moving || f->textures[t_].n_frames >= 2u;   // animated_image needs ray.time (tray_scene_create)
     uint32_t n_moving = 0;
     for (uint32_t i = 0; i < f->n_instances; ++i) {
         moving = moving || f->instances[i].animated != 0 || f->instances[i].emis_count >= 2;
@@ -402,7 +408,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     const size_t slot_lds = (size_t)e.depth * TR_BLOCK * 4, dyn_lds = (size_t)lds_depth * TR_BLOCK * 4;
     const int feat = feature_set(e);
     // the material sort of the shading stage (default of the library for the compacted schedule; trace == 2 is the slot form without queues)
-    const bool sorted = trace != 2 && !getenv("TRAYHIP_WF_SORT_OFF");
+    const bool sorted = trace != 2 && !getenv("TRAYHIP_WF_SORT_OFF") && !(feat & FEAT_TEX);
     std::vector<uint32_t> kind_queues((size_t)WF_MAT_KINDS * n_slots, 0u);
     uint32_t kinds_present = 0;
     for (const DevMaterial& dm : e.mats) kinds_present |= 1u << dm.mat_kind;
@@ -435,7 +441,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     do {                                                                                                                                    \
         if (feat == FEAT_NONE) EMU_ROUND(A, FEAT_NONE); else if (feat == FEAT_MERL) EMU_ROUND(A, FEAT_MERL);                                \
         else if (feat == FEAT_SPEC) EMU_ROUND(A, FEAT_SPEC); else if (feat == (FEAT_MERL | FEAT_SPEC)) EMU_ROUND(A, FEAT_MERL | FEAT_SPEC);  \
-        else EMU_ROUND(A, FEAT_ALL);                                                                                                        \
+        else if (feat == (FEAT_ALL | FEAT_TEX)) EMU_ROUND(A, FEAT_ALL | FEAT_TEX); else EMU_ROUND(A, FEAT_ALL);                                                                                                        \
     } while (0)
     while (rc == 0 && counters[1] < tile_count) {
         std::memset(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t));

@@ -486,3 +486,39 @@ def test_frame_on_all_gpus_of_the_process_through_the_c_abi(tmp_path):
         got = rt.get_renderf32().reshape(96, 160, 4)
         assert np.allclose(got, whole, rtol=0, atol=1e-4 * whole.max()), n_dev
         assert sum(int(p.samples) for p in per) == tim.samples and reduce_ms >= 0.0
+
+
+@pytest.mark.parametrize("moving", [False, True])
+def test_image_textures(moving, tmp_path):
+    """image / animated_image / movie textures feeding material parameters (texture/image.rs:9-47,
+    animated_image.rs:7-58): per-sample radiance and the image of the textured box against the oracle, in both schedules"""
+    kw = dict(scene_time=2.0, shutter_size=0.5) if moving else {}
+    scene, rt, _, fi = T.Scene.load_file(scenes.write_textured_box(str(tmp_path), width=160, height=120, samples=64, **kw))
+    frame = 1 if moving else 0
+    flat = scene.flatten(frame)
+    rng = np.random.default_rng(13)
+    n = 60000
+    px = rng.integers(0, 160, n).astype(np.uint32); py = rng.integers(0, 120, n).astype(np.uint32); si = rng.integers(0, 64, n).astype(np.uint32)
+    a = O.sample_radiance(flat, px, py, si, 64, seed=4)
+    dev = scene.device_scene(frame, 0)
+    b = np.zeros((n, 8), np.float32)
+    T.check(T.lib().tray_debug_sample_radiance(dev, n, px.ctypes.data, py.ctypes.data, si.ctypes.data, 64, 4, b.ctypes.data))
+    assert (a[:, 5] == b[:, 5]).mean() > 0.999
+    d = np.abs(a[:, :3] - b[:, :3]).max(axis=1)
+    assert (d > 1e-3).mean() < 1e-3 and np.median(d) < 1e-6
+    cpu, st = O.render_tiles(flat, 64, seed=4)
+    for mode in ("mega", "wave"):
+        os.environ["TRAYHIP_MODE"] = mode
+        try:
+            scene.release_device()
+            hip = T.Hip(0, seed=4)
+            rt.clear()
+            hip.render(scene, rt, _config_at(fi, frame, 64))
+        finally:
+            del os.environ["TRAYHIP_MODE"]
+        gpu = rt.get_renderf32().reshape(120, 160, 4)
+        assert hip.last_timing.samples == st.samples and abs(int(hip.last_timing.vertices) - int(st.vertices)) <= 5e-4 * st.vertices
+        r = rmse(gpu, cpu)
+        print(f"textured_box{' (moving)' if moving else ''} 160x120x64 {mode}: RMSE {r:.3e}")
+        assert r < 1e-4
+    scene.release_device()

@@ -97,7 +97,7 @@ def test_trs_decomposition_recomposes(tmp_path):
     (lambda d: d["integrator"].update(type="whitted"), L.TRAY_E_UNSUPPORTED, "hot-path scope"),
     (lambda d: d["materials"].append(dict(d["materials"][0])), L.TRAY_E_INVALID, "name conflicts"),
     (lambda d: d["materials"][0].update(type="velvet"), L.TRAY_E_PARSE, "unrecognized type"),
-    (lambda d: d["materials"][0].update(diffuse="checker"), L.TRAY_E_UNSUPPORTED, "textures"),
+    (lambda d: d["materials"][0].update(diffuse="checker"), L.TRAY_E_INVALID, "Invalid color specified for diffuse of matte"),   # no such texture
     (lambda d: d["objects"][1].update(material="nope"), L.TRAY_E_INVALID, "was not found in the material list"),
     (lambda d: d["objects"][1]["geometry"].update(type="mesh", file="models/cube.obj", model="Cube"), L.TRAY_E_INVALID, "not sampleable"),
     (lambda d: d["objects"][2]["geometry"].update(model="Sphere"), L.TRAY_E_INVALID, "was not found in"),

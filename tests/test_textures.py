@@ -1,0 +1,247 @@
+"""Image / animated_image / movie textures (reference: src/texture/mod.rs:22-40, image.rs:9-47,
+animated_image.rs:7-58, loader scene.rs:317-394): the image decoder, the loader, the oracle's sampling against an independent
+numpy restatement of the reference's arithmetic, and the DEVICE source (host emulation) against the oracle, bit for bit."""
+import ctypes as C
+import json
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import tray_rust_amd as T
+from tray_rust_amd import _lib as L, scenes
+import _oracle as O
+
+
+def png_bytes(width, height, depth, ctype, rows, palette=None, trns=None, level=6):
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    raw = b"".join(rows)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, ctype, 0, 0, 0))
+    if palette is not None:
+        out += chunk(b"PLTE", palette)
+    if trns is not None:
+        out += chunk(b"tRNS", trns)
+    data = zlib.compress(raw, level)
+    half = len(data) // 2
+    return out + chunk(b"IDAT", data[:half]) + chunk(b"IDAT", data[half:]) + chunk(b"IEND", b"")   # two IDAT chunks
+
+
+def filtered_rows(pix, width, height, bpp, filters):
+    """rows of `pix` (bytes, height x width*bpp) with the PNG filter types given per row, applied as an ENCODER does"""
+    stride = width * bpp
+    rows, prev = [], bytes(stride)
+    for y in range(height):
+        cur = pix[y * stride:(y + 1) * stride]
+        ft = filters[y % len(filters)]
+        line = bytearray()
+        for i in range(stride):
+            a = cur[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if ft == 0: pred = 0
+            elif ft == 1: pred = a
+            elif ft == 2: pred = b
+            elif ft == 3: pred = (a + b) >> 1
+            else:
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            line.append((cur[i] - pred) & 255)
+        rows.append(bytes([ft]) + bytes(line))
+        prev = cur
+    return rows
+
+
+def load_texture_scene(tmp_path, textures, material=None):
+    d = scenes.cornell_box(16, 16, 4)
+    d["textures"] = textures
+    d["materials"].append(material or {"type": "matte", "name": "probe", "diffuse": textures[0]["name"], "roughness": 0.0})
+    scenes.write_assets(str(tmp_path))
+    p = os.path.join(str(tmp_path), "t.json")
+    json.dump(d, open(p, "w"))
+    return T.Scene.load_file(p)
+
+
+def frame_pixels(fs, k):
+    fr = fs.tex_frames[k]
+    n = fr.width * fr.height * 4
+    return np.ctypeslib.as_array(fs.tex_data, (fs.n_tex_bytes,))[fr.offset:fr.offset + n].reshape(fr.height, fr.width, 4).copy(), fr
+
+
+@pytest.mark.parametrize("kind", ["rgb8", "rgba8", "grey8", "greya8", "palette", "grey4", "grey1", "rgb16", "stored"])
+def test_png_decoder_against_python_written_files(kind, tmp_path, built):
+    rng = np.random.default_rng(4)
+    w, h = 13, 9
+    level = 0 if kind == "stored" else 6
+    filters = [0, 1, 2, 3, 4]
+    os.makedirs(tmp_path / "textures", exist_ok=True)
+    path = tmp_path / "textures" / "x.png"
+    if kind in ("rgb8", "stored"):
+        pix = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        data = png_bytes(w, h, 8, 2, filtered_rows(pix.tobytes(), w, h, 3, filters), level=level)
+        want = np.concatenate([pix, np.full((h, w, 1), 255, np.uint8)], axis=2)
+    elif kind == "rgba8":
+        pix = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        data = png_bytes(w, h, 8, 6, filtered_rows(pix.tobytes(), w, h, 4, filters)); want = pix
+    elif kind == "grey8":
+        pix = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        data = png_bytes(w, h, 8, 0, filtered_rows(pix.tobytes(), w, h, 1, filters))
+        want = np.stack([pix, pix, pix, np.full((h, w), 255, np.uint8)], axis=2)
+    elif kind == "greya8":
+        pix = rng.integers(0, 256, (h, w, 2), dtype=np.uint8)
+        data = png_bytes(w, h, 8, 4, filtered_rows(pix.tobytes(), w, h, 2, filters))
+        want = np.stack([pix[..., 0]] * 3 + [pix[..., 1]], axis=2)
+    elif kind == "palette":
+        pal = rng.integers(0, 256, (7, 3), dtype=np.uint8); tr = bytes([0, 128, 255])
+        idx = rng.integers(0, 7, (h, w), dtype=np.uint8)
+        data = png_bytes(w, h, 8, 3, filtered_rows(idx.tobytes(), w, h, 1, [0]), palette=pal.tobytes(), trns=tr)
+        alpha = np.array([tr[i] if i < 3 else 255 for i in range(7)], np.uint8)
+        want = np.concatenate([pal[idx], alpha[idx][..., None]], axis=2)
+    elif kind in ("grey4", "grey1"):
+        depth = 4 if kind == "grey4" else 1
+        vals = rng.integers(0, 1 << depth, (h, w), dtype=np.uint8)
+        rows = []
+        for y in range(h):
+            bits = "".join(format(int(v), f"0{depth}b") for v in vals[y])
+            bits += "0" * (-len(bits) % 8)
+            rows.append(b"\x00" + bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8)))
+        data = png_bytes(w, h, depth, 0, rows)
+        l = (vals.astype(np.uint32) * 255 // ((1 << depth) - 1)).astype(np.uint8)
+        want = np.stack([l, l, l, np.full((h, w), 255, np.uint8)], axis=2)
+    else:   # rgb16: the high byte is kept
+        pix = rng.integers(0, 65536, (h, w, 3)).astype(">u2")
+        data = png_bytes(w, h, 16, 2, filtered_rows(pix.tobytes(), w, h, 6, filters))
+        want = np.concatenate([(pix >> 8).astype(np.uint8), np.full((h, w, 1), 255, np.uint8)], axis=2)
+    open(path, "wb").write(data)
+    scene, *_ = load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/x.png"}])
+    fs = scene.flatten(0).contents
+    assert fs.n_textures == 1 and fs.n_tex_frames == 1
+    got, fr = frame_pixels(fs, 0)
+    assert (fr.width, fr.height) == (w, h) and (got == want).all()
+
+
+def test_other_image_formats(tmp_path, built):
+    rng = np.random.default_rng(2)
+    w, h = 5, 4
+    pix = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    os.makedirs(tmp_path / "textures", exist_ok=True)
+    open(tmp_path / "textures" / "a.ppm", "wb").write(b"P6\n# comment\n%d %d\n255\n" % (w, h) + pix.tobytes())
+    open(tmp_path / "textures" / "b.pgm", "wb").write(b"P5 %d %d 255\n" % (w, h) + pix[..., 0].tobytes())
+    stride = (w * 3 + 3) & ~3
+    rows = b"".join(pix[y, :, ::-1].tobytes() + bytes(stride - w * 3) for y in range(h - 1, -1, -1))
+    bmp = b"BM" + struct.pack("<IHHI", 54 + len(rows), 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, len(rows), 2835, 2835, 0, 0) + rows
+    open(tmp_path / "textures" / "c.bmp", "wb").write(bmp)
+    tga = bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, w, 0, h, 0, 24, 0x20]) + pix[..., ::-1].tobytes()
+    open(tmp_path / "textures" / "d.tga", "wb").write(tga)
+    scene, *_ = load_texture_scene(tmp_path, [{"name": n, "type": "image", "file": "textures/" + f}
+                                              for n, f in (("a", "a.ppm"), ("b", "b.pgm"), ("c", "c.bmp"), ("d", "d.tga"))])
+    fs = scene.flatten(0).contents
+    rgba = np.concatenate([pix, np.full((h, w, 1), 255, np.uint8)], axis=2)
+    for k, want in enumerate([rgba, np.stack([pix[..., 0]] * 3 + [np.full((h, w), 255, np.uint8)], axis=2), rgba, rgba]):
+        got, _ = frame_pixels(fs, k)
+        assert (got == want).all(), k
+
+
+def numpy_image_sample(px, u, v):
+    """texture/image.rs:36-47 + texture/mod.rs:22-40 restated with numpy (f32 throughout): returns rgba"""
+    h, w = px.shape[:2]
+    f = np.float32
+    x, y = f(u) * f(w), f(v) * f(h)
+    x0 = np.uint32(min(max(x, 0), 4294967040.0)) if x == x else np.uint32(0)
+    y0 = np.uint32(min(max(y, 0), 4294967040.0)) if y == y else np.uint32(0)
+    def get(a, b):
+        a = min(int(a), w - 1); b = min(int(b), h - 1)
+        return px[b, a].astype(np.float32) / f(255.0)
+    s00, s10, s01, s11 = get(x0, y0), get(int(x0) + 1, y0), get(x0, int(y0) + 1), get(int(x0) + 1, int(y0) + 1)
+    sx, sy = f(x - f(x0)), f(y - f(y0))
+    one = f(1.0)
+    return (s00 * f(one - sx) * f(one - sy) + s10 * sx * f(one - sy) + s01 * f(one - sx) * sy + s11 * sx * sy).astype(np.float32)
+
+
+def test_oracle_sampling_matches_an_independent_restatement(tmp_path, built):
+    p = scenes.write_textured_box(str(tmp_path), scene_time=2.0, shutter_size=0.5)
+    scene, *_ = T.Scene.load_file(p)
+    flat = scene.flatten(0)
+    fs = flat.contents
+    assert fs.n_textures == 5 and fs.n_tex_frames == 1 + 1 + 1 + 2 + 3
+    rng = np.random.default_rng(9)
+    uvt = np.concatenate([rng.uniform(-0.2, 1.2, (400, 2)), rng.uniform(-0.5, 2.5, (400, 1))], axis=1).astype(np.float32)
+    uvt[:8, :2] = [[0, 0], [1, 1], [0.5, 0.5], [0.999, 0.001], [1.0, 0.0], [0.0, 1.0], [0.25, 0.75], [0.0625, 0.5]]
+    for tex in range(fs.n_textures):
+        t = fs.textures[tex]
+        frames = [frame_pixels(fs, t.first_frame + k) for k in range(t.n_frames)]
+        got = O.texture_sample(flat, tex, uvt)
+        for i, (u, v, tm) in enumerate(uvt):
+            if t.n_frames == 1:
+                want = numpy_image_sample(frames[0][0], u, v)
+            else:   # AnimatedImage::active_keyframes + lerp (animated_image.rs:18-58)
+                times = [fr.time for _, fr in frames]
+                if tm in times: want = numpy_image_sample(frames[times.index(tm)][0], u, v)
+                elif tm > times[-1]: want = numpy_image_sample(frames[-1][0], u, v)
+                elif tm < times[0]: want = numpy_image_sample(frames[0][0], u, v)
+                else:
+                    lo = max(k for k in range(len(times)) if times[k] < tm)
+                    x = np.float32((np.float32(tm) - np.float32(times[lo])) / (np.float32(times[lo + 1]) - np.float32(times[lo])))
+                    want = (numpy_image_sample(frames[lo][0], u, v) * np.float32(np.float32(1.0) - x) + numpy_image_sample(frames[lo + 1][0], u, v) * x).astype(np.float32)
+            assert np.array_equal(got[i, :4], want), (tex, i, got[i], want)
+            assert got[i, 4] == want[0]   # sample_f32 = the red channel through the same arithmetic
+
+
+def test_loader_errors_of_textures(tmp_path, built):
+    def expect(textures, material, code, text):
+        with pytest.raises(T.TrayError) as e:
+            load_texture_scene(tmp_path, textures, material)
+        assert e.value.code == code and text in e.value.message, e.value.message
+    scenes.write_textured_box(str(tmp_path))
+    ok = {"name": "a", "type": "image", "file": "textures/checker.png"}
+    expect([ok], {"type": "matte", "name": "probe", "diffuse": "missing", "roughness": 1.0}, L.TRAY_E_INVALID, "Invalid color specified for diffuse of matte")
+    expect([ok, dict(ok)], None, L.TRAY_E_INVALID, "name conflicts with an existing entry")
+    expect([{"name": "a", "type": "image", "file": "textures/none.png"}], None, L.TRAY_E_IO, "Failed to load image file")
+    expect([{"name": "a", "type": "animated_image", "keyframes": [{"file": "textures/checker.png", "time": 0}]}], None, L.TRAY_E_INVALID, "at least 2 frames")
+    expect([{"name": "a", "type": "video", "file": "x"}], None, L.TRAY_E_PARSE, "Unrecognized texture type 'video'")
+    open(tmp_path / "textures" / "bad.png", "wb").write(open(tmp_path / "textures" / "checker.png", "rb").read()[:60])
+    expect([{"name": "a", "type": "image", "file": "textures/bad.png"}], None, L.TRAY_E_IO, "Failed to load image file")
+
+
+def test_a_material_with_a_missing_texture_id_is_rejected(tmp_path, built):
+    scene, *_ = T.Scene.load_file(scenes.write_textured_box(str(tmp_path)))
+    flat = scene.flatten(0)
+    f = L.TrayFlatScene()
+    C.memmove(C.byref(f), flat, C.sizeof(L.TrayFlatScene))
+    mats = (L.TrayMaterial * f.n_materials)()
+    C.memmove(mats, f.materials, f.n_materials * C.sizeof(L.TrayMaterial))
+    mats[f.n_materials - 1].tex_c0 = 99
+    f.materials = C.cast(mats, L._P(L.TrayMaterial))
+    d = C.c_void_p()
+    rc = L.lib().tray_scene_create(C.byref(f), C.byref(d))
+    assert rc == L.TRAY_E_INVALID and b"references a missing texture" in L.lib().tray_last_error()
+
+
+@pytest.mark.parametrize("moving", [False, True])
+def test_device_code_samples_textures_like_the_oracle(moving, tmp_path, built):
+    """the DEVICE source on the host (tests/emu): per-sample radiance and the tile kernel's image on the textured box -- per-hit
+    lowering of textured materials (matte with a colour map, with a roughness map that switches Lambertian / Oren-Nayar per
+    texel, plastic with a gloss map whose black texels drop the glossy lobe), animated_image and movie frames at ray.time"""
+    import _emu as E
+    w, h, spp = 32, 24, 8
+    kw = dict(scene_time=2.0, shutter_size=0.5) if moving else {}
+    scene, *_ = T.Scene.load_file(scenes.write_textured_box(str(tmp_path), width=w, height=h, samples=spp, **kw))
+    frame = 1 if moving else 0
+    flat = scene.flatten(frame)
+    rng = np.random.default_rng(3)
+    n = 6000
+    px = rng.integers(0, w, n).astype(np.uint32); py = rng.integers(0, h, n).astype(np.uint32); si = rng.integers(0, spp, n).astype(np.uint32)
+    a = O.sample_radiance(flat, px, py, si, spp, seed=6)
+    b = E.sample_radiance(flat, px, py, si, spp, 6)
+    assert a.tobytes() == b.tobytes()
+    tiles = np.array([(x, y) for y in range(h // 8) for x in range(w // 8)], np.uint32)
+    img, st = E.render_tiles(flat, tiles, spp, 6, blocks=2)
+    ref, ost = O.render_tiles(flat, spp, seed=6)
+    rgb = lambda i: i[..., :3] / np.maximum(i[..., 3:], 1e-20)
+    assert st[:3] == (ost.samples, ost.vertices, ost.rays) and float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6
+    if not moving:
+        wimg, wst = E.render_wavefront(flat, tiles, spp, 6, trace=0)
+        assert wst[:3] == (ost.samples, ost.vertices, ost.rays) and float(np.sqrt(np.mean((rgb(wimg) - rgb(ref)) ** 2))) < 2e-6

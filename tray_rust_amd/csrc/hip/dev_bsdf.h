@@ -30,6 +30,7 @@ struct Lobe {
 // BSDF: shading frame in registers, lobes fetched from the material table when needed
 struct Bsdf {
     f3 p, n, tan;
+    float u, v;   // hit.dg.u / v for textured materials (dead in kernels built without FEAT_TEX)
     const DevMaterial* __restrict__ mat;
     const float* __restrict__ merl_data;
 };
@@ -153,7 +154,8 @@ TR_DEV f3 merl_eval(const float* __restrict__ brdf, f3 w_oi, f3 w_ii) {
 // lookup and the microfacet-transmission code out of the single eval / pdf site cuts the tile kernel's scratch from 740 to
 // 592 B per lane (cornell_box 454 -> 484, smallpt 385 -> 421 Msamples/s at 64 spp), leaving out the specular lobes and the
 // conductor Fresnel term as well to 508 B (cornell_box 545).
-enum : int { FEAT_NONE = 0, FEAT_MERL = 1, FEAT_MF_TRANS = 2, FEAT_SPEC = 4, FEAT_ALL = 7 };   // FEAT_SPEC: specular lobes and conductor Fresnel
+enum : int { FEAT_NONE = 0, FEAT_MERL = 1, FEAT_MF_TRANS = 2, FEAT_SPEC = 4, FEAT_ALL = 7,   // FEAT_SPEC: specular lobes and conductor Fresnel
+             FEAT_TEX = 8 };   // image textures: materials whose lobes are lowered per hit (dev_tex.h); always together with FEAT_ALL
 // KM: bit per lobe kind (1 << LB_*) that can occur at all. The kind-pure shading kernels of the wavefront schedule (wavefront.h:
 // k_wf_query_kind, fed by the material sort of k_wf_begin) are instantiated with the lobes of ONE material kind, so every other
 // case of the switches below is dead code there; everywhere else KM_ALL keeps them all.
@@ -408,62 +410,77 @@ TR_DEV Bsdf make_bsdf(const DevScene& sc, const Hit& hit) {
     f3 bt = normalized(hit.dp_du);
     b.tan = cross(b.n, bt);
     b.p = hit.p;
+    b.u = hit.u; b.v = hit.v;
     b.mat = sc.materials + sc.instances[hit.inst].material_id;
     b.merl_data = sc.merl_data;
     return b;
 }
 
-// Material::bsdf for the seven materials, evaluated once per material on the host
-// (material/{matte,plastic,metal,glass,rough_glass,specular_metal,merl}.rs). f32 arithmetic in the
-// reference's order; this translation unit is built with -ffp-contract=off for host and device.
-inline DevMaterial lower_material(const TrayMaterial& m, const TrayMerlTable* tables) {
-    DevMaterial d;
-    std::memset(&d, 0, sizeof d);
-    auto black = [](const float* c) { return c[0] == 0.0f && c[1] == 0.0f && c[2] == 0.0f; };
-    auto add = [&](uint32_t kind, uint32_t type, const float* color, float eta_t, float width, float ob) {
-        DevLobe& l = d.lobe[d.n_lobes++];
-        l.kind = kind; l.type = type;
-        l.color[0] = color[0]; l.color[1] = color[1]; l.color[2] = color[2];
-        l.eta_t = eta_t; l.width = width; l.ob = ob;
-    };
+// Material::bsdf for the seven materials (material/{matte,plastic,metal,glass,rough_glass,specular_metal,merl}.rs) from parameter
+// VALUES: on the host once per material whose parameters are constants, on the device per hit for textured materials (dev_tex.h).
+// f32 arithmetic in the reference's order; this translation unit is built with -ffp-contract=off for host and device.
+#ifdef TR_HOST_EMU
+#define TR_HD inline
+#else
+#define TR_HD __host__ __device__ inline
+#endif
+TR_HD void lower_values(DevMaterial& d, uint32_t kind, const float* c0, const float* c1, float f0, float f1) {
+    d.n_lobes = 0u;
     const float white[3] = {1.0f, 1.0f, 1.0f};
-    for (int i = 0; i < 3; ++i) { d.eta[i] = m.c0[i]; d.k[i] = m.c1[i]; }
-    d.mat_kind = m.kind <= TRAY_MAT_MERL ? m.kind : (uint32_t)TRAY_MAT_MERL;
-    auto beckmann = [](float w) { return w > 0.000001f ? w : 0.000001f; };   // Beckmann::new (f32::max)
-    switch (m.kind) {
+#define TR_ADD_LOBE(K, T, C, ETA, W, OB) do { DevLobe& l_ = d.lobe[d.n_lobes++]; l_.kind = (K); l_.type = (T); l_.color[0] = (C)[0]; l_.color[1] = (C)[1]; \
+                                              l_.color[2] = (C)[2]; l_.eta_t = (ETA); l_.width = (W); l_.ob = (OB); } while (0)
+#define TR_BLACK(C) ((C)[0] == 0.0f && (C)[1] == 0.0f && (C)[2] == 0.0f)
+#define TR_BECKMANN(W) ((W) > 0.000001f ? (W) : 0.000001f)   /* Beckmann::new (f32::max) */
+    for (int i = 0; i < 3; ++i) { d.eta[i] = c0[i]; d.k[i] = c1[i]; }
+    d.eta[3] = 0.0f; d.k[3] = 0.0f;
+    d.mat_kind = kind <= TRAY_MAT_MERL ? kind : (uint32_t)TRAY_MAT_MERL;
+    switch (kind) {
         case TRAY_MAT_MATTE:   // matte.rs:52-65, oren_nayar.rs:26-34
-            if (m.f0 == 0.0f) add(LB_LAMBERTIAN, BX_DIFFUSE | BX_REFLECTION, m.c0, 1.0f, 0.0f, 0.0f);
+            if (f0 == 0.0f) TR_ADD_LOBE(LB_LAMBERTIAN, BX_DIFFUSE | BX_REFLECTION, c0, 1.0f, 0.0f, 0.0f);
             else {
-                float sigma = 3.14159265358979323846f / 180.0f * m.f0;
+                float sigma = 3.14159265358979323846f / 180.0f * f0;
                 sigma *= sigma;
                 float a = 1.0f - 0.5f * sigma / (sigma + 0.33f);
                 float bb = 0.45f * sigma / (sigma + 0.09f);
-                add(LB_OREN_NAYAR, BX_DIFFUSE | BX_REFLECTION, m.c0, 1.0f, a, bb);
+                TR_ADD_LOBE(LB_OREN_NAYAR, BX_DIFFUSE | BX_REFLECTION, c0, 1.0f, a, bb);
             }
             break;
         case TRAY_MAT_PLASTIC:   // plastic.rs:59-88
-            if (!black(m.c0)) add(LB_LAMBERTIAN, BX_DIFFUSE | BX_REFLECTION, m.c0, 1.0f, 0.0f, 0.0f);
-            if (!black(m.c1)) add(LB_TS_DIEL, BX_GLOSSY | BX_REFLECTION, m.c1, 1.5f, beckmann(m.f0), 0.0f);
+            if (!TR_BLACK(c0)) TR_ADD_LOBE(LB_LAMBERTIAN, BX_DIFFUSE | BX_REFLECTION, c0, 1.0f, 0.0f, 0.0f);
+            if (!TR_BLACK(c1)) TR_ADD_LOBE(LB_TS_DIEL, BX_GLOSSY | BX_REFLECTION, c1, 1.5f, TR_BECKMANN(f0), 0.0f);
             break;
         case TRAY_MAT_METAL:   // metal.rs:56-67
-            add(LB_TS_COND, BX_GLOSSY | BX_REFLECTION, white, 1.0f, beckmann(m.f0), 0.0f);
+            TR_ADD_LOBE(LB_TS_COND, BX_GLOSSY | BX_REFLECTION, white, 1.0f, TR_BECKMANN(f0), 0.0f);
             break;
         case TRAY_MAT_GLASS:   // glass.rs:51-78
-            if (!black(m.c0)) add(LB_SPEC_REFL_DIEL, BX_SPECULAR | BX_REFLECTION, m.c0, m.f0, 0.0f, 0.0f);
-            if (!black(m.c1)) add(LB_SPEC_TRANS, BX_SPECULAR | BX_TRANSMISSION, m.c1, m.f0, 0.0f, 0.0f);
+            if (!TR_BLACK(c0)) TR_ADD_LOBE(LB_SPEC_REFL_DIEL, BX_SPECULAR | BX_REFLECTION, c0, f0, 0.0f, 0.0f);
+            if (!TR_BLACK(c1)) TR_ADD_LOBE(LB_SPEC_TRANS, BX_SPECULAR | BX_TRANSMISSION, c1, f0, 0.0f, 0.0f);
             break;
         case TRAY_MAT_ROUGH_GLASS:   // rough_glass.rs:57-85
-            if (!black(m.c0)) add(LB_TS_DIEL, BX_GLOSSY | BX_REFLECTION, m.c0, m.f0, beckmann(m.f1), 0.0f);
-            if (!black(m.c1)) add(LB_MF_TRANS, BX_GLOSSY | BX_TRANSMISSION, m.c1, m.f0, beckmann(m.f1), 0.0f);
+            if (!TR_BLACK(c0)) TR_ADD_LOBE(LB_TS_DIEL, BX_GLOSSY | BX_REFLECTION, c0, f0, TR_BECKMANN(f1), 0.0f);
+            if (!TR_BLACK(c1)) TR_ADD_LOBE(LB_MF_TRANS, BX_GLOSSY | BX_TRANSMISSION, c1, f0, TR_BECKMANN(f1), 0.0f);
             break;
         case TRAY_MAT_SPECULAR_METAL:   // specular_metal.rs:49-58
-            add(LB_SPEC_REFL_COND, BX_SPECULAR | BX_REFLECTION, white, 1.0f, 0.0f, 0.0f);
+            TR_ADD_LOBE(LB_SPEC_REFL_COND, BX_SPECULAR | BX_REFLECTION, white, 1.0f, 0.0f, 0.0f);
             break;
         default:   // TRAY_MAT_MERL, material/merl.rs:88-92
-            add(LB_MERL, BX_GLOSSY | BX_REFLECTION, white, 1.0f, 0.0f, 0.0f);
-            d.merl_offset = tables ? tables[m.table].offset : 0;
+            TR_ADD_LOBE(LB_MERL, BX_GLOSSY | BX_REFLECTION, white, 1.0f, 0.0f, 0.0f);
             break;
     }
+#undef TR_ADD_LOBE
+#undef TR_BLACK
+#undef TR_BECKMANN
+}
+// host: one DevMaterial per TrayMaterial (constants lowered here; textured ones keep their parameters for the per-hit lowering)
+inline DevMaterial lower_material(const TrayMaterial& m, const TrayMerlTable* tables) {
+    DevMaterial d;
+    std::memset(&d, 0, sizeof d);
+    lower_values(d, m.kind, m.c0, m.c1, m.f0, m.f1);
+    if (m.kind == TRAY_MAT_MERL) d.merl_offset = tables ? tables[m.table].offset : 0;
+    d.tex_c0 = m.tex_c0; d.tex_c1 = m.tex_c1; d.tex_f0 = m.tex_f0; d.tex_f1 = m.tex_f1;
+    d.textured = (m.tex_c0 != TRAY_NO_TEXTURE || m.tex_c1 != TRAY_NO_TEXTURE || m.tex_f0 != TRAY_NO_TEXTURE || m.tex_f1 != TRAY_NO_TEXTURE) ? 1u : 0u;
+    for (int i = 0; i < 3; ++i) { d.c0[i] = m.c0[i]; d.c1[i] = m.c1[i]; }
+    d.f0 = m.f0; d.f1 = m.f1;
     return d;
 }
 

@@ -35,6 +35,12 @@ struct DevMaterial {
     DevLobe lobe[2];
     float eta[4];           // conductor eta (rgb)
     float k[4];             // conductor k (rgb)
+    // image textures (dev_tex.h): a material with a textured parameter keeps its source parameters; its lobes are lowered per hit
+    // from the values sampled at the hit's (u, v, time), exactly as Material::bsdf does it in the reference
+    uint32_t textured;      // 1 => lobe[] / eta / k above are placeholders
+    uint32_t tex_c0, tex_c1, tex_f0, tex_f1;
+    float c0[3], c1[3], f0, f1;
+    uint32_t pad_tex[3];
 };
 
 struct DevScene {
@@ -69,6 +75,9 @@ struct DevScene {
     const tray::FlatLeaf* __restrict__ flat_leaves;   // the flat instance loop's view of the scene: BVH<Instance> leaves ...
     const tray::FlatInst* __restrict__ flat_insts;    // ... and their instances, one 128-B record each (host/gates.hpp)
     uint32_t n_flat_leaves, pad_flat;
+    const TrayTexture* __restrict__ textures;      // image textures (dev_tex.h); null when the scene has none
+    const TrayTexFrame* __restrict__ tex_frames;
+    const uint8_t* __restrict__ tex_data;
     uint32_t* __restrict__ retraced;               // counter of rays the flat loop handed to trace_bvh (tied candidates); may be null
     const uint8_t* __restrict__ tri_leaf;          // per triangle of a mesh with <= TR_COOP_MAX_TRIS triangles: index of its BVH<Triangle> leaf node (mesh_leaf_coop's gate)
     float filter_w, filter_h, inv_w, inv_h;
@@ -142,6 +151,7 @@ struct HitRec {   // what traversal keeps for the closest candidate
 
 struct Hit {   // DifferentialGeometry in world space (differential_geometry.rs:9-27) + instance id
     f3 p, n, ng, dp_du;
+    float u, v;   // texture coordinates (read only by kernels built with image-texture support)
     uint32_t inst;
 };
 
@@ -758,6 +768,7 @@ TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, flo
         if (dp_dv_out) *dp_dv_out = xf_vector(in->mat, dp_dv);
     }
     h.inst = rec.inst;
+    h.u = u; h.v = v;
     if (uv_out) { uv_out[0] = u; uv_out[1] = v; }
     return h;
 }

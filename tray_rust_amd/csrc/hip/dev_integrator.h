@@ -17,7 +17,7 @@
 // read the vertex; `illum += throughput * direct` still happens after the full estimate_direct value is
 // known and with the pre-update throughput, so every float operation and its operands are unchanged.
 #pragma once
-#include "dev_bsdf.h"
+#include "dev_tex.h"
 
 namespace tr {
 
@@ -295,6 +295,14 @@ template <int ANIM, int FEAT, uint32_t KM = KM_ALL>
 TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
     const bool delta = sc.instances[ln.light_inst].kind == TRAY_INST_POINT_EMITTER;
     uint32_t want = ((ln.flags & LF_SHADOW) && !occluded) ? WANT_LIGHT : (delta ? WANT_PATH : WANT_MIS);
+    // a textured material's lobes exist per hit only: lowered here from the parameters sampled at (u, v, time), as Material::bsdf
+    // does (matte.rs:55-63 etc.), kept in private memory for the queries of this vertex
+    const DevMaterial* const table_mat = ln.bsdf.mat;
+    DevMaterial hit_mat;
+    if ((FEAT & FEAT_TEX) && table_mat->textured) {
+        resolve_textured(sc, table_mat, ln.bsdf.u, ln.bsdf.v, ln.time, hit_mat);
+        ln.bsdf.mat = &hit_mat;
+    }
     // w_o in shading space, once per vertex: BSDF::eval, ::pdf and ::sample each start with the same to_shading + normalized of the
     // same vector (bsdf.rs:67-68,86,115-116). w_o is -d until the PATH query (the last one) writes the next ray's direction.
     const f3 wo_sh = normalized(to_shading(ln.bsdf, -ln.d));
@@ -311,6 +319,7 @@ TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
         TR_QCLK(ln, 2);
     }
 #endif
+    if (FEAT & FEAT_TEX) ln.bsdf.mat = table_mat;
 }
 
 // Stage C: tail of the BSDF half of estimate_direct (mod.rs:154-166), then path.rs:82 and the

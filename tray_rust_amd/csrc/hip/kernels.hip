@@ -423,7 +423,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
                     if (tr_.hit) vertex_begin<ANIM>(sc, ln, tr_.rec, cnt);
                     else ln.flags &= ~LF_ALIVE;
                 } else if (stage == 1) {
-                    vertex_queries<ANIM, FEAT_ALL>(sc, ln, tr_.hit);
+                    vertex_queries<ANIM, FEAT_ALL | FEAT_TEX>(sc, ln, tr_.hit);
                 } else {
                     if (!vertex_end<ANIM>(sc, ln, tr_.hit, tr_.rec)) ln.flags &= ~LF_ALIVE;
                 }
@@ -444,8 +444,10 @@ __global__ __launch_bounds__(64) void k_debug_bsdf(const DevScene scv, uint32_t 
     // canonical frame: n = +z, dp_du = +x; instance 0 of the (private) scene copy carries the material
     Hit h;
     h.p = mk(0.0f, 0.0f, 0.0f); h.n = mk(0.0f, 0.0f, 1.0f); h.ng = mk(0.0f, 0.0f, 1.0f); h.dp_du = mk(1.0f, 0.0f, 0.0f);
-    h.inst = 0;
+    h.inst = 0; h.u = 0.5f; h.v = 0.5f;
     Bsdf b = make_bsdf(sc, h);
+    DevMaterial hit_mat;   // a textured material: its lobes at the centre of the texture, frame time 0
+    if (b.mat->textured) { resolve_textured(sc, b.mat, h.u, h.v, 0.0f, hit_mat); b.mat = &hit_mat; }
     uint32_t flags = flags_sel == 0 ? BX_ALL : BX_NON_SPECULAR;
     f3 wo = mk(dirs[6 * i], dirs[6 * i + 1], dirs[6 * i + 2]), wi = mk(dirs[6 * i + 3], dirs[6 * i + 4], dirs[6 * i + 5]);
     float* o = out + (size_t)i * 12;
@@ -684,8 +686,14 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             }
         s->feat = (feat & FEAT_MF_TRANS) ? FEAT_ALL : feat;
         if (getenv("TRAYHIP_FEAT_ALL")) s->feat = FEAT_ALL;
+        for (const DevMaterial& dm : mats) if (dm.textured) s->feat = FEAT_ALL | FEAT_TEX;   // lobes of textured materials are only known per hit
     }
     for (const DevMaterial& dm : mats) s->mat_kinds_present |= 1u << dm.mat_kind;
+    if (f->n_textures) {
+        UP(textures, f->textures, f->n_textures)
+        UP(tex_frames, f->tex_frames, f->n_tex_frames)
+        UP(tex_data, f->tex_data, f->n_tex_bytes)
+    }
     UP(materials, mats.data(), f->n_materials)
     UP(merl_data, f->merl_data, f->n_merl_floats)
     UP(lights, f->lights, f->n_lights)
@@ -697,6 +705,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     UP(knots, f->knots, f->n_knots)
     UP(color_keys, f->color_keys, f->n_color_keys)
 #undef UP
+    for (uint32_t t = 0; t < f->n_textures; ++t) moving = moving || f->textures[t].n_frames >= 2u;   // animated_image: sampled at ray.time, which only the ANIM kernels carry
     s->animated = moving;
     if (getenv("TRAYHIP_WF_WIDE") && std::string(getenv("TRAYHIP_WF_WIDE")) == "1") {   // 4-wide BVH<Triangle> for the dynamic-fetch traversal
 #ifdef TR_QWIDE   // variant build (make EXTRA_HIPFLAGS=-DTR_QWIDE): 64-B nodes with 8-bit boxes rounded outwards (host/wide_nodes.hpp)
@@ -852,6 +861,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
                 reinterpret_cast<const void*>(k_path_tiles<0, FEAT_NONE>), reinterpret_cast<const void*>(k_path_tiles<0, FEAT_MERL>),
                 reinterpret_cast<const void*>(k_path_tiles<0, FEAT_SPEC>), reinterpret_cast<const void*>(k_path_tiles<0, FEAT_MERL | FEAT_SPEC>),
                 reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL>),
+                reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL | FEAT_TEX>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL | FEAT_TEX>),
                 reinterpret_cast<const void*>(k_path_tiles<1, FEAT_NONE>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL>),
                 reinterpret_cast<const void*>(k_path_tiles<1, FEAT_SPEC>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL | FEAT_SPEC>),
                 reinterpret_cast<const void*>(k_wf_trace<0, 0>), reinterpret_cast<const void*>(k_wf_trace<0, 1>),
@@ -925,6 +935,7 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
         HIP_CHECK(hipMalloc(&p, (4 * (size_t)n_slots + WF_QCTL_WORDS) * sizeof(uint32_t)));   // ray queues A, B, C, their counters, regeneration queue
         s->allocs.push_back(p); s->d_queues = static_cast<uint32_t*>(p);
         if (const char* e = getenv("TRAYHIP_WF_SORT")) s->wf_sort = std::string(e) != "0";
+        if (s->feat & FEAT_TEX) s->wf_sort = false;   // the kind-pure kernels read lobes from the material table; textured materials have theirs per hit
         if (s->wf_sort) {   // shading queues of the material sort (slot indices), one per material kind
             HIP_CHECK(hipMalloc(&p, (size_t)WF_MAT_KINDS * n_slots * sizeof(uint32_t)));
             s->allocs.push_back(p); s->d_kind_queues = static_cast<uint32_t*>(p);
@@ -982,7 +993,7 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
 #define WF_ROUND(A, F) wf_round<A, F>(s, grid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qctl)
 #define WF_ROUND_F(A) do { if (s->feat == FEAT_NONE) WF_ROUND(A, FEAT_NONE); else if (s->feat == FEAT_MERL) WF_ROUND(A, FEAT_MERL); \
                           else if (s->feat == FEAT_SPEC) WF_ROUND(A, FEAT_SPEC); else if (s->feat == (FEAT_MERL | FEAT_SPEC)) WF_ROUND(A, FEAT_MERL | FEAT_SPEC); \
-                          else WF_ROUND(A, FEAT_ALL); } while (0)
+                          else if (s->feat == (FEAT_ALL | FEAT_TEX)) WF_ROUND(A, FEAT_ALL | FEAT_TEX); else WF_ROUND(A, FEAT_ALL); } while (0)
         if (s->animated) WF_ROUND_F(1);
         else WF_ROUND_F(0);
 #undef WF_ROUND_F
@@ -1047,7 +1058,7 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
                                             chunk_stride, spp, kf, rgbw_dev, s->d_counter, s->d_stats)
 #define PATH_TILES_F(A) do { if (s->feat == FEAT_NONE) PATH_TILES(A, FEAT_NONE); else if (s->feat == FEAT_MERL) PATH_TILES(A, FEAT_MERL); \
                              else if (s->feat == FEAT_SPEC) PATH_TILES(A, FEAT_SPEC); else if (s->feat == (FEAT_MERL | FEAT_SPEC)) PATH_TILES(A, FEAT_MERL | FEAT_SPEC); \
-                             else PATH_TILES(A, FEAT_ALL); } while (0)
+                             else if (s->feat == (FEAT_ALL | FEAT_TEX)) PATH_TILES(A, FEAT_ALL | FEAT_TEX); else PATH_TILES(A, FEAT_ALL); } while (0)
     if (s->animated) PATH_TILES_F(1);
     else PATH_TILES_F(0);
 #undef PATH_TILES_F

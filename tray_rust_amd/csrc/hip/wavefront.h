@@ -36,6 +36,7 @@ enum {
     F_WO, F_LINST = F_WO + 3, F_LI, F_WL = F_LI + 3, F_PDFL = F_WL + 3,
     F_AUX, F_DIRECT = F_AUX + 3, F_MISF = F_DIRECT + 3, F_TV = F_MISF + 3,
     F_TIME = F_TV + 3,   // ray.time of the path (moving scenes)
+    F_U, F_V,            // hit.dg.u / v of the vertex (scenes with image textures)
     F_COUNT
 };
 
@@ -56,11 +57,13 @@ TR_DEV void ld_bsdf(const DevScene& sc, const WfPool& p, uint32_t i, Bsdf& b) {
 
     b.mat = sc.materials + pu(p, F_MAT, i);
     b.merl_data = sc.merl_data;
+    if (sc.textures) { b.u = pf(p, F_U, i); b.v = pf(p, F_V, i); } else { b.u = 0.0f; b.v = 0.0f; }
 }
 TR_DEV void st_bsdf(const DevScene& sc, const WfPool& p, uint32_t i, const Bsdf& b) {
     st3(p, F_P, i, b.p); st3(p, F_N, i, b.n); st3(p, F_TAN, i, b.tan);
 
     pu(p, F_MAT, i) = (uint32_t)(b.mat - sc.materials);
+    if (sc.textures) { pf(p, F_U, i) = b.u; pf(p, F_V, i) = b.v; }
 }
 
 // ---- stage kernels --------------------------------------------------------------------------

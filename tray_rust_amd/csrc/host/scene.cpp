@@ -20,6 +20,7 @@
 #include "validate.hpp"
 #include "json.hpp"
 #include "linalg.hpp"
+#include "image.hpp"
 
 namespace trayh {
 
@@ -152,6 +153,10 @@ struct TrayHostScene {
     uint32_t min_depth = 0, max_depth = 0;
     std::vector<TrayMaterial> materials;
     std::map<std::string, uint32_t> material_names;
+    std::vector<TrayTexture> textures;          // image / animated_image / movie (scene.rs:317-394)
+    std::vector<TrayTexFrame> tex_frames;
+    std::vector<uint8_t> tex_data;
+    std::map<std::string, uint32_t> texture_names;
     std::vector<TrayMerlTable> merl_tables;
     std::vector<float> merl_data;
     std::vector<HostMesh> meshes;
@@ -457,19 +462,25 @@ static HostCamera load_camera(const Json& e) {   // scene.rs:251-293
 
 // ------------------------------------------------------------------ materials (scene.rs:404-511)
 
-static void color_param(const Json& m, const char* key, const std::string& name, const char* what, float out[4]) {
+// LoadedTextures::find_color / find_scalar (scene.rs:57-88): a string names a loaded texture, an array / a number is a constant
+static uint32_t find_texture(const TrayHostScene& s, const std::string& tex, const std::string& name, const char* key, const char* what) {
+    auto it = s.texture_names.find(tex);
+    if (it == s.texture_names.end()) fail(TRAY_E_INVALID, "Error loading material '" + name + "': Invalid color specified for " + key + " of " + what);
+    return it->second;
+}
+static void color_param(const TrayHostScene& s, const Json& m, const char* key, const std::string& name, const char* what, float out[4], uint32_t& tex) {
     const Json* v = m.get(key);
     if (!v) fail(TRAY_E_PARSE, std::string(key) + " color/texture name is required for " + what);
-    if (v->is_string())
-        fail(TRAY_E_UNSUPPORTED, "Error loading material '" + name + "': image textures are outside the hot-path scope (SURVEY 8f)");
+    tex = TRAY_NO_TEXTURE;
+    if (v->is_string()) { tex = find_texture(s, v->str, name, key, what); return; }
     if (!v->is_array()) fail(TRAY_E_PARSE, "Invalid JSON type for colorf texture");
     if (!load_color(*v, out)) fail(TRAY_E_PARSE, "Error loading material '" + name + "': Invalid color specified for " + key + " of " + what);
 }
-static float scalar_param(const Json& m, const char* key, const std::string& name, const char* what) {
+static float scalar_param(const TrayHostScene& s, const Json& m, const char* key, const std::string& name, const char* what, uint32_t& tex) {
     const Json* v = m.get(key);
     if (!v) fail(TRAY_E_PARSE, std::string(key) + " color/texture name is required for " + what);
-    if (v->is_string())
-        fail(TRAY_E_UNSUPPORTED, "Error loading material '" + name + "': image textures are outside the hot-path scope (SURVEY 8f)");
+    tex = TRAY_NO_TEXTURE;
+    if (v->is_string()) { tex = find_texture(s, v->str, name, key, what); return 0.0f; }
     if (!v->is_number()) fail(TRAY_E_PARSE, "Invalid JSON type for scalar texture");
     return (float)v->num;
 }
@@ -506,6 +517,69 @@ static uint32_t load_merl(TrayHostScene& s, const std::string& path) {   // mate
     return (uint32_t)s.merl_tables.size() - 1;
 }
 
+// load_textures (scene.rs:317-394)
+static void add_frame(TrayHostScene& s, const std::string& path, float time) {
+    ImageRGBA8 img;
+    std::string err;
+    if (!load_image(path, img, err)) fail(TRAY_E_IO, "Failed to load image file: " + err);
+    TrayTexFrame fr{};
+    fr.time = time; fr.width = img.width; fr.height = img.height; fr.offset = s.tex_data.size();
+    s.tex_data.insert(s.tex_data.end(), img.px.begin(), img.px.end());
+    s.tex_frames.push_back(fr);
+}
+static void load_textures(TrayHostScene& s, const Json& e, const std::string& base) {
+    if (!e.is_array()) fail(TRAY_E_PARSE, "The 'textures' must be an array of textures to load");
+    for (size_t i = 0; i < e.arr.size(); ++i) {
+        const Json& t = e.arr[i];
+        const Json* nm = t.get("name");
+        if (!nm) fail(TRAY_E_PARSE, "Error loading texture #" + std::to_string(i) + ": A name is required");
+        if (!nm->is_string()) fail(TRAY_E_PARSE, "Error loading texture #" + std::to_string(i) + ": name must be a string");
+        const std::string name = nm->str;
+        const Json* tyj = t.get("type");
+        if (!tyj) fail(TRAY_E_PARSE, "Error loading material '" + name + "': A texture type is required");
+        if (!tyj->is_string()) fail(TRAY_E_PARSE, "Error loading material '" + name + "': Texture type must be a string");
+        const std::string& ty = tyj->str;
+        if (s.texture_names.count(name)) fail(TRAY_E_INVALID, "Error loading texture '" + name + "': name conflicts with an existing entry");
+        TrayTexture tex{};
+        tex.first_frame = (uint32_t)s.tex_frames.size();
+        if (ty == "image") {
+            add_frame(s, join_path(base, need_str(t, "file", "Image textures must specify an image file", "Image file name must be a string")), 0.0f);
+        } else if (ty == "animated_image") {
+            const Json* kf = t.get("keyframes");
+            if (!kf) fail(TRAY_E_PARSE, "animated_image requires keyframes");
+            if (!kf->is_array()) fail(TRAY_E_PARSE, "animated_image keyframes must be an array");
+            if (kf->arr.size() < 2) fail(TRAY_E_INVALID, "animated_image must have at least 2 frames");
+            for (const Json& f : kf->arr) {
+                const std::string& file = need_str(f, "file", "Image textures must specify an image file", "Image file name must be a string");
+                const Json* tm = f.get("time");
+                if (!tm) fail(TRAY_E_PARSE, "animated_image keyframe requires time");
+                if (!tm->is_number()) fail(TRAY_E_PARSE, "animated_image keyframe time must be a number");
+                add_frame(s, join_path(base, file), (float)tm->num);
+            }
+        } else if (ty == "movie") {   // a generated animated_image: <prefix><frame, 5 digits><suffix> played back at `framerate`
+            const std::string& prefix = need_str(t, "file_prefix", "A file_prefix for movie is required", "file_prefix for movie must be a string");
+            const std::string& suffix = need_str(t, "file_suffix", "A file_suffix for movie is required", "file_suffix for movie must be a string");
+            const Json* fr = t.get("frames");
+            const Json* rate = t.get("framerate");
+            if (!fr) fail(TRAY_E_PARSE, "# of frames for movie texture is required");
+            if (!fr->is_number() || fr->num < 0 || fr->num != std::floor(fr->num)) fail(TRAY_E_PARSE, "frames for movie texture must be an int");
+            if (!rate) fail(TRAY_E_PARSE, "A framerate for movie is required");
+            if (!rate->is_number() || rate->num < 0 || rate->num != std::floor(rate->num)) fail(TRAY_E_PARSE, "framerate for movie must be an int");
+            if (fr->num < 2) fail(TRAY_E_INVALID, "assertion failed: frames.len() >= 2");   // AnimatedImage::new
+            for (uint64_t k = 0; k < (uint64_t)fr->num; ++k) {
+                char num[32];
+                std::snprintf(num, sizeof num, "%05llu", (unsigned long long)k);
+                add_frame(s, join_path(base, prefix + num + suffix), (float)k / (float)(uint64_t)rate->num);
+            }
+        } else {
+            fail(TRAY_E_PARSE, "Unrecognized texture type '" + ty + "' for texture '" + name + "'");
+        }
+        tex.n_frames = (uint32_t)s.tex_frames.size() - tex.first_frame;
+        s.texture_names[name] = (uint32_t)s.textures.size();
+        s.textures.push_back(tex);
+    }
+}
+
 static void load_materials(TrayHostScene& s, const Json& e, const std::string& base) {
     if (!e.is_array()) fail(TRAY_E_PARSE, "The materials must be an array of materials used");
     for (size_t i = 0; i < e.arr.size(); ++i) {
@@ -516,39 +590,40 @@ static void load_materials(TrayHostScene& s, const Json& e, const std::string& b
         const std::string& ty = need_str(m, "type", "a type is required", "type must be a string");
         if (s.material_names.count(name)) fail(TRAY_E_INVALID, "Error loading material '" + name + "': name conflicts with an existing entry");
         TrayMaterial mat{};
+        mat.tex_c0 = mat.tex_c1 = mat.tex_f0 = mat.tex_f1 = TRAY_NO_TEXTURE;
         if (ty == "glass") {
             mat.kind = TRAY_MAT_GLASS;
-            color_param(m, "reflect", name, "glass", mat.c0);
-            color_param(m, "transmit", name, "glass", mat.c1);
-            mat.f0 = scalar_param(m, "eta", name, "glass");
+            color_param(s, m, "reflect", name, "glass", mat.c0, mat.tex_c0);
+            color_param(s, m, "transmit", name, "glass", mat.c1, mat.tex_c1);
+            mat.f0 = scalar_param(s, m, "eta", name, "glass", mat.tex_f0);
         } else if (ty == "rough_glass") {
             mat.kind = TRAY_MAT_ROUGH_GLASS;
-            color_param(m, "reflect", name, "rough glass", mat.c0);
-            color_param(m, "transmit", name, "rough glass", mat.c1);
-            mat.f0 = scalar_param(m, "eta", name, "rough glass");
-            mat.f1 = scalar_param(m, "roughness", name, "rough glass");
+            color_param(s, m, "reflect", name, "rough glass", mat.c0, mat.tex_c0);
+            color_param(s, m, "transmit", name, "rough glass", mat.c1, mat.tex_c1);
+            mat.f0 = scalar_param(s, m, "eta", name, "rough glass", mat.tex_f0);
+            mat.f1 = scalar_param(s, m, "roughness", name, "rough glass", mat.tex_f1);
         } else if (ty == "matte") {
             mat.kind = TRAY_MAT_MATTE;
-            color_param(m, "diffuse", name, "matte", mat.c0);
-            mat.f0 = scalar_param(m, "roughness", name, "matte");
+            color_param(s, m, "diffuse", name, "matte", mat.c0, mat.tex_c0);
+            mat.f0 = scalar_param(s, m, "roughness", name, "matte", mat.tex_f0);
         } else if (ty == "merl") {
             mat.kind = TRAY_MAT_MERL;
             const std::string& file = need_str(m, "file", "A filename containing the MERL material data is required", "The MERL file must be a string");
             mat.table = load_merl(s, join_path(base, file));
         } else if (ty == "metal") {
             mat.kind = TRAY_MAT_METAL;
-            color_param(m, "refractive_index", name, "metal", mat.c0);
-            color_param(m, "absorption_coefficient", name, "metal", mat.c1);
-            mat.f0 = scalar_param(m, "roughness", name, "metal");
+            color_param(s, m, "refractive_index", name, "metal", mat.c0, mat.tex_c0);
+            color_param(s, m, "absorption_coefficient", name, "metal", mat.c1, mat.tex_c1);
+            mat.f0 = scalar_param(s, m, "roughness", name, "metal", mat.tex_f0);
         } else if (ty == "plastic") {
             mat.kind = TRAY_MAT_PLASTIC;
-            color_param(m, "diffuse", name, "plastic", mat.c0);
-            color_param(m, "gloss", name, "plastic", mat.c1);
-            mat.f0 = scalar_param(m, "roughness", name, "plastic");
+            color_param(s, m, "diffuse", name, "plastic", mat.c0, mat.tex_c0);
+            color_param(s, m, "gloss", name, "plastic", mat.c1, mat.tex_c1);
+            mat.f0 = scalar_param(s, m, "roughness", name, "plastic", mat.tex_f0);
         } else if (ty == "specular_metal") {
             mat.kind = TRAY_MAT_SPECULAR_METAL;
-            color_param(m, "refractive_index", name, "specular metal", mat.c0);
-            color_param(m, "absorption_coefficient", name, "specular metal", mat.c1);
+            color_param(s, m, "refractive_index", name, "specular metal", mat.c0, mat.tex_c0);
+            color_param(s, m, "absorption_coefficient", name, "specular metal", mat.c1, mat.tex_c1);
         } else {
             fail(TRAY_E_PARSE, "Error parsing material '" + name + "': unrecognized type '" + ty + "'");
         }
@@ -837,10 +912,7 @@ static TrayHostScene* load_scene(const std::string& text, const std::string& bas
     } else {
         fail(TRAY_E_PARSE, "Unrecognized integrator type '" + ity + "'");
     }
-    if (const Json* tex = data.get("textures")) {
-        if (!tex->is_array()) fail(TRAY_E_PARSE, "The 'textures' must be an array of textures to load");
-        if (!tex->arr.empty()) fail(TRAY_E_UNSUPPORTED, "image / animated_image / movie textures are outside the hot-path scope (SURVEY 8f)");
-    }
+    if (const Json* tex = data.get("textures")) load_textures(*s, *tex, base);
     load_materials(*s, need(data, "materials", "An array of materials is required"), base);
     load_objects(*s, need(data, "objects", "The scene must specify a list of objects"), base, s->instances);
     build_meshes(*s);
@@ -1028,6 +1100,9 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
     f.n_mesh_nodes = (uint32_t)s.f_mesh_nodes.size(); f.mesh_nodes = s.f_mesh_nodes.data();
     f.n_tris = (uint32_t)s.f_verts.size(); f.tri_verts = s.f_verts.data(); f.tri_attrs = s.f_attrs.data();
     f.n_materials = (uint32_t)s.materials.size(); f.materials = s.materials.data();
+    f.n_textures = (uint32_t)s.textures.size(); f.textures = s.textures.data();
+    f.n_tex_frames = (uint32_t)s.tex_frames.size(); f.tex_frames = s.tex_frames.data();
+    f.n_tex_bytes = s.tex_data.size(); f.tex_data = s.tex_data.data();
     f.n_merl = (uint32_t)s.merl_tables.size(); f.merl_tables = s.merl_tables.data();
     f.n_merl_floats = s.merl_data.size(); f.merl_data = s.merl_data.data();
     f.n_lights = (uint32_t)s.f_lights.size(); f.lights = s.f_lights.data();

@@ -59,10 +59,24 @@ inline std::string validate_flat_scene(const TrayFlatScene* f) {
         if (mt.n_theta_h == 0 || mt.n_theta_d == 0 || mt.n_phi_d == 0 || mt.offset > f->n_merl_floats || floats > f->n_merl_floats - mt.offset)
             return "MERL table " + std::to_string(t) + " lies outside merl_data";
     }
+    if (!need(f->textures, f->n_textures) || !need(f->tex_frames, f->n_tex_frames) || !need(f->tex_data, f->n_tex_bytes)) return "a texture array with a non-zero count is null";
+    for (uint32_t t = 0; t < f->n_textures; ++t) {
+        const TrayTexture& tx = f->textures[t];
+        if (tx.n_frames == 0 || (uint64_t)tx.first_frame + tx.n_frames > f->n_tex_frames) return "texture " + std::to_string(t) + " refers to frames outside tex_frames";
+        for (uint32_t k = 0; k < tx.n_frames; ++k) {
+            const TrayTexFrame& fr = f->tex_frames[tx.first_frame + k];
+            const uint64_t bytes = (uint64_t)fr.width * fr.height * 4u;
+            if (fr.width == 0 || fr.height == 0 || (fr.offset & 3u) || fr.offset > f->n_tex_bytes || bytes > f->n_tex_bytes - fr.offset)
+                return "texture " + std::to_string(t) + " has a frame outside tex_data";
+            if (k > 0 && !(fr.time >= f->tex_frames[tx.first_frame + k - 1].time)) return "texture " + std::to_string(t) + " has keyframe times that do not increase";
+        }
+    }
     for (uint32_t i = 0; i < f->n_materials; ++i) {
         const TrayMaterial& ma = f->materials[i];
         if (ma.kind > TRAY_MAT_MERL) return "material " + std::to_string(i) + " has an unknown kind";
         if (ma.kind == TRAY_MAT_MERL && ma.table >= f->n_merl) return "material references a missing MERL table";
+        for (uint32_t tex : {ma.tex_c0, ma.tex_c1, ma.tex_f0, ma.tex_f1})
+            if (tex != TRAY_NO_TEXTURE && tex >= f->n_textures) return "material " + std::to_string(i) + " references a missing texture";
     }
     // instances
     auto stack_in_range = [&](uint32_t first, uint32_t count) { return (uint64_t)first + count <= f->n_xf_levels; };

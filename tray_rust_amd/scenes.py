@@ -489,6 +489,76 @@ def write_tr15_like_assets(directory, film=(1920, 1080, 512), frames=600, scene_
     return write_scene(tr15_like(*film, frames=frames, scene_time=scene_time), os.path.join(directory, "tr15_like.json")), tris
 
 
+def write_png(path, pixels, width, height, channels):
+    """8-bit PNG writer (channels: 1 grey, 2 grey+alpha, 3 RGB, 4 RGBA; non-interlaced, filter 0): the image textures of
+    textured_box() and of the tests. `pixels` = bytes, row-major, top row first."""
+    import struct
+    import zlib
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[channels]
+    stride = width * channels
+    raw = b"".join(b"\x00" + bytes(pixels[y * stride:(y + 1) * stride]) for y in range(height))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, 8, ctype, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+    return path
+
+
+def textured_box(width=160, height=120, samples=16, scene_time=0.0, shutter_size=0.0):
+    """cornell_box with every kind of texture use of the reference (scene.rs:317-394, texture/*.rs): an RGB image as the diffuse colour of
+    the back wall and floor, a grey image as the roughness of the ceiling (sample_f32 reads the red channel), an RGBA image as
+    the gloss colour of the tall cube (a mesh: interpolated uv), an animated_image (two keyed frames, lerped at ray.time) on the
+    left wall and a movie (three numbered frames at 2 frames per second) on the right wall. write_textured_box() writes the images."""
+    d = cornell_box(width, height, samples)
+    if scene_time > 0.0:
+        d["film"].update({"frames": 2, "start_frame": 0, "end_frame": 1, "scene_time": scene_time})
+        d["camera"]["shutter_size"] = shutter_size
+    d["textures"] = [
+        {"name": "checker", "type": "image", "file": "textures/checker.png"},
+        {"name": "rough_map", "type": "image", "file": "textures/rough.png"},
+        {"name": "gloss_map", "type": "image", "file": "textures/gloss.png"},
+        {"name": "blink", "type": "animated_image", "keyframes": [{"file": "textures/blink_a.png", "time": 0.0},
+                                                                   {"file": "textures/blink_b.png", "time": max(scene_time, 1.0)}]},
+        {"name": "film_strip", "type": "movie", "file_prefix": "textures/strip_", "file_suffix": ".png", "frames": 3, "framerate": 2},
+    ]
+    d["materials"] += [
+        {"type": "matte", "name": "checker_wall", "diffuse": "checker", "roughness": 1.0},
+        {"type": "matte", "name": "rough_ceiling", "diffuse": [0.74, 0.74, 0.73], "roughness": "rough_map"},
+        {"type": "plastic", "name": "gloss_plastic", "diffuse": [0.6, 0.6, 0.7], "gloss": "gloss_map", "roughness": 0.3},
+        {"type": "matte", "name": "blink_wall", "diffuse": "blink", "roughness": 0.0},
+        {"type": "matte", "name": "strip_wall", "diffuse": "film_strip", "roughness": 1.0},
+    ]
+    walls = d["objects"][0]["objects"]
+    for w, m in zip(walls, ["checker_wall", "blink_wall", "strip_wall", "rough_ceiling", "checker_wall"]):
+        w["material"] = m
+    d["objects"][2]["material"] = "gloss_plastic"
+    return d
+
+
+def write_textured_box(directory, **kw):
+    import random
+    os.makedirs(os.path.join(directory, "models"), exist_ok=True)
+    os.makedirs(os.path.join(directory, "textures"), exist_ok=True)
+    with open(os.path.join(directory, "models", "cube.obj"), "w") as f:
+        f.write(cube_obj())
+    rnd = random.Random(5)
+    t = os.path.join(directory, "textures")
+    w, h = 16, 12
+    write_png(os.path.join(t, "checker.png"), bytes(v for y in range(h) for x in range(w)
+                                                    for v in ((200, 60, 40) if (x // 2 + y // 2) % 2 else (40 + 10 * x, 180, 220 - 12 * y))), w, h, 3)
+    write_png(os.path.join(t, "rough.png"), bytes((x * 13 + y * 7) % 256 if (x + y) % 5 else 0 for y in range(8) for x in range(8)), 8, 8, 1)   # zeros: Lambertian texels
+    write_png(os.path.join(t, "gloss.png"), bytes(v for y in range(6) for x in range(6)
+                                                  for v in ((0, 0, 0, 255) if (x + y) % 4 == 0 else (rnd.randrange(256), rnd.randrange(256), rnd.randrange(256), 128))), 6, 6, 4)
+    write_png(os.path.join(t, "blink_a.png"), bytes(v for y in range(4) for x in range(4) for v in (250 - 40 * x, 30 + 50 * y, 60)), 4, 4, 3)
+    write_png(os.path.join(t, "blink_b.png"), bytes(v for y in range(5) for x in range(3) for v in (20, 240 - 30 * y, 90 + 60 * x)), 3, 5, 3)   # frames may differ in size
+    for k in range(3):
+        write_png(os.path.join(t, "strip_%05d.png" % k), bytes(v for y in range(4) for x in range(8) for v in ((80 * k + 20 * x) % 256, 200 - 40 * k, (30 * y + 70 * k) % 256, 255)), 8, 4, 4)
+    return write_scene(textured_box(**kw), os.path.join(directory, "textured_box.json"))
+
+
 def write_scene(scene, path):
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
