@@ -171,7 +171,15 @@ typedef struct TrayMaterial {
     float c0[4];
     float c1[4];
     uint32_t tex_c0, tex_c1, tex_f0, tex_f1;   /* texture ids or TRAY_NO_TEXTURE */
+    uint32_t microfacet;   /* TRAY_MF_*: the MicrofacetDistribution of plastic / metal / rough_glass. The reference's materials
+                            * always build Beckmann (plastic.rs:83, metal.rs:63, rough_glass.rs:73); its GGX (bxdf/microfacet/
+                            * ggx.rs:20-57) is selected here by the scene-file extension key "microfacet": "ggx" */
+    uint32_t pad[3];
 } TrayMaterial;
+enum { TRAY_MF_BECKMANN = 0, TRAY_MF_GGX = 1 };
+/* Integrator (src/integrator): the Path tracer (path.rs) or NormalsDebug (normals_debug.rs:28-33: (bsdf.n + 1) / 2 of the
+ * camera ray's hit). Whitted (whitted.rs) is not built. */
+enum { TRAY_INTEGRATOR_PATH = 0, TRAY_INTEGRATOR_NORMALS_DEBUG = 1 };
 
 /* MERL table header: 90*90*180 RGB-interleaved f32, already scaled (material/merl.rs:60-82) */
 typedef struct TrayMerlTable {
@@ -229,6 +237,7 @@ typedef struct TrayFlatScene {
     uint32_t n_knots;       const float* knots;
     uint32_t n_color_keys;  const TrayColorKey* color_keys;
     uint32_t animated;      /* 1 if the camera, any instance transform or any emission varies over the open shutter */
+    uint32_t integrator;    /* TRAY_INTEGRATOR_* */
     uint32_t n_textures;    const TrayTexture* textures;
     uint32_t n_tex_frames;  const TrayTexFrame* tex_frames;
     uint64_t n_tex_bytes;   const uint8_t* tex_data;            /* RGBA8 texels of all frames */

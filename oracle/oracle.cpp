@@ -260,6 +260,11 @@ Colorf trace_sample(const SceneView& sv, uint32_t kf, uint32_t px, uint32_t py, 
     if (scene_intersect(sv, ray, hit)) {
         PathSamples ps;
         ps.init(key_sample(pix.kp, s), fs.max_depth + 1);
+        if (sv.fs->integrator == TRAY_INTEGRATOR_NORMALS_DEBUG) {   // NormalsDebug::illumination (integrator/normals_debug.rs:28-33)
+            if (sv.stats) sv.stats->vertices++;
+            const BSDF bsdf = material_bsdf(*sv.fs, hit);
+            return ((Colorf(bsdf.n.x, bsdf.n.y, bsdf.n.z) + Colorf::broadcast(1.0f)) / 2.0f).clamp();
+        }
         return path_illumination(sv, ray, hit, ps).clamp();   // quirk Q3
     }
     return Colorf::black();

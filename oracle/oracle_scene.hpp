@@ -515,11 +515,25 @@ struct Fresnel {
     }
 };
 
-// microfacet/beckmann.rs
+// microfacet/beckmann.rs, microfacet/ggx.rs: the two MicrofacetDistribution impls behind one value type (the reference holds a
+// `&MicrofacetDistribution`; its materials only ever construct Beckmann -- GGX is reachable here through the loader's
+// `"microfacet": "ggx"` extension key)
 struct Beckmann {
     float width;
-    static Beckmann make(float w) { return Beckmann{std::fmax(w, 0.000001f)}; }
+    bool ggx = false;
+    static Beckmann make(float w, bool ggx_ = false) { Beckmann m{std::fmax(w, 0.000001f)}; m.ggx = ggx_; return m; }
     float normal_distribution(Vec3 w_h) const {
+        if (ggx) {   // ggx.rs:27-36; powf(x, 2.0) / powf(x, 4.0) written as products like everywhere else in this file
+            if (cos_theta(w_h) > 0.0f) {
+                float width_sqr = width * width;
+                float c = cos_theta(w_h), c2 = c * c;
+                float t = tan_theta(w_h);
+                float s = width_sqr + t * t;
+                float denom = PI * (c2 * c2) * (s * s);
+                return width_sqr / denom;
+            }
+            return 0.0f;
+        }
         float tan_sqr = tan_theta_sqr(w_h);
         if (std::isinf(tan_sqr)) return 0.0f;
         float c2 = cos_theta_sqr(w_h);
@@ -527,9 +541,21 @@ struct Beckmann {
         return std::exp(-tan_sqr / width_sqr) / (PI * width_sqr * cos_theta_4);
     }
     Vec3 sample(float u0, float u1) const {
-        float log_sample = std::log(1.0f - u0);
-        if (std::isinf(log_sample)) log_sample = 0.0f;
-        float tan_theta_sqr = -(width * width) * log_sample;
+        float tan_theta_sqr;
+        if (ggx) {   // ggx.rs:37-43
+            float t = width * std::sqrt(u0) / std::sqrt(1.0f - u0);
+            tan_theta_sqr = t * t;
+        } else {
+            float log_sample = std::log(1.0f - u0);
+            if (std::isinf(log_sample)) log_sample = 0.0f;
+            tan_theta_sqr = -(width * width) * log_sample;
+        }
+        if (ggx) {
+            float cos_t = 1.0f / std::sqrt(1.0f + tan_theta_sqr);
+            float sin_t = std::sqrt(std::fmax(0.0f, 1.0f - cos_t * cos_t));
+            float phi = 2.0f * PI * u1;
+            return spherical_dir(sin_t, cos_t, phi);
+        }
         float phi = 2.0f * PI * u1;
         float cos_t = 1.0f / std::sqrt(1.0f + tan_theta_sqr);
         float sin_t = std::sqrt(std::fmax(0.0f, 1.0f - cos_t * cos_t));
@@ -537,6 +563,10 @@ struct Beckmann {
     }
     float pdf(Vec3 w_h) const { return std::fabs(w_h.z) * normal_distribution(w_h); }
     float monodir_shadowing(Vec3 v) const {
+        if (ggx) {   // ggx.rs:53-56
+            float t = width * std::fabs(tan_theta(v));
+            return 2.0f / (1.0f + std::sqrt(1.0f + t * t));
+        }
         float a = 1.0f / (width * std::fabs(tan_theta(v)));
         if (a < 1.6f) {
             float a_sqr = a * a;
@@ -887,7 +917,7 @@ inline BSDF material_bsdf(const TrayFlatScene& fs, const Hit& hit) {
             if (!c0.is_black()) { Lobe l{}; l.kind = LB_LAMBERTIAN; l.type = BX_DIFFUSE | BX_REFLECTION; l.color = c0; b.lobes[b.n_lobes++] = l; }
             if (!c1.is_black()) {
                 Lobe l{}; l.kind = LB_TORRANCE_SPARROW; l.type = BX_GLOSSY | BX_REFLECTION; l.color = c1;
-                l.fresnel = dielectric(1.0f, 1.5f); l.mf = Beckmann::make(m.f0);
+                l.fresnel = dielectric(1.0f, 1.5f); l.mf = Beckmann::make(m.f0, m.microfacet == TRAY_MF_GGX);
                 b.lobes[b.n_lobes++] = l;
             }
             b.eta = 1.0f;
@@ -895,7 +925,7 @@ inline BSDF material_bsdf(const TrayFlatScene& fs, const Hit& hit) {
         }
         case TRAY_MAT_METAL: {   // metal.rs:56-67
             Lobe l{}; l.kind = LB_TORRANCE_SPARROW; l.type = BX_GLOSSY | BX_REFLECTION; l.color = Colorf::broadcast(1.0f);
-            l.fresnel = conductor(c0, c1); l.mf = Beckmann::make(m.f0);
+            l.fresnel = conductor(c0, c1); l.mf = Beckmann::make(m.f0, m.microfacet == TRAY_MF_GGX);
             b.lobes[b.n_lobes++] = l;
             b.eta = 1.0f;
             break;
@@ -909,7 +939,7 @@ inline BSDF material_bsdf(const TrayFlatScene& fs, const Hit& hit) {
         }
         case TRAY_MAT_ROUGH_GLASS: {   // rough_glass.rs:57-85
             Fresnel fr = dielectric(1.0f, m.f0);
-            Beckmann mf = Beckmann::make(m.f1);
+            Beckmann mf = Beckmann::make(m.f1, m.microfacet == TRAY_MF_GGX);
             if (!c0.is_black()) { Lobe l{}; l.kind = LB_TORRANCE_SPARROW; l.type = BX_GLOSSY | BX_REFLECTION; l.color = c0; l.fresnel = fr; l.mf = mf; b.lobes[b.n_lobes++] = l; }
             if (!c1.is_black()) { Lobe l{}; l.kind = LB_MICROFACET_TRANS; l.type = BX_GLOSSY | BX_TRANSMISSION; l.color = c1; l.fresnel = fr; l.mf = mf; b.lobes[b.n_lobes++] = l; }
             b.eta = m.f0;

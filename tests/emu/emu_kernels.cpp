@@ -109,7 +109,7 @@ void make_scene(const TrayFlatScene* f, int wide_format, EmuScene& e) {
     d.xf_levels = f->xf_levels; d.keyframes = f->keyframes; d.knots = f->knots; d.color_keys = f->color_keys;
     d.xf_cache = nullptr; d.moving_ids = nullptr; d.n_moving = 0; d.xf_cache_lanes = 0;
     d.n_instances = f->n_instances; d.n_lights = f->n_lights; d.min_depth = f->min_depth; d.max_depth = f->max_depth;
-    d.width = f->film.width; d.height = f->film.height; d.frame = f->frame; d.film_rows = 0; d.coop_offset = 0;
+    d.width = f->film.width; d.height = f->film.height; d.frame = f->frame; d.film_rows = 0; d.coop_offset = 0; d.integrator = f->integrator;
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
     d.camera_p = &f->camera;
@@ -152,7 +152,7 @@ int feature_set(const EmuScene& e) {
             if (k == LB_MF_TRANS) feat |= FEAT_MF_TRANS;
             if (k == LB_SPEC_REFL_DIEL || k == LB_SPEC_REFL_COND || k == LB_SPEC_TRANS || k == LB_TS_COND) feat |= FEAT_SPEC;
         }
-    for (const DevMaterial& dm : e.mats) if (dm.textured) return FEAT_ALL | FEAT_TEX;
+    for (const DevMaterial& dm : e.mats) if (dm.textured || dm.microfacet == TRAY_MF_GGX) return FEAT_ALL | FEAT_TEX;
     return (feat & FEAT_MF_TRANS) ? FEAT_ALL : feat;
 }
 bool film_rows_ok(const TrayFlatScene* f) {

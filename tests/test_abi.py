@@ -30,7 +30,7 @@ def test_struct_sizes_match_header(built):
     assert C.sizeof(L.TrayTriVerts) == 48
     assert C.sizeof(L.TrayTriAttrs) == 64
     assert C.sizeof(L.TrayInstance) == 4 * 4 + 16 + 16 + 64 + 64 + 32
-    assert C.sizeof(L.TrayMaterial) == 64
+    assert C.sizeof(L.TrayMaterial) == 80
     assert C.sizeof(L.TrayRay) == 36
     assert C.sizeof(L.TrayHit) == 4 * 3 + 12 * 3 + 8 + 24
 

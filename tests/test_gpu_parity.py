@@ -83,7 +83,8 @@ def test_scene_intersect_is_bit_exact(name, tmp_path):
     assert (np.abs(a["dp_dv"][hit] - b["dp_dv"][hit]) / scale).max() <= 1e-5
 
 
-@pytest.mark.parametrize("kind", ["matte_lambert", "matte_oren", "plastic", "metal", "glass", "rough_glass", "specular_metal"])
+@pytest.mark.parametrize("kind", ["matte_lambert", "matte_oren", "plastic", "metal", "glass", "rough_glass", "specular_metal",
+                                  "plastic_ggx", "metal_ggx", "rough_glass_ggx"])
 def test_bsdf_eval_pdf_sample(kind, tmp_path):
     d = scenes.cornell_box(64, 64, 4)
     mats = {
@@ -95,7 +96,11 @@ def test_bsdf_eval_pdf_sample(kind, tmp_path):
         "rough_glass": {"type": "rough_glass", "reflect": [1, 1, 1], "transmit": [1, 1, 1], "eta": 1.5, "roughness": 0.3},
         "specular_metal": {"type": "specular_metal", "refractive_index": [0.2, 0.9, 1.1], "absorption_coefficient": [3.9, 2.4, 2.2]},
     }
+    ggx = kind.endswith("_ggx")   # bxdf/microfacet/ggx.rs through the loader's "microfacet" key
+    kind = kind[:-4] if ggx else kind
     m = dict(mats[kind]); m["name"] = "probe"
+    if ggx:
+        m["microfacet"] = "ggx"
     d["materials"].append(m)
     scene, *_ = load(d, tmp_path)
     flat = scene.flatten(0)
@@ -521,4 +526,24 @@ def test_image_textures(moving, tmp_path):
         r = rmse(gpu, cpu)
         print(f"textured_box{' (moving)' if moving else ''} 160x120x64 {mode}: RMSE {r:.3e}")
         assert r < 1e-4
+    scene.release_device()
+
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_normals_debug_integrator(name, tmp_path):
+    """integrator/normals_debug.rs:28-33 in both schedules"""
+    d = SCENES[name](160, 96, 16)
+    d["integrator"] = {"type": "normals_debug"}
+    scene, rt, _, fi = load(d, tmp_path)
+    cpu, st = O.render_tiles(scene.flatten(0), 16, seed=2)
+    for mode in ("mega", "wave"):
+        os.environ["TRAYHIP_MODE"] = mode
+        try:
+            scene.release_device()
+            gpu, tim = gpu_render(scene, rt, 16, fi, seed=2)
+        finally:
+            del os.environ["TRAYHIP_MODE"]
+        assert (tim.samples, tim.vertices, tim.rays) == (st.samples, st.vertices, st.rays)
+        assert rmse(gpu, cpu) < 1e-5
     scene.release_device()

@@ -245,3 +245,80 @@ def test_device_code_samples_textures_like_the_oracle(moving, tmp_path, built):
     if not moving:
         wimg, wst = E.render_wavefront(flat, tiles, spp, 6, trace=0)
         assert wst[:3] == (ost.samples, ost.vertices, ost.rays) and float(np.sqrt(np.mean((rgb(wimg) - rgb(ref)) ** 2))) < 2e-6
+
+
+# ---- NormalsDebug (integrator/normals_debug.rs) and GGX (bxdf/microfacet/ggx.rs) ----------------------------
+def test_normals_debug_integrator(tmp_path, built):
+    """(bsdf.n + 1) / 2 of the camera ray's hit: oracle vs closed form on a sphere, device source vs oracle (tile kernel, wavefront)"""
+    import _emu as E
+    w, h, spp = 32, 24, 4
+    scenes.write_assets(str(tmp_path))
+    for name, make in (("cornell_box", scenes.cornell_box), ("smallpt", scenes.smallpt)):
+        d = make(w, h, spp)
+        d["integrator"] = {"type": "normals_debug"}
+        p = os.path.join(str(tmp_path), name + "_nd.json")
+        json.dump(d, open(p, "w"))
+        scene, *_ = T.Scene.load_file(p)
+        flat = scene.flatten(0)
+        assert flat.contents.integrator == 1
+        rng = np.random.default_rng(2)
+        n = 3000
+        px = rng.integers(0, w, n).astype(np.uint32); py = rng.integers(0, h, n).astype(np.uint32); si = rng.integers(0, spp, n).astype(np.uint32)
+        a = O.sample_radiance(flat, px, py, si, spp, seed=3)
+        assert (a[:, 5] <= 1).all() and (a[:, 6] == 1).all()        # one vertex at most, one ray
+        hit = a[:, 5] == 1
+        assert (np.abs(np.linalg.norm(2 * a[hit, :3] - 1, axis=1) - 1) < 1e-5).all()   # a unit normal mapped to colour
+        assert a.tobytes() == E.sample_radiance(flat, px, py, si, spp, 3).tobytes()
+        tiles = np.array([(x, y) for y in range(h // 8) for x in range(w // 8)], np.uint32)
+        ref, ost = O.render_tiles(flat, spp, seed=3)
+        rgb = lambda i: i[..., :3] / np.maximum(i[..., 3:], 1e-20)
+        for img, st in (E.render_tiles(flat, tiles, spp, 3, blocks=2), E.render_wavefront(flat, tiles, spp, 3, trace=0)):
+            assert st[:3] == (ost.samples, ost.vertices, ost.rays) and float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6
+
+
+@pytest.mark.parametrize("kind", ["plastic", "metal", "rough_glass"])
+def test_ggx_microfacet_distribution(kind, tmp_path, built):
+    """bxdf/microfacet/ggx.rs through the loader's "microfacet": "ggx" key: closed-form checks of the oracle (D integrates to one over
+    projected solid angle; pdf = |cos| D) and the device source against the oracle, eval / pdf / sample of 20 000 direction pairs"""
+    import _emu as E
+    mats = {"plastic": {"type": "plastic", "diffuse": [0.8, 0.2, 0.2], "gloss": [0.6, 0.6, 0.6], "roughness": 0.3},
+            "metal": {"type": "metal", "refractive_index": [0.155265, 0.116723, 0.138381], "absorption_coefficient": [4.82835, 3.12225, 2.14696], "roughness": 0.2},
+            "rough_glass": {"type": "rough_glass", "reflect": [1, 1, 1], "transmit": [1, 1, 1], "eta": 1.5, "roughness": 0.3}}
+    d = scenes.cornell_box(16, 16, 4)
+    m = dict(mats[kind]); m["name"] = "probe"; m["microfacet"] = "ggx"
+    b = dict(mats[kind]); b["name"] = "probe_b"
+    d["materials"] += [m, b]
+    scenes.write_assets(str(tmp_path))
+    p = os.path.join(str(tmp_path), "g.json")
+    json.dump(d, open(p, "w"))
+    scene, *_ = T.Scene.load_file(p)
+    flat = scene.flatten(0)
+    n_mat = flat.contents.n_materials
+    assert flat.contents.materials[n_mat - 2].microfacet == 1 and flat.contents.materials[n_mat - 1].microfacet == 0
+    rng = np.random.default_rng(6)
+    n = 20000
+    dirs = rng.normal(size=(n, 6)).astype(np.float32)
+    dirs[:, :3] /= np.linalg.norm(dirs[:, :3], axis=1, keepdims=True); dirs[:, 3:] /= np.linalg.norm(dirs[:, 3:], axis=1, keepdims=True)
+    u3 = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    for flags in (0, 1):
+        g = O.bsdf(flat, n_mat - 2, flags, dirs, u3)
+        k = O.bsdf(flat, n_mat - 1, flags, dirs, u3)
+        assert not np.array_equal(g, k)                                    # GGX is not Beckmann
+        assert np.array_equal(g, E.bsdf(flat, n_mat - 2, flags, dirs, u3), equal_nan=True)   # device source == oracle, bit for bit
+    if kind == "metal":   # one lobe: the sampled half vector follows pdf(w_h) = |cos| D(w_h); check the normalisation of D numerically
+        width = 0.2
+        th = np.linspace(0, np.pi / 2, 200001)[:-1]
+        c, t = np.cos(th), np.tan(th)
+        D = width ** 2 / (np.pi * c ** 4 * (width ** 2 + t ** 2) ** 2)
+        assert abs(np.trapezoid(D * c * np.sin(th) * 2 * np.pi, th) - 1) < 1e-3
+
+
+def test_microfacet_key_errors(tmp_path, built):
+    d = scenes.cornell_box(16, 16, 4)
+    d["materials"][0]["microfacet"] = "ggx"      # matte has no microfacet distribution
+    scenes.write_assets(str(tmp_path))
+    p = os.path.join(str(tmp_path), "e.json")
+    json.dump(d, open(p, "w"))
+    with pytest.raises(T.TrayError) as e:
+        T.Scene.load_file(p)
+    assert e.value.code == L.TRAY_E_INVALID and "only plastic, metal and rough_glass" in e.value.message

@@ -62,7 +62,8 @@ class TrayColorKey(C.Structure):
 
 class TrayMaterial(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("table", C.c_uint32), ("f0", C.c_float), ("f1", C.c_float), ("c0", C.c_float * 4),
-                ("c1", C.c_float * 4), ("tex_c0", C.c_uint32), ("tex_c1", C.c_uint32), ("tex_f0", C.c_uint32), ("tex_f1", C.c_uint32)]
+                ("c1", C.c_float * 4), ("tex_c0", C.c_uint32), ("tex_c1", C.c_uint32), ("tex_f0", C.c_uint32), ("tex_f1", C.c_uint32),
+                ("microfacet", C.c_uint32), ("pad", C.c_uint32 * 3)]
 
 
 class TrayTexture(C.Structure):
@@ -113,7 +114,7 @@ class TrayFlatScene(C.Structure):
         ("n_keyframes", C.c_uint32), ("keyframes", _P(TrayKeyframe)),
         ("n_knots", C.c_uint32), ("knots", _P(C.c_float)),
         ("n_color_keys", C.c_uint32), ("color_keys", _P(TrayColorKey)), ("animated", C.c_uint32),
-        ("n_textures", C.c_uint32), ("textures", _P(TrayTexture)), ("n_tex_frames", C.c_uint32), ("tex_frames", _P(TrayTexFrame)),
+        ("integrator", C.c_uint32), ("n_textures", C.c_uint32), ("textures", _P(TrayTexture)), ("n_tex_frames", C.c_uint32), ("tex_frames", _P(TrayTexFrame)),
         ("n_tex_bytes", C.c_uint64), ("tex_data", _P(C.c_uint8)),
     ]
 

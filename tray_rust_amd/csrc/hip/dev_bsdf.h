@@ -106,6 +106,40 @@ TR_DEV float beckmann_g1(float width, f3 v) {
     return 1.0f;
 }
 
+// microfacet/ggx.rs:27-57 (powf(x, 2.0) / powf(x, 4.0) as products, like beckmann_d)
+TR_DEV float ggx_d(float width, f3 w_h) {
+    if (cos_theta(w_h) > 0.0f) {
+        float width_sqr = width * width;
+        float c = cos_theta(w_h), c2 = c * c;
+        float t = tan_theta(w_h);
+        float s = width_sqr + t * t;
+        float denom = kPi * (c2 * c2) * (s * s);
+        return width_sqr / denom;
+    }
+    return 0.0f;
+}
+TR_DEV f3 ggx_sample(float width, float u0, float u1) {
+    float t = width * sqrtf(u0) / sqrtf(1.0f - u0);
+    float tan_theta_sqr_v = t * t;
+    float cos_t = 1.0f / sqrtf(1.0f + tan_theta_sqr_v);
+    float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
+    float phi = 2.0f * kPi * u1;
+    return mk(sin_t * cosf(phi), sin_t * sinf(phi), cos_t);
+}
+TR_DEV float ggx_g1(float width, f3 v) {
+    float t = width * fabsf(tan_theta(v));
+    return 2.0f / (1.0f + sqrtf(1.0f + t * t));
+}
+// the lobe's MicrofacetDistribution: Beckmann (what every material of the reference builds) or GGX (DevLobe::ob != 0 on the
+// microfacet lobes; Oren-Nayar's B lives in the same field of its own lobe kind)
+// (compiled into the kernels built with FEAT_TEX only -- the instantiation for scenes that use the rarely needed extras: image
+// textures and GGX -- so that the common kernels carry neither the test nor the code)
+#define TR_GGX(FEAT, l) (((FEAT) & 8) != 0 && (l).ob != 0.0f)
+template <int FEAT> TR_DEV float mf_d(const Lobe& l, f3 w_h) { return TR_GGX(FEAT, l) ? ggx_d(l.width, w_h) : beckmann_d(l.width, w_h); }
+template <int FEAT> TR_DEV f3 mf_sample(const Lobe& l, float u0, float u1) { return TR_GGX(FEAT, l) ? ggx_sample(l.width, u0, u1) : beckmann_sample(l.width, u0, u1); }
+template <int FEAT> TR_DEV float mf_pdf(const Lobe& l, f3 w_h) { return fabsf(w_h.z) * mf_d<FEAT>(l, w_h); }
+template <int FEAT> TR_DEV float mf_g1(const Lobe& l, f3 v) { return TR_GGX(FEAT, l) ? ggx_g1(l.width, v) : beckmann_g1(l.width, v); }
+
 // microfacet_transmission.rs:34-60 with Dielectric(1, eta_t)
 TR_DEV void mt_eta(float eta_t, f3 w_o, float& e0, float& e1) {
     if (cos_theta(w_o) > 0.0f) { e0 = 1.0f; e1 = eta_t; } else { e0 = eta_t; e1 = 1.0f; }
@@ -198,11 +232,11 @@ TR_DEV f3 lobe_eval(const Bsdf& b, const Lobe& l, f3 w_o, f3 w_i) {
             f3 w_h = w_i + w_o;
             if (w_h.x == 0.0f && w_h.y == 0.0f && w_h.z == 0.0f) return mk(0.0f, 0.0f, 0.0f);
             w_h = normalized(w_h);
-            float d = beckmann_d(l.width, w_h);
+            float d = mf_d<FEAT>(l, w_h);
             f3 f;
             if (!(FEAT & FEAT_SPEC) || !LOBE_ON(LB_TS_COND) || (LOBE_ON(LB_TS_DIEL) && l.kind == LB_TS_DIEL)) { float fr = fresnel_dielectric(l.eta_t, dot(w_i, w_h)); f = mk(fr, fr, fr); }
             else f = fresnel_conductor(mk(b.mat->eta[0], b.mat->eta[1], b.mat->eta[2]), mk(b.mat->k[0], b.mat->k[1], b.mat->k[2]), dot(w_i, w_h));
-            float g = beckmann_g1(l.width, w_i) * beckmann_g1(l.width, w_o);
+            float g = mf_g1<FEAT>(l, w_i) * mf_g1<FEAT>(l, w_o);
             return l.color * f * d * g / (4.0f * cos_ti * cos_to);
         }
         case LB_MF_TRANS: {
@@ -213,9 +247,9 @@ TR_DEV f3 lobe_eval(const Bsdf& b, const Lobe& l, f3 w_o, f3 w_i) {
             float e0, e1;
             mt_eta(l.eta_t, w_o, e0, e1);
             f3 w_h = mt_half_vector(w_o, w_i, e0, e1);
-            float d = beckmann_d(l.width, w_h);
+            float d = mf_d<FEAT>(l, w_h);
             float fr = 1.0f - fresnel_dielectric(l.eta_t, dot(w_i, w_h));
-            float g = beckmann_g1(l.width, w_i) * beckmann_g1(l.width, w_o);
+            float g = mf_g1<FEAT>(l, w_i) * mf_g1<FEAT>(l, w_o);
             float wi_dot_h = dot(w_i, w_h);
             float jac = mt_jacobian(w_o, w_i, w_h, e0, e1);
             f3 f = mk(fr, fr, fr);
@@ -231,14 +265,14 @@ TR_DEV float lobe_pdf(const Lobe& l, f3 w_o, f3 w_i) {
         if (!same_hemisphere(w_o, w_i)) return 0.0f;
         f3 w_h = normalized(w_o + w_i);
         float jac = 1.0f / (4.0f * fabsf(dot(w_o, w_h)));
-        return beckmann_pdf(l.width, w_h) * jac;
+        return mf_pdf<FEAT>(l, w_h) * jac;
     }
     if ((FEAT & FEAT_MF_TRANS) && LOBE_ON(LB_MF_TRANS) && l.kind == LB_MF_TRANS) {
         if (same_hemisphere(w_o, w_i)) return 0.0f;
         float e0, e1;
         mt_eta(l.eta_t, w_o, e0, e1);
         f3 w_h = mt_half_vector(w_o, w_i, e0, e1);
-        return beckmann_pdf(l.width, w_h) * mt_jacobian(w_o, w_i, w_h, e0, e1);
+        return mf_pdf<FEAT>(l, w_h) * mt_jacobian(w_o, w_i, w_h, e0, e1);
     }
     return same_hemisphere(w_o, w_i) ? fabsf(cos_theta(w_i)) * kInvPi : 0.0f;   // bxdf/mod.rs:112-121
 }
@@ -279,7 +313,7 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
         case LB_TS_COND: {
             if (!LOBE_ON(LB_TS_DIEL) && !LOBE_ON(LB_TS_COND)) { w_i = zero; pdf = 0.0f; return zero; }
             if (w_o.z == 0.0f) { w_i = zero; pdf = 0.0f; return zero; }
-            f3 w_h = beckmann_sample(l.width, u0, u1);
+            f3 w_h = mf_sample<FEAT>(l, u0, u1);
             if (!same_hemisphere(w_o, w_h)) w_h = -w_h;
             w_i = reflect(w_o, w_h);
             if (!same_hemisphere(w_o, w_i)) { w_i = zero; pdf = 0.0f; return zero; }
@@ -288,7 +322,7 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
         }
         case LB_MF_TRANS: {
             if (!(FEAT & FEAT_MF_TRANS) || !LOBE_ON(LB_MF_TRANS)) { w_i = zero; pdf = 0.0f; return zero; }
-            f3 w_h = beckmann_sample(l.width, u0, u1);
+            f3 w_h = mf_sample<FEAT>(l, u0, u1);
             if (!same_hemisphere(w_o, w_h)) w_h = -w_h;
             float e0, e1;
             mt_eta(l.eta_t, w_o, e0, e1);
@@ -396,9 +430,9 @@ TR_DEV SampleHead bsdf_sample_head(const Bsdf& b, f3 wo_world, uint32_t flags, f
 // Whole BSDF::sample (used by the BSDF debug kernel; the tile kernel shares one eval / pdf site
 // between the light and the BSDF halves of estimate_direct and the path continuation, dev_integrator.h)
 TR_DEV f3 bsdf_sample(const Bsdf& b, f3 wo_world, uint32_t flags, float u0, float u1, float one_d, f3& wi_world, float& pdf_out, uint32_t& sampled_type) {
-    SampleHead h = bsdf_sample_head<FEAT_ALL>(b, wo_world, flags, u0, u1, one_d);
-    if (h.need_pdf) h.pdf = bsdf_pdf<FEAT_ALL>(b, wo_world, h.wi_world, flags);
-    if (h.need_eval) h.f = bsdf_eval<FEAT_ALL>(b, wo_world, h.wi_world, flags);
+    SampleHead h = bsdf_sample_head<FEAT_ALL | FEAT_TEX>(b, wo_world, flags, u0, u1, one_d);
+    if (h.need_pdf) h.pdf = bsdf_pdf<FEAT_ALL | FEAT_TEX>(b, wo_world, h.wi_world, flags);
+    if (h.need_eval) h.f = bsdf_eval<FEAT_ALL | FEAT_TEX>(b, wo_world, h.wi_world, flags);
     wi_world = h.wi_world; pdf_out = h.pdf; sampled_type = h.sampled_type;
     return h.f;
 }
@@ -424,7 +458,8 @@ TR_DEV Bsdf make_bsdf(const DevScene& sc, const Hit& hit) {
 #else
 #define TR_HD __host__ __device__ inline
 #endif
-TR_HD void lower_values(DevMaterial& d, uint32_t kind, const float* c0, const float* c1, float f0, float f1) {
+TR_HD void lower_values(DevMaterial& d, uint32_t kind, const float* c0, const float* c1, float f0, float f1, uint32_t microfacet = 0u) {
+    const float mfd = microfacet == TRAY_MF_GGX ? 1.0f : 0.0f;   // DevLobe::ob of a microfacet lobe: 0 = Beckmann, 1 = GGX
     d.n_lobes = 0u;
     const float white[3] = {1.0f, 1.0f, 1.0f};
 #define TR_ADD_LOBE(K, T, C, ETA, W, OB) do { DevLobe& l_ = d.lobe[d.n_lobes++]; l_.kind = (K); l_.type = (T); l_.color[0] = (C)[0]; l_.color[1] = (C)[1]; \
@@ -447,18 +482,18 @@ TR_HD void lower_values(DevMaterial& d, uint32_t kind, const float* c0, const fl
             break;
         case TRAY_MAT_PLASTIC:   // plastic.rs:59-88
             if (!TR_BLACK(c0)) TR_ADD_LOBE(LB_LAMBERTIAN, BX_DIFFUSE | BX_REFLECTION, c0, 1.0f, 0.0f, 0.0f);
-            if (!TR_BLACK(c1)) TR_ADD_LOBE(LB_TS_DIEL, BX_GLOSSY | BX_REFLECTION, c1, 1.5f, TR_BECKMANN(f0), 0.0f);
+            if (!TR_BLACK(c1)) TR_ADD_LOBE(LB_TS_DIEL, BX_GLOSSY | BX_REFLECTION, c1, 1.5f, TR_BECKMANN(f0), mfd);
             break;
         case TRAY_MAT_METAL:   // metal.rs:56-67
-            TR_ADD_LOBE(LB_TS_COND, BX_GLOSSY | BX_REFLECTION, white, 1.0f, TR_BECKMANN(f0), 0.0f);
+            TR_ADD_LOBE(LB_TS_COND, BX_GLOSSY | BX_REFLECTION, white, 1.0f, TR_BECKMANN(f0), mfd);
             break;
         case TRAY_MAT_GLASS:   // glass.rs:51-78
             if (!TR_BLACK(c0)) TR_ADD_LOBE(LB_SPEC_REFL_DIEL, BX_SPECULAR | BX_REFLECTION, c0, f0, 0.0f, 0.0f);
             if (!TR_BLACK(c1)) TR_ADD_LOBE(LB_SPEC_TRANS, BX_SPECULAR | BX_TRANSMISSION, c1, f0, 0.0f, 0.0f);
             break;
         case TRAY_MAT_ROUGH_GLASS:   // rough_glass.rs:57-85
-            if (!TR_BLACK(c0)) TR_ADD_LOBE(LB_TS_DIEL, BX_GLOSSY | BX_REFLECTION, c0, f0, TR_BECKMANN(f1), 0.0f);
-            if (!TR_BLACK(c1)) TR_ADD_LOBE(LB_MF_TRANS, BX_GLOSSY | BX_TRANSMISSION, c1, f0, TR_BECKMANN(f1), 0.0f);
+            if (!TR_BLACK(c0)) TR_ADD_LOBE(LB_TS_DIEL, BX_GLOSSY | BX_REFLECTION, c0, f0, TR_BECKMANN(f1), mfd);
+            if (!TR_BLACK(c1)) TR_ADD_LOBE(LB_MF_TRANS, BX_GLOSSY | BX_TRANSMISSION, c1, f0, TR_BECKMANN(f1), mfd);
             break;
         case TRAY_MAT_SPECULAR_METAL:   // specular_metal.rs:49-58
             TR_ADD_LOBE(LB_SPEC_REFL_COND, BX_SPECULAR | BX_REFLECTION, white, 1.0f, 0.0f, 0.0f);
@@ -475,7 +510,8 @@ TR_HD void lower_values(DevMaterial& d, uint32_t kind, const float* c0, const fl
 inline DevMaterial lower_material(const TrayMaterial& m, const TrayMerlTable* tables) {
     DevMaterial d;
     std::memset(&d, 0, sizeof d);
-    lower_values(d, m.kind, m.c0, m.c1, m.f0, m.f1);
+    lower_values(d, m.kind, m.c0, m.c1, m.f0, m.f1, m.microfacet);
+    d.microfacet = m.microfacet;
     if (m.kind == TRAY_MAT_MERL) d.merl_offset = tables ? tables[m.table].offset : 0;
     d.tex_c0 = m.tex_c0; d.tex_c1 = m.tex_c1; d.tex_f0 = m.tex_f0; d.tex_f1 = m.tex_f1;
     d.textured = (m.tex_c0 != TRAY_NO_TEXTURE || m.tex_c1 != TRAY_NO_TEXTURE || m.tex_f0 != TRAY_NO_TEXTURE || m.tex_f1 != TRAY_NO_TEXTURE) ? 1u : 0u;

@@ -40,7 +40,8 @@ struct DevMaterial {
     uint32_t textured;      // 1 => lobe[] / eta / k above are placeholders
     uint32_t tex_c0, tex_c1, tex_f0, tex_f1;
     float c0[3], c1[3], f0, f1;
-    uint32_t pad_tex[3];
+    uint32_t microfacet;    // TRAY_MF_*
+    uint32_t pad_tex[2];
 };
 
 struct DevScene {
@@ -69,6 +70,7 @@ struct DevScene {
     uint32_t n_moving, xf_cache_lanes;
     uint32_t n_instances, n_lights, min_depth, max_depth;
     uint32_t width, height, frame, film_rows;   // film_rows: 1 = row-binned film (separable, filter_h == 2)
+    uint32_t integrator, pad_integrator;        // TRAY_INTEGRATOR_*
     uint32_t coop_offset;   // word offset of the cooperative leaf test's LDS area behind the traversal stacks (0 = none)
     const float* __restrict__ wide_nodes;          // 4-wide collapse of every BVH<Triangle>, 32 floats per node (wavefront_wide.h); may be null
     const uint32_t* __restrict__ mesh_wide_root;   // per mesh: index of its root's wide node

@@ -168,6 +168,11 @@ TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counte
         }
     }
     ln.bsdf = make_bsdf(sc, hit);
+    if (sc.integrator == TRAY_INTEGRATOR_NORMALS_DEBUG) {   // NormalsDebug::illumination (integrator/normals_debug.rs:28-33): (bsdf.n + 1) / 2, the sample is done
+        ln.illum = (ln.bsdf.n + mk(1.0f, 1.0f, 1.0f)) / 2.0f;
+        ln.flags &= ~(LF_ALIVE | LF_SHADOW | LF_MIS);
+        return;
+    }
     ln.direct = mk(0.0f, 0.0f, 0.0f);
     ln.t_vertex = ln.throughput;
     ln.flags &= ~(LF_SHADOW | LF_MIS | LF_LAST);

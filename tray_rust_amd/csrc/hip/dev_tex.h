@@ -62,7 +62,7 @@ TR_DEV void resolve_textured(const DevScene& sc, const DevMaterial* __restrict__
     if (m->tex_c1 != TRAY_NO_TEXTURE) { const Rgba c = texture_sample(sc, m->tex_c1, u, v, time); c1[0] = c.r; c1[1] = c.g; c1[2] = c.b; }
     if (m->tex_f0 != TRAY_NO_TEXTURE) f0 = texture_sample(sc, m->tex_f0, u, v, time).r;
     if (m->tex_f1 != TRAY_NO_TEXTURE) f1 = texture_sample(sc, m->tex_f1, u, v, time).r;
-    lower_values(out, m->mat_kind, c0, c1, f0, f1);
+    lower_values(out, m->mat_kind, c0, c1, f0, f1, m->microfacet);
     out.merl_offset = m->merl_offset;
     out.textured = 0u;
 }

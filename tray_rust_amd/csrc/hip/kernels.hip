@@ -451,8 +451,8 @@ __global__ __launch_bounds__(64) void k_debug_bsdf(const DevScene scv, uint32_t 
     uint32_t flags = flags_sel == 0 ? BX_ALL : BX_NON_SPECULAR;
     f3 wo = mk(dirs[6 * i], dirs[6 * i + 1], dirs[6 * i + 2]), wi = mk(dirs[6 * i + 3], dirs[6 * i + 4], dirs[6 * i + 5]);
     float* o = out + (size_t)i * 12;
-    f3 e = bsdf_eval<FEAT_ALL>(b, wo, wi, flags);
-    o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = bsdf_pdf<FEAT_ALL>(b, wo, wi, flags);
+    f3 e = bsdf_eval<FEAT_ALL | FEAT_TEX>(b, wo, wi, flags);
+    o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = bsdf_pdf<FEAT_ALL | FEAT_TEX>(b, wo, wi, flags);
     f3 swi;
     float spdf;
     uint32_t st;
@@ -686,7 +686,8 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
             }
         s->feat = (feat & FEAT_MF_TRANS) ? FEAT_ALL : feat;
         if (getenv("TRAYHIP_FEAT_ALL")) s->feat = FEAT_ALL;
-        for (const DevMaterial& dm : mats) if (dm.textured) s->feat = FEAT_ALL | FEAT_TEX;   // lobes of textured materials are only known per hit
+        for (const DevMaterial& dm : mats)   // lobes of textured materials are only known per hit; GGX lives in the same instantiation
+            if (dm.textured || dm.microfacet == TRAY_MF_GGX) s->feat = FEAT_ALL | FEAT_TEX;
     }
     for (const DevMaterial& dm : mats) s->mat_kinds_present |= 1u << dm.mat_kind;
     if (f->n_textures) {
@@ -752,7 +753,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
     s->n_materials = f->n_materials;
     d.n_instances = f->n_instances; d.n_lights = f->n_lights; d.min_depth = f->min_depth; d.max_depth = f->max_depth;
-    d.width = f->film.width; d.height = f->film.height; d.frame = f->frame;
+    d.width = f->film.width; d.height = f->film.height; d.frame = f->frame; d.integrator = f->integrator;
     {   // row-binned film needs: separable table, filter_h == 2 (class = eighth of a pixel), consistent factors
         bool ok = f->film.separable != 0 && f->film.filter_h == 2.0f && f->film.inv_h == 0.5f && f->film.filter_pixel_h == 4;
         for (int y = 0; ok && y < TRAY_FILTER_TABLE_SIZE; ++y)

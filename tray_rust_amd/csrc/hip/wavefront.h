@@ -390,6 +390,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
         __syncthreads();
     }
     uint32_t kind = WF_MAT_KINDS;   // no vertex from this slot
+    bool counted = false;
     uint32_t flags = i < n_active ? pu(pool, F_FLAGS, i) : 0u;
     if ((flags & LF_ALIVE) && !(flags & WF_HIT_A)) {   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
         pu(pool, F_FLAGS, i) = (flags & ~(LF_ALIVE | WF_INVERTEX)) | WF_FINISHED;
@@ -407,6 +408,12 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
         cnt.rays = 0; cnt.vertices = 0;
         ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
         vertex_begin<ANIM>(sc, ln, rec, cnt);
+        counted = true;
+        if (!(ln.flags & LF_ALIVE)) {   // NormalsDebug: the sample ended at its first hit
+            pu(pool, F_FLAGS, i) = (ln.flags & ~WF_INVERTEX) | WF_FINISHED;
+            st3(pool, F_ILLUM, i, ln.illum);
+            flags = 0u;
+        } else {
         pu(pool, F_FLAGS, i) = ln.flags | WF_INVERTEX;
         st3(pool, F_ILLUM, i, ln.illum);
         if (ln.bounce == 0u) st3(pool, F_NG, i, ln.first_ng);
@@ -419,9 +426,10 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
         st3(pool, F_TV, i, ln.t_vertex);
         flags = ln.flags;
         kind = ln.bsdf.mat->mat_kind;
+        }
     } else flags = 0u;
     {   // one counter update per wave (all lanes of the wave are here: nobody has returned)
-        const unsigned long long m = __ballot(kind < WF_MAT_KINDS);
+        const unsigned long long m = __ballot(counted);
         if (m != 0ull && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u)
             atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].vertices, (unsigned long long)__popcll(m));
     }

@@ -150,7 +150,7 @@ struct TrayHostScene {
     float scene_time = 0;
     TrayFilm film{};
     std::vector<HostCamera> cameras;
-    uint32_t min_depth = 0, max_depth = 0;
+    uint32_t min_depth = 0, max_depth = 0, integrator = TRAY_INTEGRATOR_PATH;
     std::vector<TrayMaterial> materials;
     std::map<std::string, uint32_t> material_names;
     std::vector<TrayTexture> textures;          // image / animated_image / movie (scene.rs:317-394)
@@ -627,6 +627,12 @@ static void load_materials(TrayHostScene& s, const Json& e, const std::string& b
         } else {
             fail(TRAY_E_PARSE, "Error parsing material '" + name + "': unrecognized type '" + ty + "'");
         }
+        if (const Json* mf = m.get("microfacet")) {   // extension: the reference's materials always use Beckmann; its GGX (microfacet/ggx.rs) is selectable here
+            if (!mf->is_string() || (mf->str != "beckmann" && mf->str != "ggx")) fail(TRAY_E_PARSE, "Error loading material '" + name + "': microfacet must be \"beckmann\" or \"ggx\"");
+            if (mat.kind != TRAY_MAT_PLASTIC && mat.kind != TRAY_MAT_METAL && mat.kind != TRAY_MAT_ROUGH_GLASS)
+                fail(TRAY_E_INVALID, "Error loading material '" + name + "': only plastic, metal and rough_glass have a microfacet distribution");
+            mat.microfacet = mf->str == "ggx" ? TRAY_MF_GGX : TRAY_MF_BECKMANN;
+        }
         s.material_names[name] = (uint32_t)s.materials.size();
         s.materials.push_back(mat);
     }
@@ -907,8 +913,10 @@ static TrayHostScene* load_scene(const std::string& text, const std::string& bas
         s->min_depth = (uint32_t)need_u64(integ, "min_depth", "The integrator must specify the minimum ray depth", "min_depth must be a number");
         s->max_depth = (uint32_t)need_u64(integ, "max_depth", "The integrator must specify the maximum ray depth", "max_depth must be a number");
         if (s->max_depth > 15) fail(TRAY_E_UNSUPPORTED, "pathtracer max_depth > 15 is not supported by the device sampler (sample arrays hold <= 16 entries)");
-    } else if (ity == "whitted" || ity == "normals_debug") {
-        fail(TRAY_E_UNSUPPORTED, "integrator '" + ity + "' is outside the hot-path scope (SURVEY 8f); only 'pathtracer' is built");
+    } else if (ity == "normals_debug") {   // integrator/normals_debug.rs: no parameters
+        s->integrator = TRAY_INTEGRATOR_NORMALS_DEBUG;
+    } else if (ity == "whitted") {
+        fail(TRAY_E_UNSUPPORTED, "integrator 'whitted' is outside the hot-path scope (SURVEY 8f); 'pathtracer' and 'normals_debug' are built");
     } else {
         fail(TRAY_E_PARSE, "Unrecognized integrator type '" + ity + "'");
     }
@@ -972,6 +980,7 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
     f.abi_version = TRAY_ABI_VERSION;
     f.frame = frame;
     f.film = s.film;
+    f.integrator = s.integrator;
     f.min_depth = s.min_depth;
     f.max_depth = s.max_depth;
 
