@@ -295,6 +295,10 @@ void tray_scene_destroy(TrayDeviceScene* s);
  * Adds filtered samples into rgbw_dev: device pointer, width*height*4 f32, the layout of
  * RenderTarget::get_renderf32 (render_target.rs:243-266). Asynchronous on `stream`
  * (a hipStream_t; NULL = default stream). spp must already be a power of two. */
+/* tile_count == 0 selects the whole queue whatever tile_start is (BlockQueue::new, block_queue.rs:39-41).
+ * ONE render may be in flight per TrayDeviceScene: the tile counter, the statistics, the per-path transform cache, the wavefront
+ * pool and queues and the timing events belong to the handle. Calls on one handle must be serialised by the caller (the
+ * reference blocks inside Exec::render too, multithreaded.rs:54-70); use one handle per stream for concurrent renders. */
 int tray_render_tiles_device(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count,
                              uint32_t spp, uint64_t seed, float* rgbw_dev, void* stream);
 

@@ -179,6 +179,8 @@ def test_select_blocks_and_shards_sum_to_the_frame(tmp_path):
     assert np.allclose(a + b, whole, rtol=0, atol=1e-4 * whole.max())
     empty, _ = gpu_render(scene, rt, 16, fi, seed=5, select=(n, 5))   # skip past the end -> empty queue
     assert (empty == 0).all()
+    again, _ = gpu_render(scene, rt, 16, fi, seed=5, select=(37, 0))  # count 0 = the whole queue whatever the start (block_queue.rs:39-41)
+    assert np.allclose(again, whole, rtol=0, atol=1e-4 * whole.max())
     # round-robin shards (multi-GPU partition) through the device entry point
     import torch
     dev = scene.device_scene(0, 0)

@@ -84,15 +84,17 @@ struct Lane {
     uint32_t ks;           // sample key: scrambles and shuffle entries of the six LD arrays derive from it
     float time;            // ray.time of the camera ray, inherited by every ray of the path (path.rs:110, mod.rs:154)
     uint32_t col;          // the path's column of the transform cache (ANIM): thread id (tile kernel) or pool slot (wavefront)
-    f3 o, d;               // stage A ray: camera ray, or continuation from the previous vertex
-#define LN_O(ln) ((ln).o)
+    f3 d;                  // direction of the stage A ray; its origin is bsdf.p: the previous vertex, or the camera position parked there
+                           // until the first hit (three registers less across the whole step; bit-identical on the GPU since the
+                           // device code is built without the SLP vectoriser, Makefile)
+#define LN_O(ln) ((ln).bsdf.p)
     f3 throughput, illum;
     f3 first_ng;           // hit.dg.ng of the camera ray's hit (quirk Q1)
     Bsdf bsdf;             // shading context of the current vertex (BSDF::new)
     uint32_t light_inst;
-                      // follows it) never live at the same time
-    f3 li;
-    union { f3 wi_l; f3 mis_f; };
+    f3 li;                 // light sample (stage B)           | stage C: li = (|cos|, mis weight, pdf_bsdf)
+    union { f3 wi_l; f3 mis_f; };   // wi_l (written in vertex_begin, last read by the LIGHT query) and mis_f (f of the BSDF half, written by the
+                                    // MIS query, which follows it) never live at the same time
     float pdf_l;
     f3 aux_d;              // stage B: occlusion segment p_w - p | stage C: BSDF-sampled direction
     f3 direct;             // direct_light of estimate_direct
@@ -290,7 +292,6 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want, const f
         ln.throughput = ln.throughput / cont_prob;
     }
     if (ln.bounce == sc.max_depth) { ln.flags |= LF_LAST; return WANT_NONE; }
-    ln.o = ln.bsdf.p;
     ln.d = normalized(w_i);
     return WANT_NONE;
 }

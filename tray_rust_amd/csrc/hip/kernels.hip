@@ -571,11 +571,24 @@ static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 tgrid, dim3 block, hipS
     }
 }
 
-static uint32_t wf_slot_count(const TrayDeviceScene* s) {   // never more slots than the film has pixels x 4 (one chunk of 256 per tile)
+// Path pool slots of the wavefront schedule: never more than the film has pixels x 4 (one chunk of 256 per tile), and for moving
+// scenes never more than the per-path transform cache (n_moving x 96 B per slot) can hold within a quarter of the device's
+// free memory -- 64 moving instances at 8 M slots would be 51 GB, although a few hundred thousand slots already fill the chip
+static uint32_t wf_slot_count(const TrayDeviceScene* s) {
     uint32_t n_slots = WF_SLOTS;
     if (const char* e = getenv("TRAYHIP_WF_SLOTS")) n_slots = (uint32_t)std::max(256l, atol(e)) / TR_BLOCK * TR_BLOCK;
     const uint64_t by_tiles = (uint64_t)std::max<uint32_t>(s->n_tiles, 1u) * TR_BLOCK;
-    return (uint32_t)std::min<uint64_t>(n_slots, by_tiles);
+    uint64_t slots = std::min<uint64_t>(n_slots, by_tiles);
+    if (s->animated && s->deferred_n_moving > 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
+        uint64_t budget = free_b / 4;
+        if (const char* e = getenv("TRAYHIP_XF_CACHE_BYTES")) budget = (uint64_t)std::max(0ll, atoll(e));
+        const uint64_t per_slot = (uint64_t)s->deferred_n_moving * 24u * sizeof(float);
+        const uint64_t fit = budget / per_slot / TR_BLOCK * TR_BLOCK;
+        slots = std::min<uint64_t>(slots, std::max<uint64_t>(fit, (uint64_t)64 * TR_BLOCK));   // (at least 64 chunks: below that the schedule cannot fill the chip)
+    }
+    return (uint32_t)slots;
 }
 
 extern "C" {
@@ -897,9 +910,14 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         const uint32_t* d_ids = nullptr;
         if (upload(s, ids.data(), ids.size(), &d_ids) != TRAY_OK) { tray_scene_destroy(s); return TRAY_E_NOMEM; }
         const uint32_t lanes = s->wavefront ? wf_slot_count(s) : (uint32_t)s->n_blocks * TR_BLOCK;   // one column per pool slot / per thread
+        const uint32_t n_moving_for_msg = s->deferred_n_moving;
         void* cache = nullptr;
-        if (hipMalloc(&cache, (size_t)s->deferred_n_moving * 24u * lanes * sizeof(float)) != hipSuccess) {
-            tray_scene_destroy(s); set_error("hipMalloc of the transform cache failed"); return TRAY_E_NOMEM;
+        const size_t cache_bytes = (size_t)s->deferred_n_moving * 24u * lanes * sizeof(float);
+        if (hipMalloc(&cache, cache_bytes) != hipSuccess) {
+            tray_scene_destroy(s);
+            set_error("hipMalloc of the per-path transform cache failed: " + std::to_string(cache_bytes >> 20) + " MiB for " + std::to_string(n_moving_for_msg) +
+                      " moving instances x " + std::to_string(lanes) + " paths (TRAYHIP_WF_SLOTS / TRAYHIP_XF_CACHE_BYTES bound it)");
+            return TRAY_E_NOMEM;
         }
         s->allocs.push_back(cache);
         s->dev.xf_cache = static_cast<float*>(cache);
@@ -920,7 +938,7 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
                             uint32_t spp, uint32_t kf, float* rgbw_dev, hipStream_t stream) {
     if (!s->wf_ready) {
         if (s->pool.data) { set_error("the wavefront buffers of this scene could not be allocated by an earlier call"); return TRAY_E_NOMEM; }
-        uint32_t n_slots = wf_slot_count(s);
+        uint32_t n_slots = (s->animated && s->dev.xf_cache_lanes) ? s->dev.xf_cache_lanes : wf_slot_count(s);   // (the transform cache was sized at creation)
         s->n_chunks = n_slots / TR_BLOCK;
         void* p = nullptr;
         HIP_CHECK(hipMalloc(&p, (size_t)F_COUNT * n_slots * sizeof(float)));
@@ -1017,8 +1035,9 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
 int tray_render_tiles_device(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t spp, uint64_t seed,
                              float* rgbw_dev, void* stream_) {
     if (!s || !rgbw_dev) { set_error("tray_render_tiles_device: null argument"); return TRAY_E_INVALID; }
+    if (tile_count == 0) { tile_start = 0; tile_count = s->n_tiles; }          // BlockQueue::new ignores `start` when count == 0 (block_queue.rs:39-41), like tray_block_queue
     if (tile_start > s->n_tiles) tile_start = s->n_tiles;                       // skip(start).take(count)
-    if (tile_count == 0 || tile_count > s->n_tiles - tile_start) tile_count = s->n_tiles - tile_start;
+    if (tile_count > s->n_tiles - tile_start) tile_count = s->n_tiles - tile_start;
     return launch_tiles(s, tile_start, tile_count, tile_count ? tile_count : 1, 1, spp, seed, rgbw_dev, stream_);
 }
 

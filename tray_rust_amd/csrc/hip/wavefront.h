@@ -456,7 +456,6 @@ TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, ui
     ln.aux_d = mk(0.0f, 0.0f, 0.0f); ln.mis_f = mk(0.0f, 0.0f, 0.0f);   // (before wi_l is loaded: the two share storage)
     ln.li = ld3(pool, F_LI, i); ln.wi_l = ld3(pool, F_WL, i); ln.pdf_l = pf(pool, F_PDFL, i);
     ln.direct = ld3(pool, F_DIRECT, i);
-    ln.o = mk(0.0f, 0.0f, 0.0f);
     ln.d = -ld3(pool, F_WO, i);   // (-d is the outgoing direction until the PATH query replaces d)
     ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
     vertex_queries<ANIM, FEAT, KM>(sc, ln, (flags & WF_OCCLUDED) != 0u);
