@@ -377,14 +377,6 @@ int tray_debug_sample_radiance(TrayDeviceScene* s, uint32_t n, const uint32_t* p
 int tray_debug_bsdf(TrayDeviceScene* s, uint32_t material_id, uint32_t flags, uint32_t n,
                     const float* dirs, const float* u3, float* out);
 
-/* Host only (no GPU): the packed 4-wide nodes the library derives from BVH<Triangle> of mesh `mesh` for the wide wavefront
- * traversal (csrc/host/wide_nodes.hpp; bvh.rs:81-130 is what they must reproduce). quantised = 0: 32 words per node, exact
- * boxes; 1: 16 words per node, 8-bit boxes rounded outwards. Writes min(*n_words, capacity) words to `words` (may be NULL
- * with capacity 0 to query the size), the total to *n_words and the root's wide node to *root (0xffffffff: the mesh's
- * root is a leaf, there is no wide node). Exists so that the CPU tests can traverse exactly what the device will read. */
-int tray_debug_wide_nodes(const TrayFlatScene* flat, uint32_t mesh, int quantised, uint32_t* words, uint64_t capacity,
-                          uint64_t* n_words, uint32_t* root);
-
 const char* tray_last_error(void);
 const char* tray_version(void);
 

@@ -13,55 +13,8 @@
 #include "../include/trayhip.h"
 #include "oracle_math.hpp"
 #include "oracle_scene.hpp"
-#include "proto_wide_bvh.hpp"
 
 using namespace orc;
-
-// ---- design prototype hook (proto_wide_bvh.hpp): Mesh::intersect through the 4-wide collapse, or through the binary tree with
-// fetch counters, so that the two can be compared on the same rays
-namespace orc {
-bool proto_mesh_intersect(const SceneView& sv, const TrayMesh& m, Ray& ray, Hit& h) {
-    const TrayFlatScene& fs = *sv.fs;
-    bool any = false;
-    auto leaf = [&](uint32_t first, uint32_t count) {
-        for (uint32_t k = 0; k < count; ++k) {
-            uint32_t slot = m.tri_offset + first + k;
-            Hit cand;
-            if (triangle_intersect(fs.tri_verts[slot], fs.tri_attrs[slot], ray, cand)) { h = cand; h.prim = slot; any = true; }
-        }
-    };
-    const TrayBvhNode* tree = fs.mesh_nodes + m.node_offset;
-    if ((sv.flags & ORC_PROTO_WIDE) && sv.packed) {
-        const size_t mi = (size_t)(&m - fs.meshes);
-        packed_traverse(tree, sv.packed->words + sv.packed->mesh_first[mi], sv.packed->quantised, sv.packed->mesh_root[mi], ray, leaf, sv.proto);
-    } else if (sv.flags & ORC_PROTO_WIDE) {
-        wide_traverse(tree, sv.wide[&m - fs.meshes], ray, leaf, sv.proto);
-    } else {   // bvh_traverse with counters
-        Vec3 inv_dir(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-        int neg_dir[3] = {ray.d.x < 0.0f, ray.d.y < 0.0f, ray.d.z < 0.0f};
-        uint32_t stack[64];
-        int sp = 0;
-        uint32_t current = 0;
-        for (;;) {
-            const TrayBvhNode& node = tree[current];
-            sv.proto->binary_fetches++;
-            if (bbox_fast_intersect(node, ray, inv_dir, neg_dir)) {
-                if (node.count > 0) {
-                    sv.proto->binary_fetches++; sv.proto->leaf_visits_binary++;   // the leaf's triangle records
-                    leaf(node.offset, (uint32_t)node.count);
-                    if (sp == 0) break;
-                    current = stack[--sp];
-                } else if (neg_dir[node.axis]) { stack[sp++] = current + 1; current = node.offset; }
-                else { stack[sp++] = node.offset; current = current + 1; }
-            } else {
-                if (sp == 0) break;
-                current = stack[--sp];
-            }
-        }
-    }
-    return any;
-}
-}  // namespace orc
 
 namespace {
 
@@ -464,76 +417,6 @@ int oracle_path_profile(const TrayFlatScene* fs, uint32_t n, const uint32_t* px,
     return 0;
 }
 
-// Design prototype (proto_wide_bvh.hpp): the same rays through binary BVH<Triangle> traversal and through its 4-wide collapse.
-// hits_binary / hits_wide get the full hit records; counters = {binary node+leaf fetches, wide node+leaf fetches, binary leaf
-// visits, wide leaf visits}.
-int oracle_proto_wide_bvh(const TrayFlatScene* fs, uint32_t n, const TrayRay* rays, TrayHit* hits_binary, TrayHit* hits_wide, unsigned long long* counters,
-                          int qbits) {   // qbits > 0: the wide pass uses slot boxes quantised to that many bits per coordinate
-    if (!fs || !rays || !hits_binary || !hits_wide || !counters) return -1;
-    std::vector<WideBvh> wide(fs->n_meshes);
-    for (uint32_t m = 0; m < fs->n_meshes; ++m) {
-        const TrayBvhNode* tree = fs->mesh_nodes + fs->meshes[m].node_offset;
-        if (tree[0].count == 0) wide_build(tree, 0, wide[m]);
-        if (qbits > 0) quantise_wide(wide[m], qbits);
-    }
-    ProtoCounters pc;
-    for (int pass = 0; pass < 2; ++pass) {
-        SceneView sv{fs, pass ? ORC_PROTO_WIDE : 0, nullptr};
-        sv.wide = wide.data(); sv.proto = &pc;
-        TrayHit* hits = pass ? hits_wide : hits_binary;
-        for (uint32_t i = 0; i < n; ++i) {
-            Ray r;
-            r.o = Vec3(rays[i].o[0], rays[i].o[1], rays[i].o[2]);
-            r.d = Vec3(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
-            r.min_t = rays[i].min_t; r.max_t = rays[i].max_t; r.time = rays[i].time;
-            Hit h;
-            TrayHit& o = hits[i];
-            std::memset(&o, 0, sizeof o);
-            if (scene_intersect(sv, r, h)) {
-                o.t = r.max_t; o.inst = h.inst; o.prim = h.prim;
-                for (int k = 0; k < 3; ++k) { o.p[k] = h.p[k]; o.n[k] = h.n[k]; o.ng[k] = h.ng[k]; o.dp_du[k] = h.dp_du[k]; o.dp_dv[k] = h.dp_dv[k]; }
-                o.u = h.u; o.v = h.v;
-            } else {
-                o.t = r.max_t; o.inst = 0xffffffffu;
-            }
-        }
-    }
-    counters[0] = pc.binary_fetches; counters[1] = pc.wide_fetches; counters[2] = pc.leaf_visits_binary; counters[3] = pc.leaf_visits_wide;
-    return 0;
-}
-
-// The same comparison with the wide pass walking the PRODUCT's packed nodes (tray_debug_wide_nodes) the way the device kernel does
-int oracle_proto_packed_wide(const TrayFlatScene* fs, uint32_t n, const TrayRay* rays, TrayHit* hits_binary, TrayHit* hits_wide, unsigned long long* counters,
-                             const uint32_t* words, const uint64_t* mesh_first, const uint32_t* mesh_root, int quantised) {
-    if (!fs || !rays || !hits_binary || !hits_wide || !counters || !words || !mesh_first || !mesh_root) return -1;
-    PackedWide pk{words, mesh_first, mesh_root, quantised};
-    ProtoCounters pc;
-    for (int pass = 0; pass < 2; ++pass) {
-        SceneView sv{fs, pass ? ORC_PROTO_WIDE : 0, nullptr};
-        sv.proto = &pc; sv.packed = pass ? &pk : nullptr;
-        TrayHit* hits = pass ? hits_wide : hits_binary;
-        for (uint32_t i = 0; i < n; ++i) {
-            Ray r;
-            r.o = Vec3(rays[i].o[0], rays[i].o[1], rays[i].o[2]);
-            r.d = Vec3(rays[i].d[0], rays[i].d[1], rays[i].d[2]);
-            r.min_t = rays[i].min_t; r.max_t = rays[i].max_t; r.time = rays[i].time;
-            Hit h;
-            TrayHit& o = hits[i];
-            std::memset(&o, 0, sizeof o);
-            if (scene_intersect(sv, r, h)) {
-                o.t = r.max_t; o.inst = h.inst; o.prim = h.prim;
-                for (int k = 0; k < 3; ++k) { o.p[k] = h.p[k]; o.n[k] = h.n[k]; o.ng[k] = h.ng[k]; o.dp_du[k] = h.dp_du[k]; o.dp_dv[k] = h.dp_dv[k]; }
-                o.u = h.u; o.v = h.v;
-            } else {
-                o.t = r.max_t; o.inst = 0xffffffffu;
-            }
-        }
-    }
-    counters[0] = pc.binary_fetches; counters[1] = pc.wide_fetches; counters[2] = pc.leaf_visits_binary; counters[3] = pc.leaf_visits_wide;
-    return 0;
-}
-
-// Camera::generate_ray for n raster positions: in xy[2i..], time[i] -> rays
 int oracle_camera_rays(const TrayFlatScene* fs, uint32_t n, const float* xy, const float* time, TrayRay* rays) {
     if (!fs || !xy || !rays) return -1;
     SceneView sv{fs, 0, nullptr};

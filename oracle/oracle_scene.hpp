@@ -10,10 +10,7 @@
 
 namespace orc {
 
-enum { ORC_FAITHFUL_XF = 1, ORC_BRUTE_FORCE = 2, ORC_PROTO_WIDE = 4 };   // ORC_PROTO_WIDE: proto_wide_bvh.hpp (design prototype)
-struct WideBvh;
-struct ProtoCounters;
-struct PackedWide;
+enum { ORC_FAITHFUL_XF = 1, ORC_BRUTE_FORCE = 2 };
 
 struct Stats { uint64_t samples = 0, vertices = 0, rays = 0; };
 
@@ -241,9 +238,6 @@ struct SceneView {
     const TrayFlatScene* fs;
     int flags;
     Stats* stats;
-    const WideBvh* wide = nullptr;       // per mesh, ORC_PROTO_WIDE only
-    ProtoCounters* proto = nullptr;
-    const PackedWide* packed = nullptr;  // the product's packed wide nodes (tray_debug_wide_nodes), ORC_PROTO_WIDE only
     // AnimatedTransform::transform (animated_transform.rs:40-56) from the TRS keyframes of the spline stack
     Transform stack_transform(uint32_t xf_first, uint32_t xf_count, float time) const {
         Transform t = Transform::identity();
@@ -275,11 +269,9 @@ struct SceneView {
     }
 };
 
-bool proto_mesh_intersect(const SceneView& sv, const TrayMesh& m, Ray& ray, Hit& h);   // oracle.cpp, design prototype only
 
 // Mesh::intersect (mesh.rs:82-84)
 inline bool mesh_intersect(const SceneView& sv, const TrayMesh& m, Ray& ray, Hit& h) {
-    if (sv.proto) return proto_mesh_intersect(sv, m, ray, h);
     const TrayFlatScene& fs = *sv.fs;
     bool any = false;
     auto leaf = [&](uint32_t first, uint32_t count) {

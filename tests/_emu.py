@@ -23,21 +23,21 @@ def _target(defines):
     so = os.path.join(EMU_DIR, "libtrayemu" + "".join("_" + d.lower() for d in defines).replace("_tr_", "_") + ".so")
     deps = [os.path.join(EMU_DIR, f) for f in ("emu_kernels.cpp", "hip_emu.h")]
     deps += [os.path.join(HIP_DIR, f) for f in os.listdir(HIP_DIR) if f.endswith((".h", ".hip"))]
-    deps += [os.path.join(ROOT, "tray_rust_amd", "csrc", "host", "wide_nodes.hpp"), os.path.join(ROOT, "tray_rust_amd", "csrc", "host", "gates.hpp"), os.path.join(ROOT, "include", "trayhip.h")]
+    deps += [os.path.join(ROOT, "tray_rust_amd", "csrc", "host", "gates.hpp"), os.path.join(ROOT, "include", "trayhip.h")]
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-attributes", "-shared", "-o", so,
            os.path.join(EMU_DIR, "emu_kernels.cpp")] + ["-D" + d for d in defines]
     return so, deps, cmd
 
 
-def _norm(qwide, defines):
-    return tuple(sorted(set(defines) | ({"TR_QWIDE"} if qwide else set())))
+def _norm(defines):
+    return tuple(sorted(set(defines)))
 
 
 def prebuild(define_sets):
     """compile the stale ones of several builds side by side (each takes ~25 s; the suite uses five)"""
     procs = []
     for defines in define_sets:
-        so, deps, cmd = _target(_norm(False, defines))
+        so, deps, cmd = _target(_norm(defines))
         if _stale(so, deps):
             procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, p in procs:
@@ -45,10 +45,9 @@ def prebuild(define_sets):
             raise RuntimeError("host emulation build failed: " + " ".join(cmd))
 
 
-def emu(qwide=False, defines=()):
-    """libtrayemu.so (exact 128-B wide nodes), libtrayemu_qwide.so (-DTR_QWIDE: the staged 64-B quantised nodes), or a build with
-    other staged variant macros, e.g. defines=("TR_MESH_TWO_CHILDREN",)"""
-    defines = _norm(qwide, defines)
+def emu(defines=()):
+    """libtrayemu.so, or a build of the same sources with extra macros (defines=("TR_...",))"""
+    defines = _norm(defines)
     key = defines
     if key not in _libs:
         so, deps, cmd = _target(defines)
@@ -56,11 +55,10 @@ def emu(qwide=False, defines=()):
             subprocess.run(cmd, check=True)
         h = C.CDLL(so)
         FS = C.POINTER(L.TrayFlatScene)
-        h.emu_is_qwide.restype = C.c_int
         h.emu_debug_intersect.restype = C.c_int
         h.emu_debug_intersect.argtypes = [FS, C.c_uint32, C.c_void_p, C.c_void_p]
         h.emu_wf_trace.restype = C.c_int
-        h.emu_wf_trace.argtypes = [FS, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6
+        h.emu_wf_trace.argtypes = [FS, C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6
         h.emu_debug_sample_radiance.restype = C.c_int
         h.emu_debug_sample_radiance.argtypes = [FS, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
         h.emu_debug_bsdf.restype = C.c_int
@@ -70,7 +68,6 @@ def emu(qwide=False, defines=()):
         h.emu_render_wavefront.restype = C.c_int
         h.emu_render_wavefront.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         h.emu_retraced.restype = C.c_uint
-        assert h.emu_is_qwide() == int("TR_QWIDE" in defines)
         _libs[key] = h
     return _libs[key]
 
@@ -87,13 +84,13 @@ def debug_intersect(flat, rays, hit_dtype):
     return hits
 
 
-def wf_trace(flat, rays, kernel, stage, lds_depth=0, blocks=3, qwide=False):
-    """kernel 0 = k_wf_trace_dyn, 1 = k_wf_trace_wide; returns (hit, t, inst, prim)"""
+def wf_trace(flat, rays, stage, lds_depth=0, blocks=3):
+    """k_wf_trace_dyn, stage 0 / 1 / 2 = A / B / C; returns (hit, t, inst, prim)"""
     rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 9)
     n = len(rays)
     hit = np.zeros(n, np.uint32); t = np.zeros(n, np.float32); inst = np.zeros(n, np.uint32); prim = np.zeros(n, np.uint32)
     b1 = np.zeros(n, np.float32); b2 = np.zeros(n, np.float32)
-    rc = emu(qwide).emu_wf_trace(flat, kernel, stage, n, rays.ctypes.data, lds_depth, blocks, hit.ctypes.data, t.ctypes.data,
+    rc = emu().emu_wf_trace(flat, stage, n, rays.ctypes.data, lds_depth, blocks, hit.ctypes.data, t.ctypes.data,
                                  inst.ctypes.data, prim.ctypes.data, b1.ctypes.data, b2.ctypes.data)
     assert rc == 0, rc
     return hit.astype(bool), t, inst, prim
@@ -124,13 +121,13 @@ def render_tiles(flat, tiles_xy, spp, seed, blocks=1, coop=-1, film_rows=-1, def
     return img, tuple(int(x) for x in stats)
 
 
-def render_wavefront(flat, tiles_xy, spp, seed, trace=0, n_chunks=4, trace_blocks=2, lds_depth=0, qwide=False, defines=()):
+def render_wavefront(flat, tiles_xy, spp, seed, trace=0, n_chunks=4, trace_blocks=2, lds_depth=0, defines=()):
     """the wavefront schedule (7 stage kernels per round) as SIMT emulations; returns (rgbw image, (samples, vertices, rays, rounds))"""
     fs = flat.contents
     tiles_xy = np.ascontiguousarray(tiles_xy, np.uint32).reshape(-1, 2)
     img = np.zeros((fs.film.height, fs.film.width, 4), np.float32)
     stats = np.zeros(4, np.uint64)
-    rc = emu(qwide, defines).emu_render_wavefront(flat, tiles_xy.ctypes.data, len(tiles_xy), spp, seed, img.ctypes.data, trace, n_chunks, trace_blocks,
+    rc = emu(defines).emu_render_wavefront(flat, tiles_xy.ctypes.data, len(tiles_xy), spp, seed, img.ctypes.data, trace, n_chunks, trace_blocks,
                                          lds_depth, stats.ctypes.data)
     assert rc == 0, f"emu_render_wavefront: {rc}"
     return img, tuple(int(x) for x in stats)

@@ -76,7 +76,6 @@ uint32_t g_retraced = 0;   // accumulated over the calls of this process; read a
 struct EmuScene {
     DevScene d{};
     std::vector<DevMaterial> mats;
-    std::vector<uint32_t> wide_words, wide_roots;
     std::vector<tray::FlatLeaf> flat_leaves;
     std::vector<tray::FlatInst> flat_insts;
     std::vector<uint8_t> tri_leaf;
@@ -97,7 +96,7 @@ uint32_t bvh_depth(const TrayBvhNode* nodes, uint32_t n) {
     return best;
 }
 
-void make_scene(const TrayFlatScene* f, int wide_format, EmuScene& e) {
+void make_scene(const TrayFlatScene* f, EmuScene& e) {
     DevScene& d = e.d;
     d.instances = f->instances; d.top_nodes = f->top_nodes; d.top_order = f->top_order; d.meshes = f->meshes;
     d.mesh_nodes = f->mesh_nodes; d.tri_verts = f->tri_verts; d.tri_attrs = f->tri_attrs;
@@ -119,24 +118,6 @@ void make_scene(const TrayFlatScene* f, int wide_format, EmuScene& e) {
     uint32_t mesh_depth = 0;
     for (uint32_t m = 0; m < f->n_meshes; ++m) mesh_depth = std::max(mesh_depth, bvh_depth(f->mesh_nodes + f->meshes[m].node_offset, f->meshes[m].node_count));
     e.depth = mesh_depth + bvh_depth(f->top_nodes, f->n_top_nodes) + 8u;
-    e.wide_roots.assign(f->n_meshes, 0xffffffffu);
-    if (wide_format) {
-        for (uint32_t m = 0; m < f->n_meshes; ++m) {
-            const TrayBvhNode* tree = f->mesh_nodes + f->meshes[m].node_offset;
-            if (!f->meshes[m].node_count || tree[0].count != 0) continue;
-#ifdef TR_QWIDE
-            e.wide_roots[m] = tray::build_qwide_nodes(tree, 0u, e.wide_words);
-#else
-            std::vector<float> tmp(e.wide_words.size());
-            std::memcpy(tmp.data(), e.wide_words.data(), tmp.size() * 4);
-            e.wide_roots[m] = tray::build_wide_nodes(tree, 0u, tmp);
-            e.wide_words.resize(tmp.size());
-            std::memcpy(e.wide_words.data(), tmp.data(), tmp.size() * 4);
-#endif
-        }
-        d.wide_nodes = reinterpret_cast<const float*>(e.wide_words.data());
-        d.mesh_wide_root = e.wide_roots.data();
-    }
 }
 
 using hip_emu::launch;
@@ -173,18 +154,10 @@ uint32_t key_frame_host(uint64_t seed, uint32_t frame) {   // as launch_tiles co
 
 extern "C" {
 
-int emu_is_qwide(void) {
-#ifdef TR_QWIDE
-    return 1;
-#else
-    return 0;
-#endif
-}
-
 // k_debug_intersect<0> on n rays (what tray_debug_intersect launches)
 int emu_debug_intersect(const TrayFlatScene* f, uint32_t n, const TrayRay* rays, TrayHit* hits) {
     EmuScene e;
-    make_scene(f, 0, e);
+    make_scene(f, e);
     launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_intersect<0>(e.d, n, rays, hits); });
     return 0;
 }
@@ -194,7 +167,7 @@ int emu_debug_intersect(const TrayFlatScene* f, uint32_t n, const TrayRay* rays,
 int emu_debug_sample_radiance(const TrayFlatScene* f, uint32_t n, const uint32_t* px, const uint32_t* py, const uint32_t* si, uint32_t spp,
                               uint64_t seed, float* out) {
     EmuScene e;
-    make_scene(f, 0, e);
+    make_scene(f, e);
     const uint32_t kf = key_frame_host(seed, e.d.frame);
     bool moving = f->camera.animated != 0;
     for (uint32_t t_ = 0; t_ < f->n_textures; ++t_) moving = moving || f->textures[t_].n_frames >= 2u;   // animated_image needs ray.time (tray_scene_create)
@@ -207,7 +180,7 @@ int emu_debug_sample_radiance(const TrayFlatScene* f, uint32_t n, const uint32_t
 // Debugging aid: the loop of k_debug_sample_radiance<0> for ONE sample with the lane state printed after every vertex
 int emu_trace_sample(const TrayFlatScene* f, uint32_t px, uint32_t py, uint32_t si, uint32_t spp, uint64_t seed) {
     EmuScene e;
-    make_scene(f, 0, e);
+    make_scene(f, e);
     const uint32_t kf = key_frame_host(seed, e.d.frame);
     hip_emu::launch(1, 1, [&] {
         const DevScene& sc = e.d;
@@ -252,7 +225,7 @@ int emu_trace_sample(const TrayFlatScene* f, uint32_t px, uint32_t py, uint32_t 
 int emu_debug_bsdf(const TrayFlatScene* f, uint32_t material_id, uint32_t flags, uint32_t n, const float* dirs, const float* u3, float* out) {
     if (material_id >= f->n_materials) return -1;
     EmuScene e;
-    make_scene(f, 0, e);
+    make_scene(f, e);
     TrayInstance fake;
     std::memset(&fake, 0, sizeof fake);
     fake.material_id = material_id;
@@ -262,13 +235,13 @@ int emu_debug_bsdf(const TrayFlatScene* f, uint32_t material_id, uint32_t flags,
 }
 
 // One stage of the wavefront traversal over n rays, through the pool fields and the queue the stage kernels use:
-//   kernel 0 = k_wf_trace_dyn, 1 = k_wf_trace_wide (the node format this file was compiled for); stage 0 = A (closest hit from
+//   k_wf_trace_dyn; stage 0 = A (closest hit from
 //   F_O / F_D), 1 = B (any hit on the segment F_P + t F_AUX, t in (0.001, 0.999)), 2 = C (closest hit from F_P along F_AUX).
 // lds_depth < full depth exercises the HBM overflow part of the stacks. Output per ray: hit flag, t, inst, prim, b1, b2.
-int emu_wf_trace(const TrayFlatScene* f, int kernel, int stage, uint32_t n, const TrayRay* rays, uint32_t lds_depth, uint32_t blocks,
+int emu_wf_trace(const TrayFlatScene* f, int stage, uint32_t n, const TrayRay* rays, uint32_t lds_depth, uint32_t blocks,
                  uint32_t* hit, float* t, uint32_t* inst, uint32_t* prim, float* b1, float* b2) {
     EmuScene e;
-    make_scene(f, kernel == 1, e);
+    make_scene(f, e);
     const uint32_t n_slots = (n + TR_BLOCK - 1) / TR_BLOCK * TR_BLOCK;
     std::vector<float> pool_data((size_t)F_COUNT * n_slots, 0.0f);
     WfPool pool{pool_data.data(), n_slots};
@@ -282,14 +255,13 @@ int emu_wf_trace(const TrayFlatScene* f, int kernel, int stage, uint32_t n, cons
         pu(pool, F_FLAGS, s) = LF_ALIVE;
     }
     qctl[stage] = n;
-    const uint32_t full = kernel == 1 ? 2u * e.depth + 8u : e.depth;
+    const uint32_t full = e.depth;
     if (lds_depth == 0 || lds_depth > full) lds_depth = full;
     std::vector<uint32_t> overflow((size_t)(8u * e.depth + 64u) * blocks * TR_BLOCK, 0u);
     std::vector<DevStats> stats(WF_STAT_SLOTS);
     std::memset(stats.data(), 0, stats.size() * sizeof(DevStats));
 #define EMU_TRACE(K, S) launch(blocks, TR_BLOCK, [&] { K<S, 0>(e.d, pool, queue.data(), qctl.data(), stats.data(), lds_depth, overflow.data()); })
-    if (kernel == 0) { if (stage == 0) EMU_TRACE(k_wf_trace_dyn, 0); else if (stage == 1) EMU_TRACE(k_wf_trace_dyn, 1); else EMU_TRACE(k_wf_trace_dyn, 2); }
-    else { if (stage == 0) EMU_TRACE(k_wf_trace_wide, 0); else if (stage == 1) EMU_TRACE(k_wf_trace_wide, 1); else EMU_TRACE(k_wf_trace_wide, 2); }
+    if (stage == 0) EMU_TRACE(k_wf_trace_dyn, 0); else if (stage == 1) EMU_TRACE(k_wf_trace_dyn, 1); else EMU_TRACE(k_wf_trace_dyn, 2);
 #undef EMU_TRACE
     for (uint32_t s = 0; s < n; ++s) {
         const uint32_t fl = pu(pool, F_FLAGS, s);
@@ -309,7 +281,7 @@ int emu_wf_trace(const TrayFlatScene* f, int kernel, int stage, uint32_t n, cons
 int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t tile_count, uint32_t spp, uint64_t seed, float* rgbw,
                      uint32_t blocks, int coop, int film_rows, unsigned long long* stats_out, uint32_t shard, uint32_t n_shards, uint32_t chunk_tiles) {
     EmuScene e;
-    make_scene(f, 0, e);
+    make_scene(f, e);
     bool moving = f->camera.animated != 0;
     for (uint32_t t_ = 0; t_ < f->n_textures; ++t_) moving = moving || f->textures[t_].n_frames >= 2u;   // animated_image needs ray.time (tray_scene_create)
     for (uint32_t i = 0; i < f->n_instances; ++i) moving = moving || f->instances[i].animated != 0 || f->instances[i].emis_count >= 2;
@@ -364,13 +336,13 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
 
 // The wavefront schedule (launch_wavefront + wf_round of kernels.hip): rounds of k_wf_advance -> k_wf_regen -> trace A ->
 // k_wf_begin -> trace B -> k_wf_query -> trace C over an HBM-style path pool until every tile is done. All kernels run as SIMT
-// emulations. trace: 0 = k_wf_trace_dyn (default of the library), 1 = k_wf_trace_wide (node format of this build), 2 = k_wf_trace
+// emulations. trace: 0 = k_wf_trace_dyn (default of the library), 2 = k_wf_trace
 // (one thread per slot, TRAYHIP_WF_TRACE=slot). Moving scenes run the ANIM = 1 kernels with the per-slot transform cache.
 // n_chunks = 256-slot chunks of the pool (<= tile_count); lds_depth as in emu_wf_trace.
 int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t tile_count, uint32_t spp, uint64_t seed, float* rgbw,
                          int trace, uint32_t n_chunks, uint32_t trace_blocks, uint32_t lds_depth, unsigned long long* stats_out) {
     EmuScene e;
-    make_scene(f, trace == 1, e);
+    make_scene(f, e);
     bool moving = f->camera.animated != 0;
     for (uint32_t t_ = 0; t_ < f->n_textures; ++t_) moving = moving || f->textures[t_].n_frames >= 2u;   // animated_image needs ray.time (tray_scene_create)
     uint32_t n_moving = 0;
@@ -401,7 +373,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     std::vector<uint2> tiles(tile_count);
     for (uint32_t i = 0; i < tile_count; ++i) tiles[i] = make_uint2(tiles_xy[2 * i], tiles_xy[2 * i + 1]);
     const uint32_t kf = key_frame_host(seed, e.d.frame);
-    const uint32_t full = trace == 1 ? 2u * e.depth + 8u : e.depth;
+    const uint32_t full = e.depth;
     if (lds_depth == 0 || lds_depth > full) lds_depth = full;
     trace_blocks = std::max(1u, std::min(trace_blocks, n_chunks));
     std::vector<uint32_t> overflow((size_t)(8u * e.depth + 64u) * trace_blocks * TR_BLOCK, 0u);
@@ -434,7 +406,6 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
 #define EMU_TRACE_STAGE(S, A, Q)                                                                                                            \
     do {                                                                                                                                    \
         if (trace == 0) EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data()); }, dyn_lds); \
-        else if (trace == 1) EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_wide<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data()); }, dyn_lds); \
         else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_trace<S, A>(e.d, pool, n_active, stats.data()); }, slot_lds);                             \
     } while (0)
 #define EMU_ROUND_F(A)                                                                                                                      \

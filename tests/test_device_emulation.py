@@ -1,9 +1,7 @@
 """The DEVICE source, compiled for the host (tests/emu: g++ behind a shim, one-lane waves), against the oracle -- no GPU needed.
 Covers what is per-lane in the device code: Scene::intersect as k_debug_intersect runs it (flat instance loop or two-level
-traversal, primitive tests, hit finishing) and the wavefront traversal kernels k_wf_trace_dyn / k_wf_trace_wide in all three
-stages, with the stacks split between LDS and the HBM overflow column, through the pool fields and queues the stage kernels
-use. k_wf_trace_wide is checked in both node formats: the exact 128-B nodes of the shipped library and the 64-B quantised
-nodes staged behind -DTR_QWIDE (Next / C5) -- the variant's device code has not run on a GPU yet, this is its check.
+traversal, primitive tests, hit finishing) and the wavefront traversal kernel k_wf_trace_dyn in all three stages, with the
+stacks split between LDS and the HBM overflow column, through the pool fields and queues the stage kernels use.
 Same libm on both sides here, so the records are compared bit for bit."""
 import numpy as np
 import pytest
@@ -12,14 +10,18 @@ import tray_rust_amd as T
 from tray_rust_amd import scenes
 import _emu as E
 import _oracle as O
-from test_proto_wide_bvh import mixed_rays
 
 BOX = ([-14, 1, -18], [14, 23, 19])
 
 
-@pytest.fixture(scope="module", autouse=True)
-def emulation_builds(built):
-    E.prebuild([(), ("TR_QWIDE",)])
+def mixed_rays(flat, rng, n, width, height, lo, hi, centre, spread):
+    """n camera rays + n rays from inside the scene's box, half of them segments (max_t 0.999), half unbounded and normalised"""
+    cam = O.camera_rays(flat, rng.uniform(0, [width, height], (n, 2)))
+    o = rng.uniform(lo, hi, (n, 3)); d = rng.normal(centre, spread, (n, 3)) - o
+    seg = rng.uniform(0, 1, n) < 0.5
+    d[~seg] /= np.linalg.norm(d[~seg], axis=1, keepdims=True)
+    inner = np.concatenate([o, d, np.full((n, 1), 0.001), np.where(seg, 0.999, np.inf)[:, None], np.zeros((n, 1))], axis=1).astype(np.float32)
+    return np.concatenate([cam, inner])
 
 
 
@@ -84,29 +86,21 @@ def check_stage(flat, rays, stage, got):
 
 
 @pytest.mark.parametrize("stage", [0, 1, 2])
-@pytest.mark.parametrize("kernel,qwide", [(0, False), (1, False), (1, True)], ids=["dyn", "wide-exact", "wide-quantised"])
-def test_wavefront_traversal_kernels_on_a_mesh_scene(dragon, kernel, qwide, stage):
+def test_wavefront_traversal_kernel_on_a_mesh_scene(dragon, stage):
     flat = dragon[1]
     rays = rays_for(flat, 10 + stage, 12000, stage, [8.5, 3.7, 1.5], 4.0)
     for lds_depth in (0, 3):    # everything in LDS / almost everything in the HBM overflow column
-        got = E.wf_trace(flat, rays, kernel, stage, lds_depth=lds_depth, qwide=qwide)
-        if qwide:   # a superset of the visits: a candidate the exact box culls by rounding may be accepted (none expected)
-            ref = O.intersect(flat, rays)
-            differ = int(((got[0] != (ref["inst"] != 0xffffffff))).sum())
-            assert differ <= 1
-            if differ:
-                continue
+        got = E.wf_trace(flat, rays, stage, lds_depth=lds_depth)
         frac = check_stage(flat, rays, stage, got)
         assert 0.05 < frac <= 1.0
 
 
 @pytest.mark.parametrize("stage", [0, 1])
-@pytest.mark.parametrize("kernel,qwide", [(0, False), (1, False), (1, True)], ids=["dyn", "wide-exact", "wide-quantised"])
-def test_wavefront_traversal_kernels_behind_bvh_of_instances(tr15, kernel, qwide, stage):
+def test_wavefront_traversal_kernel_behind_bvh_of_instances(tr15, stage):
     flat = tr15[1]
     assert flat.contents.n_instances > 16
     rays = rays_for(flat, 20 + stage, 8000, stage, [0, 5, 0], 10.0)
-    got = E.wf_trace(flat, rays, kernel, stage, lds_depth=4, qwide=qwide)
+    got = E.wf_trace(flat, rays, stage, lds_depth=4)
     check_stage(flat, rays, stage, got)
 
 
@@ -239,14 +233,13 @@ def tr15_dir(tmp_path_factory):
     return pathlib.Path(str(d))
 
 
-WF_CASES = [("cornell_box", 0, 0, False), ("cornell_box", 0, 2, False), ("moving_box", 3, 0, False), ("moving_box", 3, 2, False),
-            ("tr15_like", 330, 0, False), ("tr15_like", 330, 1, False), ("tr15_like", 330, 1, True)]
+WF_CASES = [("cornell_box", 0, 0), ("cornell_box", 0, 2), ("moving_box", 3, 0), ("moving_box", 3, 2), ("tr15_like", 330, 0)]
 
 
-@pytest.mark.parametrize("name,frame,trace,qwide", WF_CASES, ids=[f"{n}-{['dyn', 'wide', 'slot'][t]}{'-quantised' if q else ''}" for n, _, t, q in WF_CASES])
-def test_wavefront_schedule_emulated_as_simt(name, frame, trace, qwide, tmp_path, tr15_dir, built):
+@pytest.mark.parametrize("name,frame,trace", WF_CASES, ids=[f"{n}-{['dyn', '', 'slot'][t]}" for n, _, t in WF_CASES])
+def test_wavefront_schedule_emulated_as_simt(name, frame, trace, tmp_path, tr15_dir, built):
     """The whole wavefront schedule -- k_wf_advance (film row bins, tile switch), k_wf_regen (camera samples, the per-path transform
-    cache of moving scenes), the three traversal kernels in each of their forms, k_wf_begin, k_wf_query, ray queues -- round
+    cache of moving scenes), the three traversal stages in both of their forms, k_wf_begin, k_wf_query, ray queues -- round
     after round until every tile is done, as fibers on the host: the oracle's samples, vertices, rays and image."""
     w, h, spp = 32, 24, 8
     d = str(tmp_path)
@@ -259,7 +252,7 @@ def test_wavefront_schedule_emulated_as_simt(name, frame, trace, qwide, tmp_path
     scene, *_ = T.Scene.load_file(str(tmp_path / (name + ".json")))
     flat = scene.flatten(frame)
     img, (samples, vertices, rays, rounds) = E.render_wavefront(flat, tile_queue(w, h), spp, 5, trace=trace, n_chunks=5, trace_blocks=2,
-                                                                lds_depth=0 if trace == 2 else 4, qwide=qwide)
+                                                                lds_depth=0 if trace == 2 else 4)
     ref, st = O.render_tiles(flat, spp, seed=5)
     assert samples == st.samples == w * h * spp
     moving = bool(flat.contents.animated)

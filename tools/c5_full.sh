@@ -1,6 +1,6 @@
 #!/bin/bash
 # C5 stand-in at FULL detail (59 instances, 3.1 M triangles), frame 330, 1080p at a reduced sample count: per-kernel time of the
-# wavefront schedule (rocprofv3 --kernel-trace --stats) for the default library and, if built, the quantised wide-node variant.
+# wavefront schedule (rocprofv3 --kernel-trace --stats) with and without the material sort.
 #   gpurun --timeout 600 -- 'bash tools/c5_full.sh [spp]'
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; cd "$ROOT"; SPP=${1:-32}; OUT=$ROOT/gpurun_out/c5_full; mkdir -p "$OUT"
 L=$ROOT/tray_rust_amd
@@ -27,7 +27,6 @@ for rep in range(2):
 PY
 {
 LABEL=default timeout 120 python /tmp/c5_run.py
-[ -f $L/libtrayhip_qwide.so ] && LABEL=qwide TRAYHIP_LIB=$L/libtrayhip_qwide.so TRAYHIP_WF_WIDE=1 timeout 120 python /tmp/c5_run.py
 LABEL=nosort TRAYHIP_WF_SORT=0 timeout 120 python /tmp/c5_run.py
 cd /tmp; export TMPDIR=/tmp
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python /tmp/c5_run.py > "$OUT/prof.log" 2>&1

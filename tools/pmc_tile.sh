@@ -14,6 +14,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   name=$(echo "$set" | cut -d' ' -f1)
   timeout 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc_$name" -- python "$ROOT/tools/mini_ab.py" run $D pmc $WL:$PSPP > "$OUT/pmc_$name.log" 2>&1
 done
+[ -x "$ROOT/tools/scratch_calib" ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 "$ROOT/tools/scratch_calib.hip" -o "$ROOT/tools/scratch_calib" > "$OUT/calib_build.log" 2>&1
 if [ -x "$ROOT/tools/scratch_calib" ]; then
   for set in FETCH_SIZE WRITE_SIZE; do
     timeout 60 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/calib_$set" -- "$ROOT/tools/scratch_calib" 64 > "$OUT/calib_$set.log" 2>&1

@@ -165,7 +165,6 @@ SYMBOLS = {
     "tray_debug_intersect": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "tray_debug_sample_radiance": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]),
     "tray_debug_bsdf": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "tray_debug_wide_nodes": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "tray_last_error": (C.c_char_p, []),
     "tray_version": (C.c_char_p, []),
     "tray_abi_sizeof": (C.c_uint32, [C.c_char_p]),

@@ -72,8 +72,6 @@ struct DevScene {
     uint32_t width, height, frame, film_rows;   // film_rows: 1 = row-binned film (separable, filter_h == 2)
     uint32_t integrator, pad_integrator;        // TRAY_INTEGRATOR_*
     uint32_t coop_offset;   // word offset of the cooperative leaf test's LDS area behind the traversal stacks (0 = none)
-    const float* __restrict__ wide_nodes;          // 4-wide collapse of every BVH<Triangle>, 32 floats per node (wavefront_wide.h); may be null
-    const uint32_t* __restrict__ mesh_wide_root;   // per mesh: index of its root's wide node
     const tray::FlatLeaf* __restrict__ flat_leaves;   // the flat instance loop's view of the scene: BVH<Instance> leaves ...
     const tray::FlatInst* __restrict__ flat_insts;    // ... and their instances, one 128-B record each (host/gates.hpp)
     uint32_t n_flat_leaves, pad_flat;

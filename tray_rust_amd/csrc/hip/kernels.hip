@@ -27,7 +27,6 @@
 #include <vector>
 
 #include "../../../include/trayhip.h"
-#include "../host/wide_nodes.hpp"
 #include "../host/validate.hpp"
 #include "dev_integrator.h"
 
@@ -202,7 +201,6 @@ __device__ __forceinline__ void film_splat_rows_global(const DevScene& sc, float
 }
 
 #include "wavefront.h"
-#include "wavefront_wide.h"
 
 // Work item w (0 <= w < n_work) maps to queue entry (w / chunk) * chunk_stride * chunk + (w % chunk):
 // contiguous ranges use chunk_stride = 1; multi-GPU sharding interleaves chunks round-robin.
@@ -499,8 +497,6 @@ struct TrayDeviceScene {
     bool wf_sort = true;              // material sort of the shading stage (k_wf_begin's LDS counting sort -> k_wf_query_kind); TRAYHIP_WF_SORT=0: off
     uint32_t* d_kind_queues = nullptr;   // WF_MAT_KINDS x n_slots slot indices
     uint32_t mat_kinds_present = 0;   // bit per TRAY_MAT_* kind among the scene's materials
-    bool wf_wide = false;             // TRAYHIP_WF_WIDE=1: k_wf_trace_wide (4-wide BVH<Triangle>, wavefront_wide.h)
-    uint32_t wide_lds_words = 0, wide_lds_bytes = 0;
 };
 
 static thread_local int g_device = 0;
@@ -527,7 +523,6 @@ static int upload(TrayDeviceScene* s, const T* host, size_t n, const T** out) {
     return TRAY_OK;
 }
 
-using tray::build_wide_nodes;   // host/wide_nodes.hpp
 
 #ifndef WF_SLOTS
 #define WF_SLOTS (8u << 20)   // path pool slots (2.2 GB of pool at 66 fields): measured 36.6 / 45.2 / 53.1 Msamples/s at 2 / 4 / 8 M on the C5
@@ -543,20 +538,17 @@ static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 tgrid, dim3 block, hipS
         hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
                            spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, qa, qr, qctl);
         hipLaunchKernelGGL(k_wf_regen<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
-        if (s->wf_wide) hipLaunchKernelGGL((k_wf_trace_wide<0, ANIM>), tgrid, block, s->wide_lds_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats, s->wide_lds_words, s->d_stack_overflow);
-        else hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
+        hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
         uint32_t* const kq = s->wf_sort ? s->d_kind_queues : nullptr;
         hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, qb, qctl, kq);
-        if (s->wf_wide) hipLaunchKernelGGL((k_wf_trace_wide<1, ANIM>), tgrid, block, s->wide_lds_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats, s->wide_lds_words, s->d_stack_overflow);
-        else hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
+        hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
         if (kq) {   // kind-pure shading over the sorted queues: one launch per material kind the scene contains
 #define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), grid, block, 0, stream, s->dev, s->pool, kq, qc, qctl)
             WF_QUERY_KIND(TRAY_MAT_MATTE); WF_QUERY_KIND(TRAY_MAT_PLASTIC); WF_QUERY_KIND(TRAY_MAT_METAL); WF_QUERY_KIND(TRAY_MAT_GLASS);
             WF_QUERY_KIND(TRAY_MAT_ROUGH_GLASS); WF_QUERY_KIND(TRAY_MAT_SPECULAR_METAL); WF_QUERY_KIND(TRAY_MAT_MERL);
 #undef WF_QUERY_KIND
         } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT>), grid, block, 0, stream, s->dev, s->pool, n_active, qc, qctl);
-        if (s->wf_wide) hipLaunchKernelGGL((k_wf_trace_wide<2, ANIM>), tgrid, block, s->wide_lds_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats, s->wide_lds_words, s->d_stack_overflow);
-        else hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
+        hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
     } else {   // one thread per pool slot in every stage; only the regeneration is compacted
         uint32_t* const none = nullptr;
         uint32_t* const qr = qc + s->pool.n_slots + WF_QCTL_WORDS;
@@ -721,35 +713,6 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
 #undef UP
     for (uint32_t t = 0; t < f->n_textures; ++t) moving = moving || f->textures[t].n_frames >= 2u;   // animated_image: sampled at ray.time, which only the ANIM kernels carry
     s->animated = moving;
-    if (getenv("TRAYHIP_WF_WIDE") && std::string(getenv("TRAYHIP_WF_WIDE")) == "1") {   // 4-wide BVH<Triangle> for the dynamic-fetch traversal
-#ifdef TR_QWIDE   // variant build (make EXTRA_HIPFLAGS=-DTR_QWIDE): 64-B nodes with 8-bit boxes rounded outwards (host/wide_nodes.hpp)
-        std::vector<uint32_t> wide;
-#else
-        std::vector<float> wide;
-#endif
-        std::vector<uint32_t> roots(f->n_meshes, 0xffffffffu);
-        bool ok = true;
-        for (uint32_t m = 0; m < f->n_meshes && ok; ++m) {
-            const TrayBvhNode* tree = f->mesh_nodes + f->meshes[m].node_offset;
-            if (f->meshes[m].tri_count >= (1u << 24)) ok = false;
-            else if (f->meshes[m].node_count && tree[0].count == 0) {
-#ifdef TR_QWIDE
-                roots[m] = tray::build_qwide_nodes(tree, 0u, wide);
-                ok = roots[m] != tray::WIDE_EMPTY;
-#else
-                roots[m] = build_wide_nodes(tree, 0u, wide);
-#endif
-            }
-        }
-        if (ok && rc == TRAY_OK) {
-            const decltype(wide)::value_type* d_wide = nullptr;
-            const uint32_t* d_roots = nullptr;
-            rc = upload(s, wide.data(), wide.size(), &d_wide);
-            if (rc == TRAY_OK) rc = upload(s, roots.data(), roots.size(), &d_roots);
-            d.wide_nodes = reinterpret_cast<const float*>(d_wide); d.mesh_wide_root = d_roots;
-            s->wf_wide = rc == TRAY_OK;
-        }
-    }
     if (rc == TRAY_OK) {   // the flat instance loop's records and gates (host/gates.hpp; dev_geom.h: trace_flat, mesh_leaf_coop)
         std::vector<tray::FlatLeaf> leaves;
         std::vector<tray::FlatInst> insts;
@@ -976,13 +939,6 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             const size_t ovf_entries = (size_t)(full_depth - lds_depth + 1u) * s->n_blocks_trace * TR_BLOCK;
             HIP_CHECK(hipMalloc(&p, ovf_entries * sizeof(uint32_t)));
             s->allocs.push_back(p); s->d_stack_overflow = static_cast<uint32_t*>(p);
-            if (s->wf_wide) {   // two-word entries, up to three pending per wide level: 32 words in LDS, the rest in HBM
-                s->wide_lds_words = 32u;
-                s->wide_lds_bytes = s->wide_lds_words * TR_BLOCK * (uint32_t)sizeof(uint32_t);
-                const size_t words = (size_t)(8u * full_depth + 64u) * s->n_blocks_trace * TR_BLOCK;
-                HIP_CHECK(hipMalloc(&p, words * sizeof(uint32_t)));
-                s->allocs.push_back(p); s->d_stack_overflow = static_cast<uint32_t*>(p);
-            }
             if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] dynamic-fetch traversal: %u of %u stack entries in LDS, %d workgroups per CU\n", lds_depth, full_depth, per_cu);
             const char* e = getenv("TRAYHIP_WF_TRACE");
             s->wf_dynamic = !(e && std::string(e) == "slot");

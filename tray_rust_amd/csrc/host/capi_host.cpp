@@ -6,7 +6,6 @@
 #include <vector>
 
 #include "../../../include/trayhip.h"
-#include "wide_nodes.hpp"
 
 namespace trayh {
 
@@ -41,29 +40,6 @@ uint32_t tray_abi_sizeof(const char* name) {
     TRAY_SZ(TrayFlatScene) TRAY_SZ(TrayTexture) TRAY_SZ(TrayTexFrame) TRAY_SZ(TraySceneInfo) TRAY_SZ(TrayKernelTiming) TRAY_SZ(TrayRay) TRAY_SZ(TrayHit)
 #undef TRAY_SZ
     return 0;
-}
-
-int tray_debug_wide_nodes(const TrayFlatScene* f, uint32_t mesh, int quantised, uint32_t* words, uint64_t capacity, uint64_t* n_words, uint32_t* root) {
-    if (!f || !n_words || !root || (capacity && !words)) { set_error("tray_debug_wide_nodes: null argument"); return TRAY_E_INVALID; }
-    if (mesh >= f->n_meshes || f->meshes[mesh].node_count == 0) { set_error("tray_debug_wide_nodes: no such mesh"); return TRAY_E_INVALID; }
-    const TrayBvhNode* tree = f->mesh_nodes + f->meshes[mesh].node_offset;
-    std::vector<uint32_t> packed;
-    *root = 0xffffffffu;
-    if (tree[0].count == 0) {
-        if (quantised) {
-            *root = tray::build_qwide_nodes(tree, 0u, packed);
-            if (*root == tray::WIDE_EMPTY) { set_error("tray_debug_wide_nodes: a box of this mesh cannot be quantised (non-finite bounds)"); return TRAY_E_UNSUPPORTED; }
-        } else {
-            std::vector<float> exact;
-            *root = tray::build_wide_nodes(tree, 0u, exact);
-            packed.resize(exact.size());
-            std::memcpy(packed.data(), exact.data(), exact.size() * sizeof(float));
-        }
-    }
-    *n_words = packed.size();
-    const uint64_t n = std::min<uint64_t>(capacity, packed.size());
-    if (n) std::memcpy(words, packed.data(), n * sizeof(uint32_t));
-    return TRAY_OK;
 }
 
 int tray_block_queue(uint32_t width, uint32_t height, uint32_t select_start, uint32_t select_count,
