@@ -336,7 +336,16 @@ TR_DEV bool mesh_traverse(const DevScene& sc, uint32_t* __restrict__ stack, cons
 // caution); the caller then re-traces the ray the reference's way.
 #define TR_COOP_MAX_TRIS 16
 #define TR_COOP_WORDS 832   // per wave: ray o, d, min_t, gate max_t (8 x 64) + result t, k, b1, b2, second t (5 x 64)
-TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float* __restrict__ w_lds, bool participate, f3 o, f3 d, float min_t,
+// value of lane (l ^ step) of the same quad, step 1 or 2: a DPP quad_perm move (one VALU instruction; __shfl_xor is a ds_bpermute)
+TR_DEV float quad_xor(float v, int step) {
+#ifdef TR_HOST_EMU
+    return __shfl_xor(v, step);
+#else
+    const int i = __float_as_int(v);
+    return __int_as_float(step == 1 ? __builtin_amdgcn_mov_dpp(i, 0xB1, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(i, 0x4E, 0xf, 0xf, true));
+#endif
+}
+TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, LdsF w_lds, bool participate, f3 o, f3 d, float min_t,
                            float gate_max_t, float accept_max_t, float& t_out, uint32_t& prim, float& b1, float& b2, float& leaf_tmin, bool& hazard) {
     const uint32_t lane = threadIdx.x & 63u;
     const TrayBvhNode* __restrict__ tree = sc.mesh_nodes + m.node_offset;
@@ -357,7 +366,7 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float*
         w_lds[6 * 64 + rank] = min_t; w_lds[7 * 64 + rank] = gate_max_t;
         w_lds[9 * 64 + rank] = -1.0f;   // no candidate yet
     }
-    __builtin_amdgcn_wave_barrier();
+    TR_WAVE_SYNC();
     const uint32_t per = (T + 3u) >> 2, g = lane & 3u;
     for (uint32_t base = 0; base < n; base += 16u) {
         const uint32_t r = base + (lane >> 2);
@@ -381,8 +390,8 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float*
         // quad reduction (all four lanes of a quad are active together)
 #pragma unroll
         for (int step = 1; step <= 2; step <<= 1) {
-            const float ot = __shfl_xor(ct, step), ok = __shfl_xor(ck, step), ob1 = __shfl_xor(cb1, step), ob2 = __shfl_xor(cb2, step),
-                        o2 = __shfl_xor(c2, step);
+            const float ot = quad_xor(ct, step), ok = quad_xor(ck, step), ob1 = quad_xor(cb1, step), ob2 = quad_xor(cb2, step),
+                        o2 = quad_xor(c2, step);
             const bool both = ok >= 0.0f && ck >= 0.0f;
             const bool take = ok >= 0.0f && (ck < 0.0f || ot < ct);
             c2 = fminf(c2, o2);
@@ -393,7 +402,7 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, volatile float*
             w_lds[8 * 64 + r] = ct; w_lds[9 * 64 + r] = ck; w_lds[10 * 64 + r] = cb1; w_lds[11 * 64 + r] = cb2; w_lds[12 * 64 + r] = c2;
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    TR_WAVE_SYNC();
     bool hit = false;
     if (need) {
         const float ck = w_lds[9 * 64 + rank];
@@ -504,7 +513,7 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
             float b1 = 0.0f, b2 = 0.0f, leaf_t = -TR_INF;
             if (gt == TRAY_GEOM_MESH && sc.coop_offset != 0u && sc.meshes[mesh_id].tri_count <= TR_COOP_MAX_TRIS) {
                 // small mesh: the whole wave enters, lanes without a pending ray only lend their ALUs
-                volatile float* w_lds = reinterpret_cast<volatile float*>(stack - threadIdx.x + sc.coop_offset) + (threadIdx.x >> 6) * TR_COOP_WORDS;
+                const LdsF w_lds = TR_LDS_F(stack - threadIdx.x + sc.coop_offset) + (threadIdx.x >> 6) * TR_COOP_WORDS;
                 hit = mesh_leaf_coop(sc, sc.meshes[mesh_id], w_lds, wanted, o, d, min_t, gate_max_t, bound, t, prim, b1, b2, leaf_t, hz);
             } else if (wanted) {
                 if (gt == TRAY_GEOM_RECT) hit = rect_test(gp0, gp1, o, d, min_t, bound, t);

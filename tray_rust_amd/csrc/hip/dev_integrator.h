@@ -296,36 +296,44 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want, const f
     return WANT_NONE;
 }
 
-// Stage B after the occlusion ray: all BSDF queries of the vertex
+// Stage B after the occlusion ray: all BSDF queries of the vertex. Every lane of the wave enters (`active` = the lane has a vertex):
+// the three kinds of query run as three wave-aligned passes -- LIGHT for the lanes whose shadow ray was not occluded, then MIS,
+// then PATH -- so that the kind is wave-uniform inside query_stage (scalar branches; the sample head runs twice per vertex, not
+// three times as it did when occluded lanes started with MIS while the others were still at LIGHT).
 template <int ANIM, int FEAT, uint32_t KM = KM_ALL>
-TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded) {
-    const bool delta = sc.instances[ln.light_inst].kind == TRAY_INST_POINT_EMITTER;
-    uint32_t want = ((ln.flags & LF_SHADOW) && !occluded) ? WANT_LIGHT : (delta ? WANT_PATH : WANT_MIS);
-    // a textured material's lobes exist per hit only: lowered here from the parameters sampled at (u, v, time), as Material::bsdf
-    // does (matte.rs:55-63 etc.), kept in private memory for the queries of this vertex
-    const DevMaterial* const table_mat = ln.bsdf.mat;
+TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded, bool active = true) {
+    uint32_t want = WANT_NONE;
+    const DevMaterial* table_mat = nullptr;
     DevMaterial hit_mat;
-    if ((FEAT & FEAT_TEX) && table_mat->textured) {
-        resolve_textured(sc, table_mat, ln.bsdf.u, ln.bsdf.v, ln.time, hit_mat);
-        ln.bsdf.mat = &hit_mat;
+    f3 wo_sh = mk(0.0f, 0.0f, 1.0f);
+    if (active) {
+        const bool delta = sc.instances[ln.light_inst].kind == TRAY_INST_POINT_EMITTER;
+        want = ((ln.flags & LF_SHADOW) && !occluded) ? WANT_LIGHT : (delta ? WANT_PATH : WANT_MIS);
+        // a textured material's lobes exist per hit only: lowered here from the parameters sampled at (u, v, time), as Material::bsdf
+        // does (matte.rs:55-63 etc.), kept in private memory for the queries of this vertex
+        table_mat = ln.bsdf.mat;
+        if ((FEAT & FEAT_TEX) && table_mat->textured) {
+            resolve_textured(sc, table_mat, ln.bsdf.u, ln.bsdf.v, ln.time, hit_mat);
+            ln.bsdf.mat = &hit_mat;
+        }
+        // w_o in shading space, once per vertex: BSDF::eval, ::pdf and ::sample each start with the same to_shading + normalized of
+        // the same vector (bsdf.rs:67-68,86,115-116). w_o is -d until the PATH query (the last one) writes the next ray's direction.
+        wo_sh = normalized(to_shading(ln.bsdf, -ln.d));
     }
-    // w_o in shading space, once per vertex: BSDF::eval, ::pdf and ::sample each start with the same to_shading + normalized of the
-    // same vector (bsdf.rs:67-68,86,115-116). w_o is -d until the PATH query (the last one) writes the next ray's direction.
-    const f3 wo_sh = normalized(to_shading(ln.bsdf, -ln.d));
-#if defined(TR_EMU_PROFILE)   // divergence-profile build of tests/emu: the default schedule, its passes numbered
-    for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) {
-        TR_EMU_PHASE(pass + 1);
-        want = query_stage<ANIM, FEAT, KM>(sc, ln, want, wo_sh);
-    }
-    TR_EMU_PHASE(0);
-#else
 #pragma nounroll
-    for (int pass = 0; pass < 3 && want != WANT_NONE; ++pass) {   // LIGHT -> MIS -> PATH
-        want = query_stage<ANIM, FEAT, KM>(sc, ln, want, wo_sh);
+    for (uint32_t kind = WANT_LIGHT; kind <= WANT_PATH; ++kind) {   // LIGHT -> MIS -> PATH
+#if defined(TR_EMU_PROFILE)   // divergence-profile build of tests/emu: the passes numbered
+        TR_EMU_PHASE((int)kind);
+#endif
+        const bool go = want == kind;
+        if (!__any(go)) continue;
+        if (go) want = query_stage<ANIM, FEAT, KM>(sc, ln, kind, wo_sh);
         TR_QCLK(ln, 2);
     }
+#if defined(TR_EMU_PROFILE)
+    TR_EMU_PHASE(0);
 #endif
-    if (FEAT & FEAT_TEX) ln.bsdf.mat = table_mat;
+    if ((FEAT & FEAT_TEX) && active) ln.bsdf.mat = table_mat;
 }
 
 // Stage C: tail of the BSDF half of estimate_direct (mod.rs:154-166), then path.rs:82 and the

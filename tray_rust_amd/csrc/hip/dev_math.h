@@ -14,6 +14,16 @@ namespace tr {
 #ifndef TR_HOST_EMU
 #define TR_DYN_LDS(T, name) extern __shared__ T name[]   // the workgroup's dynamic LDS (tests/emu supplies its own definition)
 #define TR_EMU_PHASE(k) ((void)0)   // numbers the passes of a loop whose iterations the lanes of a wave execute together; read by the host emulation's divergence profile only
+// LDS through its own address space: ds_read / ds_write instead of flat accesses (a `volatile` generic pointer into LDS compiles to
+// flat_load / flat_store with a full s_waitcnt after every access). Lanes of one wave exchange data through it between
+// TR_WAVE_SYNC()s: LDS operations of a wave complete in order, the fences only keep the compiler from moving accesses across.
+typedef __attribute__((address_space(3))) float* LdsF;
+#define TR_LDS_F(generic_ptr) ((LdsF)(generic_ptr))
+#define TR_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+typedef float* LdsF;
+#define TR_LDS_F(generic_ptr) ((float*)(generic_ptr))
+#define TR_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 
 static constexpr float kPi = 3.14159265358979323846f;

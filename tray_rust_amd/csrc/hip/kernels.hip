@@ -225,7 +225,6 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
     const bool film_rows = sc.film_rows != 0u;
     Counters cnt;
     cnt.rays = 0; cnt.vertices = 0;
-    uint32_t n_samples = 0;
                           // VGPRs that live across the whole kernel
     uint32_t w_samples = 0u, w_vertices = 0u, w_rays = 0u;
 #ifdef TR_STAGE_CLOCKS
@@ -297,12 +296,12 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
                 }
                 TR_CLK(stage);   // trace A / B / C
                 if (stage == 0) w_vertices += (uint32_t)__popcll(__ballot(alive && tr_.hit));
-                if (alive) {
+                if (stage == 1) {
+                    vertex_queries<ANIM, FEAT>(sc, ln, tr_.hit, alive);   // (the whole wave enters: wave-aligned query passes)
+                } else if (alive) {
                     if (stage == 0) {
                         if (tr_.hit) vertex_begin<ANIM>(sc, ln, tr_.rec, cnt);
                         else ln.flags &= ~LF_ALIVE;   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
-                    } else if (stage == 1) {
-                        vertex_queries<ANIM, FEAT>(sc, ln, tr_.hit);
                     } else {
                         if (!vertex_end<ANIM>(sc, ln, tr_.hit, tr_.rec)) ln.flags &= ~LF_ALIVE;
                     }
@@ -416,12 +415,12 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
                 const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
                 tr_ = trace<ANIM>(scp, my_stack, r, stage == 1, want_ray);
             }
-            if (alive) {
+            if (stage == 1) {
+                vertex_queries<ANIM, FEAT_ALL | FEAT_TEX>(sc, ln, tr_.hit, alive);
+            } else if (alive) {
                 if (stage == 0) {
                     if (tr_.hit) vertex_begin<ANIM>(sc, ln, tr_.rec, cnt);
                     else ln.flags &= ~LF_ALIVE;
-                } else if (stage == 1) {
-                    vertex_queries<ANIM, FEAT_ALL | FEAT_TEX>(sc, ln, tr_.hit);
                 } else {
                     if (!vertex_end<ANIM>(sc, ln, tr_.hit, tr_.rec)) ln.flags &= ~LF_ALIVE;
                 }
