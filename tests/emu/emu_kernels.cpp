@@ -244,17 +244,17 @@ int emu_wf_trace(const TrayFlatScene* f, int stage, uint32_t n, const TrayRay* r
     make_scene(f, e);
     const uint32_t n_slots = (n + TR_BLOCK - 1) / TR_BLOCK * TR_BLOCK;
     std::vector<float> pool_data((size_t)F_COUNT * n_slots, 0.0f);
-    WfPool pool{pool_data.data(), n_slots};
-    std::vector<uint32_t> queue(n_slots), qctl(WF_QCTL_WORDS, 0u);
+    WfPool pool{pool_data.data(), n_slots, wf_seg_cap(n_slots / TR_BLOCK)};
+    std::vector<uint32_t> queue((size_t)WF_SEGS * pool.seg_cap), qctl(WF_QCTL_WORDS, 0u);
     for (uint32_t i = 0; i < n; ++i) {
-        queue[i] = n - 1u - i;   // any permutation: slots keep their place, only indices travel
-        const uint32_t s = queue[i];
+        const uint32_t s = n - 1u - i;   // any order inside a segment: slots keep their place, only indices travel
+        const uint32_t seg = (s / TR_BLOCK) & (WF_SEGS - 1u);   // the segment of the slot's chunk (wavefront.h)
+        queue[(size_t)seg * pool.seg_cap + qctl[seg * WF_SEG_STRIDE + stage]++] = s;
         const f3 o = mk(rays[s].o[0], rays[s].o[1], rays[s].o[2]), dd = mk(rays[s].d[0], rays[s].d[1], rays[s].d[2]);
         if (stage == 0) { st3(pool, F_O, s, o); st3(pool, F_D, s, dd); pu(pool, F_BOUNCE, s) = rays[s].min_t == 0.0f ? 0u : 1u; }
         else { st3(pool, F_P, s, o); st3(pool, F_AUX, s, dd); }
         pu(pool, F_FLAGS, s) = LF_ALIVE;
     }
-    qctl[stage] = n;
     const uint32_t full = e.depth;
     if (lds_depth == 0 || lds_depth > full) lds_depth = full;
     std::vector<uint32_t> overflow((size_t)(8u * e.depth + 64u) * blocks * TR_BLOCK, 0u);
@@ -354,7 +354,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     n_chunks = std::max(1u, std::min(n_chunks, tile_count));
     const uint32_t n_slots = n_chunks * TR_BLOCK, n_active = n_slots;
     std::vector<float> pool_data((size_t)F_COUNT * n_slots, 0.0f);
-    WfPool pool{pool_data.data(), n_slots};
+    WfPool pool{pool_data.data(), n_slots, wf_seg_cap(n_chunks)};
     std::vector<uint32_t> moving_ids(std::max(n_moving, 1u), 0u);
     std::vector<float> xf_cache;
     if (moving && n_moving) {   // per-path transform cache, one column per pool slot (tray_scene_create)
@@ -365,8 +365,10 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     }
     std::vector<WfChunk> chunks(n_chunks, WfChunk{WF_TILE_NEED, 0u});
     std::vector<float> bins((size_t)n_chunks * ROWBIN_SIZE, 0.0f);
-    std::vector<uint32_t> queues(4 * (size_t)n_slots + WF_QCTL_WORDS, 0u);
-    uint32_t* const qa = queues.data(), * const qb = qa + n_slots, * const qc = qb + n_slots, * const qctl = qc + n_slots, * const qr = qc + n_slots + WF_QCTL_WORDS;
+    const size_t q_cap = (size_t)WF_SEGS * pool.seg_cap;
+    const uint32_t q_blocks = (n_chunks + WF_SEGS - 1u) / WF_SEGS * WF_SEGS;   // grid of the one-thread-per-entry kernels (launch_wavefront)
+    std::vector<uint32_t> queues(4 * q_cap + WF_QCTL_WORDS, 0u);
+    uint32_t* const qa = queues.data(), * const qb = qa + q_cap, * const qc = qb + q_cap, * const qr = qc + q_cap, * const qctl = qr + q_cap;
     uint32_t counters[2] = {0u, 0u};
     std::vector<DevStats> stats(WF_STAT_SLOTS);
     std::memset(stats.data(), 0, stats.size() * sizeof(DevStats));
@@ -381,7 +383,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     const int feat = feature_set(e);
     // the material sort of the shading stage (default of the library for the compacted schedule; trace == 2 is the slot form without queues)
     const bool sorted = trace != 2 && !getenv("TRAYHIP_WF_SORT_OFF") && !(feat & FEAT_TEX);
-    std::vector<uint32_t> kind_queues((size_t)WF_MAT_KINDS * n_slots, 0u);
+    std::vector<uint32_t> kind_queues((size_t)WF_MAT_KINDS * q_cap, 0u);
     uint32_t kinds_present = 0;
     for (const DevMaterial& dm : e.mats) kinds_present |= 1u << dm.mat_kind;
     const uint64_t max_rounds = (uint64_t)((tile_count + n_chunks - 1) / n_chunks) * (((uint64_t)spp + 3) / 4 * (e.d.max_depth + 3) + 4) + 32;
@@ -392,7 +394,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     do {                                                                                                                                    \
         EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_advance<A>(e.d, pool, chunks.data(), bins.data(), tiles.data(), tile_count, tile_count, 1u, spp, kf, rgbw, \
                                                          counters, counters + 1, stats.data(), qa, qr, qctl); });                          \
-        EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_regen<A>(e.d, pool, chunks.data(), tiles.data(), tile_count, 1u, spp, kf, stats.data(), qr, qa, qctl); }); \
+        EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_regen<A>(e.d, pool, chunks.data(), tiles.data(), tile_count, 1u, spp, kf, stats.data(), qr, qa, qctl); }); \
         EMU_TRACE_STAGE(0, A, qa);                                                                                                          \
         EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_begin<A>(e.d, pool, n_active, stats.data(), trace == 2 ? nullptr : qb, trace == 2 ? nullptr : qctl, sorted ? kind_queues.data() : nullptr); }); \
         EMU_TRACE_STAGE(1, A, qb);                                                                                                          \
@@ -402,7 +404,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
         } else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query<A, F>(e.d, pool, n_active, trace == 2 ? nullptr : qc, trace == 2 ? nullptr : qctl); });  \
         EMU_TRACE_STAGE(2, A, qc);                                                                                                          \
     } while (0)
-#define EMU_QUERY_KIND(A, K) do { if (kinds_present & (1u << K)) EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query_kind<A, K>(e.d, pool, kind_queues.data(), qc, qctl); }); } while (0)
+#define EMU_QUERY_KIND(A, K) do { if (kinds_present & (1u << K)) EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_query_kind<A, K>(e.d, pool, kind_queues.data(), qc, qctl); }); } while (0)
 #define EMU_TRACE_STAGE(S, A, Q)                                                                                                            \
     do {                                                                                                                                    \
         if (trace == 0) EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data()); }, dyn_lds); \

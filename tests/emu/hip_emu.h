@@ -251,5 +251,7 @@ inline void __syncthreads() { if (hip_emu::block().simt) hip_emu::block_barrier(
 template <class T> inline T atomicAdd(T* p, T v) { T old = *p; *p = old + v; return old; }
 inline uint32_t atomicAdd(uint32_t* p, int v) { uint32_t old = *p; *p = old + (uint32_t)v; return old; }
 #define __HIP_MEMORY_SCOPE_WORKGROUP 0
+#define __HIP_MEMORY_SCOPE_AGENT 1
+template <class T> inline T __hip_atomic_load(const T* p, int, int) { return *p; }
 template <class T, class V> inline T __hip_atomic_fetch_add(T* p, V v, int, int) { T old = *p; *p = old + (T)v; return old; }
 inline long long clock64() { return 0; }

@@ -18,11 +18,15 @@ namespace tr {
 // flat_load / flat_store with a full s_waitcnt after every access). Lanes of one wave exchange data through it between
 // TR_WAVE_SYNC()s: LDS operations of a wave complete in order, the fences only keep the compiler from moving accesses across.
 typedef __attribute__((address_space(3))) float* LdsF;
+typedef __attribute__((address_space(3))) uint32_t* LdsU;
 #define TR_LDS_F(generic_ptr) ((LdsF)(generic_ptr))
+#define TR_LDS_U(generic_ptr) ((LdsU)(generic_ptr))
 #define TR_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #else
 typedef float* LdsF;
+typedef uint32_t* LdsU;
 #define TR_LDS_F(generic_ptr) ((float*)(generic_ptr))
+#define TR_LDS_U(generic_ptr) ((uint32_t*)(generic_ptr))
 #define TR_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 

@@ -529,20 +529,19 @@ static int upload(TrayDeviceScene* s, const T* host, size_t n, const T** out) {
 #define WF_POLL 16
 // one round of the wavefront schedule: advance -> trace A -> begin -> trace B -> query -> trace C
 template <int ANIM, int FEAT>
-static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 tgrid, dim3 block, hipStream_t stream, const uint2* tiles, uint32_t tile_count, uint32_t chunk,
+static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 qgrid, dim3 tgrid, dim3 block, hipStream_t stream, const uint2* tiles, uint32_t tile_count, uint32_t chunk,
                      uint32_t chunk_stride, uint32_t spp, uint32_t kf, float* rgbw_dev, uint32_t n_active, uint32_t* qa, uint32_t* qb, uint32_t* qc,
-                     uint32_t* qctl) {
+                     uint32_t* qr, uint32_t* qctl) {
     if (s->wf_dynamic) {   // compacted ray queues + persistent traversal with dynamic fetch
-        uint32_t* const qr = qc + s->pool.n_slots + WF_QCTL_WORDS;
         hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
                            spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, qa, qr, qctl);
-        hipLaunchKernelGGL(k_wf_regen<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
+        hipLaunchKernelGGL(k_wf_regen<ANIM>, qgrid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
         hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
         uint32_t* const kq = s->wf_sort ? s->d_kind_queues : nullptr;
         hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, qb, qctl, kq);
         hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
         if (kq) {   // kind-pure shading over the sorted queues: one launch per material kind the scene contains
-#define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), grid, block, 0, stream, s->dev, s->pool, kq, qc, qctl)
+#define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), qgrid, block, 0, stream, s->dev, s->pool, kq, qc, qctl)
             WF_QUERY_KIND(TRAY_MAT_MATTE); WF_QUERY_KIND(TRAY_MAT_PLASTIC); WF_QUERY_KIND(TRAY_MAT_METAL); WF_QUERY_KIND(TRAY_MAT_GLASS);
             WF_QUERY_KIND(TRAY_MAT_ROUGH_GLASS); WF_QUERY_KIND(TRAY_MAT_SPECULAR_METAL); WF_QUERY_KIND(TRAY_MAT_MERL);
 #undef WF_QUERY_KIND
@@ -550,10 +549,9 @@ static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 tgrid, dim3 block, hipS
         hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
     } else {   // one thread per pool slot in every stage; only the regeneration is compacted
         uint32_t* const none = nullptr;
-        uint32_t* const qr = qc + s->pool.n_slots + WF_QCTL_WORDS;
         hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
                            spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, qa, qr, qctl);
-        hipLaunchKernelGGL(k_wf_regen<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
+        hipLaunchKernelGGL(k_wf_regen<ANIM>, qgrid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
         hipLaunchKernelGGL((k_wf_trace<0, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
         hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, none, none, none);
         hipLaunchKernelGGL((k_wf_trace<1, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
@@ -905,7 +903,8 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
         void* p = nullptr;
         HIP_CHECK(hipMalloc(&p, (size_t)F_COUNT * n_slots * sizeof(float)));
         s->allocs.push_back(p);
-        s->pool.data = static_cast<float*>(p); s->pool.n_slots = n_slots;
+        s->pool.data = static_cast<float*>(p); s->pool.n_slots = n_slots; s->pool.seg_cap = wf_seg_cap(s->n_chunks);
+        const size_t q_cap = (size_t)WF_SEGS * s->pool.seg_cap;   // entries of one queue: WF_SEGS segments (wavefront.h)
         HIP_CHECK(hipMalloc(&p, (size_t)s->n_chunks * sizeof(WfChunk)));
         s->allocs.push_back(p); s->d_chunks = static_cast<WfChunk*>(p);
         HIP_CHECK(hipMalloc(&p, (size_t)s->n_chunks * ROWBIN_SIZE * sizeof(float)));
@@ -913,12 +912,12 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
         HIP_CHECK(hipMemset(s->d_bins, 0, (size_t)s->n_chunks * ROWBIN_SIZE * sizeof(float)));
         HIP_CHECK(hipMalloc(&p, 2 * sizeof(uint32_t)));
         s->allocs.push_back(p); s->d_wf_counters = static_cast<uint32_t*>(p);
-        HIP_CHECK(hipMalloc(&p, (4 * (size_t)n_slots + WF_QCTL_WORDS) * sizeof(uint32_t)));   // ray queues A, B, C, their counters, regeneration queue
+        HIP_CHECK(hipMalloc(&p, (4 * q_cap + WF_QCTL_WORDS) * sizeof(uint32_t)));   // ray queues A, B, C, regeneration queue, control words of their segments
         s->allocs.push_back(p); s->d_queues = static_cast<uint32_t*>(p);
         if (const char* e = getenv("TRAYHIP_WF_SORT")) s->wf_sort = std::string(e) != "0";
         if (s->feat & FEAT_TEX) s->wf_sort = false;   // the kind-pure kernels read lobes from the material table; textured materials have theirs per hit
         if (s->wf_sort) {   // shading queues of the material sort (slot indices), one per material kind
-            HIP_CHECK(hipMalloc(&p, (size_t)WF_MAT_KINDS * n_slots * sizeof(uint32_t)));
+            HIP_CHECK(hipMalloc(&p, (size_t)WF_MAT_KINDS * q_cap * sizeof(uint32_t)));
             s->allocs.push_back(p); s->d_kind_queues = static_cast<uint32_t*>(p);
         }
         {
@@ -957,14 +956,16 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     const dim3 grid(n_chunks), block(TR_BLOCK);
     const uint2* tiles = s->d_tiles + tile_start;
     uint32_t launches = 0;
-    uint32_t* const qa = s->d_queues, * const qb = qa + s->pool.n_slots, * const qc = qb + s->pool.n_slots, * const qctl = qc + s->pool.n_slots;
+    const size_t q_cap = (size_t)WF_SEGS * s->pool.seg_cap;
+    uint32_t* const qa = s->d_queues, * const qb = qa + q_cap, * const qc = qb + q_cap, * const qr = qc + q_cap, * const qctl = qr + q_cap;
+    const dim3 qgrid((n_chunks + WF_SEGS - 1u) / WF_SEGS * WF_SEGS);   // one-thread-per-entry kernels: block b reads segment b % WF_SEGS
     const dim3 tgrid(std::min<uint32_t>(s->n_blocks_trace, n_chunks));
     // every chunk needs at most (spp/4 rounded up) samples x (max_depth + 2) rounds per tile, plus one round per tile switch
     const uint64_t tiles_per_chunk = (tile_count + n_chunks - 1) / n_chunks;
     const uint64_t max_rounds = tiles_per_chunk * (((uint64_t)spp + 3) / 4 * (s->dev.max_depth + 3) + 4) + 2 * WF_POLL;
     for (uint32_t round = 0;; ++round) {
         HIP_CHECK(hipMemsetAsync(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), stream));
-#define WF_ROUND(A, F) wf_round<A, F>(s, grid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qctl)
+#define WF_ROUND(A, F) wf_round<A, F>(s, grid, qgrid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qr, qctl)
 #define WF_ROUND_F(A) do { if (s->feat == FEAT_NONE) WF_ROUND(A, FEAT_NONE); else if (s->feat == FEAT_MERL) WF_ROUND(A, FEAT_MERL); \
                           else if (s->feat == FEAT_SPEC) WF_ROUND(A, FEAT_SPEC); else if (s->feat == (FEAT_MERL | FEAT_SPEC)) WF_ROUND(A, FEAT_MERL | FEAT_SPEC); \
                           else if (s->feat == (FEAT_ALL | FEAT_TEX)) WF_ROUND(A, FEAT_ALL | FEAT_TEX); else WF_ROUND(A, FEAT_ALL); } while (0)

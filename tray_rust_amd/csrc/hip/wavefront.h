@@ -43,6 +43,7 @@ enum {
 struct WfPool {
     float* __restrict__ data;   // F_COUNT * n_slots dwords
     uint32_t n_slots;
+    uint32_t seg_cap;           // entries per segment of every queue (wf_seg_cap(chunks of the pool)); a queue holds WF_SEGS * seg_cap
 };
 struct WfChunk { uint32_t tile, done; };   // tile: index into the work list, WF_TILE_NEED or WF_TILE_IDLE
 enum : uint32_t { WF_TILE_NEED = 0xfffffffeu, WF_TILE_IDLE = 0xffffffffu };
@@ -109,20 +110,68 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace(const DevScene scv, WfPoo
 }
 
 // ---- ray queues: per-stage compaction of the slots that have a ray to trace --------------------
-// qctl[0..2] = entries in queue A / B / C, qctl[3..5] = consumer cursors; zeroed at the start of every round.
 // Producers append with one atomic per wave (ballot + prefix count); slots keep their place in the pool, only their
 // indices are compacted, so every stage still reads and writes pool fields at the slot's own address.
-#define WF_QCTL_WORDS 16   // [7] unused, [8 + k] = entries of the shading queue of material kind k (the material sort of k_wf_begin)
+// Every queue is cut into WF_SEGS segments with a counter each: appends to ONE counter serialise at 11.4 ns apiece on an MI355X
+// (tools/ubench_atomics.hip: 130 000 waves of a round = 1.5 ms per append, which was most of k_wf_advance / k_wf_begin /
+// k_wf_regen and the floor under the refills of k_wf_trace_dyn); over 64 counters on separate 128-B lines they cost 0.3 ns.
+// The entry of pool slot i lives in segment (i / 256) % WF_SEGS of whatever queue it is in: one-thread-per-slot kernels append
+// to segment blockIdx.x % WF_SEGS, one-thread-per-entry kernels read entries (blockIdx.x / WF_SEGS) * 256 ... of segment
+// blockIdx.x % WF_SEGS and append to the same segment, so a segment never holds more than the slots of its own chunks (seg_cap).
+// Control words of segment s: qctl[s * WF_SEG_STRIDE + k]; k = 0..2 entries in queue A / B / C, 3..5 consumer cursors of the
+// traversal kernels, 6 entries in the regeneration queue, 8 + kind entries of the shading queue of a material kind (the material
+// sort of k_wf_begin). All zeroed at the start of every round.
+#define WF_SEGS 64u
+#define WF_SEG_STRIDE 32u
+#define WF_QCTL_WORDS (WF_SEGS * WF_SEG_STRIDE)
 #define WF_MAT_KINDS 7     // TRAY_MAT_*
-TR_DEV void wf_enqueue(uint32_t* __restrict__ queue, uint32_t* __restrict__ count, bool want, uint32_t slot) {
+#ifdef TR_HOST_EMU
+inline
+#else
+__host__ __device__ inline
+#endif
+uint32_t wf_seg_cap(uint32_t n_chunks) { return (n_chunks + WF_SEGS - 1u) / WF_SEGS * TR_BLOCK; }
+TR_DEV uint32_t wf_my_seg() { return blockIdx.x & (WF_SEGS - 1u); }
+TR_DEV void wf_enqueue(const WfPool& pool, uint32_t* __restrict__ queue, uint32_t* __restrict__ qctl, uint32_t k, bool want, uint32_t slot) {
     const unsigned long long m = __ballot(want);
     if (m == 0ull) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+    const uint32_t seg = wf_my_seg();
     uint32_t base = 0u;
-    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    if (lane == leader) base = atomicAdd(qctl + seg * WF_SEG_STRIDE + k, (uint32_t)__popcll(m));
     base = __shfl(base, (int)leader);
-    if (want) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
+    if (want) queue[(size_t)seg * pool.seg_cap + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
+}
+// one thread per queue entry: the entry this thread owns, or false
+TR_DEV bool wf_my_entry(const WfPool& pool, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qctl, uint32_t k, uint32_t& slot) {
+    const uint32_t seg = wf_my_seg(), q = (blockIdx.x / WF_SEGS) * TR_BLOCK + threadIdx.x;
+    if (q >= qctl[seg * WF_SEG_STRIDE + k]) return false;
+    slot = queue[(size_t)seg * pool.seg_cap + q];
+    return true;
+}
+// Traversal kernels: the next segment after `seg` (cyclically; `seg` itself last) whose cursor has not reached its count, or
+// WF_SEGS. The wave reads all 64 (count, cursor) pairs with one load each; cursors are read past the non-coherent caches.
+TR_DEV uint32_t wf_next_segment(const uint32_t* __restrict__ qctl, uint32_t stage, uint32_t seg, uint32_t& count_out) {
+#ifdef TR_HOST_EMU
+    if (!hip_emu::block().simt) {   // one-lane waves: the same search, serially
+        for (uint32_t k = 1; k <= WF_SEGS; ++k) {
+            const uint32_t s2 = (seg + k) & (WF_SEGS - 1u);
+            const uint32_t c = qctl[s2 * WF_SEG_STRIDE + stage];
+            if (qctl[s2 * WF_SEG_STRIDE + 3u + stage] < c) { count_out = c; return s2; }
+        }
+        return WF_SEGS;
+    }
+#endif
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t c = qctl[lane * WF_SEG_STRIDE + stage];
+    const uint32_t u = __hip_atomic_load(qctl + lane * WF_SEG_STRIDE + 3u + stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long open = __ballot(u < c);
+    if (open == 0ull) return WF_SEGS;
+    const unsigned long long after = seg >= 63u ? 0ull : (open >> (seg + 1u)) << (seg + 1u);
+    const uint32_t next = (uint32_t)__ffsll((long long)(after ? after : open)) - 1u;
+    count_out = __shfl(c, (int)next);
+    return next;
 }
 
 // Persistent-threads traversal with dynamic ray fetch: a wave keeps 64 rays in flight; a lane whose ray is finished takes
@@ -148,19 +197,22 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                                                            uint32_t* __restrict__ overflow) {
     const DevScene& sc = scv;
     TR_DYN_LDS(uint32_t, s_stack);   // stack_depth x TR_BLOCK entries
-    uint32_t* __restrict__ stack = s_stack + threadIdx.x;
+    const LdsU stack = TR_LDS_U(s_stack) + threadIdx.x;   // (its own address space: a pop must not become a flat load that may hit either memory)
     // entries past lds_depth live in a per-thread column of `overflow` (HBM): the LDS part is sized for the occupancy the
     // kernel is compiled for, the rarely reached deep levels of the largest meshes must not cost every workgroup its LDS
     const uint32_t ovf_stride = gridDim.x * TR_BLOCK;
     uint32_t* __restrict__ ovf = overflow + (blockIdx.x * TR_BLOCK + threadIdx.x);
 #define WF_PUSH(v) do { const uint32_t v_ = (v); if ((uint32_t)sp < lds_depth) stack[sp * TR_BLOCK] = v_; else ovf[(size_t)((uint32_t)sp - lds_depth) * ovf_stride] = v_; ++sp; } while (0)
-#define WF_POP() (--sp, (uint32_t)sp < lds_depth ? stack[sp * TR_BLOCK] : ovf[(size_t)((uint32_t)sp - lds_depth) * ovf_stride])
-    const uint32_t n = qctl[STAGE];
-    uint32_t* __restrict__ cursor = qctl + 3 + STAGE;
+#define WF_POP(e) do { --sp; if ((uint32_t)sp < lds_depth) e = stack[sp * TR_BLOCK]; else e = ovf[(size_t)((uint32_t)sp - lds_depth) * ovf_stride]; } while (0)
     const uint32_t lane = threadIdx.x & 63u;
     const bool any_hit = STAGE == 1;
-    bool active = false, exhausted = false;
+    bool active = false;
     uint32_t slot = 0u, n_rays = 0u;
+    // the queue segment this wave draws from; it moves on (cyclically, to the next segment that still has entries) when the
+    // segment is drained, so the cursor atomics of the 4 x tgrid waves are spread over WF_SEGS counters
+    uint32_t seg_cnt = 0u;
+    uint32_t seg = wf_next_segment(qctl, STAGE, (blockIdx.x * (TR_BLOCK / 64u) + (threadIdx.x >> 6) + WF_SEGS - 1u) & (WF_SEGS - 1u), seg_cnt);
+    bool exhausted = seg == WF_SEGS;
 #ifdef WF_TRACE_STATS
     uint32_t c_iter = 0u, c_visit = 0u, c_expand = 0u, c_inst = 0u, c_tri = 0u;
 #define WF_COUNT(x) (++(x))
@@ -187,13 +239,12 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
             if (n_idle >= WF_REFILL_MIN || n_idle == (uint32_t)__popcll(__ballot(1))) {
                 const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
                 uint32_t base = 0u;
-                if (lane == leader) base = atomicAdd(cursor, n_idle);
+                if (lane == leader) base = atomicAdd(qctl + seg * WF_SEG_STRIDE + 3u + STAGE, n_idle);
                 base = __shfl(base, (int)leader);
-                if (base + n_idle >= n) exhausted = true;
                 if (!active) {
                     const uint32_t q = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                    if (q < n) {
-                        slot = queue[q];
+                    if (q < seg_cnt) {
+                        slot = queue[(size_t)seg * pool.seg_cap + q];
                         if (STAGE == 0) {
                             wo = ld3(pool, F_O, slot); wd = ld3(pool, F_D, slot);
                             min_t = pu(pool, F_BOUNCE, slot) == 0u ? 0.0f : 0.001f; max_t = TR_INF;
@@ -211,9 +262,13 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                         ++n_rays;
                     }
                 }
+                if (base + n_idle >= seg_cnt) {   // this segment is drained (by this refill or by somebody else's)
+                    seg = wf_next_segment(qctl, STAGE, seg, seg_cnt);
+                    exhausted = seg == WF_SEGS;
+                }
             }
         }
-        if (!__any(active)) break;
+        if (!__any(active)) { if (exhausted) break; continue; }
         // ---- traversal, while-while form. A lane is in one of three modes:
         //   TM_NODE  has one or two nodes to test: a popped node (the box test the reference runs when it reaches a node,
         //            with the ray's current max_t) or BOTH children of a node whose box was hit. Fetching the children
@@ -282,7 +337,8 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
         if (active && mode == TM_POP && !finished) {
             bool have_node = false;
             while (sp > 0) {
-                uint32_t e = WF_POP();
+                uint32_t e;
+                WF_POP(e);
                 uint32_t kind = e & STK_KIND_MASK;
                 if (kind == STK_NODE) { node_a = e; node_b = WF_NO_NODE; have_node = true; break; }
                 if (kind == STK_EXIT_MESH) {   // back to world space and the top-level tree
@@ -433,14 +489,14 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
         if (m != 0ull && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u)
             atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].vertices, (unsigned long long)__popcll(m));
     }
-    if (queue_b) wf_enqueue(queue_b, qctl + 1, kind < WF_MAT_KINDS && (flags & LF_SHADOW) != 0u, i);
+    if (queue_b) wf_enqueue(pool, queue_b, qctl, 1u, kind < WF_MAT_KINDS && (flags & LF_SHADOW) != 0u, i);
     if (kind_queues) {
         uint32_t rank = 0u;
         if (kind < WF_MAT_KINDS) rank = atomicAdd(&s_cnt[kind], 1u);
         __syncthreads();
-        if (tid < WF_MAT_KINDS && s_cnt[tid]) s_base[tid] = atomicAdd(qctl + 8 + tid, s_cnt[tid]);
+        if (tid < WF_MAT_KINDS && s_cnt[tid]) s_base[tid] = atomicAdd(qctl + wf_my_seg() * WF_SEG_STRIDE + 8u + tid, s_cnt[tid]);
         __syncthreads();
-        if (kind < WF_MAT_KINDS) kind_queues[(size_t)kind * pool.n_slots + s_base[kind] + rank] = i;
+        if (kind < WF_MAT_KINDS) kind_queues[((size_t)kind * WF_SEGS + wf_my_seg()) * pool.seg_cap + s_base[kind] + rank] = i;
     }
 }
 
@@ -477,7 +533,7 @@ TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, ui
         if (!cont) f2 = (f2 & ~LF_ALIVE) | WF_FINISHED;
         pu(pool, F_FLAGS, i) = f2;
     }
-    if (queue_c) wf_enqueue(queue_c, qctl + 2, (ln.flags & LF_MIS) != 0u, i);
+    if (queue_c) wf_enqueue(pool, queue_c, qctl, 2u, (ln.flags & LF_MIS) != 0u, i);
 }
 
 // one thread per pool slot, every material kind's code (TRAYHIP_WF_SORT=0, or the slot form of the schedule)
@@ -503,9 +559,8 @@ template <int ANIM, int MK>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_query_kind(const DevScene scv, WfPool pool, const uint32_t* __restrict__ kind_queues,
                                                             uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl) {
     const DevScene& sc = scv;
-    const uint32_t q = blockIdx.x * TR_BLOCK + threadIdx.x;
-    if (q >= qctl[8 + MK]) return;
-    const uint32_t i = kind_queues[(size_t)MK * pool.n_slots + q];
+    uint32_t i;
+    if (!wf_my_entry(pool, kind_queues + (size_t)MK * WF_SEGS * pool.seg_cap, qctl, 8u + MK, i)) return;
     wf_query_slot<ANIM, feat_of_material(MK), km_of_material(MK)>(sc, pool, i, pu(pool, F_FLAGS, i), queue_c, qctl);
 }
 
@@ -538,12 +593,11 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_regen(const DevScene scv, WfPoo
                                                        uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf, DevStats* __restrict__ stats,
                                                        const uint32_t* __restrict__ queue_r, uint32_t* __restrict__ queue_a, uint32_t* __restrict__ qctl) {
     const DevScene& sc = scv;
-    const uint32_t q = blockIdx.x * TR_BLOCK + threadIdx.x;
-    if (q >= qctl[6]) return;
-    const uint32_t i = queue_r[q];
+    uint32_t i;
+    if (!wf_my_entry(pool, queue_r, qctl, 6u, i)) return;
     wf_regenerate<ANIM>(sc, pool, i, chunks[i / TR_BLOCK].tile, tiles, chunk, chunk_stride, spp, kf, stats);
     pu(pool, F_FLAGS, i) = LF_ALIVE;
-    wf_enqueue(queue_a, qctl, true, i);
+    wf_enqueue(pool, queue_a, qctl, 0u, true, i);
 }
 
 // Round head, one workgroup per chunk: vertex_end of the previous round, film splat of finished samples,
@@ -612,10 +666,12 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
             atomicAdd(&s_fin, 1u);
         }
         __syncthreads();
-        if (film_rows && s_fin != 0u) {   // the chunk owns its bins: plain read-modify-write, coalesced
+        if (film_rows && s_fin != 0u) {
+            // the chunk owns its bins, so this is a plain sum -- issued as no-return atomics: a read-modify-write loop is a chain of
+            // 17 dependent HBM round trips per thread in a kernel that does little else, the atomic is fire-and-forget
             for (uint32_t k = tid; k < ROWBIN_SIZE; k += TR_BLOCK) {
                 const float v = s_bins[k];
-                if (v != 0.0f) my_bins[k] += v;
+                if (v != 0.0f) wg_add(my_bins + k, v);
             }
         }
         // ---- tile complete: spread the row bins over the window, flush it, take the next tile
@@ -665,9 +721,9 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
     // ---- path regeneration (multithreaded.rs:90-96): inline, or (compacted schedule) deferred to k_wf_regen so that the
     // camera rays and the per-path transforms of moving scenes are computed by full waves
     const bool wants_sample = tile_idx != WF_TILE_IDLE && !(flags & LF_ALIVE) && pu(pool, F_SNEXT, i) < spp;
-    wf_enqueue(queue_r, qctl + 6, wants_sample, i);
+    wf_enqueue(pool, queue_r, qctl, 6u, wants_sample, i);
     pu(pool, F_FLAGS, i) = flags;
-    wf_enqueue(queue_a, qctl, (flags & LF_ALIVE) != 0u, i);
+    wf_enqueue(pool, queue_a, qctl, 0u, (flags & LF_ALIVE) != 0u, i);
 }
 
 }  // namespace tr
