@@ -179,7 +179,8 @@ typedef struct TrayMaterial {
 enum { TRAY_MF_BECKMANN = 0, TRAY_MF_GGX = 1 };
 /* Integrator (src/integrator): the Path tracer (path.rs) or NormalsDebug (normals_debug.rs:28-33: (bsdf.n + 1) / 2 of the
  * camera ray's hit). Whitted (whitted.rs) is not built. */
-enum { TRAY_INTEGRATOR_PATH = 0, TRAY_INTEGRATOR_NORMALS_DEBUG = 1 };
+enum { TRAY_INTEGRATOR_PATH = 0, TRAY_INTEGRATOR_NORMALS_DEBUG = 1,
+       TRAY_INTEGRATOR_WHITTED = 2 };   /* integrator/whitted.rs: max_depth = the recursion limit (<= 16), min_depth unused */
 
 /* MERL table header: 90*90*180 RGB-interleaved f32, already scaled (material/merl.rs:60-82) */
 typedef struct TrayMerlTable {

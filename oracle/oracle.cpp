@@ -185,6 +185,55 @@ Colorf path_illumination(const SceneView& sv, const Ray& r, const Hit& hit, cons
     return illum;
 }
 
+// Whitted::illumination (integrator/whitted.rs:41-68) with Integrator::specular_reflection / specular_transmission
+// (integrator/mod.rs:49-97), recursive as in the reference. Random numbers: every activation is a node with a key; a one-element
+// LowDiscrepancy::get_samples_2d / _1d (ld.rs:54-64) is the scrambled (0,2) point of index 0 with fresh scrambles
+enum : uint32_t { WD_L2 = 0, WD_R2 = 2, WD_R1 = 4, WD_T2 = 5, WD_T1 = 7, WD_CHILD = 8 };
+Colorf whitted_illumination(const SceneView& sv, const Ray& ray, const Hit& hit, uint32_t key, uint32_t depth);
+Colorf whitted_specular(const SceneView& sv, const Ray& ray, const BSDF& bsdf, uint32_t key, uint32_t depth, bool transmission) {
+    const Vec3 w_o = -ray.d;
+    const uint32_t d2 = transmission ? WD_T2 : WD_R2, d1 = transmission ? WD_T1 : WD_R1;
+    const float u0 = van_der_corput(0u, draw(key, d2)), u1 = sobol(0u, draw(key, d2 + 1u)), one_d = van_der_corput(0u, draw(key, d1));
+    Vec3 w_i;
+    float pdf;
+    int sampled_type;
+    const Colorf f = bsdf.sample(w_o, BX_SPECULAR | (transmission ? BX_TRANSMISSION : BX_REFLECTION), u0, u1, one_d, w_i, pdf, sampled_type);
+    Colorf out = Colorf::broadcast(0.0f);
+    if (pdf > 0.0f && !f.is_black() && std::fabs(dot(w_i, bsdf.n)) != 0.0f) {
+        Ray child;   // ray.child(&bsdf.p, &w_i), min_t = 0.001 (mod.rs:65-66)
+        child.o = bsdf.p; child.d = w_i; child.min_t = 0.001f; child.max_t = INF; child.time = ray.time;
+        Hit h;
+        if (scene_intersect(sv, child, h)) {
+            const Colorf li = whitted_illumination(sv, child, h, draw(key, WD_CHILD + (transmission ? 1u : 0u)), depth + 1u);
+            out = f * li * std::fabs(dot(w_i, bsdf.n)) / pdf;
+        }
+    }
+    return out;
+}
+Colorf whitted_illumination(const SceneView& sv, const Ray& ray, const Hit& hit, uint32_t key, uint32_t depth) {
+    const TrayFlatScene& fs = *sv.fs;
+    if (sv.stats) sv.stats->vertices++;
+    const BSDF bsdf = material_bsdf(fs, hit);
+    const Vec3 w_o = -ray.d;
+    const float u0 = van_der_corput(0u, draw(key, WD_L2)), u1 = sobol(0u, draw(key, WD_L2 + 1u));
+    Colorf illum = Colorf::broadcast(0.0f);
+    const TrayInstance& inst = fs.instances[hit.inst];
+    if (depth == 0u && inst.kind != TRAY_INST_RECEIVER) illum = illum + emitter_radiance(sv, inst, w_o, hit.ng, ray.time);
+    for (uint32_t k = 0; k < fs.n_lights; ++k) {   // every light, the same sample (whitted.rs:56-62)
+        const LightSample ls = light_sample_incident(sv, fs.lights[k], bsdf.p, u0, u1, ray.time);
+        const Colorf f = bsdf.eval(w_o, ls.w_i, BX_ALL);
+        if (ls.li.is_black() || f.is_black()) continue;
+        Ray r = ls.occlusion;
+        Hit tmp;
+        if (!scene_intersect(sv, r, tmp)) illum = illum + f * ls.li * std::fabs(dot(ls.w_i, bsdf.n)) / ls.pdf;
+    }
+    if (depth < fs.max_depth) {
+        illum = illum + whitted_specular(sv, ray, bsdf, key, depth, false);
+        illum = illum + whitted_specular(sv, ray, bsdf, key, depth, true);
+    }
+    return illum;
+}
+
 struct PixelSampler {   // per-pixel part of LowDiscrepancy (ld.rs:33-64) over the counter RNG
     uint32_t kp, spp, scr_x, scr_y, key_xy, scr_t, key_t;
     void init(uint32_t kf, uint32_t pixel_index, uint32_t spp_) {
@@ -211,6 +260,7 @@ Colorf trace_sample(const SceneView& sv, uint32_t kf, uint32_t px, uint32_t py, 
     Ray ray = camera_generate_ray(sv, sx, sy, t);
     Hit hit;
     if (scene_intersect(sv, ray, hit)) {
+        if (sv.fs->integrator == TRAY_INTEGRATOR_WHITTED) return whitted_illumination(sv, ray, hit, key_sample(pix.kp, s), 0u).clamp();
         PathSamples ps;
         ps.init(key_sample(pix.kp, s), fs.max_depth + 1);
         if (sv.fs->integrator == TRAY_INTEGRATOR_NORMALS_DEBUG) {   // NormalsDebug::illumination (integrator/normals_debug.rs:28-33)

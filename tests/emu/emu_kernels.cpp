@@ -323,13 +323,16 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
 #define EMU_TILES(F)                                                                                                                                              \
     rc = moving ? launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<1, F>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4) \
                 : launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<0, F>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
-    if (feat == FEAT_NONE) EMU_TILES(FEAT_NONE);
+#define EMU_WHITTED(A) launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<A, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
+    if (e.d.integrator == TRAY_INTEGRATOR_WHITTED) rc = moving ? EMU_WHITTED(1) : EMU_WHITTED(0);   // launch_tiles: one instantiation per ANIM
+    else if (feat == FEAT_NONE) EMU_TILES(FEAT_NONE);
     else if (feat == FEAT_MERL) EMU_TILES(FEAT_MERL);
     else if (feat == FEAT_SPEC) EMU_TILES(FEAT_SPEC);
     else if (feat == (FEAT_MERL | FEAT_SPEC)) EMU_TILES(FEAT_MERL | FEAT_SPEC);
     else if (feat == (FEAT_ALL | FEAT_TEX)) EMU_TILES(FEAT_ALL | FEAT_TEX);
     else EMU_TILES(FEAT_ALL);
 #undef EMU_TILES
+#undef EMU_WHITTED
     if (stats_out) { stats_out[0] = stats.samples; stats_out[1] = stats.vertices; stats_out[2] = stats.rays; stats_out[3] = (unsigned long long)feat; }
     return rc;
 }

@@ -549,3 +549,18 @@ def test_normals_debug_integrator(name, tmp_path):
         assert (tim.samples, tim.vertices, tim.rays) == (st.samples, st.vertices, st.rays)
         assert rmse(gpu, cpu) < 1e-5
     scene.release_device()
+
+
+@pytest.mark.parametrize("name,depth", [("smallpt", 6), ("cornell_box", 4)])
+def test_whitted_integrator(name, depth, tmp_path):
+    """integrator/whitted.rs on the GPU (the tile kernel with the per-lane frame stack of dev_whitted.h) against the oracle's recursion"""
+    d = SCENES[name](160, 96, 16)
+    d["integrator"] = {"type": "whitted", "min_depth": depth}
+    scene, rt, _, fi = load(d, tmp_path)
+    cpu, st = O.render_tiles(scene.flatten(0), 16, seed=2)
+    gpu, tim = gpu_render(scene, rt, 16, fi, seed=2)
+    assert tim.samples == st.samples and abs(int(tim.vertices) - int(st.vertices)) <= 5e-4 * st.vertices and abs(int(tim.rays) - int(st.rays)) <= 5e-4 * st.rays
+    r = rmse(gpu, cpu)
+    print(f"whitted {name} depth {depth} 160x96x16: RMSE {r:.3e}, {st.vertices / st.samples:.2f} activations and {st.rays / st.samples:.2f} rays per sample")
+    assert r < 1e-4
+    scene.release_device()

@@ -94,7 +94,8 @@ def test_trs_decomposition_recomposes(tmp_path):
     (lambda d: d["film"]["filter"].update(type="box"), L.TRAY_E_PARSE, "Unrecognized filter type"),
     (lambda d: d.pop("camera"), L.TRAY_E_PARSE, "camera is required"),
     (lambda d: d["integrator"].update(type="bdpt"), L.TRAY_E_PARSE, "Unrecognized integrator"),
-    (lambda d: d["integrator"].update(type="whitted"), L.TRAY_E_UNSUPPORTED, "hot-path scope"),
+    (lambda d: d.update(integrator={"type": "whitted", "max_depth": 8}), L.TRAY_E_PARSE, "minimum ray depth"),   # scene.rs:306-309 reads "min_depth"
+    (lambda d: d.update(integrator={"type": "whitted", "min_depth": 17}), L.TRAY_E_UNSUPPORTED, "recursion depth"),
     (lambda d: d["materials"].append(dict(d["materials"][0])), L.TRAY_E_INVALID, "name conflicts"),
     (lambda d: d["materials"][0].update(type="velvet"), L.TRAY_E_PARSE, "unrecognized type"),
     (lambda d: d["materials"][0].update(diffuse="checker"), L.TRAY_E_INVALID, "Invalid color specified for diffuse of matte"),   # no such texture

@@ -7,7 +7,7 @@ timeout 20 python tools/mini_ab.py prepare $D
 timeout 15 python tools/mini_ab.py run $D default cornell_box:64 smallpt:64 dragon:32 tr15_like:16
 for v in "$@"; do
   [ -f $L/libtrayhip_$v.so ] || continue
-  if [ $v = clk ]; then TRAYHIP_LIB=$L/libtrayhip_$v.so TRAYHIP_STATS=1 timeout 15 python tools/mini_ab.py run $D $v cornell_box:64 dragon:32
+  if [ $v = clk ]; then TRAYHIP_LIB=$L/libtrayhip_$v.so TRAYHIP_STATS=1 timeout 15 python tools/mini_ab.py run $D $v cornell_box:64 smallpt:64 dragon:32
   else TRAYHIP_LIB=$L/libtrayhip_$v.so timeout 15 python tools/mini_ab.py run $D $v cornell_box:64 smallpt:64 dragon:32; fi
 done
 timeout 15 python tools/mini_ab.py run $D default2 cornell_box:64

@@ -29,6 +29,7 @@
 #include "../../../include/trayhip.h"
 #include "../host/validate.hpp"
 #include "dev_integrator.h"
+#include "dev_whitted.h"
 
 namespace trayh { void set_error(const std::string& msg); }
 using trayh::set_error;
@@ -204,7 +205,9 @@ __device__ __forceinline__ void film_splat_rows_global(const DevScene& sc, float
 
 // Work item w (0 <= w < n_work) maps to queue entry (w / chunk) * chunk_stride * chunk + (w % chunk):
 // contiguous ranges use chunk_stride = 1; multi-GPU sharding interleaves chunks round-robin.
-template <int ANIM, int FEAT>
+// INTEG: the scene's integrator. TRAY_INTEGRATOR_WHITTED runs every camera sample of a wave to its end between two
+// regenerations (dev_whitted.h) inside the same tile / film skeleton; NormalsDebug is a branch of vertex_begin.
+template <int ANIM, int FEAT, int INTEG = TRAY_INTEGRATOR_PATH>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const DevScene scv, const uint2* __restrict__ tiles, uint32_t tile_count,
                                                          uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf,
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ counter,
@@ -275,6 +278,13 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
             }
             w_samples += (uint32_t)__popcll(__ballot(started));
             if (!__any(ln.flags & LF_ALIVE)) break;
+            if (INTEG == TRAY_INTEGRATOR_WHITTED) {
+                Ray cam;
+                cam.o = LN_O(ln); cam.d = ln.d; cam.min_t = 0.0f; cam.max_t = TR_INF; cam.time = ln.time; cam.col = ln.col;
+                ln.illum = whitted_run<ANIM>(sc, scp, my_stack, cam, ln.ks, (ln.flags & LF_ALIVE) != 0u, cnt, w_vertices, w_rays);
+                ln.flags &= ~LF_ALIVE;
+                continue;
+            }
 #ifdef TR_STAGE_CLOCKS
 #define TR_CLK(slot) do { const long long now_ = clock64(); clk[slot] += (unsigned long long)(now_ - clk_t); clk_t = now_; } while (0)
             TR_CLK(6);   // regeneration + film splat
@@ -402,6 +412,13 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
     lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), key_sample(kp, si[i]));
     if (!in_range) ln.flags = 0u;
     uint32_t* const my_stack = s_stack + threadIdx.x;
+    if (sc.integrator == TRAY_INTEGRATOR_WHITTED) {   // the whole recursion of the wave's samples (dev_whitted.h)
+        Ray cam;
+        cam.o = LN_O(ln); cam.d = ln.d; cam.min_t = 0.0f; cam.max_t = TR_INF; cam.time = ln.time; cam.col = ln.col;
+        uint32_t wv = 0u, wr = 0u;
+        ln.illum = whitted_run<ANIM>(sc, scp, my_stack, cam, ln.ks, in_range, cnt, wv, wr);
+        ln.flags = 0u;
+    }
     while (__any(ln.flags & LF_ALIVE)) {
 #pragma nounroll
         for (int stage = 0; stage < 3; ++stage) {
@@ -626,7 +643,9 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         set_error("reconstruction filters wider than 2.0 are not supported by the LDS film window");
         return TRAY_E_UNSUPPORTED;
     }
-    if (f->max_depth > 15) { set_error("pathtracer max_depth > 15 is not supported"); return TRAY_E_UNSUPPORTED; }
+    if (f->integrator > TRAY_INTEGRATOR_WHITTED) { set_error("unknown integrator"); return TRAY_E_INVALID; }
+    if (f->integrator == TRAY_INTEGRATOR_WHITTED && f->max_depth > WH_MAX_DEPTH) { set_error("whitted recursion depth > 16 is not supported"); return TRAY_E_UNSUPPORTED; }
+    if (f->integrator != TRAY_INTEGRATOR_WHITTED && f->max_depth > 15) { set_error("pathtracer max_depth > 15 is not supported"); return TRAY_E_UNSUPPORTED; }
     auto stack_ok = [&](uint32_t first, uint32_t count, bool moving) {   // spline stacks the device evaluates per ray
         if ((uint64_t)first + count > f->n_xf_levels) return false;
         for (uint32_t l = 0; moving && l < count; ++l) {
@@ -737,6 +756,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         // queues, persistent traversal with dynamic fetch) for scenes that go through BVH<Instance>; TRAYHIP_MODE overrides
         s->wavefront = f->n_instances > TR_FLAT_MAX;
         if (const char* m = getenv("TRAYHIP_MODE")) s->wavefront = std::string(m) == "wave";
+        if (f->integrator == TRAY_INTEGRATOR_WHITTED) s->wavefront = false;   // the recursion runs inside the tile kernel only (dev_whitted.h)
     }
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
@@ -838,6 +858,8 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
                 reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL | FEAT_TEX>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL | FEAT_TEX>),
                 reinterpret_cast<const void*>(k_path_tiles<1, FEAT_NONE>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL>),
                 reinterpret_cast<const void*>(k_path_tiles<1, FEAT_SPEC>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL | FEAT_SPEC>),
+                reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>),
+                reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>),
                 reinterpret_cast<const void*>(k_wf_trace<0, 0>), reinterpret_cast<const void*>(k_wf_trace<0, 1>),
                 reinterpret_cast<const void*>(k_wf_trace<1, 0>), reinterpret_cast<const void*>(k_wf_trace<1, 1>),
                 reinterpret_cast<const void*>(k_wf_trace<2, 0>), reinterpret_cast<const void*>(k_wf_trace<2, 1>),
@@ -1035,8 +1057,12 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
 #define PATH_TILES_F(A) do { if (s->feat == FEAT_NONE) PATH_TILES(A, FEAT_NONE); else if (s->feat == FEAT_MERL) PATH_TILES(A, FEAT_MERL); \
                              else if (s->feat == FEAT_SPEC) PATH_TILES(A, FEAT_SPEC); else if (s->feat == (FEAT_MERL | FEAT_SPEC)) PATH_TILES(A, FEAT_MERL | FEAT_SPEC); \
                              else if (s->feat == (FEAT_ALL | FEAT_TEX)) PATH_TILES(A, FEAT_ALL | FEAT_TEX); else PATH_TILES(A, FEAT_ALL); } while (0)
-    if (s->animated) PATH_TILES_F(1);
+#define WHITTED_TILES(A) hipLaunchKernelGGL((k_path_tiles<A, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>), dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, \
+                                             s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, s->d_counter, s->d_stats)
+    if (s->dev.integrator == TRAY_INTEGRATOR_WHITTED) { if (s->animated) WHITTED_TILES(1); else WHITTED_TILES(0); }
+    else if (s->animated) PATH_TILES_F(1);
     else PATH_TILES_F(0);
+#undef WHITTED_TILES
 #undef PATH_TILES_F
 #undef PATH_TILES
     HIP_CHECK(hipGetLastError());

@@ -915,8 +915,10 @@ static TrayHostScene* load_scene(const std::string& text, const std::string& bas
         if (s->max_depth > 15) fail(TRAY_E_UNSUPPORTED, "pathtracer max_depth > 15 is not supported by the device sampler (sample arrays hold <= 16 entries)");
     } else if (ity == "normals_debug") {   // integrator/normals_debug.rs: no parameters
         s->integrator = TRAY_INTEGRATOR_NORMALS_DEBUG;
-    } else if (ity == "whitted") {
-        fail(TRAY_E_UNSUPPORTED, "integrator 'whitted' is outside the hot-path scope (SURVEY 8f); 'pathtracer' and 'normals_debug' are built");
+    } else if (ity == "whitted") {   // scene.rs:306-309: Whitted::new(min_depth) -- the recursion limit is read from the "min_depth" key
+        s->integrator = TRAY_INTEGRATOR_WHITTED;
+        s->max_depth = (uint32_t)need_u64(integ, "min_depth", "The integrator must specify the minimum ray depth", "min_depth must be a number");
+        if (s->max_depth > 16) fail(TRAY_E_UNSUPPORTED, "whitted recursion depth > 16 is not supported (the device keeps one frame per level)");
     } else {
         fail(TRAY_E_PARSE, "Unrecognized integrator type '" + ity + "'");
     }
