@@ -320,9 +320,12 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
     const uint32_t kf = key_frame_host(seed, e.d.frame);
     const int feat = feature_set(e);
     int rc;
-#define EMU_TILES(F)                                                                                                                                              \
-    rc = moving ? launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<1, F>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4) \
-                : launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<0, F>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
+    // tray_scene_create: the instantiation with mis_ray_filter for scenes with a sphere light or specular lobes
+    bool light_filter = (feat & FEAT_SPEC) != 0;
+    for (uint32_t l = 0; l < f->n_lights; ++l)
+        if (f->instances[f->lights[l]].kind != TRAY_INST_POINT_EMITTER && f->instances[f->lights[l]].geom_type == TRAY_GEOM_SPHERE) light_filter = true;
+#define EMU_TILES_L(A, F, L) launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<A, F, TRAY_INTEGRATOR_PATH, L>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
+#define EMU_TILES(F) rc = moving ? (light_filter ? EMU_TILES_L(1, F, true) : EMU_TILES_L(1, F, false)) : (light_filter ? EMU_TILES_L(0, F, true) : EMU_TILES_L(0, F, false))
 #define EMU_WHITTED(A) launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<A, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
     if (e.d.integrator == TRAY_INTEGRATOR_WHITTED) rc = moving ? EMU_WHITTED(1) : EMU_WHITTED(0);   // launch_tiles: one instantiation per ANIM
     else if (feat == FEAT_NONE) EMU_TILES(FEAT_NONE);
@@ -332,6 +335,7 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
     else if (feat == (FEAT_ALL | FEAT_TEX)) EMU_TILES(FEAT_ALL | FEAT_TEX);
     else EMU_TILES(FEAT_ALL);
 #undef EMU_TILES
+#undef EMU_TILES_L
 #undef EMU_WHITTED
     if (stats_out) { stats_out[0] = stats.samples; stats_out[1] = stats.vertices; stats_out[2] = stats.rays; stats_out[3] = (unsigned long long)feat; }
     return rc;
@@ -404,10 +408,10 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
         if (sorted) {   /* wf_round of kernels.hip: one kind-pure shading launch per material kind of the scene */                        \
             EMU_QUERY_KIND(A, TRAY_MAT_MATTE); EMU_QUERY_KIND(A, TRAY_MAT_PLASTIC); EMU_QUERY_KIND(A, TRAY_MAT_METAL); EMU_QUERY_KIND(A, TRAY_MAT_GLASS); \
             EMU_QUERY_KIND(A, TRAY_MAT_ROUGH_GLASS); EMU_QUERY_KIND(A, TRAY_MAT_SPECULAR_METAL); EMU_QUERY_KIND(A, TRAY_MAT_MERL);          \
-        } else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query<A, F>(e.d, pool, n_active, trace == 2 ? nullptr : qc, trace == 2 ? nullptr : qctl); });  \
+        } else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query<A, F>(e.d, pool, n_active, trace == 2 ? nullptr : qc, trace == 2 ? nullptr : qctl, stats.data()); });  \
         EMU_TRACE_STAGE(2, A, qc);                                                                                                          \
     } while (0)
-#define EMU_QUERY_KIND(A, K) do { if (kinds_present & (1u << K)) EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_query_kind<A, K>(e.d, pool, kind_queues.data(), qc, qctl); }); } while (0)
+#define EMU_QUERY_KIND(A, K) do { if (kinds_present & (1u << K)) EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_query_kind<A, K>(e.d, pool, kind_queues.data(), qc, qctl, stats.data()); }); } while (0)
 #define EMU_TRACE_STAGE(S, A, Q)                                                                                                            \
     do {                                                                                                                                    \
         if (trace == 0) EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data()); }, dyn_lds); \

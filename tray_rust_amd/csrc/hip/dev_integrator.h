@@ -73,7 +73,9 @@ enum : uint32_t {
     LF_SPECULAR = 2u,    // previous bounce sampled a specular lobe
     LF_SHADOW = 4u,      // stage B has an occlusion ray to trace
     LF_MIS = 8u,         // stage C has a BSDF-sampled light ray to trace
-    LF_LAST = 16u        // the path ends at this vertex (decided in stage B, applied in stage C)
+    LF_LAST = 16u,       // the path ends at this vertex (decided in stage B, applied in stage C)
+    LF_MIS_MISS = 1024u,     // the BSDF-sampled light ray cannot hit the light's own primitive: it counts as a ray, it is not traced
+    LF_MIS_UNTESTED = 2048u  // LF_MIS set for a specular sample: no Light::pdf looked at the light's primitive (mis_ray_filter)
 };
 enum : uint32_t { WANT_NONE = 0, WANT_LIGHT = 1, WANT_MIS = 2, WANT_PATH = 3 };
 
@@ -172,12 +174,12 @@ TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counte
     ln.bsdf = make_bsdf(sc, hit);
     if (sc.integrator == TRAY_INTEGRATOR_NORMALS_DEBUG) {   // NormalsDebug::illumination (integrator/normals_debug.rs:28-33): (bsdf.n + 1) / 2, the sample is done
         ln.illum = (ln.bsdf.n + mk(1.0f, 1.0f, 1.0f)) / 2.0f;
-        ln.flags &= ~(LF_ALIVE | LF_SHADOW | LF_MIS);
+        ln.flags &= ~(LF_ALIVE | LF_SHADOW | LF_MIS | LF_MIS_MISS | LF_MIS_UNTESTED);
         return;
     }
     ln.direct = mk(0.0f, 0.0f, 0.0f);
     ln.t_vertex = ln.throughput;
-    ln.flags &= ~(LF_SHADOW | LF_MIS | LF_LAST);
+    ln.flags &= ~(LF_SHADOW | LF_MIS | LF_LAST | LF_MIS_MISS | LF_MIS_UNTESTED);
     // sample_one_light (mod.rs:106-111), no 1/p_select (quirk Q6)
     float l1 = lane_1d(sc, ln, SD_L1);
     float fl = l1 * (float)sc.n_lights;
@@ -273,7 +275,7 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want, const f
                 float pl = geom_pdf(light, p_l, wl);
                 if (pl == 0.0f) return WANT_PATH;   // `return direct_light` (mod.rs:146-148)
                 w = power_heuristic(1.0f, pdf, 1.0f, pl);
-            }
+            } else ln.flags |= LF_MIS_UNTESTED;
             // direct += f * li * |cos| * w / pdf_bsdf once li is known (mod.rs:163-165): keep the factors
             ln.mis_f = f;
             ln.li = mk(fabsf(dot(w_i, ln.bsdf.n)), w, pdf);
@@ -334,6 +336,38 @@ TR_DEV void vertex_queries(const DevScene& sc, Lane& ln, bool occluded, bool act
     TR_EMU_PHASE(0);
 #endif
     if ((FEAT & FEAT_TEX) && active) ln.bsdf.mat = table_mat;
+}
+
+// Before stage C. The ray Ray::segment(p, w_i, 0.001, inf) only matters if its closest hit is this light (mod.rs:155-161). If the
+// light's own primitive is missed by the ray as Instance::intersect will see it (object space, direction not renormalised,
+// receiver.rs:29-35) with the ORIGINAL range, it is missed with every smaller max_t the traversal would bring (the range tests of
+// sphere / rectangle / disk only reject more as max_t shrinks) and whatever its boxes say: the hit is not the light, li is black,
+// nothing is added -- such a ray is counted and not traced (LF_MIS -> LF_MIS_MISS). A sphere light's pdf is the cone pdf for ANY
+// direction (sphere.rs:126-140): without this every diffuse vertex of smallpt traced a third full ray (stage C was 15.6 % of its
+// wave cycles; smallpt 576 -> 681 Msamples/s at 64 spp). Rectangle / disk lights answer the same question inside geom_pdf
+// (normalised direction): testing again cost cornell_box 2 %, so the test runs only where no pdf test ran -- sphere lights, and
+// specular samples of any light.
+template <int ANIM>
+TR_DEV void mis_ray_filter(const DevScene& sc, Lane& ln) {
+    if (!(ln.flags & LF_MIS)) return;
+    const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
+    const uint32_t gt = light->geom_type;
+    if (gt != TRAY_GEOM_SPHERE && !(ln.flags & LF_MIS_UNTESTED)) return;
+    f3 p_l, d_l;
+    if (ANIM) {
+        float x[24];
+        instance_xf_at<ANIM>(sc, light, ln.time, ln.col, x);
+        p_l = xf_point_affine(x + 12, ln.bsdf.p);
+        d_l = xf_vector(x + 12, ln.aux_d);
+    } else {
+        p_l = xf_point(light->inv, ln.bsdf.p);
+        d_l = xf_vector(light->inv, ln.aux_d);
+    }
+    float t_;
+    const bool may_hit = gt == TRAY_GEOM_RECT ? rect_test(light->geom_params[0], light->geom_params[1], p_l, d_l, 0.001f, TR_INF, t_)
+                       : (gt == TRAY_GEOM_SPHERE ? sphere_test(light->geom_params[0], p_l, d_l, 0.001f, TR_INF, t_)
+                                                 : disk_test(light->geom_params[0], light->geom_params[1], p_l, d_l, 0.001f, TR_INF, t_));
+    if (!may_hit) ln.flags = (ln.flags & ~LF_MIS) | LF_MIS_MISS;
 }
 
 // Stage C: tail of the BSDF half of estimate_direct (mod.rs:154-166), then path.rs:82 and the

@@ -207,7 +207,9 @@ __device__ __forceinline__ void film_splat_rows_global(const DevScene& sc, float
 // contiguous ranges use chunk_stride = 1; multi-GPU sharding interleaves chunks round-robin.
 // INTEG: the scene's integrator. TRAY_INTEGRATOR_WHITTED runs every camera sample of a wave to its end between two
 // regenerations (dev_whitted.h) inside the same tile / film skeleton; NormalsDebug is a branch of vertex_begin.
-template <int ANIM, int FEAT, int INTEG = TRAY_INTEGRATOR_PATH>
+// LFILT: compile mis_ray_filter in (scenes with a sphere light or specular lobes: the only ones it can act on; its mere presence costs
+// the others 2 %: cornell_box 755 -> 740 Msamples/s at 64 spp).
+template <int ANIM, int FEAT, int INTEG = TRAY_INTEGRATOR_PATH, bool LFILT = false>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const DevScene scv, const uint2* __restrict__ tiles, uint32_t tile_count,
                                                          uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf,
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ counter,
@@ -294,12 +296,14 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
 #pragma nounroll
             for (int stage = 0; stage < 3; ++stage) {
                 const bool alive = (ln.flags & LF_ALIVE) != 0u;
+                if (LFILT && stage == 2 && alive) mis_ray_filter<ANIM>(sc, ln);   // BSDF-sampled light rays that cannot hit the light are counted, not traced
                 const bool want_ray = alive && (stage == 0 || (stage == 1 && (ln.flags & LF_SHADOW)) || (stage == 2 && (ln.flags & LF_MIS)));
                 TraceResult tr_;
                 tr_.hit = false;
                 tr_.rec.t = 0.0f; tr_.rec.inst = 0xffffffffu; tr_.rec.prim = 0u; tr_.rec.b1 = 0.0f; tr_.rec.b2 = 0.0f;
                 const unsigned long long wr_ = __ballot(want_ray);
                 w_rays += (uint32_t)__popcll(wr_);
+                if (LFILT && stage == 2) w_rays += (uint32_t)__popcll(__ballot(alive && (ln.flags & LF_MIS_MISS) != 0u));   // rays proven to miss the light (query_stage): counted like the reference's
                 if (wr_ != 0ull) {
                     const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
                     tr_ = trace<ANIM>(scp, my_stack, r, stage == 1, want_ray);
@@ -423,10 +427,12 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
 #pragma nounroll
         for (int stage = 0; stage < 3; ++stage) {
             const bool alive = (ln.flags & LF_ALIVE) != 0u;
+            if (stage == 2 && alive) mis_ray_filter<ANIM>(sc, ln);
             const bool want_ray = alive && (stage == 0 || (stage == 1 && (ln.flags & LF_SHADOW)) || (stage == 2 && (ln.flags & LF_MIS)));
             TraceResult tr_;
             tr_.hit = false;
             tr_.rec.t = 0.0f; tr_.rec.inst = 0xffffffffu; tr_.rec.prim = 0u; tr_.rec.b1 = 0.0f; tr_.rec.b2 = 0.0f;
+            if (stage == 2 && alive && (ln.flags & LF_MIS_MISS)) cnt.rays++;   // proven to miss the light: counted, not traced
             if (__any(want_ray)) {
                 if (want_ray) cnt.rays++;
                 const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
@@ -510,6 +516,7 @@ struct TrayDeviceScene {
     uint32_t trace_lds_depth = 0, trace_lds_bytes = 0;   // LDS part of the dynamic-fetch kernel's stacks; deeper entries go to d_stack_overflow
     uint32_t* d_stack_overflow = nullptr;
     bool wf_dynamic = true;           // TRAYHIP_WF_TRACE=slot: one thread per pool slot instead (no compaction)
+    bool light_filter = false;        // a sphere light or specular lobes: the tile kernel with mis_ray_filter (dev_integrator.h) compiled in
     bool wf_sort = true;              // material sort of the shading stage (k_wf_begin's LDS counting sort -> k_wf_query_kind); TRAYHIP_WF_SORT=0: off
     uint32_t* d_kind_queues = nullptr;   // WF_MAT_KINDS x n_slots slot indices
     uint32_t mat_kinds_present = 0;   // bit per TRAY_MAT_* kind among the scene's materials
@@ -558,11 +565,11 @@ static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 qgrid, dim3 tgrid, dim3
         hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, qb, qctl, kq);
         hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
         if (kq) {   // kind-pure shading over the sorted queues: one launch per material kind the scene contains
-#define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), qgrid, block, 0, stream, s->dev, s->pool, kq, qc, qctl)
+#define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), qgrid, block, 0, stream, s->dev, s->pool, kq, qc, qctl, s->d_stats)
             WF_QUERY_KIND(TRAY_MAT_MATTE); WF_QUERY_KIND(TRAY_MAT_PLASTIC); WF_QUERY_KIND(TRAY_MAT_METAL); WF_QUERY_KIND(TRAY_MAT_GLASS);
             WF_QUERY_KIND(TRAY_MAT_ROUGH_GLASS); WF_QUERY_KIND(TRAY_MAT_SPECULAR_METAL); WF_QUERY_KIND(TRAY_MAT_MERL);
 #undef WF_QUERY_KIND
-        } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT>), grid, block, 0, stream, s->dev, s->pool, n_active, qc, qctl);
+        } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT>), grid, block, 0, stream, s->dev, s->pool, n_active, qc, qctl, s->d_stats);
         hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
     } else {   // one thread per pool slot in every stage; only the regeneration is compacted
         uint32_t* const none = nullptr;
@@ -572,7 +579,7 @@ static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 qgrid, dim3 tgrid, dim3
         hipLaunchKernelGGL((k_wf_trace<0, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
         hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, none, none, none);
         hipLaunchKernelGGL((k_wf_trace<1, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
-        hipLaunchKernelGGL((k_wf_query<ANIM, FEAT>), grid, block, 0, stream, s->dev, s->pool, n_active, none, none);
+        hipLaunchKernelGGL((k_wf_query<ANIM, FEAT>), grid, block, 0, stream, s->dev, s->pool, n_active, none, none, s->d_stats);
         hipLaunchKernelGGL((k_wf_trace<2, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
     }
 }
@@ -709,6 +716,10 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         if (getenv("TRAYHIP_FEAT_ALL")) s->feat = FEAT_ALL;
         for (const DevMaterial& dm : mats)   // lobes of textured materials are only known per hit; GGX lives in the same instantiation
             if (dm.textured || dm.microfacet == TRAY_MF_GGX) s->feat = FEAT_ALL | FEAT_TEX;
+        s->light_filter = (s->feat & FEAT_SPEC) != 0;
+        for (uint32_t l = 0; l < f->n_lights; ++l)
+            if (f->instances[f->lights[l]].kind != TRAY_INST_POINT_EMITTER && f->instances[f->lights[l]].geom_type == TRAY_GEOM_SPHERE) s->light_filter = true;
+        if (getenv("TRAYHIP_NO_LIGHT_FILTER")) s->light_filter = false;
     }
     for (const DevMaterial& dm : mats) s->mat_kinds_present |= 1u << dm.mat_kind;
     if (f->n_textures) {
@@ -858,6 +869,8 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
                 reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL | FEAT_TEX>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL | FEAT_TEX>),
                 reinterpret_cast<const void*>(k_path_tiles<1, FEAT_NONE>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL>),
                 reinterpret_cast<const void*>(k_path_tiles<1, FEAT_SPEC>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL | FEAT_SPEC>),
+                reinterpret_cast<const void*>(k_path_tiles<0, FEAT_NONE, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<0, FEAT_MERL, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<0, FEAT_SPEC, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<0, FEAT_MERL | FEAT_SPEC, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_PATH, true>),
+                reinterpret_cast<const void*>(k_path_tiles<1, FEAT_NONE, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_SPEC, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL | FEAT_SPEC, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_PATH, true>),
                 reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>),
                 reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>),
                 reinterpret_cast<const void*>(k_wf_trace<0, 0>), reinterpret_cast<const void*>(k_wf_trace<0, 1>),
@@ -1052,8 +1065,9 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     if (s->wavefront) return launch_wavefront(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
     int blocks = (int)std::min<uint32_t>((uint32_t)s->n_blocks, tile_count);
     HIP_CHECK(hipEventRecord(s->ev0, stream));
-#define PATH_TILES(A, F) hipLaunchKernelGGL((k_path_tiles<A, F>), dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, tile_count, chunk, \
-                                            chunk_stride, spp, kf, rgbw_dev, s->d_counter, s->d_stats)
+#define PATH_TILES_L(A, F, L) hipLaunchKernelGGL((k_path_tiles<A, F, TRAY_INTEGRATOR_PATH, L>), dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, \
+                                                 tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, s->d_counter, s->d_stats)
+#define PATH_TILES(A, F) do { if (s->light_filter) PATH_TILES_L(A, F, true); else PATH_TILES_L(A, F, false); } while (0)
 #define PATH_TILES_F(A) do { if (s->feat == FEAT_NONE) PATH_TILES(A, FEAT_NONE); else if (s->feat == FEAT_MERL) PATH_TILES(A, FEAT_MERL); \
                              else if (s->feat == FEAT_SPEC) PATH_TILES(A, FEAT_SPEC); else if (s->feat == (FEAT_MERL | FEAT_SPEC)) PATH_TILES(A, FEAT_MERL | FEAT_SPEC); \
                              else if (s->feat == (FEAT_ALL | FEAT_TEX)) PATH_TILES(A, FEAT_ALL | FEAT_TEX); else PATH_TILES(A, FEAT_ALL); } while (0)
@@ -1065,6 +1079,7 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
 #undef WHITTED_TILES
 #undef PATH_TILES_F
 #undef PATH_TILES
+#undef PATH_TILES_L
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(s->ev1, stream));
     s->timing_valid = true;

@@ -502,7 +502,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
 
 // Stage B shading of pool slot i: the BSDF queries of the vertex (light half, BSDF half, continuation)
 template <int ANIM, int FEAT, uint32_t KM>
-TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, uint32_t flags, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl) {
+TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, uint32_t flags, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl,
+                           DevStats* __restrict__ stats) {
     Lane ln;
     ln.flags = flags;
     ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
@@ -515,6 +516,13 @@ TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, ui
     ln.d = -ld3(pool, F_WO, i);   // (-d is the outgoing direction until the PATH query replaces d)
     ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
     vertex_queries<ANIM, FEAT, KM>(sc, ln, (flags & WF_OCCLUDED) != 0u);
+    mis_ray_filter<ANIM>(sc, ln);
+    {   // BSDF-sampled light rays proven to miss the light: counted like the reference's, never queued
+        const unsigned long long mm = __ballot((ln.flags & LF_MIS_MISS) != 0u);
+        if (mm != 0ull && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)mm) - 1u && stats)
+            atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].rays, (unsigned long long)__popcll(mm));
+        ln.flags &= ~(LF_MIS_MISS | LF_MIS_UNTESTED);
+    }
     st3(pool, F_T, i, ln.throughput);
     if (!(ln.flags & LF_LAST)) { st3(pool, F_O, i, LN_O(ln)); st3(pool, F_D, i, ln.d); }
     if (ln.flags & LF_MIS) {   // the vertex ends in k_wf_advance, after stage C has traced the BSDF-sampled light ray
@@ -543,13 +551,13 @@ __global__ __launch_bounds__(TR_BLOCK, WF_QUERY_WAVES) void k_wf_query(
 #else
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(
 #endif
-    const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl) {
+    const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl, DevStats* __restrict__ stats) {
     const DevScene& sc = scv;
     const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
     if (i >= n_active) return;
     const uint32_t flags = pu(pool, F_FLAGS, i);
     if ((flags & (LF_ALIVE | WF_INVERTEX)) != (LF_ALIVE | WF_INVERTEX)) return;
-    wf_query_slot<ANIM, FEAT, KM_ALL>(sc, pool, i, flags, queue_c, qctl);
+    wf_query_slot<ANIM, FEAT, KM_ALL>(sc, pool, i, flags, queue_c, qctl, stats);
 }
 
 // kind-pure shading: one thread per entry of material kind MK's queue (filled by k_wf_begin's counting sort); only the lobes that
@@ -557,11 +565,11 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(
 // every lane of a wave runs the same material's code
 template <int ANIM, int MK>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_query_kind(const DevScene scv, WfPool pool, const uint32_t* __restrict__ kind_queues,
-                                                            uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl) {
+                                                            uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl, DevStats* __restrict__ stats) {
     const DevScene& sc = scv;
     uint32_t i;
     if (!wf_my_entry(pool, kind_queues + (size_t)MK * WF_SEGS * pool.seg_cap, qctl, 8u + MK, i)) return;
-    wf_query_slot<ANIM, feat_of_material(MK), km_of_material(MK)>(sc, pool, i, pu(pool, F_FLAGS, i), queue_c, qctl);
+    wf_query_slot<ANIM, feat_of_material(MK), km_of_material(MK)>(sc, pool, i, pu(pool, F_FLAGS, i), queue_c, qctl, stats);
 }
 
 // New camera sample for pool slot i of a chunk that works on tile `tile_idx` (multithreaded.rs:90-96)
