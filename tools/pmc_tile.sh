@@ -4,7 +4,7 @@
 set -u
 TAG=${1:-x}; WL=${2:-cornell_box}; PSPP=${3:-64}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p "$OUT"
-D=/tmp/mini_ab
+D=${MINI_AB_DIR:-/tmp/mini_ab}
 cd "$ROOT"; timeout 30 python tools/mini_ab.py prepare $D > /dev/null 2>&1
 cd /tmp; export TMPDIR=/tmp
 for set in "FETCH_SIZE" "WRITE_SIZE" \

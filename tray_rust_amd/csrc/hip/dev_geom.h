@@ -275,48 +275,87 @@ enum : uint32_t { STK_NODE = 0u, STK_INSTANCE = 1u << 30, STK_EXIT_MESH = 2u << 
 // box is hit now and is re-tested when popped, so the accepted candidates and their order are the reference's
 // (bvh.rs:89-127) in about 0.65x the dependent iterations of the one-node-per-step form (measured +6 .. 17 % on
 // mesh scenes). leaf_tmin: entry distance of the leaf box of the last accepted triangle (trace_flat's hazard test).
-TR_DEV bool mesh_traverse(const DevScene& sc, uint32_t* __restrict__ stack, const TrayMesh m, f3 o, f3 d, float min_t, float& max_t,
-                          bool any_hit, uint32_t& prim, float& b1, float& b2, float& leaf_tmin) {
+// Called by ALL lanes of the wave (`participate` = this lane has a ray for the mesh; the instance is wave-uniform in trace_flat).
+// Written in while-while form -- the node step may repeat TR_WW_NODE_STEPS times while TR_WW_NODE_MIN lanes still have a node to
+// test before the (longer) triangle loop runs for the lanes that reached a leaf. Measured on the C4 stand-in at full size
+// (871 200 triangles, 32 spp) the setting hardly matters: 1 / 2 / 4 / 8 / 16 steps = 353.0 / 349.9 / 348.8 / 349.8 / 349.6 Msamples/s.
+// 4 steps / 12 lanes is kept because the cornell_box kernel (which never runs this code: its meshes take the cooperative test) came
+// out 3 % faster with it than with 1 / 1 (772 vs 747 Msamples/s at 64 spp): at 14 000 instructions the tile kernel is larger than
+// the instruction cache and its speed moves by +-2 % with the layout of code it does not even execute.
+// Whatever the setting, every lane performs the same node tests and triangle tests in the same order.
+#ifndef TR_WW_NODE_STEPS
+#define TR_WW_NODE_STEPS 4
+#endif
+#ifndef TR_WW_NODE_MIN
+#define TR_WW_NODE_MIN 12
+#endif
+TR_DEV bool mesh_traverse_ww(const DevScene& sc, uint32_t* __restrict__ stack, const TrayMesh m, bool participate, f3 o, f3 d, float min_t, float& max_t,
+                             bool any_hit, uint32_t& prim, float& b1, float& b2, float& leaf_tmin) {
     const TrayBvhNode* __restrict__ tree = sc.mesh_nodes + m.node_offset;
     const TrayTriVerts* __restrict__ tris = sc.tri_verts + m.tri_offset;
-    f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
+    const f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
+    enum : uint32_t { MW_NODE = 0u, MW_LEAF = 1u, MW_DONE = 2u };
     int sp = 0;
     bool any = false;
     const uint32_t no_node = 0xffffffffu;
-    uint32_t node_a = 0u, node_b = no_node;
+    uint32_t node_a = 0u, node_b = no_node, mode = participate ? MW_NODE : MW_DONE;
+    uint32_t leaf_offset = 0u, leaf_count = 0u;
+    float leaf_t = 0.0f;
     for (;;) {
-        const bool two = node_b != no_node;
-        const float4* qa = reinterpret_cast<const float4*>(tree + node_a);
-        const float4* qb = reinterpret_cast<const float4*>(tree + (two ? node_b : node_a));
-        const float4 alo = qa[0], ahi = qa[1], blo = qb[0], bhi = qb[1];
-        float ta, tb;
-        const bool ha = bbox_hit_t(alo, ahi, o, inv_dir, nx, ny, nz, min_t, max_t, ta);
-        const bool hb = bbox_hit_t(blo, bhi, o, inv_dir, nx, ny, nz, min_t, max_t, tb) && two;
-        if (ha || hb) {
-            if (ha && hb) { stack[sp * TR_BLOCK] = node_b; ++sp; }
-            const uint32_t cur = ha ? node_a : node_b;
-            const uint32_t offset = __float_as_uint(ha ? ahi.z : bhi.z);
-            const uint32_t meta = __float_as_uint(ha ? ahi.w : bhi.w);
-            const uint32_t count = meta & 0xffffu, axis = (meta >> 16) & 0xffu;
-            if (count == 0u) {
-                const bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
-                node_a = neg ? offset : cur + 1u;
-                node_b = neg ? cur + 1u : offset;
-                continue;
-            }
-            for (uint32_t k = 0; k < count; ++k) {
-                float t, bb1, bb2;
-                if (triangle_test(tris + offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
-                    max_t = t; prim = m.tri_offset + offset + k; b1 = bb1; b2 = bb2; any = true;
-                    leaf_tmin = ha ? ta : tb;
-                    if (any_hit) return true;
+#pragma nounroll
+        for (int it = 0; it < TR_WW_NODE_STEPS; ++it) {
+            const bool in_node = mode == MW_NODE;
+            const uint32_t n_node = (uint32_t)__popcll(__ballot(in_node));
+            if (n_node == 0u) break;
+            if (it > 0 && n_node < TR_WW_NODE_MIN && __any(mode == MW_LEAF)) break;
+            if (in_node) {
+                const bool two = node_b != no_node;
+                const float4* qa = reinterpret_cast<const float4*>(tree + node_a);
+                const float4* qb = reinterpret_cast<const float4*>(tree + (two ? node_b : node_a));
+                const float4 alo = qa[0], ahi = qa[1], blo = qb[0], bhi = qb[1];
+                float ta, tb;
+                const bool ha = bbox_hit_t(alo, ahi, o, inv_dir, nx, ny, nz, min_t, max_t, ta);
+                const bool hb = bbox_hit_t(blo, bhi, o, inv_dir, nx, ny, nz, min_t, max_t, tb) && two;
+                if (ha || hb) {
+                    if (ha && hb) { stack[sp * TR_BLOCK] = node_b; ++sp; }
+                    const uint32_t cur = ha ? node_a : node_b;
+                    const uint32_t offset = __float_as_uint(ha ? ahi.z : bhi.z);
+                    const uint32_t meta = __float_as_uint(ha ? ahi.w : bhi.w);
+                    const uint32_t count = meta & 0xffffu, axis = (meta >> 16) & 0xffu;
+                    if (count == 0u) {
+                        const bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
+                        node_a = neg ? offset : cur + 1u;
+                        node_b = neg ? cur + 1u : offset;
+                    } else {
+                        mode = MW_LEAF; leaf_offset = offset; leaf_count = count; leaf_t = ha ? ta : tb;
+                    }
+                } else if (sp == 0) {
+                    mode = MW_DONE;
+                } else {
+                    --sp;
+                    node_a = stack[sp * TR_BLOCK]; node_b = no_node;
                 }
             }
         }
-        if (sp == 0) break;
-        --sp;
-        node_a = stack[sp * TR_BLOCK]; node_b = no_node;
+        if (mode == MW_LEAF) {
+            bool stop = false;
+            for (uint32_t k = 0; k < leaf_count; ++k) {
+                float t, bb1, bb2;
+                if (triangle_test(tris + leaf_offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
+                    max_t = t; prim = m.tri_offset + leaf_offset + k; b1 = bb1; b2 = bb2; any = true;
+                    leaf_tmin = leaf_t;
+                    if (any_hit) { stop = true; break; }
+                }
+            }
+            if (stop || sp == 0) {
+                mode = MW_DONE;
+            } else {
+                --sp;
+                node_a = stack[sp * TR_BLOCK]; node_b = no_node; mode = MW_NODE;
+            }
+        }
+        if (__all(mode == MW_DONE)) break;
     }
     return any;
 }
@@ -515,14 +554,14 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
                 // small mesh: the whole wave enters, lanes without a pending ray only lend their ALUs
                 const LdsF w_lds = TR_LDS_F(stack - threadIdx.x + sc.coop_offset) + (threadIdx.x >> 6) * TR_COOP_WORDS;
                 hit = mesh_leaf_coop(sc, sc.meshes[mesh_id], w_lds, wanted, o, d, min_t, gate_max_t, bound, t, prim, b1, b2, leaf_t, hz);
+            } else if (gt == TRAY_GEOM_MESH) {   // (the instance is wave-uniform: the whole wave enters the while-while traversal)
+                float mt = gate_max_t;   // the mesh's own traversal, from the original max_t
+                hit = mesh_traverse_ww(sc, stack, sc.meshes[mesh_id], wanted, o, d, min_t, mt, any_hit, prim, b1, b2, leaf_t) && mt <= bound;
+                t = mt;
             } else if (wanted) {
                 if (gt == TRAY_GEOM_RECT) hit = rect_test(gp0, gp1, o, d, min_t, bound, t);
                 else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(gp0, o, d, min_t, bound, t);
-                else if (gt == TRAY_GEOM_MESH) {
-                    float mt = gate_max_t;   // the mesh's own traversal, from the original max_t
-                    hit = mesh_traverse(sc, stack, sc.meshes[mesh_id], o, d, min_t, mt, any_hit, prim, b1, b2, leaf_t) && mt <= bound;
-                    t = mt;
-                } else hit = disk_test(gp0, gp1, o, d, min_t, bound, t);
+                else hit = disk_test(gp0, gp1, o, d, min_t, bound, t);
             }
             if (hit) {
                 const float gate_new = fmaxf(box_t, leaf_t);
