@@ -280,8 +280,9 @@ enum : uint32_t { STK_NODE = 0u, STK_INSTANCE = 1u << 30, STK_EXIT_MESH = 2u << 
 // test before the (longer) triangle loop runs for the lanes that reached a leaf. Measured on the C4 stand-in at full size
 // (871 200 triangles, 32 spp) the setting hardly matters: 1 / 2 / 4 / 8 / 16 steps = 353.0 / 349.9 / 348.8 / 349.8 / 349.6 Msamples/s.
 // 4 steps / 12 lanes is kept because the cornell_box kernel (which never runs this code: its meshes take the cooperative test) came
-// out 3 % faster with it than with 1 / 1 (772 vs 747 Msamples/s at 64 spp): at 14 000 instructions the tile kernel is larger than
-// the instruction cache and its speed moves by +-2 % with the layout of code it does not even execute.
+// out 3 % faster with it than with 1 / 1 (772 vs 747 Msamples/s at 64 spp): the tile kernel's speed moves by +-2 % with code it does
+// not even execute (register allocation and scheduling of a 14 000-instruction kernel; not the instruction cache, whose miss
+// rate is 0.1 %, tools/pmc_icache.sh).
 // Whatever the setting, every lane performs the same node tests and triangle tests in the same order.
 #ifndef TR_WW_NODE_STEPS
 #define TR_WW_NODE_STEPS 4
