@@ -385,3 +385,37 @@ def test_whitted_direct_lighting_matches_a_hand_computation(tmp_path, built):
     scene2, *_ = T.Scene.load_file(p2)
     b = O.sample_radiance(scene2.flatten(0), px, py, si, spp, seed=1)
     assert (b[:, :3] == 0).all() and (b[:, 6] == 1).all()   # li is black: no shadow ray is traced (whitted.rs:59)
+
+
+def test_whitted_on_a_moving_scene(tmp_path, built):
+    """Whitted with every kind of motion of the reference (camera spline, moving sphere / group / lights, two lights: the per-light loop):
+    the ANIM instantiation of the frame stack against the recursive oracle. Per-ray slerp runs in f64 on both sides here (same libm)."""
+    import _emu as E
+    w, h, spp = 32, 24, 4
+    d = scenes.moving_box(w, h, spp)
+    d["integrator"] = {"type": "whitted", "min_depth": 3}
+    d["materials"].append({"type": "glass", "name": "wh_glass", "reflect": [1, 1, 1], "transmit": [1, 1, 1], "eta": 1.5})
+    for o in d["objects"]:
+        if o.get("geometry", {}).get("type") == "sphere" and o.get("type") == "receiver": o["material"] = "wh_glass"   # both children at every hit
+    scenes.write_moving_box(str(tmp_path), width=w, height=h, samples=spp)
+    p = os.path.join(str(tmp_path), "moving_wh.json")
+    json.dump(d, open(p, "w"))
+    scene, *_ = T.Scene.load_file(p)
+    flat = scene.flatten(3)
+    assert flat.contents.integrator == 2 and flat.contents.animated and flat.contents.n_lights >= 2
+    rng = np.random.default_rng(5)
+    n = 2000
+    px = rng.integers(0, w, n).astype(np.uint32); py = rng.integers(0, h, n).astype(np.uint32); si = rng.integers(0, spp, n).astype(np.uint32)
+    a = O.sample_radiance(flat, px, py, si, spp, seed=3)
+    b = E.sample_radiance(flat, px, py, si, spp, 3)
+    assert a[:, 5].max() >= 3 and a[:, 6].max() >= 4
+    same = (a == b).all(axis=1).mean()
+    diff = np.abs(a[:, :3] - b[:, :3]).max(axis=1)
+    print(f"whitted moving: {same:.4f} of the samples bit-identical, {(diff > 1e-5).mean():.4f} differ by more than 1e-5, max {diff.max():.3g}")
+    assert same > 0.98 and (diff > 1e-4).mean() < 5e-3   # (the slerp of the per-ray transforms: float on the device, a few samples take another turn)
+    tiles = np.array([(x, y) for y in range(h // 8) for x in range(w // 8)], np.uint32)
+    ref, ost = O.render_tiles(flat, spp, seed=3)
+    rgb = lambda i: i[..., :3] / np.maximum(i[..., 3:], 1e-20)
+    img, st = E.render_tiles(flat, tiles, spp, 3, blocks=2)
+    assert st[0] == ost.samples and abs(st[1] - ost.vertices) <= 2e-3 * ost.vertices
+    assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-3
