@@ -319,14 +319,18 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
     std::memset(&stats, 0, sizeof stats);
     const uint32_t kf = key_frame_host(seed, e.d.frame);
     const int feat = feature_set(e);
+    uint32_t slice_shift = 0u;   // launch_tiles' rule: tiles are cut into sample slices when there are few of them per workgroup
+    if ((spp >> 1) >= 256u && work < 12u * blocks) slice_shift = 1u;
+    if ((spp >> 2) >= 256u && work < 3u * blocks) slice_shift = 2u;
+    if (const char* e_ = getenv("TRAYHIP_TILE_SLICES")) { slice_shift = 0u; while ((2u << slice_shift) <= (uint32_t)std::max(1, atoi(e_)) && (spp >> (slice_shift + 1u)) >= 4u) ++slice_shift; }
     int rc;
     // tray_scene_create: the instantiation with mis_ray_filter for scenes with a sphere light or specular lobes
     bool light_filter = (feat & FEAT_SPEC) != 0;
     for (uint32_t l = 0; l < f->n_lights; ++l)
         if (f->instances[f->lights[l]].kind != TRAY_INST_POINT_EMITTER && f->instances[f->lights[l]].geom_type == TRAY_GEOM_SPHERE) light_filter = true;
-#define EMU_TILES_L(A, F, L) launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<A, F, TRAY_INTEGRATOR_PATH, L>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
+#define EMU_TILES_L(A, F, L) launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<A, F, TRAY_INTEGRATOR_PATH, L>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, slice_shift, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
 #define EMU_TILES(F) rc = moving ? (light_filter ? EMU_TILES_L(1, F, true) : EMU_TILES_L(1, F, false)) : (light_filter ? EMU_TILES_L(0, F, true) : EMU_TILES_L(0, F, false))
-#define EMU_WHITTED(A) launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<A, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
+#define EMU_WHITTED(A) launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<A, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, slice_shift, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
     if (e.d.integrator == TRAY_INTEGRATOR_WHITTED) rc = moving ? EMU_WHITTED(1) : EMU_WHITTED(0);   // launch_tiles: one instantiation per ANIM
     else if (feat == FEAT_NONE) EMU_TILES(FEAT_NONE);
     else if (feat == FEAT_MERL) EMU_TILES(FEAT_MERL);

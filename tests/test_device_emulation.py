@@ -225,6 +225,22 @@ def test_tile_megakernel_partial_queue_and_idle_workgroups(tmp_path, built):
     assert np.abs((a + b) - full).max() < 1e-4 * full.max()
 
 
+def test_tile_slices_are_the_same_samples(tmp_path, built, monkeypatch):
+    """launch_tiles cuts tiles into slices of their samples when a launch has few tiles per workgroup (a GPU's share of the frame
+    on an 8-GPU node): the slices of a tile are independent work items whose film contributions add up. Same samples, vertices and
+    rays as the oracle's whole tiles, same image."""
+    w, h, spp = 32, 24, 16
+    scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
+    scene, *_ = T.Scene.load_file(str(tmp_path / "smallpt.json"))
+    flat = scene.flatten(0)
+    ref, st = O.render_tiles(flat, spp, seed=4)
+    for slices in ("1", "4"):   # 4 slices of 4 samples: one sample per wave and slice
+        monkeypatch.setenv("TRAYHIP_TILE_SLICES", slices)
+        img, s_ = E.render_tiles(flat, tile_queue(w, h), spp, 4, blocks=3)
+        assert s_[:3] == (st.samples, st.vertices, st.rays)
+        assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6
+
+
 @pytest.fixture(scope="module")
 def tr15_dir(tmp_path_factory):
     import pathlib

@@ -211,7 +211,7 @@ __device__ __forceinline__ void film_splat_rows_global(const DevScene& sc, float
 // the others 2 %: cornell_box 755 -> 740 Msamples/s at 64 spp).
 template <int ANIM, int FEAT, int INTEG = TRAY_INTEGRATOR_PATH, bool LFILT = false>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const DevScene scv, const uint2* __restrict__ tiles, uint32_t tile_count,
-                                                         uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf,
+                                                         uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf, uint32_t slice_shift,
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ counter,
                                                          DevStats* __restrict__ stats) {
     __shared__ float s_win[4 * WIN_PLANE];
@@ -243,14 +243,19 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
         if (film_rows)
             for (uint32_t i = tid; i < ROWBIN_SIZE; i += TR_BLOCK) s_rowbin[i] = 0.0f;
         __syncthreads();
-        const uint32_t ti = s_tile;
-        if (ti >= tile_count) break;
+        // a work item is one SLICE of a tile: samples [sl, sl + 1) * (spp >> slice_shift) of its 64 pixels. The film is a sum, so the
+        // slices of a tile are independent; launch_tiles cuts tiles when there are too few of them per workgroup for an even finish
+        // (a GPU's share of the frame at 8 GPUs is 5.3 tiles per workgroup: 6 rounds of whole tiles, or 5.3 rounds of sixteenths)
+        const uint32_t item = s_tile;
+        if ((item >> slice_shift) >= tile_count) break;
+        const uint32_t ti = item >> slice_shift;
+        const uint32_t s_per_slice = spp >> slice_shift, s_lo = (item & ((1u << slice_shift) - 1u)) * s_per_slice, s_hi = s_lo + s_per_slice;
         const uint2 tile = tiles[(ti / chunk) * chunk_stride * chunk + (ti % chunk)];
         const int x0 = (int)tile.x * 8, y0 = (int)tile.y * 8;
         const uint32_t px = (uint32_t)x0 + (lane & 7u), py = (uint32_t)y0 + (lane >> 3);   // Region order: x fastest (ld.rs:47-51)
         const uint32_t kp = key_pixel(kf, py * sc.width + px);
 
-        uint32_t s_next = wave;
+        uint32_t s_next = s_lo + wave;
         bool pending = false;
         float sx = 0.0f, sy = 0.0f;
         Lane ln;
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
                     else film_splat(sc, s_win, s_table, x0, y0, sx, sy, lane_result(ln));
                     pending = false;
                 }
-                if (s_next < spp) {
+                if (s_next < s_hi) {
                     float t;
                     pixel_sample(kp, s_next, spp, px, py, sx, sy, t);
                     lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), key_sample(kp, s_next));
@@ -1063,16 +1068,24 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     kf = mix(kf ^ (uint32_t)(seed >> 32));
     kf = mix(kf + s->dev.frame);
     if (s->wavefront) return launch_wavefront(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
-    int blocks = (int)std::min<uint32_t>((uint32_t)s->n_blocks, tile_count);
+    // Slices per tile. A slice costs its own film resolve and flush, so tiles are only halved (quartered) when a launch has fewer than
+    // 12 (3) of them per workgroup and a slice keeps >= 256 samples per pixel -- measured on one GPU's share of C2 at 8 GPUs (4050
+    // tiles, tools/shard_tail.py): 1 / 2 / 4 / 8 / 16 slices = 797.8 / 836.6 / 819.1 / 809.5 / 772.7 Msamples/s; at 4 GPUs 851.8 /
+    // 859.2 / 846.2 / 819.1; the whole frame on one GPU loses 1 % with 2. TRAYHIP_TILE_SLICES overrides.
+    uint32_t slice_shift = 0u;
+    if ((spp >> 1) >= 256u && tile_count < 12u * (uint32_t)s->n_blocks) slice_shift = 1u;
+    if ((spp >> 2) >= 256u && tile_count < 3u * (uint32_t)s->n_blocks) slice_shift = 2u;
+    if (const char* e = getenv("TRAYHIP_TILE_SLICES")) { slice_shift = 0u; while ((2u << slice_shift) <= (uint32_t)std::max(1, atoi(e)) && (spp >> (slice_shift + 1u)) >= 4u) ++slice_shift; }
+    int blocks = (int)std::min<uint64_t>((uint64_t)s->n_blocks, (uint64_t)tile_count << slice_shift);
     HIP_CHECK(hipEventRecord(s->ev0, stream));
 #define PATH_TILES_L(A, F, L) hipLaunchKernelGGL((k_path_tiles<A, F, TRAY_INTEGRATOR_PATH, L>), dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, \
-                                                 tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, s->d_counter, s->d_stats)
+                                                 tile_count, chunk, chunk_stride, spp, kf, slice_shift, rgbw_dev, s->d_counter, s->d_stats)
 #define PATH_TILES(A, F) do { if (s->light_filter) PATH_TILES_L(A, F, true); else PATH_TILES_L(A, F, false); } while (0)
 #define PATH_TILES_F(A) do { if (s->feat == FEAT_NONE) PATH_TILES(A, FEAT_NONE); else if (s->feat == FEAT_MERL) PATH_TILES(A, FEAT_MERL); \
                              else if (s->feat == FEAT_SPEC) PATH_TILES(A, FEAT_SPEC); else if (s->feat == (FEAT_MERL | FEAT_SPEC)) PATH_TILES(A, FEAT_MERL | FEAT_SPEC); \
                              else if (s->feat == (FEAT_ALL | FEAT_TEX)) PATH_TILES(A, FEAT_ALL | FEAT_TEX); else PATH_TILES(A, FEAT_ALL); } while (0)
 #define WHITTED_TILES(A) hipLaunchKernelGGL((k_path_tiles<A, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>), dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, \
-                                             s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, s->d_counter, s->d_stats)
+                                             s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf, slice_shift, rgbw_dev, s->d_counter, s->d_stats)
     if (s->dev.integrator == TRAY_INTEGRATOR_WHITTED) { if (s->animated) WHITTED_TILES(1); else WHITTED_TILES(0); }
     else if (s->animated) PATH_TILES_F(1);
     else PATH_TILES_F(0);
