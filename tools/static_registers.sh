@@ -14,7 +14,7 @@ T=$(mktemp -d)
   /\.group_segment_fixed_size:/ {lds=$2}
   /\.sgpr_count:/ {sg=$2}
   /\.vgpr_count:/ {v=$2}
-  /\.vgpr_spill_count:/ {sp=$2; if (name ~ /k_path_tilesILi0ELi0E/) { printf "{\"device_code_hash\": \"%s\", \"kernel\": \"k_path_tiles<0,0>\", \"vgprs\": %d, \"spilled_vgprs\": %d, \"scratch_bytes_per_lane\": %d, \"sgprs\": %d, \"sgprs_spilled_to_vgpr_lanes\": %d, \"static_lds_bytes\": %d, \"waves_per_simd_by_vgprs\": %d}\n", hash, v, sp, scr, sg, ss, lds, (v <= 64 ? 8 : (v <= 72 ? 7 : (v <= 80 ? 6 : (v <= 96 ? 5 : (v <= 128 ? 4 : (v <= 168 ? 3 : (v <= 256 ? 2 : 1))))))) > "profiles/static_registers_latest.json" }
+  /\.vgpr_spill_count:/ {sp=$2; if (name ~ /k_path_tilesILi0ELi0ELi0ELb0E/) { printf "{\"device_code_hash\": \"%s\", \"kernel\": \"k_path_tiles<0,0>\", \"vgprs\": %d, \"spilled_vgprs\": %d, \"scratch_bytes_per_lane\": %d, \"sgprs\": %d, \"sgprs_spilled_to_vgpr_lanes\": %d, \"static_lds_bytes\": %d, \"waves_per_simd_by_vgprs\": %d}\n", hash, v, sp, scr, sg, ss, lds, (v <= 64 ? 8 : (v <= 72 ? 7 : (v <= 80 ? 6 : (v <= 96 ? 5 : (v <= 128 ? 4 : (v <= 168 ? 3 : (v <= 256 ? 2 : 1))))))) > "profiles/static_registers_latest.json" }
     if (name ~ /k_path_tiles|k_wf_/) printf "%-60s vgprs %3d  spilled %3d  scratch %4d B  sgprs %3d (%3d spilled to lanes)  lds %d\n", substr(name,1,60), v, sp, scr, sg, ss, lds}'
 cat profiles/static_registers_latest.json
 rm -rf $T
