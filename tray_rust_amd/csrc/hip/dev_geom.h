@@ -325,7 +325,8 @@ TR_DEV bool mesh_traverse_ww(const DevScene& sc, uint32_t* __restrict__ stack, c
                     const uint32_t meta = __float_as_uint(ha ? ahi.w : bhi.w);
                     const uint32_t count = meta & 0xffffu, axis = (meta >> 16) & 0xffu;
                     if (count == 0u) {
-                        const bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
+                        // any-hit rays take the child on the light's side first (the boolean does not depend on the order; C4 stand-in +2.5 %)
+                        const bool neg = (axis == 0u ? nx : (axis == 1u ? ny : nz)) != any_hit;
                         node_a = neg ? offset : cur + 1u;
                         node_b = neg ? cur + 1u : offset;
                     } else {
@@ -613,7 +614,7 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
         bool descend = false;
         if (bbox_hit(lo, hi, o, inv_dir, nx, ny, nz, min_t, max_t)) {
             if (count == 0u) {   // interior: near child first by the sign of the split axis (bvh.rs:105-119)
-                bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
+                bool neg = (axis == 0u ? nx : (axis == 1u ? ny : nz)) != any_hit;   // (any-hit: light's side first, see mesh_traverse_ww)
                 uint32_t far_child = neg ? current + 1u : offset;
                 current = neg ? offset : current + 1u;
                 stack[sp * TR_BLOCK] = far_child;

@@ -304,7 +304,10 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                     cur_count = meta & 0xffffu;
                     if (cur_count == 0u) {   // interior: near child first by the sign of the split axis (bvh.rs:105-119)
                         const uint32_t axis = (meta >> 16) & 0xffu;
-                        const bool neg = axis == 0u ? nx : (axis == 1u ? ny : nz);
+                        // Occlusion rays (STAGE 1) visit the child on the LIGHT's side first: the boolean does not depend on the order (until a
+                        // candidate is accepted max_t is the original one, so one is accepted iff a valid candidate exists at all), the
+                        // rays of a light converge there, and what blocks a light tends to sit near it: +1.4 % on the C5 stand-in.
+                        const bool neg = (axis == 0u ? nx : (axis == 1u ? ny : nz)) != (STAGE == 1);
                         node_a = neg ? cur_offset : cur + 1u;
                         node_b = neg ? cur + 1u : cur_offset;
                     } else {
