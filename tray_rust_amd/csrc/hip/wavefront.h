@@ -549,11 +549,7 @@ TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, ui
 
 // one thread per pool slot, every material kind's code (TRAYHIP_WF_SORT=0, or the slot form of the schedule)
 template <int ANIM, int FEAT>
-#ifdef WF_QUERY_WAVES   // staged knob: compile the shading kernel of the wavefront schedule for this many waves per SIMD (default: whatever 239 VGPRs allow, 2)
-__global__ __launch_bounds__(TR_BLOCK, WF_QUERY_WAVES) void k_wf_query(
-#else
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(
-#endif
     const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl, DevStats* __restrict__ stats) {
     const DevScene& sc = scv;
     const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
