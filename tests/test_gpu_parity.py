@@ -564,3 +564,48 @@ def test_whitted_integrator(name, depth, tmp_path):
     print(f"whitted {name} depth {depth} 160x96x16: RMSE {r:.3e}, {st.vertices / st.samples:.2f} activations and {st.rays / st.samples:.2f} rays per sample")
     assert r < 1e-4
     scene.release_device()
+
+
+def test_random_scene_sweep_on_the_gpu(tmp_path):
+    """What only the real compiler and the real chip can get wrong (round 2's SLP-vectoriser miscompile showed up as a wrong IMAGE of the
+    tile kernel while the debug kernel and the host emulation were right): 18 random scenes of tests/_random_scenes.py -- every material
+    kind, sphere / disk / rectangle / mesh, point and area lights, nested groups, both filters, depths 0..10; every third one with
+    more than 16 instances (wavefront schedule) -- rendered by the schedule the library picks, against the oracle's image, and the
+    per-sample debug kernel against the oracle's samples."""
+    import json
+    import _random_scenes as R
+    d = str(tmp_path)
+    worst = 0.0
+    for seed in range(200, 218):
+        p = R.write_random_scene(d, seed)
+        desc = json.load(open(p))
+        if seed % 3 == 0:
+            rng = np.random.default_rng(seed)
+            for k in range(14):
+                desc["objects"].append({"name": f"x{k}", "type": "receiver", "material": desc["materials"][k % len(desc["materials"])]["name"],
+                                        "geometry": {"type": "sphere", "radius": float(rng.uniform(0.3, 1.2))},
+                                        "transform": [{"type": "translate", "translation": [float(x) for x in rng.uniform([-12, 1, -12], [12, 20, 14])]}]})
+        desc["film"]["samples"] = 16
+        json.dump(desc, open(p, "w"))
+        scene, rt, spp, fi = T.Scene.load_file(p)
+        flat = scene.flatten(0)
+        w, h = flat.contents.film.width, flat.contents.film.height
+        rng = np.random.default_rng(seed)
+        n = 20000
+        px = rng.integers(0, w, n).astype(np.uint32); py = rng.integers(0, h, n).astype(np.uint32); si = rng.integers(0, spp, n).astype(np.uint32)
+        a = O.sample_radiance(flat, px, py, si, spp, seed=seed + 1)
+        b = gpu_radiance(scene, px, py, si, spp, seed + 1)
+        ok = np.isfinite(a).all(axis=1) & np.isfinite(b).all(axis=1)
+        assert (np.isfinite(a).all(axis=1) == np.isfinite(b).all(axis=1)).mean() > 0.999
+        dd = np.abs(a[ok, :3] - b[ok, :3]).max(axis=1)
+        assert (a[ok, 5] == b[ok, 5]).mean() > 0.998 and (dd > 1e-3).mean() < 2e-3, (seed, (dd > 1e-3).mean())
+        gpu, tim = gpu_render(scene, rt, spp, fi, seed=seed + 1)
+        cpu, st = O.render_tiles(flat, spp, seed=seed + 1)
+        assert tim.samples == st.samples and abs(int(tim.vertices) - int(st.vertices)) <= 2e-3 * st.vertices + 2
+        fin = np.isfinite(rgb(gpu)).all(axis=2) & np.isfinite(rgb(cpu)).all(axis=2)
+        diff = np.abs(rgb(gpu) - rgb(cpu))[fin]
+        r = float(np.sqrt(np.mean(diff ** 2)))
+        worst = max(worst, r)
+        assert fin.mean() > 0.999 and r < 1e-4 and (diff.max(axis=-1) > 1e-2).mean() < 2e-3, (seed, r)   # (worst of the 18 on an MI355X: 1e-6)
+        scene.release_device()
+    print(f"random scenes on the GPU: worst image RMSE {worst:.3e}")
