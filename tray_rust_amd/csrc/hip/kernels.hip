@@ -219,11 +219,11 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
     __shared__ float s_rowbin[ROWBIN_SIZE];
     __shared__ float s_tx[TRAY_FILTER_TABLE_SIZE], s_ty[TRAY_FILTER_TABLE_SIZE];
     TR_DYN_LDS(uint32_t, s_stack);   // stack_depth x TR_BLOCK entries, sized per scene at launch
-    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_tile, s_next_sample;
     const DevScene& sc = scv;
     const DevScene* const scp = &scv;
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t lane = tid & 63u;
     uint32_t* const my_stack = s_stack + tid;
     s_table[tid] = sc.filter_table[tid];
     if (tid < TRAY_FILTER_TABLE_SIZE) { s_tx[tid] = sc.filter_x[tid]; s_ty[tid] = sc.filter_y[tid]; }
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
 #endif
     for (;;) {
         __syncthreads();   // previous tile fully flushed
-        if (tid == 0) s_tile = atomicAdd(counter, 1u);
+        if (tid == 0) { s_tile = atomicAdd(counter, 1u); s_next_sample = 0u; }
         for (uint32_t i = tid; i < 4 * WIN_PLANE; i += TR_BLOCK) s_win[i] = 0.0f;
         if (film_rows)
             for (uint32_t i = tid; i < ROWBIN_SIZE; i += TR_BLOCK) s_rowbin[i] = 0.0f;
@@ -249,13 +249,17 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
         const uint32_t item = s_tile;
         if ((item >> slice_shift) >= tile_count) break;
         const uint32_t ti = item >> slice_shift;
-        const uint32_t s_per_slice = spp >> slice_shift, s_lo = (item & ((1u << slice_shift) - 1u)) * s_per_slice, s_hi = s_lo + s_per_slice;
+        const uint32_t s_per_slice = spp >> slice_shift, s_lo = (item & ((1u << slice_shift) - 1u)) * s_per_slice;
         const uint2 tile = tiles[(ti / chunk) * chunk_stride * chunk + (ti % chunk)];
         const int x0 = (int)tile.x * 8, y0 = (int)tile.y * 8;
-        const uint32_t px = (uint32_t)x0 + (lane & 7u), py = (uint32_t)y0 + (lane >> 3);   // Region order: x fastest (ld.rs:47-51)
-        const uint32_t kp = key_pixel(kf, py * sc.width + px);
-
-        uint32_t s_next = s_lo + wave;
+        // The (pixel, sample) pairs of the slice are handed out dynamically: a lane whose path ended takes the next pair of the
+        // workgroup's LDS counter -- pixel = pair % 64 in Region order (x fastest, ld.rs:47-51), sample = s_lo + pair / 64 -- whatever
+        // pixel that is. With a fixed pixel per lane the lanes of a wave finish their 256 samples up to ~90 path vertices apart (the
+        // sum of 256 path lengths has that spread) and idle until the last one is done; now the tile ends within one path length.
+        // Every sample is keyed by its pixel and index (TRAY-CBRNG), so who computes it does not matter.
+        const uint32_t n_pairs = 64u * s_per_slice;
+        bool pairs_left = true;   // wave-uniform
+        uint32_t row_l = 0u;       // pixel row (0..7) of the lane's current sample: row bin of the film
         bool pending = false;
         float sx = 0.0f, sy = 0.0f;
         Lane ln;
@@ -266,19 +270,29 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
 #endif
         for (;;) {   // one path vertex per live lane and step
             bool started = false;
-            if (!(ln.flags & LF_ALIVE)) {
-                // the previous sample of this lane is finished: RenderTarget::write it, start the next one
-                if (pending) {
-                    if (film_rows) film_splat_rows(sc, s_rowbin, s_tx, s_win, s_table, x0, y0, (int)(lane >> 3), sx, sy, lane_result(ln));
-                    else film_splat(sc, s_win, s_table, x0, y0, sx, sy, lane_result(ln));
-                    pending = false;
-                }
-                if (s_next < s_hi) {
+            const bool idle = !(ln.flags & LF_ALIVE);
+            if (idle && pending) {   // the previous sample of this lane is finished: RenderTarget::write it
+                if (film_rows) film_splat_rows(sc, s_rowbin, s_tx, s_win, s_table, x0, y0, (int)row_l, sx, sy, lane_result(ln));
+                else film_splat(sc, s_win, s_table, x0, y0, sx, sy, lane_result(ln));
+                pending = false;
+            }
+            const unsigned long long idle_m = __ballot(idle);
+            if (pairs_left && idle_m != 0ull) {   // ... and start the next one: one LDS atomic per wave reserves a pair for every idle lane
+                const uint32_t n_idle = (uint32_t)__popcll(idle_m), leader = (uint32_t)__ffsll((long long)idle_m) - 1u;
+                uint32_t base = 0u;
+                if (lane == leader) base = atomicAdd(&s_next_sample, n_idle);
+                base = __shfl(base, (int)leader);
+                pairs_left = base + n_idle < n_pairs;
+                const uint32_t pair = base + (uint32_t)__popcll(idle_m & ((1ull << lane) - 1ull));
+                if (idle && pair < n_pairs) {
+                    const uint32_t pix = pair & 63u, s = s_lo + (pair >> 6);
+                    const uint32_t px = (uint32_t)x0 + (pix & 7u), py = (uint32_t)y0 + (pix >> 3);
+                    const uint32_t kp = key_pixel(kf, py * sc.width + px);
                     float t;
-                    pixel_sample(kp, s_next, spp, px, py, sx, sy, t);
-                    lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), key_sample(kp, s_next));
+                    pixel_sample(kp, s, spp, px, py, sx, sy, t);
+                    lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), key_sample(kp, s));
                     if (ANIM) { ln.col = xf_cache_lane(); xf_cache_fill(sc, ln.time, ln.col); }   // the path's transforms of the moving instances, once per camera sample
-                    s_next += TR_BLOCK / 64;
+                    row_l = pix >> 3;
                     started = true;
                     pending = true;
                 }
