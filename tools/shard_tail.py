@@ -6,16 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if len(sys.argv) > 3:   # child: one measurement (the library reads TRAYHIP_TILE_SLICES per launch, a fresh process keeps things simple)
     import tray_rust_amd as T
-    from tray_rust_amd import scenes, _lib as L
+    from tray_rust_amd import scenes
     name, spp, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     d = "/tmp/shard_tail"
     scenes.write_assets(d, cornell=(1920, 1080, spp), small=(1920, 1080, spp))
     scene, rt, _, fi = T.Scene.load_file(os.path.join(d, name + ".json"))
     hip = T.Hip(0, seed=1)
-    lib = L.lib()
     buf = ctypes.c_void_p()
-    assert lib.hipMalloc is None if False else True
-    import numpy as np
     hiprt = ctypes.CDLL("libamdhip64.so")
     nbytes = 1920 * 1080 * 4 * 4
     assert hiprt.hipMalloc(ctypes.byref(buf), ctypes.c_size_t(nbytes)) == 0 and hiprt.hipMemset(buf, 0, ctypes.c_size_t(nbytes)) == 0
