@@ -45,7 +45,8 @@ struct WfPool {
     uint32_t n_slots;
     uint32_t seg_cap;           // entries per segment of every queue (wf_seg_cap(chunks of the pool)); a queue holds WF_SEGS * seg_cap
 };
-struct WfChunk { uint32_t tile, done; };   // tile: index into the work list, WF_TILE_NEED or WF_TILE_IDLE
+struct WfChunk { uint32_t tile, done, next_pair; };   // tile: index into the work list, WF_TILE_NEED or WF_TILE_IDLE; done: finished samples of the
+                                                       // tile; next_pair: first (pixel, sample) pair of the tile not handed to a slot yet
 enum : uint32_t { WF_TILE_NEED = 0xfffffffeu, WF_TILE_IDLE = 0xffffffffu };
 
 TR_DEV float& pf(const WfPool& p, int f, uint32_t i) { return p.data[(size_t)f * p.n_slots + i]; }
@@ -575,16 +576,15 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query_kind(const DevScene scv, 
 template <int ANIM>
 TR_DEV void wf_regenerate(const DevScene& sc, const WfPool& pool, uint32_t i, uint32_t tile_idx, const uint2* __restrict__ tiles, uint32_t chunk,
                           uint32_t chunk_stride, uint32_t spp, uint32_t kf, DevStats* __restrict__ stats) {
-    const uint32_t lane = i & 63u;
-    const uint32_t s_next = pu(pool, F_SNEXT, i);
+    // F_SNEXT: the (pixel, sample) pair k_wf_advance handed to this slot: pixel = pair % 64 in Region order, sample = pair / 64
+    const uint32_t pair = pu(pool, F_SNEXT, i), pix = pair & 63u, s_next = pair >> 6;
     const uint2 tile = tiles[(tile_idx / chunk) * chunk_stride * chunk + (tile_idx % chunk)];
-    const uint32_t px = tile.x * 8u + (lane & 7u), py = tile.y * 8u + (lane >> 3);
+    const uint32_t px = tile.x * 8u + (pix & 7u), py = tile.y * 8u + (pix >> 3);
     const uint32_t kp = key_pixel(kf, py * sc.width + px);
     float sx, sy, t;
     pixel_sample(kp, s_next, spp, px, py, sx, sy, t);
     const Ray cam = camera_ray<ANIM>(sc, sx, sy, t);
     if (ANIM) { pf(pool, F_TIME, i) = cam.time; xf_cache_fill(sc, cam.time, i); }
-    pu(pool, F_SNEXT, i) = s_next + TR_BLOCK / 64;
     pu(pool, F_BOUNCE, i) = 0u;
     pu(pool, F_KS, i) = key_sample(kp, s_next);
     pf(pool, F_SX, i) = sx; pf(pool, F_SY, i) = sy;
@@ -620,14 +620,14 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
     __shared__ float s_win[4 * WIN_PLANE];
     __shared__ float s_table[TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE];
     __shared__ float s_tx[TRAY_FILTER_TABLE_SIZE], s_ty[TRAY_FILTER_TABLE_SIZE];
-    __shared__ uint32_t s_tile, s_done, s_fin;
+    __shared__ uint32_t s_tile, s_done, s_fin, s_pair;
     __shared__ float s_bins[ROWBIN_SIZE];   // this round's contribution to the chunk's row bins
     const DevScene& sc = scv;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, sub = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t c = blockIdx.x;
     const uint32_t i = c * TR_BLOCK + tid;
     float* __restrict__ my_bins = bins + (size_t)c * ROWBIN_SIZE;
-    if (tid == 0) { s_tile = chunks[c].tile; s_done = chunks[c].done; s_fin = 0u; }
+    if (tid == 0) { s_tile = chunks[c].tile; s_done = chunks[c].done; s_pair = chunks[c].next_pair; s_fin = 0u; }
     s_table[tid] = sc.filter_table[tid];
     if (tid < TRAY_FILTER_TABLE_SIZE) { s_tx[tid] = sc.filter_x[tid]; s_ty[tid] = sc.filter_y[tid]; }
     for (uint32_t k = tid; k < ROWBIN_SIZE; k += TR_BLOCK) s_bins[k] = 0.0f;
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
             const f3 il = ld3(pool, F_ILLUM, i);
             const float sx = pf(pool, F_SX, i), sy = pf(pool, F_SY, i);
             const f3 col = mk(clampf(il.x, 0.0f, 1.0f), clampf(il.y, 0.0f, 1.0f), clampf(il.z, 0.0f, 1.0f));   // quirk Q3
-            if (film_rows) film_splat_rows_global<true>(sc, s_bins, s_tx, rgbw, s_table, x0, y0, (int)(lane >> 3), sx, sy, col);
+            if (film_rows) film_splat_rows_global<true>(sc, s_bins, s_tx, rgbw, s_table, x0, y0, (int)((pu(pool, F_SNEXT, i) & 63u) >> 3), sx, sy, col);
             else film_splat_global(sc, rgbw, s_table, x0, y0, sx, sy, col);
             flags &= ~WF_FINISHED;
             atomicAdd(&s_fin, 1u);
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
                 }
                 for (uint32_t k = tid; k < ROWBIN_SIZE; k += TR_BLOCK) my_bins[k] = 0.0f;
             }
-            if (tid == 0) { atomicAdd(tiles_done, 1u); s_tile = WF_TILE_NEED; s_done = 0u; }
+            if (tid == 0) { atomicAdd(tiles_done, 1u); s_tile = WF_TILE_NEED; s_done = 0u; s_pair = 0u; }
             tile_idx = WF_TILE_NEED;
         } else if (tid == 0) {
             s_done = done;
@@ -722,15 +722,29 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
         __syncthreads();
         tile_idx = s_tile;
         flags = 0u;
-        pu(pool, F_SNEXT, i) = sub;
     }
-    if (tid == 0) { chunks[c].tile = s_tile; chunks[c].done = s_done; }
-    // ---- path regeneration (multithreaded.rs:90-96): inline, or (compacted schedule) deferred to k_wf_regen so that the
-    // camera rays and the per-path transforms of moving scenes are computed by full waves
-    const bool wants_sample = tile_idx != WF_TILE_IDLE && !(flags & LF_ALIVE) && pu(pool, F_SNEXT, i) < spp;
+    // ---- path regeneration (multithreaded.rs:90-96), deferred to k_wf_regen so that the camera rays and the per-path transforms of
+    // moving scenes are computed by full waves. The (pixel, sample) pairs of the chunk's tile are handed out dynamically, as in the
+    // tile kernel: an idle slot takes the next pair of the chunk's counter whatever pixel it belongs to, so no slot sits out the end
+    // of a tile because its own pixel's samples are used up while other pixels' are not.
+    const bool idle = tile_idx != WF_TILE_IDLE && !(flags & LF_ALIVE);
+    bool wants_sample = false;
+    {
+        const unsigned long long im = __ballot(idle);
+        if (im != 0ull) {
+            const uint32_t leader = (uint32_t)__ffsll((long long)im) - 1u;
+            uint32_t base = 0u;
+            if (lane == leader) base = atomicAdd(&s_pair, (uint32_t)__popcll(im));
+            base = __shfl(base, (int)leader);
+            const uint32_t pair = base + (uint32_t)__popcll(im & ((1ull << lane) - 1ull));
+            if (idle && pair < 64u * spp) { pu(pool, F_SNEXT, i) = pair; wants_sample = true; }
+        }
+    }
     wf_enqueue(pool, queue_r, qctl, 6u, wants_sample, i);
     pu(pool, F_FLAGS, i) = flags;
     wf_enqueue(pool, queue_a, qctl, 0u, (flags & LF_ALIVE) != 0u, i);
+    __syncthreads();   // every wave has taken its pairs
+    if (tid == 0) { chunks[c].tile = s_tile; chunks[c].done = s_done; chunks[c].next_pair = s_pair < 64u * spp ? s_pair : 64u * spp; }
 }
 
 }  // namespace tr
