@@ -450,6 +450,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
         __syncthreads();
     }
     uint32_t kind = WF_MAT_KINDS;   // no vertex from this slot
+    bool dark = false;              // the slot's occlusion ray cannot matter: counted, not queued
     bool counted = false;
     uint32_t flags = i < n_active ? pu(pool, F_FLAGS, i) : 0u;
     if ((flags & LF_ALIVE) && !(flags & WF_HIT_A)) {   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
@@ -469,6 +470,20 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
         ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
         vertex_begin<ANIM>(sc, ln, rec, cnt);
         counted = true;
+        // The occlusion ray of a light sample only matters if BSDF::eval of the light direction is not black (mod.rs:127-131 test the
+        // occlusion first, then f). Where the surface has no transmission lobe and w_o, w_i do not lie strictly on the same side of
+        // the shading normal, eval removes every reflection lobe (w_o.z * w_i.z > 0 fails, bsdf.rs:71-75; the normalisation of the
+        // shading-space vectors divides by a positive length, it cannot make signs equal) and returns black whatever the ray
+        // finds: such a ray is counted like the reference's and not traced, and the vertex goes on as if it were occluded. In the
+        // queue-compacted schedule that removes rays outright (in the tile kernel the wave would trace for its other lanes anyway).
+        if (queue_b && (ln.flags & LF_SHADOW) && !ln.bsdf.mat->textured) {
+            const DevMaterial* __restrict__ m = ln.bsdf.mat;
+            uint32_t types = 0u;
+            for (uint32_t l = 0; l < m->n_lobes && l < 2u; ++l) types |= m->lobe[l].type;
+            const float zo = -dot(ln.d, ln.bsdf.n), zi = dot(ln.wi_l, ln.bsdf.n);
+            const bool same_side = (zo > 0.0f && zi > 0.0f) || (zo < 0.0f && zi < 0.0f);
+            if (!(types & BX_TRANSMISSION) && !same_side) { ln.flags &= ~LF_SHADOW; dark = true; }
+        }
         if (!(ln.flags & LF_ALIVE)) {   // NormalsDebug: the sample ended at its first hit
             pu(pool, F_FLAGS, i) = (ln.flags & ~WF_INVERTEX) | WF_FINISHED;
             st3(pool, F_ILLUM, i, ln.illum);
@@ -489,9 +504,11 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
         }
     } else flags = 0u;
     {   // one counter update per wave (all lanes of the wave are here: nobody has returned)
-        const unsigned long long m = __ballot(counted);
-        if (m != 0ull && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u)
+        const unsigned long long m = __ballot(counted), dm = __ballot(dark);
+        if (m != 0ull && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) {
             atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].vertices, (unsigned long long)__popcll(m));
+            if (dm != 0ull) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].rays, (unsigned long long)__popcll(dm));
+        }
     }
     if (queue_b) wf_enqueue(pool, queue_b, qctl, 1u, kind < WF_MAT_KINDS && (flags & LF_SHADOW) != 0u, i);
     if (kind_queues) {
