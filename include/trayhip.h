@@ -328,7 +328,9 @@ typedef struct TrayKernelTiming {
     uint32_t launches;
     uint64_t samples;       /* camera samples traced */
     uint64_t vertices;      /* path vertices shaded (iterations of path.rs:69) */
-    uint64_t rays;          /* Scene::intersect calls */
+    uint64_t rays;          /* Scene::intersect calls of the reference's algorithm. A few of them are proven irrelevant before they are traced
+                               -- a BSDF-sampled light ray that misses the light's own primitive, an occlusion ray whose BSDF value is
+                               black -- and only counted */
     uint64_t retraced;      /* rays of the flat instance loop whose closest candidates tied (or sat inside one another's bounding-box
                              * window) and that were therefore traced again with the reference's BVH<Instance> traversal
                              * (geometry/bvh.rs:81-130), which decides by its visiting order; about 1 in 1e7 on cornell_box */
