@@ -225,6 +225,27 @@ def test_tile_megakernel_partial_queue_and_idle_workgroups(tmp_path, built):
     assert np.abs((a + b) - full).max() < 1e-4 * full.max()
 
 
+def test_wavefront_schedule_on_random_scenes(tmp_path, built):
+    """The wavefront schedule on scenes with every material kind (the rays it counts without tracing -- BSDF-sampled light rays that miss
+    the light's primitive, occlusion rays whose BSDF value is black -- depend on the lobes), both light kinds and nested groups:
+    the oracle's samples, vertices, rays and image."""
+    import json
+    import _random_scenes as R
+    d = str(tmp_path)
+    for seed in (401, 402, 403, 404, 405):
+        p = R.write_random_scene(d, seed)
+        desc = json.load(open(p))
+        desc["film"].update(width=32, height=24, samples=4)
+        json.dump(desc, open(p, "w"))
+        scene, *_ = T.Scene.load_file(p)
+        flat = scene.flatten(0)
+        img, (samples, vertices, rays, rounds) = E.render_wavefront(flat, tile_queue(32, 24), 4, seed, trace=0, n_chunks=5, trace_blocks=2, lds_depth=4)
+        ref, st = O.render_tiles(flat, 4, seed=seed)
+        assert (samples, vertices, rays) == (st.samples, st.vertices, st.rays), seed
+        fin = np.isfinite(rgb(img)).all(axis=2) & np.isfinite(rgb(ref)).all(axis=2)
+        assert fin.mean() > 0.99 and float(np.sqrt(np.mean((rgb(img)[fin] - rgb(ref)[fin]) ** 2))) < 2e-6, seed
+
+
 def test_tile_slices_are_the_same_samples(tmp_path, built, monkeypatch):
     """launch_tiles cuts tiles into slices of their samples when a launch has few tiles per workgroup (a GPU's share of the frame
     on an 8-GPU node): the slices of a tile are independent work items whose film contributions add up. Same samples, vertices and
