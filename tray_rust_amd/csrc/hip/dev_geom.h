@@ -68,6 +68,9 @@ struct DevScene {
     float* __restrict__ xf_cache;              // nullptr: evaluate at every use (debug kernels)
     const uint32_t* __restrict__ moving_ids;   // instance ids of the moving instances, by moving_slot
     uint32_t n_moving, xf_cache_lanes;
+    uint32_t xf_aos;                           // layout of xf_cache: 0 = [instance][word][column] (tile kernel: a wave's columns are consecutive, every
+                                               // word is one coalesced load), 1 = [column][instance][24 words] (wavefront: the lanes of a wave hold
+                                               // arbitrary pool slots, a transform is six 16-byte loads of one 96-byte record instead of 24 cache lines)
     uint32_t n_instances, n_lights, min_depth, max_depth;
     uint32_t width, height, frame, film_rows;   // film_rows: 1 = row-binned film (separable, filter_h == 2)
     uint32_t integrator, pad_integrator;        // TRAY_INTEGRATOR_*
@@ -105,9 +108,15 @@ TR_DEV void xf_cache_fill(const DevScene& sc, float time, uint32_t lane) {
         const TrayInstance* __restrict__ in = sc.instances + sc.moving_ids[m];
         float x[24];
         eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
-        float* __restrict__ col = sc.xf_cache + (size_t)m * 24u * lanes + lane;
+        if (sc.xf_aos) {
+            float4* __restrict__ rec = reinterpret_cast<float4*>(sc.xf_cache + ((size_t)lane * sc.n_moving + m) * 24u);
 #pragma unroll
-        for (int k = 0; k < 24; ++k) col[(size_t)k * lanes] = x[k];
+            for (int q = 0; q < 6; ++q) rec[q] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+        } else {
+            float* __restrict__ col = sc.xf_cache + (size_t)m * 24u * lanes + lane;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) col[(size_t)k * lanes] = x[k];
+        }
     }
 }
 // ANIM template values: 0 = nothing moves within the frame; 1 = moving instances are read from the per-path cache (tile and
@@ -117,10 +126,16 @@ TR_DEV void xf_cache_fill(const DevScene& sc, float time, uint32_t lane) {
 template <int ANIM>
 TR_DEV void instance_inv_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, uint32_t column, float* x) {
     if (ANIM == 1) {
-        const uint32_t lanes = sc.xf_cache_lanes;
-        const float* __restrict__ col = sc.xf_cache + ((size_t)in->moving_slot * 24u + 12u) * lanes + column;
+        if (sc.xf_aos) {
+            const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.n_moving + in->moving_slot) * 24u + 12u);
 #pragma unroll
-        for (int k = 0; k < 12; ++k) x[12 + k] = col[(size_t)k * lanes];
+            for (int q = 0; q < 3; ++q) { const float4 v = rec[q]; x[12 + 4 * q] = v.x; x[13 + 4 * q] = v.y; x[14 + 4 * q] = v.z; x[15 + 4 * q] = v.w; }
+        } else {
+            const uint32_t lanes = sc.xf_cache_lanes;
+            const float* __restrict__ col = sc.xf_cache + ((size_t)in->moving_slot * 24u + 12u) * lanes + column;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) x[12 + k] = col[(size_t)k * lanes];
+        }
     } else {
         eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
     }
@@ -129,10 +144,16 @@ template <int ANIM>
 TR_DEV void instance_xf_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, uint32_t column, float* x) {
     if (in->animated) {
         if (ANIM == 1) {
-            const uint32_t lanes = sc.xf_cache_lanes;
-            const float* __restrict__ col = sc.xf_cache + (size_t)in->moving_slot * 24u * lanes + column;
+            if (sc.xf_aos) {
+                const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.n_moving + in->moving_slot) * 24u);
 #pragma unroll
-            for (int k = 0; k < 24; ++k) x[k] = col[(size_t)k * lanes];
+                for (int q = 0; q < 6; ++q) { const float4 v = rec[q]; x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w; }
+            } else {
+                const uint32_t lanes = sc.xf_cache_lanes;
+                const float* __restrict__ col = sc.xf_cache + (size_t)in->moving_slot * 24u * lanes + column;
+#pragma unroll
+                for (int k = 0; k < 24; ++k) x[k] = col[(size_t)k * lanes];
+            }
         } else {
             eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
         }

@@ -938,6 +938,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         s->dev.moving_ids = d_ids;
         s->dev.n_moving = s->deferred_n_moving;
         s->dev.xf_cache_lanes = lanes;
+        s->dev.xf_aos = s->wavefront ? 1u : 0u;
     }
     *out = s;
     return TRAY_OK;
