@@ -66,8 +66,41 @@ struct Wave {
     uint64_t slots[2][WAVE];
     uint64_t present[2] = {0, 0};
 };
+// Fiber switch. On x86-64 a hand-written switch of the callee-saved registers and the stack pointer: swapcontext() makes two
+// rt_sigprocmask system calls per switch, and a SIMT-emulated kernel switches at every wave intrinsic of every lane (the CPU
+// suite spent more time in the kernel than in the tests). Other hosts keep ucontext.
+#if defined(__x86_64__)
+#define HIP_EMU_ASM_SWITCH 1
+extern "C" void hip_emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .p2align 4
+    .type hip_emu_switch,@function
+hip_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hip_emu_switch, .-hip_emu_switch
+)");
+#endif
 struct Fiber {
+#ifdef HIP_EMU_ASM_SWITCH
+    void* sp = nullptr;
+#else
     ucontext_t ctx;
+#endif
     char* stack = nullptr;
     bool done = false;
 };
@@ -77,7 +110,11 @@ struct Block {
     uint64_t gen = 0, progress = 0;
     Wave waves[MAX_THREADS / WAVE];
     Fiber fibers[MAX_THREADS];
+#ifdef HIP_EMU_ASM_SWITCH
+    void* sched_sp = nullptr;
+#else
     ucontext_t sched;
+#endif
     std::function<void()> body;
     std::vector<uint64_t> lds;   // dynamic LDS of the block
 };
@@ -96,7 +133,11 @@ inline void prof_lane_done(uint32_t) {}
 inline void prof_wave_done(uint32_t) {}
 #endif
 
+#ifdef HIP_EMU_ASM_SWITCH
+inline void yield() { Block& b = block(); hip_emu_switch(&b.fibers[b.current].sp, b.sched_sp); }
+#else
 inline void yield() { Block& b = block(); swapcontext(&b.fibers[b.current].ctx, &b.sched); }
+#endif
 
 // all live lanes of the calling lane's wave contribute `mine`; returns after every one of them has arrived
 inline void wave_exchange(uint64_t mine, uint64_t* all, uint64_t& present) {
@@ -169,9 +210,19 @@ inline int launch_simt(uint32_t blocks, uint32_t threads, K&& kernel, size_t dyn
         for (uint32_t t = 0; t < threads; ++t) {
             Fiber& f = b.fibers[t];
             f.done = false;
+#ifdef HIP_EMU_ASM_SWITCH
+            // a fresh stack as hip_emu_switch expects it: six callee-saved registers, then the address it returns to; fiber_main
+            // starts with the alignment of a called function (rsp = 16 n + 8) and never returns
+            void** sp = reinterpret_cast<void**>(reinterpret_cast<uintptr_t>(f.stack + FIBER_STACK) & ~uintptr_t(15));
+            *--sp = nullptr;
+            *--sp = reinterpret_cast<void*>(&fiber_main);
+            for (int r = 0; r < 6; ++r) *--sp = nullptr;
+            f.sp = sp;
+#else
             getcontext(&f.ctx);
             f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = FIBER_STACK; f.ctx.uc_link = nullptr;
             makecontext(&f.ctx, (void (*)())fiber_main, 0);
+#endif
         }
         uint64_t last_progress = 0;
         uint32_t idle_rounds = 0;
@@ -179,7 +230,11 @@ inline int launch_simt(uint32_t blocks, uint32_t threads, K&& kernel, size_t dyn
             for (uint32_t t = 0; t < threads; ++t) {
                 if (b.fibers[t].done) continue;
                 b.current = t; threadIdx.x = t;
+#ifdef HIP_EMU_ASM_SWITCH
+                hip_emu_switch(&b.sched_sp, b.fibers[t].sp);
+#else
                 swapcontext(&b.sched, &b.fibers[t].ctx);
+#endif
             }
             if (b.progress == last_progress) {
                 if (++idle_rounds > 4) {   // every live fiber waits at a rendezvous that cannot complete
