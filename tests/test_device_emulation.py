@@ -225,6 +225,26 @@ def test_tile_megakernel_partial_queue_and_idle_workgroups(tmp_path, built):
     assert np.abs((a + b) - full).max() < 1e-4 * full.max()
 
 
+def test_tile_kernel_on_random_scenes(tmp_path, built):
+    """k_path_tiles itself (dynamic sample pairs, wave-aligned query passes, the instantiation with or without mis_ray_filter that
+    tray_scene_create would pick) on scenes with every material kind: the oracle's samples, vertices, rays and image."""
+    import json
+    import _random_scenes as R
+    d = str(tmp_path)
+    for seed in (411, 412, 413, 414, 415, 416):
+        p = R.write_random_scene(d, seed)
+        desc = json.load(open(p))
+        desc["film"].update(width=32, height=24, samples=8)
+        json.dump(desc, open(p, "w"))
+        scene, *_ = T.Scene.load_file(p)
+        flat = scene.flatten(0)
+        img, st = E.render_tiles(flat, tile_queue(32, 24), 8, seed, blocks=2)
+        ref, ost = O.render_tiles(flat, 8, seed=seed)
+        assert st[:3] == (ost.samples, ost.vertices, ost.rays), seed
+        fin = np.isfinite(rgb(img)).all(axis=2) & np.isfinite(rgb(ref)).all(axis=2)
+        assert fin.mean() > 0.99 and float(np.sqrt(np.mean((rgb(img)[fin] - rgb(ref)[fin]) ** 2))) < 2e-6, seed
+
+
 def test_wavefront_schedule_on_random_scenes(tmp_path, built):
     """The wavefront schedule on scenes with every material kind (the rays it counts without tracing -- BSDF-sampled light rays that miss
     the light's primitive, occlusion rays whose BSDF value is black -- depend on the lobes), both light kinds and nested groups:
