@@ -252,7 +252,7 @@ def test_wavefront_schedule_on_random_scenes(tmp_path, built):
     import json
     import _random_scenes as R
     d = str(tmp_path)
-    for seed in (401, 403, 405):
+    for seed in (401, 402, 403, 404, 405):
         p = R.write_random_scene(d, seed)
         desc = json.load(open(p))
         desc["film"].update(width=32, height=24, samples=4)
