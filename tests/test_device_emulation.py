@@ -225,6 +225,19 @@ def test_tile_megakernel_partial_queue_and_idle_workgroups(tmp_path, built):
     assert np.abs((a + b) - full).max() < 1e-4 * full.max()
 
 
+def test_wavefront_schedule_with_more_chunks_than_queue_segments(tmp_path, built):
+    """70 chunks over the 64 segments of every queue (segments 0..5 hold two chunks' entries; the one-thread-per-entry kernels run
+    128 blocks, 58 of them empty; the traversal waves hop over all 64 segments): the oracle's counts and image."""
+    w, h, spp = 96, 64, 4
+    scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
+    scene, *_ = T.Scene.load_file(str(tmp_path / "smallpt.json"))
+    flat = scene.flatten(0)
+    img, (samples, vertices, rays, rounds) = E.render_wavefront(flat, tile_queue(w, h), spp, 8, trace=0, n_chunks=70, trace_blocks=3, lds_depth=4)
+    ref, st = O.render_tiles(flat, spp, seed=8)
+    assert (samples, vertices, rays) == (st.samples, st.vertices, st.rays)
+    assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6
+
+
 def test_tile_kernel_on_random_scenes(tmp_path, built):
     """k_path_tiles itself (dynamic sample pairs, wave-aligned query passes, the instantiation with or without mis_ray_filter that
     tray_scene_create would pick) on scenes with every material kind: the oracle's samples, vertices, rays and image."""
