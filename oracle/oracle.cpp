@@ -35,23 +35,41 @@ Ray camera_generate_ray(const SceneView& sv, float px, float py, float time) {
     return r;
 }
 
-// Per-camera-sample LD arrays of path.rs:48-60 generated from the counter-based RNG
+// Per-camera-sample LD arrays of path.rs:48-60 generated from the counter-based RNG (TRAY-CBRNG v2):
+// every array has its scramble word(s) and is shuffled (ld.rs:58,63) by one of 256 pool permutations of [0, n), chosen by the low
+// byte of the array's first scramble word -- bits the scrambled 24-bit fractions never see. Pool permutation q is the
+// Fisher-Yates shuffle shuffle_small(mix32(0x50455250 + q), n).
+struct PermPool {
+    uint32_t n = 0;
+    uint8_t perm[256][16];
+    void build(uint32_t num) {
+        n = num;
+        for (uint32_t q = 0; q < 256u; ++q) shuffle_small(mix32(0x50455250u + q), n, perm[q]);
+    }
+};
+inline const PermPool& perm_pool(uint32_t n) {
+    static thread_local PermPool pools[17];
+    PermPool& p = pools[n <= 16u ? n : 16u];
+    if (p.n != n) p.build(n);
+    return p;
+}
 struct PathSamples {
     uint32_t ks;
     uint32_t n;
     uint32_t scr[9];
-    uint8_t perm[6][16];
+    const uint8_t* perm[6];
     void init(uint32_t key_samp, uint32_t num_samples) {
         ks = key_samp; n = num_samples;
-        // 2-D arrays: scramble x, scramble y, shuffle key; 1-D arrays: scramble, shuffle key
+        const PermPool& pool = perm_pool(n);
+        // 2-D arrays: scramble x, scramble y; 1-D arrays: scramble
         const int d2[3] = {SD_L2, SD_B2, SD_P2}, d1[3] = {SD_L1, SD_B1, SD_P1};
         for (int a = 0; a < 3; ++a) {
             scr[2 * a] = draw(ks, d2[a]); scr[2 * a + 1] = draw(ks, d2[a] + 1);
-            shuffle_small(draw(ks, d2[a] + 2), n, perm[a]);
+            perm[a] = pool.perm[scr[2 * a] & 255u];
         }
         for (int a = 0; a < 3; ++a) {
             scr[6 + a] = draw(ks, d1[a]);
-            shuffle_small(draw(ks, d1[a] + 1), n, perm[3 + a]);
+            perm[3 + a] = pool.perm[scr[6 + a] & 255u];
         }
     }
     void two_d(int a, uint32_t bounce, float& u0, float& u1) const {   // sample_02 (ld.rs:91-93)

@@ -79,6 +79,7 @@ struct EmuScene {
     std::vector<tray::FlatLeaf> flat_leaves;
     std::vector<tray::FlatInst> flat_insts;
     std::vector<uint8_t> tri_leaf;
+    std::vector<uint8_t> perm_pool;
     uint32_t retraced = 0;   // rays the flat loop handed to trace_bvh
     uint32_t depth = 0;   // traversal stack entries per lane, as tray_scene_create sizes them (two-level worst case, generous)
 };
@@ -112,6 +113,9 @@ void make_scene(const TrayFlatScene* f, EmuScene& e) {
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
     d.camera_p = &f->camera;
+    e.perm_pool.resize(TR_PERM_BYTES);
+    perm_pool_build(f->max_depth + 1u, e.perm_pool.data());
+    d.perm_pool = e.perm_pool.data();
     tray::flat_loop_gates(f, TR_COOP_MAX_TRIS, e.flat_leaves, e.flat_insts, e.tri_leaf);
     d.flat_leaves = e.flat_leaves.data(); d.flat_insts = e.flat_insts.data(); d.n_flat_leaves = (uint32_t)e.flat_leaves.size(); d.tri_leaf = e.tri_leaf.data();
     d.retraced = &g_retraced;

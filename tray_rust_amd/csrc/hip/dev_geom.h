@@ -87,6 +87,7 @@ struct DevScene {
     int32_t fpw, fph;
                        // where it held scalar registers for the whole kernel (193 -> 140 SGPRs spilled to VGPR lanes in k_path_tiles)
     const TrayCamera* __restrict__ camera_p;
+    const uint8_t* __restrict__ perm_pool;   // TR_PERM_BYTES: the shuffles the per-path LD arrays draw from (dev_math.h: perm_pool_build)
 };
 
 struct Ray {
@@ -397,7 +398,9 @@ TR_DEV bool mesh_traverse_ww(const DevScene& sc, uint32_t* __restrict__ stack, c
 // gate depends on the order of the reference's traversal (trace_flat explains the rule; testing ungated rivals only adds
 // caution); the caller then re-traces the ray the reference's way.
 #define TR_COOP_MAX_TRIS 16
-#define TR_COOP_WORDS 832   // per wave: ray o, d, min_t, gate max_t (8 x 64) + result t, k, b1, b2, second t (5 x 64)
+#define TR_COOP_WORDS 576   // per wave: ray o, d, min_t, gate max_t (rows 0-7) + the candidate marker k (row 8); the results t, b1, b2, second t of ray r overwrite
+                            // rows 0-3 of ITS column once its quad has read them (no other quad ever reads that column): 9 rows instead of 13 keep a
+                            // third workgroup within the CU's LDS
 // value of lane (l ^ step) of the same quad, step 1 or 2: a DPP quad_perm move (one VALU instruction; __shfl_xor is a ds_bpermute)
 TR_DEV float quad_xor(float v, int step) {
 #ifdef TR_HOST_EMU
@@ -426,7 +429,7 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, LdsF w_lds, boo
         w_lds[0 * 64 + rank] = o.x; w_lds[1 * 64 + rank] = o.y; w_lds[2 * 64 + rank] = o.z;
         w_lds[3 * 64 + rank] = d.x; w_lds[4 * 64 + rank] = d.y; w_lds[5 * 64 + rank] = d.z;
         w_lds[6 * 64 + rank] = min_t; w_lds[7 * 64 + rank] = gate_max_t;
-        w_lds[9 * 64 + rank] = -1.0f;   // no candidate yet
+        w_lds[8 * 64 + rank] = -1.0f;   // no candidate yet
     }
     TR_WAVE_SYNC();
     const uint32_t per = (T + 3u) >> 2, g = lane & 3u;
@@ -460,23 +463,23 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, LdsF w_lds, boo
             if (both) c2 = fminf(c2, take ? ct : ot);   // the loser of the two bests is the other side's closest rival
             if (take) { ct = ot; ck = ok; cb1 = ob1; cb2 = ob2; }
         }
-        if (r < n && g == 0u && ck >= 0.0f) {
-            w_lds[8 * 64 + r] = ct; w_lds[9 * 64 + r] = ck; w_lds[10 * 64 + r] = cb1; w_lds[11 * 64 + r] = cb2; w_lds[12 * 64 + r] = c2;
+        if (r < n && g == 0u && ck >= 0.0f) {   // (the four lanes of the quad have read column r above; DPP moves below are register-only)
+            w_lds[0 * 64 + r] = ct; w_lds[8 * 64 + r] = ck; w_lds[1 * 64 + r] = cb1; w_lds[2 * 64 + r] = cb2; w_lds[3 * 64 + r] = c2;
         }
     }
     TR_WAVE_SYNC();
     bool hit = false;
     if (need) {
-        const float ck = w_lds[9 * 64 + rank];
-        if (ck >= 0.0f && w_lds[8 * 64 + rank] <= accept_max_t) {
-            const float t = w_lds[8 * 64 + rank], c2 = w_lds[12 * 64 + rank];
+        const float ck = w_lds[8 * 64 + rank];
+        if (ck >= 0.0f && w_lds[0 * 64 + rank] <= accept_max_t) {
+            const float t = w_lds[0 * 64 + rank], c2 = w_lds[3 * 64 + rank];
             const uint32_t k = (uint32_t)ck;
             // the survivor's gate: the box of its BVH<Triangle> leaf, with the ray's original max_t
             const float4* lq = reinterpret_cast<const float4*>(tree + sc.tri_leaf[m.tri_offset + k]);
             float cbox;
             const bool gate = bbox_hit_t(lq[0], lq[1], o, inv_dir, dnx, dny, dnz, min_t, gate_max_t, cbox);
             t_out = t; prim = m.tri_offset + k;
-            b1 = w_lds[10 * 64 + rank]; b2 = w_lds[11 * 64 + rank];
+            b1 = w_lds[1 * 64 + rank]; b2 = w_lds[2 * 64 + rank];
             leaf_tmin = cbox;
             hazard = !gate || !(c2 > t && c2 > cbox);   // (also true when cbox is NaN)
             hit = true;

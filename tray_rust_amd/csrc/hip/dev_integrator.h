@@ -101,6 +101,7 @@ struct Lane {
     f3 aux_d;              // stage B: occlusion segment p_w - p | stage C: BSDF-sampled direction
     f3 direct;             // direct_light of estimate_direct
     f3 t_vertex;           // throughput at this vertex, kept for `illum += throughput * direct`
+    LdsB perm_lds = nullptr;   // the scene's permutation pool in LDS (tile kernel; wave-uniform, costs no register); null: read sc.perm_pool
 #ifdef TR_STAGE_CLOCKS   // instrumented builds only: wave clocks of the parts of a BSDF query (set by k_path_tiles, null elsewhere)
     unsigned long long* qclk = nullptr;   // [0] sample head / light setup, [1] eval + pdf site, [2] epilogue of the query kind
     long long qt = 0;
@@ -125,14 +126,21 @@ TR_DEV void lane_start_sample(Lane& ln, const Ray& cam_ray, uint32_t ks) {
     ln.illum = mk(0.0f, 0.0f, 0.0f);
 }
 
-// sample_02 / van_der_corput of one LD array at the current bounce (ld.rs:54-64, 91-93)
+// sample_02 / van_der_corput of one LD array at the current bounce (ld.rs:54-64, 91-93): the array's scramble word(s), its shuffle
+// out of the scene's permutation pool (dev_math.h: TRAY-CBRNG v2), the (0,2)-sequence point of the shuffled index
+TR_DEV uint32_t lane_perm_entry(const DevScene& sc, const Lane& ln, uint32_t scramble) {
+    const uint32_t off = ((scramble & (TR_PERM_POOL - 1u)) << 4) + ln.bounce;
+    return ln.perm_lds ? (uint32_t)ln.perm_lds[off] : (uint32_t)sc.perm_pool[off];
+}
 TR_DEV void lane_2d(const DevScene& sc, const Lane& ln, uint32_t dim, float& u0, float& u1) {
-    uint32_t idx = shuffle_entry(draw(ln.ks, dim + 2u), sc.max_depth + 1u, ln.bounce);
-    u0 = van_der_corput(idx, draw(ln.ks, dim));
-    u1 = sobol(idx, draw(ln.ks, dim + 1u));
+    const uint32_t sx = draw(ln.ks, dim), sy = draw(ln.ks, dim + 1u);
+    const uint32_t e = lane_perm_entry(sc, ln, sx);
+    u0 = u24_to_unit(((e & 0xf0u) << 24) ^ sx);   // van_der_corput(idx, sx)
+    u1 = u24_to_unit((e << 28) ^ sy);             // sobol(idx, sy)
 }
 TR_DEV float lane_1d(const DevScene& sc, const Lane& ln, uint32_t dim) {
-    return van_der_corput(shuffle_entry(draw(ln.ks, dim + 1u), sc.max_depth + 1u, ln.bounce), draw(ln.ks, dim));
+    const uint32_t s = draw(ln.ks, dim);
+    return u24_to_unit(((lane_perm_entry(sc, ln, s) & 0xf0u) << 24) ^ s);
 }
 
 TR_DEV Ray stage_a_ray(const Lane& ln) {

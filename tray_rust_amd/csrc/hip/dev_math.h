@@ -19,14 +19,18 @@ namespace tr {
 // TR_WAVE_SYNC()s: LDS operations of a wave complete in order, the fences only keep the compiler from moving accesses across.
 typedef __attribute__((address_space(3))) float* LdsF;
 typedef __attribute__((address_space(3))) uint32_t* LdsU;
+typedef const __attribute__((address_space(3))) uint8_t* LdsB;
 #define TR_LDS_F(generic_ptr) ((LdsF)(generic_ptr))
 #define TR_LDS_U(generic_ptr) ((LdsU)(generic_ptr))
+#define TR_LDS_B(generic_ptr) ((LdsB)(generic_ptr))
 #define TR_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #else
 typedef float* LdsF;
 typedef uint32_t* LdsU;
+typedef const uint8_t* LdsB;
 #define TR_LDS_F(generic_ptr) ((float*)(generic_ptr))
 #define TR_LDS_U(generic_ptr) ((uint32_t*)(generic_ptr))
+#define TR_LDS_B(generic_ptr) ((const uint8_t*)(generic_ptr))
 #define TR_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 
@@ -168,25 +172,49 @@ TR_DEV uint32_t permute(uint32_t i, uint32_t l, uint32_t p) {
     } while (i >= l);
     return (i + p) % l;
 }
-// Entry b of the Fisher-Yates shuffle of [0, n) defined by the oracle's shuffle_small(key, n)
-// (i from n-1 down to 1, j = (r16 * (i + 1)) >> 16 with r16 the 16-bit fields of draw(key, k >> 1),
-// k = n-1-i), WITHOUT materialising the array: position b is final after step i = b, so its content
-// is found by following one element backwards through steps b, b+1, .., n-1. Costs n - max(b, 1)
-// compare/select steps instead of keeping six packed permutations in registers for the whole path.
-TR_DEV uint32_t shuffle_entry(uint32_t key, uint32_t n, uint32_t b) {
-    uint32_t q = b;
-    uint32_t word = 0u;
-    uint32_t i = b > 0u ? b : 1u;
-    uint32_t k = n - 1u - i;                       // draw counter of step i, decreasing as i grows
-    if (i < n && (k & 1u) == 0u) word = draw(key, k >> 1);   // an even k shares its word with k + 1, which is not visited
-    for (; i < n; ++i, --k) {
-        if ((k & 1u) != 0u) word = draw(key, k >> 1);        // first use of this word (odd k comes before even k - 1)
-        uint32_t r16 = (k & 1u) ? (word >> 16) : (word & 0xffffu);
-        uint32_t j = (r16 * (i + 1u)) >> 16;
-        uint32_t qn = q == i ? j : (q == j ? i : q);
-        q = qn;
+// ---- per-path shuffles of the six LD arrays (ld.rs:58,63 called from path.rs:55-60), TRAY-CBRNG v2.
+// The reference shuffles every (max_depth + 1)-long array of every camera sample with its thread's unseeded RNG. Here a path's
+// shuffle of an array is ONE of TR_PERM_POOL permutations of [0, n) that exist once per scene: permutation q of the pool is
+// the Fisher-Yates shuffle (loop shape of Rng::shuffle: i from n-1 down to 1, j = (r16 * (i + 1)) >> 16, r16 the 16-bit
+// fields of draw(key_q, k >> 1), k = n-1-i) under key_q = mix32(0x50455250 + q), and an array picks q = low byte of its (first)
+// scramble word -- bits the scrambled 24-bit fractions never use. Round 2 ran that Fisher-Yates per array and per path vertex
+// (six times ~100 instructions at every vertex: 9 % of the tile kernel); drawing from a pool costs one byte load.
+// Pool entry (q, b) holds what the (0,2)-sequence point of index idx = perm_q[b] needs: high nibble = bit-reversed idx (the top
+// four bits of van_der_corput's __brev(idx), idx < 16), low nibble = the top four bits of sobol()'s xor of direction numbers
+// (0x8, 0xC, 0xA, 0xF for idx bits 0..3) -- so both coordinates are one xor with the scramble word, the same bits the loops of
+// van_der_corput() / sobol() below produce for idx < 16.
+#define TR_PERM_POOL 256
+#define TR_PERM_BYTES (TR_PERM_POOL * 16)
+#ifdef TR_HOST_EMU
+#define TR_HDI inline
+#else
+#define TR_HDI __host__ __device__ inline
+#endif
+TR_HDI uint32_t mix32_hd(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// host: the scene's pool for arrays of n = max_depth + 1 <= 16 entries (tray_scene_create uploads it; the tile kernel keeps it in LDS)
+inline void perm_pool_build(uint32_t n, uint8_t* out /* TR_PERM_BYTES */) {
+    if (n > 16u) n = 16u;
+    for (uint32_t q = 0; q < TR_PERM_POOL; ++q) {
+        const uint32_t key = mix32_hd(0x50455250u + q);
+        uint8_t perm[16];
+        for (uint32_t i = 0; i < 16u; ++i) perm[i] = (uint8_t)i;
+        for (uint32_t i = n > 0u ? n - 1u : 0u; i >= 1u; --i) {
+            const uint32_t k = n - 1u - i;
+            const uint32_t word = mix32_hd(key + 0x9E3779B9u * ((k >> 1) + 1u));   // draw(key, k >> 1)
+            const uint32_t r16 = (k & 1u) ? (word >> 16) : (word & 0xffffu);
+            const uint32_t j = (r16 * (i + 1u)) >> 16;
+            const uint8_t tmp = perm[i]; perm[i] = perm[j]; perm[j] = tmp;
+        }
+        for (uint32_t b = 0; b < 16u; ++b) {
+            const uint32_t idx = b < n ? perm[b] : 0u;
+            const uint32_t rev4 = ((idx & 1u) << 3) | ((idx & 2u) << 1) | ((idx & 4u) >> 1) | ((idx & 8u) >> 3);
+            const uint32_t sob4 = ((idx & 1u) ? 0x8u : 0u) ^ ((idx & 2u) ? 0xCu : 0u) ^ ((idx & 4u) ? 0xAu : 0u) ^ ((idx & 8u) ? 0xFu : 0u);
+            out[q * 16u + b] = (uint8_t)((rev4 << 4) | sob4);
+        }
     }
-    return q;
 }
 
 // ---- sampler/ld.rs:91-119

@@ -203,6 +203,8 @@ __device__ __forceinline__ void film_splat_rows_global(const DevScene& sc, float
 
 #include "wavefront.h"
 
+TR_DEV const float* sc_filter_table(const DevScene& sc) { return sc.filter_table; }
+
 // Work item w (0 <= w < n_work) maps to queue entry (w / chunk) * chunk_stride * chunk + (w % chunk):
 // contiguous ranges use chunk_stride = 1; multi-GPU sharding interleaves chunks round-robin.
 // INTEG: the scene's integrator. TRAY_INTEGRATOR_WHITTED runs every camera sample of a wave to its end between two
@@ -215,9 +217,12 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ counter,
                                                          DevStats* __restrict__ stats) {
     __shared__ float s_win[4 * WIN_PLANE];
-    __shared__ float s_table[TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE];
+    const float* __restrict__ const s_table = sc_filter_table(scv);   // the 16 x 16 table stays in global memory (1 KB, cache resident): with the row-binned film only
+                                                                       // the ~1 in 1000 samples on a class boundary read it, and the kilobyte decides whether a
+                                                                       // third workgroup fits the CU's LDS on mesh scenes (42 granules of 1280 B per workgroup)
     __shared__ float s_rowbin[ROWBIN_SIZE];
     __shared__ float s_tx[TRAY_FILTER_TABLE_SIZE], s_ty[TRAY_FILTER_TABLE_SIZE];
+    __shared__ uint4 s_perm[TR_PERM_BYTES / 16];   // the scene's permutation pool (dev_math.h): one byte read per LD array and vertex
     TR_DYN_LDS(uint32_t, s_stack);   // stack_depth x TR_BLOCK entries, sized per scene at launch
     __shared__ uint32_t s_tile, s_next_sample;
     const DevScene& sc = scv;
@@ -225,8 +230,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     uint32_t* const my_stack = s_stack + tid;
-    s_table[tid] = sc.filter_table[tid];
     if (tid < TRAY_FILTER_TABLE_SIZE) { s_tx[tid] = sc.filter_x[tid]; s_ty[tid] = sc.filter_y[tid]; }
+    s_perm[tid] = reinterpret_cast<const uint4*>(sc.perm_pool)[tid];   // TR_PERM_BYTES / 16 == TR_BLOCK
+    static_assert(TR_PERM_BYTES / 16 == TR_BLOCK, "one uint4 of the permutation pool per thread");
     const bool film_rows = sc.film_rows != 0u;
     Counters cnt;
     cnt.rays = 0; cnt.vertices = 0;
@@ -265,6 +271,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const Dev
         Lane ln;
         ln.flags = 0u;
         ln.illum = mk(0.0f, 0.0f, 0.0f);
+        ln.perm_lds = TR_LDS_B(s_perm);
 #ifdef TR_STAGE_CLOCKS
         ln.qclk = clk + 8;
 #endif
@@ -756,6 +763,11 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     UP(keyframes, f->keyframes, f->n_keyframes)
     UP(knots, f->knots, f->n_knots)
     UP(color_keys, f->color_keys, f->n_color_keys)
+    {   // the shuffles of the per-path LD arrays (path.rs:55-60: arrays of max_depth + 1 samples) come from a pool built once per scene
+        std::vector<uint8_t> pool(TR_PERM_BYTES);
+        perm_pool_build(f->max_depth + 1u, pool.data());
+        UP(perm_pool, pool.data(), pool.size())
+    }
 #undef UP
     for (uint32_t t = 0; t < f->n_textures; ++t) moving = moving || f->textures[t].n_frames >= 2u;   // animated_image: sampled at ray.time, which only the ANIM kernels carry
     s->animated = moving;
@@ -914,6 +926,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     for (uint32_t i = 0; i < f->n_instances; ++i) if (f->instances[i].animated) s->deferred_n_moving++;
     if (cus < 1) cus = 256;
     s->n_blocks = cus * per_cu;
+    if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] tile kernel: %d workgroups per CU (dynamic LDS %u B)\n", per_cu, s->stack_bytes);
     if (s->deferred_n_moving > 64) {
         tray_scene_destroy(s); set_error("more than 64 instances move within one frame: the per-path transform cache does not cover that"); return TRAY_E_UNSUPPORTED;
     }
