@@ -67,11 +67,16 @@ def device_code_hash():
         return None
 
 
-def pmc_views(workload, samples):
-    """roofline.traffic (HBM-side bytes per launch) and the compute view of the tile kernel from the committed counter passes
-    (profiles/pmc_latest.json, tools/pmc_tile.sh). The counters belong to ONE build: they are used only when the md5 of this
-    library's device code equals the one recorded with them; a different build prints traffic null and says why.
-    The passes profile a 64-spp launch; HBM-side bytes and instruction counts scale with the sample count of the launch."""
+VALU_PEAK_TLANE = 256 * 4 * 32 * 2.4e9 / 1e12   # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 at 2.4 GHz = 78.6e12 lane-instructions/s (plain, unpacked VALU)
+
+
+def pmc_views(workload, samples, kernel_seconds):
+    """roofline.traffic (HBM-side bytes per launch), the VALU view and the compute view of a workload's kernels from the committed
+    counter passes (profiles/pmc_latest.json, tools/pmc_workloads.py). The counters belong to ONE build: they are used only when
+    the md5 of this library's device code equals the one recorded with them; a different build prints nulls and says why.
+    The passes profile a cut-down sample count; HBM-side bytes and instruction counts scale with the sample count of the launch.
+    valu.achieved = VALU wave-instructions x 64 x lane utilisation (= active lane-instructions, from SQ_INSTS_VALU and
+    SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU) per sample x this launch's samples / this launch's HIP-event seconds."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     static = None
     try:
@@ -81,23 +86,31 @@ def pmc_views(workload, samples):
     try:
         p = json.load(open(path))
     except Exception:
-        return None, {"source": None, "note": "no profiles/pmc_latest.json", "static": static}
+        return None, None, {"source": None, "note": "no profiles/pmc_latest.json", "static": static}
     have = device_code_hash()
-    if p.get("workload") != workload:
-        return None, {"source": "profiles/pmc_latest.json", "note": f"counters were measured on {p.get('workload')}, not on this workload", "static": static}
     if not have or have != p.get("device_code_hash"):
-        return None, {"source": "profiles/pmc_latest.json", "static": static,
-                      "note": f"counters belong to device code {p.get('device_code_hash')}, this library is {have}: re-run tools/pmc_tile.sh"}
-    d = p.get("derived", {})
+        return None, None, {"source": "profiles/pmc_latest.json", "static": static,
+                            "note": f"counters belong to device code {p.get('device_code_hash')}, this library is {have}: re-run tools/pmc_workloads.py"}
+    d = (p.get("workloads") or {}).get(workload)
+    if not d:
+        return None, None, {"source": "profiles/pmc_latest.json", "note": f"no counters for workload {workload}", "static": static}
     per_sample = d.get("hbm_bytes_per_sample")
     traffic = int(per_sample * samples) if per_sample else None
-    compute = {"source": "profiles/pmc_latest.json (rocprofv3 --pmc passes around one %d-spp launch of this device code)" % p.get("spp", 0),
-               "device_code_hash": have,
-               "valu_busy": round(d.get("valu_busy", 0.0), 4), "valu_lane_util": round(d.get("valu_lane_utilisation", 0.0), 4),
-               "cycles_per_valu_instruction": round(d.get("cycles_per_valu_instruction", 0.0), 3),
-               "waves_per_simd": d.get("waves_per_simd"), "waiting_share_of_wave_cycles": round(d.get("waiting_share_of_wave_cycles", 0.0), 4),
-               "hbm_bytes_basis": d.get("hbm_bytes_basis"), "static": static}
-    return traffic, compute
+    valu = None
+    if d.get("valu_instructions_per_sample") and d.get("valu_lane_utilisation") and kernel_seconds > 0:
+        lane_instr = d["valu_instructions_per_sample"] * 64.0 * d["valu_lane_utilisation"] * samples
+        achieved = lane_instr / kernel_seconds / 1e12
+        valu = {"achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANE, 2), "unit": "T lane-instructions/s", "frac": round(achieved / VALU_PEAK_TLANE, 4),
+                "wave_instructions_per_sample": round(d["valu_instructions_per_sample"], 1), "lane_utilisation": round(d["valu_lane_utilisation"], 4),
+                "note": "peak = nominal issue rate of plain VALU instructions (256 CUs x 4 SIMD-32 x 2.4 GHz); the SQ counters show the VALU pipe "
+                        f"{d.get('valu_busy', 0.0):.2f} time-busy at this rate" if d.get("valu_busy") else "peak = nominal issue rate of plain VALU instructions"}
+    compute = {"source": "profiles/pmc_latest.json (rocprofv3 --pmc passes around a %d-spp launch of this device code, tools/pmc_workloads.py)" % d.get("spp", 0),
+               "device_code_hash": have, "kernel": d.get("kernel"),
+               "valu_busy": d.get("valu_busy"), "valu_lane_util": d.get("valu_lane_utilisation"),
+               "waves_per_simd": d.get("waves_per_simd"), "waiting_share_of_wave_cycles": d.get("waiting_share_of_wave_cycles"),
+               "dominant_kernel_share_of_time": d.get("dominant_kernel_share_of_time"),
+               "hbm_bytes_basis": d.get("hbm_bytes_basis"), "static": static if workload == "cornell_box" else None}
+    return traffic, valu, compute
 
 
 def main():
@@ -107,11 +120,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=0, help="debug only: the reported config is 1024 spp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="only the reported line (configs[1]), without the configs[2..4] lines attached to it")
     ap.add_argument("--workload", choices=["cornell_box", "smallpt", "dragon", "tr15_like"], default="cornell_box",
                     help="cornell_box = BASELINE.json configs[1] (the reported line); smallpt = configs[2] at 4096 spp; "
                          "dragon = configs[3] stand-in (871 200 triangles + MERL) at 2048 spp; tr15_like = configs[4] stand-in "
                          "(59 instances, 3.1 M triangles, moving camera / objects / lights), one frame at 512 spp")
     ap.add_argument("--frame", type=int, default=330, help="frame of a moving workload (tr15_like)")
+    ap.add_argument("--frames", type=int, default=1, help="tr15_like only: a step renders the SEQUENCE of frames [frame, frame + frames) -- the device scene moves from "
+                    "frame to frame with tray_scene_update_frame (Scene::update_frame, scene.rs:152-176) inside the timed region; with N GPUs the frames are "
+                    "dealt round-robin over the ranks (multi.shard_frames, BASELINE.json configs[4]), each rank renders whole frames, no collective")
     args = ap.parse_args()
 
     import torch
@@ -139,94 +156,137 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    tmp = tempfile.mkdtemp(prefix=f"traybench{rank}_")
-    want_spp = args.spp or {"cornell_box": SPP, "smallpt": 4096, "dragon": 2048, "tr15_like": 512}[args.workload]
-    frame = args.frame if args.workload == "tr15_like" else 0
-    if args.workload == "dragon":
-        scenes.write_dragon_assets(tmp, film=(WIDTH, HEIGHT, want_spp))
-    elif args.workload == "tr15_like":
-        scenes.write_tr15_like_assets(tmp, film=(WIDTH, HEIGHT, want_spp))
-    else:
-        scenes.write_assets(tmp, cornell=(WIDTH, HEIGHT, want_spp), small=(WIDTH, HEIGHT, want_spp))
-    scene, rt, spp, frame_info = T.Scene.load_file(os.path.join(tmp, args.workload + ".json"))
-    spp = T.round_spp(spp)
+    stream = torch.cuda.current_stream().cuda_stream
     hip = T.Hip(device=local_rank, seed=1)
     film = torch.zeros(WIDTH * HEIGHT * 4, dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        film.zero_()
-        if distributed:
-            multi.render_frame_sharded(   # tiles round-robin over ranks, then film::Image::add_pixels as one RCCL sum-reduce
-                lambda r, w, f: hip.render_shard_device(scene, frame, r, w, spp, f.data_ptr(), chunk_tiles=multi.DEFAULT_CHUNK_TILES, stream=stream),
-                film, rank, world, dst=0)
-        else:
-            hip.render_device(scene, frame, (0, 0), spp, film.data_ptr(), stream=stream)
+    default_spp = {"cornell_box": SPP, "smallpt": 4096, "dragon": 2048, "tr15_like": 512}
 
     def fence():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    kernel_ms, samples, vertices = [], 0, 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        tim = hip.timing(scene)   # HIP events on the launch stream around k_path_tiles
-        kernel_ms.append(tim.render_ms)
-        samples, vertices, launches = tim.samples, tim.vertices, tim.launches
-    fence()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        cnt = torch.tensor([samples, vertices], dtype=torch.float64, device="cuda")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total_samples, total_vertices = float(cnt[0].item()), float(cnt[1].item())
-    else:
-        total_samples, total_vertices = float(samples), float(vertices)
+    def run_workload(name, want_spp, steps, warmup, warmup_spp=None):
+        """K timed frames of one workload, bracketed as the contract says; returns the measurements of this rank (and the scene)"""
+        tmp = tempfile.mkdtemp(prefix=f"traybench{rank}_")
+        frame = args.frame if name == "tr15_like" else 0
+        if name == "dragon":
+            scenes.write_dragon_assets(tmp, film=(WIDTH, HEIGHT, want_spp))
+        elif name == "tr15_like":
+            scenes.write_tr15_like_assets(tmp, film=(WIDTH, HEIGHT, want_spp))
+        else:
+            scenes.write_assets(tmp, cornell=(WIDTH, HEIGHT, want_spp), small=(WIDTH, HEIGHT, want_spp))
+        scene, rt, spp, frame_info = T.Scene.load_file(os.path.join(tmp, name + ".json"))
+        spp = T.round_spp(spp)
 
-    if rank == 0:
-        frame_samples = WIDTH * HEIGHT * spp
-        assert abs(total_samples - frame_samples) < 0.5, (total_samples, frame_samples)
-        ms_per_step = elapsed * 1e3 / args.steps
+        seq = name == "tr15_like" and args.frames > 1
+
+        def step(step_spp):
+            if seq:   # this rank's frames of the sequence, one after the other through the same device scene
+                for fr in multi.shard_frames(frame, frame + args.frames - 1, rank, world):
+                    film.zero_()
+                    hip.render_device(scene, fr, (0, 0), step_spp, film.data_ptr(), stream=stream)
+                    seq_counts.append(hip.timing(scene))   # (synchronises: the next frame's update waits for the device anyway)
+                return
+            film.zero_()
+            if distributed:
+                multi.render_frame_sharded(   # tiles round-robin over ranks, then film::Image::add_pixels as one RCCL sum-reduce
+                    lambda r, w, f: hip.render_shard_device(scene, frame, r, w, step_spp, f.data_ptr(), chunk_tiles=multi.DEFAULT_CHUNK_TILES, stream=stream),
+                    film, rank, world, dst=0)
+            else:
+                hip.render_device(scene, frame, (0, 0), step_spp, film.data_ptr(), stream=stream)
+
+        seq_counts = []
+        for _ in range(warmup):
+            step(warmup_spp or spp)
+        fence()
+        kernel_ms, samples, vertices, launches = [], 0, 0, 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            seq_counts.clear()
+            step(spp)
+            if seq:   # sums over this rank's frames of the sequence
+                kernel_ms.append(sum(t.render_ms for t in seq_counts))
+                samples, vertices = sum(int(t.samples) for t in seq_counts), sum(int(t.vertices) for t in seq_counts)
+                launches = sum(int(t.launches) for t in seq_counts)
+            else:
+                tim = hip.timing(scene)   # HIP events on the launch stream around the schedule's kernels
+                kernel_ms.append(tim.render_ms)
+                samples, vertices, launches = tim.samples, tim.vertices, tim.launches
+        fence()
+        elapsed = time.perf_counter() - t0
+        if distributed:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+            cnt = torch.tensor([samples, vertices], dtype=torch.float64, device="cuda")
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            total_samples, total_vertices = float(cnt[0].item()), float(cnt[1].item())
+        else:
+            total_samples, total_vertices = float(samples), float(vertices)
+        return {"name": name, "scene": scene, "frame": frame, "spp": spp, "steps": steps, "elapsed": elapsed, "kernel_ms": sum(kernel_ms) / len(kernel_ms),
+                "n_frames": args.frames if seq else 1,
+                "samples": samples, "vertices": vertices, "launches": launches, "total_samples": total_samples, "total_vertices": total_vertices}
+
+    def line_of(m):
+        """metric, roofline (SURVEY 8d's HBM accounting + the VALU view from the hash-matched counters) of one measured workload"""
+        name, spp = m["name"], m["spp"]
+        frame_samples = WIDTH * HEIGHT * spp * m["n_frames"]   # samples of one step (a frame, or the sequence of frames)
+        assert abs(m["total_samples"] - frame_samples) < 0.5, (m["total_samples"], frame_samples)
+        ms_per_step = m["elapsed"] * 1e3 / m["steps"]
         value = frame_samples / (ms_per_step * 1e-3) / 1e6
-        # roofline of the dominant kernel (k_path_tiles) on this rank
-        vbar = total_vertices / total_samples
-        k_ms = sum(kernel_ms) / len(kernel_ms)
-        algo_bytes = samples * BYTES_PER_VERTEX * (vertices / max(samples, 1)) + (WIDTH * HEIGHT * BYTES_PER_PIXEL) / world
+        vbar = m["total_vertices"] / m["total_samples"]
+        k_ms = m["kernel_ms"]
+        algo_bytes = m["samples"] * BYTES_PER_VERTEX * (m["vertices"] / max(m["samples"], 1)) + (WIDTH * HEIGHT * BYTES_PER_PIXEL) * m["n_frames"] / world
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-        traffic, compute = pmc_views(args.workload, samples)
-        fs = scene.flatten(frame).contents
-        wave = launches > 1
+        traffic, valu, compute = pmc_views(name, m["samples"], k_ms * 1e-3)
+        fs = m["scene"].flatten(m["frame"]).contents
+        wave = m["launches"] > 1
+        frac = achieved / HBM_PEAK_GBS
         schedule = ("wavefront stage kernels over the HBM path pool (compacted ray queues, persistent dynamic-fetch traversal)" if wave
                     else "tile megakernel k_path_tiles (wave-synchronous vertex stepping)")
+        roofline = {"bound": "valu" if (valu and valu["frac"] > frac) else "hbm",
+                    "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac, 5), "traffic": traffic,
+                    "valu": valu, "compute": compute,
+                    "kernel": "7 stage kernels per round (HIP events around the whole schedule)" if wave else "k_path_tiles",
+                    "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": int(algo_bytes),
+                    "note": "achieved / peak / frac are SURVEY 8(d)'s accounting of the WAVEFRONT formulation (368 B per path vertex + 16 B per pixel) over the HIP-event "
+                            "time of the launch; `bound` names the resource the launch is closer to, `valu` prices the VALU lane-issue rate from the counters. " +
+                            ("Traversal of the 3.1 M-triangle scene is memory-latency bound." if wave
+                             else "The tile megakernel keeps path state in registers and the film in LDS: its HBM traffic (`traffic`) is a small "
+                                  "multiple of the 33 MB film, the scene is cache resident, and the kernel is bound by VALU issue at partial lane utilisation.")}
+        config = {"workload": f"{name} 1920x1080 {spp}spp, path tracer min_depth {fs.min_depth} max_depth {fs.max_depth}"
+                              f"{(', frames %d..%d, device scene updated from frame to frame inside the timed region' % (m['frame'], m['frame'] + m['n_frames'] - 1)) if m['n_frames'] > 1 else (', frame %d' % m['frame'] if name == 'tr15_like' else '')}"
+                              f" (BASELINE.json configs[{WORKLOAD_CONFIG[name]}])",
+                  "schedule": schedule, "samples_per_step": frame_samples,
+                  "parallelism": (f"frames round-robin over {world} GPU(s), no collective" if m["n_frames"] > 1 else f"tiles round-robin over {world} GPU(s), RCCL sum-reduce")
+                  if distributed else "1 GPU", "seed": 1,
+                  "vertices_per_sample": round(vbar, 4)}
+        return value, ms_per_step, config, roofline
+
+    main_m = run_workload(args.workload, args.spp or default_spp[args.workload], args.steps, args.warmup)
+    if rank == 0:
+        value, ms_per_step, config, roofline = line_of(main_m)
         out = {
             "metric": "Msamples/s (whole node) at 1920x1080; achieved HBM GB/s vs peak",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload} 1920x1080 {spp}spp, path tracer min_depth {fs.min_depth} max_depth {fs.max_depth}"
-                                   f"{', frame %d' % frame if args.workload == 'tr15_like' else ''} (BASELINE.json configs[{WORKLOAD_CONFIG[args.workload]}])",
-                       "schedule": schedule,
-                       "samples_per_step": frame_samples, "parallelism": f"tiles round-robin over {world} GPU(s), RCCL sum-reduce"
-                       if distributed else "1 GPU", "seed": 1, "vertices_per_sample": round(vbar, 4)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "compute": compute,
-                         "kernel": "7 stage kernels per round (HIP events around the whole schedule)" if wave else "k_path_tiles",
-                         "kernel_ms": round(k_ms, 3),
-                         "algorithmic_bytes_per_launch": int(algo_bytes),
-                         "note": "368 B per path vertex + 16 B per pixel is SURVEY 8(d)'s accounting of the WAVEFRONT formulation; " +
-                                 ("traversal of the 3.1 M-triangle scene is memory-latency bound" if wave
-                                  else "the tile megakernel keeps path state in registers and the film in LDS, its necessary HBM traffic is the 33 MB film: "
-                                       "the scene is cache resident and the kernel is bound by VALU issue at low lane utilisation -- see `compute`")},
+            "dtype": "f32", "data": "synthetic", "config": config, "roofline": roofline,
         }
+    # BASELINE.json configs[2..4] beside the reported line (N = 1 only, like the CPU leg): one warm-up launch at a cut-down sample
+    # count, then full-size frames -- so that the driver's own run sees every workload, not only cornell_box
+    if world == 1 and args.workload == "cornell_box" and not args.spp and not args.no_other_workloads:
+        others = []
+        for name, steps in (("smallpt", 2), ("dragon", 2), ("tr15_like", 1)):
+            m = run_workload(name, default_spp[name], steps, 1, warmup_spp=16)
+            v, ms, cfg, rf = line_of(m)
+            others.append({"workload": cfg["workload"], "schedule": cfg["schedule"], "value": round(v, 3), "unit": "Msamples/s", "steps": steps,
+                           "warmup": "1 launch at 16 spp", "ms_per_step": round(ms, 3), "vertices_per_sample": cfg["vertices_per_sample"],
+                           "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu", "kernel", "kernel_ms")}})
+        out["workloads"] = others
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene.flatten(frame), spp)
+            out["cpu_baseline"] = cpu_baseline(main_m["scene"].flatten(main_m["frame"]), main_m["spp"])
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

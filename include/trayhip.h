@@ -289,6 +289,12 @@ int tray_device_count(int* n);
 
 /* Deep-copies the flat scene to the current device. */
 int tray_scene_create(const TrayFlatScene* flat, TrayDeviceScene** out);
+/* Scene::update_frame (src/scene.rs:152-176; the frame loop of src/main.rs:91-106 keeps the Scene and rebuilds the instance
+ * transforms and BVH<Instance> per frame): `flat` is the SAME scene flattened at another frame. Instances, BVH<Instance>, camera,
+ * spline tables, emission keys and the set of moving instances are uploaded anew; meshes, MERL tables, textures, the tile queue,
+ * the wavefront pool / queues and the per-path transform cache stay on the device. Waits for the device to be idle. On an error
+ * the handle can only be passed to tray_scene_destroy. */
+int tray_scene_update_frame(TrayDeviceScene* s, const TrayFlatScene* flat);
 void tray_scene_destroy(TrayDeviceScene* s);
 
 /* thread_work over tiles [tile_start, tile_start+tile_count) of the Morton queue
@@ -341,7 +347,7 @@ int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t);
  * The reference's distributed mode hands every worker a slice of the block queue and sums the returned RGBW blocks on the
  * master (src/exec/distrib/master.rs:91-93,124-163; film::Image::add_blocks, src/film/image.rs:36-50). Here the workers are
  * the GPUs of one node: tray_multi_create deep-copies the scene to each listed device and creates one RCCL communicator per
- * device (ncclCommInitAll); tray_render_frame_multi renders shard d of n_dev on device d (tray_render_shard_device, 16-tile
+ * device (ncclCommInitAll); the calls leave the calling thread's current HIP device as they found it; tray_render_frame_multi renders shard d of n_dev on device d (tray_render_shard_device, 16-tile
  * chunks round-robin, one host thread and one stream per device), sums the per-device films onto the first device with ONE
  * ncclReduce(sum) over xGMI and adds the result into rgbw_host (width*height*4 f32, get_renderf32 layout). A Rust
  * exec::Hip that owns a whole node calls these three instead of spawning worker processes. RCCL is loaded with dlopen
@@ -349,6 +355,8 @@ int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t);
 typedef struct TrayMultiScene TrayMultiScene;
 int tray_multi_create(const TrayFlatScene* f, int n_dev, const int* dev_ids, TrayMultiScene** out);
 int tray_render_frame_multi(TrayMultiScene* m, uint32_t spp, uint64_t seed, float* rgbw_host);
+/* tray_scene_update_frame on every device of m; the communicators, films and streams are kept (scene.rs:152-176 per worker) */
+int tray_multi_update_frame(TrayMultiScene* m, const TrayFlatScene* f);
 /* per-device timings of the last tray_render_frame_multi (n_dev entries) and the duration of the reduce (ms) */
 int tray_multi_timing(TrayMultiScene* m, TrayKernelTiming* per_device, float* reduce_ms);
 void tray_multi_destroy(TrayMultiScene* m);

@@ -304,10 +304,11 @@ def test_wavefront_schedule_matches_the_oracle(name, trace, tmp_path, monkeypatc
     monkeypatch.setenv("TRAYHIP_MODE", "wave")
     monkeypatch.setenv("TRAYHIP_WF_TRACE", trace)
     monkeypatch.setenv("TRAYHIP_WF_SLOTS", "65536")
-    scene, rt, _, fi = load(SCENES[name](96, 64, 16), tmp_path)
-    gpu, tim = gpu_render(scene, rt, 16, fi, seed=6)
+    spp = 64   # (a path that ocml's sin / cos flip on the glass or metal sphere weighs 1 / spp: 16 spp left 1.2e-4 on smallpt)
+    scene, rt, _, fi = load(SCENES[name](96, 64, spp), tmp_path)
+    gpu, tim = gpu_render(scene, rt, spp, fi, seed=6)
     scene.release_device()
-    cpu, st = O.render_tiles(scene.flatten(0), 16, seed=6)
+    cpu, st = O.render_tiles(scene.flatten(0), spp, seed=6)
     assert tim.samples == st.samples
     assert abs(int(tim.vertices) - int(st.vertices)) <= 2e-4 * st.vertices
     assert rmse(gpu, cpu) < 1e-4
@@ -609,3 +610,65 @@ def test_random_scene_sweep_on_the_gpu(tmp_path):
         assert fin.mean() > 0.999 and r < 1e-4 and (diff.max(axis=-1) > 1e-2).mean() < 2e-3, (seed, r)   # (worst of the 18 on an MI355X: 1e-6)
         scene.release_device()
     print(f"random scenes on the GPU: worst image RMSE {worst:.3e}")
+
+
+def _fresh_and_updated(path, frames, spp, seed, n=4096):
+    """per-sample radiance and hit records of `frames[-1]`, once from a device scene created at that frame and once from one that
+    was created at frames[0] and walked through the others with tray_scene_update_frame; plus both images"""
+    out = []
+    for walk in (False, True):
+        scene, rt, _, fi = T.Scene.load_file(path)
+        hip = T.Hip(0, seed=seed)
+        if walk:
+            for fr in frames[:-1]:   # render every frame on the way: the pools, queues and caches are carried along
+                rt.clear()
+                hip.render(scene, rt, _config_at(fi, fr, spp))
+        frame = frames[-1]
+        rt.clear()
+        hip.render(scene, rt, _config_at(fi, frame, spp))
+        img = rt.get_renderf32().reshape(rt.height, rt.width, 4).copy()
+        dev = scene.device_scene(frame, 0)   # (the same handle: no third create)
+        rng = np.random.default_rng(5)
+        px = rng.integers(0, rt.width, n).astype(np.uint32); py = rng.integers(0, rt.height, n).astype(np.uint32)
+        si = rng.integers(0, spp, n).astype(np.uint32)
+        rad = np.zeros((n, 8), np.float32)
+        T.check(T.lib().tray_debug_sample_radiance(dev, n, px.ctypes.data, py.ctypes.data, si.ctypes.data, spp, seed, rad.ctypes.data))
+        flat = scene.flatten(frame)
+        rays = O.camera_rays(flat, rng.uniform(0, [rt.width, rt.height], (n, 2)), rng.uniform(0, 1, n).astype(np.float32))
+        hits = np.zeros(n, dtype=O.HIT_DTYPE)
+        T.check(T.lib().tray_debug_intersect(dev, n, rays.ctypes.data, hits.ctypes.data))
+        out.append((img, rad, hits, hip.last_timing))
+        scene.close()
+    return out
+
+
+@pytest.mark.parametrize("which", ["moving_box", "tr15_like"])
+def test_frame_update_equals_a_fresh_device_scene(which, tmp_path):
+    """tray_scene_update_frame (Scene::update_frame, scene.rs:152-176): a device scene walked 329 -> 330 -> 331 (moving_box:
+    0 -> 3 -> 5) answers exactly like one created at the last frame -- hit records and per-sample radiance bit for bit (the debug
+    kernels are deterministic; the film's float atomics are not ordered, so the images are compared to 1e-6 of their maximum)."""
+    if which == "moving_box":
+        path, frames, spp = scenes.write_moving_box(str(tmp_path), width=160, height=120, samples=32), (0, 3, 5), 32
+    else:
+        path, frames, spp = scenes.write_tr15_like_assets(str(tmp_path), film=(160, 96, 16), detail=0.05)[0], (329, 330, 331), 16
+    (img_a, rad_a, hit_a, tim_a), (img_b, rad_b, hit_b, tim_b) = _fresh_and_updated(path, frames, spp, seed=6)
+    assert hit_a.tobytes() == hit_b.tobytes()
+    assert rad_a.tobytes() == rad_b.tobytes()
+    assert (tim_a.samples, tim_a.vertices, tim_a.rays) == (tim_b.samples, tim_b.vertices, tim_b.rays)
+    assert np.abs(img_a - img_b).max() <= 1e-6 * img_a.max()
+
+
+def test_frame_update_of_the_multi_device_scene(tmp_path):
+    """tray_multi_update_frame keeps the communicators: frames 0 and 5 of the moving scene through ONE TrayMultiScene equal the
+    single-device renders of those frames."""
+    scene, rt, _, fi = T.Scene.load_file(scenes.write_moving_box(str(tmp_path), width=160, height=120, samples=32))
+    hip = T.Hip(0, seed=8)
+    for frame in (0, 5):
+        rt.clear()
+        hip.render_multi(scene, rt, _config_at(fi, frame, 32), [0])
+        multi_img = rt.get_renderf32().reshape(120, 160, 4).copy()
+        rt.clear()
+        hip.render(scene, rt, _config_at(fi, frame, 32))
+        single = rt.get_renderf32().reshape(120, 160, 4)
+        assert np.allclose(multi_img, single, rtol=0, atol=1e-5 * single.max()), frame
+    hip.close_multi()

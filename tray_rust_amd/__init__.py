@@ -141,8 +141,16 @@ class Scene:
         return p
 
     def device_scene(self, frame=0, device=None):
-        if self._dev is not None and (self._dev_frame != frame or (device is not None and device != self._dev_device)):
+        if self._dev is not None and device is not None and device != self._dev_device:
             self.release_device()
+        if self._dev is not None and self._dev_frame != frame:
+            # Scene::update_frame (scene.rs:152-176): the device copy moves to the new frame, meshes / tables / pools stay where they are
+            try:
+                check(lib().tray_scene_update_frame(self._dev, self.flatten(frame)))
+            except TrayError:
+                self.release_device()   # a failed update leaves a handle that can only be destroyed
+                raise
+            self._dev_frame = frame
         if self._dev is None:
             flat = self.flatten(frame)   # host work first: a scene that cannot be flattened fails here, with or without a GPU
             if device is not None:
@@ -178,6 +186,7 @@ class Hip:
         self.device, self.seed = int(device), int(seed)
         check(lib().tray_init(self.device))
         self.last_timing = None
+        self._multi, self._multi_key, self._multi_frame = None, None, None
 
     def render(self, scene, rt, config):
         spp = round_spp(config.spp)
@@ -206,20 +215,42 @@ class Hip:
     def render_multi(self, scene, rt, config, devices):
         """One frame on several GPUs of this process: tiles sharded round-robin over `devices`, the per-device films summed onto
         the first one by RCCL inside the library (tray_render_frame_multi; the master's Image::add_blocks merge,
-        exec/distrib/master.rs:124-163, film/image.rs:36-50), the result added into rt. Returns (per-device timings, reduce ms)."""
+        exec/distrib/master.rs:124-163, film/image.rs:36-50), the result added into rt. Returns (per-device timings, reduce ms).
+        The per-device scenes and the communicators are kept between calls: another frame of the same scene on the same devices
+        is a tray_multi_update_frame (scene.rs:152-176), not a new ncclCommInitAll. close_multi() releases them."""
         spp = round_spp(config.spp)
+        key = (id(scene), tuple(int(d) for d in devices))
+        if self._multi is not None and self._multi_key != key:
+            self.close_multi()
         flat = scene.flatten(config.current_frame)
-        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
-        m = C.c_void_p()
-        check(lib().tray_multi_create(flat, len(devices), ids, C.byref(m)))
-        try:
-            check(lib().tray_render_frame_multi(m, spp, self.seed, rt.pixels.ctypes.data))
-            per = (_lib.TrayKernelTiming * len(devices))()
-            ms = C.c_float()
-            check(lib().tray_multi_timing(m, per, C.byref(ms)))
-        finally:
-            lib().tray_multi_destroy(m)
+        if self._multi is None:
+            ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+            m = C.c_void_p()
+            check(lib().tray_multi_create(flat, len(devices), ids, C.byref(m)))
+            self._multi, self._multi_key, self._multi_frame = m, key, config.current_frame
+        elif self._multi_frame != config.current_frame:
+            try:
+                check(lib().tray_multi_update_frame(self._multi, flat))
+            except TrayError:
+                self.close_multi()
+                raise
+            self._multi_frame = config.current_frame
+        check(lib().tray_render_frame_multi(self._multi, spp, self.seed, rt.pixels.ctypes.data))
+        per = (_lib.TrayKernelTiming * len(devices))()
+        ms = C.c_float()
+        check(lib().tray_multi_timing(self._multi, per, C.byref(ms)))
         return list(per), float(ms.value)
+
+    def close_multi(self):
+        if self._multi is not None:
+            lib().tray_multi_destroy(self._multi)
+            self._multi = None
+
+    def __del__(self):
+        try:
+            self.close_multi()
+        except Exception:
+            pass
 
     def timing(self, scene):
         t = _lib.TrayKernelTiming()

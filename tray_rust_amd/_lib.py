@@ -152,6 +152,7 @@ SYMBOLS = {
     "tray_init": (C.c_int, [C.c_int]),
     "tray_device_count": (C.c_int, [_P(C.c_int)]),
     "tray_scene_create": (C.c_int, [_P(TrayFlatScene), _P(C.c_void_p)]),
+    "tray_scene_update_frame": (C.c_int, [C.c_void_p, _P(TrayFlatScene)]),
     "tray_scene_destroy": (None, [C.c_void_p]),
     "tray_render_tiles_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "tray_render_shard_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
@@ -159,6 +160,7 @@ SYMBOLS = {
     "tray_multi_create": (C.c_int, [_P(TrayFlatScene), C.c_int, _P(C.c_int), _P(C.c_void_p)]),
     "tray_render_frame_multi": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]),
     "tray_multi_timing": (C.c_int, [C.c_void_p, _P(TrayKernelTiming), _P(C.c_float)]),
+    "tray_multi_update_frame": (C.c_int, [C.c_void_p, _P(TrayFlatScene)]),
     "tray_multi_destroy": (None, [C.c_void_p]),
     "tray_render_tiles": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),
     "tray_last_timing": (C.c_int, [C.c_void_p, _P(TrayKernelTiming)]),

@@ -509,10 +509,15 @@ __global__ __launch_bounds__(64) void k_debug_bsdf(const DevScene scv, uint32_t 
 // ================================================================== host side of the device ABI
 #ifndef TR_HOST_EMU
 
+struct TrayDevBuf { const char* key; void* ptr; size_t bytes; };
 struct TrayDeviceScene {
     int device = 0;
     DevScene dev{};
     std::vector<void*> allocs;
+    std::vector<TrayDevBuf> bufs;        // the named uploads among `allocs`: what tray_scene_update_frame can carry over to the next frame
+    TrayDeviceScene* donor = nullptr;    // while a frame update builds the new state: the previous frame's scene, whose buffers may be taken
+    size_t xf_cache_bytes = 0;
+    bool broken = false;                 // a frame update failed half way: only tray_scene_destroy is valid
     uint2* d_tiles = nullptr;      // full Morton queue
     uint32_t n_tiles = 0;
     uint32_t* d_counter = nullptr;
@@ -559,15 +564,34 @@ static thread_local int g_device = 0;
         }                                                                                                 \
     } while (0)
 
+static void forget_alloc(TrayDeviceScene* s, void* p) {
+    s->allocs.erase(std::remove(s->allocs.begin(), s->allocs.end(), p), s->allocs.end());
+}
+// Device copy of a host array under a name. During a frame update (s->donor set) a buffer of the same name and size is taken from
+// the previous frame's scene instead of allocated: `unchanged` arrays (meshes, MERL tables, textures, the tile queue: the caller
+// passes the same scene at another frame, tray_scene_update_frame) keep their content, the others are overwritten.
 template <class T>
-static int upload(TrayDeviceScene* s, const T* host, size_t n, const T** out) {
+static int upload(TrayDeviceScene* s, const char* key, bool unchanged, const T* host, size_t n, const T** out) {
     *out = nullptr;
     size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
     void* d = nullptr;
-    HIP_CHECK(hipMalloc(&d, bytes));
+    bool reused = false;
+    if (TrayDeviceScene* don = s->donor)
+        for (size_t i = 0; i < don->bufs.size(); ++i)
+            if (std::strcmp(don->bufs[i].key, key) == 0 && don->bufs[i].bytes == bytes) {
+                d = don->bufs[i].ptr;
+                forget_alloc(don, d);
+                don->bufs.erase(don->bufs.begin() + (long)i);
+                reused = true;
+                break;
+            }
+    if (!d) HIP_CHECK(hipMalloc(&d, bytes));
     s->allocs.push_back(d);
-    if (n) HIP_CHECK(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
-    else HIP_CHECK(hipMemset(d, 0, bytes));
+    s->bufs.push_back(TrayDevBuf{key, d, bytes});
+    if (!(reused && unchanged)) {
+        if (n) HIP_CHECK(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+        else HIP_CHECK(hipMemset(d, 0, bytes));
+    }
     *out = static_cast<const T*>(d);
     return TRAY_OK;
 }
@@ -658,7 +682,9 @@ void tray_scene_destroy(TrayDeviceScene* s) {
     delete s;
 }
 
-int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
+} // extern "C" (scene_build is internal)
+
+static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDeviceScene** out) {
     if (!f || !out) { set_error("tray_scene_create: null argument"); return TRAY_E_INVALID; }
     *out = nullptr;
     if (f->abi_version != TRAY_ABI_VERSION) { set_error("tray_scene_create: ABI version mismatch"); return TRAY_E_INVALID; }
@@ -704,26 +730,29 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         if (in.geom_type == TRAY_GEOM_MESH && in.mesh_id >= f->n_meshes) { set_error("instance references a missing mesh"); return TRAY_E_INVALID; }
     }
     TrayDeviceScene* s = new TrayDeviceScene();
-    s->device = g_device;
+    s->device = donor ? donor->device : g_device;
+    s->donor = donor;
     if (hipSetDevice(s->device) != hipSuccess) { delete s; set_error("hipSetDevice failed (is a GPU present?)"); return TRAY_E_DEVICE; }
     DevScene& d = s->dev;
     int rc = TRAY_OK;
     const TrayInstance* d_inst = nullptr;
-#define UP(field, hostptr, count)                                                     \
+#define UP_(field, hostptr, count, unchanged)                                         \
     if (rc == TRAY_OK) {                                                              \
         std::remove_cv_t<std::remove_pointer_t<decltype(hostptr)>> const* _p = nullptr; \
-        rc = upload(s, hostptr, (size_t)(count), &_p);                                \
+        rc = upload(s, #field, unchanged, hostptr, (size_t)(count), &_p);             \
         d.field = _p;                                                                 \
     }
-    if (rc == TRAY_OK) rc = upload(s, f->instances, f->n_instances, &d_inst);
+#define UP(field, hostptr, count) UP_(field, hostptr, count, false)    /* may differ from frame to frame */
+#define UPS(field, hostptr, count) UP_(field, hostptr, count, true)    /* part of the scene, the same at every frame */
+    if (rc == TRAY_OK) rc = upload(s, "instances", false, f->instances, f->n_instances, &d_inst);
     d.instances = d_inst;
     s->d_instances = const_cast<TrayInstance*>(d_inst);
     UP(top_nodes, f->top_nodes, f->n_top_nodes)
     UP(top_order, f->top_order, f->n_top_order)
-    UP(meshes, f->meshes, f->n_meshes)
-    UP(mesh_nodes, f->mesh_nodes, f->n_mesh_nodes)
-    UP(tri_verts, f->tri_verts, f->n_tris)
-    UP(tri_attrs, f->tri_attrs, f->n_tris)
+    UPS(meshes, f->meshes, f->n_meshes)
+    UPS(mesh_nodes, f->mesh_nodes, f->n_mesh_nodes)
+    UPS(tri_verts, f->tri_verts, f->n_tris)
+    UPS(tri_attrs, f->tri_attrs, f->n_tris)
     std::vector<DevMaterial> mats(f->n_materials);
     for (uint32_t i = 0; i < f->n_materials; ++i) {
         if (f->materials[i].kind == TRAY_MAT_MERL && f->materials[i].table >= f->n_merl) { rc = TRAY_E_INVALID; set_error("material references a missing MERL table"); }
@@ -749,16 +778,16 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     }
     for (const DevMaterial& dm : mats) s->mat_kinds_present |= 1u << dm.mat_kind;
     if (f->n_textures) {
-        UP(textures, f->textures, f->n_textures)
-        UP(tex_frames, f->tex_frames, f->n_tex_frames)
-        UP(tex_data, f->tex_data, f->n_tex_bytes)
+        UPS(textures, f->textures, f->n_textures)
+        UPS(tex_frames, f->tex_frames, f->n_tex_frames)
+        UPS(tex_data, f->tex_data, f->n_tex_bytes)
     }
     UP(materials, mats.data(), f->n_materials)
-    UP(merl_data, f->merl_data, f->n_merl_floats)
+    UPS(merl_data, f->merl_data, f->n_merl_floats)
     UP(lights, f->lights, f->n_lights)
-    UP(filter_table, &f->film.table[0], TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE)
-    UP(filter_x, &f->film.table_x[0], TRAY_FILTER_TABLE_SIZE)
-    UP(filter_y, &f->film.table_y[0], TRAY_FILTER_TABLE_SIZE)
+    UPS(filter_table, &f->film.table[0], TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE)
+    UPS(filter_x, &f->film.table_x[0], TRAY_FILTER_TABLE_SIZE)
+    UPS(filter_y, &f->film.table_y[0], TRAY_FILTER_TABLE_SIZE)
     UP(xf_levels, f->xf_levels, f->n_xf_levels)
     UP(keyframes, f->keyframes, f->n_keyframes)
     UP(knots, f->knots, f->n_knots)
@@ -766,9 +795,11 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     {   // the shuffles of the per-path LD arrays (path.rs:55-60: arrays of max_depth + 1 samples) come from a pool built once per scene
         std::vector<uint8_t> pool(TR_PERM_BYTES);
         perm_pool_build(f->max_depth + 1u, pool.data());
-        UP(perm_pool, pool.data(), pool.size())
+        UPS(perm_pool, pool.data(), pool.size())
     }
 #undef UP
+#undef UPS
+#undef UP_
     for (uint32_t t = 0; t < f->n_textures; ++t) moving = moving || f->textures[t].n_frames >= 2u;   // animated_image: sampled at ray.time, which only the ANIM kernels carry
     s->animated = moving;
     if (rc == TRAY_OK) {   // the flat instance loop's records and gates (host/gates.hpp; dev_geom.h: trace_flat, mesh_leaf_coop)
@@ -779,9 +810,9 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         const tray::FlatLeaf* d_leaves = nullptr;
         const tray::FlatInst* d_insts = nullptr;
         const uint8_t* d_tri_leaf = nullptr;
-        rc = upload(s, leaves.data(), leaves.size(), &d_leaves);
-        if (rc == TRAY_OK) rc = upload(s, insts.data(), insts.size(), &d_insts);
-        if (rc == TRAY_OK) rc = upload(s, tri_leaf.data(), tri_leaf.size(), &d_tri_leaf);
+        rc = upload(s, "flat_leaves", false, leaves.data(), leaves.size(), &d_leaves);
+        if (rc == TRAY_OK) rc = upload(s, "flat_insts", false, insts.data(), insts.size(), &d_insts);
+        if (rc == TRAY_OK) rc = upload(s, "tri_leaf", true, tri_leaf.data(), tri_leaf.size(), &d_tri_leaf);
         d.flat_leaves = d_leaves; d.flat_insts = d_insts; d.n_flat_leaves = (uint32_t)leaves.size(); d.tri_leaf = d_tri_leaf;
     }
     if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
@@ -804,7 +835,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
     {
         const TrayCamera* d_cam = nullptr;
-        rc = upload(s, &f->camera, 1, &d_cam);
+        rc = upload(s, "camera", false, &f->camera, 1, &d_cam);
         d.camera_p = d_cam;
         if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
     }
@@ -814,7 +845,7 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     std::vector<uint32_t> xy(2 * (size_t)n_tiles);
     if (rc == TRAY_OK) rc = tray_block_queue(d.width, d.height, 0, 0, xy.data(), n_tiles, &n_tiles);
     const uint2* d_tiles = nullptr;
-    if (rc == TRAY_OK) rc = upload(s, reinterpret_cast<const uint2*>(xy.data()), n_tiles, &d_tiles);
+    if (rc == TRAY_OK) rc = upload(s, "tiles", true, reinterpret_cast<const uint2*>(xy.data()), n_tiles, &d_tiles);
     s->d_tiles = const_cast<uint2*>(d_tiles);
     s->n_tiles = n_tiles;
     const uint32_t* d_counter = nullptr;
@@ -822,16 +853,17 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
     uint32_t zero = 0;
     std::vector<DevStats> zs(WF_STAT_SLOTS);
     std::memset(zs.data(), 0, zs.size() * sizeof(DevStats));
-    if (rc == TRAY_OK) rc = upload(s, &zero, 1, &d_counter);
-    if (rc == TRAY_OK) rc = upload(s, zs.data(), zs.size(), &d_stats);
+    if (rc == TRAY_OK) rc = upload(s, "counter", false, &zero, 1, &d_counter);
+    if (rc == TRAY_OK) rc = upload(s, "stats", false, zs.data(), zs.size(), &d_stats);
     const uint32_t* d_retraced = nullptr;
-    if (rc == TRAY_OK) rc = upload(s, &zero, 1, &d_retraced);
+    if (rc == TRAY_OK) rc = upload(s, "retraced", false, &zero, 1, &d_retraced);
     s->d_counter = const_cast<uint32_t*>(d_counter);
     s->d_stats = const_cast<DevStats*>(d_stats);
     s->d_retraced = const_cast<uint32_t*>(d_retraced);
     d.retraced = s->d_retraced;
     if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
-    if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
+    if (donor && donor->ev0 && donor->ev1) { s->ev0 = donor->ev0; s->ev1 = donor->ev1; donor->ev0 = nullptr; donor->ev1 = nullptr; }
+    else if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
         tray_scene_destroy(s); set_error("hipEventCreate failed"); return TRAY_E_DEVICE;
     }
     {   // traversal stack depth: deepest node of any BVH<Triangle>; the one-loop two-level traversal (more than
@@ -935,12 +967,22 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         for (uint32_t i = 0; i < f->n_instances; ++i)
             if (f->instances[i].animated && f->instances[i].moving_slot < ids.size()) ids[f->instances[i].moving_slot] = i;
         const uint32_t* d_ids = nullptr;
-        if (upload(s, ids.data(), ids.size(), &d_ids) != TRAY_OK) { tray_scene_destroy(s); return TRAY_E_NOMEM; }
-        const uint32_t lanes = s->wavefront ? wf_slot_count(s) : (uint32_t)s->n_blocks * TR_BLOCK;   // one column per pool slot / per thread
+        if (upload(s, "moving_ids", false, ids.data(), ids.size(), &d_ids) != TRAY_OK) { tray_scene_destroy(s); return TRAY_E_NOMEM; }
+        // one column per pool slot / per thread; a frame update keeps the previous frame's pool size (the budget of wf_slot_count is a
+        // share of the memory that was free BEFORE the pool existed)
+        const bool keep_lanes = donor && donor->dev.xf_cache_lanes != 0u && donor->wavefront == s->wavefront && (s->wavefront || donor->n_blocks == s->n_blocks);
+        const uint32_t lanes = keep_lanes ? donor->dev.xf_cache_lanes : (s->wavefront ? wf_slot_count(s) : (uint32_t)s->n_blocks * TR_BLOCK);
         const uint32_t n_moving_for_msg = s->deferred_n_moving;
         void* cache = nullptr;
         const size_t cache_bytes = (size_t)s->deferred_n_moving * 24u * lanes * sizeof(float);
-        if (hipMalloc(&cache, cache_bytes) != hipSuccess) {
+        if (keep_lanes && donor->dev.xf_cache && donor->xf_cache_bytes >= cache_bytes) {   // (every path fills its columns before it reads them)
+            cache = donor->dev.xf_cache;
+            s->xf_cache_bytes = donor->xf_cache_bytes;
+            forget_alloc(donor, cache);
+            donor->dev.xf_cache = nullptr; donor->xf_cache_bytes = 0;
+        } else if (hipMalloc(&cache, cache_bytes) == hipSuccess) {
+            s->xf_cache_bytes = cache_bytes;
+        } else {
             tray_scene_destroy(s);
             set_error("hipMalloc of the per-path transform cache failed: " + std::to_string(cache_bytes >> 20) + " MiB for " + std::to_string(n_moving_for_msg) +
                       " moving instances x " + std::to_string(lanes) + " paths (TRAYHIP_WF_SLOTS / TRAYHIP_XF_CACHE_BYTES bound it)");
@@ -953,7 +995,50 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) {
         s->dev.xf_cache_lanes = lanes;
         s->dev.xf_aos = s->wavefront ? 1u : 0u;
     }
+    if (donor && donor->wf_ready && s->wavefront && donor->stack_bytes == s->stack_bytes && donor->animated == s->animated &&
+        donor->pool.n_slots == ((s->animated && s->dev.xf_cache_lanes) ? s->dev.xf_cache_lanes : wf_slot_count(s))) {
+        // the wavefront schedule's pool, queues, chunk records and row bins (2.2 GB at 8 M slots) serve the next frame as they are:
+        // launch_wavefront re-initialises the chunk records and the control words of every launch, the bins are zero between tiles
+        for (void* p : {(void*)donor->pool.data, (void*)donor->d_chunks, (void*)donor->d_bins, (void*)donor->d_wf_counters, (void*)donor->d_queues,
+                        (void*)donor->d_kind_queues, (void*)donor->d_stack_overflow})
+            if (p) { forget_alloc(donor, p); s->allocs.push_back(p); }
+        s->pool = donor->pool; s->d_chunks = donor->d_chunks; s->d_bins = donor->d_bins; s->d_wf_counters = donor->d_wf_counters;
+        s->d_queues = donor->d_queues; s->d_kind_queues = donor->d_kind_queues; s->d_stack_overflow = donor->d_stack_overflow;
+        s->h_done = donor->h_done; donor->h_done = nullptr;
+        s->n_chunks = donor->n_chunks; s->n_blocks_trace = donor->n_blocks_trace; s->trace_lds_depth = donor->trace_lds_depth;
+        s->trace_lds_bytes = donor->trace_lds_bytes; s->wf_dynamic = donor->wf_dynamic; s->wf_sort = donor->wf_sort;
+        s->wf_ready = true;
+        donor->wf_ready = false; donor->pool.data = nullptr;
+    }
+    s->donor = nullptr;
     *out = s;
+    return TRAY_OK;
+}
+
+extern "C" {
+
+int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) { return scene_build(f, nullptr, out); }
+
+// Scene::update_frame (scene.rs:152-176) for the device copy: the frame loop of main.rs:91-106 keeps the scene and rebuilds the
+// instance transforms and BVH<Instance> per frame. `f` is the SAME scene flattened at another frame: meshes, MERL tables, textures,
+// materials' tables and the tile queue are kept on the device (buffers whose size is unchanged are taken over without a copy),
+// instances, BVH<Instance>, flat-loop records, camera, spline tables, colour keys and the moving set are uploaded anew, and the
+// wavefront pool / queues and the per-path transform cache are carried over. Nothing else is assumed: every decision of
+// tray_scene_create (schedule, kernel instantiation, stack depth, occupancy) is taken again for the new frame.
+int tray_scene_update_frame(TrayDeviceScene* s, const TrayFlatScene* f) {
+    if (!s || !f) { set_error("tray_scene_update_frame: null argument"); return TRAY_E_INVALID; }
+    if (f->n_tris != 0u && s->dev.tri_verts == nullptr) { set_error("tray_scene_update_frame: not the scene this device copy was created from"); return TRAY_E_INVALID; }
+    if (f->film.width != s->dev.width || f->film.height != s->dev.height) { set_error("tray_scene_update_frame: the film size changed: create a new device scene"); return TRAY_E_INVALID; }
+    HIP_CHECK(hipSetDevice(s->device));
+    HIP_CHECK(hipDeviceSynchronize());   // (launches of the previous frame read the buffers that are about to be overwritten)
+    TrayDeviceScene* n = nullptr;
+    const int before = g_device;
+    g_device = s->device;
+    const int rc = scene_build(f, s, &n);
+    g_device = before;
+    if (rc != TRAY_OK) { s->donor = nullptr; s->broken = true; return rc; }   // buffers may have moved already: the handle can only be destroyed now
+    std::swap(*s, *n);        // the handle keeps its identity; n now owns what the new frame did not take over
+    tray_scene_destroy(n);
     return TRAY_OK;
 }
 
@@ -1084,6 +1169,7 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
                         uint32_t spp, uint64_t seed, float* rgbw_dev, void* stream_) {
     if (spp == 0 || (spp & (spp - 1)) != 0) { set_error("spp must be a power of two (LowDiscrepancy sampler, ld.rs:22-25); use tray_round_spp"); return TRAY_E_INVALID; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (s->broken) { set_error("this device scene is unusable: a tray_scene_update_frame on it failed"); return TRAY_E_INVALID; }
     HIP_CHECK(hipSetDevice(s->device));
     s->timing_valid = false;
     if (tile_count == 0) { std::fprintf(stderr, "Warning: This block queue is empty!\n"); return TRAY_OK; }   // block_queue.rs:42-44
@@ -1195,6 +1281,8 @@ struct TrayMultiScene {
 
 void tray_multi_destroy(TrayMultiScene* m) {
     if (!m) return;
+    int current = 0;
+    const bool have_current = hipGetDevice(&current) == hipSuccess;   // the caller's current device is left as it was
     for (int d = 0; d < (int)m->scenes.size(); ++d) {
         (void)hipSetDevice(m->dev_ids[d]);
         if (d < (int)m->comms.size() && m->comms[d] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comms[d]);
@@ -1203,6 +1291,7 @@ void tray_multi_destroy(TrayMultiScene* m) {
         if (d == 0) { if (m->r0) (void)hipEventDestroy(m->r0); if (m->r1) (void)hipEventDestroy(m->r1); }
         tray_scene_destroy(m->scenes[d]);
     }
+    if (have_current) (void)hipSetDevice(current);
     delete m;
 }
 
@@ -1252,8 +1341,27 @@ int tray_multi_create(const TrayFlatScene* f, int n_dev, const int* dev_ids, Tra
     return TRAY_OK;
 }
 
+// The same scene at another frame on every device (tray_scene_update_frame); communicators, films and streams stay.
+int tray_multi_update_frame(TrayMultiScene* m, const TrayFlatScene* f) {
+    if (!m || !f) { set_error("tray_multi_update_frame: null argument"); return TRAY_E_INVALID; }
+    int current = 0;
+    const bool have_current = hipGetDevice(&current) == hipSuccess;
+    int rc = TRAY_OK;
+    for (int d = 0; d < m->n_dev && rc == TRAY_OK; ++d) rc = tray_scene_update_frame(m->scenes[d], f);
+    if (have_current) (void)hipSetDevice(current);
+    return rc;
+}
+
+struct CurrentDeviceGuard {   // the multi-device entry points leave the caller's current HIP device as they found it
+    int dev = 0;
+    bool ok = false;
+    CurrentDeviceGuard() { ok = hipGetDevice(&dev) == hipSuccess; }
+    ~CurrentDeviceGuard() { if (ok) (void)hipSetDevice(dev); }
+};
+
 int tray_render_frame_multi(TrayMultiScene* m, uint32_t spp, uint64_t seed, float* rgbw_host) {
     if (!m || !rgbw_host) { set_error("tray_render_frame_multi: null argument"); return TRAY_E_INVALID; }
+    CurrentDeviceGuard keep_current;
     // one host thread per device: the wavefront schedule polls its stream, and the launches of different devices must overlap
     std::vector<int> rcs(m->n_dev, TRAY_OK);
     std::vector<std::string> errs(m->n_dev);
@@ -1269,7 +1377,9 @@ int tray_render_frame_multi(TrayMultiScene* m, uint32_t spp, uint64_t seed, floa
     for (std::thread& w : workers) w.join();
     for (int d = 0; d < m->n_dev; ++d)
         if (rcs[d] != TRAY_OK) { set_error("tray_render_frame_multi: device " + std::to_string(m->dev_ids[d]) + ": " + errs[d]); return rcs[d]; }
-    // film::Image::add_blocks on the master == one sum-reduce onto the first device (in place on the root)
+    // film::Image::add_blocks on the master == one sum-reduce onto the first device (in place on the root). Every device's shard is
+    // finished before the reduce is timed, so reduce_ms is the collective alone, not the wait for the slowest shard
+    for (int d = 0; d < m->n_dev; ++d) { HIP_CHECK(hipSetDevice(m->dev_ids[d])); HIP_CHECK(hipStreamSynchronize(m->streams[d])); }
     HIP_CHECK(hipSetDevice(m->dev_ids[0]));
     HIP_CHECK(hipEventRecord(m->r0, m->streams[0]));
     int nr = g_rccl.GroupStart();
