@@ -178,7 +178,7 @@ typedef struct TrayMaterial {
 } TrayMaterial;
 enum { TRAY_MF_BECKMANN = 0, TRAY_MF_GGX = 1 };
 /* Integrator (src/integrator): the Path tracer (path.rs) or NormalsDebug (normals_debug.rs:28-33: (bsdf.n + 1) / 2 of the
- * camera ray's hit). Whitted (whitted.rs) is not built. */
+ * camera ray's hit), or Whitted (whitted.rs:41-68 with Integrator::specular_reflection / specular_transmission, mod.rs:49-97). */
 enum { TRAY_INTEGRATOR_PATH = 0, TRAY_INTEGRATOR_NORMALS_DEBUG = 1,
        TRAY_INTEGRATOR_WHITTED = 2 };   /* integrator/whitted.rs: max_depth = the recursion limit (<= 16), min_depth unused */
 

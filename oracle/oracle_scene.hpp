@@ -515,13 +515,13 @@ struct Beckmann {
     bool ggx = false;
     static Beckmann make(float w, bool ggx_ = false) { Beckmann m{std::fmax(w, 0.000001f)}; m.ggx = ggx_; return m; }
     float normal_distribution(Vec3 w_h) const {
-        if (ggx) {   // ggx.rs:27-36; powf(x, 2.0) / powf(x, 4.0) written as products like everywhere else in this file
+        if (ggx) {   // ggx.rs:27-36; powf(x, 2.0) is x * x exactly (and what LLVM makes of it), powf(x, 4.0) is libm's powf: ONE rounding of x^4
             if (cos_theta(w_h) > 0.0f) {
                 float width_sqr = width * width;
-                float c = cos_theta(w_h), c2 = c * c;
+                float c = cos_theta(w_h);
                 float t = tan_theta(w_h);
                 float s = width_sqr + t * t;
-                float denom = PI * (c2 * c2) * (s * s);
+                float denom = PI * std::pow(c, 4.0f) * (s * s);
                 return width_sqr / denom;
             }
             return 0.0f;

@@ -119,3 +119,97 @@ def load(path):
     out["instances"] = insts
     out["lights"] = [i for i, x in enumerate(insts) if x["kind"] != 0]
     return out
+
+
+# ---- assets: OBJ meshes (tobj 0.1.6 as called by mesh.rs:50-78), MERL tables (material/merl.rs:51-84) ----------------------
+def read_obj_model(path, model):
+    """Triangles of the object / group `model` of an OBJ file as tobj hands them to Mesh::new: faces fan-triangulated, every face
+    corner v/vt/vn resolved to (position, texcoord, normal). Returns (positions [n,3,3], normals [n,3,3], texcoords [n,3,2]) in file
+    order, float64 as written in the file."""
+    v, vt, vn = [], [], []
+    tris_p, tris_n, tris_t = [], [], []
+    cur = None
+    for line in open(path):
+        p = line.split()
+        if not p or p[0].startswith("#"):
+            continue
+        if p[0] == "v": v.append([float(x) for x in p[1:4]])
+        elif p[0] == "vt": vt.append([float(x) for x in p[1:3]])
+        elif p[0] == "vn": vn.append([float(x) for x in p[1:4]])
+        elif p[0] in ("o", "g"): cur = p[1] if len(p) > 1 else ""
+        elif p[0] == "f" and cur == model:
+            corners = []
+            for tok in p[1:]:
+                a = tok.split("/")
+                idx = [int(x) if x else 0 for x in a] + [0] * (3 - len(a))
+                res = []
+                for k, arr in zip(idx, (v, vt, vn)):   # OBJ indices are 1-based, negative = relative to the end
+                    res.append(arr[k - 1] if k > 0 else arr[k])
+                corners.append(res)
+            for i in range(1, len(corners) - 1):
+                tri = (corners[0], corners[i], corners[i + 1])
+                tris_p.append([c[0] for c in tri]); tris_t.append([c[1] for c in tri]); tris_n.append([c[2] for c in tri])
+    return np.array(tris_p, np.float64), np.array(tris_n, np.float64), np.array(tris_t, np.float64)
+
+
+def read_merl(path):
+    """Merl::load_file (material/merl.rs:51-84): i32 x 3 header (90, 90, 180), then the red, green and blue planes as f64, scaled by
+    (1, 1, 1.66) / 1500 -- green WITHOUT MERL's own 1.15 (quirk Q10) --, narrowed to f32, clamped at 0, interleaved rgb."""
+    raw = open(path, "rb").read()
+    dims = np.frombuffer(raw, "<i4", 3)
+    assert tuple(dims) == (90, 90, 180), dims
+    n = int(np.prod(dims))
+    planes = np.frombuffer(raw, "<f8", 3 * n, offset=12).reshape(3, n)
+    scale = np.array([1.0 / 1500.0, 1.0 / 1500.0, 1.66 / 1500.0])
+    out = np.maximum(np.float32(0.0), (planes * scale[:, None]).astype(np.float32))
+    return np.ascontiguousarray(out.T).reshape(-1)   # brdf[3 * i + c]
+
+
+# ---- keyframed transforms (scene.rs:825-850, animated_transform.rs:22-86): the stack of spline levels of every instance --------
+def _level(o):
+    """one level of an AnimatedTransform: a constant (`transform`) or a B-spline over control transforms (`keyframes`)"""
+    if "keyframes" in o:
+        k = o["keyframes"]
+        return dict(mats=[load_transform(c["transform"]) for c in k["control_points"]], knots=[float(x) for x in k["knots"]], degree=int(k.get("degree", 3)))
+    return dict(mats=[load_transform(o.get("transform", []))], knots=None, degree=0)
+
+
+def instance_stacks(objs, parents=()):
+    """[(name, [own level, parent group's level, grandparent's, ...])] in scene order: a group composes as `group * child`, which
+    APPENDS the group's levels behind the child's (animated_transform.rs:78-86, scene.rs:568-573)"""
+    out = []
+    for o in objs:
+        if o["type"] == "group":
+            out += instance_stacks(o["objects"], (_level(o),) + tuple(parents))
+        else:
+            out.append((o["name"], [_level(o)] + list(parents)))
+    return out
+
+
+def keyframe_matrix(translation, rotation, scaling):
+    """Keyframe::transform (keyframe.rs:60-63): T * R(q) * S, q = (x, y, z, w) (quaternion.rs:67-99)"""
+    x, y, z, w = rotation
+    r = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    m = np.eye(4)
+    m[:3, :3] = r @ np.diag(scaling)
+    m[:3, 3] = translation
+    return m
+
+
+def keyframe_of(m):
+    """Keyframe::new / decompose (keyframe.rs:22-58) of a 4x4 transform, with numpy's SVD where the reference calls la::SVD: the
+    translation column; q = U V^T (negated together with p when det < 0); p = V S V^T, of which ONLY THE DIAGONAL is kept as the
+    scaling -- a control transform whose stretch is not axis-aligned after the rotation is therefore not reproduced by T R S (the
+    reference's behaviour). Returns the 4x4 matrix T * q * diag(p) the keyframe stands for."""
+    a = np.asarray(m, np.float64)[:3, :3]
+    u, sv, vt = np.linalg.svd(a)
+    q = u @ vt
+    p = vt.T @ np.diag(sv) @ vt
+    if np.linalg.det(q) < 0.0:
+        q, p = -q, -p
+    out = np.eye(4)
+    out[:3, :3] = q @ np.diag(np.diag(p))
+    out[:3, 3] = np.asarray(m, np.float64)[:3, 3]
+    return out

@@ -351,8 +351,8 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
 
 // The wavefront schedule (launch_wavefront + wf_round of kernels.hip): rounds of k_wf_advance -> k_wf_regen -> trace A ->
 // k_wf_begin -> trace B -> k_wf_query -> trace C over an HBM-style path pool until every tile is done. All kernels run as SIMT
-// emulations. trace: 0 = k_wf_trace_dyn (default of the library), 2 = k_wf_trace
-// (one thread per slot, TRAYHIP_WF_TRACE=slot). Moving scenes run the ANIM = 1 kernels with the per-slot transform cache.
+// emulations (`trace` is kept in the signature: 0 = k_wf_trace_dyn, the only traversal kernel). Moving scenes run the ANIM = 1 kernels with
+// the per-slot transform cache.
 // n_chunks = 256-slot chunks of the pool (<= tile_count); lds_depth as in emu_wf_trace.
 int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t tile_count, uint32_t spp, uint64_t seed, float* rgbw,
                          int trace, uint32_t n_chunks, uint32_t trace_blocks, uint32_t lds_depth, unsigned long long* stats_out) {
@@ -394,10 +394,11 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     if (lds_depth == 0 || lds_depth > full) lds_depth = full;
     trace_blocks = std::max(1u, std::min(trace_blocks, n_chunks));
     std::vector<uint32_t> overflow((size_t)(8u * e.depth + 64u) * trace_blocks * TR_BLOCK, 0u);
-    const size_t slot_lds = (size_t)e.depth * TR_BLOCK * 4, dyn_lds = (size_t)lds_depth * TR_BLOCK * 4;
+    const size_t dyn_lds = (size_t)lds_depth * TR_BLOCK * 4;
     const int feat = feature_set(e);
     // the material sort of the shading stage (default of the library for the compacted schedule; trace == 2 is the slot form without queues)
-    const bool sorted = trace != 2 && !getenv("TRAYHIP_WF_SORT_OFF") && !(feat & FEAT_TEX);
+    if (trace != 0) return -6;
+    const bool sorted = !(feat & FEAT_TEX);
     std::vector<uint32_t> kind_queues((size_t)WF_MAT_KINDS * q_cap, 0u);
     uint32_t kinds_present = 0;
     for (const DevMaterial& dm : e.mats) kinds_present |= 1u << dm.mat_kind;
@@ -411,19 +412,18 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
                                                          counters, counters + 1, stats.data(), qa, qr, qctl); });                          \
         EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_regen<A>(e.d, pool, chunks.data(), tiles.data(), tile_count, 1u, spp, kf, stats.data(), qr, qa, qctl); }); \
         EMU_TRACE_STAGE(0, A, qa);                                                                                                          \
-        EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_begin<A>(e.d, pool, n_active, stats.data(), trace == 2 ? nullptr : qb, trace == 2 ? nullptr : qctl, sorted ? kind_queues.data() : nullptr); }); \
+        EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_begin<A>(e.d, pool, n_active, stats.data(), qb, qctl, sorted ? kind_queues.data() : nullptr); }); \
         EMU_TRACE_STAGE(1, A, qb);                                                                                                          \
         if (sorted) {   /* wf_round of kernels.hip: one kind-pure shading launch per material kind of the scene */                        \
             EMU_QUERY_KIND(A, TRAY_MAT_MATTE); EMU_QUERY_KIND(A, TRAY_MAT_PLASTIC); EMU_QUERY_KIND(A, TRAY_MAT_METAL); EMU_QUERY_KIND(A, TRAY_MAT_GLASS); \
             EMU_QUERY_KIND(A, TRAY_MAT_ROUGH_GLASS); EMU_QUERY_KIND(A, TRAY_MAT_SPECULAR_METAL); EMU_QUERY_KIND(A, TRAY_MAT_MERL);          \
-        } else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query<A, F>(e.d, pool, n_active, trace == 2 ? nullptr : qc, trace == 2 ? nullptr : qctl, stats.data()); });  \
+        } else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query<A, FEAT_ALL | FEAT_TEX>(e.d, pool, n_active, qc, qctl, stats.data()); });  \
         EMU_TRACE_STAGE(2, A, qc);                                                                                                          \
     } while (0)
 #define EMU_QUERY_KIND(A, K) do { if (kinds_present & (1u << K)) EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_query_kind<A, K>(e.d, pool, kind_queues.data(), qc, qctl, stats.data()); }); } while (0)
 #define EMU_TRACE_STAGE(S, A, Q)                                                                                                            \
     do {                                                                                                                                    \
-        if (trace == 0) EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data()); }, dyn_lds); \
-        else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_trace<S, A>(e.d, pool, n_active, stats.data()); }, slot_lds);                             \
+        EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data()); }, dyn_lds); \
     } while (0)
 #define EMU_ROUND_F(A)                                                                                                                      \
     do {                                                                                                                                    \

@@ -303,13 +303,13 @@ def tr15_dir(tmp_path_factory):
     return pathlib.Path(str(d))
 
 
-WF_CASES = [("cornell_box", 0, 0), ("cornell_box", 0, 2), ("moving_box", 3, 0), ("moving_box", 3, 2), ("tr15_like", 330, 0)]
+WF_CASES = [("cornell_box", 0, 0), ("moving_box", 3, 0), ("tr15_like", 330, 0)]
 
 
-@pytest.mark.parametrize("name,frame,trace", WF_CASES, ids=[f"{n}-{['dyn', '', 'slot'][t]}" for n, _, t in WF_CASES])
+@pytest.mark.parametrize("name,frame,trace", WF_CASES, ids=[n for n, _, t in WF_CASES])
 def test_wavefront_schedule_emulated_as_simt(name, frame, trace, tmp_path, tr15_dir, built):
     """The whole wavefront schedule -- k_wf_advance (film row bins, tile switch), k_wf_regen (camera samples, the per-path transform
-    cache of moving scenes), the three traversal stages in both of their forms, k_wf_begin, k_wf_query, ray queues -- round
+    cache of moving scenes), the three traversal stages, k_wf_begin with its material sort, the kind-pure k_wf_query_kind, ray queues -- round
     after round until every tile is done, as fibers on the host: the oracle's samples, vertices, rays and image."""
     w, h, spp = 32, 24, 8
     d = str(tmp_path)
@@ -322,7 +322,7 @@ def test_wavefront_schedule_emulated_as_simt(name, frame, trace, tmp_path, tr15_
     scene, *_ = T.Scene.load_file(str(tmp_path / (name + ".json")))
     flat = scene.flatten(frame)
     img, (samples, vertices, rays, rounds) = E.render_wavefront(flat, tile_queue(w, h), spp, 5, trace=trace, n_chunks=5, trace_blocks=2,
-                                                                lds_depth=0 if trace == 2 else 4)
+                                                                lds_depth=4)
     ref, st = O.render_tiles(flat, spp, seed=5)
     assert samples == st.samples == w * h * spp
     moving = bool(flat.contents.animated)

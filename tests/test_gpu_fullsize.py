@@ -1,6 +1,6 @@
 """BASELINE.json's configs at their OWN size (film 1920x1080, their own sample counts, the full meshes) against the oracle.
 The whole frames are 2e9 .. 8e9 camera samples -- hours of oracle time -- so each config is compared on a strided subset of the
-8x8 tiles of its Morton queue (every 256th / 512th tile: the GPU renders shard 0 of N with one-tile chunks through
+8x8 tiles of its Morton queue (every 64th / 128th tile, 254 .. 507 tiles: the GPU renders shard 0 of N with one-tile chunks through
 tray_render_shard_device, the oracle renders `stride = N`), at the config's full sample count: same tiles, same pixels,
 same seeds, same sampler sequences as in the full frame (the RNG is keyed by pixel and sample index, not by schedule).
 Bar: pixel RMSE < 1e-4 on linear rgb / weight (north_star), vertex counts equal to 1e-4, traversal records bit for bit."""
@@ -56,7 +56,8 @@ def test_c2_cornell_box_1080p_1024spp(tmp_path):
     scenes.write_assets(str(tmp_path), cornell=(W, H, 1024), small=(W, H, 4096))
     scene, rt, spp, fi = T.Scene.load_file(str(tmp_path / "cornell_box.json"))
     assert T.round_spp(spp) == 1024
-    compare(scene, 0, 1024, 1, 256, label="C2 cornell_box")
+    compare(scene, 0, 1024, 1, 64, label="C2 cornell_box")
+    compare(scene, 0, 1024, 20260926, 256, label="C2 cornell_box, second seed")
 
 
 def test_c3_smallpt_1080p_4096spp(tmp_path):
@@ -64,7 +65,7 @@ def test_c3_smallpt_1080p_4096spp(tmp_path):
     scenes.write_assets(str(tmp_path), cornell=(W, H, 1024), small=(W, H, 4096))
     scene, rt, spp, fi = T.Scene.load_file(str(tmp_path / "smallpt.json"))
     assert T.round_spp(spp) == 4096
-    compare(scene, 0, 4096, 1, 512, label="C3 smallpt")
+    compare(scene, 0, 4096, 1, 128, label="C3 smallpt")
 
 
 def test_c4_dragon_stand_in_full_mesh_1080p_2048spp(tmp_path):
@@ -95,7 +96,7 @@ def test_c4_dragon_stand_in_full_mesh_1080p_2048spp(tmp_path):
         assert (a[f][hit] == b[f][hit]).all(), f
     for f in ("n", "ng", "u", "v", "dp_du", "dp_dv"):      # triangles: no libm on the path
         assert (a[f][mesh] == b[f][mesh]).all(), f
-    compare(scene, 0, 2048, 1, 512, vertex_tol=2e-4, label="C4 dragon stand-in (871 200 triangles)")
+    compare(scene, 0, 2048, 1, 128, label="C4 dragon stand-in (871 200 triangles)")
 
 
 def test_c5_tr15_stand_in_full_detail_1080p_512spp(tmp_path):
@@ -106,4 +107,4 @@ def test_c5_tr15_stand_in_full_detail_1080p_512spp(tmp_path):
     frame = 330
     flat = scene.flatten(frame)
     assert flat.contents.n_tris > 3000000 and flat.contents.n_instances == 59 and T.round_spp(spp) == 512
-    compare(scene, frame, 512, 2, 512, vertex_tol=1e-3, label="C5 tr15 stand-in frame 330")
+    compare(scene, frame, 512, 2, 128, label="C5 tr15 stand-in frame 330")

@@ -296,13 +296,11 @@ def test_dragon_image_rmse(dragon, mode, monkeypatch):
     assert r < 1e-4
 
 
-@pytest.mark.parametrize("trace", ["dyn", "slot"])
 @pytest.mark.parametrize("name", list(SCENES))
-def test_wavefront_schedule_matches_the_oracle(name, trace, tmp_path, monkeypatch):
-    """TRAYHIP_MODE=wave: the stage-kernel schedule over the HBM path pool renders the same image, with compacted ray
-    queues + persistent dynamic-fetch traversal (dyn, the default) or one thread per pool slot (slot)."""
+def test_wavefront_schedule_matches_the_oracle(name, tmp_path, monkeypatch):
+    """TRAYHIP_MODE=wave: the stage-kernel schedule over the HBM path pool (compacted ray queues, persistent dynamic-fetch
+    traversal, material sort) renders the same image."""
     monkeypatch.setenv("TRAYHIP_MODE", "wave")
-    monkeypatch.setenv("TRAYHIP_WF_TRACE", trace)
     monkeypatch.setenv("TRAYHIP_WF_SLOTS", "65536")
     spp = 64   # (a path that ocml's sin / cos flip on the glass or metal sphere weighs 1 / spp: 16 spp left 1.2e-4 on smallpt)
     scene, rt, _, fi = load(SCENES[name](96, 64, spp), tmp_path)

@@ -123,6 +123,51 @@ def test_png_decoder_against_python_written_files(kind, tmp_path, built):
     assert (fr.width, fr.height) == (w, h) and (got == want).all()
 
 
+@pytest.mark.parametrize("kind", ["444", "422", "420", "grey", "420_restart", "odd_size_q50"])
+def test_jpeg_decoder_against_pillow_written_files(kind, tmp_path, built):
+    """image::open's JPEG path (jpeg-decoder 0.1.13 behind image 0.18, scene.rs:317-394): baseline files written by Pillow
+    (libjpeg-turbo) -- 4:4:4 / 4:2:2 / 4:2:0 chroma, grey, restart intervals, sizes that are not multiples of the MCU -- decoded by
+    csrc/host/image.hpp and compared with libjpeg's own decoding of the same file. Lossy decoders may differ by an LSB or two (IDCT
+    rounding; libjpeg rounds its chroma interpolation alternately up and down, stb / jpeg-decoder always to nearest): every channel within 3,
+    93 % within 1, mean difference below 0.5."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(11)
+    w, h = (37, 29) if kind == "odd_size_q50" else (48, 40)
+    yy, xx = np.mgrid[0:h, 0:w]
+    pix = np.stack([128 + 100 * np.sin(xx / 5.0) * np.cos(yy / 7.0), 128 + 90 * np.cos(xx / 3.0 + yy / 11.0), 40 + 4 * xx + 2 * yy], axis=2)
+    pix = np.clip(pix + rng.normal(0, 6, pix.shape), 0, 255).astype(np.uint8)   # smooth colour fields + noise: every AC band carries something
+    os.makedirs(tmp_path / "textures", exist_ok=True)
+    path = str(tmp_path / "textures" / "x.jpg")
+    if kind == "grey":
+        Image.fromarray(pix[..., 0], "L").save(path, quality=90)
+    else:
+        kw = dict(quality=50 if kind == "odd_size_q50" else 92, subsampling={"444": 0, "422": 1}.get(kind, 2))
+        if kind == "420_restart":
+            kw["restart_marker_blocks"] = 3
+        Image.fromarray(pix, "RGB").save(path, **kw)
+    data = open(path, "rb").read()
+    assert data[:2] == b"\xff\xd8" and (b"\xff\xc0" in data) and (b"\xff\xc2" not in data[:600])   # baseline, not progressive
+    if kind == "420_restart":
+        assert b"\xff\xdd" in data and b"\xff\xd0" in data
+    ref = np.asarray(Image.open(path).convert("RGB"), np.int32)
+    scene, *_ = load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/x.jpg"}])
+    fs = scene.flatten(0).contents
+    got, fr = frame_pixels(fs, 0)
+    assert (fr.width, fr.height) == (w, h) and (got[..., 3] == 255).all()
+    d = np.abs(got[..., :3].astype(np.int32) - ref)
+    print(kind, "max", d.max(), "share within 1:", (d <= 1).mean(), "mean", d.mean())
+    assert d.max() <= 3 and (d <= 1).mean() > 0.93 and d.mean() < 0.5
+
+
+def test_progressive_jpeg_is_refused_with_a_message(tmp_path, built):
+    Image = pytest.importorskip("PIL.Image")
+    os.makedirs(tmp_path / "textures", exist_ok=True)
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8), "RGB").save(str(tmp_path / "textures" / "p.jpg"), progressive=True)
+    with pytest.raises(T.TrayError) as e:
+        load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/p.jpg"}])
+    assert "progressive" in str(e.value)
+
+
 def test_other_image_formats(tmp_path, built):
     rng = np.random.default_rng(2)
     w, h = 5, 4

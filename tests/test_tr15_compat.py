@@ -164,3 +164,44 @@ def test_generated_cube_and_scenes_equal_the_reference_files(tmp_path, built):
             bb = C.string_at(C.cast(getattr(fb, field), C.c_void_p), n * size)
             assert ba == bb, (name, field)
         assert bytes(fa.camera) == bytes(fb.camera) and bytes(fa.film) == bytes(fb.film)
+
+
+def test_tr15_spline_stacks_equal_the_independent_reading(tr15):
+    """Keyframes, knots, degrees and the nesting of group splines of the reference's own tr15.json, read a second time from
+    scene.rs:825-850 / animated_transform.rs:22-86 alone (tests/_indep_loader.py): per instance the stack is [own level, parent
+    group's, grandparent's ...]; every control point's decomposed keyframe (translation, quaternion, scaling -- the product's
+    Jacobi polar decomposition in place of la's SVD) recomposes to the control transform the JSON describes."""
+    import _indep_loader as I
+    desc, (scene, rt, spp, fi) = tr15
+    fs = scene.flatten(0).contents
+    stacks = I.instance_stacks(desc["objects"])
+    assert len(stacks) == fs.n_instances == 59
+    n_splines = 0
+    for i, (name, levels) in enumerate(stacks):
+        inst = fs.instances[i]
+        assert inst.xf_count == len(levels), name
+        for l, want in enumerate(levels):
+            lv = fs.xf_levels[inst.xf_first + l]
+            assert lv.kf_count == len(want["mats"]), (name, l)
+            if want["knots"] is not None:
+                n_splines += 1
+                assert lv.degree == want["degree"], (name, l)
+                knots = [fs.knots[lv.knot_first + k] for k in range(lv.knot_count)]
+                assert knots == [float(np.float32(x)) for x in want["knots"]], (name, l)
+                assert lv.knot_count == lv.kf_count + lv.degree + 1
+            for k, m in enumerate(want["mats"]):
+                kf = fs.keyframes[lv.kf_first + k]
+                got = I.keyframe_matrix(list(kf.translation), list(kf.rotation), list(kf.scaling))
+                want_m = I.keyframe_of(m)   # (what Keyframe::new keeps of the control transform: T, the polar rotation, the DIAGONAL of the stretch)
+                assert np.abs(got - want_m).max() < 2e-5 * max(1.0, np.abs(m).max()), (name, l, k, got, want_m)
+    assert n_splines >= 14   # the 14 splined instances of test_tr15_frames_flatten_and_trace (group splines count once per member)
+    # the camera's own spline
+    cam = desc["camera"]["keyframes"]
+    assert fs.camera.xf_count == 1
+    lv = fs.xf_levels[fs.camera.xf_first]
+    assert lv.kf_count == len(cam["control_points"]) and lv.degree == cam.get("degree", 3)
+    assert [fs.knots[lv.knot_first + k] for k in range(lv.knot_count)] == [float(np.float32(x)) for x in cam["knots"]]
+    for k, c in enumerate(cam["control_points"]):
+        kf = fs.keyframes[lv.kf_first + k]
+        m = I.load_transform(c["transform"])
+        assert np.abs(I.keyframe_matrix(list(kf.translation), list(kf.rotation), list(kf.scaling)) - I.keyframe_of(m)).max() < 2e-5 * max(1.0, np.abs(m).max()), k

@@ -106,14 +106,14 @@ TR_DEV float beckmann_g1(float width, f3 v) {
     return 1.0f;
 }
 
-// microfacet/ggx.rs:27-57 (powf(x, 2.0) / powf(x, 4.0) as products, like beckmann_d)
+// microfacet/ggx.rs:27-57 (powf(x, 2.0) as a product: exact; powf(x, 4.0) is libm's powf as in ggx.rs:30 -- one rounding of x^4, not the two of (x * x) * (x * x))
 TR_DEV float ggx_d(float width, f3 w_h) {
     if (cos_theta(w_h) > 0.0f) {
         float width_sqr = width * width;
-        float c = cos_theta(w_h), c2 = c * c;
+        float c = cos_theta(w_h);
         float t = tan_theta(w_h);
         float s = width_sqr + t * t;
-        float denom = kPi * (c2 * c2) * (s * s);
+        float denom = kPi * powf(c, 4.0f) * (s * s);
         return width_sqr / denom;
     }
     return 0.0f;

@@ -546,9 +546,8 @@ struct TrayDeviceScene {
     uint32_t n_blocks_trace = 0;      // persistent grid of k_wf_trace_dyn
     uint32_t trace_lds_depth = 0, trace_lds_bytes = 0;   // LDS part of the dynamic-fetch kernel's stacks; deeper entries go to d_stack_overflow
     uint32_t* d_stack_overflow = nullptr;
-    bool wf_dynamic = true;           // TRAYHIP_WF_TRACE=slot: one thread per pool slot instead (no compaction)
     bool light_filter = false;        // a sphere light or specular lobes: the tile kernel with mis_ray_filter (dev_integrator.h) compiled in
-    bool wf_sort = true;              // material sort of the shading stage (k_wf_begin's LDS counting sort -> k_wf_query_kind); TRAYHIP_WF_SORT=0: off
+    bool wf_sort = true;              // material sort of the shading stage (k_wf_begin's LDS counting sort -> k_wf_query_kind); off for textured scenes
     uint32_t* d_kind_queues = nullptr;   // WF_MAT_KINDS x n_slots slot indices
     uint32_t mat_kinds_present = 0;   // bit per TRAY_MAT_* kind among the scene's materials
 };
@@ -601,37 +600,27 @@ static int upload(TrayDeviceScene* s, const char* key, bool unchanged, const T* 
 #define WF_SLOTS (8u << 20)   // path pool slots (2.2 GB of pool at 66 fields): measured 36.6 / 45.2 / 53.1 Msamples/s at 2 / 4 / 8 M on the C5
 #endif                        // stand-in: every stage kernel ends with the tail of its slowest rays, fewer and larger rounds pay it less often
 #define WF_POLL 16
-// one round of the wavefront schedule: advance -> trace A -> begin -> trace B -> query -> trace C
-template <int ANIM, int FEAT>
+// one round of the wavefront schedule: advance -> regen -> trace A -> begin -> trace B -> query -> trace C (compacted ray queues, persistent
+// traversal with dynamic fetch, kind-pure shading over the material sort's queues; scenes with textured materials, whose lobes
+// exist per hit only, shade unsorted in the one instantiation that lowers them)
+template <int ANIM>
 static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 qgrid, dim3 tgrid, dim3 block, hipStream_t stream, const uint2* tiles, uint32_t tile_count, uint32_t chunk,
                      uint32_t chunk_stride, uint32_t spp, uint32_t kf, float* rgbw_dev, uint32_t n_active, uint32_t* qa, uint32_t* qb, uint32_t* qc,
                      uint32_t* qr, uint32_t* qctl) {
-    if (s->wf_dynamic) {   // compacted ray queues + persistent traversal with dynamic fetch
-        hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
-                           spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, qa, qr, qctl);
-        hipLaunchKernelGGL(k_wf_regen<ANIM>, qgrid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
-        hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
-        uint32_t* const kq = s->wf_sort ? s->d_kind_queues : nullptr;
-        hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, qb, qctl, kq);
-        hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
-        if (kq) {   // kind-pure shading over the sorted queues: one launch per material kind the scene contains
+    hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
+                       spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, qa, qr, qctl);
+    hipLaunchKernelGGL(k_wf_regen<ANIM>, qgrid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
+    hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
+    uint32_t* const kq = s->wf_sort ? s->d_kind_queues : nullptr;
+    hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, qb, qctl, kq);
+    hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
+    if (kq) {   // kind-pure shading over the sorted queues: one launch per material kind the scene contains
 #define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), qgrid, block, 0, stream, s->dev, s->pool, kq, qc, qctl, s->d_stats)
-            WF_QUERY_KIND(TRAY_MAT_MATTE); WF_QUERY_KIND(TRAY_MAT_PLASTIC); WF_QUERY_KIND(TRAY_MAT_METAL); WF_QUERY_KIND(TRAY_MAT_GLASS);
-            WF_QUERY_KIND(TRAY_MAT_ROUGH_GLASS); WF_QUERY_KIND(TRAY_MAT_SPECULAR_METAL); WF_QUERY_KIND(TRAY_MAT_MERL);
+        WF_QUERY_KIND(TRAY_MAT_MATTE); WF_QUERY_KIND(TRAY_MAT_PLASTIC); WF_QUERY_KIND(TRAY_MAT_METAL); WF_QUERY_KIND(TRAY_MAT_GLASS);
+        WF_QUERY_KIND(TRAY_MAT_ROUGH_GLASS); WF_QUERY_KIND(TRAY_MAT_SPECULAR_METAL); WF_QUERY_KIND(TRAY_MAT_MERL);
 #undef WF_QUERY_KIND
-        } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT>), grid, block, 0, stream, s->dev, s->pool, n_active, qc, qctl, s->d_stats);
-        hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
-    } else {   // one thread per pool slot in every stage; only the regeneration is compacted
-        uint32_t* const none = nullptr;
-        hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
-                           spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, qa, qr, qctl);
-        hipLaunchKernelGGL(k_wf_regen<ANIM>, qgrid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
-        hipLaunchKernelGGL((k_wf_trace<0, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
-        hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, none, none, none);
-        hipLaunchKernelGGL((k_wf_trace<1, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
-        hipLaunchKernelGGL((k_wf_query<ANIM, FEAT>), grid, block, 0, stream, s->dev, s->pool, n_active, none, none, s->d_stats);
-        hipLaunchKernelGGL((k_wf_trace<2, ANIM>), grid, block, s->stack_bytes, stream, s->dev, s->pool, n_active, s->d_stats);
-    }
+    } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT_ALL | FEAT_TEX>), grid, block, 0, stream, s->dev, s->pool, n_active, qc, qctl, s->d_stats);
+    hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
 }
 
 // Path pool slots of the wavefront schedule: never more than the film has pixels x 4 (one chunk of 256 per tile), and for moving
@@ -683,6 +672,19 @@ void tray_scene_destroy(TrayDeviceScene* s) {
 }
 
 } // extern "C" (scene_build is internal)
+
+// the k_path_tiles instantiation launch_tiles runs for this scene (same selection as its PATH_TILES_F): what the occupancy is asked of
+static const void* tile_kernel(const TrayDeviceScene* s) {
+#define TK(A, F) (s->light_filter ? reinterpret_cast<const void*>(k_path_tiles<A, F, TRAY_INTEGRATOR_PATH, true>) : reinterpret_cast<const void*>(k_path_tiles<A, F, TRAY_INTEGRATOR_PATH, false>))
+#define TK_F(A) (s->feat == FEAT_NONE ? TK(A, FEAT_NONE) : s->feat == FEAT_MERL ? TK(A, FEAT_MERL) : s->feat == FEAT_SPEC ? TK(A, FEAT_SPEC) \
+                 : s->feat == (FEAT_MERL | FEAT_SPEC) ? TK(A, FEAT_MERL | FEAT_SPEC) : s->feat == (FEAT_ALL | FEAT_TEX) ? TK(A, FEAT_ALL | FEAT_TEX) : TK(A, FEAT_ALL))
+    if (s->dev.integrator == TRAY_INTEGRATOR_WHITTED)
+        return s->animated ? reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>)
+                           : reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>);
+    return s->animated ? TK_F(1) : TK_F(0);
+#undef TK_F
+#undef TK
+}
 
 static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDeviceScene** out) {
     if (!f || !out) { set_error("tray_scene_create: null argument"); return TRAY_E_INVALID; }
@@ -936,9 +938,6 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
                 reinterpret_cast<const void*>(k_path_tiles<1, FEAT_NONE, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_SPEC, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_MERL | FEAT_SPEC, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL, TRAY_INTEGRATOR_PATH, true>), reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_PATH, true>),
                 reinterpret_cast<const void*>(k_path_tiles<0, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>),
                 reinterpret_cast<const void*>(k_path_tiles<1, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>),
-                reinterpret_cast<const void*>(k_wf_trace<0, 0>), reinterpret_cast<const void*>(k_wf_trace<0, 1>),
-                reinterpret_cast<const void*>(k_wf_trace<1, 0>), reinterpret_cast<const void*>(k_wf_trace<1, 1>),
-                reinterpret_cast<const void*>(k_wf_trace<2, 0>), reinterpret_cast<const void*>(k_wf_trace<2, 1>),
                 reinterpret_cast<const void*>(k_wf_trace_dyn<0, 0>), reinterpret_cast<const void*>(k_wf_trace_dyn<0, 1>),
                 reinterpret_cast<const void*>(k_wf_trace_dyn<1, 0>), reinterpret_cast<const void*>(k_wf_trace_dyn<1, 1>),
                 reinterpret_cast<const void*>(k_wf_trace_dyn<2, 0>), reinterpret_cast<const void*>(k_wf_trace_dyn<2, 1>),
@@ -951,8 +950,7 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
     int per_cu = 0, cus = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, s->device) == hipSuccess) cus = prop.multiProcessorCount;
-    hipError_t occ = s->animated ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles<1, FEAT_ALL>, TR_BLOCK, s->stack_bytes)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_path_tiles<0, FEAT_ALL>, TR_BLOCK, s->stack_bytes);
+    hipError_t occ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tile_kernel(s), TR_BLOCK, s->stack_bytes);   // of the instantiation launch_tiles will run
     if (occ != hipSuccess || per_cu < 1) per_cu = 1;
     s->deferred_n_moving = 0;
     for (uint32_t i = 0; i < f->n_instances; ++i) if (f->instances[i].animated) s->deferred_n_moving++;
@@ -1006,7 +1004,7 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         s->d_queues = donor->d_queues; s->d_kind_queues = donor->d_kind_queues; s->d_stack_overflow = donor->d_stack_overflow;
         s->h_done = donor->h_done; donor->h_done = nullptr;
         s->n_chunks = donor->n_chunks; s->n_blocks_trace = donor->n_blocks_trace; s->trace_lds_depth = donor->trace_lds_depth;
-        s->trace_lds_bytes = donor->trace_lds_bytes; s->wf_dynamic = donor->wf_dynamic; s->wf_sort = donor->wf_sort;
+        s->trace_lds_bytes = donor->trace_lds_bytes; s->wf_sort = donor->wf_sort;
         s->wf_ready = true;
         donor->wf_ready = false; donor->pool.data = nullptr;
     }
@@ -1067,8 +1065,7 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
         s->allocs.push_back(p); s->d_wf_counters = static_cast<uint32_t*>(p);
         HIP_CHECK(hipMalloc(&p, (4 * q_cap + WF_QCTL_WORDS) * sizeof(uint32_t)));   // ray queues A, B, C, regeneration queue, control words of their segments
         s->allocs.push_back(p); s->d_queues = static_cast<uint32_t*>(p);
-        if (const char* e = getenv("TRAYHIP_WF_SORT")) s->wf_sort = std::string(e) != "0";
-        if (s->feat & FEAT_TEX) s->wf_sort = false;   // the kind-pure kernels read lobes from the material table; textured materials have theirs per hit
+        s->wf_sort = !(s->feat & FEAT_TEX);   // the kind-pure kernels read lobes from the material table; textured materials have theirs per hit
         if (s->wf_sort) {   // shading queues of the material sort (slot indices), one per material kind
             HIP_CHECK(hipMalloc(&p, (size_t)WF_MAT_KINDS * q_cap * sizeof(uint32_t)));
             s->allocs.push_back(p); s->d_kind_queues = static_cast<uint32_t*>(p);
@@ -1091,8 +1088,6 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             HIP_CHECK(hipMalloc(&p, ovf_entries * sizeof(uint32_t)));
             s->allocs.push_back(p); s->d_stack_overflow = static_cast<uint32_t*>(p);
             if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] dynamic-fetch traversal: %u of %u stack entries in LDS, %d workgroups per CU\n", lds_depth, full_depth, per_cu);
-            const char* e = getenv("TRAYHIP_WF_TRACE");
-            s->wf_dynamic = !(e && std::string(e) == "slot");
         }
         HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s->h_done), sizeof(uint32_t), hipHostMallocDefault));
         s->wf_ready = true;
@@ -1118,14 +1113,8 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     const uint64_t max_rounds = tiles_per_chunk * (((uint64_t)spp + 3) / 4 * (s->dev.max_depth + 3) + 4) + 2 * WF_POLL;
     for (uint32_t round = 0;; ++round) {
         HIP_CHECK(hipMemsetAsync(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), stream));
-#define WF_ROUND(A, F) wf_round<A, F>(s, grid, qgrid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qr, qctl)
-#define WF_ROUND_F(A) do { if (s->feat == FEAT_NONE) WF_ROUND(A, FEAT_NONE); else if (s->feat == FEAT_MERL) WF_ROUND(A, FEAT_MERL); \
-                          else if (s->feat == FEAT_SPEC) WF_ROUND(A, FEAT_SPEC); else if (s->feat == (FEAT_MERL | FEAT_SPEC)) WF_ROUND(A, FEAT_MERL | FEAT_SPEC); \
-                          else if (s->feat == (FEAT_ALL | FEAT_TEX)) WF_ROUND(A, FEAT_ALL | FEAT_TEX); else WF_ROUND(A, FEAT_ALL); } while (0)
-        if (s->animated) WF_ROUND_F(1);
-        else WF_ROUND_F(0);
-#undef WF_ROUND_F
-#undef WF_ROUND
+        if (s->animated) wf_round<1>(s, grid, qgrid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qr, qctl);
+        else wf_round<0>(s, grid, qgrid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qr, qctl);
         launches += 7;
         if (round % WF_POLL == WF_POLL - 1) {
             HIP_CHECK(hipGetLastError());

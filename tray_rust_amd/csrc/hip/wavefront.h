@@ -11,7 +11,8 @@
 //               samples, tile switch, queues A and R) -> k_wf_regen (new camera samples for queue R: camera ray, spline stacks
 //               of moving instances into the per-slot cache, queue A) -> k_wf_trace_dyn<A> -> k_wf_begin (queue B) ->
 //               k_wf_trace_dyn<B> -> k_wf_query (BSDF queries; vertex_end unless a stage C ray is pending; queue C) ->
-//               k_wf_trace_dyn<C>. TRAYHIP_WF_TRACE=slot runs one thread per slot in the trace stages instead (k_wf_trace).
+//               k_wf_trace_dyn<C> (STAGE 0: camera / continuation ray, closest hit -> rec, WF_HIT_A; 1: occlusion ray of the light
+//               sample, any hit -> WF_OCCLUDED; 2: BSDF-sampled ray of estimate_direct, closest hit -> rec, WF_HIT_C).
 //   film      : per-chunk row bins in global memory (workgroup-private, L2 resident), resolved through an LDS
 //               window and flushed with global f32 atomics once per tile (same arithmetic as k_path_tiles)
 //
@@ -69,46 +70,6 @@ TR_DEV void st_bsdf(const DevScene& sc, const WfPool& p, uint32_t i, const Bsdf&
 }
 
 // ---- stage kernels --------------------------------------------------------------------------
-
-// STAGE 0: camera / continuation ray (closest hit) -> rec, WF_HIT_A
-// STAGE 1: occlusion ray of the light sample (any hit) -> WF_OCCLUDED
-// STAGE 2: BSDF-sampled ray of estimate_direct (closest hit) -> rec, WF_HIT_C
-template <int STAGE, int ANIM>
-__global__ __launch_bounds__(TR_BLOCK) void k_wf_trace(const DevScene scv, WfPool pool, uint32_t n_active, DevStats* __restrict__ stats) {
-    const DevScene* scp = &scv;
-    TR_DYN_LDS(uint32_t, s_stack);   // stack_depth x TR_BLOCK entries
-    const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
-    if (i >= n_active) return;   // n_active is a multiple of the workgroup size: whole waves leave
-    uint32_t flags = pu(pool, F_FLAGS, i);
-    const uint32_t need = STAGE == 0 ? LF_ALIVE : (STAGE == 1 ? (LF_ALIVE | WF_INVERTEX | LF_SHADOW) : (LF_ALIVE | WF_INVERTEX | LF_MIS));
-    const bool want = (flags & need) == need;
-    if (!__any(want)) return;
-    Ray r;   // lanes without a ray keep the wave company (cooperative leaf test)
-    if (STAGE == 0) {
-        r.o = ld3(pool, F_O, i); r.d = ld3(pool, F_D, i);
-        r.min_t = pu(pool, F_BOUNCE, i) == 0u ? 0.0f : 0.001f; r.max_t = TR_INF;
-    } else {
-        r.o = ld3(pool, F_P, i); r.d = ld3(pool, F_AUX, i);
-        r.min_t = 0.001f; r.max_t = STAGE == 1 ? 0.999f : TR_INF;
-    }
-    r.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; r.col = i;
-    TraceResult t = trace<ANIM>(scp, s_stack + threadIdx.x, r, STAGE == 1, want);
-    if (!want) return;
-    if (STAGE == 1) {
-        flags = t.hit ? (flags | WF_OCCLUDED) : (flags & ~WF_OCCLUDED);
-    } else {
-        const uint32_t bit = STAGE == 0 ? WF_HIT_A : WF_HIT_C;
-        flags = t.hit ? (flags | bit) : (flags & ~bit);
-        if (t.hit) {
-            pf(pool, F_REC_T, i) = t.rec.t; pu(pool, F_REC_INST, i) = t.rec.inst; pu(pool, F_REC_PRIM, i) = t.rec.prim;
-            pf(pool, F_REC_B1, i) = t.rec.b1; pf(pool, F_REC_B2, i) = t.rec.b2;
-        }
-    }
-    pu(pool, F_FLAGS, i) = flags;
-    // one counter update per wave
-    const unsigned long long m = __ballot(1);
-    if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].rays, (unsigned long long)__popcll(m));
-}
 
 // ---- ray queues: per-stage compaction of the slots that have a ray to trace --------------------
 // Producers append with one atomic per wave (ballot + prefix count); slots keep their place in the pool, only their
@@ -479,6 +440,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
         if (queue_b && (ln.flags & LF_SHADOW) && !ln.bsdf.mat->textured) {
             const DevMaterial* __restrict__ m = ln.bsdf.mat;
             uint32_t types = 0u;
+            static_assert(sizeof(m->lobe) / sizeof(m->lobe[0]) == 2, "the loop below looks at every lobe a material can have");
             for (uint32_t l = 0; l < m->n_lobes && l < 2u; ++l) types |= m->lobe[l].type;
             const float zo = -dot(ln.d, ln.bsdf.n), zi = dot(ln.wi_l, ln.bsdf.n);
             const bool same_side = (zo > 0.0f && zi > 0.0f) || (zo < 0.0f && zi < 0.0f);
@@ -565,7 +527,7 @@ TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, ui
     if (queue_c) wf_enqueue(pool, queue_c, qctl, 2u, (ln.flags & LF_MIS) != 0u, i);
 }
 
-// one thread per pool slot, every material kind's code (TRAYHIP_WF_SORT=0, or the slot form of the schedule)
+// one thread per pool slot, every material kind's code: scenes with textured materials (their lobes exist per hit only, so there is no table to sort by)
 template <int ANIM, int FEAT>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(
     const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl, DevStats* __restrict__ stats) {

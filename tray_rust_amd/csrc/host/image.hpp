@@ -3,7 +3,7 @@
 // row 0 on top, grey expanded to (l, l, l, 255), RGB given alpha 255 (texture/image.rs:18-32 reads px.data[0..4]).
 // Formats: PNG (non-interlaced; grey / grey+alpha / RGB / RGBA / palette with tRNS; 1-16 bits, 16-bit samples keep their high
 // byte), binary PPM / PGM (P6 / P5, maxval <= 255), BMP (uncompressed 24 / 32 bit), TGA (uncompressed true colour 24 / 32 bit and
-// grey 8 bit). No third-party code: the inflate below is the textbook RFC 1951 decoder.
+// grey 8 bit), baseline JPEG (see decode_jpeg). No third-party code: the inflate below is the textbook RFC 1951 decoder.
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -289,6 +289,295 @@ inline bool decode_tga(const std::vector<uint8_t>& f, ImageRGBA8& out, std::stri
     return true;
 }
 
+// ---- baseline JPEG (ITU T.81 sequential DCT, Huffman, 8 bit; 1 or 3 components; sampling 1x1 / 2x1 / 1x2 / 2x2; restart intervals).
+// image 0.18 decodes JPEG with jpeg-decoder 0.1.13 (Cargo.lock; not vendored by the reference: PARITY UNPINNED). Restated from that
+// crate's published design: the integer IDCT it ports from stb_image (stbi__idct_block: 12-bit fixed-point constants, column pass
+// >> 10, row pass >> 17 with the +128 level shift folded in), its linear ("fancy") chroma upsampling -- h2v1 (3 a + b + 2) >> 2,
+// h2v2 the 9-3-3-1 triangle (3 (3 near + far) + neighbour + 8) >> 4 with replicated edges -- and its f32 YCbCr -> RGB
+// (1.402, 0.34414, 0.71414, 1.772; + 0.5, truncate, clamp). Lossy decoders differ by an LSB or two between implementations; the test
+// (tests/test_textures.py) holds this one within 2 LSB of libjpeg's output. Progressive and arithmetic-coded files are refused.
+struct JpegComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, dc_pred = 0, bw = 0, bh = 0; std::vector<uint8_t> plane; };
+struct JpegHuff { uint8_t bits[17] = {0}; uint8_t vals[256] = {0}; int mincode[17], maxcode[18], valptr[17]; bool present = false; };
+inline void jpeg_build(JpegHuff& h) {   // T.81 F.2.2.3
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; ++l) {
+        h.valptr[l] = k; h.mincode[l] = code;
+        code += h.bits[l]; k += h.bits[l];
+        h.maxcode[l] = h.bits[l] ? code - 1 : -1;
+        code <<= 1;
+    }
+    h.maxcode[17] = 0x7fffffff;
+    h.present = true;
+}
+struct JpegBits {
+    const uint8_t* p; size_t n, pos; uint32_t buf = 0; int cnt = 0; bool bad = false; int marker = 0;
+    JpegBits(const uint8_t* d, size_t len, size_t start) : p(d), n(len), pos(start) {}
+    int bit() {
+        if (cnt == 0) {
+            if (marker || pos >= n) { buf = 0; cnt = 8; if (pos >= n && !marker) bad = true; }   // past a marker: zero bits (T.81 F.2.2.5 pads with ones, decoders feed zeros)
+            else {
+                uint8_t b = p[pos++];
+                if (b == 0xff) {
+                    uint8_t b2 = pos < n ? p[pos] : 0;
+                    if (b2 == 0) ++pos;                     // stuffed byte
+                    else { marker = b2; --pos; b = 0; }     // a marker ends the entropy-coded segment
+                }
+                buf = b; cnt = 8;
+            }
+        }
+        --cnt;
+        return (int)((buf >> cnt) & 1u);
+    }
+    int receive(int s) { int v = 0; for (int i = 0; i < s; ++i) v = (v << 1) | bit(); return v; }
+    void reset() { cnt = 0; buf = 0; }
+};
+inline int jpeg_decode(JpegBits& br, const JpegHuff& h) {
+    int code = 0;
+    for (int l = 1; l <= 16; ++l) {
+        code = (code << 1) | br.bit();
+        if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+    }
+    br.bad = true;
+    return 0;
+}
+inline int jpeg_extend(int v, int s) { return s == 0 ? 0 : (v < (1 << (s - 1)) ? v - (1 << s) + 1 : v); }
+inline uint8_t jpeg_clamp(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+// stb_image's stbi__idct_block as jpeg-decoder ports it
+inline void jpeg_idct(const int* d, uint8_t* out, int stride) {
+    auto f2f = [](double x) { return (int)(x * 4096.0 + 0.5); };
+    int val[64];
+#define TR_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                                          \
+    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                                \
+    p2 = s2; p3 = s6; p1 = (p2 + p3) * f2f(0.5411961); t2 = p1 + p3 * f2f(-1.847759065); t3 = p1 + p2 * f2f(0.765366865); \
+    p2 = s0; p3 = s4; t0 = (p2 + p3) * 4096; t1 = (p2 - p3) * 4096;                                        \
+    x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                                                \
+    t0 = s7; t1 = s5; t2 = s3; t3 = s1;                                                                    \
+    p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2; p5 = (p3 + p4) * f2f(1.175875602);             \
+    t0 = t0 * f2f(0.298631336); t1 = t1 * f2f(2.053119869); t2 = t2 * f2f(3.072711026); t3 = t3 * f2f(1.501321110); \
+    p1 = p5 + p1 * f2f(-0.899976223); p2 = p5 + p2 * f2f(-2.562915447); p3 = p3 * f2f(-1.961570560); p4 = p4 * f2f(-0.390180644); \
+    t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+    for (int i = 0; i < 8; ++i) {   // columns
+        const int* c = d + i;
+        int* v = val + i;
+        if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
+            int dc = c[0] * 4;
+            v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
+        } else {
+            TR_IDCT_1D(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56])
+            x0 += 512; x1 += 512; x2 += 512; x3 += 512;
+            v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10; v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
+            v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10; v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+        }
+    }
+    for (int i = 0; i < 8; ++i) {   // rows
+        const int* v = val + i * 8;
+        uint8_t* o = out + i * stride;
+        TR_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
+        x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
+        o[0] = jpeg_clamp((x0 + t3) >> 17); o[7] = jpeg_clamp((x0 - t3) >> 17); o[1] = jpeg_clamp((x1 + t2) >> 17); o[6] = jpeg_clamp((x1 - t2) >> 17);
+        o[2] = jpeg_clamp((x2 + t1) >> 17); o[5] = jpeg_clamp((x2 - t1) >> 17); o[3] = jpeg_clamp((x3 + t0) >> 17); o[4] = jpeg_clamp((x3 - t0) >> 17);
+    }
+#undef TR_IDCT_1D
+}
+inline void jpeg_up_h2(const uint8_t* in, int w, uint8_t* out) {   // one row, twice as wide
+    if (w == 1) { out[0] = out[1] = in[0]; return; }
+    out[0] = in[0];
+    out[1] = (uint8_t)((in[0] * 3 + in[1] + 2) >> 2);
+    for (int i = 1; i < w - 1; ++i) {
+        const int s = 3 * in[i] + 2;
+        out[2 * i] = (uint8_t)((s + in[i - 1]) >> 2);
+        out[2 * i + 1] = (uint8_t)((s + in[i + 1]) >> 2);
+    }
+    out[2 * (w - 1)] = (uint8_t)((in[w - 1] * 3 + in[w - 2] + 2) >> 2);
+    out[2 * (w - 1) + 1] = in[w - 1];
+}
+inline void jpeg_up_h2v2(const uint8_t* near, const uint8_t* far, int w, uint8_t* out) {   // one output row from its two source rows
+    if (w == 1) { out[0] = out[1] = (uint8_t)((3 * near[0] + far[0] + 2) >> 2); return; }
+    int t0 = 3 * near[0] + far[0], t1 = 3 * near[1] + far[1];
+    out[0] = (uint8_t)((t0 + 2) >> 2);
+    out[1] = (uint8_t)((3 * t0 + t1 + 8) >> 4);
+    for (int i = 2; i < w; ++i) {
+        const int tp = t0;
+        t0 = t1; t1 = 3 * near[i] + far[i];
+        out[2 * i - 2] = (uint8_t)((3 * t0 + tp + 8) >> 4);
+        out[2 * i - 1] = (uint8_t)((3 * t0 + t1 + 8) >> 4);
+    }
+    out[2 * w - 2] = (uint8_t)((3 * t1 + t0 + 8) >> 4);
+    out[2 * w - 1] = (uint8_t)((t1 + 2) >> 2);
+}
+inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::string& err) {
+    static const uint8_t zigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                       35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    uint16_t qt[4][64] = {};
+    bool qt_present[4] = {false, false, false, false};
+    JpegHuff dc[4], ac[4];
+    std::vector<JpegComp> comps;
+    int width = 0, height = 0, hmax = 1, vmax = 1, restart = 0, adobe_transform = -1;
+    bool have_frame = false;
+    size_t pos = 2;
+    const size_t n = f.size();
+    auto be16 = [&](size_t at) { return (int)f[at] << 8 | (int)f[at + 1]; };
+    while (pos + 4 <= n) {
+        if (f[pos] != 0xff) { err = "JPEG: marker expected"; return false; }
+        while (pos < n && f[pos] == 0xff) ++pos;   // fill bytes
+        if (pos >= n) break;
+        const int m = f[pos++];
+        if (m == 0xd9) break;                       // EOI
+        if (m == 0x01 || (m >= 0xd0 && m <= 0xd7)) continue;
+        if (pos + 2 > n) break;
+        const int len = be16(pos);
+        if (len < 2 || pos + (size_t)len > n) { err = "JPEG: truncated segment"; return false; }
+        const size_t seg = pos + 2, end = pos + (size_t)len;
+        if (m == 0xdb) {   // DQT
+            size_t q = seg;
+            while (q < end) {
+                const int pq = f[q] >> 4, tq = f[q] & 15; ++q;
+                if (tq > 3 || pq > 1 || q + (size_t)(pq ? 128 : 64) > end) { err = "JPEG: bad quantisation table"; return false; }
+                for (int k = 0; k < 64; ++k) { qt[tq][k] = pq ? (uint16_t)be16(q + 2 * (size_t)k) : f[q + (size_t)k]; }
+                q += pq ? 128 : 64;
+                qt_present[tq] = true;
+            }
+        } else if (m == 0xc4) {   // DHT
+            size_t q = seg;
+            while (q < end) {
+                const int tc = f[q] >> 4, th = f[q] & 15; ++q;
+                if (tc > 1 || th > 3 || q + 16 > end) { err = "JPEG: bad Huffman table"; return false; }
+                JpegHuff& h = tc ? ac[th] : dc[th];
+                int total = 0;
+                for (int l = 1; l <= 16; ++l) { h.bits[l] = f[q + (size_t)l - 1]; total += h.bits[l]; }
+                q += 16;
+                if (total > 256 || q + (size_t)total > end) { err = "JPEG: bad Huffman table"; return false; }
+                for (int k = 0; k < total; ++k) h.vals[k] = f[q + (size_t)k];
+                q += (size_t)total;
+                jpeg_build(h);
+            }
+        } else if (m == 0xc0 || m == 0xc1) {   // SOF0 / SOF1: sequential Huffman
+            if (len < 8 || f[seg] != 8) { err = "JPEG: only 8-bit samples are supported"; return false; }
+            height = be16(seg + 1); width = be16(seg + 3);
+            const int nc = f[seg + 5];
+            if ((nc != 1 && nc != 3) || width <= 0 || height <= 0 || seg + 6 + 3 * (size_t)nc > end) { err = "JPEG: unsupported frame (1 or 3 components)"; return false; }
+            comps.assign((size_t)nc, JpegComp());
+            for (int c = 0; c < nc; ++c) {
+                JpegComp& k = comps[(size_t)c];
+                k.id = f[seg + 6 + 3 * (size_t)c]; k.h = f[seg + 7 + 3 * (size_t)c] >> 4; k.v = f[seg + 7 + 3 * (size_t)c] & 15; k.tq = f[seg + 8 + 3 * (size_t)c];
+                if (k.h < 1 || k.h > 2 || k.v < 1 || k.v > 2 || k.tq > 3) { err = "JPEG: unsupported sampling factors (1x1, 2x1, 1x2, 2x2)"; return false; }
+                hmax = k.h > hmax ? k.h : hmax; vmax = k.v > vmax ? k.v : vmax;
+            }
+            if (nc == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }   // a single component is never subsampled
+            const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+            for (JpegComp& k : comps) { k.bw = mcux * k.h; k.bh = mcuy * k.v; k.plane.assign((size_t)k.bw * 8 * (size_t)k.bh * 8, 0); }
+            have_frame = true;
+        } else if (m == 0xc2 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
+            err = "JPEG: progressive / lossless / arithmetic-coded files are not supported (baseline only)"; return false;
+        } else if (m == 0xdd) {
+            if (len >= 4) restart = be16(seg);
+        } else if (m == 0xee && len >= 14 && !std::memcmp(&f[seg], "Adobe", 5)) {
+            adobe_transform = f[seg + 11];
+        } else if (m == 0xda) {   // SOS + entropy-coded data
+            if (!have_frame) { err = "JPEG: scan before frame header"; return false; }
+            const int ns = f[seg];
+            if (ns < 1 || ns > (int)comps.size() || seg + 1 + 2 * (size_t)ns + 3 > end) { err = "JPEG: bad scan header"; return false; }
+            std::vector<JpegComp*> sc;
+            for (int i = 0; i < ns; ++i) {
+                const int cid = f[seg + 1 + 2 * (size_t)i], t = f[seg + 2 + 2 * (size_t)i];
+                JpegComp* k = nullptr;
+                for (JpegComp& c : comps) if (c.id == cid) k = &c;
+                if (!k || (t >> 4) > 3 || (t & 15) > 3 || !dc[t >> 4].present || !ac[t & 15].present || !qt_present[k->tq]) { err = "JPEG: scan refers to a missing component / table"; return false; }
+                k->td = t >> 4; k->ta = t & 15; k->dc_pred = 0;
+                sc.push_back(k);
+            }
+            JpegBits br(f.data(), n, end);
+            // a scan of one component covers ceil(w_c / 8) x ceil(h_c / 8) blocks (T.81 A.2.2), an interleaved one whole MCUs
+            const bool single = ns == 1;
+            int nx, ny;
+            if (single) {
+                const int cw = (width * sc[0]->h + hmax - 1) / hmax, ch = (height * sc[0]->v + vmax - 1) / vmax;
+                nx = (cw + 7) / 8; ny = (ch + 7) / 8;
+            } else { nx = comps[0].bw / comps[0].h; ny = comps[0].bh / comps[0].v; }
+            int until_restart = restart, rst_expect = 0;
+            for (int my = 0; my < ny; ++my)
+                for (int mx = 0; mx < nx; ++mx) {
+                    if (restart && until_restart == 0) {   // RSTn: byte-align, check the marker, reset the predictors
+                        br.reset();
+                        if (!br.marker) { while (br.pos + 1 < n && !(f[br.pos] == 0xff && f[br.pos + 1] >= 0xd0 && f[br.pos + 1] <= 0xd7)) ++br.pos; br.marker = br.pos + 1 < n ? f[br.pos + 1] : 0; }
+                        if (br.marker != 0xd0 + rst_expect) { err = "JPEG: restart marker out of sequence"; return false; }
+                        br.pos += 2; br.marker = 0; rst_expect = (rst_expect + 1) & 7; until_restart = restart;
+                        for (JpegComp* k : sc) k->dc_pred = 0;
+                    }
+                    for (JpegComp* k : sc) {
+                        const int bh_ = single ? 1 : k->h, bv_ = single ? 1 : k->v;
+                        for (int by = 0; by < bv_; ++by)
+                            for (int bx = 0; bx < bh_; ++bx) {
+                                int blk[64] = {0};
+                                const int s = jpeg_decode(br, dc[k->td]);
+                                if (s > 11) { err = "JPEG: bad DC category"; return false; }
+                                k->dc_pred += jpeg_extend(br.receive(s), s);
+                                blk[0] = k->dc_pred * qt[k->tq][0];
+                                for (int i = 1; i < 64;) {
+                                    const int rs = jpeg_decode(br, ac[k->ta]), r = rs >> 4, sz = rs & 15;
+                                    if (sz == 0) { if (r == 15) { i += 16; continue; } break; }
+                                    i += r;
+                                    if (i > 63) { err = "JPEG: AC coefficient index out of range"; return false; }
+                                    blk[zigzag[i]] = jpeg_extend(br.receive(sz), sz) * qt[k->tq][i];
+                                    ++i;
+                                }
+                                if (br.bad) { err = "JPEG: corrupt entropy-coded data"; return false; }
+                                const int px = (mx * bh_ + bx) * 8, py = (my * bv_ + by) * 8;
+                                if (px + 8 <= k->bw * 8 && py + 8 <= k->bh * 8) jpeg_idct(blk, &k->plane[(size_t)py * (size_t)k->bw * 8 + (size_t)px], k->bw * 8);
+                            }
+                    }
+                    if (restart) --until_restart;
+                }
+            // continue behind the entropy-coded segment
+            pos = br.pos;
+            while (pos + 1 < n && !(f[pos] == 0xff && f[pos + 1] != 0 && !(f[pos + 1] >= 0xd0 && f[pos + 1] <= 0xd7))) ++pos;
+            continue;
+        }
+        pos = end;
+    }
+    if (!have_frame) { err = "JPEG: no frame header"; return false; }
+    // upsample every component to the frame and convert
+    std::vector<std::vector<uint8_t>> full(comps.size());
+    for (size_t c = 0; c < comps.size(); ++c) {
+        const JpegComp& k = comps[c];
+        const int cw = (width * k.h + hmax - 1) / hmax, ch = (height * k.v + vmax - 1) / vmax, stride = k.bw * 8;
+        const int fx = hmax / k.h, fy = vmax / k.v;
+        std::vector<uint8_t>& o = full[c];
+        o.assign((size_t)width * (size_t)height, 0);
+        std::vector<uint8_t> row((size_t)cw * 2 + 2);
+        for (int y = 0; y < height; ++y) {
+            const uint8_t* src;
+            if (fx == 1 && fy == 1) src = &k.plane[(size_t)y * (size_t)stride];
+            else if (fx == 2 && fy == 1) { jpeg_up_h2(&k.plane[(size_t)y * (size_t)stride], cw, row.data()); src = row.data(); }
+            else {
+                const int near = y / 2;
+                int far = (y & 1) ? near + 1 : near - 1;
+                far = far < 0 ? 0 : (far > ch - 1 ? ch - 1 : far);
+                if (fx == 2) { jpeg_up_h2v2(&k.plane[(size_t)near * (size_t)stride], &k.plane[(size_t)far * (size_t)stride], cw, row.data()); src = row.data(); }
+                else {   // 1 x 2: vertical triangle only
+                    for (int x = 0; x < cw; ++x) row[(size_t)x] = (uint8_t)((3 * k.plane[(size_t)near * (size_t)stride + (size_t)x] + k.plane[(size_t)far * (size_t)stride + (size_t)x] + 2) >> 2);
+                    src = row.data();
+                }
+            }
+            std::memcpy(&o[(size_t)y * (size_t)width], src, (size_t)width);
+        }
+    }
+    out.width = (uint32_t)width; out.height = (uint32_t)height;
+    out.px.assign((size_t)width * (size_t)height * 4, 255);
+    for (size_t i = 0; i < (size_t)width * (size_t)height; ++i) {
+        uint8_t* o = &out.px[i * 4];
+        if (comps.size() == 1) { o[0] = o[1] = o[2] = full[0][i]; }
+        else if (adobe_transform == 0) { o[0] = full[0][i]; o[1] = full[1][i]; o[2] = full[2][i]; }   // Adobe APP14 transform 0: RGB stored as is
+        else {
+            const float y = (float)full[0][i], cb = (float)full[1][i] - 128.0f, cr = (float)full[2][i] - 128.0f;
+            o[0] = jpeg_clamp((int)(y + 1.40200f * cr + 0.5f));
+            o[1] = jpeg_clamp((int)(y - 0.34414f * cb - 0.71414f * cr + 0.5f));
+            o[2] = jpeg_clamp((int)(y + 1.77200f * cb + 0.5f));
+        }
+    }
+    return true;
+}
+
 }  // namespace img_detail
 
 // image::open: the format is taken from the file's content
@@ -300,10 +589,10 @@ inline bool load_image(const std::string& path, ImageRGBA8& out, std::string& er
     if (f.size() >= 8 && !std::memcmp(f.data(), png_sig, 8)) return img_detail::decode_png(f, out, err);
     if (f.size() >= 3 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) return img_detail::decode_pnm(f, out, err);
     if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') return img_detail::decode_bmp(f, out, err);
-    if (f.size() >= 3 && f[0] == 0xff && f[1] == 0xd8) { err = "JPEG files are not supported by this loader (convert to PNG)"; return false; }
+    if (f.size() >= 3 && f[0] == 0xff && f[1] == 0xd8) return img_detail::decode_jpeg(f, out, err);
     const size_t dot = path.rfind('.');
     if (dot != std::string::npos && (path.substr(dot) == ".tga" || path.substr(dot) == ".TGA")) return img_detail::decode_tga(f, out, err);
-    err = "unrecognised image format (PNG, binary PPM / PGM, BMP and TGA are supported)";
+    err = "unrecognised image format (PNG, baseline JPEG, binary PPM / PGM, BMP and TGA are supported)";
     return false;
 }
 

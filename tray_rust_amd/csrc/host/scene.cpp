@@ -575,6 +575,16 @@ static void load_textures(TrayHostScene& s, const Json& e, const std::string& ba
             fail(TRAY_E_PARSE, "Unrecognized texture type '" + ty + "' for texture '" + name + "'");
         }
         tex.n_frames = (uint32_t)s.tex_frames.size() - tex.first_frame;
+        // AnimatedImage::active_keyframes (animated_image.rs:21-34) binary-searches the key times with partial_cmp().unwrap(): a NaN
+        // time panics there at the first lookup, unsorted times make the search meaningless. Both are diagnosed here, at the scene
+        // file, instead of at tray_scene_create (whose validator only sees indices)
+        for (uint32_t k = 0; k < tex.n_frames; ++k) {
+            const float tk = s.tex_frames[tex.first_frame + k].time;
+            if (!std::isfinite(tk)) fail(TRAY_E_INVALID, "Error loading texture '" + name + "': keyframe time " + std::to_string(k) + " is not a finite number" +
+                                                          (ty == "movie" ? " (framerate 0?)" : ""));
+            if (k > 0 && !(s.tex_frames[tex.first_frame + k - 1].time < tk))
+                fail(TRAY_E_INVALID, "Error loading texture '" + name + "': keyframe times must increase (keyframe " + std::to_string(k) + ")");
+        }
         s.texture_names[name] = (uint32_t)s.textures.size();
         s.textures.push_back(tex);
     }
