@@ -179,7 +179,10 @@ struct Hit {   // DifferentialGeometry in world space (differential_geometry.rs:
 
 struct Counters { uint32_t rays, vertices; };
 
-// BBox::fast_intersect (bbox.rs:75-104); comparison directions kept so NaNs fall the same way
+// BBox::fast_intersect (bbox.rs:75-104); comparison directions kept so NaNs fall the same way. Straight-line form: the reference's
+// early `return false`s only skip work, so the slab updates run unconditionally here and the early verdicts are and-ed in at the end --
+// the same boolean for every input, without the four nested branches per box (each a saveexec / cbranch pair on the scalar unit
+// that the 16 waves of a CU share: the node step of k_wf_trace_dyn was 80 scalar instructions for 24 of box arithmetic).
 TR_DEV bool bbox_hit(const float4 lo, const float4 hi, const f3 o, const f3 inv_dir, const bool nx, const bool ny, const bool nz,
                      float min_t, float max_t) {
     // lo = (bmin.x, bmin.y, bmin.z, bmax.x), hi = (bmax.y, bmax.z, offset, meta)
@@ -188,19 +191,20 @@ TR_DEV bool bbox_hit(const float4 lo, const float4 hi, const f3 o, const f3 inv_
     float tmax = ((nx ? bminx : bmaxx) - o.x) * inv_dir.x;
     float tymin = ((ny ? bmaxy : bminy) - o.y) * inv_dir.y;
     float tymax = ((ny ? bminy : bmaxy) - o.y) * inv_dir.y;
-    if (tmin > tymax || tymin > tmax) return false;
-    if (tymin > tmin) tmin = tymin;
-    if (tymax < tmax) tmax = tymax;
+    const bool miss_y = tmin > tymax || tymin > tmax;
+    tmin = tymin > tmin ? tymin : tmin;
+    tmax = tymax < tmax ? tymax : tmax;
     float tzmin = ((nz ? bmaxz : bminz) - o.z) * inv_dir.z;
     float tzmax = ((nz ? bminz : bmaxz) - o.z) * inv_dir.z;
-    if (tmin > tzmax || tzmin > tmax) return false;
-    if (tzmin > tmin) tmin = tzmin;
-    if (tzmax < tmax) tmax = tzmax;
-    return tmin < max_t && tmax > min_t;
+    const bool miss_z = tmin > tzmax || tzmin > tmax;
+    tmin = tzmin > tmin ? tzmin : tmin;
+    tmax = tzmax < tmax ? tzmax : tmax;
+    return !miss_y & !miss_z & (tmin < max_t) & (tmax > min_t);
 }
 
 // BBox::fast_intersect that also reports the entry distance it compared with max_t (the flat loop's and the cooperative
-// leaf test's gates keep it: a candidate whose box is entered at or behind its own hit distance is a hazard, see trace_flat)
+// leaf test's gates keep it: a candidate whose box is entered at or behind its own hit distance is a hazard, see trace_flat).
+// tmin_out is only read when the box was hit.
 TR_DEV bool bbox_hit_t(const float4 lo, const float4 hi, const f3 o, const f3 inv_dir, const bool nx, const bool ny, const bool nz,
                        float min_t, float max_t, float& tmin_out) {
     float bminx = lo.x, bminy = lo.y, bminz = lo.z, bmaxx = lo.w, bmaxy = hi.x, bmaxz = hi.y;
@@ -208,17 +212,16 @@ TR_DEV bool bbox_hit_t(const float4 lo, const float4 hi, const f3 o, const f3 in
     float tmax = ((nx ? bminx : bmaxx) - o.x) * inv_dir.x;
     float tymin = ((ny ? bmaxy : bminy) - o.y) * inv_dir.y;
     float tymax = ((ny ? bminy : bmaxy) - o.y) * inv_dir.y;
-    tmin_out = tmin;
-    if (tmin > tymax || tymin > tmax) return false;
-    if (tymin > tmin) tmin = tymin;
-    if (tymax < tmax) tmax = tymax;
+    const bool miss_y = tmin > tymax || tymin > tmax;
+    tmin = tymin > tmin ? tymin : tmin;
+    tmax = tymax < tmax ? tymax : tmax;
     float tzmin = ((nz ? bmaxz : bminz) - o.z) * inv_dir.z;
     float tzmax = ((nz ? bminz : bmaxz) - o.z) * inv_dir.z;
-    if (tmin > tzmax || tzmin > tmax) return false;
-    if (tzmin > tmin) tmin = tzmin;
-    if (tzmax < tmax) tmax = tzmax;
+    const bool miss_z = tmin > tzmax || tzmin > tmax;
+    tmin = tzmin > tmin ? tzmin : tmin;
+    tmax = tzmax < tmax ? tzmax : tmax;
     tmin_out = tmin;
-    return tmin < max_t && tmax > min_t;
+    return !miss_y & !miss_z & (tmin < max_t) & (tmax > min_t);
 }
 
 // Test part of intersect_triangle (mesh.rs:136-171). Inclusive range test, no back-face culling.
