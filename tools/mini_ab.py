@@ -19,6 +19,7 @@ if mode == "prepare":
     scenes.write_assets(d, cornell=(W, H, 64), small=(W, H, 64))
     grid = int(os.environ.get("MINI_DRAGON_GRID", "220"))                          # 220: 96 800 triangles, loads in a second; 660: the 871 200 of C4
     scenes.write_dragon_assets(d, film=(W, H, 32), grid=grid, extent=0.2)   # (the bench workload: grid 660, extent 0.2)
+    scenes.write_moving_box(d, width=W, height=H, samples=32)   # the moving test scene at film size (tile kernel, ANIM instantiation)
     scenes.write_tr15_like_assets(os.path.join(d, "tr15"), film=(W, H, 16), detail=float(os.environ.get("MINI_TR15_DETAIL", "0.15")))   # own directory: it brings its own models/
     sys.exit(0)
 label = sys.argv[3]
@@ -26,7 +27,7 @@ hip = T.Hip(device=0, seed=1)
 for item in sys.argv[4:]:
     name, spp = item.split(":")
     spp = int(spp)
-    frame = 330 if name == "tr15_like" else 0
+    frame = 330 if name == "tr15_like" else (3 if name == "moving_box" else 0)
     t0 = time.time()
     scene, rt, _, fi = T.Scene.load_file(os.path.join(d, "tr15" if name == "tr15_like" else "", name + ".json"))
     if frame:

@@ -278,8 +278,10 @@ TR_DEV float lobe_pdf(const Lobe& l, f3 w_o, f3 w_i) {
 }
 // BxDF::sample. For specular lobes returns f; for the others only the direction and the lobe's own pdf
 // are produced: BSDF::sample (bsdf.rs:103-109) replaces f by BSDF::eval for every non-specular lobe.
+// want_pdf = false: the caller replaces the lobe's own pdf by BSDF::pdf anyway (bsdf.rs:103-105: a non-specular lobe of a BSDF with more
+// than one matching lobe), so it is not computed (pdf = 0); the direction, and whether one exists at all, do not depend on it.
 template <int FEAT, uint32_t KM = KM_ALL>
-TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, f3& w_i, float& pdf) {
+TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, f3& w_i, float& pdf, bool want_pdf = true) {
     const f3 zero = mk(0.0f, 0.0f, 0.0f);
     switch (l.kind) {
         case LB_SPEC_REFL_DIEL:
@@ -317,7 +319,7 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
             if (!same_hemisphere(w_o, w_h)) w_h = -w_h;
             w_i = reflect(w_o, w_h);
             if (!same_hemisphere(w_o, w_i)) { w_i = zero; pdf = 0.0f; return zero; }
-            pdf = lobe_pdf<FEAT, KM>(l, w_o, w_i);
+            pdf = want_pdf ? lobe_pdf<FEAT, KM>(l, w_o, w_i) : 0.0f;
             return zero;
         }
         case LB_MF_TRANS: {
@@ -330,7 +332,7 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
             if (refract(w_o, w_h, e0 / e1, wi)) {
                 if (same_hemisphere(w_o, wi)) { w_i = zero; pdf = 0.0f; return zero; }
                 w_i = wi;
-                pdf = lobe_pdf<FEAT, KM>(l, w_o, w_i);
+                pdf = want_pdf ? lobe_pdf<FEAT, KM>(l, w_o, w_i) : 0.0f;
                 return zero;
             }
             w_i = zero; pdf = 0.0f;
@@ -340,7 +342,7 @@ TR_DEV f3 lobe_sample(const Bsdf& b, const Lobe& l, f3 w_o, float u0, float u1, 
             if (!LOBE_ON(LB_LAMBERTIAN) && !LOBE_ON(LB_OREN_NAYAR) && !LOBE_ON(LB_MERL)) { w_i = zero; pdf = 0.0f; return zero; }
             w_i = cos_sample_hemisphere(u0, u1);
             if (w_o.z < 0.0f) w_i.z *= -1.0f;
-            pdf = lobe_pdf<FEAT, KM>(l, w_o, w_i);
+            pdf = want_pdf ? lobe_pdf<FEAT, KM>(l, w_o, w_i) : 0.0f;
             return zero;
         }
     }
@@ -388,6 +390,57 @@ template <int FEAT>
 TR_DEV float bsdf_pdf(const Bsdf& b, f3 wo_world, f3 wi_world, uint32_t flags) {
     return bsdf_pdf_sh<FEAT>(b, normalized(to_shading(b, wo_world)), normalized(to_shading(b, wi_world)), flags);
 }
+// BSDF::eval and BSDF::pdf of the same (w_o, w_i) in one pass over the lobes (query_stage needs both for the light half and for every
+// two-lobe material). A Torrance-Sparrow lobe's eval (torrance_sparrow.rs:40-57) and pdf (:72-81) both start from the half vector
+// normalized(w_i + w_o) -- w_o + w_i in pdf(): the same three sums -- and the distribution's D(w_h): computed once here, every other
+// operation as in lobe_eval / lobe_pdf, so f and pdf carry the bits of bsdf_eval_sh / bsdf_pdf_sh.
+template <int FEAT, uint32_t KM = KM_ALL>
+TR_DEV void bsdf_eval_pdf_sh(const Bsdf& b, f3 w_o, f3 w_i, uint32_t flags, bool need_eval, bool need_pdf, f3& f_out, float& pdf_out) {
+    uint32_t fl_eval = flags;
+    if (w_o.z * w_i.z > 0.0f) fl_eval &= ~(uint32_t)BX_TRANSMISSION; else fl_eval &= ~(uint32_t)BX_REFLECTION;
+    f3 sum = mk(0.0f, 0.0f, 0.0f);
+    float pdf_val = 0.0f;
+    int n_comps = 0;
+    const int n = (int)b.mat->n_lobes;
+#pragma nounroll
+    for (int i = 0; i < n; ++i) {
+        const Lobe l = load_lobe(b.mat, i);
+        const bool em = need_eval && lobe_matches(l.type, fl_eval), pm = need_pdf && lobe_matches(l.type, flags);
+        if (!(em || pm)) continue;
+        const bool ts = (LOBE_ON(LB_TS_DIEL) || LOBE_ON(LB_TS_COND)) && (l.kind == LB_TS_DIEL || l.kind == LB_TS_COND);
+        if (ts && em && pm) {
+            // lobe_eval's and lobe_pdf's own early outs first, then the shared half vector and D
+            const float cos_to = fabsf(cos_theta(w_o)), cos_ti = fabsf(cos_theta(w_i));
+            f3 w_h = w_i + w_o;
+            const bool e_zero = cos_to == 0.0f || cos_ti == 0.0f || (w_h.x == 0.0f && w_h.y == 0.0f && w_h.z == 0.0f);
+            const bool p_zero = !same_hemisphere(w_o, w_i);
+            f3 e = mk(0.0f, 0.0f, 0.0f);
+            float p = 0.0f;
+            if (!(e_zero && p_zero)) {
+                w_h = normalized(w_h);
+                const float d = mf_d<FEAT>(l, w_h);
+                if (!e_zero) {
+                    f3 fr3;
+                    if (!(FEAT & FEAT_SPEC) || !LOBE_ON(LB_TS_COND) || (LOBE_ON(LB_TS_DIEL) && l.kind == LB_TS_DIEL)) { float fr = fresnel_dielectric(l.eta_t, dot(w_i, w_h)); fr3 = mk(fr, fr, fr); }
+                    else fr3 = fresnel_conductor(mk(b.mat->eta[0], b.mat->eta[1], b.mat->eta[2]), mk(b.mat->k[0], b.mat->k[1], b.mat->k[2]), dot(w_i, w_h));
+                    const float g = mf_g1<FEAT>(l, w_i) * mf_g1<FEAT>(l, w_o);
+                    e = l.color * fr3 * d * g / (4.0f * cos_ti * cos_to);
+                }
+                if (!p_zero) {
+                    const float jac = 1.0f / (4.0f * fabsf(dot(w_o, w_h)));
+                    p = fabsf(w_h.z) * d * jac;   // mf_pdf(l, w_h) * jac
+                }
+            }
+            sum = sum + e;
+            pdf_val = pdf_val + p; ++n_comps;
+        } else {
+            if (em) sum = sum + lobe_eval<FEAT, KM>(b, l, w_o, w_i);
+            if (pm) { pdf_val = pdf_val + lobe_pdf<FEAT, KM>(l, w_o, w_i); ++n_comps; }
+        }
+    }
+    if (need_eval) f_out = sum;
+    if (need_pdf) pdf_out = n_comps > 0 ? pdf_val / (float)n_comps : 0.0f;
+}
 // Head of BSDF::sample (bsdf.rs:85-102): choose the lobe, sample its direction. Outputs the world
 // direction, the lobe's own pdf, f for specular lobes, the sampled type bits (0 = nothing sampled)
 // and which of BSDF::pdf / BSDF::eval the tail (bsdf.rs:103-109) still has to evaluate.
@@ -414,7 +467,7 @@ TR_DEV SampleHead bsdf_sample_head_sh(const Bsdf& b, f3 w_o, uint32_t flags, flo
     const Lobe l = load_lobe(b.mat, li);
     f3 w_i;
     float pdf_v;
-    f3 f = lobe_sample<FEAT, KM>(b, l, w_o, u0, u1, w_i, pdf_v);
+    f3 f = lobe_sample<FEAT, KM>(b, l, w_o, u0, u1, w_i, pdf_v, n_matching <= 1);   // (n_matching > 1: BSDF::pdf below replaces a non-specular lobe's own pdf)
     if (length_sqr(w_i) == 0.0f) return h;
     h.wi_world = normalized(from_shading(b, w_i));
     bool specular = (l.type & BX_SPECULAR) != 0u;

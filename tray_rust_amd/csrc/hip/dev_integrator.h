@@ -248,8 +248,7 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want, const f
     TR_QCLK(ln, 0);
     if (h.need_eval || h.need_pdf) {
         const f3 wi_sh = normalized(to_shading(ln.bsdf, h.wi_world));
-        if (h.need_eval) h.f = bsdf_eval_sh<FEAT, KM>(ln.bsdf, wo_sh, wi_sh, flags);
-        if (h.need_pdf) h.pdf = bsdf_pdf_sh<FEAT, KM>(ln.bsdf, wo_sh, wi_sh, flags);
+        bsdf_eval_pdf_sh<FEAT, KM>(ln.bsdf, wo_sh, wi_sh, flags, h.need_eval, h.need_pdf, h.f, h.pdf);
     }
     TR_QCLK(ln, 1);
     const f3 f = h.f, w_i = h.wi_world;

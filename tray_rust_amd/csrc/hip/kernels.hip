@@ -38,6 +38,9 @@ using namespace tr;
 #ifndef TR_MIN_WAVES
 #define TR_MIN_WAVES 3
 #endif
+#ifndef TR_MIN_WAVES_ANIM   // waves per SIMD the instantiations for moving scenes are compiled for (they carry the two-level traversal and the cached transforms)
+#define TR_MIN_WAVES_ANIM 3
+#endif
 #define WIN_MAX 17          // 8 + 2*4 + 1 window columns/rows
 #define WIN_STRIDE 24       // row stride in floats: 4 rows of 8 lanes land on 32 distinct banks
 #define WIN_PLANE (WIN_MAX * WIN_STRIDE)
@@ -212,7 +215,7 @@ TR_DEV const float* sc_filter_table(const DevScene& sc) { return sc.filter_table
 // LFILT: compile mis_ray_filter in (scenes with a sphere light or specular lobes: the only ones it can act on; its mere presence costs
 // the others 2 %: cornell_box 755 -> 740 Msamples/s at 64 spp).
 template <int ANIM, int FEAT, int INTEG = TRAY_INTEGRATOR_PATH, bool LFILT = false>
-__global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_path_tiles(const DevScene scv, const uint2* __restrict__ tiles, uint32_t tile_count,
+__global__ __launch_bounds__(TR_BLOCK, ANIM ? TR_MIN_WAVES_ANIM : TR_MIN_WAVES) void k_path_tiles(const DevScene scv, const uint2* __restrict__ tiles, uint32_t tile_count,
                                                          uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf, uint32_t slice_shift,
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ counter,
                                                          DevStats* __restrict__ stats) {
