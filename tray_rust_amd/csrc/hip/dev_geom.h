@@ -232,6 +232,7 @@ TR_DEV bool triangle_test(const TrayTriVerts* __restrict__ tv, f3 o, f3 d, float
     f3 e0 = pb - pa, e1 = pc - pa;
     f3 s0 = cross(d, e1);
     float dv = dot(s0, e0);
+#ifdef TR_TRI_BRANCHES
     if (dv == 0.0f) return false;
     float div = 1.0f / dv;
     f3 dd = o - pa;
@@ -244,6 +245,20 @@ TR_DEV bool triangle_test(const TrayTriVerts* __restrict__ tv, f3 o, f3 d, float
     if (t < min_t || t > max_t) return false;
     t_out = t; b1_out = b1; b2_out = b2;
     return true;
+#else
+    // straight-line form of mesh.rs:136-171: the early `return None`s only skip work, so every quantity is computed and the verdicts
+    // are and-ed (after a rejected test the later values are garbage that nobody reads) -- the lanes of a wave test different
+    // triangles, so the four exits were four divergent branches per test
+    float div = 1.0f / dv;
+    f3 dd = o - pa;
+    float b1 = dot(dd, s0) * div;
+    f3 s1 = cross(dd, e0);
+    float b2 = dot(d, s1) * div;
+    float t = dot(e1, s1) * div;
+    const bool ok = (dv != 0.0f) & !(b1 < 0.0f || b1 > 1.0f) & !(b2 < 0.0f || b1 + b2 > 1.0f) & !(t < min_t || t > max_t);
+    if (ok) { t_out = t; b1_out = b1; b2_out = b2; }
+    return ok;
+#endif
 }
 
 TR_DEV bool sphere_test(float radius, f3 o, f3 d, float min_t, float max_t, float& t_out) {   // sphere.rs:33-53
