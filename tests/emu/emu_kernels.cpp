@@ -305,6 +305,8 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
     bool small_mesh = false;
     for (uint32_t m = 0; m < f->n_meshes; ++m) small_mesh = small_mesh || f->meshes[m].tri_count <= TR_COOP_MAX_TRIS;
     if (coop != 0 && small_mesh && !moving) { e.d.coop_offset = stack_words; stack_words += (TR_BLOCK / 64) * TR_COOP_WORDS; }
+    if (e.d.film_rows) { e.d.win_offset = 0u; stack_words = std::max(stack_words, 4u * WIN_PLANE); }   // tray_scene_create: the film window over the stacks ...
+    else { e.d.win_offset = stack_words; stack_words += 4u * WIN_PLANE; }                               // ... or in its own region
     std::vector<uint2> tiles(tile_count);
     for (uint32_t i = 0; i < tile_count; ++i) tiles[i] = make_uint2(tiles_xy[2 * i], tiles_xy[2 * i + 1]);
     // work-item mapping of launch_tiles: item w -> queue entry (w / chunk) * chunk_stride * chunk + (w % chunk), from tile_start on

@@ -77,7 +77,9 @@ struct DevScene {
     uint32_t coop_offset;   // word offset of the cooperative leaf test's LDS area behind the traversal stacks (0 = none)
     const tray::FlatLeaf* __restrict__ flat_leaves;   // the flat instance loop's view of the scene: BVH<Instance> leaves ...
     const tray::FlatInst* __restrict__ flat_insts;    // ... and their instances, one 128-B record each (host/gates.hpp)
-    uint32_t n_flat_leaves, pad_flat;
+    uint32_t n_flat_leaves;
+    uint32_t win_offset;                        // tile kernel: word offset of the 17 x 17 RGBW film window in the dynamic LDS (0: it shares the traversal stacks' memory,
+                                                // which is free while a finished tile is resolved -- row-binned film only)
     const TrayTexture* __restrict__ textures;      // image textures (dev_tex.h); null when the scene has none
     const TrayTexFrame* __restrict__ tex_frames;
     const uint8_t* __restrict__ tex_data;

@@ -87,13 +87,16 @@ __device__ __forceinline__ void film_splat(const DevScene& sc, float* __restrict
 // ty * sum(tx * c) instead of sum((tx * ty) * c): same real number, last-bit rounding differs.
 #define ROW_W WIN_MAX
 #define ROWBIN_SIZE (8 * 8 * ROW_W * 4)
+__device__ __forceinline__ void film_splat_global(const DevScene& sc, float* __restrict__ rgbw, const float* __restrict__ s_table,
+                                                  int x0, int y0, float sx, float sy, f3 c);
 __device__ __forceinline__ void film_splat_rows(const DevScene& sc, float* __restrict__ s_rowbin, const float* __restrict__ s_tx,
-                                                float* __restrict__ s_win, const float* __restrict__ s_table,
+                                                float* __restrict__ rgbw, const float* __restrict__ s_table,
                                                 int x0, int y0, int py_l, float sx, float sy, f3 c) {
     const float img_x = sx - 0.5f, img_y = sy - 0.5f;
     const float e8 = (img_y - (float)(y0 + py_l)) * 8.0f;   // exact in f32
     const float fl8 = floorf(e8);
-    if (e8 == fl8 || fl8 < -4.0f || fl8 > 3.0f) { film_splat(sc, s_win, s_table, x0, y0, sx, sy, c); return; }
+    // (the ~1 in 1000 samples on a class boundary go straight to the caller's film: the LDS window only exists while a tile is resolved)
+    if (e8 == fl8 || fl8 < -4.0f || fl8 > 3.0f) { film_splat_global(sc, rgbw, s_table, x0, y0, sx, sy, c); return; }
     const int cy = (int)fl8 + 4;
     const int fpw = sc.fpw;
     const int xr0 = max(x0 - fpw, 0), xr1 = min(x0 + 8 + fpw, (int)sc.width - 1);
@@ -219,7 +222,6 @@ __global__ __launch_bounds__(TR_BLOCK, ANIM ? TR_MIN_WAVES_ANIM : TR_MIN_WAVES) 
                                                          uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf, uint32_t slice_shift,
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ counter,
                                                          DevStats* __restrict__ stats) {
-    __shared__ float s_win[4 * WIN_PLANE];
     const float* __restrict__ const s_table = sc_filter_table(scv);   // the 16 x 16 table stays in global memory (1 KB, cache resident): with the row-binned film only
                                                                        // the ~1 in 1000 samples on a class boundary read it, and the kilobyte decides whether a
                                                                        // third workgroup fits the CU's LDS on mesh scenes (42 granules of 1280 B per workgroup)
@@ -228,6 +230,10 @@ __global__ __launch_bounds__(TR_BLOCK, ANIM ? TR_MIN_WAVES_ANIM : TR_MIN_WAVES) 
     __shared__ uint4 s_perm[TR_PERM_BYTES / 16];   // the scene's permutation pool (dev_math.h): one byte read per LD array and vertex
     TR_DYN_LDS(uint32_t, s_stack);   // stack_depth x TR_BLOCK entries, sized per scene at launch
     __shared__ uint32_t s_tile, s_next_sample;
+    // the 17 x 17 RGBW window a finished tile is resolved through. With the row-binned film nothing touches it while paths are traced, so
+    // it lies over the traversal stacks (win_offset 0) and the 6.4 KB are not part of the workgroup's LDS footprint -- which is what lets
+    // a third workgroup onto the CU when a mesh needs 29 stack entries; filters the row bins do not cover keep their own region
+    float* const s_win = reinterpret_cast<float*>(s_stack + scv.win_offset);
     const DevScene& sc = scv;
     const DevScene* const scp = &scv;
     const uint32_t tid = threadIdx.x;
@@ -248,9 +254,8 @@ __global__ __launch_bounds__(TR_BLOCK, ANIM ? TR_MIN_WAVES_ANIM : TR_MIN_WAVES) 
     for (;;) {
         __syncthreads();   // previous tile fully flushed
         if (tid == 0) { s_tile = atomicAdd(counter, 1u); s_next_sample = 0u; }
-        for (uint32_t i = tid; i < 4 * WIN_PLANE; i += TR_BLOCK) s_win[i] = 0.0f;
-        if (film_rows)
-            for (uint32_t i = tid; i < ROWBIN_SIZE; i += TR_BLOCK) s_rowbin[i] = 0.0f;
+        if (film_rows) { for (uint32_t i = tid; i < ROWBIN_SIZE; i += TR_BLOCK) s_rowbin[i] = 0.0f; }
+        else for (uint32_t i = tid; i < 4 * WIN_PLANE; i += TR_BLOCK) s_win[i] = 0.0f;
         __syncthreads();
         // a work item is one SLICE of a tile: samples [sl, sl + 1) * (spp >> slice_shift) of its 64 pixels. The film is a sum, so the
         // slices of a tile are independent; launch_tiles cuts tiles when there are too few of them per workgroup for an even finish
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(TR_BLOCK, ANIM ? TR_MIN_WAVES_ANIM : TR_MIN_WAVES) 
             bool started = false;
             const bool idle = !(ln.flags & LF_ALIVE);
             if (idle && pending) {   // the previous sample of this lane is finished: RenderTarget::write it
-                if (film_rows) film_splat_rows(sc, s_rowbin, s_tx, s_win, s_table, x0, y0, (int)row_l, sx, sy, lane_result(ln));
+                if (film_rows) film_splat_rows(sc, s_rowbin, s_tx, rgbw, s_table, x0, y0, (int)row_l, sx, sy, lane_result(ln));
                 else film_splat(sc, s_win, s_table, x0, y0, sx, sy, lane_result(ln));
                 pending = false;
             }
@@ -353,7 +358,9 @@ __global__ __launch_bounds__(TR_BLOCK, ANIM ? TR_MIN_WAVES_ANIM : TR_MIN_WAVES) 
             }
         }
         __syncthreads();
-        if (film_rows) {
+        if (film_rows) {   // (every wave is out of the step loop: the stacks' memory is the window now)
+            for (uint32_t i = tid; i < 4 * WIN_PLANE; i += TR_BLOCK) s_win[i] = 0.0f;
+            __syncthreads();
             film_resolve_rows(sc, s_rowbin, s_ty, s_win, y0, tid);
             __syncthreads();
         }
@@ -927,6 +934,11 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         if (single_leaf && !s->wavefront && !s->animated && f->n_instances <= TR_FLAT_MAX && !getenv("TRAYHIP_NO_COOP")) {
             s->dev.coop_offset = depth * TR_BLOCK;
             s->stack_bytes += (TR_BLOCK / 64) * TR_COOP_WORDS * (uint32_t)sizeof(float);
+        }
+        {   // the tile kernel's film window: over the stacks for the row-binned film, behind everything else otherwise (k_path_tiles)
+            const uint32_t win_bytes = 4u * WIN_PLANE * (uint32_t)sizeof(float);
+            if (d.film_rows) { s->dev.win_offset = 0u; s->stack_bytes = std::max(s->stack_bytes, win_bytes); }
+            else { s->dev.win_offset = s->stack_bytes / (uint32_t)sizeof(uint32_t); s->stack_bytes += win_bytes; }
         }
         if (s->stack_bytes > 32u * 1024u) {   // past the default dynamic-LDS window: raise the per-kernel limit (160 KB LDS per CU)
             const int bytes = (int)s->stack_bytes;
