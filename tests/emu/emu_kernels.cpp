@@ -79,6 +79,8 @@ struct EmuScene {
     std::vector<tray::FlatLeaf> flat_leaves;
     std::vector<tray::FlatInst> flat_insts;
     std::vector<uint8_t> tri_leaf;
+    tray::PairedTrees paired;   // the trees in device order, as tray_scene_create uploads them
+    std::vector<tray::WfInst> wf_insts;
     std::vector<uint8_t> perm_pool;
     uint32_t retraced = 0;   // rays the flat loop handed to trace_bvh
     uint32_t depth = 0;   // traversal stack entries per lane, as tray_scene_create sizes them (two-level worst case, generous)
@@ -99,8 +101,11 @@ uint32_t bvh_depth(const TrayBvhNode* nodes, uint32_t n) {
 
 void make_scene(const TrayFlatScene* f, EmuScene& e) {
     DevScene& d = e.d;
-    d.instances = f->instances; d.top_nodes = f->top_nodes; d.top_order = f->top_order; d.meshes = f->meshes;
-    d.mesh_nodes = f->mesh_nodes; d.tri_verts = f->tri_verts; d.tri_attrs = f->tri_attrs;
+    if (!tray::pair_trees(f, e.paired)) throw std::runtime_error("BVH arrays do not describe trees");
+    d.instances = f->instances; d.top_nodes = e.paired.top.data(); d.top_order = f->top_order; d.meshes = e.paired.meshes.data();
+    d.mesh_nodes = e.paired.mesh.data(); d.tri_verts = f->tri_verts; d.tri_attrs = f->tri_attrs;
+    tray::wf_inst_records(f, e.paired.meshes, e.wf_insts);
+    d.wf_insts = e.wf_insts.data();
     e.mats.resize(f->n_materials);
     for (uint32_t i = 0; i < f->n_materials; ++i) e.mats[i] = lower_material(f->materials[i], f->merl_tables);
     d.materials = e.mats.data(); d.merl_data = f->merl_data; d.lights = f->lights;
@@ -116,7 +121,7 @@ void make_scene(const TrayFlatScene* f, EmuScene& e) {
     e.perm_pool.resize(TR_PERM_BYTES);
     perm_pool_build(f->max_depth + 1u, e.perm_pool.data());
     d.perm_pool = e.perm_pool.data();
-    tray::flat_loop_gates(f, TR_COOP_MAX_TRIS, e.flat_leaves, e.flat_insts, e.tri_leaf);
+    tray::flat_loop_gates(f, e.paired, TR_COOP_MAX_TRIS, e.flat_leaves, e.flat_insts, e.tri_leaf);
     d.flat_leaves = e.flat_leaves.data(); d.flat_insts = e.flat_insts.data(); d.n_flat_leaves = (uint32_t)e.flat_leaves.size(); d.tri_leaf = e.tri_leaf.data();
     d.retraced = &g_retraced;
     uint32_t mesh_depth = 0;

@@ -90,6 +90,7 @@ struct DevScene {
                        // where it held scalar registers for the whole kernel (193 -> 140 SGPRs spilled to VGPR lanes in k_path_tiles)
     const TrayCamera* __restrict__ camera_p;
     const uint8_t* __restrict__ perm_pool;   // TR_PERM_BYTES: the shuffles the per-path LD arrays draw from (dev_math.h: perm_pool_build)
+    const tray::WfInst* __restrict__ wf_insts;   // one 64-B record per BVH<Instance> leaf slot (host/gates.hpp): the wavefront traversal's instance entry
 };
 
 struct Ray {
@@ -142,6 +143,12 @@ TR_DEV void instance_inv_at(const DevScene& sc, const TrayInstance* __restrict__
     } else {
         eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
     }
+}
+// rows of inv of moving instance `moving_slot` in the path's column of the wavefront kernels' transform cache (xf_aos = 1)
+TR_DEV void instance_inv_cached(const DevScene& sc, uint32_t moving_slot, uint32_t column, float* x) {
+    const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.n_moving + moving_slot) * 24u + 12u);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const float4 v = rec[q]; x[12 + 4 * q] = v.x; x[13 + 4 * q] = v.y; x[14 + 4 * q] = v.z; x[15 + 4 * q] = v.w; }
 }
 template <int ANIM>
 TR_DEV void instance_xf_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, uint32_t column, float* x) {
@@ -310,6 +317,12 @@ TR_DEV bool disk_test(float radius, float inner_radius, f3 o, f3 d, float min_t,
 #define TR_BLOCK 256
 #endif
 enum : uint32_t { STK_NODE = 0u, STK_INSTANCE = 1u << 30, STK_EXIT_MESH = 2u << 30, STK_KIND_MASK = 3u << 30 };
+// Word 7 of a device node (host/gates.hpp: pair_tree): the node's descriptor -- all a traversal needs of a node whose box it has
+// tested: where its children (interior: the sibling pair at `offset`) or its primitives (leaf: `count` of them from `offset`) lie and the
+// split axis. The top two bits are 0, so a descriptor is a STK_NODE stack entry as it stands.
+TR_DEV uint32_t nd_offset(uint32_t desc) { return desc & 0x7fffffu; }
+TR_DEV uint32_t nd_count(uint32_t desc) { return (desc >> 23) & 31u; }
+TR_DEV uint32_t nd_axis(uint32_t desc) { return (desc >> 28) & 3u; }
 
 // BVH<Triangle>::intersect over one mesh (bvh.rs:81-130, leaf <= 16). Returns true if a triangle was
 // accepted; max_t shrinks as candidates are accepted. any_hit: stop at the first accepted candidate.
@@ -362,15 +375,14 @@ TR_DEV bool mesh_traverse_ww(const DevScene& sc, uint32_t* __restrict__ stack, c
                 const bool hb = bbox_hit_t(blo, bhi, o, inv_dir, nx, ny, nz, min_t, max_t, tb) && two;
                 if (ha || hb) {
                     if (ha && hb) { stack[sp * TR_BLOCK] = node_b; ++sp; }
-                    const uint32_t cur = ha ? node_a : node_b;
                     const uint32_t offset = __float_as_uint(ha ? ahi.z : bhi.z);
                     const uint32_t meta = __float_as_uint(ha ? ahi.w : bhi.w);
-                    const uint32_t count = meta & 0xffffu, axis = (meta >> 16) & 0xffu;
+                    const uint32_t count = nd_count(meta), axis = nd_axis(meta);
                     if (count == 0u) {
                         // any-hit rays take the child on the light's side first (the boolean does not depend on the order; C4 stand-in +2.5 %)
                         const bool neg = (axis == 0u ? nx : (axis == 1u ? ny : nz)) != any_hit;
-                        node_a = neg ? offset : cur + 1u;
-                        node_b = neg ? cur + 1u : offset;
+                        node_a = neg ? offset + 1u : offset;   // (device order: the children are the pair at `offset`, host/gates.hpp)
+                        node_b = neg ? offset : offset + 1u;
                     } else {
                         mode = MW_LEAF; leaf_offset = offset; leaf_count = count; leaf_t = ha ? ta : tb;
                     }
@@ -653,14 +665,14 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
         const float4* nq = reinterpret_cast<const float4*>(tree + current);
         float4 lo = nq[0], hi = nq[1];
         uint32_t offset = __float_as_uint(hi.z);
-        uint32_t meta = __float_as_uint(hi.w);   // count (16) | axis (8) | pad (8)
-        uint32_t count = meta & 0xffffu, axis = (meta >> 16) & 0xffu;
+        uint32_t meta = __float_as_uint(hi.w);   // the node's descriptor
+        uint32_t count = nd_count(meta), axis = nd_axis(meta);
         bool descend = false;
         if (bbox_hit(lo, hi, o, inv_dir, nx, ny, nz, min_t, max_t)) {
             if (count == 0u) {   // interior: near child first by the sign of the split axis (bvh.rs:105-119)
                 bool neg = (axis == 0u ? nx : (axis == 1u ? ny : nz)) != any_hit;   // (any-hit: light's side first, see mesh_traverse_ww)
-                uint32_t far_child = neg ? current + 1u : offset;
-                current = neg ? offset : current + 1u;
+                uint32_t far_child = neg ? offset : offset + 1u;   // (device order: the children are the pair at `offset`, host/gates.hpp)
+                current = neg ? offset + 1u : offset;
                 stack[sp * TR_BLOCK] = far_child;
                 ++sp;
                 descend = true;

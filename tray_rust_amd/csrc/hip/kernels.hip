@@ -554,6 +554,8 @@ struct TrayDeviceScene {
     int feat = FEAT_ALL;              // lobe kinds of the scene's materials that need the large kernels (dev_bsdf.h)
     uint32_t* d_queues = nullptr;     // wavefront schedule: ray queues A, B, C (n_slots each) + WF_QCTL_WORDS counters
     uint32_t n_blocks_trace = 0;      // persistent grid of k_wf_trace_dyn
+    std::vector<TrayMesh> paired_meshes;   // the meshes with node_offset / node_count in device order (what the `meshes` buffer holds)
+    bool narrow_trees = true;         // every node's offset fits a descriptor (host/gates.hpp): the wavefront traversal keeps nodes as descriptors
     uint32_t trace_lds_depth = 0, trace_lds_bytes = 0;   // LDS part of the dynamic-fetch kernel's stacks; deeper entries go to d_stack_overflow
     uint32_t* d_stack_overflow = nullptr;
     bool light_filter = false;        // a sphere light or specular lobes: the tile kernel with mis_ray_filter (dev_integrator.h) compiled in
@@ -759,10 +761,26 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
     if (rc == TRAY_OK) rc = upload(s, "instances", false, f->instances, f->n_instances, &d_inst);
     d.instances = d_inst;
     s->d_instances = const_cast<TrayInstance*>(d_inst);
-    UP(top_nodes, f->top_nodes, f->n_top_nodes)
+    // the trees in device order (host/gates.hpp: sibling pairs); the BVH<Triangle>s are part of the scene, a frame update keeps the donor's
+    tray::PairedTrees paired;
+    size_t n_paired = 0;   // nodes of the BVH<Triangle>s in device order: one more per tree
+    for (uint32_t m = 0; m < f->n_meshes; ++m) n_paired += f->meshes[m].node_count ? f->meshes[m].node_count + 1u : 0u;
+    bool keep_trees = false;
+    if (donor)
+        for (const TrayDevBuf& b : donor->bufs)
+            keep_trees = keep_trees || (std::strcmp(b.key, "mesh_nodes") == 0 && b.bytes == std::max<size_t>(n_paired, 1) * sizeof(TrayBvhNode));
+    if (rc == TRAY_OK && !tray::pair_trees(f, paired, keep_trees)) { rc = TRAY_E_INVALID; set_error("BVH arrays do not describe trees"); }
+    s->narrow_trees = keep_trees ? donor->narrow_trees : paired.narrow;
+    s->paired_meshes = keep_trees ? donor->paired_meshes : paired.meshes;
+    {   // the wavefront traversal's instance records (host/gates.hpp): per frame, as the instances are
+        std::vector<tray::WfInst> recs;
+        tray::wf_inst_records(f, s->paired_meshes, recs);
+        UP(wf_insts, recs.data(), recs.size())
+    }
+    UP(top_nodes, paired.top.data(), paired.top.size())
     UP(top_order, f->top_order, f->n_top_order)
-    UPS(meshes, f->meshes, f->n_meshes)
-    UPS(mesh_nodes, f->mesh_nodes, f->n_mesh_nodes)
+    UPS(meshes, keep_trees ? f->meshes : paired.meshes.data(), f->n_meshes)          // (kept: the donor's copies are not written)
+    UPS(mesh_nodes, keep_trees ? f->mesh_nodes : paired.mesh.data(), n_paired)
     UPS(tri_verts, f->tri_verts, f->n_tris)
     UPS(tri_attrs, f->tri_attrs, f->n_tris)
     std::vector<DevMaterial> mats(f->n_materials);
@@ -818,7 +836,7 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         std::vector<tray::FlatLeaf> leaves;
         std::vector<tray::FlatInst> insts;
         std::vector<uint8_t> tri_leaf;
-        tray::flat_loop_gates(f, TR_COOP_MAX_TRIS, leaves, insts, tri_leaf);
+        tray::flat_loop_gates(f, paired, TR_COOP_MAX_TRIS, leaves, insts, tri_leaf);
         const tray::FlatLeaf* d_leaves = nullptr;
         const tray::FlatInst* d_insts = nullptr;
         const uint8_t* d_tri_leaf = nullptr;
@@ -1062,6 +1080,7 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
 // The host only polls a "tiles done" word every WF_POLL rounds; kernels of finished chunks exit at once.
 static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride,
                             uint32_t spp, uint32_t kf, float* rgbw_dev, hipStream_t stream) {
+    if (!s->narrow_trees) { set_error("wavefront schedule: a BVH of more than 8 388 607 nodes or triangles (the traversal keeps a node as a 32-bit descriptor)"); return TRAY_E_UNSUPPORTED; }
     if (!s->wf_ready) {
         if (s->pool.data) { set_error("the wavefront buffers of this scene could not be allocated by an earlier call"); return TRAY_E_NOMEM; }
         uint32_t n_slots = (s->animated && s->dev.xf_cache_lanes) ? s->dev.xf_cache_lanes : wf_slot_count(s);   // (the transform cache was sized at creation)
@@ -1090,7 +1109,8 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
             // LDS stack entries per lane such that WF_TRACE_WAVES workgroups (4 waves each = one wave per SIMD) fit in the CU's 160 KB
-            const uint32_t full_depth = s->stack_bytes / (TR_BLOCK * (uint32_t)sizeof(uint32_t));
+            // (a node on this kernel's stack is two words: descriptor and entry distance)
+            const uint32_t full_depth = 2u * (s->stack_bytes / (TR_BLOCK * (uint32_t)sizeof(uint32_t)));
             uint32_t lds_depth = std::min<uint32_t>(full_depth, (160u * 1024u / WF_TRACE_WAVES) / (TR_BLOCK * (uint32_t)sizeof(uint32_t)));
             if (const char* e = getenv("TRAYHIP_WF_LDS_DEPTH")) lds_depth = std::min<uint32_t>(full_depth, (uint32_t)std::max(1, atoi(e)));
             s->trace_lds_depth = lds_depth;
@@ -1439,6 +1459,15 @@ int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t) {
         const char* parts[3] = {"sample head / light setup", "eval + pdf site", "epilogue of the query kind"};
         for (int k = 0; k < 3; ++k) fprintf(stderr, "[trayhip]   queries: %-28s %5.1f %% of wave cycles\n", parts[k], 100.0 * (double)st.trav[8 + k] / tot);
     }
+#elif defined(WF_TRACE_CLOCKS)
+    if (getenv("TRAYHIP_STATS") && st.rays)
+        for (int g = 0; g < 3; ++g) {
+            const unsigned long long* t = st.trav + g * 6;
+            double tot = 0;
+            for (int k = 0; k < 5; ++k) tot += (double)t[k];
+            if (tot > 0) fprintf(stderr, "[trayhip] trace %c wave cycles: refill %.1f %%  node phase %.1f %%  leaf phase %.1f %%  pop phase %.1f %%  result write %.1f %%\n", "ABC"[g],
+                                 100 * t[0] / tot, 100 * t[1] / tot, 100 * t[2] / tot, 100 * t[3] / tot, 100 * t[4] / tot);
+        }
 #else
     if (getenv("TRAYHIP_STATS") && st.rays)
         for (int g = 0; g < 3; ++g) {

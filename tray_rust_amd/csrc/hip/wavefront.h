@@ -190,6 +190,18 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
     uint32_t* __restrict__ ovf = overflow + (blockIdx.x * TR_BLOCK + threadIdx.x);
 #define WF_PUSH(v) do { const uint32_t v_ = (v); if ((uint32_t)sp < lds_depth) stack[sp * TR_BLOCK] = v_; else ovf[(size_t)((uint32_t)sp - lds_depth) * ovf_stride] = v_; ++sp; } while (0)
 #define WF_POP(e) do { --sp; if ((uint32_t)sp < lds_depth) e = stack[sp * TR_BLOCK]; else e = ovf[(size_t)((uint32_t)sp - lds_depth) * ovf_stride]; } while (0)
+    // pops node entries until one passes the box test of the moment (stored entry distance < max_t now) -- the lane goes on with it -- or
+    // something else is on top (instance entry, end of a mesh: left for the pop phase) or the stack is empty; cheap (LDS), so it runs
+    // wherever a lane runs out of node work instead of sending the lane through the pop phase
+#define WF_POP_NODES() do {                                                                                                          \
+        while (sp > 0) {                                                                                                             \
+            uint32_t e_, t_;                                                                                                         \
+            WF_POP(e_);                                                                                                              \
+            if ((e_ & STK_KIND_MASK) != STK_NODE) { ++sp; break; }                                                                   \
+            WF_POP(t_);                                                                                                              \
+            if (__uint_as_float(t_) < max_t) { cur = e_; cur_count = nd_count(e_); cur_offset = nd_offset(e_); mode = cur_count != 0u ? TM_LEAF : TM_NODE; break; } \
+        }                                                                                                                            \
+    } while (0)
     const uint32_t lane = threadIdx.x & 63u;
     const bool any_hit = STAGE == 1;
     bool active = false;
@@ -205,13 +217,20 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
 #else
 #define WF_COUNT(x) ((void)0)
 #endif
+#ifdef WF_TRACE_CLOCKS   // where a wave's cycles go: 0 refill, 1 node phase, 2 leaf phase, 3 pop phase, 4 result write
+    unsigned long long wclk[5] = {0, 0, 0, 0, 0};
+    long long wclk_t = clock64();
+#define WF_CLK(slot) do { const long long now_ = clock64(); wclk[slot] += (unsigned long long)(now_ - wclk_t); wclk_t = now_; } while (0)
+#else
+#define WF_CLK(slot) ((void)0)
+#endif
     // traversal state (trace_bvh)
     f3 wo = mk(0, 0, 0), wd = mk(0, 0, 0), o = wo, d = wd, inv_dir = wo;
     bool nx = false, ny = false, nz = false, in_mesh = false, any = false;
-    float min_t = 0.0f, max_t = 0.0f, time = 0.0f;
+    float min_t = 0.0f, max_t = 0.0f;
     int sp = 0;
-    uint32_t node_a = 0u, node_b = 0xffffffffu, cur_inst = 0u, tri_base = 0u, cur_offset = 0u, cur_count = 0u;
-    enum : uint32_t { TM_NODE = 0u, TM_LEAF = 1u, TM_POP = 2u, WF_NO_NODE = 0xffffffffu };
+    uint32_t cur = 0u, cur_inst = 0u, tri_base = 0u, cur_offset = 0u, cur_count = 0u;   // cur: descriptor of the node to expand (dev_geom.h: nd_*)
+    enum : uint32_t { TM_NODE = 0u, TM_LEAF = 1u, TM_POP = 2u };
     uint32_t mode = TM_NODE;
     const TrayBvhNode* __restrict__ tree = sc.top_nodes;
     const TrayTriVerts* __restrict__ tris = nullptr;
@@ -238,11 +257,10 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                             wo = ld3(pool, F_P, slot); wd = ld3(pool, F_AUX, slot);
                             min_t = 0.001f; max_t = STAGE == 1 ? 0.999f : TR_INF;
                         }
-                        if (ANIM) time = pf(pool, F_TIME, slot);
                         o = wo; d = wd;
                         inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                         nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
-                        tree = sc.top_nodes; node_a = 0u; node_b = WF_NO_NODE; sp = 0; in_mesh = false; any = false; mode = TM_NODE;
+                        tree = sc.top_nodes; cur = 0u; sp = 0; in_mesh = false; any = false; mode = TM_NODE;
                         rec.t = 0.0f; rec.inst = 0xffffffffu; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
                         active = true;
                         ++n_rays;
@@ -254,16 +272,19 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                 }
             }
         }
+        WF_CLK(0);
         if (!__any(active)) { if (exhausted) break; continue; }
         // ---- traversal, while-while form. A lane is in one of three modes:
-        //   TM_NODE  has one or two nodes to test: a popped node (the box test the reference runs when it reaches a node,
-        //            with the ray's current max_t) or BOTH children of a node whose box was hit. Fetching the children
-        //            together means a child whose box is missed never costs a dependent fetch of its own; the far child is
-        //            pushed only if its box is hit now (a box missed with the current max_t is missed with any later, smaller
-        //            one) and is re-tested when popped, so the accepted candidates and their order are exactly the
-        //            reference's (bvh.rs:89-127).
+        //   TM_NODE  EXPANDS a node whose box it has passed (`cur`, the node's descriptor): the boxes of both children are one
+        //            64-byte record (device order of the trees, host/gates.hpp) and are tested together with the ray's current
+        //            max_t. If both are hit the far one goes on the stack as (descriptor, entry distance); the near one, or the only
+        //            one hit, is expanded next. A ray enters a tree by expanding node "0": the pair (root, empty twin).
         //   TM_LEAF  reached a leaf: triangles of a BVH<Triangle> leaf, or the instances of a BVH<Instance> leaf
-        //   TM_POP   needs the next stack entry (instance entry, primitive tests, leaving a mesh)
+        //   TM_POP   needs a stack entry that is not a node (instance entry, leaving a mesh) or has none left
+        // The reference tests a node's box when it reaches the node, with the max_t of that moment (bvh.rs:89-127). max_t enters
+        // the slab test only through `tmin < max_t` (bbox_hit), everything else in it is the same whenever it is evaluated, so the
+        // test at pop time is the stored entry distance against the current max_t: no second fetch of the node, and a step of the
+        // loop is always one record for two boxes. Candidates and their order are exactly the reference's.
         // The node phase repeats while enough lanes have node work, so the (much longer) leaf / pop code runs once per
         // several node steps instead of once per step for whichever few lanes happen to need it.
         bool finished = false;
@@ -275,35 +296,31 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
             if (it > 0 && n_node < WF_NODE_MIN && __any(active && mode != TM_NODE)) break;
             if (in_node) {
                 WF_COUNT(c_iter);
-                const bool two = node_b != WF_NO_NODE;
-                const float4* qa = reinterpret_cast<const float4*>(tree + node_a);
-                const float4* qb = reinterpret_cast<const float4*>(tree + (two ? node_b : node_a));
-                const float4 alo = qa[0], ahi = qa[1], blo = qb[0], bhi = qb[1];
-                const bool ha = bbox_hit(alo, ahi, o, inv_dir, nx, ny, nz, min_t, max_t);
-                const bool hb = two && bbox_hit(blo, bhi, o, inv_dir, nx, ny, nz, min_t, max_t);
-                if (two) WF_COUNT(c_expand); else WF_COUNT(c_visit);
+                const float4* q = reinterpret_cast<const float4*>(tree + nd_offset(cur));
+                const float4 alo = q[0], ahi = q[1], blo = q[2], bhi = q[3];
+                float ta, tb;
+                const bool ha = bbox_hit_t(alo, ahi, o, inv_dir, nx, ny, nz, min_t, max_t, ta);
+                const bool hb = bbox_hit_t(blo, bhi, o, inv_dir, nx, ny, nz, min_t, max_t, tb);
+                WF_COUNT(c_expand);
                 if (ha || hb) {
-                    if (ha && hb) WF_PUSH(node_b);
-                    const uint32_t cur = ha ? node_a : node_b;
-                    cur_offset = __float_as_uint(ha ? ahi.z : bhi.z);
-                    const uint32_t meta = __float_as_uint(ha ? ahi.w : bhi.w);
-                    cur_count = meta & 0xffffu;
-                    if (cur_count == 0u) {   // interior: near child first by the sign of the split axis (bvh.rs:105-119)
-                        const uint32_t axis = (meta >> 16) & 0xffu;
-                        // Occlusion rays (STAGE 1) visit the child on the LIGHT's side first: the boolean does not depend on the order (until a
-                        // candidate is accepted max_t is the original one, so one is accepted iff a valid candidate exists at all), the
-                        // rays of a light converge there, and what blocks a light tends to sit near it: +1.4 % on the C5 stand-in.
-                        const bool neg = (axis == 0u ? nx : (axis == 1u ? ny : nz)) != (STAGE == 1);
-                        node_a = neg ? cur_offset : cur + 1u;
-                        node_b = neg ? cur + 1u : cur_offset;
-                    } else {
-                        mode = TM_LEAF;
-                    }
+                    // near child first by the sign of the split axis (bvh.rs:105-119); occlusion rays (STAGE 1) visit the child on the LIGHT's
+                    // side first: the boolean does not depend on the order (until a candidate is accepted max_t is the original one, so
+                    // one is accepted iff a valid candidate exists at all), the rays of a light converge there, and what blocks a light
+                    // tends to sit near it: +1.4 % on the C5 stand-in.
+                    const uint32_t axis = nd_axis(cur);
+                    const bool neg = (axis == 0u ? nx : (axis == 1u ? ny : nz)) != (STAGE == 1);
+                    const uint32_t da = __float_as_uint(ahi.w), db = __float_as_uint(bhi.w);
+                    if (ha && hb) { WF_PUSH(__float_as_uint(neg ? ta : tb)); WF_PUSH(neg ? da : db); }
+                    cur = (ha && hb) ? (neg ? db : da) : (ha ? da : db);
+                    cur_count = nd_count(cur);
+                    if (cur_count != 0u) { cur_offset = nd_offset(cur); mode = TM_LEAF; }
                 } else {
                     mode = TM_POP;
+                    WF_POP_NODES();
                 }
             }
         }
+        WF_CLK(1);
         if (active && mode == TM_LEAF) {
             if (in_mesh) {   // BVH<Triangle> leaf (<= 16 triangles), tested in order
                 for (uint32_t k = 0; k < cur_count; ++k) {
@@ -322,14 +339,23 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                 }
             }
             mode = TM_POP;
+            if (!finished) WF_POP_NODES();
         }
+        WF_CLK(2);
         if (active && mode == TM_POP && !finished) {
             bool have_node = false;
             while (sp > 0) {
                 uint32_t e;
                 WF_POP(e);
                 uint32_t kind = e & STK_KIND_MASK;
-                if (kind == STK_NODE) { node_a = e; node_b = WF_NO_NODE; have_node = true; break; }
+                if (kind == STK_NODE) {   // the box test the reference runs when it reaches the node: the stored entry distance against max_t now
+                    uint32_t tb_;
+                    WF_POP(tb_);
+                    if (!(__uint_as_float(tb_) < max_t)) continue;
+                    cur = e; cur_count = nd_count(e); cur_offset = nd_offset(e);
+                    have_node = true;
+                    break;
+                }
                 if (kind == STK_EXIT_MESH) {   // back to world space and the top-level tree
                     in_mesh = false;
                     tree = sc.top_nodes;
@@ -338,42 +364,49 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                     nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
                     continue;
                 }
-                // Instance::intersect (receiver.rs:29-35): world ray -> object ray by `inv`, direction not renormalised
-                uint32_t i = sc.top_order[e & ~STK_KIND_MASK];
-                const TrayInstance* __restrict__ in = sc.instances + i;
-                if (in->kind == TRAY_INST_POINT_EMITTER) continue;   // emitter.rs:120
+                // Instance::intersect (receiver.rs:29-35): world ray -> object ray by `inv`, direction not renormalised. The entry's
+                // 64-byte record (host/gates.hpp: WfInst) holds all of it: one fetch, no dependent second one for static instances
+                const float4* __restrict__ wr = reinterpret_cast<const float4*>(sc.wf_insts + (e & ~STK_KIND_MASK));
+                const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+                const uint32_t wflags = __float_as_uint(w3.x);
+                if (wflags & tray::WI_POINT) continue;   // emitter.rs:120
+                const uint32_t i = __float_as_uint(w3.y);
                 WF_COUNT(c_inst);
                 f3 lo_, ld;
-                if (ANIM && in->animated) {   // the path's transform of a moving instance, from the per-slot cache
+                if (ANIM && (wflags & tray::WI_ANIMATED)) {   // the path's transform of a moving instance, from the per-slot cache
                     float x[24];
-                    instance_inv_at<ANIM>(sc, in, time, slot, x);
+                    instance_inv_cached(sc, wflags >> 8, slot, x);
                     lo_ = xf_point_affine(x + 12, wo);
                     ld = xf_vector(x + 12, wd);
+                } else if (wflags & tray::WI_AFFINE) {
+                    const float m[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+                    lo_ = xf_point_affine(m, wo);   // (row 3 = 0 0 0 1: xf_point's w is exactly one)
+                    ld = xf_vector(m, wd);
                 } else {
+                    const TrayInstance* __restrict__ in = sc.instances + i;
                     lo_ = xf_point(in->inv, wo);
                     ld = xf_vector(in->inv, wd);
                 }
-                uint32_t gt = in->geom_type;
+                const uint32_t gt = wflags & 7u;
                 if (gt == TRAY_GEOM_MESH) {
-                    const TrayMesh m = sc.meshes[in->mesh_id];
                     WF_PUSH(STK_EXIT_MESH);
                     in_mesh = true;
                     cur_inst = i;
-                    tree = sc.mesh_nodes + m.node_offset;
-                    tris = sc.tri_verts + m.tri_offset;
-                    tri_base = m.tri_offset;
+                    tree = sc.mesh_nodes + __float_as_uint(w3.z);
+                    tri_base = __float_as_uint(w3.w);
+                    tris = sc.tri_verts + tri_base;
                     o = lo_; d = ld;
                     inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                     nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
-                    node_a = 0u; node_b = WF_NO_NODE;
+                    cur = 0u; cur_count = 0u;
                     have_node = true;
                     break;
                 }
                 float t;
                 bool hit;
-                if (gt == TRAY_GEOM_RECT) hit = rect_test(in->geom_params[0], in->geom_params[1], lo_, ld, min_t, max_t, t);
-                else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(in->geom_params[0], lo_, ld, min_t, max_t, t);
-                else hit = disk_test(in->geom_params[0], in->geom_params[1], lo_, ld, min_t, max_t, t);
+                if (gt == TRAY_GEOM_RECT) hit = rect_test(w3.z, w3.w, lo_, ld, min_t, max_t, t);
+                else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(w3.z, lo_, ld, min_t, max_t, t);
+                else hit = disk_test(w3.z, w3.w, lo_, ld, min_t, max_t, t);
                 if (hit) {
                     max_t = t;
                     rec.t = t; rec.inst = i; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
@@ -381,9 +414,10 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                     if (any_hit) { finished = true; break; }
                 }
             }
-            if (have_node) mode = TM_NODE;
+            if (have_node) mode = cur_count != 0u ? TM_LEAF : TM_NODE;
             else finished = true;
         }
+        WF_CLK(3);
         if (finished) {   // write the result to the ray's own slot
             uint32_t flags = pu(pool, F_FLAGS, slot);
             if (STAGE == 1) {
@@ -399,7 +433,11 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
             pu(pool, F_FLAGS, slot) = flags;
             active = false;
         }
+        WF_CLK(4);
     }
+#ifdef WF_TRACE_CLOCKS
+    if (lane == 0u) for (int k = 0; k < 5; ++k) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].trav[STAGE * 6 + k], wclk[k]);
+#endif
     // one counter update per wave
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
     if (lane == 0u && n_rays) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].rays, (unsigned long long)n_rays);
@@ -413,8 +451,10 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
     if (lane == 0u && n_rays) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].trav[STAGE * 6 + 5], (unsigned long long)n_rays);
 #endif
 #undef WF_COUNT
+#undef WF_CLK
 #undef WF_PUSH
 #undef WF_POP
+#undef WF_POP_NODES
 }
 
 // Stage A shading: vertex_begin for the slots whose ray hit, end of the sample for those that missed.
