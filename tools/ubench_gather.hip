@@ -7,6 +7,7 @@
 //          records are handed to their owners through LDS -- 4x fewer (instruction, line) pairs for the L1's tagger,
 //          the same bytes
 //   half   `lane` with 32-byte records (one box per step)
+//   wide   `lane` with 128-byte records (eight 16-byte loads: what a step over a 4-wide node would fetch)
 // over tables of 2 MB (L2 resident) .. 512 MB (HBM), with all 64 lanes of a wave active or only every third one (the
 // traversal kernel runs at 37 % of its lanes), at 4 waves per SIMD. Printed: G records/s and ns per dependent step.
 #include <hip/hip_runtime.h>
@@ -31,6 +32,13 @@ __global__ __launch_bounds__(256, 4) void k_chase(const uint4* __restrict__ tabl
             if (active) { const uint4* p = table + (size_t)idx * 4u; a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
         } else if (MODE == 2) {
             if (active) { const uint4* p = table + (size_t)idx * 2u; a = p[0]; b = p[1]; }
+        } else if (MODE == 3) {
+            if (active) {
+                const uint4* p = table + (size_t)idx * 8u;
+                const uint4 e = p[4], f = p[5], g = p[6], h = p[7];
+                a = p[0]; b = p[1]; c = p[2]; d = p[3];
+                a.x ^= e.x; b.x ^= f.x; c.x ^= g.x; d.x ^= h.x;
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -54,7 +62,7 @@ __global__ __launch_bounds__(256, 4) void k_chase(const uint4* __restrict__ tabl
 int main() {
     const int cus = 256, grid = cus * 4, steps = 512;
     uint32_t* d_out; CHECK(hipMalloc(&d_out, 4));
-    const char* names[3] = {"lane", "quad", "half"};
+    const char* names[4] = {"lane", "quad", "half", "wide"};
     for (uint32_t mb : {2u, 32u, 512u}) {
         const uint32_t n = mb * (1u << 20) / 64u;   // records
         std::vector<uint4> h((size_t)n * 4u);
@@ -62,15 +70,16 @@ int main() {
         uint4* d_t; CHECK(hipMalloc(&d_t, h.size() * 16u));
         CHECK(hipMemcpy(d_t, h.data(), h.size() * 16u, hipMemcpyHostToDevice));
         for (int sparse = 0; sparse < 2; ++sparse)
-            for (int mode = 0; mode < 3; ++mode) {
+            for (int mode = 0; mode < 4; ++mode) {
                 hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
                 float best = 1e30f;
                 for (int rep = 0; rep < 3; ++rep) {
                     CHECK(hipEventRecord(e0));
-                    const uint32_t m = mode == 2 ? 2u * n - 1u : n - 1u;
+                    const uint32_t m = mode == 2 ? 2u * n - 1u : (mode == 3 ? n / 2u - 1u : n - 1u);
                     if (mode == 0) hipLaunchKernelGGL(k_chase<0>, dim3(grid), dim3(256), 0, 0, d_t, m, steps, sparse, d_out);
                     else if (mode == 1) hipLaunchKernelGGL(k_chase<1>, dim3(grid), dim3(256), 0, 0, d_t, m, steps, sparse, d_out);
-                    else hipLaunchKernelGGL(k_chase<2>, dim3(grid), dim3(256), 0, 0, d_t, m, steps, sparse, d_out);
+                    else if (mode == 2) hipLaunchKernelGGL(k_chase<2>, dim3(grid), dim3(256), 0, 0, d_t, m, steps, sparse, d_out);
+                    else hipLaunchKernelGGL(k_chase<3>, dim3(grid), dim3(256), 0, 0, d_t, m, steps, sparse, d_out);
                     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
                     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
                     best = ms < best ? ms : best;

@@ -519,6 +519,9 @@ __global__ __launch_bounds__(64) void k_debug_bsdf(const DevScene scv, uint32_t 
 // ================================================================== host side of the device ABI
 #ifndef TR_HOST_EMU
 
+#ifndef WF_PIPES_MAX
+#define WF_PIPES_MAX 4   // views of the wavefront schedule (WfView below) the buffers are sized for
+#endif
 struct TrayDevBuf { const char* key; void* ptr; size_t bytes; };
 struct TrayDeviceScene {
     int device = 0;
@@ -558,6 +561,9 @@ struct TrayDeviceScene {
     bool narrow_trees = true;         // every node's offset fits a descriptor (host/gates.hpp): the wavefront traversal keeps nodes as descriptors
     uint32_t trace_lds_depth = 0, trace_lds_bytes = 0;   // LDS part of the dynamic-fetch kernel's stacks; deeper entries go to d_stack_overflow
     uint32_t* d_stack_overflow = nullptr;
+    size_t ovf_entries = 0;              // ... per view of the schedule (WF_PIPES_MAX of them)
+    hipStream_t wf_streams[WF_PIPES_MAX] = {nullptr, nullptr, nullptr, nullptr};   // streams of views 1.. (view 0 runs on the caller's), created on first use
+    hipEvent_t wf_fork = nullptr, wf_join[WF_PIPES_MAX] = {nullptr, nullptr, nullptr, nullptr};
     bool light_filter = false;        // a sphere light or specular lobes: the tile kernel with mis_ray_filter (dev_integrator.h) compiled in
     bool wf_sort = true;              // material sort of the shading stage (k_wf_begin's LDS counting sort -> k_wf_query_kind); off for textured scenes
     uint32_t* d_kind_queues = nullptr;   // WF_MAT_KINDS x n_slots slot indices
@@ -615,24 +621,40 @@ static int upload(TrayDeviceScene* s, const char* key, bool unchanged, const T* 
 // one round of the wavefront schedule: advance -> regen -> trace A -> begin -> trace B -> query -> trace C (compacted ray queues, persistent
 // traversal with dynamic fetch, kind-pure shading over the material sort's queues; scenes with textured materials, whose lobes
 // exist per hit only, shade unsorted in the one instantiation that lowers them)
+// A VIEW of the wavefront buffers: a range of the pool's chunks with queues, control words and overflow columns of its own. The schedule
+// runs WF_PIPES views, each on its own stream: every stage kernel ends with the tail of its slowest rays (trace C is nearly all
+// tail: a few thousand rays, ~600 us for the longest chain of dependent fetches), and while one view's kernel drains, the
+// workgroups it frees run the other view's kernels. The views share the tile counter, so the split does not unbalance them.
+struct WfView {
+    DevScene dev;       // the scene with xf_cache moved to the view's first slot
+    WfPool pool;        // data moved to the view's first slot, n_slots = the pool's stride, seg_cap of the view's chunks
+    WfChunk* chunks;
+    float* bins;
+    uint32_t *qa, *qb, *qc, *qr, *qctl, *kq, *overflow;
+    uint32_t n_chunks;
+    hipStream_t stream;
+};
 template <int ANIM>
-static void wf_round(TrayDeviceScene* s, dim3 grid, dim3 qgrid, dim3 tgrid, dim3 block, hipStream_t stream, const uint2* tiles, uint32_t tile_count, uint32_t chunk,
-                     uint32_t chunk_stride, uint32_t spp, uint32_t kf, float* rgbw_dev, uint32_t n_active, uint32_t* qa, uint32_t* qb, uint32_t* qc,
-                     uint32_t* qr, uint32_t* qctl) {
-    hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, s->dev, s->pool, s->d_chunks, s->d_bins, tiles, tile_count, chunk, chunk_stride,
-                       spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, qa, qr, qctl);
-    hipLaunchKernelGGL(k_wf_regen<ANIM>, qgrid, block, 0, stream, s->dev, s->pool, s->d_chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, qr, qa, qctl);
-    hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qa, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
-    uint32_t* const kq = s->wf_sort ? s->d_kind_queues : nullptr;
-    hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, s->dev, s->pool, n_active, s->d_stats, qb, qctl, kq);
-    hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qb, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
-    if (kq) {   // kind-pure shading over the sorted queues: one launch per material kind the scene contains
-#define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), qgrid, block, 0, stream, s->dev, s->pool, kq, qc, qctl, s->d_stats)
+static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride, uint32_t spp,
+                     uint32_t kf, float* rgbw_dev) {
+    const dim3 grid(v.n_chunks), block(TR_BLOCK);
+    const dim3 qgrid((v.n_chunks + WF_SEGS - 1u) / WF_SEGS * WF_SEGS);   // one-thread-per-entry kernels: block b reads segment b % WF_SEGS
+    const dim3 tgrid(std::min<uint32_t>(s->n_blocks_trace, v.n_chunks));
+    const uint32_t n_active = v.n_chunks * TR_BLOCK;
+    hipStream_t stream = v.stream;
+    hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, v.dev, v.pool, v.chunks, v.bins, tiles, tile_count, chunk, chunk_stride,
+                       spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, v.qa, v.qr, v.qctl);
+    hipLaunchKernelGGL(k_wf_regen<ANIM>, qgrid, block, 0, stream, v.dev, v.pool, v.chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, v.qr, v.qa, v.qctl);
+    hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qa, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow);
+    hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, v.dev, v.pool, n_active, s->d_stats, v.qb, v.qctl, v.kq);
+    hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qb, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow);
+    if (v.kq) {   // kind-pure shading over the sorted queues: one launch per material kind the scene contains
+#define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), qgrid, block, 0, stream, v.dev, v.pool, v.kq, v.qc, v.qctl, s->d_stats)
         WF_QUERY_KIND(TRAY_MAT_MATTE); WF_QUERY_KIND(TRAY_MAT_PLASTIC); WF_QUERY_KIND(TRAY_MAT_METAL); WF_QUERY_KIND(TRAY_MAT_GLASS);
         WF_QUERY_KIND(TRAY_MAT_ROUGH_GLASS); WF_QUERY_KIND(TRAY_MAT_SPECULAR_METAL); WF_QUERY_KIND(TRAY_MAT_MERL);
 #undef WF_QUERY_KIND
-    } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT_ALL | FEAT_TEX>), grid, block, 0, stream, s->dev, s->pool, n_active, qc, qctl, s->d_stats);
-    hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, s->dev, s->pool, qc, qctl, s->d_stats, s->trace_lds_depth, s->d_stack_overflow);
+    } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT_ALL | FEAT_TEX>), grid, block, 0, stream, v.dev, v.pool, n_active, v.qc, v.qctl, s->d_stats);
+    hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qc, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow);
 }
 
 // Path pool slots of the wavefront schedule: never more than the film has pixels x 4 (one chunk of 256 per tile), and for moving
@@ -678,6 +700,11 @@ void tray_scene_destroy(TrayDeviceScene* s) {
     (void)hipSetDevice(s->device);
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->h_done) (void)hipHostFree(s->h_done);
+    for (int k = 0; k < WF_PIPES_MAX; ++k) {
+        if (s->wf_streams[k]) (void)hipStreamDestroy(s->wf_streams[k]);
+        if (s->wf_join[k]) (void)hipEventDestroy(s->wf_join[k]);
+    }
+    if (s->wf_fork) (void)hipEventDestroy(s->wf_fork);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -1037,7 +1064,7 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         s->d_queues = donor->d_queues; s->d_kind_queues = donor->d_kind_queues; s->d_stack_overflow = donor->d_stack_overflow;
         s->h_done = donor->h_done; donor->h_done = nullptr;
         s->n_chunks = donor->n_chunks; s->n_blocks_trace = donor->n_blocks_trace; s->trace_lds_depth = donor->trace_lds_depth;
-        s->trace_lds_bytes = donor->trace_lds_bytes; s->wf_sort = donor->wf_sort;
+        s->trace_lds_bytes = donor->trace_lds_bytes; s->wf_sort = donor->wf_sort; s->ovf_entries = donor->ovf_entries;
         s->wf_ready = true;
         donor->wf_ready = false; donor->pool.data = nullptr;
     }
@@ -1097,11 +1124,14 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
         HIP_CHECK(hipMemset(s->d_bins, 0, (size_t)s->n_chunks * ROWBIN_SIZE * sizeof(float)));
         HIP_CHECK(hipMalloc(&p, 2 * sizeof(uint32_t)));
         s->allocs.push_back(p); s->d_wf_counters = static_cast<uint32_t*>(p);
-        HIP_CHECK(hipMalloc(&p, (4 * q_cap + WF_QCTL_WORDS) * sizeof(uint32_t)));   // ray queues A, B, C, regeneration queue, control words of their segments
+        // ray queues A, B, C, regeneration queue and the control words of their segments, for up to WF_PIPES_MAX views (a view's segments
+        // are sized for its own chunks: WF_SEGS * TR_BLOCK entries of rounding per view and queue)
+        const size_t q_slack = (size_t)WF_PIPES_MAX * WF_SEGS * TR_BLOCK;
+        HIP_CHECK(hipMalloc(&p, (4 * (q_cap + q_slack) + (size_t)WF_PIPES_MAX * WF_QCTL_WORDS) * sizeof(uint32_t)));
         s->allocs.push_back(p); s->d_queues = static_cast<uint32_t*>(p);
         s->wf_sort = !(s->feat & FEAT_TEX);   // the kind-pure kernels read lobes from the material table; textured materials have theirs per hit
         if (s->wf_sort) {   // shading queues of the material sort (slot indices), one per material kind
-            HIP_CHECK(hipMalloc(&p, (size_t)WF_MAT_KINDS * q_cap * sizeof(uint32_t)));
+            HIP_CHECK(hipMalloc(&p, (size_t)WF_MAT_KINDS * (q_cap + q_slack) * sizeof(uint32_t)));
             s->allocs.push_back(p); s->d_kind_queues = static_cast<uint32_t*>(p);
         }
         {
@@ -1119,8 +1149,9 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, 0>, TR_BLOCK, s->trace_lds_bytes);
             if (oe != hipSuccess || per_cu < 1) per_cu = 1;
             s->n_blocks_trace = (uint32_t)(cus * per_cu);
-            const size_t ovf_entries = (size_t)(full_depth - lds_depth + 1u) * s->n_blocks_trace * TR_BLOCK;
-            HIP_CHECK(hipMalloc(&p, ovf_entries * sizeof(uint32_t)));
+            const size_t ovf_entries = (size_t)(full_depth - lds_depth + 1u) * s->n_blocks_trace * TR_BLOCK;   // per view: their traversal kernels overlap
+            s->ovf_entries = ovf_entries;
+            HIP_CHECK(hipMalloc(&p, (size_t)WF_PIPES_MAX * ovf_entries * sizeof(uint32_t)));
             s->allocs.push_back(p); s->d_stack_overflow = static_cast<uint32_t*>(p);
             if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] dynamic-fetch traversal: %u of %u stack entries in LDS, %d workgroups per CU\n", lds_depth, full_depth, per_cu);
         }
@@ -1128,7 +1159,6 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
         s->wf_ready = true;
     }
     const uint32_t n_chunks = std::min(s->n_chunks, tile_count);
-    const uint32_t n_active = n_chunks * TR_BLOCK;
     HIP_CHECK(hipMemsetAsync(s->d_wf_counters, 0, 2 * sizeof(uint32_t), stream));
         {   // chunks start in WF_TILE_NEED with done = 0
         std::vector<WfChunk> init(n_chunks, WfChunk{WF_TILE_NEED, 0u});
@@ -1136,28 +1166,73 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
         HIP_CHECK(hipStreamSynchronize(stream));   // `init` is pageable host memory
     }
     HIP_CHECK(hipEventRecord(s->ev0, stream));
-    const dim3 grid(n_chunks), block(TR_BLOCK);
     const uint2* tiles = s->d_tiles + tile_start;
     uint32_t launches = 0;
-    const size_t q_cap = (size_t)WF_SEGS * s->pool.seg_cap;
-    uint32_t* const qa = s->d_queues, * const qb = qa + q_cap, * const qc = qb + q_cap, * const qr = qc + q_cap, * const qctl = qr + q_cap;
-    const dim3 qgrid((n_chunks + WF_SEGS - 1u) / WF_SEGS * WF_SEGS);   // one-thread-per-entry kernels: block b reads segment b % WF_SEGS
-    const dim3 tgrid(std::min<uint32_t>(s->n_blocks_trace, n_chunks));
+    // the views: equal shares of the chunks in use. Measured on the C5 stand-in at full detail (1 / 2 / 3 / 4 views): see DESIGN.md section 4
+    uint32_t n_views = 2u;
+    if (const char* e = getenv("TRAYHIP_WF_PIPES")) n_views = (uint32_t)std::max(1, std::min(WF_PIPES_MAX, atoi(e)));
+    n_views = std::max(1u, std::min(n_views, n_chunks / WF_SEGS));   // (a view of a few chunks would only add launches)
+    WfView views[WF_PIPES_MAX];
+    {
+        const size_t q_total = (size_t)WF_SEGS * s->pool.seg_cap + (size_t)WF_PIPES_MAX * WF_SEGS * TR_BLOCK;   // entries of one queue kind over all views
+        uint32_t* const qbase[4] = {s->d_queues, s->d_queues + q_total, s->d_queues + 2 * q_total, s->d_queues + 3 * q_total};
+        uint32_t* const qctl_base = s->d_queues + 4 * q_total;
+        size_t q_off = 0;
+        uint32_t c0 = 0;
+        for (uint32_t k = 0; k < n_views; ++k) {
+            const uint32_t c1 = (uint32_t)((uint64_t)n_chunks * (k + 1u) / n_views);
+            WfView& v = views[k];
+            v.n_chunks = c1 - c0;
+            v.dev = s->dev;
+            if (v.dev.xf_cache) v.dev.xf_cache += (size_t)c0 * TR_BLOCK * v.dev.n_moving * 24u;   // [slot][moving instance][24]
+            v.pool = s->pool;
+            v.pool.data += (size_t)c0 * TR_BLOCK;
+            v.pool.seg_cap = wf_seg_cap(v.n_chunks);
+            v.chunks = s->d_chunks + c0;
+            v.bins = s->d_bins + (size_t)c0 * ROWBIN_SIZE;
+            v.qa = qbase[0] + q_off; v.qb = qbase[1] + q_off; v.qc = qbase[2] + q_off; v.qr = qbase[3] + q_off;
+            v.qctl = qctl_base + (size_t)k * WF_QCTL_WORDS;
+            v.kq = s->wf_sort ? s->d_kind_queues + (size_t)WF_MAT_KINDS * q_off : nullptr;
+            v.overflow = s->d_stack_overflow + (size_t)k * s->ovf_entries;
+            v.stream = stream;
+            if (k > 0) {
+                if (!s->wf_streams[k]) HIP_CHECK(hipStreamCreateWithFlags(&s->wf_streams[k], hipStreamNonBlocking));
+                if (!s->wf_join[k]) HIP_CHECK(hipEventCreateWithFlags(&s->wf_join[k], hipEventDisableTiming));
+                v.stream = s->wf_streams[k];
+            }
+            q_off += (size_t)WF_SEGS * v.pool.seg_cap;
+            c0 = c1;
+        }
+        if (n_views > 1u) {   // the other views start after what this call has put on the caller's stream so far
+            if (!s->wf_fork) HIP_CHECK(hipEventCreateWithFlags(&s->wf_fork, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(s->wf_fork, stream));
+            for (uint32_t k = 1; k < n_views; ++k) HIP_CHECK(hipStreamWaitEvent(views[k].stream, s->wf_fork, 0));
+        }
+    }
     // every chunk needs at most (spp/4 rounded up) samples x (max_depth + 2) rounds per tile, plus one round per tile switch
     const uint64_t tiles_per_chunk = (tile_count + n_chunks - 1) / n_chunks;
     const uint64_t max_rounds = tiles_per_chunk * (((uint64_t)spp + 3) / 4 * (s->dev.max_depth + 3) + 4) + 2 * WF_POLL;
-    for (uint32_t round = 0;; ++round) {
-        HIP_CHECK(hipMemsetAsync(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), stream));
-        if (s->animated) wf_round<1>(s, grid, qgrid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qr, qctl);
-        else wf_round<0>(s, grid, qgrid, tgrid, block, stream, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, n_active, qa, qb, qc, qr, qctl);
-        launches += 7;
+    bool done = false;
+    for (uint32_t round = 0; !done; ++round) {
+        for (uint32_t k = 0; k < n_views; ++k) {
+            const WfView& v = views[k];
+            HIP_CHECK(hipMemsetAsync(v.qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), v.stream));
+            if (s->animated) wf_round<1>(s, v, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev);
+            else wf_round<0>(s, v, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev);
+            launches += 7;
+        }
         if (round % WF_POLL == WF_POLL - 1) {
             HIP_CHECK(hipGetLastError());
+            for (uint32_t k = 1; k < n_views; ++k) HIP_CHECK(hipStreamSynchronize(views[k].stream));
             HIP_CHECK(hipMemcpyAsync(s->h_done, s->d_wf_counters + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
-            if (*s->h_done >= tile_count) break;
+            done = *s->h_done >= tile_count;
         }
         if (round > max_rounds) { set_error("wavefront schedule did not terminate"); return TRAY_E_DEVICE; }
+    }
+    for (uint32_t k = 1; k < n_views; ++k) {   // (the polls above have synchronised them; this keeps the caller's stream ordered after them in any case)
+        HIP_CHECK(hipEventRecord(s->wf_join[k], views[k].stream));
+        HIP_CHECK(hipStreamWaitEvent(stream, s->wf_join[k], 0));
     }
     HIP_CHECK(hipEventRecord(s->ev1, stream));
     s->timing_valid = true;
@@ -1465,8 +1540,8 @@ int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t) {
             const unsigned long long* t = st.trav + g * 6;
             double tot = 0;
             for (int k = 0; k < 5; ++k) tot += (double)t[k];
-            if (tot > 0) fprintf(stderr, "[trayhip] trace %c wave cycles: refill %.1f %%  node phase %.1f %%  leaf phase %.1f %%  pop phase %.1f %%  result write %.1f %%\n", "ABC"[g],
-                                 100 * t[0] / tot, 100 * t[1] / tot, 100 * t[2] / tot, 100 * t[3] / tot, 100 * t[4] / tot);
+            if (tot > 0) fprintf(stderr, "[trayhip] trace %c wave cycles: refill %.1f %%  node phase %.1f %%  leaf phase %.1f %%  pop phase %.1f %%  result write %.1f %%  (%.3e clock64 ticks in all waves)\n", "ABC"[g],
+                                 100 * t[0] / tot, 100 * t[1] / tot, 100 * t[2] / tot, 100 * t[3] / tot, 100 * t[4] / tot, tot);
         }
 #else
     if (getenv("TRAYHIP_STATS") && st.rays)
