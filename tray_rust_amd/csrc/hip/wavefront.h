@@ -192,7 +192,9 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
 #define WF_POP(e) do { --sp; if ((uint32_t)sp < lds_depth) e = stack[sp * TR_BLOCK]; else e = ovf[(size_t)((uint32_t)sp - lds_depth) * ovf_stride]; } while (0)
     // pops node entries until one passes the box test of the moment (stored entry distance < max_t now) -- the lane goes on with it -- or
     // something else is on top (instance entry, end of a mesh: left for the pop phase) or the stack is empty; cheap (LDS), so it runs
-    // wherever a lane runs out of node work instead of sending the lane through the pop phase
+    // wherever a lane runs out of node work instead of sending the lane through the pop phase. (Leaving a mesh here as well -- the
+    // world ray back into o / d / inv_dir and the direction signs, inside the node loop -- was measured: C5 stand-in 102 -> 87 Msamples/s,
+    // profiles/r03_c5_inline_mesh_exit_ab.txt.)
 #define WF_POP_NODES() do {                                                                                                          \
         while (sp > 0) {                                                                                                             \
             uint32_t e_, t_;                                                                                                         \
