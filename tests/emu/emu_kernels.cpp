@@ -458,4 +458,19 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
 
 }  // extern "C"
 
+// The device order of the trees and the wavefront traversal's instance records, as tray_scene_create uploads them (host/gates.hpp), for
+// tests/test_device_tree_order.py. Two calls: with null outputs the counts come back (top nodes, mesh nodes, meshes, records).
+extern "C" int emu_device_trees(const TrayFlatScene* f, uint32_t* counts, TrayBvhNode* top, TrayBvhNode* mesh, TrayMesh* meshes, void* wf_insts, int* narrow) {
+    tray::PairedTrees p;
+    if (!tray::pair_trees(f, p)) return 1;
+    std::vector<tray::WfInst> recs;
+    tray::wf_inst_records(f, p.meshes, recs);
+    counts[0] = (uint32_t)p.top.size(); counts[1] = (uint32_t)p.mesh.size(); counts[2] = (uint32_t)p.meshes.size(); counts[3] = (uint32_t)recs.size();
+    if (top) std::memcpy(top, p.top.data(), p.top.size() * sizeof(TrayBvhNode));
+    if (mesh) std::memcpy(mesh, p.mesh.data(), p.mesh.size() * sizeof(TrayBvhNode));
+    if (meshes) std::memcpy(meshes, p.meshes.data(), p.meshes.size() * sizeof(TrayMesh));
+    if (wf_insts) std::memcpy(wf_insts, recs.data(), recs.size() * sizeof(tray::WfInst));
+    if (narrow) *narrow = p.narrow ? 1 : 0;
+    return 0;
+}
 extern "C" unsigned emu_retraced(void) { const unsigned r = g_retraced; g_retraced = 0; return r; }
