@@ -312,6 +312,30 @@ def test_wavefront_schedule_matches_the_oracle(name, tmp_path, monkeypatch):
     assert rmse(gpu, cpu) < 1e-4
 
 
+def test_wavefront_views_render_the_same_frame(tmp_path, monkeypatch):
+    """The wavefront schedule runs as 1 .. 3 views of the pool's chunks on as many streams (TRAYHIP_WF_PIPES; queues, control words,
+    stack overflow columns and the window of the per-path transform cache are per view): same samples, same vertices, the same image
+    up to the order of the film's f32 sums -- on a moving scene, whose transform cache is indexed by pool slot."""
+    monkeypatch.setenv("TRAYHIP_MODE", "wave")
+    monkeypatch.setenv("TRAYHIP_WF_SLOTS", "65536")
+    scene, rt, _, fi = T.Scene.load_file(scenes.write_moving_box(str(tmp_path), width=128, height=128, samples=32))
+    images, timings = [], []
+    for pipes in ("1", "2", "3"):
+        monkeypatch.setenv("TRAYHIP_WF_PIPES", pipes)
+        rt.clear()
+        hip = T.Hip(0, seed=9)
+        hip.render(scene, rt, _config_at(fi, 0, 32))
+        images.append(rt.get_renderf32().reshape(rt.height, rt.width, 4).copy()); timings.append(hip.last_timing)
+        scene.release_device()
+    assert timings[1].launches == 2 * timings[0].launches and timings[2].launches == 3 * timings[0].launches   # (256 tiles: every view has its 64 chunks)
+    for img, tim in zip(images[1:], timings[1:]):
+        assert tim.samples == timings[0].samples and tim.vertices == timings[0].vertices and tim.rays == timings[0].rays
+        assert np.abs(img - images[0]).max() <= 2e-5 * max(1.0, float(np.abs(images[0]).max()))
+    cpu, st = O.render_tiles(scene.flatten(0), 32, seed=9)
+    assert timings[0].samples == st.samples
+    assert rmse(images[1], cpu) < 1e-4
+
+
 # ---- moving scenes (SURVEY 8f rank 1): per-ray spline evaluation, animated emission and camera ----
 @pytest.fixture(scope="module")
 def moving(tmp_path_factory):
