@@ -305,7 +305,10 @@ void tray_scene_destroy(TrayDeviceScene* s);
 /* tile_count == 0 selects the whole queue whatever tile_start is (BlockQueue::new, block_queue.rs:39-41).
  * ONE render may be in flight per TrayDeviceScene: the tile counter, the statistics, the per-path transform cache, the wavefront
  * pool and queues and the timing events belong to the handle. Calls on one handle must be serialised by the caller (the
- * reference blocks inside Exec::render too, multithreaded.rs:54-70); use one handle per stream for concurrent renders. */
+ * reference blocks inside Exec::render too, multithreaded.rs:54-70); use one handle per stream for concurrent renders.
+ * Scenes that traverse BVH<Instance> (more than 16 instances) run the wavefront schedule: it polls for completion (the call
+ * returns when the tiles are done), uses one internal stream beside `stream` (forked from and joined back to it with events) and
+ * returns TRAY_E_UNSUPPORTED for a mesh of more than 8 388 607 BVH nodes or triangles (its traversal keeps a node as a 32-bit word). */
 int tray_render_tiles_device(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count,
                              uint32_t spp, uint64_t seed, float* rgbw_dev, void* stream);
 
