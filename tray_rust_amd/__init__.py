@@ -7,6 +7,8 @@ behaviour follow /root/reference):
     FrameInfo, Config                                           src/film/mod.rs:19-36, src/exec/mod.rs:17-38
     Hip().render(scene, rt, config)                             trait Exec, src/exec/mod.rs:41-49
     RenderTarget.get_renderf32 / get_render / clear             src/film/render_target.rs:168-266
+    RenderTarget.get_rendered_blocks / add_blocks               src/film/render_target.rs:215-241, src/film/image.rs:36-50
+    distrib.worker_node(Hip()) / `python -m tray_rust_amd --worker`   src/exec/distrib/worker.rs, src/main.rs:148-166
     BlockQueue(img, dim, select_blocks)                         src/sampler/block_queue.rs:11-66
 
 Everything below the Python layer is libtrayhip.so (include/trayhip.h): a C++ scene loader and
@@ -95,6 +97,29 @@ class RenderTarget:
 
     def get_renderf32(self):
         return self.pixels.copy()
+
+    lock_size = (2, 2)   # the reference's lock blocks, hard-coded by its loader (scene.rs:224)
+
+    def get_rendered_blocks(self):
+        """render_target.rs:215-241: (block size, positions in pixels of the 2x2 blocks whose FOUR pixels all have a non-zero
+        weight, their RGBW one block after the other) -- what a distributed worker sends to the master. Blocks in row order,
+        pixels row-major inside a block. (A block with an untouched pixel is left out whole, as in the reference.)"""
+        bw, bh = self.lock_size
+        xb, yb = self.width // bw, self.height // bh
+        img = self.pixels.reshape(self.height, self.width, 4)[:yb * bh, :xb * bw]
+        tiles = img.reshape(yb, bh, xb, bw, 4).transpose(0, 2, 1, 3, 4)          # [by][bx][y][x][rgbw]
+        full = (tiles[..., 3] != 0.0).all(axis=(2, 3))
+        by, bx = np.nonzero(full)
+        blocks = np.stack([bx * bw, by * bh], axis=1).astype(np.uint64)
+        return (bw, bh), blocks, np.ascontiguousarray(tiles[by, bx]).reshape(-1)
+
+    def add_blocks(self, block_size, blocks, pixels):
+        """film::Image::add_blocks (src/film/image.rs:36-50): what the master does with a worker's blocks"""
+        bw, bh = int(block_size[0]), int(block_size[1])
+        img = self.pixels.reshape(self.height, self.width, 4)
+        px = np.asarray(pixels, dtype=np.float32).reshape(-1, bh, bw, 4)
+        for k, (x, y) in enumerate(np.asarray(blocks, dtype=np.int64).reshape(-1, 2)):
+            img[y:y + bh, x:x + bw] += px[k]
 
     def get_render(self):
         """sRGB8, 3 bytes per pixel (render_target.rs:185-210)."""
