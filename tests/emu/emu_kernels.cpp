@@ -254,12 +254,13 @@ int emu_wf_trace(const TrayFlatScene* f, int stage, uint32_t n, const TrayRay* r
     const uint32_t n_slots = (n + TR_BLOCK - 1) / TR_BLOCK * TR_BLOCK;
     std::vector<float> pool_data((size_t)F_COUNT * n_slots, 0.0f);
     WfPool pool{pool_data.data(), n_slots, wf_seg_cap(n_slots / TR_BLOCK)};
-    std::vector<uint32_t> queue((size_t)WF_SEGS * pool.seg_cap), qctl(WF_QCTL_WORDS, 0u);
+    std::vector<uint32_t> queue((size_t)WF_SEGS * pool.seg_cap * WF_RAY_WORDS), qctl(WF_QCTL_WORDS, 0u);
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t s = n - 1u - i;   // any order inside a segment: slots keep their place, only indices travel
         const uint32_t seg = (s / TR_BLOCK) & (WF_SEGS - 1u);   // the segment of the slot's chunk (wavefront.h)
-        queue[(size_t)seg * pool.seg_cap + qctl[seg * WF_SEG_STRIDE + stage]++] = s;
         const f3 o = mk(rays[s].o[0], rays[s].o[1], rays[s].o[2]), dd = mk(rays[s].d[0], rays[s].d[1], rays[s].d[2]);
+        wf_put_ray(queue.data(), (size_t)seg * pool.seg_cap + qctl[seg * WF_SEG_STRIDE + stage]++, s, o, dd,
+                   LF_ALIVE | (stage == 0 && rays[s].min_t == 0.0f ? WF_CAMERA_RAY : 0u));   // an entry of a ray queue is the ray (wavefront.h)
         if (stage == 0) { st3(pool, F_O, s, o); st3(pool, F_D, s, dd); pu(pool, F_BOUNCE, s) = rays[s].min_t == 0.0f ? 0u : 1u; }
         else { st3(pool, F_P, s, o); st3(pool, F_AUX, s, dd); }
         pu(pool, F_FLAGS, s) = LF_ALIVE;
@@ -389,8 +390,8 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     std::vector<float> bins((size_t)n_chunks * ROWBIN_SIZE, 0.0f);
     const size_t q_cap = (size_t)WF_SEGS * pool.seg_cap;
     const uint32_t q_blocks = (n_chunks + WF_SEGS - 1u) / WF_SEGS * WF_SEGS;   // grid of the one-thread-per-entry kernels (launch_wavefront)
-    std::vector<uint32_t> queues(4 * q_cap + WF_QCTL_WORDS, 0u);
-    uint32_t* const qa = queues.data(), * const qb = qa + q_cap, * const qc = qb + q_cap, * const qr = qc + q_cap, * const qctl = qr + q_cap;
+    std::vector<uint32_t> queues((3 * WF_RAY_WORDS + 1) * q_cap + WF_QCTL_WORDS, 0u);   // ray queues A, B, C (the rays themselves), regeneration queue (slot indices)
+    uint32_t* const qa = queues.data(), * const qb = qa + WF_RAY_WORDS * q_cap, * const qc = qb + WF_RAY_WORDS * q_cap, * const qr = qc + WF_RAY_WORDS * q_cap, * const qctl = qr + q_cap;
     uint32_t counters[2] = {0u, 0u};
     std::vector<DevStats> stats(WF_STAT_SLOTS);
     std::memset(stats.data(), 0, stats.size() * sizeof(DevStats));

@@ -1127,7 +1127,8 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
         // ray queues A, B, C, regeneration queue and the control words of their segments, for up to WF_PIPES_MAX views (a view's segments
         // are sized for its own chunks: WF_SEGS * TR_BLOCK entries of rounding per view and queue)
         const size_t q_slack = (size_t)WF_PIPES_MAX * WF_SEGS * TR_BLOCK;
-        HIP_CHECK(hipMalloc(&p, (4 * (q_cap + q_slack) + (size_t)WF_PIPES_MAX * WF_QCTL_WORDS) * sizeof(uint32_t)));
+        // (an entry of a ray queue is the ray: WF_RAY_WORDS words; the regeneration queue holds slot indices)
+        HIP_CHECK(hipMalloc(&p, ((3 * WF_RAY_WORDS + 1) * (q_cap + q_slack) + (size_t)WF_PIPES_MAX * WF_QCTL_WORDS) * sizeof(uint32_t)));
         s->allocs.push_back(p); s->d_queues = static_cast<uint32_t*>(p);
         s->wf_sort = !(s->feat & FEAT_TEX);   // the kind-pure kernels read lobes from the material table; textured materials have theirs per hit
         if (s->wf_sort) {   // shading queues of the material sort (slot indices), one per material kind
@@ -1175,8 +1176,8 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     WfView views[WF_PIPES_MAX];
     {
         const size_t q_total = (size_t)WF_SEGS * s->pool.seg_cap + (size_t)WF_PIPES_MAX * WF_SEGS * TR_BLOCK;   // entries of one queue kind over all views
-        uint32_t* const qbase[4] = {s->d_queues, s->d_queues + q_total, s->d_queues + 2 * q_total, s->d_queues + 3 * q_total};
-        uint32_t* const qctl_base = s->d_queues + 4 * q_total;
+        uint32_t* const qbase[4] = {s->d_queues, s->d_queues + WF_RAY_WORDS * q_total, s->d_queues + 2 * WF_RAY_WORDS * q_total, s->d_queues + 3 * WF_RAY_WORDS * q_total};
+        uint32_t* const qctl_base = qbase[3] + q_total;
         size_t q_off = 0;
         uint32_t c0 = 0;
         for (uint32_t k = 0; k < n_views; ++k) {
@@ -1190,7 +1191,7 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             v.pool.seg_cap = wf_seg_cap(v.n_chunks);
             v.chunks = s->d_chunks + c0;
             v.bins = s->d_bins + (size_t)c0 * ROWBIN_SIZE;
-            v.qa = qbase[0] + q_off; v.qb = qbase[1] + q_off; v.qc = qbase[2] + q_off; v.qr = qbase[3] + q_off;
+            v.qa = qbase[0] + WF_RAY_WORDS * q_off; v.qb = qbase[1] + WF_RAY_WORDS * q_off; v.qc = qbase[2] + WF_RAY_WORDS * q_off; v.qr = qbase[3] + q_off;
             v.qctl = qctl_base + (size_t)k * WF_QCTL_WORDS;
             v.kq = s->wf_sort ? s->d_kind_queues + (size_t)WF_MAT_KINDS * q_off : nullptr;
             v.overflow = s->d_stack_overflow + (size_t)k * s->ovf_entries;

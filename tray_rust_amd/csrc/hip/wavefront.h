@@ -94,6 +94,28 @@ __host__ __device__ inline
 #endif
 uint32_t wf_seg_cap(uint32_t n_chunks) { return (n_chunks + WF_SEGS - 1u) / WF_SEGS * TR_BLOCK; }
 TR_DEV uint32_t wf_my_seg() { return blockIdx.x & (WF_SEGS - 1u); }
+// An entry of a RAY queue (A, B, C) is the ray itself: 8 words = slot, origin, direction, the slot's F_FLAGS word as the producer
+// left it (bit 31: a camera ray, min_t = 0). The traversal kernel's refill is then ONE coalesced fetch after its atomic (64 lanes,
+// 64 consecutive 32-byte records) instead of entry -> seven fields scattered over the pool, and its result write needs no read
+// of the flags. The regeneration queue and the material kinds' shading queues hold slot indices only.
+#define WF_RAY_WORDS 8u
+enum : uint32_t { WF_CAMERA_RAY = 1u << 31 };
+TR_DEV void wf_put_ray(uint32_t* __restrict__ queue, size_t pos, uint32_t slot, f3 o, f3 d, uint32_t flags) {
+    uint4* __restrict__ r = reinterpret_cast<uint4*>(queue + pos * WF_RAY_WORDS);
+    r[0] = make_uint4(slot, __float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z));
+    r[1] = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), flags);
+}
+TR_DEV void wf_enqueue_ray(const WfPool& pool, uint32_t* __restrict__ queue, uint32_t* __restrict__ qctl, uint32_t k, bool want, uint32_t slot, f3 o, f3 d, uint32_t flags) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+    const uint32_t seg = blockIdx.x & (WF_SEGS - 1u);
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(qctl + seg * WF_SEG_STRIDE + k, (uint32_t)__popcll(m));
+    base = __shfl(base, (int)leader);
+    if (want) wf_put_ray(queue, (size_t)seg * pool.seg_cap + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), slot, o, d, flags);
+}
 TR_DEV void wf_enqueue(const WfPool& pool, uint32_t* __restrict__ queue, uint32_t* __restrict__ qctl, uint32_t k, bool want, uint32_t slot) {
     const unsigned long long m = __ballot(want);
     if (m == 0ull) return;
@@ -112,8 +134,8 @@ TR_DEV void wf_enqueue(const WfPool& pool, uint32_t* __restrict__ queue, uint32_
 #define WF_SORT_KEYS 8u     // direction octant (adding the origin's octant of the scene box as 3 more key bits measured the same: 82.3 vs 82.2 Msamples/s)
 TR_DEV uint32_t wf_octant(f3 d) { return (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u); }
 #ifndef WF_NO_OCTANT_SORT
-TR_DEV void wf_enqueue_by_key(const WfPool& pool, uint32_t* __restrict__ queue, uint32_t* __restrict__ qctl, uint32_t k, bool want, uint32_t slot, uint32_t key,
-                              uint32_t* s_cnt /* WF_SORT_KEYS */, uint32_t* s_base /* WF_SORT_KEYS */) {
+TR_DEV void wf_enqueue_ray_by_key(const WfPool& pool, uint32_t* __restrict__ queue, uint32_t* __restrict__ qctl, uint32_t k, bool want, uint32_t slot, f3 o, f3 d,
+                                  uint32_t flags, uint32_t key, uint32_t* s_cnt /* WF_SORT_KEYS */, uint32_t* s_base /* WF_SORT_KEYS */) {
     if (threadIdx.x < WF_SORT_KEYS) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t rank = 0u;
@@ -126,7 +148,7 @@ TR_DEV void wf_enqueue_by_key(const WfPool& pool, uint32_t* __restrict__ queue, 
         for (uint32_t b = 0; b < WF_SORT_KEYS; ++b) s_base[b] += base;
     }
     __syncthreads();
-    if (want) queue[(size_t)wf_my_seg() * pool.seg_cap + s_base[key & (WF_SORT_KEYS - 1u)] + rank] = slot;
+    if (want) wf_put_ray(queue, (size_t)wf_my_seg() * pool.seg_cap + s_base[key & (WF_SORT_KEYS - 1u)] + rank, slot, o, d, flags);
 }
 #endif
 // one thread per queue entry: the entry this thread owns, or false
@@ -207,7 +229,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
     const uint32_t lane = threadIdx.x & 63u;
     const bool any_hit = STAGE == 1;
     bool active = false;
-    uint32_t slot = 0u, n_rays = 0u;
+    uint32_t slot = 0u, n_rays = 0u, ray_flags = 0u;
     // the queue segment this wave draws from; it moves on (cyclically, to the next segment that still has entries) when the
     // segment is drained, so the cursor atomics of the 4 x tgrid waves are spread over WF_SEGS counters
     uint32_t seg_cnt = 0u;
@@ -251,14 +273,14 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                 if (!active) {
                     const uint32_t q = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                     if (q < seg_cnt) {
-                        slot = queue[(size_t)seg * pool.seg_cap + q];
-                        if (STAGE == 0) {
-                            wo = ld3(pool, F_O, slot); wd = ld3(pool, F_D, slot);
-                            min_t = pu(pool, F_BOUNCE, slot) == 0u ? 0.0f : 0.001f; max_t = TR_INF;
-                        } else {
-                            wo = ld3(pool, F_P, slot); wd = ld3(pool, F_AUX, slot);
-                            min_t = 0.001f; max_t = STAGE == 1 ? 0.999f : TR_INF;
-                        }
+                        const uint4* __restrict__ rr = reinterpret_cast<const uint4*>(queue + ((size_t)seg * pool.seg_cap + q) * WF_RAY_WORDS);
+                        const uint4 r0 = rr[0], r1 = rr[1];   // the ray record (wf_put_ray)
+                        slot = r0.x;
+                        wo = mk(__uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
+                        wd = mk(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z));
+                        ray_flags = r1.w & ~WF_CAMERA_RAY;
+                        if (STAGE == 0) { min_t = (r1.w & WF_CAMERA_RAY) ? 0.0f : 0.001f; max_t = TR_INF; }
+                        else { min_t = 0.001f; max_t = STAGE == 1 ? 0.999f : TR_INF; }
                         o = wo; d = wd;
                         inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                         nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
@@ -421,7 +443,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
         }
         WF_CLK(3);
         if (finished) {   // write the result to the ray's own slot
-            uint32_t flags = pu(pool, F_FLAGS, slot);
+            uint32_t flags = ray_flags;   // (the slot's F_FLAGS, brought by the ray: nobody else touches the slot while its ray is traced)
             if (STAGE == 1) {
                 flags = any ? (flags | WF_OCCLUDED) : (flags & ~WF_OCCLUDED);
             } else {
@@ -471,6 +493,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
     __shared__ uint32_t s_cnt[8], s_base[8];
     __shared__ uint32_t s_oct_cnt[WF_SORT_KEYS], s_oct_base[WF_SORT_KEYS];
     uint32_t b_oct = 0u;   // direction octant of the slot's occlusion ray
+    f3 b_o = mk(0.0f, 0.0f, 0.0f), b_d = b_o;   // ... and the ray
     const DevScene& sc = scv;
     const uint32_t tid = threadIdx.x;
     const uint32_t i = blockIdx.x * TR_BLOCK + tid;
@@ -526,7 +549,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
         st3(pool, F_WO, i, -ln.d);
         pu(pool, F_LINST, i) = ln.light_inst;
         st3(pool, F_LI, i, ln.li); st3(pool, F_WL, i, ln.wi_l); pf(pool, F_PDFL, i) = ln.pdf_l;
-        if (ln.flags & LF_SHADOW) { st3(pool, F_AUX, i, ln.aux_d); b_oct = wf_octant(ln.aux_d); }
+        if (ln.flags & LF_SHADOW) { st3(pool, F_AUX, i, ln.aux_d); b_oct = wf_octant(ln.aux_d); b_o = ln.bsdf.p; b_d = ln.aux_d; }
         st3(pool, F_DIRECT, i, ln.direct);
         st3(pool, F_TV, i, ln.t_vertex);
         flags = ln.flags;
@@ -541,9 +564,9 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
         }
     }
 #ifndef WF_NO_OCTANT_SORT
-    if (queue_b) wf_enqueue_by_key(pool, queue_b, qctl, 1u, kind < WF_MAT_KINDS && (flags & LF_SHADOW) != 0u, i, b_oct, s_oct_cnt, s_oct_base);
+    if (queue_b) wf_enqueue_ray_by_key(pool, queue_b, qctl, 1u, kind < WF_MAT_KINDS && (flags & LF_SHADOW) != 0u, i, b_o, b_d, flags | WF_INVERTEX, b_oct, s_oct_cnt, s_oct_base);
 #else
-    if (queue_b) wf_enqueue(pool, queue_b, qctl, 1u, kind < WF_MAT_KINDS && (flags & LF_SHADOW) != 0u, i);
+    if (queue_b) wf_enqueue_ray(pool, queue_b, qctl, 1u, kind < WF_MAT_KINDS && (flags & LF_SHADOW) != 0u, i, b_o, b_d, flags | WF_INVERTEX);
 #endif
     if (kind_queues) {
         uint32_t rank = 0u;
@@ -596,7 +619,7 @@ TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, ui
         if (!cont) f2 = (f2 & ~LF_ALIVE) | WF_FINISHED;
         pu(pool, F_FLAGS, i) = f2;
     }
-    if (queue_c) wf_enqueue(pool, queue_c, qctl, 2u, (ln.flags & LF_MIS) != 0u, i);
+    if (queue_c) wf_enqueue_ray(pool, queue_c, qctl, 2u, (ln.flags & LF_MIS) != 0u, i, ln.bsdf.p, ln.aux_d, ln.flags);
 }
 
 // one thread per pool slot, every material kind's code: scenes with textured materials (their lobes exist per hit only, so there is no table to sort by)
@@ -626,7 +649,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query_kind(const DevScene scv, 
 // New camera sample for pool slot i of a chunk that works on tile `tile_idx` (multithreaded.rs:90-96)
 template <int ANIM>
 TR_DEV void wf_regenerate(const DevScene& sc, const WfPool& pool, uint32_t i, uint32_t tile_idx, const uint2* __restrict__ tiles, uint32_t chunk,
-                          uint32_t chunk_stride, uint32_t spp, uint32_t kf, DevStats* __restrict__ stats) {
+                          uint32_t chunk_stride, uint32_t spp, uint32_t kf, DevStats* __restrict__ stats, f3& ray_o, f3& ray_d) {
     // F_SNEXT: the (pixel, sample) pair k_wf_advance handed to this slot: pixel = pair % 64 in Region order, sample = pair / 64
     const uint32_t pair = pu(pool, F_SNEXT, i), pix = pair & 63u, s_next = pair >> 6;
     const uint2 tile = tiles[(tile_idx / chunk) * chunk_stride * chunk + (tile_idx % chunk)];
@@ -640,6 +663,7 @@ TR_DEV void wf_regenerate(const DevScene& sc, const WfPool& pool, uint32_t i, ui
     pu(pool, F_KS, i) = key_sample(kp, s_next);
     pf(pool, F_SX, i) = sx; pf(pool, F_SY, i) = sy;
     st3(pool, F_O, i, cam.o); st3(pool, F_D, i, cam.d);
+    ray_o = cam.o; ray_d = cam.d;
     st3(pool, F_T, i, mk(1.0f, 1.0f, 1.0f)); st3(pool, F_ILLUM, i, mk(0.0f, 0.0f, 0.0f));
     const unsigned long long m = __ballot(1);
     if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].samples, (unsigned long long)__popcll(m));
@@ -653,9 +677,10 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_regen(const DevScene scv, WfPoo
     const DevScene& sc = scv;
     uint32_t i;
     if (!wf_my_entry(pool, queue_r, qctl, 6u, i)) return;
-    wf_regenerate<ANIM>(sc, pool, i, chunks[i / TR_BLOCK].tile, tiles, chunk, chunk_stride, spp, kf, stats);
+    f3 ray_o, ray_d;
+    wf_regenerate<ANIM>(sc, pool, i, chunks[i / TR_BLOCK].tile, tiles, chunk, chunk_stride, spp, kf, stats, ray_o, ray_d);
     pu(pool, F_FLAGS, i) = LF_ALIVE;
-    wf_enqueue(pool, queue_a, qctl, 0u, true, i);
+    wf_enqueue_ray(pool, queue_a, qctl, 0u, true, i, ray_o, ray_d, LF_ALIVE | WF_CAMERA_RAY);
 }
 
 // Round head, one workgroup per chunk: vertex_end of the previous round, film splat of finished samples,
@@ -797,11 +822,19 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
 #ifndef WF_NO_OCTANT_SORT
     {   // the continuation rays of this chunk, grouped by direction octant
         const bool cont_ray = (flags & LF_ALIVE) != 0u;
-        const uint32_t oct = cont_ray ? wf_octant(ld3(pool, F_D, i)) : 0u;
-        wf_enqueue_by_key(pool, queue_a, qctl, 0u, cont_ray, i, oct, s_oct_cnt, s_oct_base);
+        f3 ro = mk(0.0f, 0.0f, 0.0f), rd = ro;
+        uint32_t rf = flags;
+        if (cont_ray) { ro = ld3(pool, F_O, i); rd = ld3(pool, F_D, i); if (pu(pool, F_BOUNCE, i) == 0u) rf |= WF_CAMERA_RAY; }
+        wf_enqueue_ray_by_key(pool, queue_a, qctl, 0u, cont_ray, i, ro, rd, rf, cont_ray ? wf_octant(rd) : 0u, s_oct_cnt, s_oct_base);
     }
 #else
-    wf_enqueue(pool, queue_a, qctl, 0u, (flags & LF_ALIVE) != 0u, i);
+    {
+        const bool cont_ray = (flags & LF_ALIVE) != 0u;
+        f3 ro = mk(0.0f, 0.0f, 0.0f), rd = ro;
+        uint32_t rf = flags;
+        if (cont_ray) { ro = ld3(pool, F_O, i); rd = ld3(pool, F_D, i); if (pu(pool, F_BOUNCE, i) == 0u) rf |= WF_CAMERA_RAY; }
+        wf_enqueue_ray(pool, queue_a, qctl, 0u, cont_ray, i, ro, rd, rf);
+    }
 #endif
     __syncthreads();   // every wave has taken its pairs
     if (tid == 0) { chunks[c].tile = s_tile; chunks[c].done = s_done; chunks[c].next_pair = s_pair < 64u * spp ? s_pair : 64u * spp; }
