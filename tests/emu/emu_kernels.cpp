@@ -72,6 +72,7 @@ namespace trayh { void set_error(const std::string&) {} }
 namespace {
 
 uint32_t g_retraced = 0;   // accumulated over the calls of this process; read and reset by emu_retraced()
+uint32_t g_wf_deferred = 0;   // rays k_wf_trace_dyn handed to k_wf_trace_fallback; read and reset by emu_wf_deferred()
 
 struct EmuScene {
     DevScene d{};
@@ -80,10 +81,13 @@ struct EmuScene {
     std::vector<tray::FlatInst> flat_insts;
     std::vector<uint8_t> tri_leaf;
     tray::PairedTrees paired;   // the trees in device order, as tray_scene_create uploads them
+    tray::QuadTrees quads;      // ... and as the wavefront traversal's 128-byte records
+    std::vector<tray::QuadNode> all_quads;
     std::vector<tray::WfInst> wf_insts;
     std::vector<uint8_t> perm_pool;
     uint32_t retraced = 0;   // rays the flat loop handed to trace_bvh
     uint32_t depth = 0;   // traversal stack entries per lane, as tray_scene_create sizes them (two-level worst case, generous)
+    uint32_t quad_words = 0;   // stack words per lane of the wavefront traversal (node entries are two words, up to three per record)
 };
 
 uint32_t bvh_depth(const TrayBvhNode* nodes, uint32_t n) {
@@ -104,7 +108,11 @@ void make_scene(const TrayFlatScene* f, EmuScene& e) {
     if (!tray::pair_trees(f, e.paired)) throw std::runtime_error("BVH arrays do not describe trees");
     d.instances = f->instances; d.top_nodes = e.paired.top.data(); d.top_order = f->top_order; d.meshes = e.paired.meshes.data();
     d.mesh_nodes = e.paired.mesh.data(); d.tri_verts = f->tri_verts; d.tri_attrs = f->tri_attrs;
-    tray::wf_inst_records(f, e.paired.meshes, e.wf_insts);
+    tray::quad_trees(f, e.quads);
+    e.all_quads = e.quads.mesh;   // one buffer, as tray_scene_create uploads it: the BVH<Triangle>s, then BVH<Instance>
+    e.all_quads.insert(e.all_quads.end(), e.quads.top.begin(), e.quads.top.end());
+    d.quads = reinterpret_cast<const float4*>(e.all_quads.data()); d.top_quad_first = (uint32_t)e.quads.mesh.size();
+    tray::wf_inst_records(f, e.quads.mesh_first, e.wf_insts);
     d.wf_insts = e.wf_insts.data();
     e.mats.resize(f->n_materials);
     for (uint32_t i = 0; i < f->n_materials; ++i) e.mats[i] = lower_material(f->materials[i], f->merl_tables);
@@ -127,6 +135,7 @@ void make_scene(const TrayFlatScene* f, EmuScene& e) {
     uint32_t mesh_depth = 0;
     for (uint32_t m = 0; m < f->n_meshes; ++m) mesh_depth = std::max(mesh_depth, bvh_depth(f->mesh_nodes + f->meshes[m].node_offset, f->meshes[m].node_count));
     e.depth = mesh_depth + bvh_depth(f->top_nodes, f->n_top_nodes) + 8u;
+    e.quad_words = 2u * (e.quads.top_pend + e.quads.mesh_pend) + 34u;
 }
 
 using hip_emu::launch;
@@ -265,14 +274,18 @@ int emu_wf_trace(const TrayFlatScene* f, int stage, uint32_t n, const TrayRay* r
         else { st3(pool, F_P, s, o); st3(pool, F_AUX, s, dd); }
         pu(pool, F_FLAGS, s) = LF_ALIVE;
     }
-    const uint32_t full = e.depth;
+    const uint32_t full = e.quad_words;
     if (lds_depth == 0 || lds_depth > full) lds_depth = full;
-    std::vector<uint32_t> overflow((size_t)(8u * e.depth + 64u) * blocks * TR_BLOCK, 0u);
+    std::vector<uint32_t> overflow((size_t)(full + 64u) * blocks * TR_BLOCK, 0u);
+    std::vector<uint32_t> fallback(n_slots, 0u);
     std::vector<DevStats> stats(WF_STAT_SLOTS);
     std::memset(stats.data(), 0, stats.size() * sizeof(DevStats));
-#define EMU_TRACE(K, S) launch(blocks, TR_BLOCK, [&] { K<S, 0>(e.d, pool, queue.data(), qctl.data(), stats.data(), lds_depth, overflow.data()); })
-    if (stage == 0) EMU_TRACE(k_wf_trace_dyn, 0); else if (stage == 1) EMU_TRACE(k_wf_trace_dyn, 1); else EMU_TRACE(k_wf_trace_dyn, 2);
+    // (the traversal, then the rays it handed to the reference's binary traversal: wf_round of kernels.hip)
+#define EMU_TRACE(S) do { launch(blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, 0>(e.d, pool, queue.data(), qctl.data(), stats.data(), lds_depth, overflow.data(), fallback.data()); }); \
+                          launch(2, TR_BLOCK, [&] { k_wf_trace_fallback<S, 0>(e.d, pool, qctl.data(), fallback.data()); }); } while (0)
+    if (stage == 0) EMU_TRACE(0); else if (stage == 1) EMU_TRACE(1); else EMU_TRACE(2);
 #undef EMU_TRACE
+    g_wf_deferred += qctl[WF_FB_WORD + stage];
     for (uint32_t s = 0; s < n; ++s) {
         const uint32_t fl = pu(pool, F_FLAGS, s);
         hit[s] = stage == 0 ? (fl & WF_HIT_A) != 0u : (stage == 1 ? (fl & WF_OCCLUDED) != 0u : (fl & WF_HIT_C) != 0u);
@@ -398,10 +411,12 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     std::vector<uint2> tiles(tile_count);
     for (uint32_t i = 0; i < tile_count; ++i) tiles[i] = make_uint2(tiles_xy[2 * i], tiles_xy[2 * i + 1]);
     const uint32_t kf = key_frame_host(seed, e.d.frame);
-    const uint32_t full = e.depth;
+    const uint32_t full = e.quad_words;
     if (lds_depth == 0 || lds_depth > full) lds_depth = full;
     trace_blocks = std::max(1u, std::min(trace_blocks, n_chunks));
-    std::vector<uint32_t> overflow((size_t)(8u * e.depth + 64u) * trace_blocks * TR_BLOCK, 0u);
+    std::vector<uint32_t> overflow((size_t)(full + 64u) * trace_blocks * TR_BLOCK, 0u);
+    std::vector<uint32_t> fallback(n_slots, 0u);
+    const size_t fb_lds = (size_t)e.depth * TR_BLOCK * 4;
     const size_t dyn_lds = (size_t)lds_depth * TR_BLOCK * 4;
     const int feat = feature_set(e);
     // the material sort of the shading stage (default of the library for the compacted schedule; trace == 2 is the slot form without queues)
@@ -431,7 +446,9 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
 #define EMU_QUERY_KIND(A, K) do { if (kinds_present & (1u << K)) EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_query_kind<A, K>(e.d, pool, kind_queues.data(), qc, qctl, stats.data()); }); } while (0)
 #define EMU_TRACE_STAGE(S, A, Q)                                                                                                            \
     do {                                                                                                                                    \
-        EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data()); }, dyn_lds); \
+        EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data(), fallback.data()); }, dyn_lds); \
+        EMU_K(1u, TR_BLOCK, [&] { k_wf_trace_fallback<S, A>(e.d, pool, qctl, fallback.data()); }, fb_lds);                                    \
+        g_wf_deferred += qctl[WF_FB_WORD + S];                                                                                              \
     } while (0)
 #define EMU_ROUND_F(A)                                                                                                                      \
     do {                                                                                                                                    \
@@ -465,7 +482,9 @@ extern "C" int emu_device_trees(const TrayFlatScene* f, uint32_t* counts, TrayBv
     tray::PairedTrees p;
     if (!tray::pair_trees(f, p)) return 1;
     std::vector<tray::WfInst> recs;
-    tray::wf_inst_records(f, p.meshes, recs);
+    tray::QuadTrees q;
+    tray::quad_trees(f, q);
+    tray::wf_inst_records(f, q.mesh_first, recs);
     counts[0] = (uint32_t)p.top.size(); counts[1] = (uint32_t)p.mesh.size(); counts[2] = (uint32_t)p.meshes.size(); counts[3] = (uint32_t)recs.size();
     if (top) std::memcpy(top, p.top.data(), p.top.size() * sizeof(TrayBvhNode));
     if (mesh) std::memcpy(mesh, p.mesh.data(), p.mesh.size() * sizeof(TrayBvhNode));
@@ -475,3 +494,18 @@ extern "C" int emu_device_trees(const TrayFlatScene* f, uint32_t* counts, TrayBv
     return 0;
 }
 extern "C" unsigned emu_retraced(void) { const unsigned r = g_retraced; g_retraced = 0; return r; }
+extern "C" unsigned emu_wf_deferred(void) { const unsigned r = g_wf_deferred; g_wf_deferred = 0; return r; }
+// The wavefront traversal's quad records (host/gates.hpp: QuadTrees), for tests/test_device_tree_order.py. counts: top records, mesh records,
+// meshes, top_pend, mesh_pend; null outputs = counts only. bfs_levels < 0: the library's default.
+extern "C" int emu_quad_trees(const TrayFlatScene* f, int bfs_levels, uint32_t* counts, void* top, void* mesh, uint32_t* mesh_first, int* narrow) {
+    tray::PairedTrees p;
+    if (!tray::pair_trees(f, p)) return 1;
+    tray::QuadTrees q;
+    if (bfs_levels < 0) tray::quad_trees(f, q); else tray::quad_trees(f, q, false, (uint32_t)bfs_levels);
+    counts[0] = (uint32_t)q.top.size(); counts[1] = (uint32_t)q.mesh.size(); counts[2] = (uint32_t)q.mesh_first.size(); counts[3] = q.top_pend; counts[4] = q.mesh_pend;
+    if (top) std::memcpy(top, q.top.data(), q.top.size() * sizeof(tray::QuadNode));
+    if (mesh) std::memcpy(mesh, q.mesh.data(), q.mesh.size() * sizeof(tray::QuadNode));
+    if (mesh_first) std::memcpy(mesh_first, q.mesh_first.data(), q.mesh_first.size() * sizeof(uint32_t));
+    if (narrow) *narrow = q.narrow ? 1 : 0;
+    return 0;
+}

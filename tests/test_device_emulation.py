@@ -104,6 +104,73 @@ def test_wavefront_traversal_kernel_behind_bvh_of_instances(tr15, stage):
     check_stage(flat, rays, stage, got)
 
 
+def wf_deferred():
+    h = E.emu()
+    h.emu_wf_deferred.restype = __import__("ctypes").c_uint
+    return int(h.emu_wf_deferred())
+
+
+@pytest.mark.parametrize("which", ["dragon", "tr15"])
+@pytest.mark.parametrize("stage", [0, 1])
+def test_wavefront_traversal_hands_axis_parallel_rays_to_the_reference_traversal(dragon, tr15, which, stage):
+    """The quad records drop the box of a node that was replaced by its children; that is only sound for rays whose reciprocal direction
+    is finite and nonzero (host/gates.hpp). Rays with a zero (+0 and -0), denormal or infinite direction component -- for which the
+    reference's slab test itself is erratic -- must come back exactly as the reference's binary traversal answers them: k_wf_trace_dyn
+    hands them to k_wf_trace_fallback (trace_bvh)."""
+    flat = (dragon if which == "dragon" else tr15)[1]
+    centre, spread = ([8.5, 3.7, 1.5], 4.0) if which == "dragon" else ([0, 5, 0], 10.0)
+    rays = rays_for(flat, 40 + stage, 3000, stage, centre, spread)
+    rng = np.random.default_rng(41)
+    special = np.array([0.0, -0.0, 1e-42, -1e-42, 0.0, -0.0], np.float32)
+    for k in range(len(rays)):      # one or two components of every ray's direction become +0 / -0 / denormal
+        for c in rng.choice(3, rng.integers(1, 3), replace=False):
+            rays[k, 3 + c] = special[rng.integers(0, len(special))]
+    # ... and origins on the box planes of the scene, where 0 * inf shows up in the slab test
+    rays[::7, 0] = np.float32(BOX[0][0]); rays[1::7, 1] = np.float32(BOX[0][1])
+    wf_deferred()
+    got = E.wf_trace(flat, rays, stage, lds_depth=4)
+    n_deferred = wf_deferred()
+    assert n_deferred >= len(rays), n_deferred        # (a ray is handed over at most once; camera + inner rays of rays_for)
+    check_stage(flat, rays, stage, got)
+    # the regular rays of the other tests are never handed over on the way into a mesh either
+    regular = rays_for(flat, 50 + stage, 2000, stage, centre, spread)
+    E.wf_trace(flat, regular, stage)
+    assert wf_deferred() == 0
+
+
+def test_wavefront_traversal_hands_over_a_ray_that_turns_axis_parallel_inside_an_instance(tmp_path, built):
+    """A ray that is regular in world space but gets a zero direction component in an instance's object space (here: a sheared
+    mesh instance and rays with d.x = -d.y) is handed over when it enters that instance's mesh -- whole, from its origin."""
+    p, _ = scenes.write_dragon_assets(str(tmp_path), film=(160, 120, 4), grid=48, extent=1.0)
+    scene, *_ = T.Scene.load_file(p)
+    flat = scene.flatten(0)
+    f = flat.contents
+    mesh_inst = [i for i in range(f.n_instances) if f.instances[i].geom_type == 3][0]
+    inst = f.instances[mesh_inst]
+    inv0 = np.array(inst.inv[:16], np.float64).reshape(4, 4)
+    sc = 0.078125                                                          # ~ the instance's own 1 / 13, exact in binary
+    new_inv = np.array([[sc, sc, 0, inv0[0, 3]], [0, sc, 0, inv0[1, 3]], [0, 0, sc, inv0[2, 3]], [0, 0, 0, 1]])   # object x = s (x + y): zero for d.x = -d.y
+    new_mat = np.linalg.inv(new_inv)
+    for k in range(16):
+        inst.inv[k] = float(np.float32(new_inv.flat[k])); inst.mat[k] = float(np.float32(new_mat.flat[k]))
+    new_inv = new_inv.astype(np.float32)
+    rng = np.random.default_rng(61)
+    n = 4000
+    o = rng.uniform(BOX[0], BOX[1], (n, 3)).astype(np.float32)
+    target = rng.normal([8.5, 3.7, 1.5], 3.0, (n, 3)).astype(np.float32)
+    d = target - o
+    v = (0.5 * (d[:, 0] - d[:, 1])).astype(np.float32)
+    d[:, 0] = v; d[:, 1] = -v
+    rays = np.concatenate([o, d, np.full((n, 1), 0.001), np.full((n, 1), np.inf), np.zeros((n, 1))], axis=1).astype(np.float32)
+    rays[:, 8] = f.camera.shutter_open
+    row0 = new_inv[0, :3]
+    assert ((row0[0] * rays[:, 3] + row0[1] * rays[:, 4]) + row0[2] * rays[:, 5] == 0).mean() > 0.5   # (xf_vector's order of operations)
+    wf_deferred()
+    got = E.wf_trace(flat, rays, 0, lds_depth=4)
+    assert 0 < wf_deferred() < n          # only the rays that reach the instance
+    check_stage(flat, rays, 0, got)
+
+
 # ---- the whole per-sample path: sampler, camera, traversal, integrator, BSDFs (k_debug_sample_radiance, k_debug_bsdf)
 
 @pytest.mark.parametrize("name,spp", [("cornell_box", 64), ("smallpt", 64), ("dragon", 16)])

@@ -91,6 +91,10 @@ struct DevScene {
     const TrayCamera* __restrict__ camera_p;
     const uint8_t* __restrict__ perm_pool;   // TR_PERM_BYTES: the shuffles the per-path LD arrays draw from (dev_math.h: perm_pool_build)
     const tray::WfInst* __restrict__ wf_insts;   // one 64-B record per BVH<Instance> leaf slot (host/gates.hpp): the wavefront traversal's instance entry
+    const float4* __restrict__ quads;            // the wavefront traversal's trees (host/gates.hpp: QuadTrees): 128-byte records of up to four (box, descriptor)
+                                                 // slots = two levels of the binary trees above. ONE buffer -- the BVH<Triangle>s first, then this frame's
+                                                 // BVH<Instance> from record top_quad_first -- so that a record's address is a uniform base + a 32-bit offset
+    uint32_t top_quad_first, pad_quads;
 };
 
 struct Ray {

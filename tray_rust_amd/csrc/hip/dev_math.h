@@ -62,6 +62,35 @@ TR_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi 
 TR_DEV float lerpf(float t, float a, float b) { return a * (1.0f - t) + b * t; }
 TR_DEV float to_radians(float d) { return kPi / 180.0f * d; }
 
+// Two f32 side by side for the packed VALU operations of gfx950 (v_pk_add_f32 / v_pk_mul_f32: two lanes' worth of arithmetic per
+// issue slot, each half rounded exactly like the plain instruction -- tools/pk_denorm_check.hip; no v_pk_fma is formed: the
+// translation unit is built with -ffp-contract=off). profiles/r04_ubench_valu.txt: a packed instruction costs 4.5-4.9 cycles against
+// 3.8-3.9 for the plain one at >= 4 waves per SIMD, i.e. 0.6 of the issue time per f32.
+#ifndef TR_HOST_EMU
+typedef float f2 __attribute__((ext_vector_type(2)));
+#else
+struct f2 { float x, y; };
+inline f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
+inline f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
+inline f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
+#endif
+TR_DEV f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+TR_DEV f2 splat2(float a) { return mk2(a, a); }
+// (a - s.lo, b - s.lo) etc.: a packed operation whose second operand is ONE half of a register pair for both results -- the op_sel
+// operand modifiers of the VOP3P encoding (op_sel picks the half that feeds the low result, op_sel_hi the high one), so two scalars
+// share a pair and nothing is moved. hipcc does not form these from shuffles (it copies the scalar into both halves of a fresh pair).
+#ifndef TR_HOST_EMU
+TR_DEV f2 pk_sub_lo(f2 a, f2 s) { f2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(s)); return r; }
+TR_DEV f2 pk_sub_hi(f2 a, f2 s) { f2 r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(s)); return r; }
+TR_DEV f2 pk_mul_lo(f2 a, f2 s) { f2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(s)); return r; }
+TR_DEV f2 pk_mul_hi(f2 a, f2 s) { f2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(s)); return r; }
+#else
+inline f2 pk_sub_lo(f2 a, f2 s) { return f2{a.x - s.x, a.y - s.x}; }
+inline f2 pk_sub_hi(f2 a, f2 s) { return f2{a.x - s.y, a.y - s.y}; }
+inline f2 pk_mul_lo(f2 a, f2 s) { return f2{a.x * s.x, a.y * s.x}; }
+inline f2 pk_mul_hi(f2 a, f2 s) { return f2{a.x * s.y, a.y * s.y}; }
+#endif
+
 // Transform * Point / inv_mul_point (transform.rs:152-163,199-216): m is a row-major 4x4
 TR_DEV f3 xf_point(const float* __restrict__ m, f3 p) {
     f3 r;

@@ -558,7 +558,13 @@ struct TrayDeviceScene {
     uint32_t* d_queues = nullptr;     // wavefront schedule: ray queues A, B, C (n_slots each) + WF_QCTL_WORDS counters
     uint32_t n_blocks_trace = 0;      // persistent grid of k_wf_trace_dyn
     std::vector<TrayMesh> paired_meshes;   // the meshes with node_offset / node_count in device order (what the `meshes` buffer holds)
+    std::vector<uint32_t> quad_first;      // per mesh: entry record of its tree in the `mesh_quads` buffer (host/gates.hpp: QuadTrees)
+    size_t n_mesh_quads = 0;               // records of the BVH<Triangle>s at the head of the `quads` buffer
+    uint32_t quad_mesh_pend = 0;           // most node entries a traversal of one BVH<Triangle>'s quad records can have pending
+    uint32_t quad_stack_words = 0;         // stack words per lane the wavefront traversal needs for this frame's trees
+    uint32_t* d_fallback = nullptr;        // slots of the rays k_wf_trace_dyn hands to k_wf_trace_fallback (one word per pool slot)
     bool narrow_trees = true;         // every node's offset fits a descriptor (host/gates.hpp): the wavefront traversal keeps nodes as descriptors
+    bool ordered_boxes = true;        // every BVH box has min <= max (host/gates.hpp: QuadTrees::ordered)
     uint32_t trace_lds_depth = 0, trace_lds_bytes = 0;   // LDS part of the dynamic-fetch kernel's stacks; deeper entries go to d_stack_overflow
     uint32_t* d_stack_overflow = nullptr;
     size_t ovf_entries = 0;              // ... per view of the schedule (WF_PIPES_MAX of them)
@@ -630,7 +636,7 @@ struct WfView {
     WfPool pool;        // data moved to the view's first slot, n_slots = the pool's stride, seg_cap of the view's chunks
     WfChunk* chunks;
     float* bins;
-    uint32_t *qa, *qb, *qc, *qr, *qctl, *kq, *overflow;
+    uint32_t *qa, *qb, *qc, *qr, *qctl, *kq, *overflow, *fallback;
     uint32_t n_chunks;
     hipStream_t stream;
 };
@@ -645,16 +651,23 @@ static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, ui
     hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, v.dev, v.pool, v.chunks, v.bins, tiles, tile_count, chunk, chunk_stride,
                        spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, v.qa, v.qr, v.qctl);
     hipLaunchKernelGGL(k_wf_regen<ANIM>, qgrid, block, 0, stream, v.dev, v.pool, v.chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, v.qr, v.qa, v.qctl);
-    hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qa, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow);
+    // (each traversal is followed by the few-thread kernel that traces the rays it handed over to the reference's binary traversal:
+    // direction components that are zero / denormal / not finite -- normally none, the kernel reads one word and exits)
+    const dim3 fgrid(8);
+    static const int wf_exp = getenv("TRAYHIP_WF_EXPERIMENT") ? atoi(getenv("TRAYHIP_WF_EXPERIMENT")) : 0;   // MEASUREMENT ONLY (wrong images): 1 = no fallback launches, 2 = no stage C
+    hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qa, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.fallback);
+    if (!(wf_exp & 1)) hipLaunchKernelGGL((k_wf_trace_fallback<0, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.fallback);
     hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, v.dev, v.pool, n_active, s->d_stats, v.qb, v.qctl, v.kq);
-    hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qb, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow);
+    hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qb, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.fallback);
+    if (!(wf_exp & 1)) hipLaunchKernelGGL((k_wf_trace_fallback<1, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.fallback);
     if (v.kq) {   // kind-pure shading over the sorted queues: one launch per material kind the scene contains
 #define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), qgrid, block, 0, stream, v.dev, v.pool, v.kq, v.qc, v.qctl, s->d_stats)
         WF_QUERY_KIND(TRAY_MAT_MATTE); WF_QUERY_KIND(TRAY_MAT_PLASTIC); WF_QUERY_KIND(TRAY_MAT_METAL); WF_QUERY_KIND(TRAY_MAT_GLASS);
         WF_QUERY_KIND(TRAY_MAT_ROUGH_GLASS); WF_QUERY_KIND(TRAY_MAT_SPECULAR_METAL); WF_QUERY_KIND(TRAY_MAT_MERL);
 #undef WF_QUERY_KIND
     } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT_ALL | FEAT_TEX>), grid, block, 0, stream, v.dev, v.pool, n_active, v.qc, v.qctl, s->d_stats);
-    hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qc, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow);
+    if (!(wf_exp & 2)) hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qc, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.fallback);
+    if (!(wf_exp & 1)) hipLaunchKernelGGL((k_wf_trace_fallback<2, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.fallback);
 }
 
 // Path pool slots of the wavefront schedule: never more than the film has pixels x 4 (one chunk of 256 per tile), and for moving
@@ -793,18 +806,57 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
     size_t n_paired = 0;   // nodes of the BVH<Triangle>s in device order: one more per tree
     for (uint32_t m = 0; m < f->n_meshes; ++m) n_paired += f->meshes[m].node_count ? f->meshes[m].node_count + 1u : 0u;
     bool keep_trees = false;
-    if (donor)
-        for (const TrayDevBuf& b : donor->bufs)
-            keep_trees = keep_trees || (std::strcmp(b.key, "mesh_nodes") == 0 && b.bytes == std::max<size_t>(n_paired, 1) * sizeof(TrayBvhNode));
+    const size_t top_quad_cap = 2u * (size_t)f->n_instances + 2u;   // records a BVH<Instance> of this scene can need (one per interior node + the entry)
+    if (donor && donor->quad_first.size() == f->n_meshes) {
+        bool have_pairs = false, have_quads = false;
+        for (const TrayDevBuf& b : donor->bufs) {
+            have_pairs = have_pairs || (std::strcmp(b.key, "mesh_nodes") == 0 && b.bytes == std::max<size_t>(n_paired, 1) * sizeof(TrayBvhNode));
+            have_quads = have_quads || (std::strcmp(b.key, "quads") == 0 && b.bytes == (donor->n_mesh_quads + top_quad_cap) * sizeof(tray::QuadNode));
+        }
+        keep_trees = have_pairs && have_quads;
+    }
     if (rc == TRAY_OK && !tray::pair_trees(f, paired, keep_trees)) { rc = TRAY_E_INVALID; set_error("BVH arrays do not describe trees"); }
     s->narrow_trees = keep_trees ? donor->narrow_trees : paired.narrow;
     s->paired_meshes = keep_trees ? donor->paired_meshes : paired.meshes;
+    // the same trees as 128-byte records of two levels each, for the wavefront traversal (host/gates.hpp: QuadTrees)
+    tray::QuadTrees quads;
+    if (rc == TRAY_OK) {
+        uint32_t bfs_levels = TRAY_QUAD_BFS_LEVELS;
+        if (const char* e = getenv("TRAYHIP_QUAD_BFS")) bfs_levels = (uint32_t)std::max(0, atoi(e));
+        tray::quad_trees(f, quads, keep_trees, bfs_levels);
+        s->narrow_trees = s->narrow_trees && quads.narrow;
+        s->ordered_boxes = (keep_trees ? donor->ordered_boxes : true) && quads.ordered;
+        s->quad_first = keep_trees ? donor->quad_first : quads.mesh_first;
+        s->n_mesh_quads = keep_trees ? donor->n_mesh_quads : quads.mesh.size();
+        s->quad_mesh_pend = keep_trees ? donor->quad_mesh_pend : quads.mesh_pend;
+        // per lane: node entries are two words (descriptor, entry distance); the instances of a BVH<Instance> leaf (<= 31) and the
+        // exit-mesh sentinel one each; rounded up so that consecutive frames of a sequence keep the pool's overflow columns
+        s->quad_stack_words = (2u * (quads.top_pend + s->quad_mesh_pend) + 32u + 2u + 15u) / 16u * 16u;
+    }
     {   // the wavefront traversal's instance records (host/gates.hpp): per frame, as the instances are
         std::vector<tray::WfInst> recs;
-        tray::wf_inst_records(f, s->paired_meshes, recs);
+        tray::wf_inst_records(f, s->quad_first, recs);
         UP(wf_insts, recs.data(), recs.size())
     }
     UP(top_nodes, paired.top.data(), paired.top.size())
+    if (rc == TRAY_OK && (quads.top.size() > top_quad_cap || (s->n_mesh_quads + top_quad_cap) * sizeof(tray::QuadNode) >= ((size_t)1 << 32))) {
+        rc = TRAY_E_UNSUPPORTED; set_error("the quad records of the scene's trees do not fit 32-bit offsets");
+    }
+    if (rc == TRAY_OK) {   // one buffer: the BVH<Triangle>s (kept across frames), then this frame's BVH<Instance>
+        const tray::QuadNode* dq = nullptr;
+        std::vector<tray::QuadNode> all;
+        if (!keep_trees) {
+            all = quads.mesh;
+            all.insert(all.end(), quads.top.begin(), quads.top.end());
+            all.resize(s->n_mesh_quads + top_quad_cap, tray::quad_empty_record());
+        }
+        rc = upload(s, "quads", true, keep_trees ? static_cast<const tray::QuadNode*>(nullptr) : all.data(), s->n_mesh_quads + top_quad_cap, &dq);
+        if (rc == TRAY_OK && keep_trees && hipMemcpy(const_cast<tray::QuadNode*>(dq) + s->n_mesh_quads, quads.top.data(), quads.top.size() * sizeof(tray::QuadNode), hipMemcpyHostToDevice) != hipSuccess) {
+            rc = TRAY_E_DEVICE; set_error("hipMemcpy of the BVH<Instance> records failed");
+        }
+        d.quads = reinterpret_cast<const float4*>(dq);
+        d.top_quad_first = (uint32_t)s->n_mesh_quads;
+    }
     UP(top_order, f->top_order, f->n_top_order)
     UPS(meshes, keep_trees ? f->meshes : paired.meshes.data(), f->n_meshes)          // (kept: the donor's copies are not written)
     UPS(mesh_nodes, keep_trees ? f->mesh_nodes : paired.mesh.data(), n_paired)
@@ -1001,6 +1053,9 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
                 reinterpret_cast<const void*>(k_wf_trace_dyn<0, 0>), reinterpret_cast<const void*>(k_wf_trace_dyn<0, 1>),
                 reinterpret_cast<const void*>(k_wf_trace_dyn<1, 0>), reinterpret_cast<const void*>(k_wf_trace_dyn<1, 1>),
                 reinterpret_cast<const void*>(k_wf_trace_dyn<2, 0>), reinterpret_cast<const void*>(k_wf_trace_dyn<2, 1>),
+                reinterpret_cast<const void*>(k_wf_trace_fallback<0, 0>), reinterpret_cast<const void*>(k_wf_trace_fallback<0, 1>),
+                reinterpret_cast<const void*>(k_wf_trace_fallback<1, 0>), reinterpret_cast<const void*>(k_wf_trace_fallback<1, 1>),
+                reinterpret_cast<const void*>(k_wf_trace_fallback<2, 0>), reinterpret_cast<const void*>(k_wf_trace_fallback<2, 1>),
                 reinterpret_cast<const void*>(k_debug_intersect<0>), reinterpret_cast<const void*>(k_debug_intersect<2>),
                 reinterpret_cast<const void*>(k_debug_sample_radiance<0>), reinterpret_cast<const void*>(k_debug_sample_radiance<2>)};
             for (const void* k : traversing) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1053,15 +1108,15 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         s->dev.xf_cache_lanes = lanes;
         s->dev.xf_aos = s->wavefront ? 1u : 0u;
     }
-    if (donor && donor->wf_ready && s->wavefront && donor->stack_bytes == s->stack_bytes && donor->animated == s->animated &&
+    if (donor && donor->wf_ready && s->wavefront && donor->stack_bytes == s->stack_bytes && donor->quad_stack_words == s->quad_stack_words && donor->animated == s->animated &&
         donor->pool.n_slots == ((s->animated && s->dev.xf_cache_lanes) ? s->dev.xf_cache_lanes : wf_slot_count(s))) {
         // the wavefront schedule's pool, queues, chunk records and row bins (2.2 GB at 8 M slots) serve the next frame as they are:
         // launch_wavefront re-initialises the chunk records and the control words of every launch, the bins are zero between tiles
         for (void* p : {(void*)donor->pool.data, (void*)donor->d_chunks, (void*)donor->d_bins, (void*)donor->d_wf_counters, (void*)donor->d_queues,
-                        (void*)donor->d_kind_queues, (void*)donor->d_stack_overflow})
+                        (void*)donor->d_kind_queues, (void*)donor->d_stack_overflow, (void*)donor->d_fallback})
             if (p) { forget_alloc(donor, p); s->allocs.push_back(p); }
         s->pool = donor->pool; s->d_chunks = donor->d_chunks; s->d_bins = donor->d_bins; s->d_wf_counters = donor->d_wf_counters;
-        s->d_queues = donor->d_queues; s->d_kind_queues = donor->d_kind_queues; s->d_stack_overflow = donor->d_stack_overflow;
+        s->d_queues = donor->d_queues; s->d_kind_queues = donor->d_kind_queues; s->d_stack_overflow = donor->d_stack_overflow; s->d_fallback = donor->d_fallback;
         s->h_done = donor->h_done; donor->h_done = nullptr;
         s->n_chunks = donor->n_chunks; s->n_blocks_trace = donor->n_blocks_trace; s->trace_lds_depth = donor->trace_lds_depth;
         s->trace_lds_bytes = donor->trace_lds_bytes; s->wf_sort = donor->wf_sort; s->ovf_entries = donor->ovf_entries;
@@ -1108,6 +1163,7 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
 static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride,
                             uint32_t spp, uint32_t kf, float* rgbw_dev, hipStream_t stream) {
     if (!s->narrow_trees) { set_error("wavefront schedule: a BVH of more than 8 388 607 nodes or triangles (the traversal keeps a node as a 32-bit descriptor)"); return TRAY_E_UNSUPPORTED; }
+    if (!s->ordered_boxes) { set_error("wavefront schedule: a BVH box with min > max (or NaN) on some axis; TRAYHIP_MODE=mega renders such a scene with the tile kernel"); return TRAY_E_UNSUPPORTED; }
     if (!s->wf_ready) {
         if (s->pool.data) { set_error("the wavefront buffers of this scene could not be allocated by an earlier call"); return TRAY_E_NOMEM; }
         uint32_t n_slots = (s->animated && s->dev.xf_cache_lanes) ? s->dev.xf_cache_lanes : wf_slot_count(s);   // (the transform cache was sized at creation)
@@ -1140,8 +1196,8 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
             // LDS stack entries per lane such that WF_TRACE_WAVES workgroups (4 waves each = one wave per SIMD) fit in the CU's 160 KB
-            // (a node on this kernel's stack is two words: descriptor and entry distance)
-            const uint32_t full_depth = 2u * (s->stack_bytes / (TR_BLOCK * (uint32_t)sizeof(uint32_t)));
+            // (a node on this kernel's stack is two words: descriptor and entry distance; up to three per expanded record)
+            const uint32_t full_depth = std::max(s->quad_stack_words, 8u);
             uint32_t lds_depth = std::min<uint32_t>(full_depth, (160u * 1024u / WF_TRACE_WAVES) / (TR_BLOCK * (uint32_t)sizeof(uint32_t)));
             if (const char* e = getenv("TRAYHIP_WF_LDS_DEPTH")) lds_depth = std::min<uint32_t>(full_depth, (uint32_t)std::max(1, atoi(e)));
             s->trace_lds_depth = lds_depth;
@@ -1154,6 +1210,8 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             s->ovf_entries = ovf_entries;
             HIP_CHECK(hipMalloc(&p, (size_t)WF_PIPES_MAX * ovf_entries * sizeof(uint32_t)));
             s->allocs.push_back(p); s->d_stack_overflow = static_cast<uint32_t*>(p);
+            HIP_CHECK(hipMalloc(&p, (size_t)n_slots * sizeof(uint32_t)));
+            s->allocs.push_back(p); s->d_fallback = static_cast<uint32_t*>(p);
             if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] dynamic-fetch traversal: %u of %u stack entries in LDS, %d workgroups per CU\n", lds_depth, full_depth, per_cu);
         }
         HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s->h_done), sizeof(uint32_t), hipHostMallocDefault));
@@ -1195,6 +1253,7 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             v.qctl = qctl_base + (size_t)k * WF_QCTL_WORDS;
             v.kq = s->wf_sort ? s->d_kind_queues + (size_t)WF_MAT_KINDS * q_off : nullptr;
             v.overflow = s->d_stack_overflow + (size_t)k * s->ovf_entries;
+            v.fallback = s->d_fallback + (size_t)c0 * TR_BLOCK;
             v.stream = stream;
             if (k > 0) {
                 if (!s->wf_streams[k]) HIP_CHECK(hipStreamCreateWithFlags(&s->wf_streams[k], hipStreamNonBlocking));
@@ -1220,7 +1279,7 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             HIP_CHECK(hipMemsetAsync(v.qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), v.stream));
             if (s->animated) wf_round<1>(s, v, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev);
             else wf_round<0>(s, v, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev);
-            launches += 7;
+            launches += 10;
         }
         if (round % WF_POLL == WF_POLL - 1) {
             HIP_CHECK(hipGetLastError());

@@ -199,10 +199,20 @@ TR_DEV uint32_t wf_next_segment(const uint32_t* __restrict__ qctl, uint32_t stag
 #ifndef WF_NODE_MIN
 #define WF_NODE_MIN 16     // ... as long as this many lanes still have node work (or nobody waits for the leaf / pop phase)
 #endif
+// Control words 16 + STAGE of segment 0: rays of the stage handed to k_wf_trace_fallback (below); their slots are listed in `fallback`.
+#define WF_FB_WORD 16u
+// A ray whose reciprocal direction is finite and nonzero in every component: for those the box of a node is implied by the boxes of its
+// children (host/gates.hpp: QuadTrees), which is what lets a record hold the grandchildren. Everything else -- a zero or denormal
+// direction component (1 / d = inf: 0 * inf and -0 * inf make the reference's slab test erratic), NaN, inf -- is traced by the
+// reference's own binary traversal.
+TR_DEV bool wf_regular(f3 inv_dir) {
+    const float ax = fabsf(inv_dir.x), ay = fabsf(inv_dir.y), az = fabsf(inv_dir.z);
+    return (ax > 0.0f) & (ax < TR_INF) & (ay > 0.0f) & (ay < TR_INF) & (az > 0.0f) & (az < TR_INF);
+}
 template <int STAGE, int ANIM>
 __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const DevScene scv, WfPool pool, const uint32_t* __restrict__ queue,
                                                            uint32_t* __restrict__ qctl, DevStats* __restrict__ stats, uint32_t lds_depth,
-                                                           uint32_t* __restrict__ overflow) {
+                                                           uint32_t* __restrict__ overflow, uint32_t* __restrict__ fallback) {
     const DevScene& sc = scv;
     TR_DYN_LDS(uint32_t, s_stack);   // stack_depth x TR_BLOCK entries
     const LdsU stack = TR_LDS_U(s_stack) + threadIdx.x;   // (its own address space: a pop must not become a flat load that may hit either memory)
@@ -212,6 +222,13 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
     uint32_t* __restrict__ ovf = overflow + (blockIdx.x * TR_BLOCK + threadIdx.x);
 #define WF_PUSH(v) do { const uint32_t v_ = (v); if ((uint32_t)sp < lds_depth) stack[sp * TR_BLOCK] = v_; else ovf[(size_t)((uint32_t)sp - lds_depth) * ovf_stride] = v_; ++sp; } while (0)
 #define WF_POP(e) do { --sp; if ((uint32_t)sp < lds_depth) e = stack[sp * TR_BLOCK]; else e = ovf[(size_t)((uint32_t)sp - lds_depth) * ovf_stride]; } while (0)
+    // a node entry is two words, the entry distance below the descriptor: one test for both where they lie in LDS (the usual case)
+#define WF_PUSH_NODE(t_, d_) do { const uint32_t tw_ = (t_), dw_ = (d_);                                                               \
+        if ((uint32_t)sp + 2u <= lds_depth) { stack[sp * TR_BLOCK] = tw_; stack[(sp + 1) * TR_BLOCK] = dw_; sp += 2; }                   \
+        else { WF_PUSH(tw_); WF_PUSH(dw_); } } while (0)
+#define WF_POP_NODE(d_, t_) do {                                                                                                       \
+        if ((uint32_t)sp <= lds_depth) { sp -= 2; d_ = stack[(sp + 1) * TR_BLOCK]; t_ = stack[sp * TR_BLOCK]; }                          \
+        else { WF_POP(d_); WF_POP(t_); } } while (0)
     // pops node entries until one passes the box test of the moment (stored entry distance < max_t now) -- the lane goes on with it -- or
     // something else is on top (instance entry, end of a mesh: left for the pop phase) or the stack is empty; cheap (LDS), so it runs
     // wherever a lane runs out of node work instead of sending the lane through the pop phase. (Leaving a mesh here as well -- the
@@ -249,17 +266,28 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
 #define WF_CLK(slot) ((void)0)
 #endif
     // traversal state (trace_bvh)
-    f3 wo = mk(0, 0, 0), wd = mk(0, 0, 0), o = wo, d = wd, inv_dir = wo;
-    bool nx = false, ny = false, nz = false, in_mesh = false, any = false;
+    f3 wo = mk(0, 0, 0), wd = mk(0, 0, 0), d = wd;
+    // origin and reciprocal direction of the ray in the space it is traversing, as the register pairs the node step's packed arithmetic
+    // reads them from: (o.x, o.y), (o.z, 1 / d.x), (1 / d.y, 1 / d.z)
+    f2 oxy = mk2(0.0f, 0.0f), ozix = oxy, iyz = oxy;
+#define WF_SET_RAY(o_, inv_) do { oxy = mk2((o_).x, (o_).y); ozix = mk2((o_).z, (inv_).x); iyz = mk2((inv_).y, (inv_).z); } while (0)
+    bool in_mesh = false, any = false;
+    // the direction signs of the ray in the space it is traversing, as what the node step needs of them: the byte offset of the plane
+    // the ray ENTERS through inside a record's six plane rows (0 = the row of minima, 48 = the row of maxima, per axis; the other one
+    // is the exit) and 3 x the direction octant (the shift that finds the octant's visiting order in the record)
+    uint32_t sel_x = 0u, sel_y = 0u, sel_z = 0u, oct3 = 0u;
+#define WF_SIGNS() do { sel_x = d.x < 0.0f ? 48u : 0u; sel_y = d.y < 0.0f ? 48u : 0u; sel_z = d.z < 0.0f ? 48u : 0u;                       \
+                        oct3 = 3u * ((d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u)); } while (0)
     float min_t = 0.0f, max_t = 0.0f;
     int sp = 0;
     uint32_t cur = 0u, cur_inst = 0u, tri_base = 0u, cur_offset = 0u, cur_count = 0u;   // cur: descriptor of the node to expand (dev_geom.h: nd_*)
     enum : uint32_t { TM_NODE = 0u, TM_LEAF = 1u, TM_POP = 2u };
     uint32_t mode = TM_NODE;
-    const TrayBvhNode* __restrict__ tree = sc.top_nodes;
-    const TrayTriVerts* __restrict__ tris = nullptr;
+    uint32_t tree = sc.top_quad_first;   // entry record of the tree the ray is in (index into sc.quads)
     HitRec rec;
     rec.t = 0.0f; rec.inst = 0xffffffffu; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
+    // hands the lane's ray to k_wf_trace_fallback (the result is written there)
+#define WF_DEFER() do { const uint32_t k_ = atomicAdd(qctl + WF_FB_WORD + STAGE, 1u); fallback[k_] = slot; } while (0)
     for (;;) {
         // ---- refill idle lanes from the queue
         if (!exhausted) {
@@ -281,13 +309,15 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                         ray_flags = r1.w & ~WF_CAMERA_RAY;
                         if (STAGE == 0) { min_t = (r1.w & WF_CAMERA_RAY) ? 0.0f : 0.001f; max_t = TR_INF; }
                         else { min_t = 0.001f; max_t = STAGE == 1 ? 0.999f : TR_INF; }
-                        o = wo; d = wd;
-                        inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                        nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
-                        tree = sc.top_nodes; cur = 0u; sp = 0; in_mesh = false; any = false; mode = TM_NODE;
+                        d = wd;
+                        const f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        WF_SET_RAY(wo, inv_dir);
+                        WF_SIGNS();
+                        tree = sc.top_quad_first; cur = 0u; sp = 0; in_mesh = false; any = false; mode = TM_NODE;
                         rec.t = 0.0f; rec.inst = 0xffffffffu; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
-                        active = true;
                         ++n_rays;
+                        if (wf_regular(inv_dir)) active = true;
+                        else WF_DEFER();
                     }
                 }
                 if (base + n_idle >= seg_cnt) {   // this segment is drained (by this refill or by somebody else's)
@@ -299,16 +329,18 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
         WF_CLK(0);
         if (!__any(active)) { if (exhausted) break; continue; }
         // ---- traversal, while-while form. A lane is in one of three modes:
-        //   TM_NODE  EXPANDS a node whose box it has passed (`cur`, the node's descriptor): the boxes of both children are one
-        //            64-byte record (device order of the trees, host/gates.hpp) and are tested together with the ray's current
-        //            max_t. If both are hit the far one goes on the stack as (descriptor, entry distance); the near one, or the only
-        //            one hit, is expanded next. A ray enters a tree by expanding node "0": the pair (root, empty twin).
+        //   TM_NODE  EXPANDS the record `cur` refers to (host/gates.hpp: QuadTrees): up to four (box, descriptor) slots -- the children of
+        //            a node, with an interior child replaced by ITS two children -- in one 128-byte fetch. All four boxes are tested with
+        //            the ray's current max_t; the slots hit are taken in the order in which the reference would reach them (near child of
+        //            the node first, inside a child its near child first: bvh.rs:105-119 with the three split axes the record carries);
+        //            the first goes on, the others go on the stack as (descriptor, entry distance). A ray enters a tree at record 0.
         //   TM_LEAF  reached a leaf: triangles of a BVH<Triangle> leaf, or the instances of a BVH<Instance> leaf
         //   TM_POP   needs a stack entry that is not a node (instance entry, leaving a mesh) or has none left
         // The reference tests a node's box when it reaches the node, with the max_t of that moment (bvh.rs:89-127). max_t enters
         // the slab test only through `tmin < max_t` (bbox_hit), everything else in it is the same whenever it is evaluated, so the
-        // test at pop time is the stored entry distance against the current max_t: no second fetch of the node, and a step of the
-        // loop is always one record for two boxes. Candidates and their order are exactly the reference's.
+        // test at pop time is the stored entry distance against the current max_t: no second fetch of the node. The box of a child
+        // that was replaced by its children is never tested: for the rays this kernel traverses (wf_regular) it is hit whenever one
+        // of them is. Candidates and their order are exactly the reference's.
         // The node phase repeats while enough lanes have node work, so the (much longer) leaf / pop code runs once per
         // several node steps instead of once per step for whichever few lanes happen to need it.
         bool finished = false;
@@ -320,22 +352,56 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
             if (it > 0 && n_node < WF_NODE_MIN && __any(active && mode != TM_NODE)) break;
             if (in_node) {
                 WF_COUNT(c_iter);
-                const float4* q = reinterpret_cast<const float4*>(tree + nd_offset(cur));
-                const float4 alo = q[0], ahi = q[1], blo = q[2], bhi = q[3];
-                float ta, tb;
-                const bool ha = bbox_hit_t(alo, ahi, o, inv_dir, nx, ny, nz, min_t, max_t, ta);
-                const bool hb = bbox_hit_t(blo, bhi, o, inv_dir, nx, ny, nz, min_t, max_t, tb);
+                // the record's planes are fetched as the ray meets them: per axis the plane it enters through and the one it leaves through
+                // (bbox.rs:77-85 picks them by the sign of the direction; here the sign picks the ADDRESS, so nothing is selected afterwards)
+                // (all records of a scene lie in one buffer of < 4 GB: a uniform base and 32-bit offsets, one add per row)
+                const char* __restrict__ qb = reinterpret_cast<const char*>(sc.quads);
+                const uint32_t rb = (tree + nd_offset(cur)) << 7;
+                const float4 nxp = *reinterpret_cast<const float4*>(qb + (rb + sel_x)), fxp = *reinterpret_cast<const float4*>(qb + (rb + (sel_x ^ 48u)));
+                const float4 nyp = *reinterpret_cast<const float4*>(qb + (rb + sel_y) + 16), fyp = *reinterpret_cast<const float4*>(qb + (rb + (sel_y ^ 48u)) + 16);
+                const float4 nzp = *reinterpret_cast<const float4*>(qb + (rb + sel_z) + 32), fzp = *reinterpret_cast<const float4*>(qb + (rb + (sel_z ^ 48u)) + 32);
+                const float4 dq = *reinterpret_cast<const float4*>(qb + rb + 96);
+                const uint32_t order = *reinterpret_cast<const uint32_t*>(qb + rb + 116);
+                // fast_intersect (bbox.rs:75-104) of the four slots, two at a time in packed arithmetic: t = (plane - o) * inv_dir per axis
+                // and side, then tmin = the largest entry, tmax = the smallest exit. For the rays this kernel traverses (wf_regular) and boxes
+                // with min <= max none of these values is a NaN and the reference's early-out comparisons (tmin > tymax || tymin > tmax,
+                // then the same against z) say exactly "some entry lies behind some exit", i.e. max3(entries) > min3(exits); the entry of an
+                // axis never lies behind its own exit (monotone rounding). An unused slot's planes are all +inf: tmin = +inf or tmax = -inf.
+                // (the ray's origin and reciprocal direction live in three register pairs: oxy, ozix, iyz)
+                const f2 nxa = pk_mul_hi(pk_sub_lo(mk2(nxp.x, nxp.y), oxy), ozix), nxb = pk_mul_hi(pk_sub_lo(mk2(nxp.z, nxp.w), oxy), ozix);
+                const f2 fxa = pk_mul_hi(pk_sub_lo(mk2(fxp.x, fxp.y), oxy), ozix), fxb = pk_mul_hi(pk_sub_lo(mk2(fxp.z, fxp.w), oxy), ozix);
+                const f2 nya = pk_mul_lo(pk_sub_hi(mk2(nyp.x, nyp.y), oxy), iyz), nyb = pk_mul_lo(pk_sub_hi(mk2(nyp.z, nyp.w), oxy), iyz);
+                const f2 fya = pk_mul_lo(pk_sub_hi(mk2(fyp.x, fyp.y), oxy), iyz), fyb = pk_mul_lo(pk_sub_hi(mk2(fyp.z, fyp.w), oxy), iyz);
+                const f2 nza = pk_mul_hi(pk_sub_lo(mk2(nzp.x, nzp.y), ozix), iyz), nzb = pk_mul_hi(pk_sub_lo(mk2(nzp.z, nzp.w), ozix), iyz);
+                const f2 fza = pk_mul_hi(pk_sub_lo(mk2(fzp.x, fzp.y), ozix), iyz), fzb = pk_mul_hi(pk_sub_lo(mk2(fzp.z, fzp.w), ozix), iyz);
+                float t0 = fmaxf(fmaxf(nxa.x, nya.x), nza.x), t1 = fmaxf(fmaxf(nxa.y, nya.y), nza.y), t2 = fmaxf(fmaxf(nxb.x, nyb.x), nzb.x), t3 = fmaxf(fmaxf(nxb.y, nyb.y), nzb.y);
+                const float x0 = fminf(fminf(fxa.x, fya.x), fza.x), x1 = fminf(fminf(fxa.y, fya.y), fza.y), x2 = fminf(fminf(fxb.x, fyb.x), fzb.x), x3 = fminf(fminf(fxb.y, fyb.y), fzb.y);
+                // (a slot that is hit has tmin < max_t <= inf, so inf marks a miss)
+                if (!((t0 <= x0) & (t0 < max_t) & (x0 > min_t))) t0 = TR_INF;
+                if (!((t1 <= x1) & (t1 < max_t) & (x1 > min_t))) t1 = TR_INF;
+                if (!((t2 <= x2) & (t2 < max_t) & (x2 > min_t))) t2 = TR_INF;
+                if (!((t3 <= x3) & (t3 < max_t) & (x3 > min_t))) t3 = TR_INF;
                 WF_COUNT(c_expand);
-                if (ha || hb) {
-                    // near child first by the sign of the split axis (bvh.rs:105-119); occlusion rays (STAGE 1) visit the child on the LIGHT's
-                    // side first: the boolean does not depend on the order (until a candidate is accepted max_t is the original one, so
-                    // one is accepted iff a valid candidate exists at all), the rays of a light converge there, and what blocks a light
-                    // tends to sit near it: +1.4 % on the C5 stand-in.
-                    const uint32_t axis = nd_axis(cur);
-                    const bool neg = (axis == 0u ? nx : (axis == 1u ? ny : nz)) != (STAGE == 1);
-                    const uint32_t da = __float_as_uint(ahi.w), db = __float_as_uint(bhi.w);
-                    if (ha && hb) { WF_PUSH(__float_as_uint(neg ? ta : tb)); WF_PUSH(neg ? da : db); }
-                    cur = (ha && hb) ? (neg ? db : da) : (ha ? da : db);
+                // visiting order: near child first by the sign of the split axis (bvh.rs:105-119), on both levels -- the record holds the three
+                // decisions for each of the eight direction octants (host/gates.hpp: bit 0 = second child of the node first, bit 1 / 2 = second
+                // slot of the A / B group first); occlusion rays (STAGE 1) visit the child on the LIGHT's side first, i.e. every decision
+                // inverted: the boolean does not depend on the order (until a candidate is accepted max_t is the original one, so one is
+                // accepted iff a valid candidate exists at all), the rays of a light converge there, and what blocks a light tends to sit
+                // near it: +1.4 % on the C5 stand-in.
+                const uint32_t ord = (order >> oct3) ^ (STAGE == 1 ? 7u : 0u);
+                const bool neg_n = (ord & 1u) != 0u, neg_a = (ord & 2u) != 0u, neg_b = (ord & 4u) != 0u;
+                const uint32_t d0 = __float_as_uint(dq.x), d1 = __float_as_uint(dq.y), d2 = __float_as_uint(dq.z), d3 = __float_as_uint(dq.w);
+                const float ta0 = neg_a ? t1 : t0, ta1 = neg_a ? t0 : t1, tb0 = neg_b ? t3 : t2, tb1 = neg_b ? t2 : t3;
+                const uint32_t da0 = neg_a ? d1 : d0, da1 = neg_a ? d0 : d1, db0 = neg_b ? d3 : d2, db1 = neg_b ? d2 : d3;
+                const float v0 = neg_n ? tb0 : ta0, v1 = neg_n ? tb1 : ta1, v2 = neg_n ? ta0 : tb0, v3 = neg_n ? ta1 : tb1;
+                const uint32_t e0 = neg_n ? db0 : da0, e1 = neg_n ? db1 : da1, e2 = neg_n ? da0 : db0, e3 = neg_n ? da1 : db1;
+                const bool g0 = v0 < TR_INF, g1 = v1 < TR_INF, g2 = v2 < TR_INF, g3 = v3 < TR_INF;
+                const bool b1_ = g0, b2_ = g0 | g1, b3_ = g0 | g1 | g2;   // something earlier in the order is hit
+                if (g3 & b3_) WF_PUSH_NODE(__float_as_uint(v3), e3);
+                if (g2 & b2_) WF_PUSH_NODE(__float_as_uint(v2), e2);
+                if (g1 & b1_) WF_PUSH_NODE(__float_as_uint(v1), e1);
+                if (b3_ | g3) {
+                    cur = g0 ? e0 : (g1 ? e1 : (g2 ? e2 : e3));
                     cur_count = nd_count(cur);
                     if (cur_count != 0u) { cur_offset = nd_offset(cur); mode = TM_LEAF; }
                 } else {
@@ -350,7 +416,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                 for (uint32_t k = 0; k < cur_count; ++k) {
                     float t, bb1, bb2;
                     WF_COUNT(c_tri);
-                    if (triangle_test(tris + cur_offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
+                    if (triangle_test(sc.tri_verts + (tri_base + cur_offset + k), mk(oxy.x, oxy.y, ozix.x), d, min_t, max_t, t, bb1, bb2)) {
                         max_t = t;
                         rec.t = t; rec.inst = cur_inst; rec.prim = tri_base + cur_offset + k; rec.b1 = bb1; rec.b2 = bb2;
                         any = true;
@@ -366,6 +432,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
             if (!finished) WF_POP_NODES();
         }
         WF_CLK(2);
+        bool deferred = false;
         if (active && mode == TM_POP && !finished) {
             bool have_node = false;
             while (sp > 0) {
@@ -382,16 +449,21 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                 }
                 if (kind == STK_EXIT_MESH) {   // back to world space and the top-level tree
                     in_mesh = false;
-                    tree = sc.top_nodes;
-                    o = wo; d = wd;
-                    inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
+                    tree = sc.top_quad_first;
+                    d = wd;
+                    WF_SET_RAY(wo, mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z));
+                    WF_SIGNS();
                     continue;
                 }
                 // Instance::intersect (receiver.rs:29-35): world ray -> object ray by `inv`, direction not renormalised. The entry's
                 // 64-byte record (host/gates.hpp: WfInst) holds all of it: one fetch, no dependent second one for static instances
                 const float4* __restrict__ wr = reinterpret_cast<const float4*>(sc.wf_insts + (e & ~STK_KIND_MASK));
                 const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+#ifndef TR_HOST_EMU
+                // (all four words of the last quarter are wanted NOW: hipcc otherwise fetches the flags alone, tests the point-emitter bit and
+                // only then fetches the other three words -- a second dependent round trip for every instance entry)
+                asm volatile("" :: "v"(w3.y), "v"(w3.z), "v"(w3.w));
+#endif
                 const uint32_t wflags = __float_as_uint(w3.x);
                 if (wflags & tray::WI_POINT) continue;   // emitter.rs:120
                 const uint32_t i = __float_as_uint(w3.y);
@@ -413,15 +485,16 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                 }
                 const uint32_t gt = wflags & 7u;
                 if (gt == TRAY_GEOM_MESH) {
+                    const f3 inv_obj = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+                    if (!wf_regular(inv_obj)) { WF_DEFER(); deferred = true; break; }   // (the whole ray: the reference's traversal decides, as at the refill)
                     WF_PUSH(STK_EXIT_MESH);
                     in_mesh = true;
                     cur_inst = i;
-                    tree = sc.mesh_nodes + __float_as_uint(w3.z);
+                    tree = __float_as_uint(w3.z);
                     tri_base = __float_as_uint(w3.w);
-                    tris = sc.tri_verts + tri_base;
-                    o = lo_; d = ld;
-                    inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
+                    d = ld;
+                    WF_SET_RAY(lo_, inv_obj);
+                    WF_SIGNS();
                     cur = 0u; cur_count = 0u;
                     have_node = true;
                     break;
@@ -441,6 +514,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
             if (have_node) mode = cur_count != 0u ? TM_LEAF : TM_NODE;
             else finished = true;
         }
+        if (deferred) { finished = false; active = false; }
         WF_CLK(3);
         if (finished) {   // write the result to the ray's own slot
             uint32_t flags = ray_flags;   // (the slot's F_FLAGS, brought by the ray: nobody else touches the slot while its ray is traced)
@@ -478,7 +552,45 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
 #undef WF_CLK
 #undef WF_PUSH
 #undef WF_POP
+#undef WF_PUSH_NODE
+#undef WF_POP_NODE
 #undef WF_POP_NODES
+#undef WF_DEFER
+#undef WF_SIGNS
+#undef WF_SET_RAY
+}
+
+// The rays k_wf_trace_dyn<STAGE> did not traverse (direction components that are zero, denormal or not finite; about one ray in 1e7 on
+// the bundled scenes): one thread per entry of `fallback`, the reference's own traversal over the binary trees (trace_bvh), the result
+// written exactly as k_wf_trace_dyn writes it. The ray is rebuilt from the pool fields its producer stored next to the queue entry.
+template <int STAGE, int ANIM>
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_fallback(const DevScene scv, WfPool pool, const uint32_t* __restrict__ qctl, const uint32_t* __restrict__ fallback) {
+    const DevScene& sc = scv;
+    TR_DYN_LDS(uint32_t, s_stack);
+    const uint32_t n = qctl[WF_FB_WORD + STAGE];
+    for (uint32_t k = blockIdx.x * TR_BLOCK + threadIdx.x; k < n; k += gridDim.x * TR_BLOCK) {
+        const uint32_t slot = fallback[k];
+        uint32_t flags = pu(pool, F_FLAGS, slot);
+        Ray ray;
+        if (STAGE == 0) { ray.o = ld3(pool, F_O, slot); ray.d = ld3(pool, F_D, slot); ray.min_t = pu(pool, F_BOUNCE, slot) == 0u ? 0.0f : 0.001f; ray.max_t = TR_INF; }
+        else { ray.o = ld3(pool, F_P, slot); ray.d = ld3(pool, F_AUX, slot); ray.min_t = 0.001f; ray.max_t = STAGE == 1 ? 0.999f : TR_INF; }
+        ray.time = ANIM ? pf(pool, F_TIME, slot) : 0.0f;
+        ray.col = slot;
+        HitRec rec;
+        rec.t = 0.0f; rec.inst = 0xffffffffu; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
+        const bool any = trace_bvh<ANIM>(sc, s_stack + threadIdx.x, ray, STAGE == 1, rec);
+        if (STAGE == 1) {
+            flags = any ? (flags | WF_OCCLUDED) : (flags & ~WF_OCCLUDED);
+        } else {
+            const uint32_t bit = STAGE == 0 ? WF_HIT_A : WF_HIT_C;
+            flags = any ? (flags | bit) : (flags & ~bit);
+            if (any) {
+                pf(pool, F_REC_T, slot) = rec.t; pu(pool, F_REC_INST, slot) = rec.inst; pu(pool, F_REC_PRIM, slot) = rec.prim;
+                pf(pool, F_REC_B1, slot) = rec.b1; pf(pool, F_REC_B2, slot) = rec.b2;
+            }
+        }
+        pu(pool, F_FLAGS, slot) = flags;
+    }
 }
 
 // Stage A shading: vertex_begin for the slots whose ray hit, end of the sample for those that missed.

@@ -98,6 +98,157 @@ inline bool pair_trees(const TrayFlatScene* f, PairedTrees& p, bool top_only = f
     return true;
 }
 
+// QuadTrees: the wavefront traversal's view of the same trees (hip/wavefront.h: k_wf_trace_dyn) -- TWO levels of the binary tree per
+// 128-byte record, so a ray's chain of dependent fetches is half as long (a divergent lane's step costs one round trip whatever the
+// record's size once it comes out of HBM: profiles/r03_ubench_gather.txt). The record of an interior node N with children A, B holds
+// up to four SLOTS -- (box, descriptor) pairs -- in the fixed order [A-group | B-group]:
+//     a leaf child C             -> (C)                      its own box, descriptor = (first primitive, count)
+//     an interior child C        -> (C.first, C.second)      the grandchildren's boxes; C's own box is NOT stored
+// and the split axes of N, A and B (meta word 0), from which follows the order in which the reference would reach the slots: near
+// child of N first (bvh.rs:105-119), inside a group the near child of A (of B) -- tabulated per direction octant in meta word 1. The
+// descriptor of an interior slot X is the index of X's own record. Unused slots hold a box no ray enters (every plane at +inf).
+// Why C's own box may be skipped: the reference tests it before it looks at C.first / C.second (bvh.rs:89-92), and a BVH node's box is
+// the exact union of its children's (min / max of floats are exact), so C.first's box lies inside C's componentwise; for a ray whose
+// reciprocal direction is finite and nonzero in every component the slab arithmetic of fast_intersect (bbox.rs:75-104: subtract,
+// multiply, compare -- each monotone, no NaN can arise) then gives tmin(C) <= tmin(C.first) and tmax(C) >= tmax(C.first) axis by axis,
+// hence hit(C.first, max_t) implies hit(C, max_t'), for every max_t' >= max_t: C's test can only fail where both grandchildren's fail.
+// The traversal sends rays with a zero / denormal / non-finite direction component (where -0 * inf and 0 * inf break that argument and
+// the reference's own behaviour is erratic) to the binary trees instead (k_wf_trace_fallback -> trace_bvh). The builder checks the
+// containment for every collapsed child and keeps a child whose box does NOT contain its children's (a caller-built BVH) as a slot of
+// its own with an explicit test, so the result is the reference's for any tree validate_flat_scene admits.
+// Record order: the top `bfs_levels` levels of a tree breadth-first (dense, cache resident), below them depth-first with the records
+// of a node's interior slots adjacent (as pair_tree).
+struct QuadNode {   // 128 B = 8 float4: lo.x, lo.y, lo.z, hi.x, hi.y, hi.z of the 4 slots, 4 descriptors, meta
+    float lo[3][4], hi[3][4];
+    uint32_t desc[4];
+    uint32_t meta[4];   // [0]: axis of N (bits 0-1), of the A-group's node (2-3), of the B-group's node (4-5)
+                        // [1]: the visiting order per direction octant o = (d.x < 0) | (d.y < 0) << 1 | (d.z < 0) << 2, three bits at 3 * o:
+                        //      bit 0 = N's second child first, bit 1 / 2 = the A / B group's second slot first (bvh.rs:105-119 on both levels)
+};
+static_assert(sizeof(QuadNode) == 128, "one record = eight 16-byte loads of one 128-byte line");
+struct QuadTrees {
+    std::vector<QuadNode> top, mesh;     // BVH<Instance>; all BVH<Triangle>s
+    std::vector<uint32_t> mesh_first;    // per mesh: index of its entry record in `mesh`
+    bool narrow = true;                  // every descriptor field fits (23-bit offsets, 5-bit counts)
+    bool ordered = true;                 // every box has min <= max on every axis (no NaN): the traversal's form of the slab test assumes it
+    uint32_t top_pend = 0, mesh_pend = 0;   // most node entries (descriptor + entry distance pairs) a traversal of BVH<Instance> / of one BVH<Triangle> can have pending
+};
+#ifndef TRAY_QUAD_BFS_LEVELS
+#define TRAY_QUAD_BFS_LEVELS 5
+#endif
+inline QuadNode quad_empty_record() {
+    QuadNode q{};
+    // every plane at +inf: whatever the signs of a (regular) ray's direction, the slot's entry distance is +inf or its exit distance -inf
+    for (int a = 0; a < 3; ++a) for (int s = 0; s < 4; ++s) { q.lo[a][s] = INFINITY; q.hi[a][s] = INFINITY; }
+    for (int s = 0; s < 4; ++s) q.desc[s] = 1u << 23;   // (a leaf of one primitive behind a box nothing enters)
+    return q;
+}
+// appends the quad records of the reference-order tree ref[0 .. n) (a tree: pair_tree has accepted it); the entry record is the
+// first one appended. Returns the largest number of node entries a traversal of this tree can have pending at once.
+inline uint32_t quad_tree(const TrayBvhNode* ref, uint32_t n, std::vector<QuadNode>& out, bool& narrow, bool& ordered, uint32_t bfs_levels = TRAY_QUAD_BFS_LEVELS) {
+    if (n == 0u) { out.push_back(quad_empty_record()); return 1u; }
+    const size_t base = out.size();
+    const uint32_t none = 0xffffffffu;
+    auto is_leaf = [&](uint32_t i) { return ref[i].count != 0; };
+    auto inside = [&](uint32_t c, uint32_t p) {   // box of c within box of p, componentwise (false for NaNs)
+        for (int a = 0; a < 3; ++a) if (!(ref[c].bmin[a] >= ref[p].bmin[a] && ref[c].bmax[a] <= ref[p].bmax[a])) return false;
+        return true;
+    };
+    auto collapsible = [&](uint32_t i) {   // an interior node whose own box test is implied by its children's
+        return !is_leaf(i) && i + 1u < n && ref[i].offset < n && inside(i + 1u, i) && inside(ref[i].offset, i);
+    };
+    // a record to fill: the slots of interior node `node` (wrap: `node` itself as the only slot -- a leaf root, or a root whose box
+    // does not contain its children's); pend: node entries pending on the stack when the traversal expands this record
+    struct Job { uint32_t node, rec, level, pend; bool wrap; };
+    uint32_t worst = 0u;
+    auto alloc = [&] { out.push_back(quad_empty_record()); return (uint32_t)(out.size() - base - 1u); };
+    // fills j's record; the records of its interior slots are allocated adjacently in slot order and their jobs appended to `next`
+    // (reverse: last slot first, for a stack whose top is processed next)
+    auto fill = [&](const Job j, std::vector<Job>& next, bool reverse) {
+        uint32_t slot_node[4] = {none, none, none, none};
+        uint32_t axes = 0u;
+        if (j.wrap) slot_node[0] = j.node;
+        else {
+            const uint32_t c[2] = {j.node + 1u, ref[j.node].offset};
+            axes = (uint32_t)ref[j.node].axis & 3u;
+            for (int g = 0; g < 2; ++g) {
+                if (collapsible(c[g])) {
+                    slot_node[2 * g] = c[g] + 1u; slot_node[2 * g + 1] = ref[c[g]].offset;
+                    axes |= ((uint32_t)ref[c[g]].axis & 3u) << (2 + 2 * g);
+                } else slot_node[2 * g] = c[g];
+            }
+        }
+        uint32_t used = 0u;
+        for (int s = 0; s < 4; ++s) used += slot_node[s] != none ? 1u : 0u;
+        // of the slots hit, all but the one the traversal goes on with are pushed
+        const uint32_t pend = j.pend + used - 1u;
+        worst = std::max(worst, pend);
+        Job kids[4];
+        int n_kids = 0;
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t x = slot_node[s];
+            if (x == none) continue;
+            uint32_t desc;
+            if (is_leaf(x)) {
+                if (ref[x].offset > 0x7fffffu || ref[x].count > 31u) narrow = false;
+                desc = (ref[x].offset & 0x7fffffu) | ((uint32_t)std::min<uint32_t>(ref[x].count, 31u) << 23);
+            } else {
+                const uint32_t r = alloc();   // (may move `out`: the record is addressed by index below)
+                if (r > 0x7fffffu) narrow = false;
+                desc = r & 0x7fffffu;
+                kids[n_kids++] = Job{x, r, j.level + 1u, pend, false};
+            }
+            QuadNode& q = out[base + j.rec];
+            for (int a = 0; a < 3; ++a) {
+                q.lo[a][s] = ref[x].bmin[a]; q.hi[a][s] = ref[x].bmax[a];
+                if (!(ref[x].bmin[a] <= ref[x].bmax[a])) ordered = false;
+            }
+            q.desc[s] = desc;
+        }
+        out[base + j.rec].meta[0] = axes;
+        uint32_t order = 0u;
+        for (uint32_t oct = 0; oct < 8u; ++oct) {
+            const uint32_t neg_n = (oct >> (axes & 3u)) & 1u, neg_a = (oct >> ((axes >> 2) & 3u)) & 1u, neg_b = (oct >> ((axes >> 4) & 3u)) & 1u;
+            order |= (neg_n | (neg_a << 1) | (neg_b << 2)) << (3u * oct);
+        }
+        out[base + j.rec].meta[1] = order;
+        if (reverse) for (int k = n_kids - 1; k >= 0; --k) next.push_back(kids[k]);
+        else for (int k = 0; k < n_kids; ++k) next.push_back(kids[k]);
+    };
+    // breadth-first for the top levels ...
+    std::vector<Job> bfs, dfs_roots;
+    bfs.push_back(Job{0u, alloc(), 0u, 0u, is_leaf(0u) || !collapsible(0u)});
+    for (size_t head = 0; head < bfs.size(); ++head) {
+        const Job j = bfs[head];
+        if (!j.wrap && j.level >= bfs_levels) dfs_roots.push_back(j);
+        else fill(j, bfs, false);
+    }
+    // ... depth-first below them (a slot's subtree follows the records of its siblings)
+    std::vector<Job> st;
+    for (const Job& root : dfs_roots) {
+        st.push_back(root);
+        while (!st.empty()) {
+            const Job j = st.back();
+            st.pop_back();
+            fill(j, st, true);
+        }
+    }
+    return worst + 1u;
+}
+inline void quad_trees(const TrayFlatScene* f, QuadTrees& q, bool top_only = false, uint32_t bfs_levels = TRAY_QUAD_BFS_LEVELS) {
+    q.top.clear();
+    q.top_pend = quad_tree(f->top_nodes, f->n_top_nodes, q.top, q.narrow, q.ordered, bfs_levels);
+    if (top_only) return;
+    q.mesh.clear();
+    q.mesh_first.assign(f->n_meshes, 0u);
+    q.mesh_pend = 0u;
+    for (uint32_t m = 0; m < f->n_meshes; ++m) {
+        const TrayMesh& me = f->meshes[m];
+        q.mesh_first[m] = (uint32_t)q.mesh.size();
+        q.mesh_pend = std::max(q.mesh_pend, quad_tree(f->mesh_nodes + me.node_offset, me.node_count, q.mesh, q.narrow, q.ordered, bfs_levels));
+    }
+}
+
 // One 64-byte record per BVH<Instance> leaf slot (top_order), for the wavefront traversal (hip/wavefront.h): everything an instance
 // entry needs -- rows 0..2 of world -> object, what the instance is, and where its tree / what its parameters are -- in ONE
 // fetch addressed by the stack entry itself, instead of the chain top_order -> TrayInstance (kind, animated, geom_type, inv at four
@@ -108,11 +259,11 @@ struct WfInst {
     float inv[12];
     uint32_t flags;   // bits 0-2 geom_type, WI_* bits, moving_slot << 8
     uint32_t inst;    // index in instances[]
-    union { float gp[2]; uint32_t tree[2]; };   // geometry parameters | first node of the BVH<Triangle> in mesh_nodes, first triangle in tri_verts
+    union { float gp[2]; uint32_t tree[2]; };   // geometry parameters | entry record of the BVH<Triangle> in mesh_quads (QuadTrees), first triangle in tri_verts
 };
 static_assert(sizeof(WfInst) == 64, "one record = one 64-byte fetch");
 enum : uint32_t { WI_POINT = 1u << 3, WI_ANIMATED = 1u << 4, WI_AFFINE = 1u << 5 };
-inline void wf_inst_records(const TrayFlatScene* f, const std::vector<TrayMesh>& paired_meshes, std::vector<WfInst>& out) {
+inline void wf_inst_records(const TrayFlatScene* f, const std::vector<uint32_t>& quad_first, std::vector<WfInst>& out) {
     out.assign(f->n_top_order, WfInst{});
     for (uint32_t k = 0; k < f->n_top_order; ++k) {
         WfInst& r = out[k];
@@ -125,9 +276,9 @@ inline void wf_inst_records(const TrayFlatScene* f, const std::vector<TrayMesh>&
         if (in.kind == TRAY_INST_POINT_EMITTER) r.flags |= WI_POINT;
         if (in.animated) r.flags |= WI_ANIMATED | (in.moving_slot << 8);
         if (in.inv[12] == 0.0f && in.inv[13] == 0.0f && in.inv[14] == 0.0f && in.inv[15] == 1.0f) r.flags |= WI_AFFINE;
-        if (in.geom_type == TRAY_GEOM_MESH && in.mesh_id < paired_meshes.size()) {
-            r.tree[0] = paired_meshes[in.mesh_id].node_offset;
-            r.tree[1] = paired_meshes[in.mesh_id].tri_offset;
+        if (in.geom_type == TRAY_GEOM_MESH && in.mesh_id < quad_first.size() && in.mesh_id < f->n_meshes) {
+            r.tree[0] = quad_first[in.mesh_id];
+            r.tree[1] = f->meshes[in.mesh_id].tri_offset;
         } else {
             r.gp[0] = in.geom_params[0]; r.gp[1] = in.geom_params[1];
         }
