@@ -67,7 +67,16 @@ def device_code_hash():
         return None
 
 
-VALU_PEAK_TLANE = 256 * 4 * 32 * 2.4e9 / 1e12   # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 at 2.4 GHz = 78.6e12 lane-instructions/s (plain, unpacked VALU)
+# VALU peak, MEASURED (profiles/r04_ubench_valu.txt, tools/ubench_valu.hip): under a pure VALU load the shader clock holds 2.24 - 2.40 GHz
+# (s_memtime against the 100 MHz s_memrealtime) and a SIMD retires one plain wave64 instruction (v_mul_f32 / v_add_f32 / v_mov_b32 /
+# v_xor_b32) every 3.8 cycles at >= 4 waves per SIMD (4.05 at 2; v_fma_f32 3.05; the guide's nominal figure is 2) -- 64 lanes each.
+# Packed f32 (v_pk_mul_f32 / v_pk_add_f32: two f32 per lane) costs 4.5 - 4.9 cycles at >= 4 waves, 5.9 at 2: 0.6 - 0.73 of the plain price
+# per f32. The peak below is the plain rate; a kernel made of packed instructions could exceed it by up to 1.6x.
+VALU_CLOCK_GHZ = 2.33
+VALU_CYCLES_PER_WAVE_INSTRUCTION = 3.8
+VALU_PEAK_TLANE = 256 * 4 * 64 * VALU_CLOCK_GHZ * 1e9 / VALU_CYCLES_PER_WAVE_INSTRUCTION / 1e12   # 40.2e12 lane-instructions/s
+VALU_PEAK_NOTE = ("peak = MEASURED issue rate of plain VALU instructions: 256 CUs x 4 SIMDs x 64 lanes per 3.8 cycles at 2.33 GHz under load "
+                  "(profiles/r04_ubench_valu.txt; the nominal 2 cycles per wave64 instruction at 2.4 GHz would be 78.6)")
 
 
 def pmc_views(workload, samples, kernel_seconds):
@@ -78,16 +87,19 @@ def pmc_views(workload, samples, kernel_seconds):
     valu.achieved = VALU wave-instructions x 64 x lane utilisation (= active lane-instructions, from SQ_INSTS_VALU and
     SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU) per sample x this launch's samples / this launch's HIP-event seconds."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    static = None
+    have = device_code_hash()
+    static = None   # static registers of the tile kernel: only those of THIS device code (tools/static_registers.sh records the hash)
     try:
         static = json.load(open(os.path.join(ROOT, "profiles", "static_registers_latest.json")))
+        if not have or static.get("device_code_hash") != have:
+            static = {"note": f"profiles/static_registers_latest.json belongs to device code {static.get('device_code_hash')}, this library is {have}: "
+                              "re-run tools/static_registers.sh"}
     except Exception:
         pass
     try:
         p = json.load(open(path))
     except Exception:
         return None, None, {"source": None, "note": "no profiles/pmc_latest.json", "static": static}
-    have = device_code_hash()
     if not have or have != p.get("device_code_hash"):
         return None, None, {"source": "profiles/pmc_latest.json", "static": static,
                             "note": f"counters belong to device code {p.get('device_code_hash')}, this library is {have}: re-run tools/pmc_workloads.py"}
@@ -102,8 +114,7 @@ def pmc_views(workload, samples, kernel_seconds):
         achieved = lane_instr / kernel_seconds / 1e12
         valu = {"achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANE, 2), "unit": "T lane-instructions/s", "frac": round(achieved / VALU_PEAK_TLANE, 4),
                 "wave_instructions_per_sample": round(d["valu_instructions_per_sample"], 1), "lane_utilisation": round(d["valu_lane_utilisation"], 4),
-                "note": "peak = nominal issue rate of plain VALU instructions (256 CUs x 4 SIMD-32 x 2.4 GHz); the SQ counters show the VALU pipe "
-                        f"{d.get('valu_busy', 0.0):.2f} time-busy at this rate" if d.get("valu_busy") else "peak = nominal issue rate of plain VALU instructions"}
+                "note": VALU_PEAK_NOTE + (f"; the SQ counters show the VALU pipe {d.get('valu_busy', 0.0):.2f} time-busy" if d.get("valu_busy") else "")}
     compute = {"source": "profiles/pmc_latest.json (rocprofv3 --pmc passes around a %d-spp launch of this device code, tools/pmc_workloads.py)" % d.get("spp", 0),
                "device_code_hash": have, "kernel": d.get("kernel"),
                "valu_busy": d.get("valu_busy"), "valu_lane_util": d.get("valu_lane_utilisation"),
@@ -166,8 +177,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_workload(name, want_spp, steps, warmup, warmup_spp=None):
-        """K timed frames of one workload, bracketed as the contract says; returns the measurements of this rank (and the scene)"""
+    def run_workload(name, want_spp, steps, warmup, warmup_spp=None, frames=1):
+        """K timed steps of one workload (a step = one frame, or a sequence of `frames` frames of the moving workload), bracketed as the
+        contract says; returns the measurements of this rank (and the scene)"""
         tmp = tempfile.mkdtemp(prefix=f"traybench{rank}_")
         frame = args.frame if name == "tr15_like" else 0
         if name == "dragon":
@@ -179,11 +191,11 @@ def main():
         scene, rt, spp, frame_info = T.Scene.load_file(os.path.join(tmp, name + ".json"))
         spp = T.round_spp(spp)
 
-        seq = name == "tr15_like" and args.frames > 1
+        seq = name == "tr15_like" and frames > 1
 
         def step(step_spp):
             if seq:   # this rank's frames of the sequence, one after the other through the same device scene
-                for fr in multi.shard_frames(frame, frame + args.frames - 1, rank, world):
+                for fr in multi.shard_frames(frame, frame + frames - 1, rank, world):
                     film.zero_()
                     hip.render_device(scene, fr, (0, 0), step_spp, film.data_ptr(), stream=stream)
                     seq_counts.append(hip.timing(scene))   # (synchronises: the next frame's update waits for the device anyway)
@@ -225,7 +237,7 @@ def main():
         else:
             total_samples, total_vertices = float(samples), float(vertices)
         return {"name": name, "scene": scene, "frame": frame, "spp": spp, "steps": steps, "elapsed": elapsed, "kernel_ms": sum(kernel_ms) / len(kernel_ms),
-                "n_frames": args.frames if seq else 1,
+                "n_frames": frames if seq else 1,
                 "samples": samples, "vertices": vertices, "launches": launches, "total_samples": total_samples, "total_vertices": total_vertices}
 
     def line_of(m):
@@ -264,7 +276,7 @@ def main():
                   "vertices_per_sample": round(vbar, 4)}
         return value, ms_per_step, config, roofline
 
-    main_m = run_workload(args.workload, args.spp or default_spp[args.workload], args.steps, args.warmup)
+    main_m = run_workload(args.workload, args.spp or default_spp[args.workload], args.steps, args.warmup, frames=args.frames)
     if rank == 0:
         value, ms_per_step, config, roofline = line_of(main_m)
         out = {
@@ -277,12 +289,18 @@ def main():
     # count, then full-size frames -- so that the driver's own run sees every workload, not only cornell_box
     if world == 1 and args.workload == "cornell_box" and not args.spp and not args.no_other_workloads:
         others = []
-        for name, steps in (("smallpt", 2), ("dragon", 2), ("tr15_like", 1)):
-            m = run_workload(name, default_spp[name], steps, 1, warmup_spp=16)
+        # (configs[4] is a SEQUENCE: the tr15 stand-in runs two consecutive frames per step, the device scene moved from one to the next with
+        # tray_scene_update_frame inside the timed region; `frame_kernel_value` is the rate of the frames' kernels alone, HIP events)
+        for name, steps, frames in (("smallpt", 2, 1), ("dragon", 2, 1), ("tr15_like", 1, 2)):
+            m = run_workload(name, default_spp[name], steps, 1, warmup_spp=16, frames=frames)
             v, ms, cfg, rf = line_of(m)
-            others.append({"workload": cfg["workload"], "schedule": cfg["schedule"], "value": round(v, 3), "unit": "Msamples/s", "steps": steps,
-                           "warmup": "1 launch at 16 spp", "ms_per_step": round(ms, 3), "vertices_per_sample": cfg["vertices_per_sample"],
-                           "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu", "kernel", "kernel_ms")}})
+            entry = {"workload": cfg["workload"], "schedule": cfg["schedule"], "value": round(v, 3), "unit": "Msamples/s", "steps": steps,
+                     "warmup": "1 launch at 16 spp", "ms_per_step": round(ms, 3), "vertices_per_sample": cfg["vertices_per_sample"],
+                     "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu", "kernel", "kernel_ms")}}
+            if frames > 1:
+                entry["frames_per_step"] = frames
+                entry["frame_kernel_value"] = round(m["samples"] / (m["kernel_ms"] * 1e-3) / 1e6, 3)
+            others.append(entry)
         out["workloads"] = others
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

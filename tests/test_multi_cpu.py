@@ -94,6 +94,60 @@ def test_frames_shard_round_robin():
     assert multi.shard_frames(5, 6, 3, 8) == [] and multi.shard_frames(5, 6, 1, 8) == [6]
 
 
+def _frame_worker(rank, world, port, scene_path, out_dir, first, last):
+    """BASELINE.json configs[4] on two ranks: the frames of a sequence dealt round-robin (multi.shard_frames), every rank renders WHOLE
+    frames with the tile worker's device code (host emulation) and writes them itself -- frames are independent (main.rs:91-106), there is
+    no collective on the data path; the process group only provides the ranks and the final barrier."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import tray_rust_amd as T
+    from tray_rust_amd import multi
+    import _emu as E
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene, rt, spp, fi = T.Scene.load_file(scene_path)
+    tiles = np.array(T.BlockQueue((rt.width, rt.height), (8, 8)).blocks, np.uint32).reshape(-1, 2)
+    mine = multi.shard_frames(first, last, rank, world)
+    for fr in mine:
+        img, _ = E.render_tiles(scene.flatten(fr), tiles, spp, 11, blocks=2)
+        np.save(os.path.join(out_dir, f"frame{fr}_rank{rank}.npy"), img)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_render_the_frames_of_a_sequence(tmp_path, built):
+    """frames f .. f+2 of the moving test scene over two ranks: rank 0 gets f and f+2, rank 1 gets f+1; every frame equals the one a single
+    process renders with the same device code, bit for bit (nothing is merged), and no frame is rendered twice or left out"""
+    import glob
+    import torch.multiprocessing as mp
+    import tray_rust_amd as T
+    from tray_rust_amd import scenes
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _emu as E
+    d = str(tmp_path)
+    scenes.write_moving_box(d, width=32, height=24, samples=4)
+    scene_path = os.path.join(d, "moving_box.json")
+    E.emu()
+    first, last = 2, 4
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_frame_worker, args=(2, port, scene_path, d, first, last), nprocs=2, join=True)
+    files = sorted(os.path.basename(f) for f in glob.glob(os.path.join(d, "frame*_rank*.npy")))
+    assert files == ["frame2_rank0.npy", "frame3_rank1.npy", "frame4_rank0.npy"]
+    scene, rt, spp, fi = T.Scene.load_file(scene_path)
+    tiles = np.array(T.BlockQueue((rt.width, rt.height), (8, 8)).blocks, np.uint32).reshape(-1, 2)
+    frames = []
+    for fr, name in zip(range(first, last + 1), files):
+        flat = scene.flatten(fr)
+        assert flat.contents.animated
+        one, _ = E.render_tiles(flat, tiles, spp, 11, blocks=2)
+        got = np.load(os.path.join(d, name))
+        assert got.tobytes() == one.tobytes(), f"frame {fr}"
+        assert (got[..., 3] > 0).all()
+        frames.append(got)
+    assert np.abs(frames[0] - frames[1]).max() > 1e-3      # the box moves: consecutive frames differ
+
+
 # ---- the same two-rank flow with the REAL per-rank renderer (tray_render_shard_device) and RCCL: needs two GPUs ----
 def _gpu_worker(rank, world, port, scene_path, out_path):
     sys.path.insert(0, ROOT)

@@ -211,7 +211,7 @@ class Hip:
         self.device, self.seed = int(device), int(seed)
         check(lib().tray_init(self.device))
         self.last_timing = None
-        self._multi, self._multi_key, self._multi_frame = None, None, None
+        self._multi, self._multi_key, self._multi_frame, self._multi_scene = None, None, None, None
 
     def render(self, scene, rt, config):
         spp = round_spp(config.spp)
@@ -244,15 +244,18 @@ class Hip:
         The per-device scenes and the communicators are kept between calls: another frame of the same scene on the same devices
         is a tray_multi_update_frame (scene.rs:152-176), not a new ncclCommInitAll. close_multi() releases them."""
         spp = round_spp(config.spp)
-        key = (id(scene), tuple(int(d) for d in devices))
-        if self._multi is not None and self._multi_key != key:
+        key = tuple(int(d) for d in devices)
+        # the cached device copies belong to ONE scene object, held by a strong reference and compared by identity: an id() alone
+        # could be reused by another Scene allocated at the same address after this one was collected, and that scene's frame would
+        # then be grafted onto the old one's meshes and tables by tray_multi_update_frame
+        if self._multi is not None and (self._multi_scene is not scene or self._multi_key != key):
             self.close_multi()
         flat = scene.flatten(config.current_frame)
         if self._multi is None:
             ids = (C.c_int * len(devices))(*[int(d) for d in devices])
             m = C.c_void_p()
             check(lib().tray_multi_create(flat, len(devices), ids, C.byref(m)))
-            self._multi, self._multi_key, self._multi_frame = m, key, config.current_frame
+            self._multi, self._multi_key, self._multi_frame, self._multi_scene = m, key, config.current_frame, scene
         elif self._multi_frame != config.current_frame:
             try:
                 check(lib().tray_multi_update_frame(self._multi, flat))
@@ -270,6 +273,7 @@ class Hip:
         if self._multi is not None:
             lib().tray_multi_destroy(self._multi)
             self._multi = None
+        self._multi_scene = None
 
     def __del__(self):
         try:

@@ -523,11 +523,37 @@ __global__ __launch_bounds__(64) void k_debug_bsdf(const DevScene scv, uint32_t 
 #define WF_PIPES_MAX 4   // views of the wavefront schedule (WfView below) the buffers are sized for
 #endif
 struct TrayDevBuf { const char* key; void* ptr; size_t bytes; };
+// What tray_scene_update_frame requires of its argument: the SAME scene at another frame. The device buffers a frame update takes
+// over without a copy (meshes, trees, triangles, MERL tables, textures, permutation pool, filter tables) are recognised by name and size
+// only, so the sizes and parameters they depend on are recorded at creation and compared before anything is moved.
+struct TraySceneIdentity {
+    uint32_t n_instances, n_meshes, n_mesh_nodes, n_tris, n_materials, n_merl, n_textures, n_tex_frames, max_depth, min_depth, integrator, width, height;
+    uint64_t n_merl_floats, n_tex_bytes;
+    float filter[4];
+    int32_t filter_px[2];
+    uint32_t filter_hash;
+    bool operator==(const TraySceneIdentity& o) const { return std::memcmp(this, &o, sizeof *this) == 0; }
+};
+static TraySceneIdentity scene_identity(const TrayFlatScene* f) {
+    TraySceneIdentity id;
+    std::memset(&id, 0, sizeof id);   // (padding bytes take part in the comparison)
+    id.n_instances = f->n_instances; id.n_meshes = f->n_meshes; id.n_mesh_nodes = f->n_mesh_nodes; id.n_tris = f->n_tris; id.n_materials = f->n_materials;
+    id.n_merl = f->n_merl; id.n_textures = f->n_textures; id.n_tex_frames = f->n_tex_frames; id.max_depth = f->max_depth; id.min_depth = f->min_depth;
+    id.integrator = f->integrator; id.width = f->film.width; id.height = f->film.height;
+    id.n_merl_floats = f->n_merl_floats; id.n_tex_bytes = f->n_tex_bytes;
+    id.filter[0] = f->film.filter_w; id.filter[1] = f->film.filter_h; id.filter[2] = f->film.inv_w; id.filter[3] = f->film.inv_h;
+    id.filter_px[0] = f->film.filter_pixel_w; id.filter_px[1] = f->film.filter_pixel_h;
+    uint32_t h = 2166136261u;   // FNV-1a over the filter table's bits
+    for (int k = 0; k < TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE; ++k) { uint32_t w; std::memcpy(&w, &f->film.table[k], 4); h = (h ^ w) * 16777619u; }
+    id.filter_hash = h;
+    return id;
+}
 struct TrayDeviceScene {
     int device = 0;
     DevScene dev{};
     std::vector<void*> allocs;
     std::vector<TrayDevBuf> bufs;        // the named uploads among `allocs`: what tray_scene_update_frame can carry over to the next frame
+    TraySceneIdentity identity{};
     TrayDeviceScene* donor = nullptr;    // while a frame update builds the new state: the previous frame's scene, whose buffers may be taken
     size_t xf_cache_bytes = 0;
     bool broken = false;                 // a frame update failed half way: only tray_scene_destroy is valid
@@ -654,26 +680,27 @@ static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, ui
     // (each traversal is followed by the few-thread kernel that traces the rays it handed over to the reference's binary traversal:
     // direction components that are zero / denormal / not finite -- normally none, the kernel reads one word and exits)
     const dim3 fgrid(8);
-    static const int wf_exp = getenv("TRAYHIP_WF_EXPERIMENT") ? atoi(getenv("TRAYHIP_WF_EXPERIMENT")) : 0;   // MEASUREMENT ONLY (wrong images): 1 = no fallback launches, 2 = no stage C
     hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qa, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.fallback);
-    if (!(wf_exp & 1)) hipLaunchKernelGGL((k_wf_trace_fallback<0, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.fallback);
+    hipLaunchKernelGGL((k_wf_trace_fallback<0, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.fallback);
     hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, v.dev, v.pool, n_active, s->d_stats, v.qb, v.qctl, v.kq);
     hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qb, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.fallback);
-    if (!(wf_exp & 1)) hipLaunchKernelGGL((k_wf_trace_fallback<1, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.fallback);
+    hipLaunchKernelGGL((k_wf_trace_fallback<1, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.fallback);
     if (v.kq) {   // kind-pure shading over the sorted queues: one launch per material kind the scene contains
 #define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), qgrid, block, 0, stream, v.dev, v.pool, v.kq, v.qc, v.qctl, s->d_stats)
         WF_QUERY_KIND(TRAY_MAT_MATTE); WF_QUERY_KIND(TRAY_MAT_PLASTIC); WF_QUERY_KIND(TRAY_MAT_METAL); WF_QUERY_KIND(TRAY_MAT_GLASS);
         WF_QUERY_KIND(TRAY_MAT_ROUGH_GLASS); WF_QUERY_KIND(TRAY_MAT_SPECULAR_METAL); WF_QUERY_KIND(TRAY_MAT_MERL);
 #undef WF_QUERY_KIND
     } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT_ALL | FEAT_TEX>), grid, block, 0, stream, v.dev, v.pool, n_active, v.qc, v.qctl, s->d_stats);
-    if (!(wf_exp & 2)) hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qc, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.fallback);
-    if (!(wf_exp & 1)) hipLaunchKernelGGL((k_wf_trace_fallback<2, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.fallback);
+    hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qc, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.fallback);
+    hipLaunchKernelGGL((k_wf_trace_fallback<2, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.fallback);
 }
 
 // Path pool slots of the wavefront schedule: never more than the film has pixels x 4 (one chunk of 256 per tile), and for moving
 // scenes never more than the per-path transform cache (n_moving x 96 B per slot) can hold within a quarter of the device's
 // free memory -- 64 moving instances at 8 M slots would be 51 GB, although a few hundred thousand slots already fill the chip
-static uint32_t wf_slot_count(const TrayDeviceScene* s) {
+// reclaimable: bytes a frame update's donor still holds that the new frame either takes over or frees (its pool and transform cache):
+// they count as free, or the budget -- and with it the pool size -- would depend on which frame came first
+static uint32_t wf_slot_count(const TrayDeviceScene* s, size_t reclaimable = 0) {
     uint32_t n_slots = WF_SLOTS;
     if (const char* e = getenv("TRAYHIP_WF_SLOTS")) n_slots = (uint32_t)std::max(256l, atol(e)) / TR_BLOCK * TR_BLOCK;
     const uint64_t by_tiles = (uint64_t)std::max<uint32_t>(s->n_tiles, 1u) * TR_BLOCK;
@@ -681,7 +708,7 @@ static uint32_t wf_slot_count(const TrayDeviceScene* s) {
     if (s->animated && s->deferred_n_moving > 0) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
-        uint64_t budget = free_b / 4;
+        uint64_t budget = (free_b + reclaimable) / 4;
         if (const char* e = getenv("TRAYHIP_XF_CACHE_BYTES")) budget = (uint64_t)std::max(0ll, atoll(e));
         const uint64_t per_slot = (uint64_t)s->deferred_n_moving * 24u * sizeof(float);
         const uint64_t fit = budget / per_slot / TR_BLOCK * TR_BLOCK;
@@ -784,6 +811,7 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         if (in.geom_type == TRAY_GEOM_MESH && in.mesh_id >= f->n_meshes) { set_error("instance references a missing mesh"); return TRAY_E_INVALID; }
     }
     TrayDeviceScene* s = new TrayDeviceScene();
+    s->identity = scene_identity(f);
     s->device = donor ? donor->device : g_device;
     s->donor = donor;
     if (hipSetDevice(s->device) != hipSuccess) { delete s; set_error("hipSetDevice failed (is a GPU present?)"); return TRAY_E_DEVICE; }
@@ -1084,7 +1112,8 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         // one column per pool slot / per thread; a frame update keeps the previous frame's pool size (the budget of wf_slot_count is a
         // share of the memory that was free BEFORE the pool existed)
         const bool keep_lanes = donor && donor->dev.xf_cache_lanes != 0u && donor->wavefront == s->wavefront && (s->wavefront || donor->n_blocks == s->n_blocks);
-        const uint32_t lanes = keep_lanes ? donor->dev.xf_cache_lanes : (s->wavefront ? wf_slot_count(s) : (uint32_t)s->n_blocks * TR_BLOCK);
+        const size_t reclaimable = donor ? donor->xf_cache_bytes + (donor->pool.data ? (size_t)F_COUNT * donor->pool.n_slots * sizeof(float) : 0) : 0;
+        const uint32_t lanes = keep_lanes ? donor->dev.xf_cache_lanes : (s->wavefront ? wf_slot_count(s, reclaimable) : (uint32_t)s->n_blocks * TR_BLOCK);
         const uint32_t n_moving_for_msg = s->deferred_n_moving;
         void* cache = nullptr;
         const size_t cache_bytes = (size_t)s->deferred_n_moving * 24u * lanes * sizeof(float);
@@ -1140,16 +1169,25 @@ int tray_scene_create(const TrayFlatScene* f, TrayDeviceScene** out) { return sc
 // tray_scene_create (schedule, kernel instantiation, stack depth, occupancy) is taken again for the new frame.
 int tray_scene_update_frame(TrayDeviceScene* s, const TrayFlatScene* f) {
     if (!s || !f) { set_error("tray_scene_update_frame: null argument"); return TRAY_E_INVALID; }
-    if (f->n_tris != 0u && s->dev.tri_verts == nullptr) { set_error("tray_scene_update_frame: not the scene this device copy was created from"); return TRAY_E_INVALID; }
     if (f->film.width != s->dev.width || f->film.height != s->dev.height) { set_error("tray_scene_update_frame: the film size changed: create a new device scene"); return TRAY_E_INVALID; }
+    // nothing has moved yet: a scene that is not the one this copy was created from is refused and the handle stays usable
+    if (!(scene_identity(f) == s->identity)) {
+        set_error("tray_scene_update_frame: not the scene this device copy was created from (mesh / triangle / material / table counts, depths, integrator or filter differ)");
+        return TRAY_E_INVALID;
+    }
     HIP_CHECK(hipSetDevice(s->device));
     HIP_CHECK(hipDeviceSynchronize());   // (launches of the previous frame read the buffers that are about to be overwritten)
     TrayDeviceScene* n = nullptr;
     const int before = g_device;
     g_device = s->device;
+    const size_t owned_before = s->allocs.size();
     const int rc = scene_build(f, s, &n);
     g_device = before;
-    if (rc != TRAY_OK) { s->donor = nullptr; s->broken = true; return rc; }   // buffers may have moved already: the handle can only be destroyed now
+    if (rc != TRAY_OK) {   // if a buffer has moved to the half-built (and now destroyed) new state the handle can only be destroyed; a refusal before that leaves it as it was
+        s->donor = nullptr;
+        if (s->allocs.size() != owned_before) s->broken = true;
+        return rc;
+    }
     std::swap(*s, *n);        // the handle keeps its identity; n now owns what the new frame did not take over
     tray_scene_destroy(n);
     return TRAY_OK;

@@ -643,8 +643,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
         if (queue_b && (ln.flags & LF_SHADOW) && !ln.bsdf.mat->textured) {
             const DevMaterial* __restrict__ m = ln.bsdf.mat;
             uint32_t types = 0u;
-            static_assert(sizeof(m->lobe) / sizeof(m->lobe[0]) == 2, "the loop below looks at every lobe a material can have");
-            for (uint32_t l = 0; l < m->n_lobes && l < 2u; ++l) types |= m->lobe[l].type;
+            constexpr uint32_t kMaxLobes = sizeof(m->lobe) / sizeof(m->lobe[0]);   // every lobe a material can have
+            for (uint32_t l = 0; l < m->n_lobes && l < kMaxLobes; ++l) types |= m->lobe[l].type;
             const float zo = -dot(ln.d, ln.bsdf.n), zi = dot(ln.wi_l, ln.bsdf.n);
             const bool same_side = (zo > 0.0f && zi > 0.0f) || (zo < 0.0f && zi < 0.0f);
             if (!(types & BX_TRANSMISSION) && !same_side) { ln.flags &= ~LF_SHADOW; dark = true; }

@@ -453,7 +453,9 @@ inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::str
             }
         } else if (m == 0xc0 || m == 0xc1) {   // SOF0 / SOF1: sequential Huffman
             if (len < 8 || f[seg] != 8) { err = "JPEG: only 8-bit samples are supported"; return false; }
+            if (have_frame) { err = "JPEG: more than one frame header"; return false; }   // (a second SOF would meet the first one's sampling factors and planes)
             height = be16(seg + 1); width = be16(seg + 3);
+            if ((size_t)width * (size_t)height > ((size_t)1 << 28)) { err = "JPEG: image larger than 2^28 pixels"; return false; }   // (planes are allocated from the header alone)
             const int nc = f[seg + 5];
             if ((nc != 1 && nc != 3) || width <= 0 || height <= 0 || seg + 6 + 3 * (size_t)nc > end) { err = "JPEG: unsupported frame (1 or 3 components)"; return false; }
             comps.assign((size_t)nc, JpegComp());
@@ -475,6 +477,7 @@ inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::str
             adobe_transform = f[seg + 11];
         } else if (m == 0xda) {   // SOS + entropy-coded data
             if (!have_frame) { err = "JPEG: scan before frame header"; return false; }
+            if (len < 3 || seg >= end) { err = "JPEG: bad scan header"; return false; }   // (the component count is the first byte of the segment's body)
             const int ns = f[seg];
             if (ns < 1 || ns > (int)comps.size() || seg + 1 + 2 * (size_t)ns + 3 > end) { err = "JPEG: bad scan header"; return false; }
             std::vector<JpegComp*> sc;
@@ -586,14 +589,16 @@ inline bool load_image(const std::string& path, ImageRGBA8& out, std::string& er
     if (!in) { err = "cannot open " + path; return false; }
     std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
     static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-    if (f.size() >= 8 && !std::memcmp(f.data(), png_sig, 8)) return img_detail::decode_png(f, out, err);
-    if (f.size() >= 3 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) return img_detail::decode_pnm(f, out, err);
-    if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') return img_detail::decode_bmp(f, out, err);
-    if (f.size() >= 3 && f[0] == 0xff && f[1] == 0xd8) return img_detail::decode_jpeg(f, out, err);
+    bool ok;
     const size_t dot = path.rfind('.');
-    if (dot != std::string::npos && (path.substr(dot) == ".tga" || path.substr(dot) == ".TGA")) return img_detail::decode_tga(f, out, err);
-    err = "unrecognised image format (PNG, baseline JPEG, binary PPM / PGM, BMP and TGA are supported)";
-    return false;
+    if (f.size() >= 8 && !std::memcmp(f.data(), png_sig, 8)) ok = img_detail::decode_png(f, out, err);
+    else if (f.size() >= 3 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) ok = img_detail::decode_pnm(f, out, err);
+    else if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') ok = img_detail::decode_bmp(f, out, err);
+    else if (f.size() >= 3 && f[0] == 0xff && f[1] == 0xd8) ok = img_detail::decode_jpeg(f, out, err);
+    else if (dot != std::string::npos && (path.substr(dot) == ".tga" || path.substr(dot) == ".TGA")) ok = img_detail::decode_tga(f, out, err);
+    else { ok = false; err = "unrecognised image format (PNG, baseline JPEG, binary PPM / PGM, BMP and TGA are supported)"; }
+    if (!ok) err = path + ": " + err;   // (which file: a scene names dozens of textures)
+    return ok;
 }
 
 }  // namespace trayh

@@ -117,8 +117,13 @@ class Frame:
         return f
 
 
-def read_message(stream):
-    """one length-prefixed message off a socket: 8 bytes of size, then the rest (worker.rs:63-83, master.rs:166-192)"""
+MAX_INSTRUCTIONS_BYTES = 1 << 16   # Instructions: five u64 + a scene path; anything longer is not a master speaking
+
+
+def read_message(stream, max_size=MAX_INSTRUCTIONS_BYTES):
+    """one length-prefixed message off a socket: 8 bytes of size, then the rest (worker.rs:63-83, master.rs:166-192). The size a peer
+    may announce is capped by what the caller expects (the worker only ever reads Instructions: a few hundred bytes; a reader of Frames
+    passes 8 + 40 + blocks * (16 + 64) for its film) -- whoever connects to the listening port must not make the worker buffer gigabytes."""
     def read_exact(n):
         buf = bytearray()
         while len(buf) < n:
@@ -129,8 +134,8 @@ def read_message(stream):
         return bytes(buf)
     head = read_exact(8)
     size = struct.unpack("<Q", head)[0]
-    if size < 8 or size > (1 << 34):
-        raise WireError(f"implausible message size {size}")
+    if size < 8 or size > max_size:
+        raise WireError(f"implausible message size {size} (at most {max_size} bytes expected)")
     return head + read_exact(size - 8)
 
 
