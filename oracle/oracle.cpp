@@ -35,10 +35,10 @@ Ray camera_generate_ray(const SceneView& sv, float px, float py, float time) {
     return r;
 }
 
-// Per-camera-sample LD arrays of path.rs:48-60 generated from the counter-based RNG (TRAY-CBRNG v2):
-// every array has its scramble word(s) and is shuffled (ld.rs:58,63) by one of 256 pool permutations of [0, n), chosen by the low
-// byte of the array's first scramble word -- bits the scrambled 24-bit fractions never see. Pool permutation q is the
-// Fisher-Yates shuffle shuffle_small(mix32(0x50455250 + q), n).
+// Per-camera-sample LD arrays of path.rs:48-60 generated from the counter-based RNG (TRAY-CBRNG v3):
+// every array has its scramble word(s) and is shuffled (ld.rs:58,63) by the composition of two of 256 pool permutations of [0, n),
+// perm_q2[perm_q1[.]]: q1 = the low byte of the array's first scramble word, q2 = the low byte of its second one (2-D arrays) or
+// bits 8..15 of its only one (1-D arrays). Pool permutation q is the Fisher-Yates shuffle shuffle_small(mix32(0x50455250 + q), n).
 struct PermPool {
     uint32_t n = 0;
     uint8_t perm[256][16];
@@ -58,19 +58,26 @@ struct PathSamples {
     uint32_t n;
     uint32_t scr[9];
     const uint8_t* perm[6];
-    void init(uint32_t key_samp, uint32_t num_samples) {
+    uint8_t own[6][16];   // this path's six shuffles (the composed pool permutations; ORC_FRESH_SHUFFLES: six Fisher-Yates shuffles of its own)
+    void init(uint32_t key_samp, uint32_t num_samples, bool fresh = false) {
         ks = key_samp; n = num_samples;
         const PermPool& pool = perm_pool(n);
         // 2-D arrays: scramble x, scramble y; 1-D arrays: scramble
         const int d2[3] = {SD_L2, SD_B2, SD_P2}, d1[3] = {SD_L1, SD_B1, SD_P1};
+        auto compose = [&](int a, uint32_t q1, uint32_t q2) {
+            for (uint32_t b = 0; b < 16u; ++b) own[a][b] = b < (n <= 16u ? n : 16u) ? pool.perm[q2 & 255u][pool.perm[q1 & 255u][b]] : (uint8_t)b;
+            perm[a] = own[a];
+        };
         for (int a = 0; a < 3; ++a) {
             scr[2 * a] = draw(ks, d2[a]); scr[2 * a + 1] = draw(ks, d2[a] + 1);
-            perm[a] = pool.perm[scr[2 * a] & 255u];
+            compose(a, scr[2 * a], scr[2 * a + 1]);
         }
         for (int a = 0; a < 3; ++a) {
             scr[6 + a] = draw(ks, d1[a]);
-            perm[3 + a] = pool.perm[scr[6 + a] & 255u];
+            compose(3 + a, scr[6 + a], scr[6 + a] >> 8);
         }
+        if (fresh)   // Rng::shuffle per array (ld.rs:58,63), each under a key of its own
+            for (int a = 0; a < 6; ++a) { shuffle_small(draw(ks, 40u + (uint32_t)a), n <= 16u ? n : 16u, own[a]); perm[a] = own[a]; }
     }
     void two_d(int a, uint32_t bounce, float& u0, float& u1) const {   // sample_02 (ld.rs:91-93)
         uint32_t idx = perm[a][bounce];
@@ -280,7 +287,7 @@ Colorf trace_sample(const SceneView& sv, uint32_t kf, uint32_t px, uint32_t py, 
     if (scene_intersect(sv, ray, hit)) {
         if (sv.fs->integrator == TRAY_INTEGRATOR_WHITTED) return whitted_illumination(sv, ray, hit, key_sample(pix.kp, s), 0u).clamp();
         PathSamples ps;
-        ps.init(key_sample(pix.kp, s), fs.max_depth + 1);
+        ps.init(key_sample(pix.kp, s), fs.max_depth + 1, (sv.flags & ORC_FRESH_SHUFFLES) != 0);
         if (sv.fs->integrator == TRAY_INTEGRATOR_NORMALS_DEBUG) {   // NormalsDebug::illumination (integrator/normals_debug.rs:28-33)
             if (sv.stats) sv.stats->vertices++;
             const BSDF bsdf = material_bsdf(*sv.fs, hit);
@@ -627,9 +634,14 @@ void oracle_pixel_sample(uint64_t seed, uint32_t frame, uint32_t width, uint32_t
     out3[2] = pix.time(s);
 }
 // the six per-bounce LD values of a camera sample: out[b*9 + {l2x,l2y,b2x,b2y,p2x,p2y,l1,b1,p1}], rr[b]
+void oracle_path_samples_mode(uint64_t seed, uint32_t frame, uint32_t width, uint32_t px, uint32_t py, uint32_t s, uint32_t n, int fresh, float* out, float* rr);
 void oracle_path_samples(uint64_t seed, uint32_t frame, uint32_t width, uint32_t px, uint32_t py, uint32_t s, uint32_t n, float* out, float* rr) {
+    oracle_path_samples_mode(seed, frame, width, px, py, s, n, 0, out, rr);
+}
+// ... fresh != 0: with per-array Fisher-Yates shuffles (ORC_FRESH_SHUFFLES) instead of the permutation pool
+void oracle_path_samples_mode(uint64_t seed, uint32_t frame, uint32_t width, uint32_t px, uint32_t py, uint32_t s, uint32_t n, int fresh, float* out, float* rr) {
     PathSamples ps;
-    ps.init(key_sample(key_pixel(key_frame(seed, frame), py * width + px), s), n);
+    ps.init(key_sample(key_pixel(key_frame(seed, frame), py * width + px), s), n, fresh != 0);
     for (uint32_t b = 0; b < n; ++b) {
         float* o = out + 9 * b;
         ps.two_d(0, b, o[0], o[1]); ps.two_d(1, b, o[2], o[3]); ps.two_d(2, b, o[4], o[5]);

@@ -10,7 +10,9 @@
 
 namespace orc {
 
-enum { ORC_FAITHFUL_XF = 1, ORC_BRUTE_FORCE = 2 };
+enum { ORC_FAITHFUL_XF = 1, ORC_BRUTE_FORCE = 2,
+       ORC_FRESH_SHUFFLES = 4 };   // every per-path LD array shuffled by its OWN Fisher-Yates (ld.rs:58,63 as written) instead of a pool permutation:
+                                   // a different sampler definition (not the product's), for the statistical comparison in tests/test_sampler_pool.py
 
 struct Stats { uint64_t samples = 0, vertices = 0, rays = 0; };
 

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 
-FAITHFUL_XF, BRUTE_FORCE = 1, 2
+FAITHFUL_XF, BRUTE_FORCE, FRESH_SHUFFLES = 1, 2, 4
 
 
 class OracleStats(C.Structure):

@@ -316,14 +316,14 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
     if (moving && n_moving) {   // per-path transform cache, one column per thread of the grid (tray_scene_create)
         for (uint32_t i = 0; i < f->n_instances; ++i)
             if (f->instances[i].animated && f->instances[i].moving_slot < n_moving) moving_ids[f->instances[i].moving_slot] = i;
-        xf_cache.assign((size_t)n_moving * 24u * blocks * TR_BLOCK, 0.0f);
+        xf_cache.assign((size_t)n_moving * TR_XF_WORDS * blocks * TR_BLOCK, 0.0f);
         e.d.xf_cache = xf_cache.data(); e.d.moving_ids = moving_ids.data(); e.d.n_moving = n_moving; e.d.xf_cache_lanes = blocks * TR_BLOCK;
     }
     e.d.film_rows = (film_rows != 0 && film_rows_ok(f)) ? 1u : 0u;
     uint32_t stack_words = e.depth * TR_BLOCK;
     bool small_mesh = false;
     for (uint32_t m = 0; m < f->n_meshes; ++m) small_mesh = small_mesh || f->meshes[m].tri_count <= TR_COOP_MAX_TRIS;
-    if (coop != 0 && small_mesh && !moving) { e.d.coop_offset = stack_words; stack_words += (TR_BLOCK / 64) * TR_COOP_WORDS; }
+    if (coop != 0 && small_mesh && f->n_instances <= TR_FLAT_MAX) { e.d.coop_offset = stack_words; stack_words += (TR_BLOCK / 64) * TR_COOP_WORDS; }
     if (e.d.film_rows) { e.d.win_offset = 0u; stack_words = std::max(stack_words, 4u * WIN_PLANE); }   // tray_scene_create: the film window over the stacks ...
     else { e.d.win_offset = stack_words; stack_words += 4u * WIN_PLANE; }                               // ... or in its own region
     std::vector<uint2> tiles(tile_count);
@@ -396,7 +396,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     if (moving && n_moving) {   // per-path transform cache, one column per pool slot (tray_scene_create)
         for (uint32_t i = 0; i < f->n_instances; ++i)
             if (f->instances[i].animated && f->instances[i].moving_slot < n_moving) moving_ids[f->instances[i].moving_slot] = i;
-        xf_cache.assign((size_t)n_moving * 24u * n_slots, 0.0f);
+        xf_cache.assign((size_t)n_moving * TR_XF_WORDS * n_slots, 0.0f);
         e.d.xf_cache = xf_cache.data(); e.d.moving_ids = moving_ids.data(); e.d.n_moving = n_moving; e.d.xf_cache_lanes = n_slots; e.d.xf_aos = 1u;
     }
     std::vector<WfChunk> chunks(n_chunks, WfChunk{WF_TILE_NEED, 0u});
@@ -491,6 +491,12 @@ extern "C" int emu_device_trees(const TrayFlatScene* f, uint32_t* counts, TrayBv
     if (meshes) std::memcpy(meshes, p.meshes.data(), p.meshes.size() * sizeof(TrayMesh));
     if (wf_insts) std::memcpy(wf_insts, recs.data(), recs.size() * sizeof(tray::WfInst));
     if (narrow) *narrow = p.narrow ? 1 : 0;
+    return 0;
+}
+// AnimatedTransform::transform(time) of a spline stack as the DEVICE evaluates it (dev_anim.h: eval_xform_stack): rows 0..2 of mat, rows 0..2 of inv
+extern "C" int emu_stack_transform(const TrayFlatScene* f, uint32_t xf_first, uint32_t xf_count, uint32_t n, const float* times, float* out) {
+    if (!f || (uint64_t)xf_first + xf_count > f->n_xf_levels) return -1;
+    for (uint32_t k = 0; k < n; ++k) eval_xform_stack(f->xf_levels, f->keyframes, f->knots, xf_first, xf_count, times[k], out + (size_t)TR_XF_WORDS * k);
     return 0;
 }
 extern "C" unsigned emu_retraced(void) { const unsigned r = g_retraced; g_retraced = 0; return r; }

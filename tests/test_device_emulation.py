@@ -192,24 +192,69 @@ def test_per_sample_radiance_of_the_device_code_is_bit_identical(name, spp, tmp_
     assert a.tobytes() == b.tobytes()
 
 
-def test_per_sample_radiance_of_the_device_code_on_a_moving_scene(tmp_path, built):
-    """Moving scenes: the device evaluates slerp's acos / sin / cos in f64 and rounds once, the oracle calls the f32 functions like
-    the reference -- the same value for almost every argument, so most samples are identical and the rest differ in the last bits."""
+@pytest.mark.parametrize("name,frames", [("moving_box", (0, 3, 5)), ("tr15_like", (0, 127, 330))])
+def test_per_sample_radiance_of_the_device_code_on_a_moving_scene(name, frames, tmp_path, built):
+    """Moving scenes, bit for bit: the device evaluates the spline stacks with the libm the reference calls -- glibc's acosf / sinf / cosf
+    restated in dev_libm.h (tools/libm_port_check.cpp compares them with the system's exhaustively) -- and applies Transform * Point's
+    w quirk (Q5) with the inverse's own [3][3] element, which Matrix4::inverse leaves an ulp off one for some keyframes. Round 3 rounded
+    f64 results and assumed w == 1: 0.8 .. 10 % of the samples of these scenes then differed in their last bits, a few took another path."""
     d = str(tmp_path)
-    scenes.write_moving_box(d, width=128, height=96, samples=32)
+    if name == "moving_box":
+        scenes.write_moving_box(d, width=128, height=96, samples=32)
+        scene, *_ = T.Scene.load_file(str(tmp_path / "moving_box.json"))
+        w, h, spp, n = 128, 96, 32, 8000
+    else:
+        p = scenes.write_tr15_like_assets(d, film=(64, 48, 8), detail=0.02)
+        scene, *_ = T.Scene.load_file(p if isinstance(p, str) else p[0])
+        w, h, spp, n = 64, 48, 8, 4000
+    lit = False
+    for frame in frames:
+        flat = scene.flatten(frame)
+        assert flat.contents.animated
+        rng = np.random.default_rng(12 + frame)
+        px = rng.integers(0, w, n).astype(np.uint32); py = rng.integers(0, h, n).astype(np.uint32); si = rng.integers(0, spp, n).astype(np.uint32)
+        a = O.sample_radiance(flat, px, py, si, spp, seed=5)
+        b = E.sample_radiance(flat, px, py, si, spp, 5)
+        assert a[:, 5].mean() > 1.0
+        lit = lit or bool((a[:, :3] > 0).any())      # (the stand-in's lights are keyed: dark at frame 0)
+        assert a.tobytes() == b.tobytes(), f"{name} frame {frame}: {(~(a == b).all(axis=1)).sum()} of {n} samples differ"
+    assert lit
+
+
+def test_spline_stacks_of_the_device_code_are_bit_identical(tmp_path, built):
+    """AnimatedTransform::transform(time) of every moving stack (camera, instances, nested groups) at 4000 shutter times: rows of mat and
+    inv and the inverse's [3][3] element, device source against the oracle, every bit"""
+    import ctypes as C
+    from tray_rust_amd import _lib as L
+    d = str(tmp_path)
+    scenes.write_moving_box(d, width=64, height=48, samples=4)
     scene, *_ = T.Scene.load_file(str(tmp_path / "moving_box.json"))
-    flat = scene.flatten(3)
-    assert flat.contents.animated
-    rng = np.random.default_rng(12)
-    n = 8000
-    px = rng.integers(0, 128, n).astype(np.uint32); py = rng.integers(0, 96, n).astype(np.uint32); si = rng.integers(0, 32, n).astype(np.uint32)
-    a = O.sample_radiance(flat, px, py, si, 32, seed=5)
-    b = E.sample_radiance(flat, px, py, si, 32, 5)
-    assert (a[:, 3:5] == b[:, 3:5]).all()
-    assert (a == b).all(axis=1).mean() > 0.9
-    assert (a[:, 5] == b[:, 5]).mean() > 0.999
-    d_ = np.abs(a[:, :3] - b[:, :3]).max(axis=1)
-    assert np.quantile(d_, 0.99) < 1e-5
+    h = E.emu()
+    h.emu_stack_transform.restype = C.c_int
+    h.emu_stack_transform.argtypes = [C.POINTER(L.TrayFlatScene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    o = O.oracle()
+    o.oracle_stack_transform.restype = C.c_int
+    o.oracle_stack_transform.argtypes = [C.POINTER(L.TrayFlatScene), C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
+    off_one = 0
+    for frame in (0, 3, 7):
+        flat = scene.flatten(frame)
+        f = flat.contents
+        n = 4000
+        times = np.random.default_rng(frame).uniform(f.camera.shutter_open, f.camera.shutter_close, n).astype(np.float32)
+        stacks = [(f.camera.xf_first, f.camera.xf_count)] + [(f.instances[i].xf_first, f.instances[i].xf_count) for i in range(f.n_instances) if f.instances[i].animated]
+        assert len(stacks) >= 4
+        for first, count in stacks:
+            dev = np.zeros((n, 28), np.float32)
+            assert h.emu_stack_transform(flat, first, count, n, times.ctypes.data, dev.ctypes.data) == 0
+            ora = np.zeros((n, 32), np.float32)
+            for k in range(n):
+                assert o.oracle_stack_transform(flat, first, count, float(times[k]), ora[k].ctypes.data) == 0
+            assert dev[:, :12].tobytes() == np.ascontiguousarray(ora[:, :12]).tobytes()          # rows 0..2 of mat
+            assert dev[:, 12:24].tobytes() == np.ascontiguousarray(ora[:, 16:28]).tobytes()      # rows 0..2 of inv
+            assert (dev[:, 24] == ora[:, 31]).all() and (dev[:, 25] == ora[:, 15]).all()         # the [3][3] elements
+            assert (ora[:, 12:15] == 0).all() and (ora[:, 28:31] == 0).all()                     # row 3 is (0, 0, 0, w)
+            off_one += int((ora[:, 31] != 1.0).sum())
+    assert off_one > 0, "the scene is meant to contain keyframes whose inverse has w != 1 (quirk Q5 then divides)"
 
 
 MATERIALS = {
@@ -392,13 +437,9 @@ def test_wavefront_schedule_emulated_as_simt(name, frame, trace, tmp_path, tr15_
                                                                 lds_depth=4)
     ref, st = O.render_tiles(flat, spp, seed=5)
     assert samples == st.samples == w * h * spp
-    moving = bool(flat.contents.animated)
-    if moving:   # slerp's transcendental in f64 on the device side: a handful of paths may take another turn
-        assert abs(vertices - st.vertices) <= 2e-3 * st.vertices and abs(rays - st.rays) <= 2e-3 * st.rays
-    else:
-        assert (vertices, rays) == (st.vertices, st.rays)
+    assert (vertices, rays) == (st.vertices, st.rays)      # moving scenes too: the spline stacks are evaluated bit for bit (dev_libm.h)
     assert rgb(ref).max() > 0.05
-    assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < (2e-3 if moving else 2e-6)
+    assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6
     assert np.abs(img[..., 3] - ref[..., 3]).max() < 1e-4 * ref[..., 3].max()
 
 

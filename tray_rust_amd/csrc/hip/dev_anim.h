@@ -12,6 +12,7 @@
 #pragma once
 #include "../../../include/trayhip.h"
 #include "dev_math.h"
+#include "dev_libm.h"
 
 namespace tr {
 
@@ -49,15 +50,14 @@ TR_DEV DevKey key_interpolate(const DevKey& a, const DevKey& b, float t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) r.q[i] = q[i] / len;
     } else {
-        // acos / cos / sin through f64 and rounded once: the host libm the reference (and the oracle) calls is correctly
-        // rounded for almost every argument, ocml's f32 versions are 1-2 ulp; every ulp here moves a whole instance
-        float theta = (float)acos((double)clampf(cos_theta, -1.0f, 1.0f));
+        // acos / cos / sin as the host libm the reference (and the oracle) calls computes them, bit for bit (ref_acosf / ref_sincosf above)
+        float theta = ref_acosf(clampf(cos_theta, -1.0f, 1.0f));
         float theta_t = theta * t;
         float perp[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) perp[i] = b.q[i] - a.q[i] * cos_theta;
         float len = sqrtf(quat_dot(perp, perp));
-        float c = (float)cos((double)theta_t), sn = (float)sin((double)theta_t);
+        float c = ref_sincosf(theta_t, 1), sn = ref_sincosf(theta_t, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) r.q[i] = a.q[i] * c + (perp[i] / len) * sn;
     }
@@ -158,7 +158,12 @@ TR_DEV void key_transform(const DevKey& k, float* __restrict__ mat, float* __res
     m4_mul(si, b, inv);     // (.. * scale).inv = scale.inv * (..).inv
 }
 
-// AnimatedTransform::transform(time). out24 = rows 0..2 of mat, then rows 0..2 of inv.
+// AnimatedTransform::transform(time) as TR_XF_WORDS floats: rows 0..2 of mat [0..11], rows 0..2 of inv [12..23], then the two elements
+// [3][3]: of inv [24] and of mat [25] ([26], [27] pad the record to whole 16-byte pieces). Row 3 of a product of TRS keyframes is
+// (0, 0, 0, w): the zeros are exact, but w of the INVERSE is not always 1 -- Matrix4::inverse (matrix4.rs:48-172) divides a 3x3 determinant
+// by the same determinant accumulated in another order, so it comes out as 1 +- an ulp for some scalings / rotations -- and then
+// Transform * Point divides by it (quirk Q5, transform.rs:211-215: it divides exactly when |w - 1| < eps). xf_point_affine_w below does.
+#define TR_XF_WORDS 28
 TR_ANIM_EVAL void eval_xform_stack(const TrayXformLevel* __restrict__ levels, const TrayKeyframe* __restrict__ kfs,
                                               const float* __restrict__ knots, uint32_t xf_first, uint32_t xf_count, float time,
                                               float* out24) {
@@ -185,11 +190,19 @@ TR_ANIM_EVAL void eval_xform_stack(const TrayXformLevel* __restrict__ levels, co
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) { out24[i] = mat[i]; out24[12 + i] = inv[i]; }
+    out24[24] = inv[15]; out24[25] = mat[15]; out24[26] = 0.0f; out24[27] = 0.0f;
 }
 
 // Transform * Point for an affine matrix given by its rows 0..2 (w == 1, so the w test of transform.rs:211-215 is a no-op)
 TR_DEV f3 xf_point_affine(const float* __restrict__ m, f3 p) {
     return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7], m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+// ... for a matrix whose row 3 is (0, 0, 0, w): the reference's w = 0 x + 0 y + 0 z + w is that element itself, and quirk Q5 divides by it
+// when it is almost -- but not exactly -- one (xf_point in dev_math.h is the general form)
+TR_DEV f3 xf_point_affine_w(const float* __restrict__ m, float w, f3 p) {
+    f3 r = xf_point_affine(m, p);
+    if (w != 1.0f && fabsf(w - 1.0f) < kEps) r = r / w;
+    return r;
 }
 
 // AnimatedColor::color (film/animated_color.rs:52-78) over keys sorted by time; n >= 2

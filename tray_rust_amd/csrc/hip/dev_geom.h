@@ -64,7 +64,7 @@ struct DevScene {
     const TrayColorKey* __restrict__ color_keys;
     // Per-path transform cache of the moving instances (ANIM kernels): every ray of a path carries the camera ray's time, so
     // each lane evaluates the spline stacks ONCE per camera sample and keeps mat/inv rows in HBM, laid out
-    // [moving_slot][24 floats][lane] so that a wave reads / writes 256 contiguous bytes per float.
+    // [moving_slot][TR_XF_WORDS floats][lane] so that a wave reads / writes 256 contiguous bytes per float.
     float* __restrict__ xf_cache;              // nullptr: evaluate at every use (debug kernels)
     const uint32_t* __restrict__ moving_ids;   // instance ids of the moving instances, by moving_slot
     uint32_t n_moving, xf_cache_lanes;
@@ -114,35 +114,36 @@ TR_DEV void xf_cache_fill(const DevScene& sc, float time, uint32_t lane) {
     const uint32_t lanes = sc.xf_cache_lanes;
     for (uint32_t m = 0; m < sc.n_moving; ++m) {
         const TrayInstance* __restrict__ in = sc.instances + sc.moving_ids[m];
-        float x[24];
+        float x[TR_XF_WORDS];
         eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
         if (sc.xf_aos) {
-            float4* __restrict__ rec = reinterpret_cast<float4*>(sc.xf_cache + ((size_t)lane * sc.n_moving + m) * 24u);
+            float4* __restrict__ rec = reinterpret_cast<float4*>(sc.xf_cache + ((size_t)lane * sc.n_moving + m) * TR_XF_WORDS);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) rec[q] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+            for (int q = 0; q < TR_XF_WORDS / 4; ++q) rec[q] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
         } else {
-            float* __restrict__ col = sc.xf_cache + (size_t)m * 24u * lanes + lane;
+            float* __restrict__ col = sc.xf_cache + (size_t)m * TR_XF_WORDS * lanes + lane;
 #pragma unroll
-            for (int k = 0; k < 24; ++k) col[(size_t)k * lanes] = x[k];
+            for (int k = 0; k < 26; ++k) col[(size_t)k * lanes] = x[k];
         }
     }
 }
 // ANIM template values: 0 = nothing moves within the frame; 1 = moving instances are read from the per-path cache (tile and
 // wavefront kernels: no function call in their hot loops, a call would raise their register allocation to the callee's);
 // 2 = the spline stacks are evaluated at every use (debug kernels, whose grids are not sized by the cache)
-// rows of inv only (x + 12 .. x + 23 are written)
+// rows of inv and its [3][3] only (x + 12 .. x + 24 are written)
 template <int ANIM>
 TR_DEV void instance_inv_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, uint32_t column, float* x) {
     if (ANIM == 1) {
         if (sc.xf_aos) {
-            const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.n_moving + in->moving_slot) * 24u + 12u);
+            const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.n_moving + in->moving_slot) * TR_XF_WORDS + 12u);
 #pragma unroll
             for (int q = 0; q < 3; ++q) { const float4 v = rec[q]; x[12 + 4 * q] = v.x; x[13 + 4 * q] = v.y; x[14 + 4 * q] = v.z; x[15 + 4 * q] = v.w; }
+            x[24] = rec[3].x;
         } else {
             const uint32_t lanes = sc.xf_cache_lanes;
-            const float* __restrict__ col = sc.xf_cache + ((size_t)in->moving_slot * 24u + 12u) * lanes + column;
+            const float* __restrict__ col = sc.xf_cache + ((size_t)in->moving_slot * TR_XF_WORDS + 12u) * lanes + column;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) x[12 + k] = col[(size_t)k * lanes];
+            for (int k = 0; k < 13; ++k) x[12 + k] = col[(size_t)k * lanes];
         }
     } else {
         eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
@@ -150,23 +151,24 @@ TR_DEV void instance_inv_at(const DevScene& sc, const TrayInstance* __restrict__
 }
 // rows of inv of moving instance `moving_slot` in the path's column of the wavefront kernels' transform cache (xf_aos = 1)
 TR_DEV void instance_inv_cached(const DevScene& sc, uint32_t moving_slot, uint32_t column, float* x) {
-    const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.n_moving + moving_slot) * 24u + 12u);
+    const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.n_moving + moving_slot) * TR_XF_WORDS + 12u);
 #pragma unroll
     for (int q = 0; q < 3; ++q) { const float4 v = rec[q]; x[12 + 4 * q] = v.x; x[13 + 4 * q] = v.y; x[14 + 4 * q] = v.z; x[15 + 4 * q] = v.w; }
+    x[24] = rec[3].x;
 }
 template <int ANIM>
 TR_DEV void instance_xf_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, uint32_t column, float* x) {
     if (in->animated) {
         if (ANIM == 1) {
             if (sc.xf_aos) {
-                const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.n_moving + in->moving_slot) * 24u);
+                const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.n_moving + in->moving_slot) * TR_XF_WORDS);
 #pragma unroll
-                for (int q = 0; q < 6; ++q) { const float4 v = rec[q]; x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w; }
+                for (int q = 0; q < TR_XF_WORDS / 4; ++q) { const float4 v = rec[q]; x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w; }
             } else {
                 const uint32_t lanes = sc.xf_cache_lanes;
-                const float* __restrict__ col = sc.xf_cache + (size_t)in->moving_slot * 24u * lanes + column;
+                const float* __restrict__ col = sc.xf_cache + (size_t)in->moving_slot * TR_XF_WORDS * lanes + column;
 #pragma unroll
-                for (int k = 0; k < 24; ++k) x[k] = col[(size_t)k * lanes];
+                for (int k = 0; k < 26; ++k) x[k] = col[(size_t)k * lanes];
             }
         } else {
             eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
@@ -174,6 +176,7 @@ TR_DEV void instance_xf_at(const DevScene& sc, const TrayInstance* __restrict__ 
     } else {
 #pragma unroll
         for (int k = 0; k < 12; ++k) { x[k] = in->mat[k]; x[12 + k] = in->inv[k]; }
+        x[24] = in->inv[15]; x[25] = in->mat[15];
     }
 }
 
@@ -569,6 +572,11 @@ TR_DEV bool own_box_pass(const float* __restrict__ lo, const float* __restrict__
     if (tzmax < tmax) tmax = tzmax;
     return !(tmin > tmax) && !(tmin >= max_t) && !(tmax <= min_t);
 }
+// ANIM: an instance that moves within the frame takes the path's own transform (per-path cache) instead of the scalar record's -- the
+// loop over leaves and instances stays wave-uniform, only the world -> object transform is per lane. Its gate is the box of its
+// BVH<Instance> leaf exactly as for the others (the reference's swept bounds with quirk Q12, whatever they cover: the reference reaches
+// the instance through nothing else); the own-box cull of occlusion rays is off for it (host/gates.hpp).
+template <int ANIM>
 TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, bool active, HitRec& rec, bool& hazard) {
     const float min_t = ray.min_t, gate_max_t = ray.max_t;
     float max_t = ray.max_t;          // closest accepted candidate so far
@@ -605,8 +613,16 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
             for (int c = 0; c < 16; ++c) inv[c] = in->inv[c];
             const float gp0 = in->gp0, gp1 = in->gp1;
             // Instance::intersect (receiver.rs:29-35): world ray -> object ray by `inv`, direction not renormalised
-            const f3 o = xf_point(inv, ray.o);
-            const f3 d = xf_vector(inv, ray.d);
+            f3 o, d;
+            if (ANIM && in->animated != 0u) {   // transform.transform(ray.time) of a moving instance (receiver.rs:30), from the path's cache column
+                float x[TR_XF_WORDS];
+                instance_inv_at<ANIM>(sc, sc.instances + inst_id, ray.time, ray.col, x);
+                o = xf_point_affine_w(x + 12, x[24], ray.o);
+                d = xf_vector(x + 12, ray.d);
+            } else {
+                o = xf_point(inv, ray.o);
+                d = xf_vector(inv, ray.d);
+            }
             const float bound = fmaxf(max_t, best_gate);   // (best_gate is -inf until a candidate was accepted)
             float t = bound;
             bool hit = false, hz = false;
@@ -720,9 +736,9 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
             if (in->kind == TRAY_INST_POINT_EMITTER) continue;   // emitter.rs:120
             f3 lo_, ld;
             if (ANIM && in->animated) {   // transform.transform(ray.time) per visit (receiver.rs:30)
-                float x[24];
+                float x[TR_XF_WORDS];
                 instance_inv_at<ANIM>(sc, in, ray.time, ray.col, x);
-                lo_ = xf_point_affine(x + 12, ray.o);
+                lo_ = xf_point_affine_w(x + 12, x[24], ray.o);
                 ld = xf_vector(x + 12, ray.d);
             } else {
                 lo_ = xf_point(in->inv, ray.o);
@@ -771,16 +787,16 @@ TR_DEV TraceResult trace(const DevScene* __restrict__ scp, uint32_t* __restrict_
     const DevScene& sc = *scp;
     TraceResult r;
     r.rec.t = 0.0f; r.rec.inst = 0xffffffffu; r.rec.prim = 0u; r.rec.b1 = 0.0f; r.rec.b2 = 0.0f;
-    // moving scenes always take BVH<Instance>: its boxes are the reference's swept bounds (animated_transform.rs:58-71),
-    // including the instances those bounds cut off, which the flat loop would not reproduce
-    if (!ANIM && sc.n_instances <= TR_FLAT_MAX) {
+    // (moving scenes too since round 4: the flat loop's gates are the boxes of the BVH<Instance> leaves -- for a moving scene the reference's
+    // swept bounds of animated_transform.rs:58-71 with quirk Q12 -- so it reaches exactly the instances the reference's traversal can reach)
+    if (sc.n_instances <= TR_FLAT_MAX) {
         bool hazard = false;
-        r.hit = trace_flat(sc, stack, ray, any_hit, active, r.rec, hazard);
+        r.hit = trace_flat<ANIM>(sc, stack, ray, any_hit, active, r.rec, hazard);
         if (__any(hazard)) {   // (about one ray in 1e7: tied candidates, or a box entered behind its own hit) the reference's traversal decides
             if (hazard) {
                 if (sc.retraced) atomicAdd(sc.retraced, 1u);
                 r.rec.t = 0.0f; r.rec.inst = 0xffffffffu; r.rec.prim = 0u; r.rec.b1 = 0.0f; r.rec.b2 = 0.0f;
-                r.hit = trace_bvh<0>(sc, stack, ray, false, r.rec);
+                r.hit = trace_bvh<ANIM>(sc, stack, ray, false, r.rec);
             }
         }
     } else r.hit = active ? trace_bvh<ANIM>(sc, stack, ray, any_hit, r.rec) : false;
@@ -792,11 +808,11 @@ TR_DEV TraceResult trace(const DevScene* __restrict__ scp, uint32_t* __restrict_
 template <int ANIM>
 TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, float* uv_out = nullptr, f3* dp_dv_out = nullptr) {
     const TrayInstance* __restrict__ in = sc.instances + rec.inst;
-    float x[24];
+    float x[TR_XF_WORDS];
     f3 o, d;
     if (ANIM) {
         instance_xf_at<ANIM>(sc, in, ray.time, ray.col, x);
-        o = xf_point_affine(x + 12, ray.o);
+        o = xf_point_affine_w(x + 12, x[24], ray.o);
         d = xf_vector(x + 12, ray.d);
     } else {
         o = xf_point(in->inv, ray.o);
@@ -865,7 +881,7 @@ TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, flo
     }
     Hit h;
     if (ANIM) {
-        h.p = xf_point_affine(x, p);
+        h.p = xf_point_affine_w(x, x[25], p);
         h.n = xf_normal_t(x + 12, n);
         h.ng = xf_normal_t(x + 12, ng);
         h.dp_du = xf_vector(x, dp_du);
@@ -890,10 +906,10 @@ TR_DEV f3 finish_hit_ng(const DevScene& sc, const Ray& ray, const HitRec& rec) {
     const TrayInstance* __restrict__ in = sc.instances + rec.inst;
     uint32_t gt = in->geom_type;
     f3 ng;
-    float x[24];
+    float x[TR_XF_WORDS];
     if (ANIM) instance_xf_at<ANIM>(sc, in, ray.time, ray.col, x);
     if (gt == TRAY_GEOM_SPHERE) {
-        f3 o = ANIM ? xf_point_affine(x + 12, ray.o) : xf_point(in->inv, ray.o);
+        f3 o = ANIM ? xf_point_affine_w(x + 12, x[24], ray.o) : xf_point(in->inv, ray.o);
         f3 d = ANIM ? xf_vector(x + 12, ray.d) : xf_vector(in->inv, ray.d);
         ng = normalized(o + d * rec.t);
     } else if (gt == TRAY_GEOM_MESH) {

@@ -32,9 +32,9 @@ TR_DEV Ray camera_ray(const DevScene& sc, float px, float py, float time) {
     const float frame_time = (c.shutter_close - c.shutter_open) * time + c.shutter_open;
     Ray r;
     if (ANIM && c.animated) {   // cam_world.transform(frame_time) * Ray (camera.rs:156)
-        float x[24];
+        float x[TR_XF_WORDS];
         eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, c.xf_first, c.xf_count, frame_time, x);
-        r.o = xf_point_affine(x, mk(0.0f, 0.0f, 0.0f));
+        r.o = xf_point_affine_w(x, x[25], mk(0.0f, 0.0f, 0.0f));
         r.d = xf_vector(x, d);
     } else {
         r.o = xf_point(c.cam_world, mk(0.0f, 0.0f, 0.0f));
@@ -128,19 +128,27 @@ TR_DEV void lane_start_sample(Lane& ln, const Ray& cam_ray, uint32_t ks) {
 
 // sample_02 / van_der_corput of one LD array at the current bounce (ld.rs:54-64, 91-93): the array's scramble word(s), its shuffle
 // out of the scene's permutation pool (dev_math.h: TRAY-CBRNG v2), the (0,2)-sequence point of the shuffled index
-TR_DEV uint32_t lane_perm_entry(const DevScene& sc, const Lane& ln, uint32_t scramble) {
-    const uint32_t off = ((scramble & (TR_PERM_POOL - 1u)) << 4) + ln.bounce;
-    return ln.perm_lds ? (uint32_t)ln.perm_lds[off] : (uint32_t)sc.perm_pool[off];
+// TRAY-CBRNG v3 (round 4): a path's shuffle of an array is the COMPOSITION of two pool permutations, idx = perm_q2[perm_q1[bounce]] -- q1 the
+// low byte of the array's first scramble word, q2 the low byte of its second one (2-D arrays) or bits 8..15 of its only one (1-D arrays: the
+// bits every point of the array shares) -- 65 536 shuffles per array instead of 256. With 256 the joint distribution of an array's points at
+// two bounces was a sample of 256 draws over the 72 ordered pairs (n = 9): the covariance of those two values sat up to 4e-3 (12 sigma of
+// 60 000 paths) off the value per-array Fisher-Yates shuffles (ld.rs:58,63) give; composed, it is inside the sampling error
+// (tests/test_sampler_pool.py). Cost: a second byte load and a 4-bit reversal (the first entry's high nibble is the bit-reversed index).
+TR_DEV uint32_t lane_perm_entry(const DevScene& sc, const Lane& ln, uint32_t s1, uint32_t s2) {
+    const uint32_t off1 = ((s1 & (TR_PERM_POOL - 1u)) << 4) + ln.bounce;
+    const uint32_t e1 = ln.perm_lds ? (uint32_t)ln.perm_lds[off1] : (uint32_t)sc.perm_pool[off1];
+    const uint32_t off2 = ((s2 & (TR_PERM_POOL - 1u)) << 4) + (__brev(e1 >> 4) >> 28);
+    return ln.perm_lds ? (uint32_t)ln.perm_lds[off2] : (uint32_t)sc.perm_pool[off2];
 }
 TR_DEV void lane_2d(const DevScene& sc, const Lane& ln, uint32_t dim, float& u0, float& u1) {
     const uint32_t sx = draw(ln.ks, dim), sy = draw(ln.ks, dim + 1u);
-    const uint32_t e = lane_perm_entry(sc, ln, sx);
+    const uint32_t e = lane_perm_entry(sc, ln, sx, sy);
     u0 = u24_to_unit(((e & 0xf0u) << 24) ^ sx);   // van_der_corput(idx, sx)
     u1 = u24_to_unit((e << 28) ^ sy);             // sobol(idx, sy)
 }
 TR_DEV float lane_1d(const DevScene& sc, const Lane& ln, uint32_t dim) {
     const uint32_t s = draw(ln.ks, dim);
-    return u24_to_unit(((lane_perm_entry(sc, ln, s) & 0xf0u) << 24) ^ s);
+    return u24_to_unit(((lane_perm_entry(sc, ln, s, s >> 8) & 0xf0u) << 24) ^ s);
 }
 
 TR_DEV Ray stage_a_ray(const Lane& ln) {
@@ -197,10 +205,10 @@ TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counte
     const TrayInstance* __restrict__ light = sc.instances + ln.light_inst;
     // Light::sample_incident (emitter.rs:165-186)
     f3 p_w;
-    float x[24];   // ANIM: self.transform.transform(time) (emitter.rs:168,175)
+    float x[TR_XF_WORDS];   // ANIM: self.transform.transform(time) (emitter.rs:168,175)
     if (ANIM) instance_xf_at<ANIM>(sc, light, ln.time, ln.col, x);
     if (light->kind == TRAY_INST_POINT_EMITTER) {
-        f3 pos = ANIM ? xf_point_affine(x, mk(0.0f, 0.0f, 0.0f)) : xf_point(light->mat, mk(0.0f, 0.0f, 0.0f));
+        f3 pos = ANIM ? xf_point_affine_w(x, x[25], mk(0.0f, 0.0f, 0.0f)) : xf_point(light->mat, mk(0.0f, 0.0f, 0.0f));
         ln.wi_l = normalized(pos - ln.bsdf.p);
         ln.li = inst_emission<ANIM>(sc, light, ln.time) / length_sqr(pos - ln.bsdf.p);
         ln.pdf_l = 1.0f;
@@ -208,13 +216,13 @@ TR_DEV void vertex_begin(const DevScene& sc, Lane& ln, const HitRec& rec, Counte
     } else {
         float l2x, l2y;
         lane_2d(sc, ln, SD_L2, l2x, l2y);
-        f3 p_l = ANIM ? xf_point_affine(x + 12, ln.bsdf.p) : xf_point(light->inv, ln.bsdf.p);
+        f3 p_l = ANIM ? xf_point_affine_w(x + 12, x[24], ln.bsdf.p) : xf_point(light->inv, ln.bsdf.p);
         f3 p_sampled, normal;
         geom_sample(light, p_l, l2x, l2y, p_sampled, normal);
         f3 w_il = normalized(p_sampled - p_l);
         ln.pdf_l = geom_pdf(light, p_l, w_il);
         ln.li = emitter_radiance<ANIM>(sc, light, -w_il, normal, ln.time);
-        p_w = ANIM ? xf_point_affine(x, p_sampled) : xf_point(light->mat, p_sampled);
+        p_w = ANIM ? xf_point_affine_w(x, x[25], p_sampled) : xf_point(light->mat, p_sampled);
         ln.wi_l = ANIM ? xf_vector(x, w_il) : xf_vector(light->mat, w_il);
     }
     if (ln.pdf_l > 0.0f && !is_black(ln.li)) {
@@ -271,9 +279,9 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want, const f
                 // Light::pdf (emitter.rs:193-203)
                 f3 p_l, wl;
                 if (ANIM) {
-                    float x[24];
+                    float x[TR_XF_WORDS];
                     instance_xf_at<ANIM>(sc, light, ln.time, ln.col, x);
-                    p_l = xf_point_affine(x + 12, ln.bsdf.p);
+                    p_l = xf_point_affine_w(x + 12, x[24], ln.bsdf.p);
                     wl = normalized(xf_vector(x + 12, w_i));
                 } else {
                     p_l = xf_point(light->inv, ln.bsdf.p);
@@ -362,9 +370,9 @@ TR_DEV void mis_ray_filter(const DevScene& sc, Lane& ln) {
     if (gt != TRAY_GEOM_SPHERE && !(ln.flags & LF_MIS_UNTESTED)) return;
     f3 p_l, d_l;
     if (ANIM) {
-        float x[24];
+        float x[TR_XF_WORDS];
         instance_xf_at<ANIM>(sc, light, ln.time, ln.col, x);
-        p_l = xf_point_affine(x + 12, ln.bsdf.p);
+        p_l = xf_point_affine_w(x + 12, x[24], ln.bsdf.p);
         d_l = xf_vector(x + 12, ln.aux_d);
     } else {
         p_l = xf_point(light->inv, ln.bsdf.p);

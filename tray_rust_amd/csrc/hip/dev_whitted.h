@@ -34,22 +34,22 @@ struct WhFrame {        // one activation of Whitted::illumination
 template <int ANIM>
 TR_DEV void wh_light_sample(const DevScene& sc, const TrayInstance* __restrict__ light, f3 p, float u0, float u1, float time, uint32_t col,
                             f3& li, f3& w_i, float& pdf, f3& p_w) {
-    float x[24];
+    float x[TR_XF_WORDS];
     if (ANIM) instance_xf_at<ANIM>(sc, light, time, col, x);
     if (light->kind == TRAY_INST_POINT_EMITTER) {
-        const f3 pos = ANIM ? xf_point_affine(x, mk(0.0f, 0.0f, 0.0f)) : xf_point(light->mat, mk(0.0f, 0.0f, 0.0f));
+        const f3 pos = ANIM ? xf_point_affine_w(x, x[25], mk(0.0f, 0.0f, 0.0f)) : xf_point(light->mat, mk(0.0f, 0.0f, 0.0f));
         w_i = normalized(pos - p);
         li = inst_emission<ANIM>(sc, light, time) / length_sqr(pos - p);
         pdf = 1.0f;
         p_w = pos;
     } else {
-        const f3 p_l = ANIM ? xf_point_affine(x + 12, p) : xf_point(light->inv, p);
+        const f3 p_l = ANIM ? xf_point_affine_w(x + 12, x[24], p) : xf_point(light->inv, p);
         f3 p_sampled, normal;
         geom_sample(light, p_l, u0, u1, p_sampled, normal);
         const f3 w_il = normalized(p_sampled - p_l);
         pdf = geom_pdf(light, p_l, w_il);
         li = emitter_radiance<ANIM>(sc, light, -w_il, normal, time);
-        p_w = ANIM ? xf_point_affine(x, p_sampled) : xf_point(light->mat, p_sampled);
+        p_w = ANIM ? xf_point_affine_w(x, x[25], p_sampled) : xf_point(light->mat, p_sampled);
         w_i = ANIM ? xf_vector(x, w_il) : xf_vector(light->mat, w_il);
     }
 }

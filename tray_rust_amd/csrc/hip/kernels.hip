@@ -710,7 +710,7 @@ static uint32_t wf_slot_count(const TrayDeviceScene* s, size_t reclaimable = 0) 
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
         uint64_t budget = (free_b + reclaimable) / 4;
         if (const char* e = getenv("TRAYHIP_XF_CACHE_BYTES")) budget = (uint64_t)std::max(0ll, atoll(e));
-        const uint64_t per_slot = (uint64_t)s->deferred_n_moving * 24u * sizeof(float);
+        const uint64_t per_slot = (uint64_t)s->deferred_n_moving * TR_XF_WORDS * sizeof(float);
         const uint64_t fit = budget / per_slot / TR_BLOCK * TR_BLOCK;
         slots = std::min<uint64_t>(slots, std::max<uint64_t>(fit, (uint64_t)64 * TR_BLOCK));   // (at least 64 chunks: below that the schedule cannot fill the chip)
     }
@@ -1056,7 +1056,7 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         // cooperative test of small meshes (dev_geom.h: mesh_leaf_coop) in the flat instance loop: per-wave LDS behind the stacks
         bool single_leaf = false;
         for (uint32_t m = 0; m < f->n_meshes; ++m) single_leaf = single_leaf || f->meshes[m].tri_count <= TR_COOP_MAX_TRIS;
-        if (single_leaf && !s->wavefront && !s->animated && f->n_instances <= TR_FLAT_MAX && !getenv("TRAYHIP_NO_COOP")) {
+        if (single_leaf && !s->wavefront && f->n_instances <= TR_FLAT_MAX && !getenv("TRAYHIP_NO_COOP")) {   // (moving scenes too: the flat loop serves them since round 4)
             s->dev.coop_offset = depth * TR_BLOCK;
             s->stack_bytes += (TR_BLOCK / 64) * TR_COOP_WORDS * (uint32_t)sizeof(float);
         }
@@ -1116,7 +1116,7 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         const uint32_t lanes = keep_lanes ? donor->dev.xf_cache_lanes : (s->wavefront ? wf_slot_count(s, reclaimable) : (uint32_t)s->n_blocks * TR_BLOCK);
         const uint32_t n_moving_for_msg = s->deferred_n_moving;
         void* cache = nullptr;
-        const size_t cache_bytes = (size_t)s->deferred_n_moving * 24u * lanes * sizeof(float);
+        const size_t cache_bytes = (size_t)s->deferred_n_moving * TR_XF_WORDS * lanes * sizeof(float);
         if (keep_lanes && donor->dev.xf_cache && donor->xf_cache_bytes >= cache_bytes) {   // (every path fills its columns before it reads them)
             cache = donor->dev.xf_cache;
             s->xf_cache_bytes = donor->xf_cache_bytes;
@@ -1281,7 +1281,7 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             WfView& v = views[k];
             v.n_chunks = c1 - c0;
             v.dev = s->dev;
-            if (v.dev.xf_cache) v.dev.xf_cache += (size_t)c0 * TR_BLOCK * v.dev.n_moving * 24u;   // [slot][moving instance][24]
+            if (v.dev.xf_cache) v.dev.xf_cache += (size_t)c0 * TR_BLOCK * v.dev.n_moving * TR_XF_WORDS;   // [slot][moving instance][TR_XF_WORDS]
             v.pool = s->pool;
             v.pool.data += (size_t)c0 * TR_BLOCK;
             v.pool.seg_cap = wf_seg_cap(v.n_chunks);

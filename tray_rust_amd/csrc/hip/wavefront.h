@@ -470,9 +470,9 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                 WF_COUNT(c_inst);
                 f3 lo_, ld;
                 if (ANIM && (wflags & tray::WI_ANIMATED)) {   // the path's transform of a moving instance, from the per-slot cache
-                    float x[24];
+                    float x[TR_XF_WORDS];
                     instance_inv_cached(sc, wflags >> 8, slot, x);
-                    lo_ = xf_point_affine(x + 12, wo);
+                    lo_ = xf_point_affine_w(x + 12, x[24], wo);
                     ld = xf_vector(x + 12, wd);
                 } else if (wflags & tray::WI_AFFINE) {
                     const float m[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};

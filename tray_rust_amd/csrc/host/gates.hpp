@@ -34,7 +34,9 @@ struct FlatInst {   // 128 B
     float inv[16];            // world -> object (row 3 matters only for quirk Q5)
     float lo[3], hi[3];       // own world bounds, inflated (conservative cull)
     float gp0, gp1;
-    uint32_t geom_type, mesh_id, inst, pad[5];
+    uint32_t geom_type, mesh_id, inst;
+    uint32_t animated;        // the instance moves while the shutter is open: its transform is the path's (per-path cache), `inv` above is not used
+    uint32_t pad[4];
 };
 static_assert(sizeof(FlatLeaf) == 32 && sizeof(FlatInst) == 128, "records are read with aligned scalar loads");
 
@@ -303,7 +305,7 @@ inline void flat_loop_gates(const TrayFlatScene* f, const PairedTrees& paired, u
             FlatInst fi{};
             std::memcpy(fi.inv, in.inv, sizeof fi.inv);
             fi.gp0 = in.geom_params[0]; fi.gp1 = in.geom_params[1];
-            fi.geom_type = in.geom_type; fi.mesh_id = in.mesh_id; fi.inst = i;
+            fi.geom_type = in.geom_type; fi.mesh_id = in.mesh_id; fi.inst = i; fi.animated = in.animated ? 1u : 0u;
             // object-space bounds of the geometry
             float olo[3] = {0, 0, 0}, ohi[3] = {0, 0, 0};
             if (in.geom_type == TRAY_GEOM_RECT) { olo[0] = -0.5f * std::fabs(in.geom_params[0]); ohi[0] = -olo[0]; olo[1] = -0.5f * std::fabs(in.geom_params[1]); ohi[1] = -olo[1]; }
@@ -323,8 +325,9 @@ inline void flat_loop_gates(const TrayFlatScene* f, const PairedTrees& paired, u
                     wlo[r] = std::min(wlo[r], v); whi[r] = std::max(whi[r], v);
                 }
             }
-            // row 3 other than (0 0 0 1) would make the transform projective: no cull then
-            finite = finite && in.mat[12] == 0.0f && in.mat[13] == 0.0f && in.mat[14] == 0.0f && in.mat[15] == 1.0f;
+            // row 3 other than (0 0 0 1) would make the transform projective: no cull then; nor for an instance that moves within the frame
+            // (its own box would have to be its swept one; the gate that counts -- the BVH<Instance> leaf's box -- is the reference's either way)
+            finite = finite && in.mat[12] == 0.0f && in.mat[13] == 0.0f && in.mat[14] == 0.0f && in.mat[15] == 1.0f && !in.animated;
             double scale = 0.0;
             for (int r = 0; r < 3; ++r) scale = std::max({scale, std::fabs(wlo[r]), std::fabs(whi[r])});
             const double margin = 1e-4 * scale + 1e-6;
