@@ -156,6 +156,16 @@ TR_DEV void instance_inv_cached(const DevScene& sc, uint32_t moving_slot, uint32
     for (int q = 0; q < 3; ++q) { const float4 v = rec[q]; x[12 + 4 * q] = v.x; x[13 + 4 * q] = v.y; x[14 + 4 * q] = v.z; x[15 + 4 * q] = v.w; }
     x[24] = rec[3].x;
 }
+// rows of inv and its [3][3] (x + 12 .. x + 24) of ANY instance in a kernel built for moving scenes: the path's own if the instance moves
+template <int ANIM>
+TR_DEV void instance_inv_any(const DevScene& sc, const TrayInstance* __restrict__ in, float time, uint32_t column, float* x) {
+    if (in->animated) instance_inv_at<ANIM>(sc, in, time, column, x);
+    else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) x[12 + k] = in->inv[k];
+        x[24] = in->inv[15];
+    }
+}
 template <int ANIM>
 TR_DEV void instance_xf_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, uint32_t column, float* x) {
     if (in->animated) {
@@ -907,7 +917,7 @@ TR_DEV f3 finish_hit_ng(const DevScene& sc, const Ray& ray, const HitRec& rec) {
     uint32_t gt = in->geom_type;
     f3 ng;
     float x[TR_XF_WORDS];
-    if (ANIM) instance_xf_at<ANIM>(sc, in, ray.time, ray.col, x);
+    if (ANIM) instance_inv_any<ANIM>(sc, in, ray.time, ray.col, x);   // (only the inverse is used below)
     if (gt == TRAY_GEOM_SPHERE) {
         f3 o = ANIM ? xf_point_affine_w(x + 12, x[24], ray.o) : xf_point(in->inv, ray.o);
         f3 d = ANIM ? xf_vector(x + 12, ray.d) : xf_vector(in->inv, ray.d);

@@ -137,6 +137,9 @@ TR_DEV void lane_start_sample(Lane& ln, const Ray& cam_ray, uint32_t ks) {
 TR_DEV uint32_t lane_perm_entry(const DevScene& sc, const Lane& ln, uint32_t s1, uint32_t s2) {
     const uint32_t off1 = ((s1 & (TR_PERM_POOL - 1u)) << 4) + ln.bounce;
     const uint32_t e1 = ln.perm_lds ? (uint32_t)ln.perm_lds[off1] : (uint32_t)sc.perm_pool[off1];
+#ifdef TR_PERM_SINGLE   // (timing switch only: the v2 sampler, another definition)
+    (void)s2; return e1;
+#endif
     const uint32_t off2 = ((s2 & (TR_PERM_POOL - 1u)) << 4) + (__brev(e1 >> 4) >> 28);
     return ln.perm_lds ? (uint32_t)ln.perm_lds[off2] : (uint32_t)sc.perm_pool[off2];
 }
@@ -280,7 +283,7 @@ TR_DEV uint32_t query_stage(const DevScene& sc, Lane& ln, uint32_t want, const f
                 f3 p_l, wl;
                 if (ANIM) {
                     float x[TR_XF_WORDS];
-                    instance_xf_at<ANIM>(sc, light, ln.time, ln.col, x);
+                    instance_inv_any<ANIM>(sc, light, ln.time, ln.col, x);   // (Light::pdf needs the inverse only)
                     p_l = xf_point_affine_w(x + 12, x[24], ln.bsdf.p);
                     wl = normalized(xf_vector(x + 12, w_i));
                 } else {
@@ -371,7 +374,7 @@ TR_DEV void mis_ray_filter(const DevScene& sc, Lane& ln) {
     f3 p_l, d_l;
     if (ANIM) {
         float x[TR_XF_WORDS];
-        instance_xf_at<ANIM>(sc, light, ln.time, ln.col, x);
+        instance_inv_any<ANIM>(sc, light, ln.time, ln.col, x);
         p_l = xf_point_affine_w(x + 12, x[24], ln.bsdf.p);
         d_l = xf_vector(x + 12, ln.aux_d);
     } else {

@@ -604,6 +604,10 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
                                                        uint32_t* __restrict__ queue_b, uint32_t* __restrict__ qctl, uint32_t* __restrict__ kind_queues) {
     __shared__ uint32_t s_cnt[8], s_base[8];
     __shared__ uint32_t s_oct_cnt[WF_SORT_KEYS], s_oct_base[WF_SORT_KEYS];
+    // the scene's permutation pool in LDS, as in the tile kernel: a shuffled index is two dependent byte reads (dev_integrator.h: lane_perm_entry)
+    __shared__ uint4 s_perm[TR_PERM_BYTES / 16];
+    s_perm[threadIdx.x] = reinterpret_cast<const uint4*>(scv.perm_pool)[threadIdx.x];   // TR_PERM_BYTES / 16 == TR_BLOCK
+    __syncthreads();
     uint32_t b_oct = 0u;   // direction octant of the slot's occlusion ray
     f3 b_o = mk(0.0f, 0.0f, 0.0f), b_d = b_o;   // ... and the ray
     const DevScene& sc = scv;
@@ -621,6 +625,9 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
         pu(pool, F_FLAGS, i) = (flags & ~(LF_ALIVE | WF_INVERTEX)) | WF_FINISHED;
     } else if (flags & LF_ALIVE) {
         Lane ln;
+#ifndef WF_PERM_GLOBAL
+        ln.perm_lds = TR_LDS_B(s_perm);
+#endif
         ln.flags = flags;
         ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
         LN_O(ln) = ld3(pool, F_O, i); ln.d = ld3(pool, F_D, i);
@@ -693,8 +700,11 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
 // Stage B shading of pool slot i: the BSDF queries of the vertex (light half, BSDF half, continuation)
 template <int ANIM, int FEAT, uint32_t KM>
 TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, uint32_t flags, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl,
-                           DevStats* __restrict__ stats) {
+                           DevStats* __restrict__ stats, LdsB perm_lds) {
     Lane ln;
+#ifndef WF_PERM_GLOBAL
+    ln.perm_lds = perm_lds;
+#endif
     ln.flags = flags;
     ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
     ln.throughput = ld3(pool, F_T, i);
@@ -739,11 +749,14 @@ template <int ANIM, int FEAT>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(
     const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl, DevStats* __restrict__ stats) {
     const DevScene& sc = scv;
+    __shared__ uint4 s_perm[TR_PERM_BYTES / 16];   // the permutation pool in LDS (as in k_wf_begin)
+    s_perm[threadIdx.x] = reinterpret_cast<const uint4*>(sc.perm_pool)[threadIdx.x];
+    __syncthreads();
     const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
     if (i >= n_active) return;
     const uint32_t flags = pu(pool, F_FLAGS, i);
     if ((flags & (LF_ALIVE | WF_INVERTEX)) != (LF_ALIVE | WF_INVERTEX)) return;
-    wf_query_slot<ANIM, FEAT, KM_ALL>(sc, pool, i, flags, queue_c, qctl, stats);
+    wf_query_slot<ANIM, FEAT, KM_ALL>(sc, pool, i, flags, queue_c, qctl, stats, TR_LDS_B(s_perm));
 }
 
 // kind-pure shading: one thread per entry of material kind MK's queue (filled by k_wf_begin's counting sort); only the lobes that
@@ -753,9 +766,13 @@ template <int ANIM, int MK>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_query_kind(const DevScene scv, WfPool pool, const uint32_t* __restrict__ kind_queues,
                                                             uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl, DevStats* __restrict__ stats) {
     const DevScene& sc = scv;
+    __shared__ uint4 s_perm[TR_PERM_BYTES / 16];   // the permutation pool in LDS (as in k_wf_begin)
+    if (blockIdx.x / WF_SEGS * TR_BLOCK >= qctl[wf_my_seg() * WF_SEG_STRIDE + 8u + MK]) return;   // (the whole workgroup lies past the queue's end)
+    s_perm[threadIdx.x] = reinterpret_cast<const uint4*>(sc.perm_pool)[threadIdx.x];
+    __syncthreads();
     uint32_t i;
     if (!wf_my_entry(pool, kind_queues + (size_t)MK * WF_SEGS * pool.seg_cap, qctl, 8u + MK, i)) return;
-    wf_query_slot<ANIM, feat_of_material(MK), km_of_material(MK)>(sc, pool, i, pu(pool, F_FLAGS, i), queue_c, qctl, stats);
+    wf_query_slot<ANIM, feat_of_material(MK), km_of_material(MK)>(sc, pool, i, pu(pool, F_FLAGS, i), queue_c, qctl, stats, TR_LDS_B(s_perm));
 }
 
 // New camera sample for pool slot i of a chunk that works on tile `tile_idx` (multithreaded.rs:90-96)
