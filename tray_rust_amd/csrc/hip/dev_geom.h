@@ -594,6 +594,9 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
     bool any = false, done = !active;   // lanes without a ray run along: the cooperative leaf test uses their ALUs
     const f3 w_inv_dir = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     const bool wnx = ray.d.x < 0.0f, wny = ray.d.y < 0.0f, wnz = ray.d.z < 0.0f;
+#ifdef TR_FLAT_PK
+    const f2 wpx = mk2(ray.o.x, ray.d.x), wpy = mk2(ray.o.y, ray.d.y), wpz = mk2(ray.o.z, ray.d.z);
+#endif
     // the leaf and instance indices are wave-uniform: the records are read through the constant address space so that boxes,
     // transforms and geometry parameters arrive as scalar loads (SGPRs), not 64 identical lane loads
     typedef const __attribute__((address_space(4))) tray::FlatLeaf* ConstLeaf;
@@ -630,8 +633,18 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
                 o = xf_point_affine_w(x + 12, x[24], ray.o);
                 d = xf_vector(x + 12, ray.d);
             } else {
+#ifdef TR_FLAT_PK   // (experiment, profiles/r04_tile_kernel_packed_ab.txt: origin and direction side by side in packed arithmetic; the matrix is scalar)
+                const f2 a0 = wpx * splat2(inv[0]) + wpy * splat2(inv[1]) + wpz * splat2(inv[2]);
+                const f2 a1 = wpx * splat2(inv[4]) + wpy * splat2(inv[5]) + wpz * splat2(inv[6]);
+                const f2 a2 = wpx * splat2(inv[8]) + wpy * splat2(inv[9]) + wpz * splat2(inv[10]);
+                o = mk(a0.x + inv[3], a1.x + inv[7], a2.x + inv[11]);
+                d = mk(a0.y, a1.y, a2.y);
+                const float w = inv[12] * ray.o.x + inv[13] * ray.o.y + inv[14] * ray.o.z + inv[15];
+                if (w != 1.0f && fabsf(w - 1.0f) < kEps) o = o / w;   // quirk Q5 (xf_point)
+#else
                 o = xf_point(inv, ray.o);
                 d = xf_vector(inv, ray.d);
+#endif
             }
             const float bound = fmaxf(max_t, best_gate);   // (best_gate is -inf until a candidate was accepted)
             float t = bound;
