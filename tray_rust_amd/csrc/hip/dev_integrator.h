@@ -137,9 +137,6 @@ TR_DEV void lane_start_sample(Lane& ln, const Ray& cam_ray, uint32_t ks) {
 TR_DEV uint32_t lane_perm_entry(const DevScene& sc, const Lane& ln, uint32_t s1, uint32_t s2) {
     const uint32_t off1 = ((s1 & (TR_PERM_POOL - 1u)) << 4) + ln.bounce;
     const uint32_t e1 = ln.perm_lds ? (uint32_t)ln.perm_lds[off1] : (uint32_t)sc.perm_pool[off1];
-#ifdef TR_PERM_SINGLE   // (timing switch only: the v2 sampler, another definition)
-    (void)s2; return e1;
-#endif
     const uint32_t off2 = ((s2 & (TR_PERM_POOL - 1u)) << 4) + (__brev(e1 >> 4) >> 28);
     return ln.perm_lds ? (uint32_t)ln.perm_lds[off2] : (uint32_t)sc.perm_pool[off2];
 }

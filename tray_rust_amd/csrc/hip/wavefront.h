@@ -625,9 +625,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
         pu(pool, F_FLAGS, i) = (flags & ~(LF_ALIVE | WF_INVERTEX)) | WF_FINISHED;
     } else if (flags & LF_ALIVE) {
         Lane ln;
-#ifndef WF_PERM_GLOBAL
         ln.perm_lds = TR_LDS_B(s_perm);
-#endif
         ln.flags = flags;
         ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
         LN_O(ln) = ld3(pool, F_O, i); ln.d = ld3(pool, F_D, i);
@@ -702,9 +700,7 @@ template <int ANIM, int FEAT, uint32_t KM>
 TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, uint32_t flags, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl,
                            DevStats* __restrict__ stats, LdsB perm_lds) {
     Lane ln;
-#ifndef WF_PERM_GLOBAL
     ln.perm_lds = perm_lds;
-#endif
     ln.flags = flags;
     ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
     ln.throughput = ld3(pool, F_T, i);
