@@ -330,6 +330,27 @@ int tray_shard_tiles(uint32_t n_tiles, uint32_t shard, uint32_t n_shards, uint32
 int tray_render_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count,
                       uint32_t spp, uint64_t seed, float* rgbw_host);
 
+/* ---- the other Samplers (src/sampler/mod.rs:20-49) -----------------------------------------------------------------
+ * thread_work constructs `sampler::LowDiscrepancy::new(queue.block_dim(), spp)` (exec/multithreaded.rs:74); sampler/uniform.rs and
+ * sampler/adaptive.rs implement the same trait and are what a maintainer would write there instead. tray_scene_set_sampler selects
+ * which one the render calls on this handle stand for:
+ *   TRAY_SAMPLER_LOW_DISCREPANCY  LowDiscrepancy::new(dim, spp) -- the default; `spp` of the render call (ld.rs:20-31)
+ *   TRAY_SAMPLER_UNIFORM          Uniform::new(dim): one sample at the centre of every pixel, every other number an independent
+ *                                 uniform draw (uniform.rs:22-47); the render call's spp is not used
+ *   TRAY_SAMPLER_ADAPTIVE         Adaptive::new(dim, min_spp, max_spp): min_spp samples per pixel, then step_size more while the
+ *                                 luminance of any of the pixel's samples so far lies more than 50 % off their running average and fewer
+ *                                 than max_spp have been taken (adaptive.rs:34-75, 133-143 incl. its (i - 1) / i averaging and the
+ *                                 sample-index offsets of adaptive.rs:112-121); min_spp / max_spp are rounded up to powers of two as
+ *                                 Adaptive::new does (0 counts as 1); the render call's spp is not used
+ * Every sample is still keyed by (seed, frame, pixel, pass, index) (TRAY-CBRNG), so shards and tile ranges add up
+ * to the same film. Uniform and Adaptive run one thread per camera sample of a pass (k_sampler_pass) for every scene; the per-pixel
+ * sample counts of the last render are reported through TrayKernelTiming.samples (their sum). min_spp / max_spp are ignored for the
+ * other two kinds. Returns TRAY_E_INVALID for an unknown kind or max_spp < min_spp after rounding. */
+enum { TRAY_SAMPLER_LOW_DISCREPANCY = 0, TRAY_SAMPLER_UNIFORM = 1, TRAY_SAMPLER_ADAPTIVE = 2 };
+int tray_scene_set_sampler(TrayDeviceScene* s, uint32_t kind, uint32_t min_spp, uint32_t max_spp);
+/* Adaptive::new's step_size (adaptive.rs:48): ((max_spp - min_spp) / 5).next_power_of_two(), of the ROUNDED min / max */
+uint32_t tray_adaptive_step(uint32_t min_spp, uint32_t max_spp);
+
 /* Timing of the most recent tray_render_tiles_device launch sequence on this scene, measured with
  * HIP events on the launch stream. Blocks until those kernels finished. */
 typedef struct TrayKernelTiming {
@@ -358,6 +379,8 @@ int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t);
 typedef struct TrayMultiScene TrayMultiScene;
 int tray_multi_create(const TrayFlatScene* f, int n_dev, const int* dev_ids, TrayMultiScene** out);
 int tray_render_frame_multi(TrayMultiScene* m, uint32_t spp, uint64_t seed, float* rgbw_host);
+/* tray_scene_set_sampler on every device of m */
+int tray_multi_set_sampler(TrayMultiScene* m, uint32_t kind, uint32_t min_spp, uint32_t max_spp);
 /* tray_scene_update_frame on every device of m; the communicators, films and streams are kept (scene.rs:152-176 per worker) */
 int tray_multi_update_frame(TrayMultiScene* m, const TrayFlatScene* f);
 /* per-device timings of the last tray_render_frame_multi (n_dev entries) and the duration of the reduce (ms) */

@@ -59,8 +59,12 @@ struct PathSamples {
     uint32_t scr[9];
     const uint8_t* perm[6];
     uint8_t own[6][16];   // this path's six shuffles (the composed pool permutations; ORC_FRESH_SHUFFLES: six Fisher-Yates shuffles of its own)
-    void init(uint32_t key_samp, uint32_t num_samples, bool fresh = false) {
-        ks = key_samp; n = num_samples;
+    // which Sampler fills the arrays (sampler/mod.rs:20-49): LowDiscrepancy (ld.rs:54-64); Adaptive -- the same with the (0,2) points
+    // starting at index samples_taken (adaptive.rs:112-121: ld::sample_2d(samples, scramble, self.samples_taken)); Uniform -- every entry
+    // Range::new(0.0, 1.0).ind_sample(rng) (uniform.rs:36-46), here next_f32 of draw(ks, 64 + 32 * dim + 2 * entry (+ 1 for the second coordinate))
+    uint32_t kind = TRAY_SAMPLER_LOW_DISCREPANCY, offset = 0;
+    void init(uint32_t key_samp, uint32_t num_samples, bool fresh = false, uint32_t sampler_kind = TRAY_SAMPLER_LOW_DISCREPANCY, uint32_t samples_taken = 0) {
+        ks = key_samp; n = num_samples; kind = sampler_kind; offset = sampler_kind == TRAY_SAMPLER_ADAPTIVE ? samples_taken : 0u;
         const PermPool& pool = perm_pool(n);
         // 2-D arrays: scramble x, scramble y; 1-D arrays: scramble
         const int d2[3] = {SD_L2, SD_B2, SD_P2}, d1[3] = {SD_L1, SD_B1, SD_P1};
@@ -79,12 +83,19 @@ struct PathSamples {
         if (fresh)   // Rng::shuffle per array (ld.rs:58,63), each under a key of its own
             for (int a = 0; a < 6; ++a) { shuffle_small(draw(ks, 40u + (uint32_t)a), n <= 16u ? n : 16u, own[a]); perm[a] = own[a]; }
     }
+    float uniform(uint32_t dim, uint32_t bounce, uint32_t c) const { return (float)(draw(ks, 64u + 32u * dim + 2u * bounce + c) >> 8) / (float)(1u << 24); }
     void two_d(int a, uint32_t bounce, float& u0, float& u1) const {   // sample_02 (ld.rs:91-93)
-        uint32_t idx = perm[a][bounce];
+        const uint32_t d2[3] = {SD_L2, SD_B2, SD_P2};
+        if (kind == TRAY_SAMPLER_UNIFORM) { u0 = uniform(d2[a], bounce, 0u); u1 = uniform(d2[a], bounce, 1u); return; }
+        uint32_t idx = perm[a][bounce] + offset;
         u0 = van_der_corput(idx, scr[2 * a]);
         u1 = sobol(idx, scr[2 * a + 1]);
     }
-    float one_d(int a, uint32_t bounce) const { return van_der_corput(perm[3 + a][bounce], scr[6 + a]); }
+    float one_d(int a, uint32_t bounce) const {
+        const uint32_t d1[3] = {SD_L1, SD_B1, SD_P1};
+        if (kind == TRAY_SAMPLER_UNIFORM) return uniform(d1[a], bounce, 0u);
+        return van_der_corput(perm[3 + a][bounce] + offset, scr[6 + a]);
+    }
     float rr(uint32_t bounce) const { return (float)(draw(ks, SD_RR + bounce) >> 8) / (float)(1u << 24); }   // Rng::next_f32
 };
 
@@ -214,11 +225,20 @@ Colorf path_illumination(const SceneView& sv, const Ray& r, const Hit& hit, cons
 // (integrator/mod.rs:49-97), recursive as in the reference. Random numbers: every activation is a node with a key; a one-element
 // LowDiscrepancy::get_samples_2d / _1d (ld.rs:54-64) is the scrambled (0,2) point of index 0 with fresh scrambles
 enum : uint32_t { WD_L2 = 0, WD_R2 = 2, WD_R1 = 4, WD_T2 = 5, WD_T1 = 7, WD_CHILD = 8 };
+// (a one-element array under the scene's Sampler: LowDiscrepancy -- the point of index 0; Adaptive -- of index samples_taken; Uniform -- a uniform draw)
+inline float whitted_vdc(const SceneView& sv, uint32_t key, uint32_t d) {
+    if (sv.smp_kind == TRAY_SAMPLER_UNIFORM) return (float)(draw(key, d) >> 8) / (float)(1u << 24);
+    return van_der_corput(sv.smp_kind == TRAY_SAMPLER_ADAPTIVE ? sv.smp_offset : 0u, draw(key, d));
+}
+inline float whitted_sobol(const SceneView& sv, uint32_t key, uint32_t d) {
+    if (sv.smp_kind == TRAY_SAMPLER_UNIFORM) return (float)(draw(key, d) >> 8) / (float)(1u << 24);
+    return sobol(sv.smp_kind == TRAY_SAMPLER_ADAPTIVE ? sv.smp_offset : 0u, draw(key, d));
+}
 Colorf whitted_illumination(const SceneView& sv, const Ray& ray, const Hit& hit, uint32_t key, uint32_t depth);
 Colorf whitted_specular(const SceneView& sv, const Ray& ray, const BSDF& bsdf, uint32_t key, uint32_t depth, bool transmission) {
     const Vec3 w_o = -ray.d;
     const uint32_t d2 = transmission ? WD_T2 : WD_R2, d1 = transmission ? WD_T1 : WD_R1;
-    const float u0 = van_der_corput(0u, draw(key, d2)), u1 = sobol(0u, draw(key, d2 + 1u)), one_d = van_der_corput(0u, draw(key, d1));
+    const float u0 = whitted_vdc(sv, key, d2), u1 = whitted_sobol(sv, key, d2 + 1u), one_d = whitted_vdc(sv, key, d1);
     Vec3 w_i;
     float pdf;
     int sampled_type;
@@ -240,7 +260,7 @@ Colorf whitted_illumination(const SceneView& sv, const Ray& ray, const Hit& hit,
     if (sv.stats) sv.stats->vertices++;
     const BSDF bsdf = material_bsdf(fs, hit);
     const Vec3 w_o = -ray.d;
-    const float u0 = van_der_corput(0u, draw(key, WD_L2)), u1 = sobol(0u, draw(key, WD_L2 + 1u));
+    const float u0 = whitted_vdc(sv, key, WD_L2), u1 = whitted_sobol(sv, key, WD_L2 + 1u);
     Colorf illum = Colorf::broadcast(0.0f);
     const TrayInstance& inst = fs.instances[hit.inst];
     if (depth == 0u && inst.kind != TRAY_INST_RECEIVER) illum = illum + emitter_radiance(sv, inst, w_o, hit.ng, ray.time);
@@ -274,20 +294,17 @@ struct PixelSampler {   // per-pixel part of LowDiscrepancy (ld.rs:33-64) over t
     float time(uint32_t s) const { return van_der_corput(permute(s, spp, key_t), scr_t); }
 };
 
-// One camera sample of thread_work's inner loop (multithreaded.rs:94-103): returns the clamped colour
-Colorf trace_sample(const SceneView& sv, uint32_t kf, uint32_t px, uint32_t py, uint32_t s, uint32_t spp, float& sx, float& sy) {
+// The body of thread_work's inner loop for one camera sample (multithreaded.rs:95-103): the clamped colour of the sample at film
+// position (sx, sy) and time t; ks = the key every random number of the path derives from
+Colorf sample_radiance(const SceneView& sv, float sx, float sy, float t, uint32_t ks) {
     const TrayFlatScene& fs = *sv.fs;
-    PixelSampler pix;
-    pix.init(kf, py * fs.film.width + px, spp);
-    pix.position(s, px, py, sx, sy);
-    float t = pix.time(s);
     if (sv.stats) sv.stats->samples++;
     Ray ray = camera_generate_ray(sv, sx, sy, t);
     Hit hit;
     if (scene_intersect(sv, ray, hit)) {
-        if (sv.fs->integrator == TRAY_INTEGRATOR_WHITTED) return whitted_illumination(sv, ray, hit, key_sample(pix.kp, s), 0u).clamp();
+        if (sv.fs->integrator == TRAY_INTEGRATOR_WHITTED) return whitted_illumination(sv, ray, hit, ks, 0u).clamp();
         PathSamples ps;
-        ps.init(key_sample(pix.kp, s), fs.max_depth + 1, (sv.flags & ORC_FRESH_SHUFFLES) != 0);
+        ps.init(ks, fs.max_depth + 1, (sv.flags & ORC_FRESH_SHUFFLES) != 0, sv.smp_kind, sv.smp_offset);
         if (sv.fs->integrator == TRAY_INTEGRATOR_NORMALS_DEBUG) {   // NormalsDebug::illumination (integrator/normals_debug.rs:28-33)
             if (sv.stats) sv.stats->vertices++;
             const BSDF bsdf = material_bsdf(*sv.fs, hit);
@@ -297,8 +314,151 @@ Colorf trace_sample(const SceneView& sv, uint32_t kf, uint32_t px, uint32_t py, 
     }
     return Colorf::black();
 }
+// ... with LowDiscrepancy's positions and times (ld.rs:33-64): sample s of pixel (px, py)
+Colorf trace_sample(const SceneView& sv, uint32_t kf, uint32_t px, uint32_t py, uint32_t s, uint32_t spp, float& sx, float& sy) {
+    PixelSampler pix;
+    pix.init(kf, py * sv.fs->film.width + px, spp);
+    pix.position(s, px, py, sx, sy);
+    return sample_radiance(sv, sx, sy, pix.time(s), key_sample(pix.kp, s));
+}
 
 struct ImageSample { float x, y; Colorf c; };
+
+// ---- the Sampler trait as thread_work uses it (sampler/mod.rs:20-49), over the counter RNG: every number is a function of the frame
+// key, the pixel, the get_samples round and the index inside it, so tiles, threads and shards add up to the same film.
+struct Region {   // sampler/mod.rs:62-98
+    uint32_t cur_x = 0, cur_y = 0, start_x = 0, start_y = 0, end_x = 0, end_y = 0;
+    void select_region(uint32_t x0, uint32_t y0) { start_x = cur_x = x0; start_y = cur_y = y0; end_x = x0 + 8; end_y = y0 + 8; }
+    void advance() {   // x fastest (ld.rs:47-51, uniform.rs:29-33, adaptive.rs:137-141)
+        cur_x += 1;
+        if (cur_x == end_x) { cur_x = start_x; cur_y += 1; }
+    }
+};
+inline uint32_t next_power_of_two(uint32_t v) { uint32_t p = 1; while (p < v && p < 0x80000000u) p <<= 1; return p; }   // usize::next_power_of_two (0 -> 1)
+
+// sampler/ld.rs:20-64: all spp samples of a pixel per get_samples call
+struct LowDiscrepancySampler {
+    uint32_t kf, width, spp;
+    Region region;
+    PixelSampler pix;
+    uint32_t sx = 0, sy = 0;
+    LowDiscrepancySampler(uint32_t kf_, uint32_t width_, uint32_t spp_) : kf(kf_), width(width_), spp(spp_) {}
+    uint32_t max_spp() const { return spp; }
+    uint32_t kind() const { return TRAY_SAMPLER_LOW_DISCREPANCY; }
+    uint32_t samples_taken() const { return 0u; }
+    void select_block(uint32_t x0, uint32_t y0) { region.select_region(x0, y0); }
+    bool has_samples() const { return region.cur_y != region.end_y; }
+    void get_samples(std::vector<std::pair<float, float>>& samples) {
+        samples.clear();
+        if (!has_samples()) return;
+        sx = region.cur_x; sy = region.cur_y;
+        pix.init(kf, sy * width + sx, spp);
+        samples.resize(spp);
+        for (uint32_t s = 0; s < spp; ++s) pix.position(s, sx, sy, samples[s].first, samples[s].second);
+        region.advance();
+    }
+    void get_samples_1d(std::vector<float>& t) { for (uint32_t s = 0; s < spp && s < t.size(); ++s) t[s] = pix.time(s); }
+    uint32_t path_key(uint32_t k) const { return key_sample(pix.kp, k); }
+    uint32_t sampled_x() const { return sx; }
+    uint32_t sampled_y() const { return sy; }
+    bool report_results(const ImageSample*, size_t) { return true; }   // sampler/mod.rs:48
+};
+
+// sampler/uniform.rs:15-55: one sample at the centre of the pixel; every other number an independent uniform draw
+struct UniformSampler {
+    uint32_t kf, width;
+    Region region;
+    uint32_t kp = 0, sx = 0, sy = 0;
+    UniformSampler(uint32_t kf_, uint32_t width_) : kf(kf_), width(width_) {}
+    uint32_t max_spp() const { return 1u; }
+    uint32_t kind() const { return TRAY_SAMPLER_UNIFORM; }
+    uint32_t samples_taken() const { return 0u; }
+    void select_block(uint32_t x0, uint32_t y0) { region.select_region(x0, y0); }
+    bool has_samples() const { return region.cur_y != region.end_y; }
+    void get_samples(std::vector<std::pair<float, float>>& samples) {
+        samples.clear();
+        if (!has_samples()) return;
+        sx = region.cur_x; sy = region.cur_y;
+        kp = key_pixel(kf, sy * width + sx);
+        samples.push_back({(float)sx + 0.5f, (float)sy + 0.5f});   // uniform.rs:28
+        region.advance();
+    }
+    void get_samples_1d(std::vector<float>& t) { if (!t.empty()) t[0] = (float)(draw(kp, PD_SCR_T) >> 8) / (float)(1u << 24); }   // uniform.rs:42-46
+    uint32_t path_key(uint32_t) const { return key_sample(kp, 0u); }
+    uint32_t sampled_x() const { return sx; }
+    uint32_t sampled_y() const { return sy; }
+    bool report_results(const ImageSample*, size_t) { return true; }
+};
+
+// sampler/adaptive.rs:17-143. Round j of a pixel (the j-th get_samples call before report_results lets go of it) has the key
+// key_pass(kp, j): its two position scrambles, its time scramble and its two shuffles (Kensler's hashed permutation stands for
+// rng.shuffle, as in PixelSampler) derive from it; sample i of the round has the path key key_sample(key_pass, i).
+struct AdaptiveSampler {
+    uint32_t kf, width;
+    Region region;
+    uint32_t min_spp, max_spp_, step_size, taken = 0;
+    float avg_luminance = 0.0f;
+    uint32_t round = 0, count = 0, kq = 0, sx = 0, sy = 0;
+    AdaptiveSampler(uint32_t kf_, uint32_t width_, uint32_t min_spp_, uint32_t max_spp__) : kf(kf_), width(width_) {
+        min_spp = next_power_of_two(min_spp_);    // adaptive.rs:36-47 (is_power_of_two is false for 0)
+        max_spp_ = next_power_of_two(max_spp__);
+        step_size = next_power_of_two((max_spp_ - min_spp) / 5u);   // adaptive.rs:48
+    }
+    uint32_t max_spp() const { return max_spp_; }
+    uint32_t kind() const { return TRAY_SAMPLER_ADAPTIVE; }
+    uint32_t samples_taken() const { return taken; }
+    void select_block(uint32_t x0, uint32_t y0) { region.select_region(x0, y0); }
+    bool has_samples() const { return region.cur_y != region.end_y; }
+    void get_samples(std::vector<std::pair<float, float>>& samples) {
+        samples.clear();
+        if (!has_samples()) return;
+        sx = region.cur_x; sy = region.cur_y;
+        if (taken == 0) { taken += min_spp; count = min_spp; round = 0; }   // adaptive.rs:97-102
+        else { taken += step_size; count = step_size; round += 1; }         // adaptive.rs:103-109
+        samples.resize(count);
+        kq = key_pass(key_pixel(kf, sy * width + sx), round);
+        // get_samples_2d (adaptive.rs:112-116): sample_2d(samples, scramble, samples_taken), then rng.shuffle
+        const uint32_t scr_x = draw(kq, PD_SCR_X), scr_y = draw(kq, PD_SCR_Y), key_xy = draw(kq, PD_PERM_XY);
+        for (uint32_t i = 0; i < count; ++i) {
+            const uint32_t n = permute(i, count, key_xy) + taken;
+            samples[i].first = van_der_corput(n, scr_x) + (float)sx;      // adaptive.rs:107-110
+            samples[i].second = sobol(n, scr_y) + (float)sy;
+        }
+    }
+    // get_samples_1d (adaptive.rs:117-121) on thread_work's max_spp-long time_samples: every entry is filled and shuffled, the zip
+    // of multithreaded.rs:94 then uses the first `count`
+    void get_samples_1d(std::vector<float>& t) {
+        const uint32_t scr_t = draw(kq, PD_SCR_T), key_t = draw(kq, PD_PERM_T);
+        for (uint32_t i = 0; i < t.size(); ++i) t[i] = van_der_corput(permute(i, (uint32_t)t.size(), key_t) + taken, scr_t);
+    }
+    uint32_t path_key(uint32_t i) const { return key_sample(kq, i); }
+    uint32_t sampled_x() const { return sx; }
+    uint32_t sampled_y() const { return sy; }
+    // adaptive.rs:55-75
+    bool needs_supersampling(const ImageSample* samples, size_t n) {
+        const float max_contrast = 0.5f;
+        if (taken == min_spp) {
+            float ac = 0.0f;
+            for (size_t k = 0; k < n; ++k) ac = ac + samples[k].c.luminance();
+            avg_luminance = ac / (float)n;
+        } else {
+            const size_t prev_samples = n - step_size;
+            for (size_t i = prev_samples; i < n; ++i) avg_luminance = (samples[i].c.luminance() + (float)(i - 1) * avg_luminance) / (float)i;
+        }
+        for (size_t k = 0; k < n; ++k)
+            if (std::fabs(samples[k].c.luminance() - avg_luminance) / avg_luminance > max_contrast) return true;
+        return false;
+    }
+    // adaptive.rs:133-143
+    bool report_results(const ImageSample* samples, size_t n) {
+        if (taken >= max_spp_ || !needs_supersampling(samples, n)) {
+            taken = 0;
+            region.advance();
+            return true;
+        }
+        return false;
+    }
+};
 
 // RenderTarget::write (render_target.rs:77-165) into a dense RGBW image (get_renderf32 layout)
 // Destination pixel (ix, iy) lives at dst + ((iy - oy) * stride + (ix - ox)) * 4.
@@ -369,14 +529,16 @@ extern "C" {
 
 typedef struct OracleStats { uint64_t samples, vertices, rays; double seconds; } OracleStats;
 
-// thread_work over tiles [tile_start, tile_start + tile_count) of the Morton queue with n_threads
-// workers pulling tiles from an atomic counter (block_queue.rs:52-59). Adds into rgbw
-// (width*height*4 f32). Tile results are merged in queue order so the output does not depend on
-// the thread count. flags: ORC_FAITHFUL_XF | ORC_BRUTE_FORCE. `stride` > 1 renders only every
-// stride-th tile of the range (bench subset).
-int oracle_render_tiles(const TrayFlatScene* fs, uint32_t tile_start, uint32_t tile_count, uint32_t stride, uint32_t spp,
-                        uint64_t seed, float* rgbw, int n_threads, int flags, OracleStats* stats_out) {
-    if (!fs || !rgbw || fs->n_lights == 0 || (spp & (spp - 1)) != 0 || spp == 0) return -1;
+}  // extern "C"
+
+// thread_work (exec/multithreaded.rs:72-114) over tiles [tile_start, tile_start + tile_count) of the Morton queue with n_threads
+// workers pulling tiles from an atomic counter (block_queue.rs:52-59), each with a Sampler of its own from `make_sampler`
+// (multithreaded.rs:74). Adds into rgbw (width*height*4 f32). Tile results are merged in queue order so the output does not depend
+// on the thread count. flags: ORC_FAITHFUL_XF | ORC_BRUTE_FORCE. `stride` > 1 renders only every stride-th tile of the range (bench
+// subset). counts (optional, width*height): camera samples taken per pixel.
+template <class MakeSampler>
+static int render_tiles_with(const TrayFlatScene* fs, uint32_t tile_start, uint32_t tile_count, uint32_t stride, uint64_t seed, float* rgbw,
+                             int n_threads, int flags, OracleStats* stats_out, uint32_t* counts, MakeSampler make_sampler) {
     auto queue = block_queue(fs->film.width, fs->film.height);
     if (tile_start > queue.size()) tile_start = (uint32_t)queue.size();
     if (tile_count == 0 || tile_start + (size_t)tile_count > queue.size()) tile_count = (uint32_t)(queue.size() - tile_start);
@@ -396,21 +558,33 @@ int oracle_render_tiles(const TrayFlatScene* fs, uint32_t tile_start, uint32_t t
     auto worker = [&](int tid) {
         Stats st;
         SceneView sv{fs, flags, &st};
+        auto sampler = make_sampler(kf);                                   // multithreaded.rs:74
+        std::vector<std::pair<float, float>> sample_pos;
+        std::vector<float> time_samples(sampler.max_spp(), 0.0f);          // multithreaded.rs:76
         std::vector<ImageSample> block_samples;
-        block_samples.reserve((size_t)spp * 64);
+        block_samples.reserve((size_t)sampler.max_spp() * 64);
         for (;;) {
             size_t qi = next.fetch_add(1);
             if (qi >= tiles.size()) break;
             auto tile = queue[tiles[qi]];
             uint32_t x0 = tile.first * 8, y0 = tile.second * 8;
             block_samples.clear();
-            for (uint32_t py = y0; py < y0 + 8; ++py)        // Region iteration order (ld.rs:47-51): x fastest
-                for (uint32_t px = x0; px < x0 + 8; ++px)
-                    for (uint32_t s = 0; s < spp; ++s) {
-                        ImageSample is;
-                        is.c = trace_sample(sv, kf, px, py, s, spp, is.x, is.y);
-                        block_samples.push_back(is);
-                    }
+            sampler.select_block(x0, y0);                                  // multithreaded.rs:88
+            size_t pixel_samples = 0;
+            while (sampler.has_samples()) {
+                sampler.get_samples(sample_pos);                           // a pixel's (next) samples, multithreaded.rs:92
+                sampler.get_samples_1d(time_samples);
+                sv.smp_kind = sampler.kind(); sv.smp_offset = sampler.samples_taken();
+                for (size_t k = 0; k < sample_pos.size() && k < time_samples.size(); ++k) {   // zip, multithreaded.rs:94
+                    ImageSample is;
+                    is.x = sample_pos[k].first; is.y = sample_pos[k].second;
+                    is.c = sample_radiance(sv, is.x, is.y, time_samples[k], sampler.path_key((uint32_t)k));
+                    block_samples.push_back(is);
+                }
+                if (counts) counts[(size_t)sampler.sampled_y() * W + sampler.sampled_x()] += (uint32_t)sample_pos.size();
+                if (sampler.report_results(block_samples.data() + pixel_samples, block_samples.size() - pixel_samples))   // multithreaded.rs:107-109
+                    pixel_samples = block_samples.size();
+            }
             // RenderTarget::write into this tile's private window
             float* win = windows.data() + qi * (size_t)win_w * win_h * 4;
             film_write(fs->film, block_samples, x0, y0, win, (int)x0 - fpw, (int)y0 - fph, win_w);
@@ -448,7 +622,59 @@ int oracle_render_tiles(const TrayFlatScene* fs, uint32_t tile_start, uint32_t t
     return 0;
 }
 
-// Scene::intersect for n rays (layout of TrayRay / TrayHit in include/trayhip.h)
+extern "C" {
+
+int oracle_render_tiles(const TrayFlatScene* fs, uint32_t tile_start, uint32_t tile_count, uint32_t stride, uint32_t spp,
+                        uint64_t seed, float* rgbw, int n_threads, int flags, OracleStats* stats_out) {
+    if (!fs || !rgbw || fs->n_lights == 0 || (spp & (spp - 1)) != 0 || spp == 0) return -1;
+    const uint32_t width = fs->film.width;
+    return render_tiles_with(fs, tile_start, tile_count, stride, seed, rgbw, n_threads, flags, stats_out, nullptr,
+                             [=](uint32_t kf) { return LowDiscrepancySampler(kf, width, spp); });
+}
+
+// The same with sampler::Uniform::new(dim) (kind TRAY_SAMPLER_UNIFORM) or sampler::Adaptive::new(dim, min_spp, max_spp)
+// (TRAY_SAMPLER_ADAPTIVE) in place of LowDiscrepancy -- the counterpart of tray_scene_set_sampler. counts: see render_tiles_with.
+int oracle_render_tiles_sampler(const TrayFlatScene* fs, uint32_t tile_start, uint32_t tile_count, uint32_t stride, uint32_t kind,
+                                uint32_t min_spp, uint32_t max_spp, uint64_t seed, float* rgbw, int n_threads, int flags,
+                                OracleStats* stats_out, uint32_t* counts) {
+    if (!fs || !rgbw || fs->n_lights == 0) return -1;
+    const uint32_t width = fs->film.width;
+    if (kind == TRAY_SAMPLER_UNIFORM)
+        return render_tiles_with(fs, tile_start, tile_count, stride, seed, rgbw, n_threads, flags, stats_out, counts,
+                                 [=](uint32_t kf) { return UniformSampler(kf, width); });
+    if (kind == TRAY_SAMPLER_ADAPTIVE) {
+        if (next_power_of_two(max_spp) < next_power_of_two(min_spp)) return -1;   // (Adaptive::new would underflow, adaptive.rs:48)
+        return render_tiles_with(fs, tile_start, tile_count, stride, seed, rgbw, n_threads, flags, stats_out, counts,
+                                 [=](uint32_t kf) { return AdaptiveSampler(kf, width, min_spp, max_spp); });
+    }
+    return -1;
+}
+// How many samples Adaptive takes for ONE pixel whose successive samples have the grey colours lum[0], lum[1], ... (n of them available;
+// returns 0 if it would need more): get_samples / report_results (adaptive.rs:92-110, 133-143) driven as thread_work drives them.
+uint32_t oracle_adaptive_samples_for(const float* lum, uint32_t n, uint32_t min_spp, uint32_t max_spp) {
+    AdaptiveSampler a(0u, 8u, min_spp, max_spp);
+    a.select_block(0u, 0u);
+    std::vector<std::pair<float, float>> pos;
+    std::vector<ImageSample> got;
+    for (;;) {
+        a.get_samples(pos);
+        if (got.size() + pos.size() > n) return 0u;
+        for (size_t k = 0; k < pos.size(); ++k) {
+            ImageSample is;
+            is.x = pos[k].first; is.y = pos[k].second;
+            const float l = lum[got.size()];
+            is.c = Colorf(l, l, l);
+            got.push_back(is);
+        }
+        if (a.report_results(got.data(), got.size())) return (uint32_t)got.size();
+    }
+}
+// Adaptive::new's rounding and step (adaptive.rs:36-48): out = {min_spp, max_spp, step_size}
+void oracle_adaptive_params(uint32_t min_spp, uint32_t max_spp, uint32_t* out3) {
+    AdaptiveSampler a(0u, 8u, min_spp, max_spp);
+    out3[0] = a.min_spp; out3[1] = a.max_spp_; out3[2] = a.step_size;
+}
+
 int oracle_intersect(const TrayFlatScene* fs, uint32_t n, const TrayRay* rays, TrayHit* hits, int flags) {
     if (!fs || !rays || !hits) return -1;
     SceneView sv{fs, flags, nullptr};

@@ -330,6 +330,7 @@ inline uint32_t key_frame(uint64_t seed, uint32_t frame) {
 }
 inline uint32_t key_pixel(uint32_t kf, uint32_t pixel_index) { return mix32(kf + 0x9E3779B1u * (pixel_index + 1u)); }
 inline uint32_t key_sample(uint32_t kp, uint32_t s) { return mix32((kp ^ 0xA511E9B3u) + 0x9E3779B1u * (s + 1u)); }
+inline uint32_t key_pass(uint32_t kp, uint32_t j) { return mix32((kp ^ 0x41445054u) + 0x9E3779B1u * (j + 1u)); }   // round j of a pixel under the Adaptive sampler
 inline uint32_t draw(uint32_t key, uint32_t dim) { return mix32(key + 0x9E3779B9u * (dim + 1u)); }
 
 // pixel-level dimensions

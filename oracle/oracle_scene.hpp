@@ -240,6 +240,8 @@ struct SceneView {
     const TrayFlatScene* fs;
     int flags;
     Stats* stats;
+    // the Sampler the integrator draws from (TRAY_SAMPLER_*; Adaptive: its samples_taken at the moment) -- see PathSamples in oracle.cpp
+    uint32_t smp_kind = TRAY_SAMPLER_LOW_DISCREPANCY, smp_offset = 0;
     // AnimatedTransform::transform (animated_transform.rs:40-56) from the TRS keyframes of the spline stack
     Transform stack_transform(uint32_t xf_first, uint32_t xf_count, float time) const {
         Transform t = Transform::identity();

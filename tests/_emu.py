@@ -67,6 +67,8 @@ def emu(defines=()):
         h.emu_render_tiles.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         h.emu_render_wavefront.restype = C.c_int
         h.emu_render_wavefront.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        h.emu_render_sampler.restype = C.c_int
+        h.emu_render_sampler.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
         h.emu_retraced.restype = C.c_uint
         _libs[key] = h
     return _libs[key]
@@ -118,6 +120,17 @@ def render_tiles(flat, tiles_xy, spp, seed, blocks=1, coop=-1, film_rows=-1, def
     stats = np.zeros(4, np.uint64)
     rc = emu(defines=defines).emu_render_tiles(flat, tiles_xy.ctypes.data, len(tiles_xy), spp, seed, img.ctypes.data, blocks, coop, film_rows, stats.ctypes.data, *shard)
     assert rc == 0, f"emu_render_tiles: {rc}"
+    return img, tuple(int(x) for x in stats)
+
+
+def render_sampler(flat, tiles_xy, kind, min_spp=1, max_spp=1, seed=1, batch_tiles=0):
+    """launch_sampler's rounds of k_sampler_pass / k_sampler_decide over the given tiles; returns (rgbw image, (samples, vertices, rays))"""
+    fs = flat.contents
+    tiles_xy = np.ascontiguousarray(tiles_xy, np.uint32).reshape(-1, 2)
+    img = np.zeros((fs.film.height, fs.film.width, 4), np.float32)
+    stats = np.zeros(3, np.uint64)
+    rc = emu().emu_render_sampler(flat, tiles_xy.ctypes.data, len(tiles_xy), kind, min_spp, max_spp, seed, img.ctypes.data, batch_tiles, stats.ctypes.data)
+    assert rc == 0, f"emu_render_sampler: {rc}"
     return img, tuple(int(x) for x in stats)
 
 

@@ -36,6 +36,13 @@ def oracle():
         o.oracle_render_tiles.restype = C.c_int
         o.oracle_render_tiles.argtypes = [FS, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int, C.c_int,
                                           C.POINTER(OracleStats)]
+        o.oracle_render_tiles_sampler.restype = C.c_int
+        o.oracle_render_tiles_sampler.argtypes = [FS, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p,
+                                                  C.c_int, C.c_int, C.POINTER(OracleStats), C.c_void_p]
+        o.oracle_adaptive_samples_for.restype = C.c_uint32
+        o.oracle_adaptive_samples_for.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        o.oracle_adaptive_params.restype = None
+        o.oracle_adaptive_params.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         o.oracle_intersect.restype = C.c_int
         o.oracle_intersect.argtypes = [FS, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
         o.oracle_camera_rays.restype = C.c_int
@@ -97,6 +104,38 @@ def render_tiles(flat, spp, seed=1, tile_start=0, tile_count=0, stride=1, thread
     if rc != 0:
         raise RuntimeError("oracle_render_tiles failed")
     return img, st
+
+
+SAMPLER_LOW_DISCREPANCY, SAMPLER_UNIFORM, SAMPLER_ADAPTIVE = 0, 1, 2
+
+
+def render_tiles_sampler(flat, kind, min_spp=1, max_spp=1, seed=1, tile_start=0, tile_count=0, stride=1, threads=None, flags=0):
+    """thread_work with sampler::Uniform / sampler::Adaptive. Returns (rgbw float32[h, w, 4], OracleStats, samples per pixel uint32[h, w])."""
+    fs = flat.contents
+    w, h = fs.film.width, fs.film.height
+    img = np.zeros((h, w, 4), dtype=np.float32)
+    counts = np.zeros((h, w), dtype=np.uint32)
+    st = OracleStats()
+    if threads is None:
+        threads = os.cpu_count() or 1
+    rc = oracle().oracle_render_tiles_sampler(flat, tile_start, tile_count, stride, kind, min_spp, max_spp, seed, img.ctypes.data, threads, flags,
+                                              C.byref(st), counts.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("oracle_render_tiles_sampler failed")
+    return img, st, counts
+
+
+def adaptive_samples_for(lum, min_spp, max_spp):
+    """samples Adaptive takes for one pixel whose successive samples are the greys lum[...] (0: it would need more than given)"""
+    lum = np.ascontiguousarray(lum, np.float32)
+    return int(oracle().oracle_adaptive_samples_for(lum.ctypes.data, len(lum), min_spp, max_spp))
+
+
+def adaptive_params(min_spp, max_spp):
+    """Adaptive::new's rounded (min_spp, max_spp, step_size) (adaptive.rs:36-48)"""
+    out = np.zeros(3, np.uint32)
+    oracle().oracle_adaptive_params(min_spp, max_spp, out.ctypes.data)
+    return tuple(int(v) for v in out)
 
 
 def sample_radiance(flat, px, py, si, spp, seed=1, flags=0):

@@ -195,6 +195,54 @@ int emu_debug_sample_radiance(const TrayFlatScene* f, uint32_t n, const uint32_t
     return 0;
 }
 
+// launch_sampler (kernels.hip) for the tiles given: thread_work with sampler::Uniform / sampler::Adaptive. batch_tiles bounds the tiles per
+// batch (0 = all at once), so that tests can see batches add up. stats_out: samples, vertices, rays.
+int emu_render_sampler(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t tile_count, uint32_t kind, uint32_t min_spp, uint32_t max_spp,
+                       uint64_t seed, float* rgbw, uint32_t batch_tiles, unsigned long long* stats_out) {
+    EmuScene e;
+    make_scene(f, e);
+    const uint32_t kf = key_frame_host(seed, e.d.frame);
+    bool moving = f->camera.animated != 0;
+    for (uint32_t t_ = 0; t_ < f->n_textures; ++t_) moving = moving || f->textures[t_].n_frames >= 2u;
+    for (uint32_t i = 0; i < f->n_instances; ++i) moving = moving || f->instances[i].animated != 0 || f->instances[i].emis_count >= 2;
+    std::vector<uint2> tiles(tile_count);
+    for (uint32_t i = 0; i < tile_count; ++i) tiles[i] = make_uint2(tiles_xy[2 * i], tiles_xy[2 * i + 1]);
+    DevStats stats;
+    std::memset(&stats, 0, sizeof stats);
+    auto round_up = [](uint32_t v) { uint32_t p = 1; while (p < v && p < 0x80000000u) p <<= 1; return p; };
+    SamplerPass sp{};
+    sp.kind = kind; sp.min_spp = round_up(min_spp); sp.max_spp = round_up(max_spp);
+    uint32_t rounds = 1;
+    if (kind == TRAY_SAMPLER_ADAPTIVE) {
+        if (sp.max_spp < sp.min_spp) return -1;
+        sp.step = round_up((sp.max_spp - sp.min_spp) / 5u);
+        while (sp.min_spp + (rounds - 1u) * sp.step < sp.max_spp) ++rounds;
+        sp.lum_cap = sp.min_spp + (rounds - 1u) * sp.step;
+    } else if (kind == TRAY_SAMPLER_UNIFORM) { sp.min_spp = sp.max_spp = 1u; sp.step = 1u; sp.lum_cap = 0u; }
+    else return -1;
+    const uint32_t batch = batch_tiles ? std::min(batch_tiles, std::max(tile_count, 1u)) : std::max(tile_count, 1u);
+    std::vector<uint32_t> px_state((size_t)batch * 64u);
+    std::vector<float> px_avg((size_t)batch * 64u), px_lum((size_t)batch * 64u * std::max(sp.lum_cap, 1u));
+    const uint32_t chunk = tile_count ? tile_count : 1u;
+    for (uint32_t item0 = 0; item0 < tile_count; item0 += batch) {
+        const uint32_t n_items = std::min(batch, tile_count - item0), n_px = n_items * 64u;
+        std::fill(px_state.begin(), px_state.end(), 0u); std::fill(px_avg.begin(), px_avg.end(), 0.0f);
+        for (uint32_t j = 0; j < rounds; ++j) {
+            sp.pass = j;
+            sp.count = kind == TRAY_SAMPLER_ADAPTIVE ? (j == 0u ? sp.min_spp : sp.step) : 1u;
+            sp.taken = kind == TRAY_SAMPLER_ADAPTIVE ? sp.min_spp + j * sp.step : 0u;
+            sp.before = j == 0u ? 0u : sp.min_spp + (j - 1u) * sp.step;
+            const uint32_t grid = (uint32_t)(((size_t)n_px * sp.count + TR_BLOCK - 1) / TR_BLOCK);
+            if (moving) launch(grid, TR_BLOCK, [&] { k_sampler_pass<2>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
+            else launch(grid, TR_BLOCK, [&] { k_sampler_pass<0>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
+            if (kind == TRAY_SAMPLER_ADAPTIVE)
+                launch((n_px + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_sampler_decide(n_px, sp, px_state.data(), px_avg.data(), px_lum.data()); });
+        }
+    }
+    if (stats_out) { stats_out[0] = stats.samples; stats_out[1] = stats.vertices; stats_out[2] = stats.rays; }
+    return 0;
+}
+
 // Debugging aid: the loop of k_debug_sample_radiance<0> for ONE sample with the lane state printed after every vertex
 int emu_trace_sample(const TrayFlatScene* f, uint32_t px, uint32_t py, uint32_t si, uint32_t spp, uint64_t seed) {
     EmuScene e;

@@ -694,3 +694,77 @@ def test_frame_update_of_the_multi_device_scene(tmp_path):
         single = rt.get_renderf32().reshape(120, 160, 4)
         assert np.allclose(multi_img, single, rtol=0, atol=1e-5 * single.max()), frame
     hip.close_multi()
+
+
+# ---- the other Samplers (sampler/uniform.rs, sampler/adaptive.rs; tray_scene_set_sampler) ----
+
+def gpu_render_sampler(scene, rt, make_sampler, fi, seed, select=(0, 0), frame=None):
+    rt.clear()
+    hip = T.Hip(0, seed=seed, sampler=make_sampler)
+    if frame is not None:
+        fi = T.FrameInfo(fi.frames, fi.time, frame, frame)
+    hip.render(scene, rt, T.Config(".", "s", 1, 1, fi, select))
+    return rt.get_renderf32().reshape(rt.height, rt.width, 4), hip.last_timing
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "smallpt"])
+def test_gpu_other_samplers_against_the_oracle(name, tmp_path):
+    """Uniform: every sample is its pixel's centre -- the weight planes agree to the rounding of the sums, the pixels to 1e-6 in the median
+    with at most 0.2 % of them carrying a path that flipped at a last-bit boundary (the bar of test_per_sample_radiance). Adaptive(4, 32): a pixel's decision to go on hangs on |lum - avg| / avg > 0.5 of f32 luminances that differ
+    in the last bits between ocml and glibc, so a few pixels may take a different number of rounds -- the sample totals agree to 1 %, the
+    images to 2e-3 RMSE, and the pixels whose sample count is the same (weight plane equal) to 1e-4."""
+    scene, rt, _, fi = load(SCENES[name](160, 96, 4), tmp_path)
+    flat = scene.flatten(0)
+    gpu, tim = gpu_render_sampler(scene, rt, lambda dim, spp: T.sampler.Uniform(dim), fi, seed=4)
+    cpu, st, _ = O.render_tiles_sampler(flat, O.SAMPLER_UNIFORM, seed=4)
+    assert tim.samples == st.samples == 160 * 96
+    assert np.abs(gpu[..., 3] - cpu[..., 3]).max() < 1e-5 * cpu[..., 3].max()
+    d = np.abs(rgb(gpu) - rgb(cpu)).max(axis=-1)      # ONE sample per pixel: a path that flips at a 1-ulp boundary is a visible pixel, not an average
+    print(f"{name} uniform: RMSE {rmse(gpu, cpu):.3e}, pixels off by > 1e-3: {(d > 1e-3).mean():.2e}, median {np.median(d):.1e}")
+    assert (d > 1e-3).mean() < 2e-3 and np.median(d) < 1e-6 and rmse(gpu, cpu) < 1e-3
+    gpu, tim = gpu_render_sampler(scene, rt, lambda dim, spp: T.sampler.Adaptive(dim, 4, 32), fi, seed=4)
+    cpu, st, counts = O.render_tiles_sampler(flat, O.SAMPLER_ADAPTIVE, 4, 32, seed=4)
+    print(f"{name} adaptive(4, 32): GPU {tim.samples} samples, oracle {st.samples}; RMSE {rmse(gpu, cpu):.3e}; launches {tim.launches}")
+    assert abs(int(tim.samples) - int(st.samples)) <= 0.01 * st.samples and counts.max() == 36
+    assert rmse(gpu, cpu) < 2e-3
+    same = np.abs(gpu[..., 3] - cpu[..., 3]) < 1e-4 * cpu[..., 3].max()
+    assert same.mean() > 0.97
+    assert np.sqrt(np.mean((rgb(gpu) - rgb(cpu))[same] ** 2)) < 1e-4
+    # min_spp == max_spp: no decisions -- plain parity at 8 samples per pixel
+    gpu, tim = gpu_render_sampler(scene, rt, lambda dim, spp: T.sampler.Adaptive(dim, 8, 8), fi, seed=4)
+    cpu, st, _ = O.render_tiles_sampler(flat, O.SAMPLER_ADAPTIVE, 8, 8, seed=4)
+    assert tim.samples == st.samples == 8 * 160 * 96 and rmse(gpu, cpu) < 1e-4
+
+
+def test_gpu_other_samplers_tile_ranges_frames_and_errors(tmp_path):
+    """tile ranges and round-robin shards add up under Adaptive (every number is keyed by pixel, round and index); the sampler choice
+    survives tray_scene_update_frame; a moving scene runs the per-use transform evaluation; bad arguments are refused."""
+    scene, rt, _, fi = T.Scene.load_file(scenes.write_moving_box(str(tmp_path), width=96, height=64, samples=4))
+    adaptive = lambda dim, spp: T.sampler.Adaptive(dim, 2, 16)
+    whole, tim = gpu_render_sampler(scene, rt, adaptive, fi, seed=3, frame=1)
+    cpu, st, _ = O.render_tiles_sampler(scene.flatten(1), O.SAMPLER_ADAPTIVE, 2, 16, seed=3)
+    assert abs(int(tim.samples) - int(st.samples)) <= 0.02 * st.samples and rmse(whole, cpu) < 3e-3
+    a, _ = gpu_render_sampler(scene, rt, adaptive, fi, seed=3, select=(0, 40), frame=1)
+    b, _ = gpu_render_sampler(scene, rt, adaptive, fi, seed=3, select=(40, 1000), frame=1)
+    assert np.allclose(a + b, whole, rtol=0, atol=1e-4 * whole.max())
+    import torch
+    dev = scene.device_scene(1, 0)
+    total = torch.zeros(96 * 64 * 4, dtype=torch.float32, device="cuda")
+    for r in range(3):
+        part = torch.zeros_like(total)
+        T.check(T.lib().tray_render_shard_device(dev, r, 3, 4, 1, 3, C.c_void_p(part.data_ptr()), None))
+        torch.cuda.synchronize()
+        total += part
+    assert np.allclose(total.cpu().numpy().reshape(64, 96, 4), whole, rtol=0, atol=1e-4 * whole.max())
+    # the next frame through tray_scene_update_frame: still Adaptive(2, 16)
+    nxt, tim2 = gpu_render_sampler(scene, rt, adaptive, fi, seed=3, frame=2)
+    cpu2, st2, _ = O.render_tiles_sampler(scene.flatten(2), O.SAMPLER_ADAPTIVE, 2, 16, seed=3)
+    assert abs(int(tim2.samples) - int(st2.samples)) <= 0.02 * st2.samples and rmse(nxt, cpu2) < 3e-3
+    # back to LowDiscrepancy on the same handle
+    ld, tim3 = gpu_render(scene, rt, 4, T.FrameInfo(fi.frames, fi.time, 2, 2), seed=3)
+    cpu3, st3 = O.render_tiles(scene.flatten(2), 4, seed=3)
+    assert tim3.samples == st3.samples and rmse(ld, cpu3) < 1e-4
+    dev = scene.device_scene(2, 0)
+    for bad in ((3, 1, 1), (T.sampler.ADAPTIVE, 64, 4), (T.sampler.ADAPTIVE, 1, 1 << 20)):
+        with pytest.raises(T.TrayError):
+            T.check(T.lib().tray_scene_set_sampler(dev, *bad))

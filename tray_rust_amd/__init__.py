@@ -10,6 +10,7 @@ behaviour follow /root/reference):
     RenderTarget.get_rendered_blocks / add_blocks               src/film/render_target.rs:215-241, src/film/image.rs:36-50
     distrib.worker_node(Hip()) / `python -m tray_rust_amd --worker`   src/exec/distrib/worker.rs, src/main.rs:148-166
     BlockQueue(img, dim, select_blocks)                         src/sampler/block_queue.rs:11-66
+    sampler.LowDiscrepancy / Uniform / Adaptive                 src/sampler/{ld,uniform,adaptive}.rs (Hip(sampler=...))
 
 Everything below the Python layer is libtrayhip.so (include/trayhip.h): a C++ scene loader and
 hand-written HIP kernels for gfx950. The reference panics on invalid input; here the same
@@ -21,9 +22,10 @@ import os
 import numpy as np
 
 from . import _lib
+from . import sampler
 from ._lib import TrayError, lib, check
 
-__all__ = ["Scene", "FrameInfo", "Config", "RenderTarget", "Hip", "BlockQueue", "TrayError", "round_spp"]
+__all__ = ["Scene", "FrameInfo", "Config", "RenderTarget", "Hip", "BlockQueue", "TrayError", "round_spp", "sampler"]
 
 
 def round_spp(spp):
@@ -207,15 +209,28 @@ class Hip:
     """Execution backend in the place of exec::MultiThreaded (src/exec/multithreaded.rs:20-70): renders
     config.select_blocks of frame config.current_frame on one MI355X and adds the result into rt."""
 
-    def __init__(self, device=0, seed=1):
+    def __init__(self, device=0, seed=1, sampler=None):
+        """sampler: callable (block_dim, spp) -> sampler.LowDiscrepancy / Uniform / Adaptive -- what thread_work constructs per worker
+        (exec/multithreaded.rs:74); None = LowDiscrepancy::new(block_dim, spp)."""
         self.device, self.seed = int(device), int(seed)
+        self.sampler = sampler
         check(lib().tray_init(self.device))
         self.last_timing = None
         self._multi, self._multi_key, self._multi_frame, self._multi_scene = None, None, None, None
 
+    def _select_sampler(self, dev, spp, multi=False):
+        """tells the device scene which Sampler the next render stands for; returns the spp the render call takes"""
+        if self.sampler is None:
+            smp_kind, lo, hi, spp = sampler.LOW_DISCREPANCY, 1, 1, round_spp(spp)
+        else:
+            smp = self.sampler((8, 8), spp)     # BlockQueue::block_dim (main.rs:101: (8, 8))
+            smp_kind, lo, hi, spp = smp.KIND, smp.min_spp, smp.max_spp_, smp.spp
+        check((lib().tray_multi_set_sampler if multi else lib().tray_scene_set_sampler)(dev, smp_kind, lo, hi))
+        return spp
+
     def render(self, scene, rt, config):
-        spp = round_spp(config.spp)
         dev = scene.device_scene(config.current_frame, self.device)
+        spp = self._select_sampler(dev, config.spp)
         start, count = config.select_blocks
         check(lib().tray_render_tiles(dev, int(start), int(count), spp, self.seed, rt.pixels.ctypes.data))
         t = _lib.TrayKernelTiming()
@@ -226,6 +241,7 @@ class Hip:
     def render_device(self, scene, frame, select_blocks, spp, rgbw_ptr, stream=None):
         """Asynchronous variant: accumulate into a device RGBW buffer (e.g. torch tensor .data_ptr())."""
         dev = scene.device_scene(frame, self.device)
+        spp = self._select_sampler(dev, spp)
         check(lib().tray_render_tiles_device(dev, int(select_blocks[0]), int(select_blocks[1]), int(spp), self.seed,
                                              C.c_void_p(int(rgbw_ptr)), C.c_void_p(int(stream)) if stream else None))
         return dev
@@ -233,6 +249,7 @@ class Hip:
     def render_shard_device(self, scene, frame, shard, n_shards, spp, rgbw_ptr, chunk_tiles=16, stream=None):
         """One rank's share of a frame (round-robin chunks of the Morton queue); merge = sum over ranks."""
         dev = scene.device_scene(frame, self.device)
+        spp = self._select_sampler(dev, spp)
         check(lib().tray_render_shard_device(dev, int(shard), int(n_shards), int(chunk_tiles), int(spp), self.seed,
                                              C.c_void_p(int(rgbw_ptr)), C.c_void_p(int(stream)) if stream else None))
         return dev
@@ -243,7 +260,6 @@ class Hip:
         exec/distrib/master.rs:124-163, film/image.rs:36-50), the result added into rt. Returns (per-device timings, reduce ms).
         The per-device scenes and the communicators are kept between calls: another frame of the same scene on the same devices
         is a tray_multi_update_frame (scene.rs:152-176), not a new ncclCommInitAll. close_multi() releases them."""
-        spp = round_spp(config.spp)
         key = tuple(int(d) for d in devices)
         # the cached device copies belong to ONE scene object, held by a strong reference and compared by identity: an id() alone
         # could be reused by another Scene allocated at the same address after this one was collected, and that scene's frame would
@@ -263,6 +279,7 @@ class Hip:
                 self.close_multi()
                 raise
             self._multi_frame = config.current_frame
+        spp = self._select_sampler(self._multi, config.spp, multi=True)
         check(lib().tray_render_frame_multi(self._multi, spp, self.seed, rt.pixels.ctypes.data))
         per = (_lib.TrayKernelTiming * len(devices))()
         ms = C.c_float()

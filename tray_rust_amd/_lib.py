@@ -154,6 +154,9 @@ SYMBOLS = {
     "tray_scene_create": (C.c_int, [_P(TrayFlatScene), _P(C.c_void_p)]),
     "tray_scene_update_frame": (C.c_int, [C.c_void_p, _P(TrayFlatScene)]),
     "tray_scene_destroy": (None, [C.c_void_p]),
+    "tray_scene_set_sampler": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "tray_multi_set_sampler": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "tray_adaptive_step": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "tray_render_tiles_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "tray_render_shard_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "tray_shard_tiles": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_uint32), C.c_uint32, _P(C.c_uint32)]),

@@ -102,6 +102,10 @@ struct Lane {
     f3 direct;             // direct_light of estimate_direct
     f3 t_vertex;           // throughput at this vertex, kept for `illum += throughput * direct`
     LdsB perm_lds = nullptr;   // the scene's permutation pool in LDS (tile kernel; wave-uniform, costs no register); null: read sc.perm_pool
+    // which Sampler fills the path's arrays (sampler/mod.rs:20-49; see lane_2d) and, for Adaptive, its samples_taken when the path was
+    // started (adaptive.rs:115,120). The tile and wavefront kernels never write these: the constants fold and the LowDiscrepancy code is
+    // all that is compiled into them; k_sampler_pass sets them from its launch parameters.
+    uint32_t smp_kind = TRAY_SAMPLER_LOW_DISCREPANCY, smp_offset = 0u;
 #ifdef TR_STAGE_CLOCKS   // instrumented builds only: wave clocks of the parts of a BSDF query (set by k_path_tiles, null elsewhere)
     unsigned long long* qclk = nullptr;   // [0] sample head / light setup, [1] eval + pdf site, [2] epilogue of the query kind
     long long qt = 0;
@@ -140,15 +144,29 @@ TR_DEV uint32_t lane_perm_entry(const DevScene& sc, const Lane& ln, uint32_t s1,
     const uint32_t off2 = ((s2 & (TR_PERM_POOL - 1u)) << 4) + (__brev(e1 >> 4) >> 28);
     return ln.perm_lds ? (uint32_t)ln.perm_lds[off2] : (uint32_t)sc.perm_pool[off2];
 }
+// Uniform (sampler/uniform.rs:36-46): every entry of every array is Range::new(0.0, 1.0).ind_sample(rng) -- next_f32 of a draw of its own,
+// counter 64 + 32 * dim + 2 * bounce (+ 1 for the second coordinate); no scrambles, no shuffles.
+TR_DEV float lane_uniform(const Lane& ln, uint32_t dim, uint32_t c) {
+    return (float)(draw(ln.ks, 64u + 32u * dim + 2u * ln.bounce + c) >> 8) / 16777216.0f;
+}
 TR_DEV void lane_2d(const DevScene& sc, const Lane& ln, uint32_t dim, float& u0, float& u1) {
+    if (ln.smp_kind == TRAY_SAMPLER_UNIFORM) { u0 = lane_uniform(ln, dim, 0u); u1 = lane_uniform(ln, dim, 1u); return; }
     const uint32_t sx = draw(ln.ks, dim), sy = draw(ln.ks, dim + 1u);
     const uint32_t e = lane_perm_entry(sc, ln, sx, sy);
+    if (ln.smp_kind == TRAY_SAMPLER_ADAPTIVE) {   // ld::sample_2d(samples, scramble, self.samples_taken) (adaptive.rs:112-116): the points idx + offset
+        const uint32_t idx = (__brev(e >> 4) >> 28) + ln.smp_offset;
+        u0 = van_der_corput(idx, sx); u1 = sobol(idx, sy);
+        return;
+    }
     u0 = u24_to_unit(((e & 0xf0u) << 24) ^ sx);   // van_der_corput(idx, sx)
     u1 = u24_to_unit((e << 28) ^ sy);             // sobol(idx, sy)
 }
 TR_DEV float lane_1d(const DevScene& sc, const Lane& ln, uint32_t dim) {
+    if (ln.smp_kind == TRAY_SAMPLER_UNIFORM) return lane_uniform(ln, dim, 0u);
     const uint32_t s = draw(ln.ks, dim);
-    return u24_to_unit(((lane_perm_entry(sc, ln, s, s >> 8) & 0xf0u) << 24) ^ s);
+    const uint32_t e = lane_perm_entry(sc, ln, s, s >> 8);
+    if (ln.smp_kind == TRAY_SAMPLER_ADAPTIVE) return van_der_corput((__brev(e >> 4) >> 28) + ln.smp_offset, s);   // ld::sample_1d(.., self.samples_taken) (adaptive.rs:117-121)
+    return u24_to_unit(((e & 0xf0u) << 24) ^ s);
 }
 
 TR_DEV Ray stage_a_ray(const Lane& ln) {

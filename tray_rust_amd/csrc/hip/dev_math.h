@@ -177,6 +177,8 @@ TR_DEV uint32_t key_frame(uint64_t seed, uint32_t frame) {
 TR_DEV uint32_t key_pixel(uint32_t kf, uint32_t pixel_index) { return mix32(kf + 0x9E3779B1u * (pixel_index + 1u)); }
 TR_DEV uint32_t key_sample(uint32_t kp, uint32_t s) { return mix32((kp ^ 0xA511E9B3u) + 0x9E3779B1u * (s + 1u)); }
 TR_DEV uint32_t draw(uint32_t key, uint32_t dim) { return mix32(key + 0x9E3779B9u * (dim + 1u)); }
+// pass j of a pixel under the Adaptive sampler (adaptive.rs:92-110: every get_samples call draws fresh scrambles and shuffles)
+TR_DEV uint32_t key_pass(uint32_t kp, uint32_t j) { return mix32((kp ^ 0x41445054u) + 0x9E3779B1u * (j + 1u)); }
 
 enum { PD_SCR_X = 0, PD_SCR_Y = 1, PD_PERM_XY = 2, PD_SCR_T = 3, PD_PERM_T = 4 };
 enum { SD_L2 = 0, SD_B2 = 3, SD_P2 = 6, SD_L1 = 9, SD_B1 = 11, SD_P1 = 13, SD_RR = 16 };

@@ -59,7 +59,12 @@ TR_DEV void wh_light_sample(const DevScene& sc, const TrayInstance* __restrict__
 // illumination() and rays; n_vertices / n_rays: the same as wave totals (the tile kernel's statistics).
 template <int ANIM>
 TR_DEV f3 whitted_run(const DevScene& sc, const DevScene* __restrict__ scp, uint32_t* __restrict__ stack, const Ray& cam, uint32_t ks, bool active,
-                      Counters& cnt, uint32_t& n_vertices, uint32_t& n_rays) {
+                      Counters& cnt, uint32_t& n_vertices, uint32_t& n_rays, uint32_t smp_kind = TRAY_SAMPLER_LOW_DISCREPANCY, uint32_t smp_offset = 0u) {
+    // the one-element arrays of an activation under the scene's Sampler (whitted.rs:46-47, mod.rs:59-60,83-84): LowDiscrepancy -- the scrambled
+    // (0,2) point of index 0; Adaptive -- of index samples_taken (adaptive.rs:112-121); Uniform -- plain uniform draws (uniform.rs:36-46).
+    // (constants at the tile kernel's call site: only the first form is compiled there)
+#define WH_VDC(key_, d_) (smp_kind == TRAY_SAMPLER_UNIFORM ? (float)(draw(key_, d_) >> 8) / 16777216.0f : van_der_corput(smp_kind == TRAY_SAMPLER_ADAPTIVE ? smp_offset : 0u, draw(key_, d_)))
+#define WH_SOB(key_, d_) (smp_kind == TRAY_SAMPLER_UNIFORM ? (float)(draw(key_, d_) >> 8) / 16777216.0f : sobol(smp_kind == TRAY_SAMPLER_ADAPTIVE ? smp_offset : 0u, draw(key_, d_)))
     constexpr int FEAT = FEAT_ALL | FEAT_TEX;
     WhFrame frames[WH_MAX_FRAMES];
     int sp = 0;
@@ -91,7 +96,7 @@ TR_DEV f3 whitted_run(const DevScene& sc, const DevScene* __restrict__ scp, uint
                 resolve_textured(sc, bsdf.mat, bsdf.u, bsdf.v, r.time, hit_mat);
                 bsdf.mat = &hit_mat;
             }
-            l2x = van_der_corput(0u, draw(rkey, WD_L2)); l2y = sobol(0u, draw(rkey, WD_L2 + 1u));
+            l2x = WH_VDC(rkey, WD_L2); l2y = WH_SOB(rkey, WD_L2 + 1u);
             const TrayInstance* __restrict__ inst = sc.instances + hit.inst;
             if (rdepth == 0u && inst->kind != TRAY_INST_RECEIVER)   // whitted.rs:49-54
                 illum = illum + emitter_radiance<ANIM>(sc, inst, w_o, hit.ng, r.time);
@@ -127,12 +132,10 @@ TR_DEV f3 whitted_run(const DevScene& sc, const DevScene* __restrict__ scp, uint
                 f3 w_i;
                 float pdf;
                 uint32_t ty;
-                f3 f = bsdf_sample(bsdf, w_o, BX_SPECULAR | BX_REFLECTION, van_der_corput(0u, draw(rkey, WD_R2)), sobol(0u, draw(rkey, WD_R2 + 1u)),
-                                   van_der_corput(0u, draw(rkey, WD_R1)), w_i, pdf, ty);
+                f3 f = bsdf_sample(bsdf, w_o, BX_SPECULAR | BX_REFLECTION, WH_VDC(rkey, WD_R2), WH_SOB(rkey, WD_R2 + 1u), WH_VDC(rkey, WD_R1), w_i, pdf, ty);
                 float c = fabsf(dot(w_i, bsdf.n));
                 if (pdf > 0.0f && !is_black(f) && c != 0.0f) { fr.wr = w_i; fr.fr = f; fr.cr = c; fr.pr = pdf; }
-                f = bsdf_sample(bsdf, w_o, BX_SPECULAR | BX_TRANSMISSION, van_der_corput(0u, draw(rkey, WD_T2)), sobol(0u, draw(rkey, WD_T2 + 1u)),
-                                van_der_corput(0u, draw(rkey, WD_T1)), w_i, pdf, ty);
+                f = bsdf_sample(bsdf, w_o, BX_SPECULAR | BX_TRANSMISSION, WH_VDC(rkey, WD_T2), WH_SOB(rkey, WD_T2 + 1u), WH_VDC(rkey, WD_T1), w_i, pdf, ty);
                 c = fabsf(dot(w_i, bsdf.n));
                 if (pdf > 0.0f && !is_black(f) && c != 0.0f) { fr.wt = w_i; fr.ft = f; fr.ct = c; fr.pt = pdf; }
             }
@@ -168,6 +171,8 @@ TR_DEV f3 whitted_run(const DevScene& sc, const DevScene* __restrict__ scp, uint
         }
     }
     return result;
+#undef WH_VDC
+#undef WH_SOB
 }
 
 }  // namespace tr

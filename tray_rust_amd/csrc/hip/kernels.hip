@@ -492,6 +492,129 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
     o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = sx; o[4] = sy; o[5] = (float)cnt.vertices; o[6] = (float)cnt.rays; o[7] = 0.0f;
 }
 
+// ---- the Samplers thread_work does not construct (sampler/uniform.rs, sampler/adaptive.rs; include/trayhip.h: tray_scene_set_sampler) ----
+// One launch = one get_samples() round of every pixel of a batch of tiles (multithreaded.rs:91-103): a thread per camera sample of the
+// round, driven through the same lane machine as the tile kernel, the sample written straight into the caller's film
+// (RenderTarget::write, render_target.rs:118-146). Not a hot path: one instantiation per ANIM (0 / 2), every lobe compiled in.
+//   Uniform   one round: the pixel's centre, a uniform time, uniform numbers for every array of the integrator (uniform.rs:22-47).
+//   Adaptive  round j generates `count` = min_spp (j = 0) or step_size positions -- sample_02(i + samples_taken) under the round's
+//             scrambles, shuffled (adaptive.rs:92-116; Kensler's hashed permutation stands for rng.shuffle as in pixel_sample) -- and
+//             max_spp time values of which thread_work's zip uses the first `count` (multithreaded.rs:76,93-94, adaptive.rs:117-121);
+//             the integrator's arrays start at index samples_taken as well (lane_2d). A pixel k_sampler_decide has finished sits out.
+struct SamplerPass {
+    uint32_t kind, pass, count;
+    uint32_t taken;         // Adaptive: samples_taken while the round's numbers are generated = min_spp + pass * step
+    uint32_t before;        // samples of a pixel before this round
+    uint32_t min_spp, max_spp, step;
+    uint32_t lum_cap;       // luminance slots per pixel
+};
+template <int ANIM>
+__global__ __launch_bounds__(TR_BLOCK) void k_sampler_pass(const DevScene scv, const uint2* __restrict__ tiles, uint32_t item0, uint32_t n_items,
+                                                           uint32_t chunk, uint32_t chunk_stride, uint32_t kf, SamplerPass sp,
+                                                           const uint32_t* __restrict__ px_state, float* __restrict__ px_lum,
+                                                           float* __restrict__ rgbw, DevStats* __restrict__ stats) {
+    TR_DYN_LDS(uint32_t, s_stack);
+    const DevScene& sc = scv;
+    const DevScene* const scp = &scv;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = idx < n_items * 64u * sp.count;   // the whole wave steps together (cooperative leaf test inside the traversal)
+    const uint32_t slot = in_range ? idx / sp.count : 0u, i = in_range ? idx % sp.count : 0u;   // pixel of the batch, sample of the round
+    const uint32_t ti = item0 + (slot >> 6), pix = slot & 63u;
+    const uint2 tile = tiles[(ti / chunk) * chunk_stride * chunk + (ti % chunk)];
+    const int x0 = (int)tile.x * 8, y0 = (int)tile.y * 8;
+    const uint32_t px = (uint32_t)x0 + (pix & 7u), py = (uint32_t)y0 + (pix >> 3);   // Region order: x fastest (sampler/mod.rs:82-98)
+    const bool active = in_range && !(sp.kind == TRAY_SAMPLER_ADAPTIVE && (px_state[slot] & 1u));
+    const uint32_t kp = key_pixel(kf, py * sc.width + px);
+    float sx, sy, t;
+    uint32_t ks;
+    if (sp.kind == TRAY_SAMPLER_UNIFORM) {
+        sx = (float)px + 0.5f; sy = (float)py + 0.5f;                      // uniform.rs:28
+        t = (float)(draw(kp, PD_SCR_T) >> 8) / 16777216.0f;                // uniform.rs:42-46
+        ks = key_sample(kp, 0u);
+    } else {
+        const uint32_t kq = key_pass(kp, sp.pass);
+        const uint32_t n_xy = permute(i, sp.count, draw(kq, PD_PERM_XY)) + sp.taken;
+        sx = van_der_corput(n_xy, draw(kq, PD_SCR_X)) + (float)px;         // adaptive.rs:106-110
+        sy = sobol(n_xy, draw(kq, PD_SCR_Y)) + (float)py;
+        t = van_der_corput(permute(i, sp.max_spp, draw(kq, PD_PERM_T)) + sp.taken, draw(kq, PD_SCR_T));
+        ks = key_sample(kq, i);
+    }
+    Counters cnt;
+    cnt.rays = 0; cnt.vertices = 0;
+    Lane ln;
+    lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), ks);
+    ln.smp_kind = sp.kind; ln.smp_offset = sp.taken;
+    if (!active) ln.flags = 0u;
+    uint32_t* const my_stack = s_stack + threadIdx.x;
+    if (sc.integrator == TRAY_INTEGRATOR_WHITTED) {
+        Ray cam;
+        cam.o = LN_O(ln); cam.d = ln.d; cam.min_t = 0.0f; cam.max_t = TR_INF; cam.time = ln.time; cam.col = ln.col;
+        uint32_t wv = 0u, wr = 0u;
+        ln.illum = whitted_run<ANIM>(sc, scp, my_stack, cam, ln.ks, active, cnt, wv, wr, sp.kind, sp.taken);
+        ln.flags = 0u;
+    }
+    while (__any(ln.flags & LF_ALIVE)) {
+#pragma nounroll
+        for (int stage = 0; stage < 3; ++stage) {
+            const bool alive = (ln.flags & LF_ALIVE) != 0u;
+            if (stage == 2 && alive) mis_ray_filter<ANIM>(sc, ln);
+            const bool want_ray = alive && (stage == 0 || (stage == 1 && (ln.flags & LF_SHADOW)) || (stage == 2 && (ln.flags & LF_MIS)));
+            TraceResult tr_;
+            tr_.hit = false;
+            tr_.rec.t = 0.0f; tr_.rec.inst = 0xffffffffu; tr_.rec.prim = 0u; tr_.rec.b1 = 0.0f; tr_.rec.b2 = 0.0f;
+            if (stage == 2 && alive && (ln.flags & LF_MIS_MISS)) cnt.rays++;
+            if (__any(want_ray)) {
+                if (want_ray) cnt.rays++;
+                const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
+                tr_ = trace<ANIM>(scp, my_stack, r, stage == 1, want_ray);
+            }
+            if (stage == 1) {
+                vertex_queries<ANIM, FEAT_ALL | FEAT_TEX>(sc, ln, tr_.hit, alive);
+            } else if (alive) {
+                if (stage == 0) {
+                    if (tr_.hit) vertex_begin<ANIM>(sc, ln, tr_.rec, cnt);
+                    else ln.flags &= ~LF_ALIVE;
+                } else {
+                    if (!vertex_end<ANIM>(sc, ln, tr_.hit, tr_.rec)) ln.flags &= ~LF_ALIVE;
+                }
+            }
+        }
+    }
+    if (active) {
+        const f3 c = lane_result(ln);
+        film_splat_global(sc, rgbw, sc.filter_table, x0, y0, sx, sy, c);
+        if (sp.kind == TRAY_SAMPLER_ADAPTIVE) px_lum[(size_t)slot * sp.lum_cap + sp.before + i] = 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z;   // Colorf::luminance (color.rs:43-45)
+    }
+    if (stats && active) {   // (the compiler's atomic optimizer turns these into one atomic per wave)
+        atomicAdd(&stats->samples, 1ull);
+        atomicAdd(&stats->vertices, (unsigned long long)cnt.vertices);
+        atomicAdd(&stats->rays, (unsigned long long)cnt.rays);
+    }
+}
+// Adaptive::report_results / needs_supersampling (adaptive.rs:55-75, 133-143) of every unfinished pixel of the batch, after round
+// `sp.pass`: one thread per pixel walks the luminances of ALL the pixel's samples so far in the order they were taken.
+__global__ __launch_bounds__(TR_BLOCK) void k_sampler_decide(uint32_t n_pixels, SamplerPass sp, uint32_t* __restrict__ px_state,
+                                                             float* __restrict__ px_avg, const float* __restrict__ px_lum) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_pixels || (px_state[slot] & 1u)) return;
+    const float* __restrict__ lum = px_lum + (size_t)slot * sp.lum_cap;
+    const uint32_t n = sp.before + sp.count;
+    bool more = false;
+    if (sp.taken < sp.max_spp) {   // (report_results tests samples_taken >= max_spp first: the average is not touched then)
+        float avg = px_avg[slot];
+        if (sp.taken == sp.min_spp) {   // first round: the plain mean
+            float ac = 0.0f;
+            for (uint32_t k = 0; k < n; ++k) ac = ac + lum[k];
+            avg = ac / (float)n;
+        } else {                        // the new samples enter a running average -- with (i - 1) / i where a mean would have i / (i + 1)
+            for (uint32_t k = n - sp.step; k < n; ++k) avg = (lum[k] + (float)(k - 1u) * avg) / (float)k;
+        }
+        px_avg[slot] = avg;
+        for (uint32_t k = 0; k < n && !more; ++k) more = fabsf(lum[k] - avg) / avg > 0.5f;
+    }
+    if (!more) px_state[slot] |= 1u;
+}
+
 __global__ __launch_bounds__(64) void k_debug_bsdf(const DevScene scv, uint32_t flags_sel, uint32_t n,
                                                    const float* __restrict__ dirs, const float* __restrict__ u3, float* __restrict__ out) {
     const DevScene& sc = scv;
@@ -600,6 +723,10 @@ struct TrayDeviceScene {
     bool wf_sort = true;              // material sort of the shading stage (k_wf_begin's LDS counting sort -> k_wf_query_kind); off for textured scenes
     uint32_t* d_kind_queues = nullptr;   // WF_MAT_KINDS x n_slots slot indices
     uint32_t mat_kinds_present = 0;   // bit per TRAY_MAT_* kind among the scene's materials
+    // tray_scene_set_sampler: which Sampler the render calls stand for, and the per-pixel state of k_sampler_pass / k_sampler_decide
+    uint32_t sampler_kind = TRAY_SAMPLER_LOW_DISCREPANCY, smp_min = 1, smp_max = 1;
+    void* d_smp = nullptr;            // [state u32 | running average f32 | luminances f32 x cap] per pixel of a batch of tiles
+    size_t smp_bytes = 0;
 };
 
 static thread_local int g_device = 0;
@@ -739,6 +866,7 @@ void tray_scene_destroy(TrayDeviceScene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (void* p : s->allocs) (void)hipFree(p);
+    if (s->d_smp) (void)hipFree(s->d_smp);
     if (s->h_done) (void)hipHostFree(s->h_done);
     for (int k = 0; k < WF_PIPES_MAX; ++k) {
         if (s->wf_streams[k]) (void)hipStreamDestroy(s->wf_streams[k]);
@@ -1085,7 +1213,8 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
                 reinterpret_cast<const void*>(k_wf_trace_fallback<1, 0>), reinterpret_cast<const void*>(k_wf_trace_fallback<1, 1>),
                 reinterpret_cast<const void*>(k_wf_trace_fallback<2, 0>), reinterpret_cast<const void*>(k_wf_trace_fallback<2, 1>),
                 reinterpret_cast<const void*>(k_debug_intersect<0>), reinterpret_cast<const void*>(k_debug_intersect<2>),
-                reinterpret_cast<const void*>(k_debug_sample_radiance<0>), reinterpret_cast<const void*>(k_debug_sample_radiance<2>)};
+                reinterpret_cast<const void*>(k_debug_sample_radiance<0>), reinterpret_cast<const void*>(k_debug_sample_radiance<2>),
+                reinterpret_cast<const void*>(k_sampler_pass<0>), reinterpret_cast<const void*>(k_sampler_pass<2>)};
             for (const void* k : traversing) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipGetLastError();
         }
@@ -1188,6 +1317,8 @@ int tray_scene_update_frame(TrayDeviceScene* s, const TrayFlatScene* f) {
         if (s->allocs.size() != owned_before) s->broken = true;
         return rc;
     }
+    n->sampler_kind = s->sampler_kind; n->smp_min = s->smp_min; n->smp_max = s->smp_max;   // (tray_scene_set_sampler belongs to the handle)
+    std::swap(n->d_smp, s->d_smp); std::swap(n->smp_bytes, s->smp_bytes);
     std::swap(*s, *n);        // the handle keeps its identity; n now owns what the new frame did not take over
     tray_scene_destroy(n);
     return TRAY_OK;
@@ -1338,6 +1469,19 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     return TRAY_OK;
 }
 
+int tray_scene_set_sampler(TrayDeviceScene* s, uint32_t kind, uint32_t min_spp, uint32_t max_spp) {
+    if (!s) { set_error("tray_scene_set_sampler: null argument"); return TRAY_E_INVALID; }
+    if (kind > TRAY_SAMPLER_ADAPTIVE) { set_error("tray_scene_set_sampler: unknown sampler kind"); return TRAY_E_INVALID; }
+    if (kind == TRAY_SAMPLER_ADAPTIVE) {
+        if (min_spp > (1u << 16) || max_spp > (1u << 16)) { set_error("tray_scene_set_sampler: Adaptive takes at most 65 536 samples per pixel here"); return TRAY_E_UNSUPPORTED; }
+        const uint32_t lo = tray_round_spp(min_spp), hi = tray_round_spp(max_spp);   // adaptive.rs:36-47
+        if (hi < lo) { set_error("tray_scene_set_sampler: max_spp < min_spp (Adaptive::new would underflow, adaptive.rs:48)"); return TRAY_E_INVALID; }
+        s->smp_min = lo; s->smp_max = hi;
+    } else { s->smp_min = s->smp_max = 1u; }
+    s->sampler_kind = kind;
+    return TRAY_OK;
+}
+
 int tray_render_tiles_device(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t spp, uint64_t seed,
                              float* rgbw_dev, void* stream_) {
     if (!s || !rgbw_dev) { set_error("tray_render_tiles_device: null argument"); return TRAY_E_INVALID; }
@@ -1362,9 +1506,64 @@ int tray_render_shard_device(TrayDeviceScene* s, uint32_t shard, uint32_t n_shar
     return launch_tiles(s, shard * chunk_tiles, work, chunk_tiles, n_shards, spp, seed, rgbw_dev, stream_);
 }
 
+// thread_work with sampler::Uniform / sampler::Adaptive (include/trayhip.h: tray_scene_set_sampler): rounds of k_sampler_pass (+
+// k_sampler_decide) over batches of tiles, all on `stream`, no host synchronisation -- a pixel that is finished sits out the later rounds.
+static int launch_sampler(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride,
+                          uint32_t kf, float* rgbw_dev, hipStream_t stream) {
+    SamplerPass sp{};
+    sp.kind = s->sampler_kind; sp.min_spp = s->smp_min; sp.max_spp = s->smp_max;
+    uint32_t rounds = 1;
+    if (sp.kind == TRAY_SAMPLER_ADAPTIVE) {
+        sp.step = tray_adaptive_step(sp.min_spp, sp.max_spp);
+        while (sp.min_spp + (rounds - 1u) * sp.step < sp.max_spp) ++rounds;     // get_samples until samples_taken >= max_spp (adaptive.rs:136)
+        sp.lum_cap = sp.min_spp + (rounds - 1u) * sp.step;
+    } else { sp.min_spp = sp.max_spp = 1u; sp.step = 1u; sp.lum_cap = 0u; }
+    // tiles per batch: the per-pixel state within 256 MB and the largest round within 2^28 threads
+    const size_t px_bytes = 8u + 4u * (size_t)sp.lum_cap;
+    const uint32_t widest = std::max(sp.min_spp, sp.step);
+    uint32_t batch = (uint32_t)std::min<size_t>({(size_t)tile_count, ((size_t)256 << 20) / (64u * px_bytes), ((size_t)1 << 28) / (64u * (size_t)widest)});
+    if (batch == 0u) { set_error("Adaptive sampler: min_spp / max_spp too large for one tile's state"); return TRAY_E_UNSUPPORTED; }
+    const size_t need = (size_t)batch * 64u * px_bytes;
+    if (need > s->smp_bytes) {
+        if (s->d_smp) { HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(s->d_smp); s->d_smp = nullptr; s->smp_bytes = 0; }
+        HIP_CHECK(hipMalloc(&s->d_smp, need));
+        s->smp_bytes = need;
+    }
+    uint32_t* const px_state = static_cast<uint32_t*>(s->d_smp);
+    float* const px_avg = reinterpret_cast<float*>(px_state + (size_t)batch * 64u);
+    float* const px_lum = px_avg + (size_t)batch * 64u;
+    HIP_CHECK(hipEventRecord(s->ev0, stream));
+    uint32_t launches = 0;
+    for (uint32_t item0 = 0; item0 < tile_count; item0 += batch) {
+        const uint32_t n_items = std::min(batch, tile_count - item0), n_px = n_items * 64u;
+        if (sp.kind == TRAY_SAMPLER_ADAPTIVE) HIP_CHECK(hipMemsetAsync(s->d_smp, 0, (size_t)batch * 64u * 8u, stream));   // states and averages
+        for (uint32_t j = 0; j < rounds; ++j) {
+            sp.pass = j;
+            sp.count = sp.kind == TRAY_SAMPLER_ADAPTIVE ? (j == 0u ? sp.min_spp : sp.step) : 1u;
+            sp.taken = sp.kind == TRAY_SAMPLER_ADAPTIVE ? sp.min_spp + j * sp.step : 0u;
+            sp.before = j == 0u ? 0u : sp.min_spp + (j - 1u) * sp.step;
+            const dim3 grid((uint32_t)(((size_t)n_px * sp.count + TR_BLOCK - 1) / TR_BLOCK)), block(TR_BLOCK);
+            if (s->animated) hipLaunchKernelGGL(k_sampler_pass<2>, grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats);
+            else hipLaunchKernelGGL(k_sampler_pass<0>, grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats);
+            ++launches;
+            if (sp.kind == TRAY_SAMPLER_ADAPTIVE) {
+                hipLaunchKernelGGL(k_sampler_decide, dim3((n_px + TR_BLOCK - 1) / TR_BLOCK), block, 0, stream, n_px, sp, px_state, px_avg, px_lum);
+                ++launches;
+            }
+        }
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(s->ev1, stream));
+    s->timing_valid = true;
+    s->launches = launches;
+    return TRAY_OK;
+}
+
 static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride,
                         uint32_t spp, uint64_t seed, float* rgbw_dev, void* stream_) {
-    if (spp == 0 || (spp & (spp - 1)) != 0) { set_error("spp must be a power of two (LowDiscrepancy sampler, ld.rs:22-25); use tray_round_spp"); return TRAY_E_INVALID; }
+    if (s->sampler_kind == TRAY_SAMPLER_LOW_DISCREPANCY && (spp == 0 || (spp & (spp - 1)) != 0)) {
+        set_error("spp must be a power of two (LowDiscrepancy sampler, ld.rs:22-25); use tray_round_spp"); return TRAY_E_INVALID;
+    }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (s->broken) { set_error("this device scene is unusable: a tray_scene_update_frame on it failed"); return TRAY_E_INVALID; }
     HIP_CHECK(hipSetDevice(s->device));
@@ -1378,6 +1577,7 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
     kf = mix(kf ^ (uint32_t)(seed >> 32));
     kf = mix(kf + s->dev.frame);
+    if (s->sampler_kind != TRAY_SAMPLER_LOW_DISCREPANCY) return launch_sampler(s, tile_start, tile_count, chunk, chunk_stride, kf, rgbw_dev, stream);
     if (s->wavefront) return launch_wavefront(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
     // Slices per tile. A slice costs its own film resolve and flush, so tiles are only halved (quartered) when a launch has fewer than
     // 12 (3) of them per workgroup and a slice keeps >= 256 samples per pixel -- measured on one GPU's share of C2 at 8 GPUs (4050
@@ -1539,6 +1739,15 @@ int tray_multi_create(const TrayFlatScene* f, int n_dev, const int* dev_ids, Tra
 }
 
 // The same scene at another frame on every device (tray_scene_update_frame); communicators, films and streams stay.
+int tray_multi_set_sampler(TrayMultiScene* m, uint32_t kind, uint32_t min_spp, uint32_t max_spp) {
+    if (!m) { set_error("tray_multi_set_sampler: null argument"); return TRAY_E_INVALID; }
+    for (TrayDeviceScene* s : m->scenes) {
+        const int rc = tray_scene_set_sampler(s, kind, min_spp, max_spp);
+        if (rc != TRAY_OK) return rc;
+    }
+    return TRAY_OK;
+}
+
 int tray_multi_update_frame(TrayMultiScene* m, const TrayFlatScene* f) {
     if (!m || !f) { set_error("tray_multi_update_frame: null argument"); return TRAY_E_INVALID; }
     int current = 0;

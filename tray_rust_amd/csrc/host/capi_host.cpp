@@ -89,6 +89,11 @@ uint32_t tray_round_spp(uint32_t spp) {   // ld.rs:22-25 (usize::next_power_of_t
     return p;
 }
 
+uint32_t tray_adaptive_step(uint32_t min_spp, uint32_t max_spp) {   // adaptive.rs:36-48
+    const uint32_t lo = tray_round_spp(min_spp), hi = tray_round_spp(max_spp);
+    return tray_round_spp(hi > lo ? (hi - lo) / 5u : 0u);
+}
+
 int tray_resolve_srgb8(const float* rgbw, uint32_t width, uint32_t height, uint8_t* rgb8) {   // render_target.rs:185-210, color.rs:36-71
     if (!rgbw || !rgb8) { set_error("tray_resolve_srgb8: null argument"); return TRAY_E_INVALID; }
     const size_t n = size_t(width) * height;
