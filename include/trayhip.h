@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TRAY_ABI_VERSION 3
+#define TRAY_ABI_VERSION 4
 
 enum {
     TRAY_OK = 0,
@@ -76,7 +76,18 @@ typedef struct TrayMesh {
     uint32_t tri_count;
 } TrayMesh;
 
-enum { TRAY_GEOM_SPHERE = 0, TRAY_GEOM_DISK = 1, TRAY_GEOM_RECT = 2, TRAY_GEOM_MESH = 3, TRAY_GEOM_NONE = 4 };
+/* AnimatedMesh (src/geometry/animated_mesh.rs:93-143): a mesh whose vertex positions, normals and texcoords are interpolated linearly
+ * between keyframes at ray.time (AnimatedMeshData::position / normal / texcoord, :72-107), behind ONE BVH<AnimatedTriangle> built over the
+ * triangles' bounds at times[0] and times[1] (AnimatedMesh::new, :124-126 -- Boundable::update_deformation, :140-142, has no caller in the
+ * reference, so that tree serves every frame: quirk Q13). meshes[m] describes the tree and ONE keyframe's triangles (tri_count); keyframe k
+ * of the mesh lies at tri_verts / tri_attrs [tri_offset + k * tri_count ...], all in the leaf order of that tree; mesh_keys[m] names the
+ * keyframe times. n_keys == 1 for a plain Mesh. */
+typedef struct TrayMeshKeys {
+    uint32_t n_keys;       /* >= 2 for an animated mesh */
+    uint32_t time_first;   /* into TrayFlatScene.key_times (ascending per mesh) */
+} TrayMeshKeys;
+
+enum { TRAY_GEOM_SPHERE = 0, TRAY_GEOM_DISK = 1, TRAY_GEOM_RECT = 2, TRAY_GEOM_MESH = 3, TRAY_GEOM_NONE = 4, TRAY_GEOM_ANIMATED_MESH = 5 };
 enum { TRAY_INST_RECEIVER = 0, TRAY_INST_AREA_EMITTER = 1, TRAY_INST_POINT_EMITTER = 2 };
 
 /* One Instance (src/geometry/instance.rs:72-105) with its transform evaluated for the frame.
@@ -242,6 +253,8 @@ typedef struct TrayFlatScene {
     uint32_t n_textures;    const TrayTexture* textures;
     uint32_t n_tex_frames;  const TrayTexFrame* tex_frames;
     uint64_t n_tex_bytes;   const uint8_t* tex_data;            /* RGBA8 texels of all frames */
+    uint32_t n_mesh_keys;   const TrayMeshKeys* mesh_keys;      /* n_meshes entries, or 0 / NULL when no mesh is animated */
+    uint32_t n_key_times;   const float* key_times;
 } TrayFlatScene;
 
 /* ---------------------------------------------------------------- host side: loader (scene.rs) */

@@ -290,12 +290,58 @@ inline bool mesh_intersect(const SceneView& sv, const TrayMesh& m, Ray& ray, Hit
     return any;
 }
 
+// AnimatedMesh::intersect (animated_mesh.rs:130-134): BVH<AnimatedTriangle>::intersect over the ONE tree AnimatedMesh::new built for
+// times[0] .. times[1] (:124-126; Boundable::update_deformation has no caller -- quirk Q13), every triangle at the ray's time:
+// AnimatedMeshData::active_keyframes (:56-70), position / normal / texcoord = lerp of the two keyframes' values (:72-107, linalg/mod.rs:47-49),
+// then mesh.rs's intersect_triangle (AnimatedTriangle::intersect, :160-172).
+inline bool animated_mesh_intersect(const SceneView& sv, uint32_t mesh_id, Ray& ray, Hit& h) {
+    const TrayFlatScene& fs = *sv.fs;
+    const TrayMesh& m = fs.meshes[mesh_id];
+    const TrayMeshKeys& mk = fs.mesh_keys[mesh_id];
+    const float* times = fs.key_times + mk.time_first;
+    // times.binary_search_by(|t| t.partial_cmp(&time).unwrap()) over ascending times
+    uint32_t i = 0;
+    while (i < mk.n_keys && times[i] < ray.time) ++i;
+    uint32_t lo, hi;
+    bool two = false;
+    if (i < mk.n_keys && times[i] == ray.time) { lo = hi = i; }            // Ok(i) => (i, None)
+    else if (i == mk.n_keys) { lo = hi = i - 1; }                           // Err(len) => (len - 1, None)
+    else if (i == 0) { lo = hi = 0; }                                       // Err(0) => (0, None)
+    else { lo = i - 1; hi = i; two = true; }                                // Err(i) => (i - 1, Some(i))
+    const float x = two ? (ray.time - times[lo]) / (times[hi] - times[lo]) : 0.0f;
+    auto lerp3 = [&](const float* a, const float* b, float* out) { for (int c = 0; c < 3; ++c) out[c] = a[c] * (1.0f - x) + b[c] * x; };
+    auto lerp2 = [&](const float* a, const float* b, float* out) { for (int c = 0; c < 2; ++c) out[c] = a[c] * (1.0f - x) + b[c] * x; };
+    bool any = false;
+    auto leaf = [&](uint32_t first, uint32_t count) {
+        for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t slot = m.tri_offset + first + k;   // the triangle's record in keyframe 0
+            const TrayTriVerts& v0 = fs.tri_verts[slot + (size_t)lo * m.tri_count];
+            const TrayTriAttrs& a0 = fs.tri_attrs[slot + (size_t)lo * m.tri_count];
+            TrayTriVerts v = v0;
+            TrayTriAttrs a = a0;
+            if (two) {
+                const TrayTriVerts& v1 = fs.tri_verts[slot + (size_t)hi * m.tri_count];
+                const TrayTriAttrs& a1 = fs.tri_attrs[slot + (size_t)hi * m.tri_count];
+                lerp3(v0.pa, v1.pa, v.pa); lerp3(v0.pb, v1.pb, v.pb); lerp3(v0.pc, v1.pc, v.pc);
+                lerp3(a0.na, a1.na, a.na); lerp3(a0.nb, a1.nb, a.nb); lerp3(a0.nc, a1.nc, a.nc);
+                lerp2(a0.ta, a1.ta, a.ta); lerp2(a0.tb, a1.tb, a.tb); lerp2(a0.tc, a1.tc, a.tc);
+            }
+            Hit cand;
+            if (triangle_intersect(v, a, ray, cand)) { h = cand; h.prim = slot; any = true; }
+        }
+    };
+    if (sv.flags & ORC_BRUTE_FORCE) leaf(0, m.tri_count);
+    else bvh_traverse(fs.mesh_nodes + m.node_offset, ray, leaf);
+    return any;
+}
+
 inline bool geom_intersect(const SceneView& sv, const TrayInstance& in, Ray& local, Hit& h) {
     switch (in.geom_type) {
         case TRAY_GEOM_SPHERE: return sphere_intersect(in.geom_params[0], local, h);
         case TRAY_GEOM_DISK: return disk_intersect(in.geom_params[0], in.geom_params[1], local, h);
         case TRAY_GEOM_RECT: return rect_intersect(in.geom_params[0], in.geom_params[1], local, h);
         case TRAY_GEOM_MESH: return mesh_intersect(sv, sv.fs->meshes[in.mesh_id], local, h);
+        case TRAY_GEOM_ANIMATED_MESH: return animated_mesh_intersect(sv, in.mesh_id, local, h);
         default: return false;
     }
 }

@@ -103,6 +103,12 @@ uint32_t bvh_depth(const TrayBvhNode* nodes, uint32_t n) {
     return best;
 }
 
+// the scene holds an AnimatedMesh: the ANIM = 3 instantiations run (tray_scene_create: TrayDeviceScene::deforming)
+static bool deforming(const TrayFlatScene* f) {
+    for (uint32_t i = 0; i < f->n_instances; ++i) if (f->instances[i].geom_type == TRAY_GEOM_ANIMATED_MESH) return true;
+    return false;
+}
+
 void make_scene(const TrayFlatScene* f, EmuScene& e) {
     DevScene& d = e.d;
     if (!tray::pair_trees(f, e.paired)) throw std::runtime_error("BVH arrays do not describe trees");
@@ -132,6 +138,7 @@ void make_scene(const TrayFlatScene* f, EmuScene& e) {
     tray::flat_loop_gates(f, e.paired, TR_COOP_MAX_TRIS, e.flat_leaves, e.flat_insts, e.tri_leaf);
     d.flat_leaves = e.flat_leaves.data(); d.flat_insts = e.flat_insts.data(); d.n_flat_leaves = (uint32_t)e.flat_leaves.size(); d.tri_leaf = e.tri_leaf.data();
     d.retraced = &g_retraced;
+    d.mesh_keys = f->mesh_keys; d.key_times = f->key_times;
     uint32_t mesh_depth = 0;
     for (uint32_t m = 0; m < f->n_meshes; ++m) mesh_depth = std::max(mesh_depth, bvh_depth(f->mesh_nodes + f->meshes[m].node_offset, f->meshes[m].node_count));
     e.depth = mesh_depth + bvh_depth(f->top_nodes, f->n_top_nodes) + 8u;
@@ -176,7 +183,8 @@ extern "C" {
 int emu_debug_intersect(const TrayFlatScene* f, uint32_t n, const TrayRay* rays, TrayHit* hits) {
     EmuScene e;
     make_scene(f, e);
-    launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_intersect<0>(e.d, n, rays, hits); });
+    if (deforming(f)) launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_intersect<3>(e.d, n, rays, hits); });
+    else launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_intersect<0>(e.d, n, rays, hits); });
     return 0;
 }
 
@@ -190,7 +198,8 @@ int emu_debug_sample_radiance(const TrayFlatScene* f, uint32_t n, const uint32_t
     bool moving = f->camera.animated != 0;
     for (uint32_t t_ = 0; t_ < f->n_textures; ++t_) moving = moving || f->textures[t_].n_frames >= 2u;   // animated_image needs ray.time (tray_scene_create)
     for (uint32_t i = 0; i < f->n_instances; ++i) moving = moving || f->instances[i].animated != 0 || f->instances[i].emis_count >= 2;
-    if (moving) launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_sample_radiance<2>(e.d, n, px, py, si, spp, kf, out); });
+    if (deforming(f)) launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_sample_radiance<3>(e.d, n, px, py, si, spp, kf, out); });
+    else if (moving) launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_sample_radiance<2>(e.d, n, px, py, si, spp, kf, out); });
     else launch((n + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_debug_sample_radiance<0>(e.d, n, px, py, si, spp, kf, out); });
     return 0;
 }
@@ -219,6 +228,7 @@ int emu_render_sampler(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_
         while (sp.min_spp + (rounds - 1u) * sp.step < sp.max_spp) ++rounds;
         sp.lum_cap = sp.min_spp + (rounds - 1u) * sp.step;
     } else if (kind == TRAY_SAMPLER_UNIFORM) { sp.min_spp = sp.max_spp = 1u; sp.step = 1u; sp.lum_cap = 0u; }
+    else if (kind == TRAY_SAMPLER_LOW_DISCREPANCY) { sp.max_spp = sp.min_spp; sp.step = 1u; sp.lum_cap = 0u; }   // (scenes with an AnimatedMesh: min_spp = the render's spp)
     else return -1;
     const uint32_t batch = batch_tiles ? std::min(batch_tiles, std::max(tile_count, 1u)) : std::max(tile_count, 1u);
     std::vector<uint32_t> px_state((size_t)batch * 64u);
@@ -229,11 +239,12 @@ int emu_render_sampler(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_
         std::fill(px_state.begin(), px_state.end(), 0u); std::fill(px_avg.begin(), px_avg.end(), 0.0f);
         for (uint32_t j = 0; j < rounds; ++j) {
             sp.pass = j;
-            sp.count = kind == TRAY_SAMPLER_ADAPTIVE ? (j == 0u ? sp.min_spp : sp.step) : 1u;
+            sp.count = kind == TRAY_SAMPLER_ADAPTIVE ? (j == 0u ? sp.min_spp : sp.step) : sp.min_spp;
             sp.taken = kind == TRAY_SAMPLER_ADAPTIVE ? sp.min_spp + j * sp.step : 0u;
             sp.before = j == 0u ? 0u : sp.min_spp + (j - 1u) * sp.step;
             const uint32_t grid = (uint32_t)(((size_t)n_px * sp.count + TR_BLOCK - 1) / TR_BLOCK);
-            if (moving) launch(grid, TR_BLOCK, [&] { k_sampler_pass<2>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
+            if (deforming(f)) launch(grid, TR_BLOCK, [&] { k_sampler_pass<3>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
+            else if (moving) launch(grid, TR_BLOCK, [&] { k_sampler_pass<2>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
             else launch(grid, TR_BLOCK, [&] { k_sampler_pass<0>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
             if (kind == TRAY_SAMPLER_ADAPTIVE)
                 launch((n_px + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_sampler_decide(n_px, sp, px_state.data(), px_avg.data(), px_lum.data()); });

@@ -57,3 +57,19 @@ with tempfile.TemporaryDirectory() as d:
     img, st = O.render_tiles(scene.flatten(3), 256, seed=9)
     np.savez_compressed(os.path.join(HERE, "moving_box_48x32_256spp_seed9.npz"), rgbw=img, vertices=st.vertices, rays=st.rays, frame=3)
     print("moving_box 256 spp", img.shape, st.vertices, st.rays)
+
+# the waving sheet (an AnimatedMesh, frame 1) under LowDiscrepancy, and cornell_box under the Uniform and Adaptive(4, 32)
+# samplers -- films, per-pixel sample counts and totals
+with tempfile.TemporaryDirectory() as d:
+    scene, *_ = T.Scene.load_file(scenes.write_waving_flag(d, grid=12, n_keys=4, width=48, height=32, samples=16))
+    img, st = O.render_tiles(scene.flatten(1), 16, seed=9)
+    scenes.write_assets(d)
+    p = os.path.join(d, "s.json")
+    json.dump(scenes.cornell_box(48, 32, 16), open(p, "w"))
+    cornell = T.Scene.load_file(p)[0]      # (the flat view borrows from the scene object)
+    flat = cornell.flatten(0)
+    uni, st_u, _ = O.render_tiles_sampler(flat, O.SAMPLER_UNIFORM, seed=9)
+    ada, st_a, counts = O.render_tiles_sampler(flat, O.SAMPLER_ADAPTIVE, 4, 32, seed=9)
+    np.savez_compressed(os.path.join(HERE, "rank4_48x32_seed9.npz"), flag=img, flag_vertices=st.vertices, flag_rays=st.rays, flag_frame=1,
+                        uniform=uni, uniform_vertices=st_u.vertices, adaptive=ada, adaptive_samples=st_a.samples, adaptive_counts=counts.astype(np.uint8))
+    print("rank 4", st.vertices, st_u.vertices, st_a.samples)

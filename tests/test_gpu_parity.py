@@ -768,3 +768,49 @@ def test_gpu_other_samplers_tile_ranges_frames_and_errors(tmp_path):
     for bad in ((3, 1, 1), (T.sampler.ADAPTIVE, 64, 4), (T.sampler.ADAPTIVE, 1, 1 << 20)):
         with pytest.raises(T.TrayError):
             T.check(T.lib().tray_scene_set_sampler(dev, *bad))
+
+
+def test_gpu_animated_mesh(tmp_path):
+    """AnimatedMesh (geometry/animated_mesh.rs): hit records bit for bit at keyframe times, between keyframes and outside their range;
+    LowDiscrepancy and Adaptive renders (k_sampler_pass<3>: one thread per sample) against the oracle; frame updates keep the keyframes."""
+    path = scenes.write_waving_flag(str(tmp_path), grid=24, n_keys=4, width=160, height=96, samples=16, frames=8, scene_time=2.0)
+    scene, rt, _, fi = T.Scene.load_file(path)
+    flat = scene.flatten(0)
+    rng = np.random.default_rng(2)
+    n = 20000
+    o = rng.uniform([-14, 2, -30], [14, 22, -10], (n, 3)); tgt = rng.uniform([-8, 4, 0], [6, 18, 8], (n, 3))
+    d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    times = rng.choice(np.array([0.0, 0.1, 2.0 / 3.0, 0.5, 1.0, 1.7, 2.0, 3.0, -1.0], np.float32), n)
+    rays = np.concatenate([o, d, np.zeros((n, 1)), np.full((n, 1), np.inf), times[:, None]], axis=1).astype(np.float32)
+    a, b = O.intersect(flat, rays), gpu_intersect(scene, rays)
+    fs = flat.contents
+    flag_inst = [i for i in range(fs.n_instances) if fs.instances[i].geom_type == 5][0]
+    assert (a["inst"] == flag_inst).mean() > 0.2
+    for f in ("t", "inst", "prim"):
+        assert np.array_equal(a[f], b[f]), f
+    on_flag = a["inst"] == flag_inst
+    assert np.array_equal(a["u"][on_flag], b["u"][on_flag]) and np.array_equal(a["v"][on_flag], b["v"][on_flag])   # (barycentric sums: no libm)
+    for f in ("p", "n", "ng", "dp_du", "dp_dv", "u", "v"):
+        np.testing.assert_allclose(a[f], b[f], rtol=0, atol=2e-5)      # (normalize: ocml vs glibc sqrt / division order)
+    for frame, spp in ((1, 16), (5, 16)):
+        gpu, tim = gpu_render(scene, rt, spp, T.FrameInfo(fi.frames, fi.time, frame, frame), seed=6)
+        cpu, st = O.render_tiles(scene.flatten(frame), spp, seed=6)
+        assert tim.samples == st.samples and abs(int(tim.vertices) - int(st.vertices)) <= 1e-4 * st.vertices
+        print(f"waving_flag frame {frame} 160x96x{spp}: RMSE {rmse(gpu, cpu):.3e}")
+        assert rmse(gpu, cpu) < 1e-4
+    gpu, tim = gpu_render_sampler(scene, rt, lambda dim, spp: T.sampler.Adaptive(dim, 4, 32), fi, seed=6, frame=5)
+    cpu, st, _ = O.render_tiles_sampler(scene.flatten(5), O.SAMPLER_ADAPTIVE, 4, 32, seed=6)
+    assert abs(int(tim.samples) - int(st.samples)) <= 0.01 * st.samples and rmse(gpu, cpu) < 2e-3
+
+
+def test_gpu_matches_the_rank_4_golden(tmp_path):
+    g = np.load(os.path.join(GOLDEN, "rank4_48x32_seed9.npz"))
+    scene, rt, _, fi = T.Scene.load_file(scenes.write_waving_flag(str(tmp_path), grid=12, n_keys=4, width=48, height=32, samples=16))
+    frame = int(g["flag_frame"])
+    gpu, tim = gpu_render(scene, rt, 16, T.FrameInfo(fi.frames, fi.time, frame, frame), seed=9)
+    assert rmse(gpu, g["flag"]) < 1e-4 and abs(int(tim.vertices) - int(g["flag_vertices"])) <= 3
+    cornell, rt2, _, fi2 = load(scenes.cornell_box(48, 32, 16), tmp_path)
+    gpu, tim = gpu_render_sampler(cornell, rt2, lambda dim, spp: T.sampler.Uniform(dim), fi2, seed=9)
+    assert rmse(gpu, g["uniform"]) < 1e-3 and abs(int(tim.vertices) - int(g["uniform_vertices"])) <= 3
+    gpu, tim = gpu_render_sampler(cornell, rt2, lambda dim, spp: T.sampler.Adaptive(dim, 4, 32), fi2, seed=9)
+    assert abs(int(tim.samples) - int(g["adaptive_samples"])) <= 0.01 * int(g["adaptive_samples"]) and rmse(gpu, g["adaptive"]) < 2e-3

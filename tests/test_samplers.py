@@ -202,3 +202,23 @@ def test_device_code_of_adaptive_on_a_moving_scene(tmp_path, built):
     img, (samples, _, _) = E.render_sampler(flat, q, O.SAMPLER_ADAPTIVE, 2, 16, seed=3)
     assert samples == st.samples and counts.max() > 2
     np.testing.assert_allclose(img, ref, rtol=5e-5, atol=5e-5)
+
+
+def test_oracle_reproduces_the_rank_4_golden(tmp_path, built):
+    """tests/golden/rank4_48x32_seed9.npz (make_golden.py): the AnimatedMesh scene under LowDiscrepancy, cornell_box under Uniform and Adaptive"""
+    import json
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rank4_48x32_seed9.npz"))
+    scene, *_ = T.Scene.load_file(scenes.write_waving_flag(str(tmp_path), grid=12, n_keys=4, width=48, height=32, samples=16))
+    img, st = O.render_tiles(scene.flatten(int(g["flag_frame"])), 16, seed=9)
+    assert st.vertices == int(g["flag_vertices"]) and st.rays == int(g["flag_rays"])
+    assert np.abs(img - g["flag"]).max() <= 1e-5 * np.abs(g["flag"]).max()
+    scenes.write_assets(str(tmp_path))
+    p = os.path.join(str(tmp_path), "s.json")
+    json.dump(scenes.cornell_box(48, 32, 16), open(p, "w"))
+    cornell, *_ = T.Scene.load_file(p)
+    flat = cornell.flatten(0)
+    uni, st_u, _ = O.render_tiles_sampler(flat, O.SAMPLER_UNIFORM, seed=9)
+    ada, st_a, counts = O.render_tiles_sampler(flat, O.SAMPLER_ADAPTIVE, 4, 32, seed=9)
+    assert st_u.vertices == int(g["uniform_vertices"]) and st_a.samples == int(g["adaptive_samples"]) and np.array_equal(counts, g["adaptive_counts"])
+    assert np.abs(uni - g["uniform"]).max() <= 1e-5 * np.abs(g["uniform"]).max() and np.abs(ada - g["adaptive"]).max() <= 1e-5 * np.abs(g["adaptive"]).max()

@@ -96,6 +96,10 @@ def _P(t):
     return C.POINTER(t)
 
 
+class TrayMeshKeys(C.Structure):
+    _fields_ = [("n_keys", C.c_uint32), ("time_first", C.c_uint32)]
+
+
 class TrayFlatScene(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("frame", C.c_uint32), ("film", TrayFilm), ("camera", TrayCamera),
@@ -116,6 +120,7 @@ class TrayFlatScene(C.Structure):
         ("n_color_keys", C.c_uint32), ("color_keys", _P(TrayColorKey)), ("animated", C.c_uint32),
         ("integrator", C.c_uint32), ("n_textures", C.c_uint32), ("textures", _P(TrayTexture)), ("n_tex_frames", C.c_uint32), ("tex_frames", _P(TrayTexFrame)),
         ("n_tex_bytes", C.c_uint64), ("tex_data", _P(C.c_uint8)),
+        ("n_mesh_keys", C.c_uint32), ("mesh_keys", _P(TrayMeshKeys)), ("n_key_times", C.c_uint32), ("key_times", _P(C.c_float)),
     ]
 
 

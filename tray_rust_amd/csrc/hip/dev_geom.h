@@ -95,6 +95,10 @@ struct DevScene {
                                                  // slots = two levels of the binary trees above. ONE buffer -- the BVH<Triangle>s first, then this frame's
                                                  // BVH<Instance> from record top_quad_first -- so that a record's address is a uniform base + a 32-bit offset
     uint32_t top_quad_first, pad_quads;
+    // AnimatedMesh (geometry/animated_mesh.rs; include/trayhip.h: TrayMeshKeys): per mesh its keyframe count and times, or null. Only the
+    // ANIM = 3 instantiations (debug kernels, k_sampler_pass) read them.
+    const TrayMeshKeys* __restrict__ mesh_keys;
+    const float* __restrict__ key_times;
 };
 
 struct Ray {
@@ -130,6 +134,8 @@ TR_DEV void xf_cache_fill(const DevScene& sc, float time, uint32_t lane) {
 // ANIM template values: 0 = nothing moves within the frame; 1 = moving instances are read from the per-path cache (tile and
 // wavefront kernels: no function call in their hot loops, a call would raise their register allocation to the callee's);
 // 2 = the spline stacks are evaluated at every use (debug kernels, whose grids are not sized by the cache)
+// 3 = as 2, and the scene may hold AnimatedMeshes: Scene::intersect is the reference's two-level traversal with the triangles of such a
+//     mesh interpolated at ray.time (trace_bvh, finish_hit); the scenes' renders go through k_sampler_pass<3> whatever the sampler
 // rows of inv and its [3][3] only (x + 12 .. x + 24 are written)
 template <int ANIM>
 TR_DEV void instance_inv_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, uint32_t column, float* x) {
@@ -285,6 +291,45 @@ TR_DEV bool triangle_test(const TrayTriVerts* __restrict__ tv, f3 o, f3 d, float
     if (ok) { t_out = t; b1_out = b1; b2_out = b2; }
     return ok;
 #endif
+}
+
+// AnimatedMeshData::active_keyframes (animated_mesh.rs:56-70) and the interpolation factor of position / normal / texcoord (:72-107) for
+// one ray.time: keyframes lo and hi (hi == lo: one keyframe applies -- the time IS a keyframe's, or lies outside the keyframes' range)
+struct KeyPair { uint32_t lo, hi; float x; };
+TR_DEV KeyPair active_keyframes(const DevScene& sc, uint32_t mesh_id, float time) {
+    const TrayMeshKeys mk = sc.mesh_keys[mesh_id];
+    const float* __restrict__ times = sc.key_times + mk.time_first;
+    uint32_t i = 0u;   // times.binary_search_by(|t| t.partial_cmp(&time)) over ascending, distinct times: Ok(i) if times[i] == time, else Err(first i with times[i] > time)
+    while (i < mk.n_keys && times[i] < time) ++i;
+    KeyPair kp;
+    kp.x = 0.0f;
+    if (i < mk.n_keys && times[i] == time) { kp.lo = kp.hi = i; }
+    else if (i == mk.n_keys) { kp.lo = kp.hi = i - 1u; }
+    else if (i == 0u) { kp.lo = kp.hi = 0u; }
+    else { kp.lo = i - 1u; kp.hi = i; kp.x = (time - times[kp.lo]) / (times[kp.hi] - times[kp.lo]); }
+    return kp;
+}
+TR_DEV f3 key_lerp(float x, f3 a, f3 b) { return a * (1.0f - x) + b * x; }   // linalg::lerp (linalg/mod.rs:47-49)
+// the triangle in slot `tv` of keyframe 0 (leaf order; keyframe k lies k * stride records on) at the ray's time: AnimatedTriangle::intersect's
+// pa, pb, pc (animated_mesh.rs:160-163)
+TR_DEV void key_triangle(const TrayTriVerts* __restrict__ tv, uint32_t stride, KeyPair kp, f3& pa, f3& pb, f3& pc) {
+    const float4* q = reinterpret_cast<const float4*>(tv + (size_t)kp.lo * stride);
+    const float4 A = q[0], B = q[1], C = q[2];
+    pa = mk(A.x, A.y, A.z); pb = mk(B.x, B.y, B.z); pc = mk(C.x, C.y, C.z);
+    if (kp.hi != kp.lo) {
+        const float4* r = reinterpret_cast<const float4*>(tv + (size_t)kp.hi * stride);
+        const float4 D = r[0], E = r[1], F = r[2];
+        pa = key_lerp(kp.x, pa, mk(D.x, D.y, D.z)); pb = key_lerp(kp.x, pb, mk(E.x, E.y, E.z)); pc = key_lerp(kp.x, pc, mk(F.x, F.y, F.z));
+    }
+}
+TR_DEV bool key_triangle_test(const TrayTriVerts* __restrict__ tv, uint32_t stride, KeyPair kp, f3 o, f3 d, float min_t, float max_t, float& t_out, float& b1_out, float& b2_out) {
+    alignas(16) TrayTriVerts now;
+    f3 pa, pb, pc;
+    key_triangle(tv, stride, kp, pa, pb, pc);
+    now.pa[0] = pa.x; now.pa[1] = pa.y; now.pa[2] = pa.z; now.tri_id = 0u;
+    now.pb[0] = pb.x; now.pb[1] = pb.y; now.pb[2] = pb.z; now.pad0 = 0u;
+    now.pc[0] = pc.x; now.pc[1] = pc.y; now.pc[2] = pc.z; now.pad1 = 0u;
+    return triangle_test(&now, o, d, min_t, max_t, t_out, b1_out, b2_out);
 }
 
 TR_DEV bool sphere_test(float radius, f3 o, f3 d, float min_t, float max_t, float& t_out) {   // sphere.rs:33-53
@@ -703,6 +748,10 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
     uint32_t tri_base = 0;
     bool in_mesh = false;
     bool any = false;
+    bool deforming = false;        // (ANIM = 3) the mesh being traversed is an AnimatedMesh: its triangles at ray.time
+    KeyPair keys;
+    keys.lo = keys.hi = 0u; keys.x = 0.0f;
+    uint32_t key_stride = 0u;
     for (;;) {
         // ---- node test (both levels)
         const float4* nq = reinterpret_cast<const float4*>(tree + current);
@@ -722,7 +771,9 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
             } else if (in_mesh) {   // BVH<Triangle> leaf (<= 16 triangles), tested in order
                 for (uint32_t k = 0; k < count; ++k) {
                     float t, bb1, bb2;
-                    if (triangle_test(tris + offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
+                    const bool tri_hit = (ANIM == 3 && deforming) ? key_triangle_test(tris + offset + k, key_stride, keys, o, d, min_t, max_t, t, bb1, bb2)
+                                                                  : triangle_test(tris + offset + k, o, d, min_t, max_t, t, bb1, bb2);
+                    if (tri_hit) {
                         max_t = t;
                         rec.t = t; rec.inst = cur_inst; rec.prim = tri_base + offset + k; rec.b1 = bb1; rec.b2 = bb2;
                         any = true;
@@ -768,8 +819,12 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
                 ld = xf_vector(in->inv, ray.d);
             }
             uint32_t gt = in->geom_type;
-            if (gt == TRAY_GEOM_MESH) {
+            if (gt == TRAY_GEOM_MESH || (ANIM == 3 && gt == TRAY_GEOM_ANIMATED_MESH)) {
                 const TrayMesh m = sc.meshes[in->mesh_id];
+                if (ANIM == 3) {   // AnimatedMesh::intersect (animated_mesh.rs:130-134): the same traversal over ITS tree, triangles at ray.time
+                    deforming = gt == TRAY_GEOM_ANIMATED_MESH;
+                    if (deforming) { keys = active_keyframes(sc, in->mesh_id, ray.time); key_stride = m.tri_count; }
+                }
                 stack[sp * TR_BLOCK] = STK_EXIT_MESH;
                 ++sp;
                 in_mesh = true;
@@ -812,7 +867,7 @@ TR_DEV TraceResult trace(const DevScene* __restrict__ scp, uint32_t* __restrict_
     r.rec.t = 0.0f; r.rec.inst = 0xffffffffu; r.rec.prim = 0u; r.rec.b1 = 0.0f; r.rec.b2 = 0.0f;
     // (moving scenes too since round 4: the flat loop's gates are the boxes of the BVH<Instance> leaves -- for a moving scene the reference's
     // swept bounds of animated_transform.rs:58-71 with quirk Q12 -- so it reaches exactly the instances the reference's traversal can reach)
-    if (sc.n_instances <= TR_FLAT_MAX) {
+    if (ANIM != 3 && sc.n_instances <= TR_FLAT_MAX) {
         bool hazard = false;
         r.hit = trace_flat<ANIM>(sc, stack, ray, any_hit, active, r.rec, hazard);
         if (__any(hazard)) {   // (about one ray in 1e7: tied candidates, or a box entered behind its own hit) the reference's traversal decides
@@ -863,7 +918,7 @@ TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, flo
         dp_dv = mk(p.z * cos_phi, p.z * sin_phi, -radius * sinf(theta)) * kPi;
         n = normalized(p);
         ng = n;
-    } else if (gt == TRAY_GEOM_MESH) {   // mesh.rs:172-197
+    } else if (gt == TRAY_GEOM_MESH || (ANIM == 3 && gt == TRAY_GEOM_ANIMATED_MESH)) {   // mesh.rs:172-197
         const float4* q = reinterpret_cast<const float4*>(sc.tri_verts + rec.prim);
         float4 A = q[0], B = q[1], C = q[2];
         f3 pa = mk(A.x, A.y, A.z), pb = mk(B.x, B.y, B.z), pc = mk(C.x, C.y, C.z);
@@ -871,6 +926,21 @@ TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, flo
         float4 a0 = aq[0], a1 = aq[1], a2 = aq[2], a3 = aq[3];
         f3 na = mk(a0.x, a0.y, a0.z), nb = mk(a0.w, a1.x, a1.y), nc = mk(a1.z, a1.w, a2.x);
         f3 ta = mk(a2.y, a2.z, 0.0f), tb = mk(a2.w, a3.x, 0.0f), tc = mk(a3.y, a3.z, 0.0f);
+        if (ANIM == 3 && gt == TRAY_GEOM_ANIMATED_MESH) {   // AnimatedTriangle::intersect (animated_mesh.rs:160-172): everything at ray.time (rec.prim: the slot in keyframe 0)
+            const KeyPair kp = active_keyframes(sc, in->mesh_id, ray.time);
+            const uint32_t stride = sc.meshes[in->mesh_id].tri_count;
+            key_triangle(sc.tri_verts + rec.prim, stride, kp, pa, pb, pc);
+            const float4* lq = reinterpret_cast<const float4*>(sc.tri_attrs + rec.prim + (size_t)kp.lo * stride);
+            a0 = lq[0]; a1 = lq[1]; a2 = lq[2]; a3 = lq[3];
+            na = mk(a0.x, a0.y, a0.z); nb = mk(a0.w, a1.x, a1.y); nc = mk(a1.z, a1.w, a2.x);
+            ta = mk(a2.y, a2.z, 0.0f); tb = mk(a2.w, a3.x, 0.0f); tc = mk(a3.y, a3.z, 0.0f);
+            if (kp.hi != kp.lo) {
+                const float4* hq = reinterpret_cast<const float4*>(sc.tri_attrs + rec.prim + (size_t)kp.hi * stride);
+                const float4 h0 = hq[0], h1 = hq[1], h2 = hq[2], h3 = hq[3];
+                na = key_lerp(kp.x, na, mk(h0.x, h0.y, h0.z)); nb = key_lerp(kp.x, nb, mk(h0.w, h1.x, h1.y)); nc = key_lerp(kp.x, nc, mk(h1.z, h1.w, h2.x));
+                ta = key_lerp(kp.x, ta, mk(h2.y, h2.z, 0.0f)); tb = key_lerp(kp.x, tb, mk(h2.w, h3.x, 0.0f)); tc = key_lerp(kp.x, tc, mk(h3.y, h3.z, 0.0f));
+            }
+        }
         float b1 = rec.b1, b2 = rec.b2;
         float b0 = 1.0f - b1 - b2;
         n = normalized(normalized(b0 * na + b1 * nb + b2 * nc));   // normalised in mesh.rs:172 AND in DifferentialGeometry::with_normal (differential_geometry.rs:51)

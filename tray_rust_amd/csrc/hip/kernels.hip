@@ -527,7 +527,10 @@ __global__ __launch_bounds__(TR_BLOCK) void k_sampler_pass(const DevScene scv, c
     const uint32_t kp = key_pixel(kf, py * sc.width + px);
     float sx, sy, t;
     uint32_t ks;
-    if (sp.kind == TRAY_SAMPLER_UNIFORM) {
+    if (sp.kind == TRAY_SAMPLER_LOW_DISCREPANCY) {                          // the tile kernel's samples, one thread each (scenes with an AnimatedMesh)
+        pixel_sample(kp, i, sp.count, px, py, sx, sy, t);
+        ks = key_sample(kp, i);
+    } else if (sp.kind == TRAY_SAMPLER_UNIFORM) {
         sx = (float)px + 0.5f; sy = (float)py + 0.5f;                      // uniform.rs:28
         t = (float)(draw(kp, PD_SCR_T) >> 8) / 16777216.0f;                // uniform.rs:42-46
         ks = key_sample(kp, 0u);
@@ -724,6 +727,7 @@ struct TrayDeviceScene {
     uint32_t* d_kind_queues = nullptr;   // WF_MAT_KINDS x n_slots slot indices
     uint32_t mat_kinds_present = 0;   // bit per TRAY_MAT_* kind among the scene's materials
     // tray_scene_set_sampler: which Sampler the render calls stand for, and the per-pixel state of k_sampler_pass / k_sampler_decide
+    bool deforming = false;           // the scene holds an AnimatedMesh: every render runs k_sampler_pass<3> (dev_geom.h: ANIM = 3), the debug kernels their <3> forms
     uint32_t sampler_kind = TRAY_SAMPLER_LOW_DISCREPANCY, smp_min = 1, smp_max = 1;
     void* d_smp = nullptr;            // [state u32 | running average f32 | luminances f32 x cap] per pixel of a batch of tiles
     size_t smp_bytes = 0;
@@ -927,6 +931,7 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
     if (!stack_ok(f->camera.xf_first, f->camera.xf_count, f->camera.animated != 0)) {
         set_error("camera keyframes: the device evaluates B-splines of degree <= 3 with consistent knot vectors"); return TRAY_E_UNSUPPORTED;
     }
+    bool deforming = false;
     bool moving = f->camera.animated != 0;
     for (uint32_t i = 0; i < f->n_instances; ++i) {
         const TrayInstance& in = f->instances[i];
@@ -936,9 +941,11 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         if (in.emis_count && (uint64_t)in.emis_first + in.emis_count > f->n_color_keys) { set_error("instance references missing colour keys"); return TRAY_E_INVALID; }
         moving = moving || in.animated != 0 || in.emis_count >= 2;
         if (in.kind != TRAY_INST_POINT_EMITTER && in.material_id >= f->n_materials) { set_error("instance references a missing material"); return TRAY_E_INVALID; }
-        if (in.geom_type == TRAY_GEOM_MESH && in.mesh_id >= f->n_meshes) { set_error("instance references a missing mesh"); return TRAY_E_INVALID; }
+        if ((in.geom_type == TRAY_GEOM_MESH || in.geom_type == TRAY_GEOM_ANIMATED_MESH) && in.mesh_id >= f->n_meshes) { set_error("instance references a missing mesh"); return TRAY_E_INVALID; }
+        if (in.geom_type == TRAY_GEOM_ANIMATED_MESH) { deforming = true; moving = true; }
     }
     TrayDeviceScene* s = new TrayDeviceScene();
+    s->deforming = deforming;
     s->identity = scene_identity(f);
     s->device = donor ? donor->device : g_device;
     s->donor = donor;
@@ -1018,6 +1025,8 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
     UPS(mesh_nodes, keep_trees ? f->mesh_nodes : paired.mesh.data(), n_paired)
     UPS(tri_verts, f->tri_verts, f->n_tris)
     UPS(tri_attrs, f->tri_attrs, f->n_tris)
+    UPS(mesh_keys, f->mesh_keys, f->n_mesh_keys)      // (AnimatedMesh: keyframe counts and times; read by the ANIM = 3 kernels only)
+    UPS(key_times, f->key_times, f->n_key_times)
     std::vector<DevMaterial> mats(f->n_materials);
     for (uint32_t i = 0; i < f->n_materials; ++i) {
         if (f->materials[i].kind == TRAY_MAT_MERL && f->materials[i].table >= f->n_merl) { rc = TRAY_E_INVALID; set_error("material references a missing MERL table"); }
@@ -1095,6 +1104,7 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         s->wavefront = f->n_instances > TR_FLAT_MAX;
         if (const char* m = getenv("TRAYHIP_MODE")) s->wavefront = std::string(m) == "wave";
         if (f->integrator == TRAY_INTEGRATOR_WHITTED) s->wavefront = false;   // the recursion runs inside the tile kernel only (dev_whitted.h)
+        if (s->deforming) s->wavefront = false;   // (k_sampler_pass<3> renders these scenes: launch_tiles)
     }
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
     d.fpw = f->film.filter_pixel_w; d.fph = f->film.filter_pixel_h;
@@ -1169,7 +1179,7 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
                     uint32_t need = (dep - 1) + (nd.count - 1 - j);
                     if (nd.offset + j < f->n_top_order) {
                         const TrayInstance& in = f->instances[f->top_order[nd.offset + j]];
-                        if (in.geom_type == TRAY_GEOM_MESH && in.mesh_id < f->n_meshes) need += 1 + (mesh_depths[in.mesh_id] > 0 ? mesh_depths[in.mesh_id] - 1 : 0);
+                        if ((in.geom_type == TRAY_GEOM_MESH || in.geom_type == TRAY_GEOM_ANIMATED_MESH) && in.mesh_id < f->n_meshes) need += 1 + (mesh_depths[in.mesh_id] > 0 ? mesh_depths[in.mesh_id] - 1 : 0);
                     }
                     worst = std::max(worst, need);
                 }
@@ -1214,7 +1224,8 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
                 reinterpret_cast<const void*>(k_wf_trace_fallback<2, 0>), reinterpret_cast<const void*>(k_wf_trace_fallback<2, 1>),
                 reinterpret_cast<const void*>(k_debug_intersect<0>), reinterpret_cast<const void*>(k_debug_intersect<2>),
                 reinterpret_cast<const void*>(k_debug_sample_radiance<0>), reinterpret_cast<const void*>(k_debug_sample_radiance<2>),
-                reinterpret_cast<const void*>(k_sampler_pass<0>), reinterpret_cast<const void*>(k_sampler_pass<2>)};
+                reinterpret_cast<const void*>(k_sampler_pass<0>), reinterpret_cast<const void*>(k_sampler_pass<2>), reinterpret_cast<const void*>(k_sampler_pass<3>),
+                reinterpret_cast<const void*>(k_debug_intersect<3>), reinterpret_cast<const void*>(k_debug_sample_radiance<3>)};
             for (const void* k : traversing) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipGetLastError();
         }
@@ -1509,11 +1520,13 @@ int tray_render_shard_device(TrayDeviceScene* s, uint32_t shard, uint32_t n_shar
 // thread_work with sampler::Uniform / sampler::Adaptive (include/trayhip.h: tray_scene_set_sampler): rounds of k_sampler_pass (+
 // k_sampler_decide) over batches of tiles, all on `stream`, no host synchronisation -- a pixel that is finished sits out the later rounds.
 static int launch_sampler(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride,
-                          uint32_t kf, float* rgbw_dev, hipStream_t stream) {
+                          uint32_t spp, uint32_t kf, float* rgbw_dev, hipStream_t stream) {
     SamplerPass sp{};
     sp.kind = s->sampler_kind; sp.min_spp = s->smp_min; sp.max_spp = s->smp_max;
     uint32_t rounds = 1;
-    if (sp.kind == TRAY_SAMPLER_ADAPTIVE) {
+    if (sp.kind == TRAY_SAMPLER_LOW_DISCREPANCY) {   // (scenes with an AnimatedMesh: LowDiscrepancy::get_samples hands out all spp samples of a pixel at once, ld.rs:33-52)
+        sp.min_spp = sp.max_spp = spp; sp.step = 1u; sp.lum_cap = 0u;
+    } else if (sp.kind == TRAY_SAMPLER_ADAPTIVE) {
         sp.step = tray_adaptive_step(sp.min_spp, sp.max_spp);
         while (sp.min_spp + (rounds - 1u) * sp.step < sp.max_spp) ++rounds;     // get_samples until samples_taken >= max_spp (adaptive.rs:136)
         sp.lum_cap = sp.min_spp + (rounds - 1u) * sp.step;
@@ -1539,11 +1552,12 @@ static int launch_sampler(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile
         if (sp.kind == TRAY_SAMPLER_ADAPTIVE) HIP_CHECK(hipMemsetAsync(s->d_smp, 0, (size_t)batch * 64u * 8u, stream));   // states and averages
         for (uint32_t j = 0; j < rounds; ++j) {
             sp.pass = j;
-            sp.count = sp.kind == TRAY_SAMPLER_ADAPTIVE ? (j == 0u ? sp.min_spp : sp.step) : 1u;
+            sp.count = sp.kind == TRAY_SAMPLER_ADAPTIVE ? (j == 0u ? sp.min_spp : sp.step) : sp.min_spp;   // (Uniform: 1, LowDiscrepancy: spp)
             sp.taken = sp.kind == TRAY_SAMPLER_ADAPTIVE ? sp.min_spp + j * sp.step : 0u;
             sp.before = j == 0u ? 0u : sp.min_spp + (j - 1u) * sp.step;
             const dim3 grid((uint32_t)(((size_t)n_px * sp.count + TR_BLOCK - 1) / TR_BLOCK)), block(TR_BLOCK);
-            if (s->animated) hipLaunchKernelGGL(k_sampler_pass<2>, grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats);
+            if (s->deforming) hipLaunchKernelGGL(k_sampler_pass<3>, grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats);
+            else if (s->animated) hipLaunchKernelGGL(k_sampler_pass<2>, grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats);
             else hipLaunchKernelGGL(k_sampler_pass<0>, grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats);
             ++launches;
             if (sp.kind == TRAY_SAMPLER_ADAPTIVE) {
@@ -1577,7 +1591,7 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
     kf = mix(kf ^ (uint32_t)(seed >> 32));
     kf = mix(kf + s->dev.frame);
-    if (s->sampler_kind != TRAY_SAMPLER_LOW_DISCREPANCY) return launch_sampler(s, tile_start, tile_count, chunk, chunk_stride, kf, rgbw_dev, stream);
+    if (s->sampler_kind != TRAY_SAMPLER_LOW_DISCREPANCY || s->deforming) return launch_sampler(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
     if (s->wavefront) return launch_wavefront(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
     // Slices per tile. A slice costs its own film resolve and flush, so tiles are only halved (quartered) when a launch has fewer than
     // 12 (3) of them per workgroup and a slice keeps >= 256 samples per pixel -- measured on one GPU's share of C2 at 8 GPUs (4050
@@ -1877,7 +1891,8 @@ int tray_debug_intersect(TrayDeviceScene* s, uint32_t n, const TrayRay* rays, Tr
     if (e == hipSuccess) e = hipMemcpy(d_r, rays, n * sizeof(TrayRay), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         // ANIM = 2: debug grids are sized by the item count, not by the transform cache, so the spline stacks are evaluated at every use
-        if (s->animated) hipLaunchKernelGGL(k_debug_intersect<2>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_r, d_h);
+        if (s->deforming) hipLaunchKernelGGL(k_debug_intersect<3>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_r, d_h);
+        else if (s->animated) hipLaunchKernelGGL(k_debug_intersect<2>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_r, d_h);
         else hipLaunchKernelGGL(k_debug_intersect<0>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_r, d_h);
         e = hipGetLastError();
     }
@@ -1908,7 +1923,9 @@ int tray_debug_sample_radiance(TrayDeviceScene* s, uint32_t n, const uint32_t* p
         uint32_t kf = mix((uint32_t)seed + 0x9E3779B9u);
         kf = mix(kf ^ (uint32_t)(seed >> 32));
         kf = mix(kf + s->dev.frame);
-        if (s->animated)
+        if (s->deforming)
+            hipLaunchKernelGGL(k_debug_sample_radiance<3>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
+        else if (s->animated)
             hipLaunchKernelGGL(k_debug_sample_radiance<2>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);
         else
             hipLaunchKernelGGL(k_debug_sample_radiance<0>, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), s->stack_bytes, 0, s->dev, n, d_in, d_in + n, d_in + 2 * (size_t)n, spp, kf, d_out);

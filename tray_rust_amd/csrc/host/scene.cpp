@@ -115,8 +115,11 @@ struct HostMesh {
     std::string key;   // file + '\n' + model
     std::string file, model;   // build_meshes() fills bvh / verts / attrs after the whole scene is parsed
     BvhBuild bvh;
-    std::vector<TrayTriVerts> verts;   // leaf order
+    std::vector<TrayTriVerts> verts;   // leaf order; an AnimatedMesh: keyframe after keyframe, each in the leaf order of the ONE tree
     std::vector<TrayTriAttrs> attrs;
+    // AnimatedMesh (geometry/animated_mesh.rs): `file` is the first keyframe's; every keyframe's file and time, ascending
+    std::vector<std::string> key_files;
+    std::vector<float> key_times;
 };
 
 struct HostInstance {
@@ -170,6 +173,8 @@ struct TrayHostScene {
     std::vector<TrayMesh> f_meshes;
     std::vector<TrayTriVerts> f_verts;
     std::vector<TrayTriAttrs> f_attrs;
+    std::vector<TrayMeshKeys> f_mesh_keys;
+    std::vector<float> f_key_times;
     std::vector<TrayXformLevel> f_levels;
     std::vector<TrayKeyframe> f_keyframes;
     std::vector<float> f_knots;
@@ -745,6 +750,76 @@ static uint32_t get_mesh(TrayHostScene& s, const std::string& file, const std::s
     return (uint32_t)s.meshes.size() - 1;
 }
 
+// an AnimatedMesh request (animated_mesh.rs:14-27: "model" + "keyframes": [{"file", "time"}, ...]); two requests with the same files, times
+// and model share one
+static uint32_t get_animated_mesh(TrayHostScene& s, const std::vector<std::string>& files, const std::vector<float>& times, const std::string& model) {
+    std::string key = "animated\n" + model;
+    for (size_t k = 0; k < files.size(); ++k) { key += "\n" + files[k] + "@"; key.append(reinterpret_cast<const char*>(&times[k]), sizeof(float)); }
+    for (size_t i = 0; i < s.meshes.size(); ++i)
+        if (s.meshes[i].key == key) return (uint32_t)i;
+    HostMesh hm;
+    hm.key = key; hm.file = files[0]; hm.model = model; hm.key_files = files; hm.key_times = times;
+    s.meshes.push_back(std::move(hm));
+    return (uint32_t)s.meshes.size() - 1;
+}
+
+static const ObjModel& find_model(const std::vector<ObjModel>& models, const std::string& model, const std::string& file) {
+    for (auto& m : models) {
+        if (m.normals.empty() || m.texcoords.empty()) continue;   // mesh.rs:57-61: skipped
+        if (m.name == model) {
+            if (m.normals.size() / 3 != m.positions.size() / 3 || m.texcoords.size() / 2 != m.positions.size() / 3)
+                fail(TRAY_E_PARSE, "model '" + model + "' mixes vertices with and without normals/texcoords");
+            return m;
+        }
+    }
+    fail(TRAY_E_INVALID, "Requested model '" + model + "' was not found in \"" + file + "\"");
+}
+
+// AnimatedMesh::new (animated_mesh.rs:113-127) over the keyframes' Meshes (Mesh::load_obj each, mesh.rs:44-78): the triangles are
+// meshes[0]'s -- its index triples, in file order (BVH::iter walks `geometry`, bvh.rs:131-133) -- and every keyframe contributes its
+// positions / normals / texcoords by vertex index. ONE tree: BVH::new(16, tris, times[0], times[1]) over AnimatedTriangle::bounds
+// (animated_mesh.rs:176-185): the triangle's vertices at times[0] and at times[1] -- exactly keyframes 0 and 1 (position() at a keyframe's
+// own time returns that keyframe's vertex, :73-76).
+static void build_animated_mesh(HostMesh& hm, const std::vector<const std::vector<ObjModel>*>& per_key) {
+    const size_t n_keys = hm.key_files.size();
+    std::vector<const ObjModel*> km(n_keys);
+    for (size_t k = 0; k < n_keys; ++k) km[k] = &find_model(*per_key[k], hm.model, hm.key_files[k]);
+    const ObjModel& m0 = *km[0];
+    const size_t ntri = m0.indices.size() / 3, nvert = m0.positions.size() / 3;
+    for (size_t k = 1; k < n_keys; ++k)   // ("the topology of the mesh being animated does not change", animated_mesh.rs:1-3: the reference would index out of bounds)
+        if (km[k]->positions.size() / 3 != nvert)
+            fail(TRAY_E_INVALID, "animated mesh '" + hm.model + "': keyframe \"" + hm.key_files[k] + "\" has " + std::to_string(km[k]->positions.size() / 3) +
+                                     " vertices, the first keyframe " + std::to_string(nvert));
+    std::vector<BBox> bounds(ntri);
+    auto P = [&](size_t k, uint32_t i) { return V3(km[k]->positions[3 * i], km[k]->positions[3 * i + 1], km[k]->positions[3 * i + 2]); };
+    for (size_t t = 0; t < ntri; ++t) {
+        const uint32_t ia = m0.indices[3 * t], ib = m0.indices[3 * t + 1], ic = m0.indices[3 * t + 2];
+        bounds[t] = BBox(P(0, ia), P(0, ia)).point_union(P(0, ib)).point_union(P(0, ic)).point_union(P(1, ia)).point_union(P(1, ib)).point_union(P(1, ic));
+    }
+    hm.bvh = build_bvh(bounds, 16);
+    hm.verts.resize(n_keys * ntri);
+    hm.attrs.resize(n_keys * ntri);
+    for (size_t k = 0; k < n_keys; ++k) {
+        const ObjModel& m = *km[k];
+        for (size_t slot = 0; slot < ntri; ++slot) {
+            const uint32_t t = hm.bvh.ordered[slot];
+            TrayTriVerts& tv = hm.verts[k * ntri + slot];
+            TrayTriAttrs& ta = hm.attrs[k * ntri + slot];
+            std::memset(&tv, 0, sizeof tv);
+            std::memset(&ta, 0, sizeof ta);
+            tv.tri_id = t;
+            const uint32_t ia = m0.indices[3 * t], ib = m0.indices[3 * t + 1], ic = m0.indices[3 * t + 2];
+            for (int c = 0; c < 3; ++c) {
+                tv.pa[c] = m.positions[3 * ia + c]; tv.pb[c] = m.positions[3 * ib + c]; tv.pc[c] = m.positions[3 * ic + c];
+                ta.na[c] = m.normals[3 * ia + c]; ta.nb[c] = m.normals[3 * ib + c]; ta.nc[c] = m.normals[3 * ic + c];
+            }
+            for (int c = 0; c < 2; ++c) {
+                ta.ta[c] = m.texcoords[2 * ia + c]; ta.tb[c] = m.texcoords[2 * ib + c]; ta.tc[c] = m.texcoords[2 * ic + c];
+            }
+        }
+    }
+}
+
 // Mesh::load_obj + BVH::unanimated for one (file, model) request (mesh.rs:44-78)
 static void build_mesh(HostMesh& hm, const std::vector<ObjModel>& models) {
     const ObjModel* found = nullptr;
@@ -786,8 +861,11 @@ static void build_mesh(HostMesh& hm, const std::vector<ObjModel>& models) {
 // cores: the results do not depend on the schedule, each mesh is built from its own model alone.
 static void build_meshes(TrayHostScene& s) {
     std::vector<std::string> files;
-    for (auto& hm : s.meshes)
+    for (auto& hm : s.meshes) {
         if (std::find(files.begin(), files.end(), hm.file) == files.end()) files.push_back(hm.file);
+        for (auto& kf : hm.key_files)
+            if (std::find(files.begin(), files.end(), kf) == files.end()) files.push_back(kf);
+    }
     std::vector<std::vector<ObjModel>> parsed(files.size());
     struct Err { int code = TRAY_OK; std::string msg; };
     std::vector<Err> file_err(files.size()), mesh_err(s.meshes.size());
@@ -808,7 +886,13 @@ static void build_meshes(TrayHostScene& s) {
     run(s.meshes.size(), [&](size_t i) {
         size_t fi = (size_t)(std::find(files.begin(), files.end(), s.meshes[i].file) - files.begin());
         if (file_err[fi].code != TRAY_OK) { mesh_err[i] = file_err[fi]; return; }
-        try { build_mesh(s.meshes[i], parsed[fi]); }
+        std::vector<const std::vector<ObjModel>*> per_key;
+        for (auto& kf : s.meshes[i].key_files) {
+            const size_t ki = (size_t)(std::find(files.begin(), files.end(), kf) - files.begin());
+            if (file_err[ki].code != TRAY_OK) { mesh_err[i] = file_err[ki]; return; }
+            per_key.push_back(&parsed[ki]);
+        }
+        try { if (per_key.empty()) build_mesh(s.meshes[i], parsed[fi]); else build_animated_mesh(s.meshes[i], per_key); }
         catch (const LoadError& e) { mesh_err[i].code = e.code; mesh_err[i].msg = e.what(); }
         catch (const std::exception& e) { mesh_err[i].code = TRAY_E_PARSE; mesh_err[i].msg = e.what(); }
     });
@@ -839,6 +923,23 @@ static void load_geometry(TrayHostScene& s, const Json& e, const std::string& ba
         const std::string& model = need_str(e, "model", "A model name is required for geometry", "Model name type must be a string");
         inst.geom_type = TRAY_GEOM_MESH;
         inst.mesh_id = get_mesh(s, join_path(base, file), model);
+    } else if (ty == "animated_mesh" && !sampleable) {
+        // geometry/animated_mesh.rs:14-27 documents this entry; scene.rs:588-628 has no branch that reads it, so the
+        // messages are this loader's
+        const std::string& model = need_str(e, "model", "A model name is required for geometry", "Model name type must be a string");
+        const Json& kfs = need(e, "keyframes", "Keyframes are required for an animated mesh");
+        if (!kfs.is_array()) fail(TRAY_E_PARSE, "The keyframes of an animated mesh must be an array");
+        std::vector<std::string> files;
+        std::vector<float> times;
+        for (const Json& k : kfs.arr) {
+            files.push_back(join_path(base, need_str(k, "file", "An OBJ file is required for every keyframe of an animated mesh", "OBJ filename must be a string")));
+            times.push_back(need_f32(k, "time", "A time is required for every keyframe of an animated mesh", "keyframe time must be a number"));
+        }
+        if (files.size() < 2) fail(TRAY_E_INVALID, "An animated mesh needs at least two keyframes (AnimatedMesh::new reads times[1], animated_mesh.rs:125)");
+        for (size_t k = 1; k < times.size(); ++k)   // "It's assumed the meshes are sorted in ascending time" (animated_mesh.rs:112): binary_search_by needs it
+            if (!(times[k] > times[k - 1])) fail(TRAY_E_INVALID, "The keyframes of an animated mesh must be in ascending time");
+        inst.geom_type = TRAY_GEOM_ANIMATED_MESH;
+        inst.mesh_id = get_animated_mesh(s, files, times, model);
     } else if (sampleable) {
         fail(TRAY_E_INVALID, "Geometry of type '" + ty + "' is not sampleable and can't be used for area light geometry");
     } else {
@@ -962,7 +1063,8 @@ static BBox geom_bounds(const TrayHostScene& s, const HostInstance& inst) {
             float hw = inst.geom_params[0] / 2.0f, hh = inst.geom_params[1] / 2.0f;
             return BBox(V3(-hw, -hh, 0.0f), V3(hw, hh, 0.0f));
         }
-        case TRAY_GEOM_MESH: {   // BVH::bounds = root node bounds
+        case TRAY_GEOM_ANIMATED_MESH:   // AnimatedMesh::bounds = self.bvh.bounds (animated_mesh.rs:136-138): the tree of times[0] .. times[1], whatever the frame (quirk Q13)
+        case TRAY_GEOM_MESH: {   // BVH::bounds = root node bounds (bvh.rs:270-274)
             const TrayBvhNode& n = s.meshes[inst.mesh_id].bvh.nodes[0];
             return BBox(V3(n.bmin[0], n.bmin[1], n.bmin[2]), V3(n.bmax[0], n.bmax[1], n.bmax[2]));
         }
@@ -1089,6 +1191,7 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
         ti.animated = hi.xf.varies_over(shutter_open, shutter_close) ? 1u : 0u;
         ti.moving_slot = 0xffffffffu;
         if (ti.animated) { any_animated = true; ti.moving_slot = n_moving++; }
+        if (hi.geom_type == TRAY_GEOM_ANIMATED_MESH) any_animated = true;   // its vertices are functions of ray.time (animated_mesh.rs:160-172), open shutter or not
         Xform t = hi.xf.transform(shutter_open);
         std::memcpy(ti.mat, t.mat.m, sizeof ti.mat);
         std::memcpy(ti.inv, t.inv.m, sizeof ti.inv);
@@ -1103,11 +1206,17 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
     s.f_top_order = top.ordered;
 
     // Meshes
-    s.f_meshes.clear(); s.f_mesh_nodes.clear(); s.f_verts.clear(); s.f_attrs.clear();
+    s.f_meshes.clear(); s.f_mesh_nodes.clear(); s.f_verts.clear(); s.f_attrs.clear(); s.f_mesh_keys.clear(); s.f_key_times.clear();
+    bool any_keys = false;
     for (auto& m : s.meshes) {
         TrayMesh tm{};
+        const size_t n_keys = std::max<size_t>(m.key_times.size(), 1);
+        TrayMeshKeys mk{(uint32_t)n_keys, (uint32_t)s.f_key_times.size()};
+        s.f_key_times.insert(s.f_key_times.end(), m.key_times.begin(), m.key_times.end());
+        s.f_mesh_keys.push_back(mk);
+        any_keys = any_keys || n_keys > 1;
         tm.node_offset = (uint32_t)s.f_mesh_nodes.size(); tm.node_count = (uint32_t)m.bvh.nodes.size();
-        tm.tri_offset = (uint32_t)s.f_verts.size(); tm.tri_count = (uint32_t)m.verts.size();
+        tm.tri_offset = (uint32_t)s.f_verts.size(); tm.tri_count = (uint32_t)(m.verts.size() / n_keys);
         s.f_mesh_nodes.insert(s.f_mesh_nodes.end(), m.bvh.nodes.begin(), m.bvh.nodes.end());
         s.f_verts.insert(s.f_verts.end(), m.verts.begin(), m.verts.end());
         s.f_attrs.insert(s.f_attrs.end(), m.attrs.begin(), m.attrs.end());
@@ -1120,6 +1229,8 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
     f.n_meshes = (uint32_t)s.f_meshes.size(); f.meshes = s.f_meshes.data();
     f.n_mesh_nodes = (uint32_t)s.f_mesh_nodes.size(); f.mesh_nodes = s.f_mesh_nodes.data();
     f.n_tris = (uint32_t)s.f_verts.size(); f.tri_verts = s.f_verts.data(); f.tri_attrs = s.f_attrs.data();
+    f.n_mesh_keys = any_keys ? (uint32_t)s.f_mesh_keys.size() : 0u; f.mesh_keys = any_keys ? s.f_mesh_keys.data() : nullptr;
+    f.n_key_times = (uint32_t)s.f_key_times.size(); f.key_times = s.f_key_times.data();
     f.n_materials = (uint32_t)s.materials.size(); f.materials = s.materials.data();
     f.n_textures = (uint32_t)s.textures.size(); f.textures = s.textures.data();
     f.n_tex_frames = (uint32_t)s.tex_frames.size(); f.tex_frames = s.tex_frames.data();

@@ -34,8 +34,10 @@ inline std::string validate_flat_scene(const TrayFlatScene* f) {
         !need(f->meshes, f->n_meshes) || !need(f->mesh_nodes, f->n_mesh_nodes) || !need(f->tri_verts, f->n_tris) ||
         !need(f->tri_attrs, f->n_tris) || !need(f->materials, f->n_materials) || !need(f->merl_tables, f->n_merl) ||
         !need(f->merl_data, f->n_merl_floats) || !need(f->lights, f->n_lights) || !need(f->xf_levels, f->n_xf_levels) ||
-        !need(f->keyframes, f->n_keyframes) || !need(f->knots, f->n_knots) || !need(f->color_keys, f->n_color_keys))
+        !need(f->keyframes, f->n_keyframes) || !need(f->knots, f->n_knots) || !need(f->color_keys, f->n_color_keys) ||
+        !need(f->mesh_keys, f->n_mesh_keys) || !need(f->key_times, f->n_key_times))
         return "an array with a non-zero count is null";
+    if (f->n_mesh_keys != 0 && f->n_mesh_keys != f->n_meshes) return "mesh_keys must have one entry per mesh (or none)";
     if (f->n_instances == 0) return "the scene has no instances";
     if (f->min_depth > f->max_depth) return "integrator min_depth > max_depth";
     // BVH<Instance>
@@ -46,7 +48,17 @@ inline std::string validate_flat_scene(const TrayFlatScene* f) {
     // meshes and their BVH<Triangle>
     for (uint32_t m = 0; m < f->n_meshes; ++m) {
         const TrayMesh& me = f->meshes[m];
-        if ((uint64_t)me.node_offset + me.node_count > f->n_mesh_nodes || (uint64_t)me.tri_offset + me.tri_count > f->n_tris)
+        const uint64_t n_keys = f->n_mesh_keys ? f->mesh_keys[m].n_keys : 1u;   // (keyframe k of the mesh: tri_offset + k * tri_count)
+        if (f->n_mesh_keys) {
+            const TrayMeshKeys& mk = f->mesh_keys[m];
+            if (mk.n_keys == 0) return "mesh " + std::to_string(m) + " has no keyframe";
+            if (mk.n_keys > 1) {
+                if ((uint64_t)mk.time_first + mk.n_keys > f->n_key_times) return "mesh " + std::to_string(m) + " refers to keyframe times outside key_times";
+                for (uint32_t k = 1; k < mk.n_keys; ++k)
+                    if (!(f->key_times[mk.time_first + k] > f->key_times[mk.time_first + k - 1])) return "mesh " + std::to_string(m) + ": keyframe times must ascend";
+            }
+        }
+        if ((uint64_t)me.node_offset + me.node_count > f->n_mesh_nodes || (uint64_t)me.tri_offset + n_keys * me.tri_count > f->n_tris)
             return "mesh " + std::to_string(m) + " refers to nodes or triangles outside the arrays";
         if (me.node_count == 0 || me.tri_count == 0) return "mesh " + std::to_string(m) + " is empty";
         if (std::string e = validate_bvh(f->mesh_nodes + me.node_offset, me.node_count, me.tri_count, 16u, "BVH<Triangle>"); !e.empty())
@@ -87,10 +99,15 @@ inline std::string validate_flat_scene(const TrayFlatScene* f) {
         if (in.kind == TRAY_INST_POINT_EMITTER) {
             if (in.geom_type != TRAY_GEOM_NONE) return who + ": a point emitter has no geometry";
         } else {
-            if (in.geom_type > TRAY_GEOM_MESH) return who + " has an unknown geometry type";
+            const bool any_mesh = in.geom_type == TRAY_GEOM_MESH || in.geom_type == TRAY_GEOM_ANIMATED_MESH;
+            if (in.geom_type > TRAY_GEOM_MESH && in.geom_type != TRAY_GEOM_ANIMATED_MESH) return who + " has an unknown geometry type";
             if (in.material_id >= f->n_materials) return "instance references a missing material";
-            if (in.geom_type == TRAY_GEOM_MESH && in.mesh_id >= f->n_meshes) return "instance references a missing mesh";
-            if (in.kind == TRAY_INST_AREA_EMITTER && in.geom_type == TRAY_GEOM_MESH) return who + ": area lights are spheres, disks or rectangles (scene.rs:584-654)";
+            if (any_mesh && in.mesh_id >= f->n_meshes) return "instance references a missing mesh";
+            if (in.kind == TRAY_INST_AREA_EMITTER && any_mesh) return who + ": area lights are spheres, disks or rectangles (scene.rs:584-654)";
+            // a Mesh has one keyframe, an AnimatedMesh at least two (AnimatedMesh::new reads times[1], animated_mesh.rs:125)
+            const uint32_t n_keys = any_mesh && f->n_mesh_keys ? f->mesh_keys[in.mesh_id].n_keys : 1u;
+            if (in.geom_type == TRAY_GEOM_MESH && n_keys != 1u) return who + ": a mesh instance refers to an animated mesh's triangles";
+            if (in.geom_type == TRAY_GEOM_ANIMATED_MESH && n_keys < 2u) return who + ": an animated mesh needs at least two keyframes";
         }
         if (!stack_in_range(in.xf_first, in.xf_count)) return who + " refers to spline levels outside xf_levels";
         if (in.emis_count && (uint64_t)in.emis_first + in.emis_count > f->n_color_keys) return "instance references missing colour keys";

@@ -559,6 +559,66 @@ def write_textured_box(directory, **kw):
     return write_scene(textured_box(**kw), os.path.join(directory, "textured_box.json"))
 
 
+# ---- AnimatedMesh (geometry/animated_mesh.rs): no scene of the reference uses one (its loader cannot construct it); this is the test scene
+def flag_obj(grid, phase, amplitude=1.5, size=12.0):
+    """a (grid x grid)-quad sheet in the xy plane, z = amplitude * sin(2 pi x / size + phase) * (x - x0) / size: the same topology for every
+    phase, analytic normals, texcoords = the sheet's parameters"""
+    import math
+    lines = ["o Flag"]
+    pos, nrm, tex = [], [], []
+    for j in range(grid + 1):
+        for i in range(grid + 1):
+            u, v = i / grid, j / grid
+            x, y = (u - 0.5) * size, (v - 0.5) * size
+            k = 2.0 * math.pi / size
+            z = amplitude * math.sin(k * x + phase) * u
+            dz_dx = amplitude * (k * math.cos(k * x + phase) * u + math.sin(k * x + phase) / size)
+            n = (-dz_dx, 0.0, 1.0)
+            ln = math.sqrt(n[0] ** 2 + 1.0)
+            pos.append((x, y, z)); nrm.append((n[0] / ln, 0.0, 1.0 / ln)); tex.append((u, v))
+    lines += ["v %.6f %.6f %.6f" % p_ for p_ in pos]
+    lines += ["vt %.6f %.6f" % t_ for t_ in tex]
+    lines += ["vn %.6f %.6f %.6f" % n_ for n_ in nrm]
+    for j in range(grid):
+        for i in range(grid):
+            a_ = j * (grid + 1) + i + 1
+            b_, c_, d_ = a_ + 1, a_ + grid + 2, a_ + grid + 1
+            lines.append("f " + " ".join("%d/%d/%d" % (q, q, q) for q in (a_, b_, c_, d_)))
+    return "\n".join(lines) + "\n"
+
+
+def waving_flag(width=160, height=120, samples=16, frames=8, scene_time=2.0, shutter_size=0.5, n_keys=4, times=None):
+    """Cornell walls, the disk light, and a sheet that waves: an "animated_mesh" (animated_mesh.rs:14-27) of n_keys keyframes spread over
+    the scene's time, under a static transform; a mirror ball so that paths meet the sheet from both sides."""
+    d = cornell_box(width, height, samples)
+    d["film"].update({"frames": frames, "start_frame": 0, "end_frame": frames - 1, "scene_time": scene_time})
+    d["camera"] = {"fov": 30, "shutter_size": shutter_size, "transform": [_t(0, 12, -60)]}
+    d["materials"] += [{"type": "metal", "name": "metal", "refractive_index": [0.155265, 0.116723, 0.138381],
+                        "absorption_coefficient": [4.82835, 3.12225, 2.14696], "roughness": 0.2}]
+    if times is None:
+        times = [scene_time * k / (n_keys - 1) for k in range(n_keys)]
+    walls = d["objects"][0]
+    light = [o for o in d["objects"] if o.get("type") == "emitter"][0]
+    flag = {"name": "flag", "type": "receiver", "material": "white_plastic",
+            "geometry": {"type": "animated_mesh", "model": "Flag",
+                         "keyframes": [{"file": "models/flag_%d.obj" % k, "time": times[k]} for k in range(n_keys)]},
+            "transform": [_ry(25), _t(-1, 11, 4)]}
+    ball = {"name": "ball", "type": "receiver", "material": "metal", "geometry": {"type": "sphere", "radius": 3.0}, "transform": [_t(7, 3, -4)]}
+    d["objects"] = [walls, light, flag, ball]
+    return d
+
+
+def write_waving_flag(directory, grid=12, n_keys=4, **kw):
+    import math
+    os.makedirs(os.path.join(directory, "models"), exist_ok=True)
+    with open(os.path.join(directory, "models", "cube.obj"), "w") as f:
+        f.write(cube_obj())
+    for k in range(n_keys):
+        with open(os.path.join(directory, "models", "flag_%d.obj" % k), "w") as f:
+            f.write(flag_obj(grid, 2.0 * math.pi * k / n_keys))
+    return write_scene(waving_flag(n_keys=n_keys, **kw), os.path.join(directory, "waving_flag.json"))
+
+
 def write_scene(scene, path):
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
