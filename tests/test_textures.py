@@ -159,13 +159,97 @@ def test_jpeg_decoder_against_pillow_written_files(kind, tmp_path, built):
     assert d.max() <= 3 and (d <= 1).mean() > 0.93 and d.mean() < 0.5
 
 
-def test_progressive_jpeg_is_refused_with_a_message(tmp_path, built):
+@pytest.mark.parametrize("kind", ["420", "444", "grey", "420_restart", "odd_size_q40"])
+def test_progressive_jpeg_decoder_against_pillow_written_files(kind, tmp_path, built):
+    """SOF2 files (T.81 Annex G: libjpeg's default progression -- DC first with successive approximation, AC bands per component, AC and DC
+    refinement scans with end-of-band runs): collected scan by scan, transformed once. Same bars as the baseline test, and the SAME pixels as
+    this decoder's own baseline decoding of the same picture at the same quality (a progressive file holds the same coefficients)."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(12)
+    w, h = (37, 29) if kind == "odd_size_q40" else (64, 48)
+    yy, xx = np.mgrid[0:h, 0:w]
+    pix = np.stack([128 + 100 * np.sin(xx / 5.0) * np.cos(yy / 7.0), 128 + 90 * np.cos(xx / 3.0 + yy / 11.0), 40 + 3 * xx + 2 * yy], axis=2)
+    pix = np.clip(pix + rng.normal(0, 6, pix.shape), 0, 255).astype(np.uint8)
+    os.makedirs(tmp_path / "textures", exist_ok=True)
+    prog, base = str(tmp_path / "textures" / "p.jpg"), str(tmp_path / "textures" / "b.jpg")
+    if kind == "grey":
+        img, kw = Image.fromarray(pix[..., 0], "L"), dict(quality=90)
+    else:
+        img, kw = Image.fromarray(pix, "RGB"), dict(quality=40 if kind == "odd_size_q40" else 92, subsampling=0 if kind == "444" else 2)
+        if kind == "420_restart":
+            kw["restart_marker_blocks"] = 2
+    img.save(prog, progressive=True, **kw)
+    img.save(base, **kw)
+    data = open(prog, "rb").read()
+    assert b"\xff\xc2" in data[:800] and data.count(b"\xff\xda") >= (6 if kind == "grey" else 8)      # SOF2 and many scans
+    ref = np.asarray(Image.open(prog).convert("RGB"), np.int32)
+    scene, *_ = load_texture_scene(tmp_path, [{"name": "p", "type": "image", "file": "textures/p.jpg"}, {"name": "b", "type": "image", "file": "textures/b.jpg"}])
+    fs = scene.flatten(0).contents
+    got, fr = frame_pixels(fs, 0)
+    same, _ = frame_pixels(fs, 1)
+    assert (fr.width, fr.height) == (w, h) and (got[..., 3] == 255).all()
+    d = np.abs(got[..., :3].astype(np.int32) - ref)
+    print(kind, "max", d.max(), "share within 1:", (d <= 1).mean(), "mean", d.mean())
+    assert d.max() <= 3 and (d <= 1).mean() > 0.93 and d.mean() < 0.5
+    assert np.array_equal(got, same)
+
+
+def test_lossless_and_arithmetic_jpeg_are_refused_with_a_message(tmp_path, built):
     Image = pytest.importorskip("PIL.Image")
     os.makedirs(tmp_path / "textures", exist_ok=True)
-    Image.fromarray(np.zeros((16, 16, 3), np.uint8), "RGB").save(str(tmp_path / "textures" / "p.jpg"), progressive=True)
+    p = str(tmp_path / "textures" / "a.jpg")
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8), "RGB").save(p)
+    data = bytearray(open(p, "rb").read())
+    i = data.index(b"\xff\xc0")
+    data[i + 1] = 0xc9      # SOF9: extended sequential, arithmetic coding
+    open(p, "wb").write(bytes(data))
     with pytest.raises(T.TrayError) as e:
-        load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/p.jpg"}])
-    assert "progressive" in str(e.value)
+        load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/a.jpg"}])
+    assert "arithmetic" in str(e.value) and "a.jpg" in str(e.value)
+
+
+@pytest.mark.parametrize("kind", ["plain", "interlaced", "transparent", "local_table_2_colours", "noise_full_table"])
+def test_gif_first_frame(kind, tmp_path, built):
+    """image::open of a .gif: the first frame as RGBA -- palette lookup, the transparent index as alpha 0, interlaced rows put back, LZW with
+    table resets (a noisy 256-colour picture fills the 4096-entry table several times). Against Pillow's decoding of the same file."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    w, h = (97, 61) if kind == "noise_full_table" else (33, 21)
+    if kind == "local_table_2_colours":
+        idx = (rng.integers(0, 2, (h, w))).astype(np.uint8)
+        pal = [10, 20, 30, 200, 180, 40]
+    elif kind == "noise_full_table":
+        idx = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        pal = list(rng.integers(0, 256, 768))
+    else:
+        yy, xx = np.mgrid[0:h, 0:w]
+        idx = ((xx // 3 + yy // 2) % 7).astype(np.uint8)
+        pal = list(rng.integers(0, 256, 21))
+    im = Image.fromarray(idx, "P")
+    im.putpalette([int(v) for v in pal] + [0] * (768 - len(pal)))
+    os.makedirs(tmp_path / "textures", exist_ok=True)
+    path = str(tmp_path / "textures" / "x.gif")
+    kw = {}
+    if kind == "interlaced":
+        kw["interlace"] = 1
+    if kind == "transparent":
+        kw["transparency"] = 3
+    frames = [Image.fromarray(((idx + 1) % 5).astype(np.uint8), "P")]      # a second frame that must be ignored
+    frames[0].putpalette([int(v) for v in pal] + [0] * (768 - len(pal)))
+    im.save(path, save_all=True, append_images=frames, **kw)
+    data = open(path, "rb").read()
+    assert data[:3] == b"GIF"
+    ref = np.asarray(Image.open(path).convert("RGBA"))
+    scene, *_ = load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/x.gif"}])
+    fs = scene.flatten(0).contents
+    got, fr = frame_pixels(fs, 0)
+    assert (fr.width, fr.height) == (w, h)
+    if kind == "transparent":
+        assert (got[..., 3] == 0).any() and np.array_equal(got[..., 3] == 0, idx == 3)
+        opaque = got[..., 3] == 255
+        assert np.array_equal(got[opaque], ref[opaque]) and np.array_equal(got[..., 3], ref[..., 3])
+    else:
+        assert np.array_equal(got, ref)
 
 
 def test_other_image_formats(tmp_path, built):

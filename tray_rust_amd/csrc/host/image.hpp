@@ -3,7 +3,8 @@
 // row 0 on top, grey expanded to (l, l, l, 255), RGB given alpha 255 (texture/image.rs:18-32 reads px.data[0..4]).
 // Formats: PNG (non-interlaced; grey / grey+alpha / RGB / RGBA / palette with tRNS; 1-16 bits, 16-bit samples keep their high
 // byte), binary PPM / PGM (P6 / P5, maxval <= 255), BMP (uncompressed 24 / 32 bit), TGA (uncompressed true colour 24 / 32 bit and
-// grey 8 bit), baseline JPEG (see decode_jpeg). No third-party code: the inflate below is the textbook RFC 1951 decoder.
+// grey 8 bit), baseline and progressive JPEG (see decode_jpeg), GIF (first frame, see decode_gif). No third-party code: the inflate below
+// is the textbook RFC 1951 decoder.
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -295,8 +296,12 @@ inline bool decode_tga(const std::vector<uint8_t>& f, ImageRGBA8& out, std::stri
 // >> 10, row pass >> 17 with the +128 level shift folded in), its linear ("fancy") chroma upsampling -- h2v1 (3 a + b + 2) >> 2,
 // h2v2 the 9-3-3-1 triangle (3 (3 near + far) + neighbour + 8) >> 4 with replicated edges -- and its f32 YCbCr -> RGB
 // (1.402, 0.34414, 0.71414, 1.772; + 0.5, truncate, clamp). Lossy decoders differ by an LSB or two between implementations; the test
-// (tests/test_textures.py) holds this one within 2 LSB of libjpeg's output. Progressive and arithmetic-coded files are refused.
-struct JpegComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, dc_pred = 0, bw = 0, bh = 0; std::vector<uint8_t> plane; };
+// (tests/test_textures.py) holds this one within 2 LSB of libjpeg's output. Progressive files (SOF2, T.81 Annex G: spectral selection and
+// successive approximation; DC first / refinement scans interleaved or not, AC first / refinement scans per component with end-of-band
+// runs) are collected coefficient by coefficient and transformed after the last scan, as jpeg-decoder does. Lossless, hierarchical and
+// arithmetic-coded files are refused.
+struct JpegComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, dc_pred = 0, bw = 0, bh = 0; std::vector<uint8_t> plane;
+                  std::vector<int16_t> coef; };   // progressive frames: 64 coefficients per block (natural order), filled scan by scan
 struct JpegHuff { uint8_t bits[17] = {0}; uint8_t vals[256] = {0}; int mincode[17], maxcode[18], valptr[17]; bool present = false; };
 inline void jpeg_build(JpegHuff& h) {   // T.81 F.2.2.3
     int code = 0, k = 0;
@@ -413,7 +418,7 @@ inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::str
     JpegHuff dc[4], ac[4];
     std::vector<JpegComp> comps;
     int width = 0, height = 0, hmax = 1, vmax = 1, restart = 0, adobe_transform = -1;
-    bool have_frame = false;
+    bool have_frame = false, progressive = false;
     size_t pos = 2;
     const size_t n = f.size();
     auto be16 = [&](size_t at) { return (int)f[at] << 8 | (int)f[at + 1]; };
@@ -451,7 +456,8 @@ inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::str
                 q += (size_t)total;
                 jpeg_build(h);
             }
-        } else if (m == 0xc0 || m == 0xc1) {   // SOF0 / SOF1: sequential Huffman
+        } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) {   // SOF0 / SOF1: sequential Huffman; SOF2: progressive Huffman
+            progressive = m == 0xc2;
             if (len < 8 || f[seg] != 8) { err = "JPEG: only 8-bit samples are supported"; return false; }
             if (have_frame) { err = "JPEG: more than one frame header"; return false; }   // (a second SOF would meet the first one's sampling factors and planes)
             height = be16(seg + 1); width = be16(seg + 3);
@@ -468,9 +474,10 @@ inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::str
             if (nc == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }   // a single component is never subsampled
             const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
             for (JpegComp& k : comps) { k.bw = mcux * k.h; k.bh = mcuy * k.v; k.plane.assign((size_t)k.bw * 8 * (size_t)k.bh * 8, 0); }
+            if (progressive) for (JpegComp& k : comps) k.coef.assign((size_t)k.bw * (size_t)k.bh * 64, 0);
             have_frame = true;
-        } else if (m == 0xc2 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
-            err = "JPEG: progressive / lossless / arithmetic-coded files are not supported (baseline only)"; return false;
+        } else if (m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
+            err = "JPEG: lossless / hierarchical / arithmetic-coded files are not supported (baseline and progressive Huffman only)"; return false;
         } else if (m == 0xdd) {
             if (len >= 4) restart = be16(seg);
         } else if (m == 0xee && len >= 14 && !std::memcmp(&f[seg], "Adobe", 5)) {
@@ -480,12 +487,16 @@ inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::str
             if (len < 3 || seg >= end) { err = "JPEG: bad scan header"; return false; }   // (the component count is the first byte of the segment's body)
             const int ns = f[seg];
             if (ns < 1 || ns > (int)comps.size() || seg + 1 + 2 * (size_t)ns + 3 > end) { err = "JPEG: bad scan header"; return false; }
+            // spectral selection Ss..Se and successive approximation Ah / Al (T.81 B.2.3; 0, 63, 0, 0 in a sequential scan)
+            const int ss = f[seg + 1 + 2 * (size_t)ns], se = f[seg + 2 + 2 * (size_t)ns], ah = f[seg + 3 + 2 * (size_t)ns] >> 4, al = f[seg + 3 + 2 * (size_t)ns] & 15;
+            if (progressive && (ss > se || se > 63 || (ss == 0 && se != 0) || (ss > 0 && ns != 1) || al > 13 || (ah != 0 && ah != al + 1))) { err = "JPEG: bad progressive scan parameters"; return false; }
             std::vector<JpegComp*> sc;
             for (int i = 0; i < ns; ++i) {
                 const int cid = f[seg + 1 + 2 * (size_t)i], t = f[seg + 2 + 2 * (size_t)i];
                 JpegComp* k = nullptr;
                 for (JpegComp& c : comps) if (c.id == cid) k = &c;
-                if (!k || (t >> 4) > 3 || (t & 15) > 3 || !dc[t >> 4].present || !ac[t & 15].present || !qt_present[k->tq]) { err = "JPEG: scan refers to a missing component / table"; return false; }
+                const bool need_dc = !progressive || ss == 0, need_ac = !progressive || ss > 0;
+                if (!k || (t >> 4) > 3 || (t & 15) > 3 || (need_dc && ah == 0 && !dc[t >> 4].present) || (need_ac && !ac[t & 15].present) || !qt_present[k->tq]) { err = "JPEG: scan refers to a missing component / table"; return false; }
                 k->td = t >> 4; k->ta = t & 15; k->dc_pred = 0;
                 sc.push_back(k);
             }
@@ -497,7 +508,7 @@ inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::str
                 const int cw = (width * sc[0]->h + hmax - 1) / hmax, ch = (height * sc[0]->v + vmax - 1) / vmax;
                 nx = (cw + 7) / 8; ny = (ch + 7) / 8;
             } else { nx = comps[0].bw / comps[0].h; ny = comps[0].bh / comps[0].v; }
-            int until_restart = restart, rst_expect = 0;
+            int until_restart = restart, rst_expect = 0, eobrun = 0;
             for (int my = 0; my < ny; ++my)
                 for (int mx = 0; mx < nx; ++mx) {
                     if (restart && until_restart == 0) {   // RSTn: byte-align, check the marker, reset the predictors
@@ -506,11 +517,68 @@ inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::str
                         if (br.marker != 0xd0 + rst_expect) { err = "JPEG: restart marker out of sequence"; return false; }
                         br.pos += 2; br.marker = 0; rst_expect = (rst_expect + 1) & 7; until_restart = restart;
                         for (JpegComp* k : sc) k->dc_pred = 0;
+                        eobrun = 0;
                     }
                     for (JpegComp* k : sc) {
                         const int bh_ = single ? 1 : k->h, bv_ = single ? 1 : k->v;
                         for (int by = 0; by < bv_; ++by)
                             for (int bx = 0; bx < bh_; ++bx) {
+                                const int px = (mx * bh_ + bx) * 8, py = (my * bv_ + by) * 8;
+                                if (progressive) {
+                                    if (px + 8 > k->bw * 8 || py + 8 > k->bh * 8) { err = "JPEG: block outside the frame"; return false; }
+                                    int16_t* c = &k->coef[((size_t)(py / 8) * (size_t)k->bw + (size_t)(px / 8)) * 64];
+                                    if (ss == 0) {   // DC scan (G.1.2.1): first pass = the difference, shifted; refinement = one more bit
+                                        if (ah == 0) {
+                                            const int s = jpeg_decode(br, dc[k->td]);
+                                            if (s > 11) { err = "JPEG: bad DC category"; return false; }
+                                            k->dc_pred += jpeg_extend(br.receive(s), s);
+                                            c[0] = (int16_t)(k->dc_pred * (1 << al));
+                                        } else if (br.bit()) c[0] = (int16_t)(c[0] | (1 << al));
+                                    } else if (ah == 0) {   // AC first pass (G.1.2.2) with end-of-band runs
+                                        if (eobrun > 0) --eobrun;
+                                        else for (int i = ss; i <= se;) {
+                                            const int rs = jpeg_decode(br, ac[k->ta]), r = rs >> 4, sz = rs & 15;
+                                            if (sz == 0) {
+                                                if (r == 15) { i += 16; continue; }
+                                                eobrun = (1 << r) - 1;
+                                                if (r) eobrun += br.receive(r);
+                                                break;
+                                            }
+                                            i += r;
+                                            if (i > se) { err = "JPEG: AC coefficient index out of range"; return false; }
+                                            c[zigzag[i]] = (int16_t)(jpeg_extend(br.receive(sz), sz) * (1 << al));
+                                            ++i;
+                                        }
+                                    } else {   // AC refinement (G.1.2.3): a correction bit for every coefficient that is already nonzero, new +-1 << al ones in between
+                                        const int p1 = 1 << al;
+                                        auto refine = [&](int16_t& v) { if (br.bit() && (v & p1) == 0) v = (int16_t)(v >= 0 ? v + p1 : v - p1); };
+                                        int i = ss;
+                                        if (eobrun == 0) {
+                                            while (i <= se) {
+                                                const int rs = jpeg_decode(br, ac[k->ta]), sz = rs & 15;
+                                                int r = rs >> 4, value = 0;
+                                                if (sz == 0) {
+                                                    if (r < 15) { eobrun = 1 << r; if (r) eobrun += br.receive(r); break; }
+                                                } else {
+                                                    if (sz != 1) { err = "JPEG: bad refinement scan"; return false; }
+                                                    value = br.bit() ? p1 : -p1;
+                                                }
+                                                while (i <= se) {   // r zero-valued coefficients are skipped, the nonzero ones in between refined
+                                                    int16_t& v = c[zigzag[i++]];
+                                                    if (v != 0) refine(v);
+                                                    else { if (r == 0) { if (value) v = (int16_t)value; break; } --r; }
+                                                }
+                                                if (br.bad) break;
+                                            }
+                                        }
+                                        if (eobrun > 0) {   // the rest of the band belongs to an end-of-band run: refinement bits only
+                                            for (; i <= se; ++i) { int16_t& v = c[zigzag[i]]; if (v != 0) refine(v); }
+                                            --eobrun;
+                                        }
+                                    }
+                                    if (br.bad) { err = "JPEG: corrupt entropy-coded data"; return false; }
+                                    continue;
+                                }
                                 int blk[64] = {0};
                                 const int s = jpeg_decode(br, dc[k->td]);
                                 if (s > 11) { err = "JPEG: bad DC category"; return false; }
@@ -525,7 +593,6 @@ inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::str
                                     ++i;
                                 }
                                 if (br.bad) { err = "JPEG: corrupt entropy-coded data"; return false; }
-                                const int px = (mx * bh_ + bx) * 8, py = (my * bv_ + by) * 8;
                                 if (px + 8 <= k->bw * 8 && py + 8 <= k->bh * 8) jpeg_idct(blk, &k->plane[(size_t)py * (size_t)k->bw * 8 + (size_t)px], k->bw * 8);
                             }
                     }
@@ -539,6 +606,19 @@ inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::str
         pos = end;
     }
     if (!have_frame) { err = "JPEG: no frame header"; return false; }
+    if (progressive)   // every scan has contributed: dequantise (the table is indexed in zigzag order) and transform
+        for (JpegComp& k : comps) {
+            if (!qt_present[k.tq]) { err = "JPEG: missing quantisation table"; return false; }
+            int qnat[64];
+            for (int i = 0; i < 64; ++i) qnat[zigzag[i]] = qt[k.tq][i];
+            for (int by = 0; by < k.bh; ++by)
+                for (int bx = 0; bx < k.bw; ++bx) {
+                    const int16_t* c = &k.coef[((size_t)by * (size_t)k.bw + (size_t)bx) * 64];
+                    int blk[64];
+                    for (int i = 0; i < 64; ++i) blk[i] = c[i] * qnat[i];
+                    jpeg_idct(blk, &k.plane[(size_t)by * 8 * (size_t)k.bw * 8 + (size_t)bx * 8], k.bw * 8);
+                }
+        }
     // upsample every component to the frame and convert
     std::vector<std::vector<uint8_t>> full(comps.size());
     for (size_t c = 0; c < comps.size(); ++c) {
@@ -581,6 +661,96 @@ inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::str
     return true;
 }
 
+// ---- GIF (87a / 89a): what image::open returns for a .gif -- the FIRST frame as RGBA (image 0.18 decodes GIF with the gif crate 0.9,
+// Cargo.lock; not vendored by the reference: PARITY UNPINNED): palette lookup through the frame's local colour table or the global one,
+// the graphic control extension's transparent index -> (r, g, b, 0), interlaced frames put back in row order, variable-width LZW
+// (clear / end codes, 12-bit table, deferred clear). The image crate builds the picture from the screen's size and the frame's buffer,
+// so a first frame that does not cover the logical screen is refused here (it is an error there).
+inline bool decode_gif(const std::vector<uint8_t>& f, ImageRGBA8& out, std::string& err) {
+    const size_t n = f.size();
+    if (n < 13 || std::memcmp(f.data(), "GIF8", 4) || (f[4] != '7' && f[4] != '9') || f[5] != 'a') { err = "GIF: bad signature"; return false; }
+    auto le16 = [&](size_t at) { return (int)f[at] | (int)f[at + 1] << 8; };
+    const int sw = le16(6), sh = le16(8);
+    size_t pos = 13;
+    std::vector<uint8_t> global;
+    if (f[10] & 0x80) { const size_t sz = (size_t)3 << ((f[10] & 7) + 1); if (pos + sz > n) { err = "GIF: truncated colour table"; return false; } global.assign(f.begin() + (long)pos, f.begin() + (long)(pos + sz)); pos += sz; }
+    int transparent = -1;
+    while (pos < n) {
+        const int b = f[pos++];
+        if (b == 0x3b) break;                         // trailer
+        if (b == 0x21) {                              // extension: label, sub-blocks
+            if (pos >= n) break;
+            const int label = f[pos++];
+            if (label == 0xf9 && pos + 5 < n && f[pos] == 4 && (f[pos + 1] & 1)) transparent = f[pos + 4];   // graphic control: transparent colour flag + index
+            while (pos < n && f[pos] != 0) pos += (size_t)f[pos] + 1;
+            ++pos;
+            continue;
+        }
+        if (b != 0x2c) { err = "GIF: unexpected block"; return false; }
+        if (pos + 9 > n) { err = "GIF: truncated image descriptor"; return false; }
+        const int left = le16(pos), top = le16(pos + 2), w = le16(pos + 4), h = le16(pos + 6), flags = f[pos + 8];
+        pos += 9;
+        if (w <= 0 || h <= 0 || (size_t)w * (size_t)h > ((size_t)1 << 28)) { err = "GIF: bad frame size"; return false; }
+        if (left != 0 || top != 0 || w != sw || h != sh) { err = "GIF: the first frame does not cover the logical screen"; return false; }
+        std::vector<uint8_t> local;
+        if (flags & 0x80) { const size_t sz = (size_t)3 << ((flags & 7) + 1); if (pos + sz > n) { err = "GIF: truncated colour table"; return false; } local.assign(f.begin() + (long)pos, f.begin() + (long)(pos + sz)); pos += sz; }
+        const std::vector<uint8_t>& pal = local.empty() ? global : local;
+        if (pal.empty()) { err = "GIF: no colour table"; return false; }
+        if (pos >= n) { err = "GIF: truncated image data"; return false; }
+        const int min_code = f[pos++];
+        if (min_code < 2 || min_code > 8) { err = "GIF: bad LZW minimum code size"; return false; }
+        std::vector<uint8_t> data;                    // the sub-blocks, concatenated
+        while (pos < n && f[pos] != 0) { const size_t len = f[pos]; if (pos + 1 + len > n) { err = "GIF: truncated image data"; return false; } data.insert(data.end(), f.begin() + (long)pos + 1, f.begin() + (long)(pos + 1 + len)); pos += len + 1; }
+        // LZW, least significant bit first
+        std::vector<uint8_t> idx;
+        idx.reserve((size_t)w * (size_t)h);
+        const int clear = 1 << min_code, end_code = clear + 1;
+        std::vector<int16_t> prefix(4096, -1);
+        std::vector<uint8_t> suffix(4096, 0), stack(4097);
+        for (int i = 0; i < clear; ++i) suffix[(size_t)i] = (uint8_t)i;
+        int width = min_code + 1, next = end_code + 1, prev = -1;
+        uint32_t acc = 0; int nbits = 0; size_t dp = 0;
+        while (idx.size() < (size_t)w * (size_t)h) {
+            while (nbits < width && dp < data.size()) { acc |= (uint32_t)data[dp++] << nbits; nbits += 8; }
+            if (nbits < width) break;                 // data ran out: the rest of the frame stays at index 0
+            const int code = (int)(acc & ((1u << width) - 1u)); acc >>= width; nbits -= width;
+            if (code == clear) { width = min_code + 1; next = end_code + 1; prev = -1; continue; }
+            if (code == end_code) break;
+            if (prev < 0) { if (code >= clear) { err = "GIF: corrupt LZW stream"; return false; } idx.push_back((uint8_t)code); prev = code; continue; }
+            int cur = code, sp = 0;
+            if (code > next || (code == next && next >= 4096)) { err = "GIF: corrupt LZW stream"; return false; }
+            if (code == next) { cur = prev; }         // the string being defined: prev + first(prev)
+            while (cur >= clear) { if (cur == end_code || sp >= 4096) { err = "GIF: corrupt LZW stream"; return false; } stack[(size_t)sp++] = suffix[(size_t)cur]; cur = prefix[(size_t)cur]; }
+            const uint8_t first = (uint8_t)cur;
+            stack[(size_t)sp++] = first;
+            while (sp > 0) idx.push_back(stack[(size_t)--sp]);
+            if (code == next) idx.push_back(first);
+            if (next < 4096) {
+                prefix[(size_t)next] = (int16_t)prev; suffix[(size_t)next] = first; ++next;
+                if (next == (1 << width) && width < 12) ++width;
+            }
+            prev = code;
+        }
+        idx.resize((size_t)w * (size_t)h, 0);
+        out.width = (uint32_t)w; out.height = (uint32_t)h;
+        out.px.assign((size_t)w * (size_t)h * 4, 0);
+        // interlaced frames store rows 0, 8, 16, ... then 4, 12, ... then 2, 6, ... then 1, 3, ...
+        std::vector<int> row_of((size_t)h);
+        if (flags & 0x40) { int r = 0; const int start[4] = {0, 4, 2, 1}, step[4] = {8, 8, 4, 2}; for (int p = 0; p < 4; ++p) for (int y = start[p]; y < h; y += step[p]) row_of[(size_t)r++] = y; }
+        else for (int y = 0; y < h; ++y) row_of[(size_t)y] = y;
+        for (int r = 0; r < h; ++r)
+            for (int x = 0; x < w; ++x) {
+                const int i = idx[(size_t)r * (size_t)w + (size_t)x];
+                uint8_t* o = &out.px[((size_t)row_of[(size_t)r] * (size_t)w + (size_t)x) * 4];
+                if ((size_t)i * 3 + 2 < pal.size()) { o[0] = pal[(size_t)i * 3]; o[1] = pal[(size_t)i * 3 + 1]; o[2] = pal[(size_t)i * 3 + 2]; }
+                o[3] = i == transparent ? 0 : 255;
+            }
+        return true;
+    }
+    err = "GIF: no image";
+    return false;
+}
+
 }  // namespace img_detail
 
 // image::open: the format is taken from the file's content
@@ -595,8 +765,9 @@ inline bool load_image(const std::string& path, ImageRGBA8& out, std::string& er
     else if (f.size() >= 3 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) ok = img_detail::decode_pnm(f, out, err);
     else if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') ok = img_detail::decode_bmp(f, out, err);
     else if (f.size() >= 3 && f[0] == 0xff && f[1] == 0xd8) ok = img_detail::decode_jpeg(f, out, err);
+    else if (f.size() >= 6 && !std::memcmp(f.data(), "GIF8", 4)) ok = img_detail::decode_gif(f, out, err);
     else if (dot != std::string::npos && (path.substr(dot) == ".tga" || path.substr(dot) == ".TGA")) ok = img_detail::decode_tga(f, out, err);
-    else { ok = false; err = "unrecognised image format (PNG, baseline JPEG, binary PPM / PGM, BMP and TGA are supported)"; }
+    else { ok = false; err = "unrecognised image format (PNG, JPEG, GIF, binary PPM / PGM, BMP and TGA are supported)"; }
     if (!ok) err = path + ": " + err;   // (which file: a scene names dozens of textures)
     return ok;
 }
