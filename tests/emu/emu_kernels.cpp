@@ -234,6 +234,7 @@ int emu_render_sampler(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_
     std::vector<uint32_t> px_state((size_t)batch * 64u);
     std::vector<float> px_avg((size_t)batch * 64u), px_lum((size_t)batch * 64u * std::max(sp.lum_cap, 1u));
     const uint32_t chunk = tile_count ? tile_count : 1u;
+    int rc = 0;   // (the window is shared by the block's threads: a SIMT emulation, as for k_path_tiles)
     for (uint32_t item0 = 0; item0 < tile_count; item0 += batch) {
         const uint32_t n_items = std::min(batch, tile_count - item0), n_px = n_items * 64u;
         std::fill(px_state.begin(), px_state.end(), 0u); std::fill(px_avg.begin(), px_avg.end(), 0.0f);
@@ -242,10 +243,12 @@ int emu_render_sampler(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_
             sp.count = kind == TRAY_SAMPLER_ADAPTIVE ? (j == 0u ? sp.min_spp : sp.step) : sp.min_spp;
             sp.taken = kind == TRAY_SAMPLER_ADAPTIVE ? sp.min_spp + j * sp.step : 0u;
             sp.before = j == 0u ? 0u : sp.min_spp + (j - 1u) * sp.step;
-            const uint32_t grid = (uint32_t)(((size_t)n_px * sp.count + TR_BLOCK - 1) / TR_BLOCK);
-            if (deforming(f)) launch(grid, TR_BLOCK, [&] { k_sampler_pass<3>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
-            else if (moving) launch(grid, TR_BLOCK, [&] { k_sampler_pass<2>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
-            else launch(grid, TR_BLOCK, [&] { k_sampler_pass<0>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
+            const uint32_t per_tile = 64u * sp.count;
+            const uint32_t grid = per_tile >= TR_BLOCK ? n_items * ((per_tile + TR_BLOCK - 1u) / TR_BLOCK) : (n_items * per_tile + TR_BLOCK - 1u) / TR_BLOCK;
+            if (deforming(f)) rc = launch_simt(grid, TR_BLOCK, [&] { k_sampler_pass<3>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
+            else if (moving) rc = launch_simt(grid, TR_BLOCK, [&] { k_sampler_pass<2>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
+            else rc = launch_simt(grid, TR_BLOCK, [&] { k_sampler_pass<0>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
+            if (rc != 0) return -3;
             if (kind == TRAY_SAMPLER_ADAPTIVE)
                 launch((n_px + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_sampler_decide(n_px, sp, px_state.data(), px_avg.data(), px_lum.data()); });
         }

@@ -494,8 +494,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_debug_sample_radiance(const DevSce
 
 // ---- the Samplers thread_work does not construct (sampler/uniform.rs, sampler/adaptive.rs; include/trayhip.h: tray_scene_set_sampler) ----
 // One launch = one get_samples() round of every pixel of a batch of tiles (multithreaded.rs:91-103): a thread per camera sample of the
-// round, driven through the same lane machine as the tile kernel, the sample written straight into the caller's film
-// (RenderTarget::write, render_target.rs:118-146). Not a hot path: one instantiation per ANIM (0 / 2), every lobe compiled in.
+// round, driven through the same lane machine as the tile kernel, the sample written into the block's film window in LDS
+// (RenderTarget::write, render_target.rs:118-146) that is added to the caller's film at the end. Not a hot path: one instantiation per ANIM (0 / 2), every lobe compiled in.
 //   Uniform   one round: the pixel's centre, a uniform time, uniform numbers for every array of the integrator (uniform.rs:22-47).
 //   Adaptive  round j generates `count` = min_spp (j = 0) or step_size positions -- sample_02(i + samples_taken) under the round's
 //             scrambles, shuffled (adaptive.rs:92-116; Kensler's hashed permutation stands for rng.shuffle as in pixel_sample) -- and
@@ -514,12 +514,23 @@ __global__ __launch_bounds__(TR_BLOCK) void k_sampler_pass(const DevScene scv, c
                                                            const uint32_t* __restrict__ px_state, float* __restrict__ px_lum,
                                                            float* __restrict__ rgbw, DevStats* __restrict__ stats) {
     TR_DYN_LDS(uint32_t, s_stack);
+    // the film of the block's tile while its samples are traced: the 17 x 17 RGBW window of the tile kernel (a sample written straight into
+    // the caller's film is ~100 global atomics, 3/4 of this kernel's time when it was measured: profiles/r04_side_paths.txt)
+    __shared__ float s_win[4 * WIN_PLANE];
     const DevScene& sc = scv;
     const DevScene* const scp = &scv;
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = idx < n_items * 64u * sp.count;   // the whole wave steps together (cooperative leaf test inside the traversal)
-    const uint32_t slot = in_range ? idx / sp.count : 0u, i = in_range ? idx % sp.count : 0u;   // pixel of the batch, sample of the round
+    // a block belongs to ONE tile where a tile's round fills one (64 * count >= TR_BLOCK): blocks_per_tile of them share the tile's 64 * count
+    // (pixel, sample) pairs; smaller rounds (Uniform, count < 4) pack several tiles into a block and write to the caller's film directly
+    const uint32_t per_tile = 64u * sp.count;
+    const bool windowed = per_tile >= TR_BLOCK;
+    const uint32_t blocks_per_tile = (per_tile + TR_BLOCK - 1u) / TR_BLOCK, flat_idx = blockIdx.x * TR_BLOCK + threadIdx.x;
+    const uint32_t item = windowed ? blockIdx.x / blocks_per_tile : flat_idx / per_tile;
+    const uint32_t pair = windowed ? (blockIdx.x % blocks_per_tile) * TR_BLOCK + threadIdx.x : flat_idx % per_tile;
+    const bool in_range = item < n_items && pair < per_tile;   // the whole wave steps together (cooperative leaf test inside the traversal)
+    const uint32_t slot = (item < n_items ? item : 0u) * 64u + (in_range ? pair / sp.count : 0u), i = in_range ? pair % sp.count : 0u;   // pixel of the batch, sample of the round
     const uint32_t ti = item0 + (slot >> 6), pix = slot & 63u;
+    for (uint32_t k = threadIdx.x; k < 4 * WIN_PLANE; k += TR_BLOCK) s_win[k] = 0.0f;
+    __syncthreads();
     const uint2 tile = tiles[(ti / chunk) * chunk_stride * chunk + (ti % chunk)];
     const int x0 = (int)tile.x * 8, y0 = (int)tile.y * 8;
     const uint32_t px = (uint32_t)x0 + (pix & 7u), py = (uint32_t)y0 + (pix >> 3);   // Region order: x fastest (sampler/mod.rs:82-98)
@@ -585,8 +596,27 @@ __global__ __launch_bounds__(TR_BLOCK) void k_sampler_pass(const DevScene scv, c
     }
     if (active) {
         const f3 c = lane_result(ln);
-        film_splat_global(sc, rgbw, sc.filter_table, x0, y0, sx, sy, c);
+        if (windowed) film_splat(sc, s_win, sc.filter_table, x0, y0, sx, sy, c);   // RenderTarget::write into the block's window (LDS atomics)
+        else film_splat_global(sc, rgbw, sc.filter_table, x0, y0, sx, sy, c);
         if (sp.kind == TRAY_SAMPLER_ADAPTIVE) px_lum[(size_t)slot * sp.lum_cap + sp.before + i] = 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z;   // Colorf::luminance (color.rs:43-45)
+    }
+    __syncthreads();
+    if (windowed) {   // flush the window: film::Image::add_pixels semantics on the caller's RGBW buffer (as k_path_tiles)
+        const int wx0 = x0 - sc.fpw, wy0 = y0 - sc.fph;
+        const int ww = 8 + 2 * sc.fpw + 1, wh = 8 + 2 * sc.fph + 1;
+        for (int k = (int)threadIdx.x; k < ww * wh; k += TR_BLOCK) {
+            const int wy = k / ww, wx = k - wy * ww;
+            const int ix = wx0 + wx, iy = wy0 + wy;
+            if (ix < 0 || iy < 0 || ix >= (int)sc.width || iy >= (int)sc.height) continue;
+            const int o = wy * WIN_STRIDE + wx;
+            const float a = s_win[o + 3 * WIN_PLANE];
+            if (a == 0.0f && s_win[o] == 0.0f && s_win[o + WIN_PLANE] == 0.0f && s_win[o + 2 * WIN_PLANE] == 0.0f) continue;
+            float* dst = rgbw + ((size_t)iy * sc.width + ix) * 4;
+            atomicAdd(dst + 0, s_win[o]);
+            atomicAdd(dst + 1, s_win[o + WIN_PLANE]);
+            atomicAdd(dst + 2, s_win[o + 2 * WIN_PLANE]);
+            atomicAdd(dst + 3, a);
+        }
     }
     if (stats && active) {   // (the compiler's atomic optimizer turns these into one atomic per wave)
         atomicAdd(&stats->samples, 1ull);
@@ -1534,7 +1564,7 @@ static int launch_sampler(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile
     // tiles per batch: the per-pixel state within 256 MB and the largest round within 2^28 threads
     const size_t px_bytes = 8u + 4u * (size_t)sp.lum_cap;
     const uint32_t widest = std::max(sp.min_spp, sp.step);
-    uint32_t batch = (uint32_t)std::min<size_t>({(size_t)tile_count, ((size_t)256 << 20) / (64u * px_bytes), ((size_t)1 << 28) / (64u * (size_t)widest)});
+    uint32_t batch = (uint32_t)std::min<size_t>({(size_t)tile_count, ((size_t)256 << 20) / (64u * px_bytes), ((size_t)1 << 28) / (64u * (size_t)widest + TR_BLOCK)});
     if (batch == 0u) { set_error("Adaptive sampler: min_spp / max_spp too large for one tile's state"); return TRAY_E_UNSUPPORTED; }
     const size_t need = (size_t)batch * 64u * px_bytes;
     if (need > s->smp_bytes) {
@@ -1555,7 +1585,8 @@ static int launch_sampler(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile
             sp.count = sp.kind == TRAY_SAMPLER_ADAPTIVE ? (j == 0u ? sp.min_spp : sp.step) : sp.min_spp;   // (Uniform: 1, LowDiscrepancy: spp)
             sp.taken = sp.kind == TRAY_SAMPLER_ADAPTIVE ? sp.min_spp + j * sp.step : 0u;
             sp.before = j == 0u ? 0u : sp.min_spp + (j - 1u) * sp.step;
-            const dim3 grid((uint32_t)(((size_t)n_px * sp.count + TR_BLOCK - 1) / TR_BLOCK)), block(TR_BLOCK);
+            const uint32_t per_tile = 64u * sp.count;   // (k_sampler_pass: whole blocks per tile, or several tiles per block for small rounds)
+            const dim3 grid(per_tile >= TR_BLOCK ? n_items * ((per_tile + TR_BLOCK - 1u) / TR_BLOCK) : (n_items * per_tile + TR_BLOCK - 1u) / TR_BLOCK), block(TR_BLOCK);
             if (s->deforming) hipLaunchKernelGGL(k_sampler_pass<3>, grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats);
             else if (s->animated) hipLaunchKernelGGL(k_sampler_pass<2>, grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats);
             else hipLaunchKernelGGL(k_sampler_pass<0>, grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats);
