@@ -2,10 +2,11 @@
  * write (src/main.rs:56-109), through the C ABI only -- the calls the Rust `exec::Hip` of INTEGRATION.md makes.
  *
  *   cc -O2 -Iinclude examples/trayhip_render.c -Ltray_rust_amd -ltrayhip -Wl,-rpath,$PWD/tray_rust_amd -o trayhip_render
- *   ./trayhip_render scene.json out.ppm [frame] [seed]
+ *   ./trayhip_render scene.json out.ppm [frame] [seed] [uniform | adaptive:MIN:MAX]
  */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "trayhip.h"
 
 static int fail(const char* what, int rc) {
@@ -14,7 +15,7 @@ static int fail(const char* what, int rc) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s scene.json out.ppm [frame] [seed]\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s scene.json out.ppm [frame] [seed] [uniform | adaptive:MIN:MAX]\n", argv[0]); return 2; }
     const uint32_t frame = argc > 3 ? (uint32_t)atoi(argv[3]) : 0u;
     const uint64_t seed = argc > 4 ? (uint64_t)atoll(argv[4]) : 1u;
     TrayHostScene* host = NULL;
@@ -31,6 +32,13 @@ int main(int argc, char** argv) {
     TrayDeviceScene* dev = NULL;
     rc = tray_scene_create(flat, &dev);
     if (rc != TRAY_OK) return fail("tray_scene_create", rc);
+    if (argc > 5) {   /* the Sampler thread_work would construct (exec/multithreaded.rs:74); default: LowDiscrepancy::new(block_dim, spp) */
+        unsigned lo = 0, hi = 0;
+        if (!strcmp(argv[5], "uniform")) rc = tray_scene_set_sampler(dev, TRAY_SAMPLER_UNIFORM, 0, 0);
+        else if (sscanf(argv[5], "adaptive:%u:%u", &lo, &hi) == 2) rc = tray_scene_set_sampler(dev, TRAY_SAMPLER_ADAPTIVE, lo, hi);
+        else { fprintf(stderr, "unknown sampler '%s'\n", argv[5]); return 2; }
+        if (rc != TRAY_OK) return fail("tray_scene_set_sampler", rc);
+    }
     const size_t n = (size_t)info.width * info.height;
     float* rgbw = (float*)calloc(n * 4, sizeof(float));
     unsigned char* rgb8 = (unsigned char*)malloc(n * 3);

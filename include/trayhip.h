@@ -314,7 +314,8 @@ void tray_scene_destroy(TrayDeviceScene* s);
  * (exec/multithreaded.rs:72-114 with Config.select_blocks, exec/mod.rs:25-27).
  * Adds filtered samples into rgbw_dev: device pointer, width*height*4 f32, the layout of
  * RenderTarget::get_renderf32 (render_target.rs:243-266). Asynchronous on `stream`
- * (a hipStream_t; NULL = default stream). spp must already be a power of two. */
+ * (a hipStream_t; NULL = default stream). spp must already be a power of two (it is not used when tray_scene_set_sampler chose
+ * Uniform or Adaptive). */
 /* tile_count == 0 selects the whole queue whatever tile_start is (BlockQueue::new, block_queue.rs:39-41).
  * ONE render may be in flight per TrayDeviceScene: the tile counter, the statistics, the per-path transform cache, the wavefront
  * pool and queues and the timing events belong to the handle. Calls on one handle must be serialised by the caller (the

@@ -118,3 +118,10 @@ def test_plain_c_host_renders(tmp_path):
     assert data.startswith(b"P6\n64 48\n255\n")
     px = np.frombuffer(data[len(b"P6\n64 48\n255\n"):], np.uint8)
     assert px.size == 64 * 48 * 3 and px.max() > 100
+    # ... and with sampler::Adaptive::new(dim, 4, 32) in LowDiscrepancy's place (tray_scene_set_sampler from plain C)
+    r = subprocess.run([exe, os.path.join(str(tmp_path), "cornell_box.json"), out, "0", "1", "adaptive:4:32"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    px2 = np.frombuffer(open(out, "rb").read()[len(b"P6\n64 48\n255\n"):], np.uint8)
+    assert px2.size == px.size and np.abs(px2.astype(int) - px.astype(int)).mean() < 12
+    r = subprocess.run([exe, os.path.join(str(tmp_path), "cornell_box.json"), out, "0", "1", "stratified"], capture_output=True, text=True)
+    assert r.returncode == 2 and "unknown sampler" in r.stderr

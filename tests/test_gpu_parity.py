@@ -516,6 +516,15 @@ def test_frame_on_all_gpus_of_the_process_through_the_c_abi(tmp_path):
         got = rt.get_renderf32().reshape(96, 160, 4)
         assert np.allclose(got, whole, rtol=0, atol=1e-4 * whole.max()), n_dev
         assert sum(int(p.samples) for p in per) == tim.samples and reduce_ms >= 0.0
+    # the Sampler choice reaches every device of a TrayMultiScene (tray_multi_set_sampler)
+    adaptive = lambda dim, spp: T.sampler.Adaptive(dim, 2, 16)
+    ref, tim_a = gpu_render_sampler(scene, rt, adaptive, fi, seed=5)
+    rt.clear()
+    hip = T.Hip(0, seed=5, sampler=adaptive)
+    per, _ = hip.render_multi(scene, rt, T.Config(".", "s", 16, 1, fi, (0, 0)), [0])
+    assert sum(int(p.samples) for p in per) == tim_a.samples and tim_a.samples > 2 * 160 * 96
+    assert np.allclose(rt.get_renderf32().reshape(96, 160, 4), ref, rtol=0, atol=1e-4 * ref.max())
+    hip.close_multi()
 
 
 @pytest.mark.parametrize("moving", [False, True])

@@ -222,3 +222,17 @@ def test_oracle_reproduces_the_rank_4_golden(tmp_path, built):
     ada, st_a, counts = O.render_tiles_sampler(flat, O.SAMPLER_ADAPTIVE, 4, 32, seed=9)
     assert st_u.vertices == int(g["uniform_vertices"]) and st_a.samples == int(g["adaptive_samples"]) and np.array_equal(counts, g["adaptive_counts"])
     assert np.abs(uni - g["uniform"]).max() <= 1e-5 * np.abs(g["uniform"]).max() and np.abs(ada - g["adaptive"]).max() <= 1e-5 * np.abs(g["adaptive"]).max()
+
+
+def test_device_code_of_adaptive_behind_bvh_of_instances(tmp_path, built):
+    """59 instances, moving, many meshes (the C5 stand-in at low detail): the sampler kernels run the reference's two-level traversal there
+    (trace_bvh), whatever schedule LowDiscrepancy renders of the scene use"""
+    p = scenes.write_tr15_like_assets(str(tmp_path), film=(32, 24, 4), detail=0.02)
+    scene, *_ = T.Scene.load_file(p if isinstance(p, str) else p[0])
+    flat = scene.flatten(330)
+    assert flat.contents.n_instances > 16
+    q = np.array(list(T.BlockQueue((32, 24))), np.uint32)
+    ref, st, counts = O.render_tiles_sampler(flat, O.SAMPLER_ADAPTIVE, 2, 8, seed=4, threads=1)
+    img, (samples, _, _) = E.render_sampler(flat, q, O.SAMPLER_ADAPTIVE, 2, 8, seed=4)
+    assert samples == st.samples and counts.max() > 2
+    np.testing.assert_allclose(img, ref, rtol=5e-5, atol=5e-5)
