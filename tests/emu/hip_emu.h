@@ -303,6 +303,7 @@ inline void __builtin_amdgcn_wave_barrier() {
     hip_emu::wave_exchange(0u, all, present);
 }
 inline void __syncthreads() { if (hip_emu::block().simt) hip_emu::block_barrier(); }
+inline void __threadfence_block() {}   // (fibers run one at a time: every store is visible at once)
 template <class T> inline T atomicAdd(T* p, T v) { T old = *p; *p = old + v; return old; }
 inline uint32_t atomicAdd(uint32_t* p, int v) { uint32_t old = *p; *p = old + (uint32_t)v; return old; }
 #define __HIP_MEMORY_SCOPE_WORKGROUP 0

@@ -131,6 +131,43 @@ TR_DEV void xf_cache_fill(const DevScene& sc, float time, uint32_t lane) {
         }
     }
 }
+// The same for the lanes of a wave that start a camera sample in the same step of the tile kernel (`started`; called by ALL lanes). A step
+// regenerates a third of the wave's lanes or fewer, and the evaluation of a spline stack is long: run under the starting lanes' mask it
+// occupied 44 % of the moving test scene's wave cycles (profiles/r04_moving_box_cooperative_fill_ab.txt). Here the (starting lane,
+// moving instance) pairs are dealt out to all the lanes of the wave -- instance-major, so neighbouring lanes evaluate the SAME stack at
+// different times and stay in step -- and every lane writes its result into the column of the lane it worked for. Values and layout are
+// exactly xf_cache_fill's; the stores are made visible to the wave before anybody reads its column.
+TR_DEV void xf_cache_fill_wave(const DevScene& sc, bool started, float time, uint32_t column) {
+    if (!sc.xf_cache) return;
+    const unsigned long long start_m = __ballot(started), exec_m = __ballot(1);
+    if (start_m == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_exec = (uint32_t)__popcll(exec_m), my_rank = (uint32_t)__popcll(exec_m & ((1ull << lane) - 1ull));
+    const uint32_t n_start = (uint32_t)__popcll(start_m), n_tasks = n_start * sc.n_moving;
+    const uint32_t lanes = sc.xf_cache_lanes;
+    for (uint32_t base = 0; base < n_tasks; base += n_exec) {
+        const uint32_t task = base + my_rank;
+        const bool valid = task < n_tasks;
+        const uint32_t m = valid ? task / n_start : 0u, which = valid ? task % n_start : 0u;
+        // the which-th starting lane of the wave (a scalar walk over the mask's bits)
+        uint32_t src = 0u, k = 0u;
+        for (unsigned long long rest = start_m; rest != 0ull; rest &= rest - 1ull, ++k) {
+            const uint32_t b = (uint32_t)__ffsll((long long)rest) - 1u;
+            if (k == which) src = b;
+        }
+        const float t = __shfl(time, (int)src);
+        const uint32_t col = __shfl(column, (int)src);
+        if (valid) {
+            const TrayInstance* __restrict__ in = sc.instances + sc.moving_ids[m];
+            float x[TR_XF_WORDS];
+            eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, t, x);
+            float* __restrict__ dst = sc.xf_cache + (size_t)m * TR_XF_WORDS * lanes + col;
+#pragma unroll
+            for (int q = 0; q < 26; ++q) dst[(size_t)q * lanes] = x[q];
+        }
+    }
+    __threadfence_block();   // (a lane reads its column next: written by another lane of this wave)
+}
 // ANIM template values: 0 = nothing moves within the frame; 1 = moving instances are read from the per-path cache (tile and
 // wavefront kernels: no function call in their hot loops, a call would raise their register allocation to the callee's);
 // 2 = the spline stacks are evaluated at every use (debug kernels, whose grids are not sized by the cache)

@@ -306,12 +306,13 @@ __global__ __launch_bounds__(TR_BLOCK, ANIM ? TR_MIN_WAVES_ANIM : TR_MIN_WAVES) 
                     float t;
                     pixel_sample(kp, s, spp, px, py, sx, sy, t);
                     lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), key_sample(kp, s));
-                    if (ANIM) { ln.col = xf_cache_lane(); xf_cache_fill(sc, ln.time, ln.col); }   // the path's transforms of the moving instances, once per camera sample
+                    if (ANIM) ln.col = xf_cache_lane();
                     row_l = pix >> 3;
                     started = true;
                     pending = true;
                 }
             }
+            if (ANIM && idle_m != 0ull) xf_cache_fill_wave(sc, started, ln.time, ln.col);   // the paths' transforms of the moving instances, once per camera sample: the whole wave evaluates for the lanes that start one
             w_samples += (uint32_t)__popcll(__ballot(started));
             if (!__any(ln.flags & LF_ALIVE)) break;
             if (INTEG == TRAY_INTEGRATOR_WHITTED) {
