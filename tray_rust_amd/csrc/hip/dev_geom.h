@@ -166,6 +166,7 @@ TR_DEV void xf_cache_fill_wave(const DevScene& sc, bool started, float time, uin
             for (int q = 0; q < 26; ++q) dst[(size_t)q * lanes] = x[q];
         }
     }
+    __builtin_amdgcn_wave_barrier();   // (no instruction on the device, where a wave's lanes move together; the host emulation's lanes meet here)
     __threadfence_block();   // (a lane reads its column next: written by another lane of this wave)
 }
 // ANIM template values: 0 = nothing moves within the frame; 1 = moving instances are read from the per-path cache (tile and
