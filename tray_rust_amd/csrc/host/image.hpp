@@ -346,13 +346,14 @@ inline int jpeg_decode(JpegBits& br, const JpegHuff& h) {
     return 0;
 }
 inline int jpeg_extend(int v, int s) { return s == 0 ? 0 : (v < (1 << (s - 1)) ? v - (1 << s) + 1 : v); }
-inline uint8_t jpeg_clamp(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
-// stb_image's stbi__idct_block as jpeg-decoder ports it
+inline uint8_t jpeg_clamp(long long x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+// stb_image's stbi__idct_block as jpeg-decoder ports it. The arithmetic is 64 bits wide: a valid file's values stay far inside 32 bits
+// (same results), a corrupt file's coefficients must not overflow a signed int on the way to being clamped
 inline void jpeg_idct(const int* d, uint8_t* out, int stride) {
-    auto f2f = [](double x) { return (int)(x * 4096.0 + 0.5); };
-    int val[64];
+    auto f2f = [](double x) { return (long long)(x * 4096.0 + 0.5); };
+    long long val[64];
 #define TR_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                                          \
-    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                                \
+    long long t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                          \
     p2 = s2; p3 = s6; p1 = (p2 + p3) * f2f(0.5411961); t2 = p1 + p3 * f2f(-1.847759065); t3 = p1 + p2 * f2f(0.765366865); \
     p2 = s0; p3 = s4; t0 = (p2 + p3) * 4096; t1 = (p2 - p3) * 4096;                                        \
     x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                                                \
@@ -363,9 +364,9 @@ inline void jpeg_idct(const int* d, uint8_t* out, int stride) {
     t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
     for (int i = 0; i < 8; ++i) {   // columns
         const int* c = d + i;
-        int* v = val + i;
+        long long* v = val + i;
         if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
-            int dc = c[0] * 4;
+            const long long dc = (long long)c[0] * 4;
             v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
         } else {
             TR_IDCT_1D(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56])
@@ -375,10 +376,10 @@ inline void jpeg_idct(const int* d, uint8_t* out, int stride) {
         }
     }
     for (int i = 0; i < 8; ++i) {   // rows
-        const int* v = val + i * 8;
+        const long long* v = val + i * 8;
         uint8_t* o = out + i * stride;
         TR_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
-        x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
+        x0 += 65536 + (128ll << 17); x1 += 65536 + (128ll << 17); x2 += 65536 + (128ll << 17); x3 += 65536 + (128ll << 17);
         o[0] = jpeg_clamp((x0 + t3) >> 17); o[7] = jpeg_clamp((x0 - t3) >> 17); o[1] = jpeg_clamp((x1 + t2) >> 17); o[6] = jpeg_clamp((x1 - t2) >> 17);
         o[2] = jpeg_clamp((x2 + t1) >> 17); o[5] = jpeg_clamp((x2 - t1) >> 17); o[3] = jpeg_clamp((x3 + t0) >> 17); o[4] = jpeg_clamp((x3 - t0) >> 17);
     }
@@ -532,7 +533,8 @@ inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::str
                                             const int s = jpeg_decode(br, dc[k->td]);
                                             if (s > 11) { err = "JPEG: bad DC category"; return false; }
                                             k->dc_pred += jpeg_extend(br.receive(s), s);
-                                            c[0] = (int16_t)(k->dc_pred * (1 << al));
+                                            if (k->dc_pred > 32767 || k->dc_pred < -32768) { err = "JPEG: DC coefficient out of range"; return false; }   // (12 bits in a valid file; keeps the products below in range)
+                                            c[0] = (int16_t)((unsigned)k->dc_pred << al);
                                         } else if (br.bit()) c[0] = (int16_t)(c[0] | (1 << al));
                                     } else if (ah == 0) {   // AC first pass (G.1.2.2) with end-of-band runs
                                         if (eobrun > 0) --eobrun;
@@ -583,6 +585,7 @@ inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::str
                                 const int s = jpeg_decode(br, dc[k->td]);
                                 if (s > 11) { err = "JPEG: bad DC category"; return false; }
                                 k->dc_pred += jpeg_extend(br.receive(s), s);
+                                if (k->dc_pred > 32767 || k->dc_pred < -32768) { err = "JPEG: DC coefficient out of range"; return false; }   // (12 bits in a valid file; keeps the product in range)
                                 blk[0] = k->dc_pred * qt[k->tq][0];
                                 for (int i = 1; i < 64;) {
                                     const int rs = jpeg_decode(br, ac[k->ta]), r = rs >> 4, sz = rs & 15;
