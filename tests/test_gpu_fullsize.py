@@ -148,3 +148,41 @@ def test_c5_tr15_stand_in_full_detail_1080p_512spp(tmp_path):
               f"V {st.vertices / st.samples:.4f} (gpu {tim.vertices / tim.samples:.4f}), oracle {st.seconds:.1f}s")
         flip_split(scene, frame, 512, seed, f"   frame {frame} seed {seed}")
     assert worst < 1e-4, worst
+
+
+def test_rank_4_pieces_at_the_film_size_of_the_configs(tmp_path):
+    """SURVEY 8f rank 4 at 1920x1080: cornell_box under sampler::Adaptive::new(dim, 16, 128) and under sampler::Uniform, and the AnimatedMesh
+    scene at 64 spp -- every 64th tile through the shard entry point against the oracle on the same tiles. Adaptive's per-pixel decisions hang
+    on f32 luminances (ocml vs glibc in the last bits), so its sample total may differ in a pixel or two: 0.2 %, RMSE 1e-3; the other two
+    keep the 1e-4 / per-pixel bars of their small-film tests."""
+    import torch
+    scenes.write_assets(str(tmp_path), cornell=(W, H, 1024), small=(W, H, 4096))
+    scene, rt, spp, fi = T.Scene.load_file(str(tmp_path / "cornell_box.json"))
+    flat = scene.flatten(0)
+    dev = scene.device_scene(0, 0)
+
+    def strided(kind, lo, hi, stride, seed):
+        T.check(T.lib().tray_scene_set_sampler(dev, kind, lo, hi))
+        film = torch.zeros(W * H * 4, dtype=torch.float32, device="cuda")
+        T.check(T.lib().tray_render_shard_device(dev, 0, stride, 1, 1, seed, C.c_void_p(film.data_ptr()), None))
+        torch.cuda.synchronize()
+        return film.cpu().numpy().reshape(H, W, 4), T.Hip(0, seed=seed).timing(scene)
+
+    gpu, tim = strided(O.SAMPLER_ADAPTIVE, 16, 128, 64, 7)
+    cpu, st, counts = O.render_tiles_sampler(flat, O.SAMPLER_ADAPTIVE, 16, 128, seed=7, stride=64)
+    touched = cpu[..., 3] > 0
+    r = float(np.sqrt(np.mean((rgb(gpu) - rgb(cpu))[touched] ** 2)))
+    print(f"Adaptive(16, 128) 1080p, {(N_TILES + 63) // 64} tiles: GPU {tim.samples} samples, oracle {st.samples} (up to {counts.max()} per pixel), RMSE {r:.3e}, {tim.launches} launches")
+    assert abs(int(tim.samples) - int(st.samples)) <= 2e-3 * st.samples and counts.max() > 100 and r < 1e-3
+    gpu, tim = strided(O.SAMPLER_UNIFORM, 1, 1, 16, 7)
+    cpu, st, _ = O.render_tiles_sampler(flat, O.SAMPLER_UNIFORM, seed=7, stride=16)
+    d = np.abs(rgb(gpu) - rgb(cpu)).max(axis=-1)[cpu[..., 3] > 0]
+    assert tim.samples == st.samples and (d > 1e-3).mean() < 2e-3 and np.median(d) < 1e-6
+    T.check(T.lib().tray_scene_set_sampler(dev, O.SAMPLER_LOW_DISCREPANCY, 1, 1))
+    flag_scene, *_ = T.Scene.load_file(scenes.write_waving_flag(str(tmp_path / "flag"), grid=96, n_keys=4, width=W, height=H, samples=64))
+    gpu, tim = strided_gpu(flag_scene, 2, 64, 7, 64)
+    cpu, st = O.render_tiles(flag_scene.flatten(2), 64, seed=7, stride=64)
+    touched = cpu[..., 3] > 0
+    r = float(np.sqrt(np.mean((rgb(gpu) - rgb(cpu))[touched] ** 2)))
+    print(f"waving_flag (18 432 triangles x 4 keyframes) 1080p 64 spp: RMSE {r:.3e}, V {st.vertices / st.samples:.4f}")
+    assert tim.samples == st.samples and abs(int(tim.vertices) - int(st.vertices)) <= 1e-4 * st.vertices and r < 1e-4
