@@ -245,9 +245,12 @@ int emu_render_sampler(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_
             sp.before = j == 0u ? 0u : sp.min_spp + (j - 1u) * sp.step;
             const uint32_t per_tile = 64u * sp.count;
             const uint32_t grid = per_tile >= TR_BLOCK ? n_items * ((per_tile + TR_BLOCK - 1u) / TR_BLOCK) : (n_items * per_tile + TR_BLOCK - 1u) / TR_BLOCK;
-            if (deforming(f)) rc = launch_simt(grid, TR_BLOCK, [&] { k_sampler_pass<3>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
-            else if (moving) rc = launch_simt(grid, TR_BLOCK, [&] { k_sampler_pass<2>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
-            else rc = launch_simt(grid, TR_BLOCK, [&] { k_sampler_pass<0>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); });
+#define EMU_SAMPLER_PASS(A, F) rc = launch_simt(grid, TR_BLOCK, [&] { k_sampler_pass<A, F>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); })
+            const bool lean = feature_set(e) == FEAT_NONE && f->integrator != TRAY_INTEGRATOR_WHITTED;   // launch_sampler's choice of the instantiation
+            if (deforming(f)) { if (lean) EMU_SAMPLER_PASS(3, FEAT_NONE); else EMU_SAMPLER_PASS(3, FEAT_ALL | FEAT_TEX); }
+            else if (moving) { if (lean) EMU_SAMPLER_PASS(2, FEAT_NONE); else EMU_SAMPLER_PASS(2, FEAT_ALL | FEAT_TEX); }
+            else { if (lean) EMU_SAMPLER_PASS(0, FEAT_NONE); else EMU_SAMPLER_PASS(0, FEAT_ALL | FEAT_TEX); }
+#undef EMU_SAMPLER_PASS
             if (rc != 0) return -3;
             if (kind == TRAY_SAMPLER_ADAPTIVE)
                 launch((n_px + TR_BLOCK - 1) / TR_BLOCK, TR_BLOCK, [&] { k_sampler_decide(n_px, sp, px_state.data(), px_avg.data(), px_lum.data()); });

@@ -509,7 +509,9 @@ struct SamplerPass {
     uint32_t min_spp, max_spp, step;
     uint32_t lum_cap;       // luminance slots per pixel
 };
-template <int ANIM>
+// FEAT: the lobe set compiled in, as for the tile kernel -- none of the optional ones (FEAT_NONE: matte / plastic / metal scenes, the common
+// case) or all of them with textures (which also carries the Whitted integrator).
+template <int ANIM, int FEAT = FEAT_ALL | FEAT_TEX>
 __global__ __launch_bounds__(TR_BLOCK) void k_sampler_pass(const DevScene scv, const uint2* __restrict__ tiles, uint32_t item0, uint32_t n_items,
                                                            uint32_t chunk, uint32_t chunk_stride, uint32_t kf, SamplerPass sp,
                                                            const uint32_t* __restrict__ px_state, float* __restrict__ px_lum,
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_sampler_pass(const DevScene scv, c
     ln.smp_kind = sp.kind; ln.smp_offset = sp.taken;
     if (!active) ln.flags = 0u;
     uint32_t* const my_stack = s_stack + threadIdx.x;
-    if (sc.integrator == TRAY_INTEGRATOR_WHITTED) {
+    if (FEAT == (FEAT_ALL | FEAT_TEX) && sc.integrator == TRAY_INTEGRATOR_WHITTED) {
         Ray cam;
         cam.o = LN_O(ln); cam.d = ln.d; cam.min_t = 0.0f; cam.max_t = TR_INF; cam.time = ln.time; cam.col = ln.col;
         uint32_t wv = 0u, wr = 0u;
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_sampler_pass(const DevScene scv, c
                 tr_ = trace<ANIM>(scp, my_stack, r, stage == 1, want_ray);
             }
             if (stage == 1) {
-                vertex_queries<ANIM, FEAT_ALL | FEAT_TEX>(sc, ln, tr_.hit, alive);
+                vertex_queries<ANIM, FEAT>(sc, ln, tr_.hit, alive);
             } else if (alive) {
                 if (stage == 0) {
                     if (tr_.hit) vertex_begin<ANIM>(sc, ln, tr_.rec, cnt);
@@ -1256,6 +1258,7 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
                 reinterpret_cast<const void*>(k_debug_intersect<0>), reinterpret_cast<const void*>(k_debug_intersect<2>),
                 reinterpret_cast<const void*>(k_debug_sample_radiance<0>), reinterpret_cast<const void*>(k_debug_sample_radiance<2>),
                 reinterpret_cast<const void*>(k_sampler_pass<0>), reinterpret_cast<const void*>(k_sampler_pass<2>), reinterpret_cast<const void*>(k_sampler_pass<3>),
+                reinterpret_cast<const void*>(k_sampler_pass<0, FEAT_NONE>), reinterpret_cast<const void*>(k_sampler_pass<2, FEAT_NONE>), reinterpret_cast<const void*>(k_sampler_pass<3, FEAT_NONE>),
                 reinterpret_cast<const void*>(k_debug_intersect<3>), reinterpret_cast<const void*>(k_debug_sample_radiance<3>)};
             for (const void* k : traversing) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             (void)hipGetLastError();
@@ -1588,9 +1591,12 @@ static int launch_sampler(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile
             sp.before = j == 0u ? 0u : sp.min_spp + (j - 1u) * sp.step;
             const uint32_t per_tile = 64u * sp.count;   // (k_sampler_pass: whole blocks per tile, or several tiles per block for small rounds)
             const dim3 grid(per_tile >= TR_BLOCK ? n_items * ((per_tile + TR_BLOCK - 1u) / TR_BLOCK) : (n_items * per_tile + TR_BLOCK - 1u) / TR_BLOCK), block(TR_BLOCK);
-            if (s->deforming) hipLaunchKernelGGL(k_sampler_pass<3>, grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats);
-            else if (s->animated) hipLaunchKernelGGL(k_sampler_pass<2>, grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats);
-            else hipLaunchKernelGGL(k_sampler_pass<0>, grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats);
+#define SAMPLER_PASS(A, F) hipLaunchKernelGGL((k_sampler_pass<A, F>), grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats)
+            const bool lean = s->feat == FEAT_NONE && s->dev.integrator != TRAY_INTEGRATOR_WHITTED;   // (no optional lobe, no texture: the small instantiation)
+            if (s->deforming) { if (lean) SAMPLER_PASS(3, FEAT_NONE); else SAMPLER_PASS(3, FEAT_ALL | FEAT_TEX); }
+            else if (s->animated) { if (lean) SAMPLER_PASS(2, FEAT_NONE); else SAMPLER_PASS(2, FEAT_ALL | FEAT_TEX); }
+            else { if (lean) SAMPLER_PASS(0, FEAT_NONE); else SAMPLER_PASS(0, FEAT_ALL | FEAT_TEX); }
+#undef SAMPLER_PASS
             ++launches;
             if (sp.kind == TRAY_SAMPLER_ADAPTIVE) {
                 hipLaunchKernelGGL(k_sampler_decide, dim3((n_px + TR_BLOCK - 1) / TR_BLOCK), block, 0, stream, n_px, sp, px_state, px_avg, px_lum);
