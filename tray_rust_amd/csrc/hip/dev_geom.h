@@ -172,8 +172,8 @@ TR_DEV void xf_cache_fill_wave(const DevScene& sc, bool started, float time, uin
 // ANIM template values: 0 = nothing moves within the frame; 1 = moving instances are read from the per-path cache (tile and
 // wavefront kernels: no function call in their hot loops, a call would raise their register allocation to the callee's);
 // 2 = the spline stacks are evaluated at every use (debug kernels, whose grids are not sized by the cache)
-// 3 = as 2, and the scene may hold AnimatedMeshes: Scene::intersect is the reference's two-level traversal with the triangles of such a
-//     mesh interpolated at ray.time (trace_bvh, finish_hit); the scenes' renders go through k_sampler_pass<3> whatever the sampler
+// 3 = as 2, and the scene may hold AnimatedMeshes: the triangles of such a mesh are interpolated at ray.time in the flat loop's mesh traversal,
+//     in the two-level traversal and in finish_hit; the scenes' renders go through k_sampler_pass<3> whatever the sampler
 // rows of inv and its [3][3] only (x + 12 .. x + 24 are written)
 template <int ANIM>
 TR_DEV void instance_inv_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, uint32_t column, float* x) {
@@ -445,8 +445,10 @@ TR_DEV uint32_t nd_axis(uint32_t desc) { return (desc >> 28) & 3u; }
 #ifndef TR_WW_NODE_MIN
 #define TR_WW_NODE_MIN 12
 #endif
+// DEFORM (ANIM = 3 kernels only): the mesh is an AnimatedMesh, its triangles are taken at the ray's time (`keys`, see active_keyframes)
+template <int DEFORM = 0>
 TR_DEV bool mesh_traverse_ww(const DevScene& sc, uint32_t* __restrict__ stack, const TrayMesh m, bool participate, f3 o, f3 d, float min_t, float& max_t,
-                             bool any_hit, uint32_t& prim, float& b1, float& b2, float& leaf_tmin) {
+                             bool any_hit, uint32_t& prim, float& b1, float& b2, float& leaf_tmin, KeyPair keys = KeyPair{0u, 0u, 0.0f}) {
     const TrayBvhNode* __restrict__ tree = sc.mesh_nodes + m.node_offset;
     const TrayTriVerts* __restrict__ tris = sc.tri_verts + m.tri_offset;
     const f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -498,7 +500,8 @@ TR_DEV bool mesh_traverse_ww(const DevScene& sc, uint32_t* __restrict__ stack, c
             bool stop = false;
             for (uint32_t k = 0; k < leaf_count; ++k) {
                 float t, bb1, bb2;
-                if (triangle_test(tris + leaf_offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
+                if (DEFORM ? key_triangle_test(tris + leaf_offset + k, m.tri_count, keys, o, d, min_t, max_t, t, bb1, bb2)
+                           : triangle_test(tris + leaf_offset + k, o, d, min_t, max_t, t, bb1, bb2)) {
                     max_t = t; prim = m.tri_offset + leaf_offset + k; b1 = bb1; b2 = bb2; any = true;
                     leaf_tmin = leaf_t;
                     if (any_hit) { stop = true; break; }
@@ -738,9 +741,11 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
                 // small mesh: the whole wave enters, lanes without a pending ray only lend their ALUs
                 const LdsF w_lds = TR_LDS_F(stack - threadIdx.x + sc.coop_offset) + (threadIdx.x >> 6) * TR_COOP_WORDS;
                 hit = mesh_leaf_coop(sc, sc.meshes[mesh_id], w_lds, wanted, o, d, min_t, gate_max_t, bound, t, prim, b1, b2, leaf_t, hz);
-            } else if (gt == TRAY_GEOM_MESH) {   // (the instance is wave-uniform: the whole wave enters the while-while traversal)
+            } else if (gt == TRAY_GEOM_MESH || (ANIM == 3 && gt == TRAY_GEOM_ANIMATED_MESH)) {   // (the instance is wave-uniform: the whole wave enters the while-while traversal)
                 float mt = gate_max_t;   // the mesh's own traversal, from the original max_t
-                hit = mesh_traverse_ww(sc, stack, sc.meshes[mesh_id], wanted, o, d, min_t, mt, any_hit, prim, b1, b2, leaf_t) && mt <= bound;
+                if (ANIM == 3 && gt == TRAY_GEOM_ANIMATED_MESH)   // AnimatedMesh::intersect: the same traversal over its one tree, triangles at ray.time
+                    hit = mesh_traverse_ww<1>(sc, stack, sc.meshes[mesh_id], wanted, o, d, min_t, mt, any_hit, prim, b1, b2, leaf_t, active_keyframes(sc, mesh_id, ray.time)) && mt <= bound;
+                else hit = mesh_traverse_ww(sc, stack, sc.meshes[mesh_id], wanted, o, d, min_t, mt, any_hit, prim, b1, b2, leaf_t) && mt <= bound;
                 t = mt;
             } else if (wanted) {
                 if (gt == TRAY_GEOM_RECT) hit = rect_test(gp0, gp1, o, d, min_t, bound, t);
@@ -905,7 +910,7 @@ TR_DEV TraceResult trace(const DevScene* __restrict__ scp, uint32_t* __restrict_
     r.rec.t = 0.0f; r.rec.inst = 0xffffffffu; r.rec.prim = 0u; r.rec.b1 = 0.0f; r.rec.b2 = 0.0f;
     // (moving scenes too since round 4: the flat loop's gates are the boxes of the BVH<Instance> leaves -- for a moving scene the reference's
     // swept bounds of animated_transform.rs:58-71 with quirk Q12 -- so it reaches exactly the instances the reference's traversal can reach)
-    if (ANIM != 3 && sc.n_instances <= TR_FLAT_MAX) {
+    if (sc.n_instances <= TR_FLAT_MAX) {
         bool hazard = false;
         r.hit = trace_flat<ANIM>(sc, stack, ray, any_hit, active, r.rec, hazard);
         if (__any(hazard)) {   // (about one ray in 1e7: tied candidates, or a box entered behind its own hit) the reference's traversal decides

@@ -311,7 +311,7 @@ inline void flat_loop_gates(const TrayFlatScene* f, const PairedTrees& paired, u
             if (in.geom_type == TRAY_GEOM_RECT) { olo[0] = -0.5f * std::fabs(in.geom_params[0]); ohi[0] = -olo[0]; olo[1] = -0.5f * std::fabs(in.geom_params[1]); ohi[1] = -olo[1]; }
             else if (in.geom_type == TRAY_GEOM_SPHERE) { for (int k = 0; k < 3; ++k) { olo[k] = -std::fabs(in.geom_params[0]); ohi[k] = std::fabs(in.geom_params[0]); } }
             else if (in.geom_type == TRAY_GEOM_DISK) { for (int k = 0; k < 2; ++k) { olo[k] = -std::fabs(in.geom_params[0]); ohi[k] = std::fabs(in.geom_params[0]); } }
-            else if (in.geom_type == TRAY_GEOM_MESH && in.mesh_id < f->n_meshes && f->meshes[in.mesh_id].node_count) {
+            else if ((in.geom_type == TRAY_GEOM_MESH || in.geom_type == TRAY_GEOM_ANIMATED_MESH) && in.mesh_id < f->n_meshes && f->meshes[in.mesh_id].node_count) {   // (an AnimatedMesh: the root of its one tree -- nothing outside it is ever reached, quirk Q13)
                 const TrayBvhNode& root = f->mesh_nodes[f->meshes[in.mesh_id].node_offset];
                 for (int k = 0; k < 3; ++k) { olo[k] = root.bmin[k]; ohi[k] = root.bmax[k]; }
             }
