@@ -33,6 +33,11 @@ def _worker(rank, world, port, scene_path, out_path, renderer="oracle"):
             import _emu as E
             tiles = np.array(T.BlockQueue((rt.width, rt.height), (8, 8)).blocks, np.uint32).reshape(-1, 2)
             acc, _ = E.render_tiles(flat, tiles, spp, 11, blocks=2, shard=(r, w, 3))
+        elif renderer == "emu_adaptive":   # sampler::Adaptive(2, 16): k_sampler_pass / k_sampler_decide over the rank's tiles (every number keyed by pixel, round, index)
+            import _emu as E
+            tiles = np.array(T.BlockQueue((rt.width, rt.height), (8, 8)).blocks, np.uint32).reshape(-1, 2)
+            mine = tiles[multi.shard_tiles(n_tiles, r, w, chunk_tiles=3)]
+            acc, _ = E.render_sampler(flat, mine, O.SAMPLER_ADAPTIVE, 2, 16, seed=11)
         else:
             for t in multi.shard_tiles(n_tiles, r, w, chunk_tiles=3):
                 img, _ = O.render_tiles(flat, spp, seed=11, tile_start=t, tile_count=1, threads=1)
@@ -47,7 +52,7 @@ def _worker(rank, world, port, scene_path, out_path, renderer="oracle"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("renderer", ["oracle", "emu"])
+@pytest.mark.parametrize("renderer", ["oracle", "emu", "emu_adaptive"])
 def test_two_rank_sharded_frame_equals_single_process(renderer, tmp_path, built):
     import torch.multiprocessing as mp
     import tray_rust_amd as T
@@ -58,13 +63,18 @@ def test_two_rank_sharded_frame_equals_single_process(renderer, tmp_path, built)
     json.dump(scenes.cornell_box(48, 32, 8), open(scene_path, "w"))
     out_path = os.path.join(str(tmp_path), "merged.npy")
     port = 29500 + os.getpid() % 2000
-    if renderer == "emu":
+    if renderer != "oracle":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import _emu as E
         E.emu()   # build the emulation library once, before two processes race for it
     mp.spawn(_worker, args=(2, port, scene_path, out_path, renderer), nprocs=2, join=True)
     merged = np.load(out_path).reshape(32, 48, 4)
     scene, *_ = T.Scene.load_file(scene_path)
+    if renderer == "emu_adaptive":   # the same Sampler in ONE process: the oracle's thread_work over the whole block queue
+        whole, st, counts = O.render_tiles_sampler(scene.flatten(0), O.SAMPLER_ADAPTIVE, 2, 16, seed=11)
+        assert counts.max() > 2
+        np.testing.assert_allclose(merged, whole, rtol=5e-5, atol=5e-5)
+        return
     whole, _ = O.render_tiles(scene.flatten(0), 8, seed=11)
     # (the emulated tile kernel bins the film by rows: same sums grouped differently, a few ulps of the largest pixel value)
     diff = float(np.abs(merged - whole).max())
