@@ -222,3 +222,14 @@ def test_gaussian_filter_table(tmp_path, built):
     gy = np.maximum(0, np.exp(-1.25 * fy.astype(np.float64) ** 2) - np.exp(-1.25 * 2.0 ** 2))
     assert np.allclose(tab, np.outer(gy, gx), rtol=2e-6, atol=1e-7)
     assert (film.filter_pixel_w, film.filter_pixel_h, film.separable) == (3, 4, 1)
+
+
+def test_the_flat_view_keeps_its_scene_alive(tmp_path, built):
+    """Scene.flatten() returns a view that borrows from the host scene: the Python pointer holds a reference, so a temporary Scene cannot be
+    collected under it (round 4: tests/golden/make_golden.py crashed exactly there)."""
+    import gc
+    from tray_rust_amd import scenes
+    scenes.write_assets(str(tmp_path), cornell=(32, 24, 4), small=(32, 24, 4))
+    flat = T.Scene.load_file(str(tmp_path / "cornell_box.json"))[0].flatten(0)
+    gc.collect()
+    assert flat.contents.n_instances == 8 and flat.contents.film.width == 32

@@ -162,9 +162,11 @@ class Scene:
         return s, RenderTarget(i.width, i.height), int(i.spp), FrameInfo(i.frames, i.scene_time, i.start_frame, i.end_frame)
 
     def flatten(self, frame=0):
-        """Scene::update_frame + lowering to the TrayFlatScene POD (borrowed from this scene)."""
+        """Scene::update_frame + lowering to the TrayFlatScene POD. The view borrows from this scene -- it is valid until the next
+        flatten() / close() -- so the returned pointer keeps the scene alive (`T.Scene.load_file(p)[0].flatten(0)` must not dangle)."""
         p = C.POINTER(_lib.TrayFlatScene)()
         check(lib().tray_host_scene_flatten(self._h, int(frame), C.byref(p)))
+        p._scene = self
         return p
 
     def device_scene(self, frame=0, device=None):
