@@ -823,3 +823,23 @@ def test_gpu_matches_the_rank_4_golden(tmp_path):
     assert rmse(gpu, g["uniform"]) < 1e-3 and abs(int(tim.vertices) - int(g["uniform_vertices"])) <= 3
     gpu, tim = gpu_render_sampler(cornell, rt2, lambda dim, spp: T.sampler.Adaptive(dim, 4, 32), fi2, seed=9)
     assert abs(int(tim.samples) - int(g["adaptive_samples"])) <= 0.01 * int(g["adaptive_samples"]) and rmse(gpu, g["adaptive"]) < 2e-3
+
+
+def test_gpu_other_samplers_with_every_lobe_and_with_whitted(tmp_path):
+    """the full instantiation of the sampler kernel (optional lobes, textures, the Whitted integrator): a textured scene and smallpt-Whitted under
+    Adaptive and Uniform against the oracle"""
+    scene, rt, _, fi = T.Scene.load_file(scenes.write_textured_box(str(tmp_path / "t"), width=96, height=64, samples=8))
+    flat = scene.flatten(0)
+    gpu, tim = gpu_render_sampler(scene, rt, lambda dim, spp: T.sampler.Adaptive(dim, 4, 16), fi, seed=8)
+    cpu, st, counts = O.render_tiles_sampler(flat, O.SAMPLER_ADAPTIVE, 4, 16, seed=8)
+    assert abs(int(tim.samples) - int(st.samples)) <= 0.01 * st.samples and counts.max() > 4 and rmse(gpu, cpu) < 2e-3
+    scenes.write_assets(str(tmp_path), cornell=(96, 64, 8), small=(96, 64, 8))
+    doc = json.load(open(tmp_path / "smallpt.json"))
+    doc["integrator"]["type"] = "whitted"
+    json.dump(doc, open(tmp_path / "w.json", "w"))
+    scene, rt, _, fi = T.Scene.load_file(str(tmp_path / "w.json"))
+    flat = scene.flatten(0)
+    for make, kind, args, bar in ((lambda dim, spp: T.sampler.Adaptive(dim, 2, 8), O.SAMPLER_ADAPTIVE, (2, 8), 2e-3), (lambda dim, spp: T.sampler.Uniform(dim), O.SAMPLER_UNIFORM, (1, 1), 2e-3)):
+        gpu, tim = gpu_render_sampler(scene, rt, make, fi, seed=8)
+        cpu, st, _ = O.render_tiles_sampler(flat, kind, *args, seed=8)
+        assert abs(int(tim.samples) - int(st.samples)) <= 0.01 * st.samples and rmse(gpu, cpu) < bar, (kind, rmse(gpu, cpu))
