@@ -452,7 +452,12 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
         if (f->instances[i].animated) ++n_moving;
     }
     e.d.film_rows = film_rows_ok(f) ? 1u : 0u;
-    n_chunks = std::max(1u, std::min(n_chunks, tile_count));
+    // launch_wavefront's rule: tiles are cut into slices of their samples while the pool has more chunks than work items (k_wf_advance)
+    uint32_t slice_shift = 0u;
+    while ((1u << (slice_shift + 1u)) <= 4u && ((uint64_t)tile_count << slice_shift) * 3u / 2u <= n_chunks && (spp >> (slice_shift + 1u)) >= 16u) ++slice_shift;
+    if (const char* sl = getenv("TRAYHIP_WF_SLICES")) { slice_shift = 0u; while ((2u << slice_shift) <= (uint32_t)std::max(1, atoi(sl)) && (2u << slice_shift) <= 4u && (spp >> (slice_shift + 1u)) >= 1u) ++slice_shift; }
+    const uint32_t n_items = tile_count << slice_shift;
+    n_chunks = std::max(1u, std::min(n_chunks, n_items));
     const uint32_t n_slots = n_chunks * TR_BLOCK, n_active = n_slots;
     std::vector<float> pool_data((size_t)F_COUNT * n_slots, 0.0f);
     WfPool pool{pool_data.data(), n_slots, wf_seg_cap(n_chunks)};
@@ -490,15 +495,15 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     std::vector<uint32_t> kind_queues((size_t)WF_MAT_KINDS * q_cap, 0u);
     uint32_t kinds_present = 0;
     for (const DevMaterial& dm : e.mats) kinds_present |= 1u << dm.mat_kind;
-    const uint64_t max_rounds = (uint64_t)((tile_count + n_chunks - 1) / n_chunks) * (((uint64_t)spp + 3) / 4 * (e.d.max_depth + 3) + 4) + 32;
+    const uint64_t max_rounds = (uint64_t)((n_items + n_chunks - 1) / n_chunks) * (((uint64_t)spp + 3) / 4 * (e.d.max_depth + 3) + 4) + 32;
     int rc = 0;
     uint64_t rounds = 0;
 #define EMU_K(...) do { if (rc == 0) rc = launch_simt(__VA_ARGS__); } while (0)
 #define EMU_ROUND(A, F)                                                                                                                     \
     do {                                                                                                                                    \
-        EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_advance<A>(e.d, pool, chunks.data(), bins.data(), tiles.data(), tile_count, tile_count, 1u, spp, kf, rgbw, \
-                                                         counters, counters + 1, stats.data(), qa, qr, qctl); });                          \
-        EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_regen<A>(e.d, pool, chunks.data(), tiles.data(), tile_count, 1u, spp, kf, stats.data(), qr, qa, qctl); }); \
+        EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_advance<A>(e.d, pool, chunks.data(), bins.data(), tiles.data(), n_items, tile_count, 1u, spp, kf, rgbw, \
+                                                         counters, counters + 1, stats.data(), qa, qr, qctl, slice_shift); });                          \
+        EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_regen<A>(e.d, pool, chunks.data(), tiles.data(), tile_count, 1u, spp, kf, stats.data(), qr, qa, qctl, slice_shift); }); \
         EMU_TRACE_STAGE(0, A, qa);                                                                                                          \
         EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_begin<A>(e.d, pool, n_active, stats.data(), qb, qctl, sorted ? kind_queues.data() : nullptr); }); \
         EMU_TRACE_STAGE(1, A, qb);                                                                                                          \
@@ -521,7 +526,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
         else if (feat == FEAT_SPEC) EMU_ROUND(A, FEAT_SPEC); else if (feat == (FEAT_MERL | FEAT_SPEC)) EMU_ROUND(A, FEAT_MERL | FEAT_SPEC);  \
         else if (feat == (FEAT_ALL | FEAT_TEX)) EMU_ROUND(A, FEAT_ALL | FEAT_TEX); else EMU_ROUND(A, FEAT_ALL);                                                                                                        \
     } while (0)
-    while (rc == 0 && counters[1] < tile_count) {
+    while (rc == 0 && counters[1] < n_items) {
         std::memset(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t));
         if (moving) EMU_ROUND_F(1); else EMU_ROUND_F(0);
         if (++rounds > max_rounds) rc = -5;   // "wavefront schedule did not terminate"

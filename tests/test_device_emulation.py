@@ -443,6 +443,26 @@ def test_wavefront_schedule_emulated_as_simt(name, frame, trace, tmp_path, tr15_
     assert np.abs(img[..., 3] - ref[..., 3]).max() < 1e-4 * ref[..., 3].max()
 
 
+@pytest.mark.parametrize("slices", [2, 4])
+def test_wavefront_schedule_with_tiles_cut_into_sample_slices(slices, tmp_path, built, monkeypatch):
+    """launch_wavefront cuts the tiles' samples into work items when the pool has more chunks than the launch has tiles (round 4: the
+    schedule's rate grows with the slots in flight). 12 tiles as 24 / 48 items over 17 chunks: two chunks of the same tile resolve their row
+    bins separately, the (pixel, sample) pairs of a slice start at the slice's first sample -- same samples, vertices, rays, image."""
+    w, h, spp = 32, 24, 8
+    scenes.write_moving_box(str(tmp_path), width=w, height=h, samples=spp)
+    scene, *_ = T.Scene.load_file(str(tmp_path / "moving_box.json"))
+    flat = scene.flatten(3)
+    monkeypatch.setenv("TRAYHIP_WF_SLICES", str(slices))
+    img, (samples, vertices, rays, rounds) = E.render_wavefront(flat, tile_queue(w, h), spp, 5, n_chunks=17, trace_blocks=2, lds_depth=4)
+    monkeypatch.delenv("TRAYHIP_WF_SLICES")
+    ref, st = O.render_tiles(flat, spp, seed=5)
+    assert samples == st.samples == w * h * spp and (vertices, rays) == (st.vertices, st.rays)
+    assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6
+    assert np.abs(img[..., 3] - ref[..., 3]).max() < 1e-4 * ref[..., 3].max()
+    one, _ = E.render_wavefront(flat, tile_queue(w, h), spp, 5, n_chunks=17, trace_blocks=2, lds_depth=4)      # whole tiles: 12 of the 17 chunks busy
+    assert np.abs(img - one).max() < 1e-5 * one.max()
+
+
 def test_random_scene_sweep_of_the_per_sample_path(tmp_path, built):
     """60 random static scenes (tests/_random_scenes.py: all material kinds, spheres / disks / rectangles / meshes with texture
     coordinates, point and area lights, nested groups, every transform op, both filters, depths 0..10), 1000 camera samples

@@ -811,9 +811,12 @@ static int upload(TrayDeviceScene* s, const char* key, bool unchanged, const T* 
 
 
 #ifndef WF_SLOTS
-#define WF_SLOTS (8u << 20)   // path pool slots (2.2 GB of pool at 66 fields): measured 36.6 / 45.2 / 53.1 Msamples/s at 2 / 4 / 8 M on the C5
+#define WF_SLOTS (16u << 20)  // path pool slots (4.4 GB of pool at 66 fields): measured 78 / 106 / 132 Msamples/s at 2 / 4 / 8 M on the C5 (round 4;
 #endif                        // stand-in: every stage kernel ends with the tail of its slowest rays, fewer and larger rounds pay it less often
 #define WF_POLL 16
+#ifndef WF_MAX_SLICES
+#define WF_MAX_SLICES 4u   // work items a tile's samples are cut into at most (k_wf_advance): the pool may hold that many chunks per tile
+#endif
 // one round of the wavefront schedule: advance -> regen -> trace A -> begin -> trace B -> query -> trace C (compacted ray queues, persistent
 // traversal with dynamic fetch, kind-pure shading over the material sort's queues; scenes with textured materials, whose lobes
 // exist per hit only, shade unsorted in the one instantiation that lowers them)
@@ -832,15 +835,15 @@ struct WfView {
 };
 template <int ANIM>
 static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride, uint32_t spp,
-                     uint32_t kf, float* rgbw_dev) {
+                     uint32_t kf, float* rgbw_dev, uint32_t slice_shift) {
     const dim3 grid(v.n_chunks), block(TR_BLOCK);
     const dim3 qgrid((v.n_chunks + WF_SEGS - 1u) / WF_SEGS * WF_SEGS);   // one-thread-per-entry kernels: block b reads segment b % WF_SEGS
     const dim3 tgrid(std::min<uint32_t>(s->n_blocks_trace, v.n_chunks));
     const uint32_t n_active = v.n_chunks * TR_BLOCK;
     hipStream_t stream = v.stream;
     hipLaunchKernelGGL(k_wf_advance<ANIM>, grid, block, 0, stream, v.dev, v.pool, v.chunks, v.bins, tiles, tile_count, chunk, chunk_stride,
-                       spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, v.qa, v.qr, v.qctl);
-    hipLaunchKernelGGL(k_wf_regen<ANIM>, qgrid, block, 0, stream, v.dev, v.pool, v.chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, v.qr, v.qa, v.qctl);
+                       spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, v.qa, v.qr, v.qctl, slice_shift);
+    hipLaunchKernelGGL(k_wf_regen<ANIM>, qgrid, block, 0, stream, v.dev, v.pool, v.chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, v.qr, v.qa, v.qctl, slice_shift);
     // (each traversal is followed by the few-thread kernel that traces the rays it handed over to the reference's binary traversal:
     // direction components that are zero / denormal / not finite -- normally none, the kernel reads one word and exits)
     const dim3 fgrid(8);
@@ -859,20 +862,21 @@ static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, ui
     hipLaunchKernelGGL((k_wf_trace_fallback<2, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.fallback);
 }
 
-// Path pool slots of the wavefront schedule: never more than the film has pixels x 4 (one chunk of 256 per tile), and for moving
-// scenes never more than the per-path transform cache (n_moving x 96 B per slot) can hold within a quarter of the device's
-// free memory -- 64 moving instances at 8 M slots would be 51 GB, although a few hundred thousand slots already fill the chip
+// Path pool slots of the wavefront schedule: never more than the film has pixels x 4 x WF_MAX_SLICES (a chunk of 256 per tile slice), and for
+// moving scenes never more than the per-path transform cache (n_moving x 112 B per slot) can hold within two fifths of the device's
+// free memory -- 59 moving instances at 16 M slots are 106 GB; a few hundred thousand slots already fill the chip, but every stage kernel
+// ends with the tail of its slowest rays and fewer, larger rounds pay it less often
 // reclaimable: bytes a frame update's donor still holds that the new frame either takes over or frees (its pool and transform cache):
 // they count as free, or the budget -- and with it the pool size -- would depend on which frame came first
 static uint32_t wf_slot_count(const TrayDeviceScene* s, size_t reclaimable = 0) {
     uint32_t n_slots = WF_SLOTS;
     if (const char* e = getenv("TRAYHIP_WF_SLOTS")) n_slots = (uint32_t)std::max(256l, atol(e)) / TR_BLOCK * TR_BLOCK;
-    const uint64_t by_tiles = (uint64_t)std::max<uint32_t>(s->n_tiles, 1u) * TR_BLOCK;
+    const uint64_t by_tiles = (uint64_t)std::max<uint32_t>(s->n_tiles, 1u) * TR_BLOCK * WF_MAX_SLICES;   // (a tile's samples can be cut into that many work items: launch_wavefront)
     uint64_t slots = std::min<uint64_t>(n_slots, by_tiles);
     if (s->animated && s->deferred_n_moving > 0) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
-        uint64_t budget = (free_b + reclaimable) / 4;
+        uint64_t budget = (free_b + reclaimable) / 5 * 2;   // (two fifths: 59 moving instances at 16 M slots are 106 GB of the 288)
         if (const char* e = getenv("TRAYHIP_XF_CACHE_BYTES")) budget = (uint64_t)std::max(0ll, atoll(e));
         const uint64_t per_slot = (uint64_t)s->deferred_n_moving * TR_XF_WORDS * sizeof(float);
         const uint64_t fit = budget / per_slot / TR_BLOCK * TR_BLOCK;
@@ -1431,6 +1435,13 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
         HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s->h_done), sizeof(uint32_t), hipHostMallocDefault));
         s->wf_ready = true;
     }
+    // tiles are cut into slices of their samples while the pool has at least half again as many chunks as the launch has work items
+    // (k_wf_advance; a slice costs its own film resolve: at 8 M slots and 32 400 tiles halving them measured 124 against 132 Msamples/s); a
+    // slice keeps at least 16 samples per pixel (TRAYHIP_WF_SLICES overrides: 1, 2, 4)
+    uint32_t slice_shift = 0u;
+    while ((1u << (slice_shift + 1u)) <= WF_MAX_SLICES && ((uint64_t)tile_count << slice_shift) * 3u / 2u <= s->n_chunks && (spp >> (slice_shift + 1u)) >= 16u) ++slice_shift;
+    if (const char* e = getenv("TRAYHIP_WF_SLICES")) { slice_shift = 0u; while ((2u << slice_shift) <= (uint32_t)std::max(1, atoi(e)) && (2u << slice_shift) <= WF_MAX_SLICES && (spp >> (slice_shift + 1u)) >= 1u) ++slice_shift; }
+    tile_count <<= slice_shift;   // from here on: work items
     const uint32_t n_chunks = std::min(s->n_chunks, tile_count);
     HIP_CHECK(hipMemsetAsync(s->d_wf_counters, 0, 2 * sizeof(uint32_t), stream));
         {   // chunks start in WF_TILE_NEED with done = 0
@@ -1485,14 +1496,14 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     }
     // every chunk needs at most (spp/4 rounded up) samples x (max_depth + 2) rounds per tile, plus one round per tile switch
     const uint64_t tiles_per_chunk = (tile_count + n_chunks - 1) / n_chunks;
-    const uint64_t max_rounds = tiles_per_chunk * (((uint64_t)spp + 3) / 4 * (s->dev.max_depth + 3) + 4) + 2 * WF_POLL;
+    const uint64_t max_rounds = tiles_per_chunk * (((uint64_t)(spp >> slice_shift) + 3) / 4 * (s->dev.max_depth + 3) + 4) + 2 * WF_POLL;
     bool done = false;
     for (uint32_t round = 0; !done; ++round) {
         for (uint32_t k = 0; k < n_views; ++k) {
             const WfView& v = views[k];
             HIP_CHECK(hipMemsetAsync(v.qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), v.stream));
-            if (s->animated) wf_round<1>(s, v, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev);
-            else wf_round<0>(s, v, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev);
+            if (s->animated) wf_round<1>(s, v, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, slice_shift);
+            else wf_round<0>(s, v, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, slice_shift);
             launches += 10;
         }
         if (round % WF_POLL == WF_POLL - 1) {

@@ -775,7 +775,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query_kind(const DevScene scv, 
 template <int ANIM>
 TR_DEV void wf_regenerate(const DevScene& sc, const WfPool& pool, uint32_t i, uint32_t tile_idx, const uint2* __restrict__ tiles, uint32_t chunk,
                           uint32_t chunk_stride, uint32_t spp, uint32_t kf, DevStats* __restrict__ stats, f3& ray_o, f3& ray_d) {
-    // F_SNEXT: the (pixel, sample) pair k_wf_advance handed to this slot: pixel = pair % 64 in Region order, sample = pair / 64
+    // F_SNEXT: the (pixel, sample) pair k_wf_advance handed to this slot: pixel = pair % 64 in Region order, sample = pair / 64 (the slice's
+    // first sample included: tile_idx is the TILE here, the caller has shifted the slice bits of the work item out)
     const uint32_t pair = pu(pool, F_SNEXT, i), pix = pair & 63u, s_next = pair >> 6;
     const uint2 tile = tiles[(tile_idx / chunk) * chunk_stride * chunk + (tile_idx % chunk)];
     const uint32_t px = tile.x * 8u + (pix & 7u), py = tile.y * 8u + (pix >> 3);
@@ -798,12 +799,13 @@ TR_DEV void wf_regenerate(const DevScene& sc, const WfPool& pool, uint32_t i, ui
 template <int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_regen(const DevScene scv, WfPool pool, const WfChunk* __restrict__ chunks, const uint2* __restrict__ tiles,
                                                        uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf, DevStats* __restrict__ stats,
-                                                       const uint32_t* __restrict__ queue_r, uint32_t* __restrict__ queue_a, uint32_t* __restrict__ qctl) {
+                                                       const uint32_t* __restrict__ queue_r, uint32_t* __restrict__ queue_a, uint32_t* __restrict__ qctl,
+                                                       uint32_t slice_shift) {
     const DevScene& sc = scv;
     uint32_t i;
     if (!wf_my_entry(pool, queue_r, qctl, 6u, i)) return;
     f3 ray_o, ray_d;
-    wf_regenerate<ANIM>(sc, pool, i, chunks[i / TR_BLOCK].tile, tiles, chunk, chunk_stride, spp, kf, stats, ray_o, ray_d);
+    wf_regenerate<ANIM>(sc, pool, i, chunks[i / TR_BLOCK].tile >> slice_shift, tiles, chunk, chunk_stride, spp, kf, stats, ray_o, ray_d);
     pu(pool, F_FLAGS, i) = LF_ALIVE;
     wf_enqueue_ray(pool, queue_a, qctl, 0u, true, i, ray_o, ray_d, LF_ALIVE | WF_CAMERA_RAY);
 }
@@ -817,7 +819,12 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ tile_counter,
                                                          uint32_t* __restrict__ tiles_done, DevStats* __restrict__ stats,
                                                          uint32_t* __restrict__ queue_a, uint32_t* __restrict__ queue_r,
-                                                         uint32_t* __restrict__ qctl) {
+                                                         uint32_t* __restrict__ qctl, uint32_t slice_shift) {
+    // A work item is a SLICE of a tile: samples [slice, slice + 1) * (spp >> slice_shift) of its 64 pixels (item = tile << slice_shift | slice;
+    // tile_count counts items). The film is a sum and every sample is keyed by pixel and index, so the slices of a tile are independent:
+    // launch_wavefront cuts tiles when the pool has more chunks than the launch has tiles -- the schedule's rate grows with the slots in flight
+    // (C5 stand-in 78 / 106 / 132 Msamples/s at 2 / 4 / 8 M slots), and one chunk per tile capped them at 4 per pixel.
+    const uint32_t s_per = spp >> slice_shift, n_pairs = 64u * s_per;
     __shared__ float s_win[4 * WIN_PLANE];
     __shared__ float s_table[TRAY_FILTER_TABLE_SIZE * TRAY_FILTER_TABLE_SIZE];
     __shared__ float s_tx[TRAY_FILTER_TABLE_SIZE], s_ty[TRAY_FILTER_TABLE_SIZE];
@@ -839,7 +846,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
     if (tile_idx == WF_TILE_IDLE) return;
     const bool film_rows = sc.film_rows != 0u;
     if (tile_idx != WF_TILE_NEED) {
-        const uint2 tile = tiles[(tile_idx / chunk) * chunk_stride * chunk + (tile_idx % chunk)];
+        const uint32_t tile_of = tile_idx >> slice_shift;
+        const uint2 tile = tiles[(tile_of / chunk) * chunk_stride * chunk + (tile_of % chunk)];
         const int x0 = (int)tile.x * 8, y0 = (int)tile.y * 8;
         // ---- stage C shading of the previous round
         if ((flags & (LF_ALIVE | WF_INVERTEX)) == (LF_ALIVE | WF_INVERTEX)) {
@@ -886,7 +894,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
         // ---- tile complete: spread the row bins over the window, flush it, take the next tile
         const uint32_t done = s_done + s_fin;
         __syncthreads();   // everybody has read s_done / s_fin before thread 0 rewrites them; the bins are up to date
-        if (done == 64u * spp) {
+        if (done == n_pairs) {
             if (film_rows) {
                 for (uint32_t k = tid; k < 4 * WIN_PLANE; k += TR_BLOCK) s_win[k] = 0.0f;
                 __syncthreads();
@@ -939,7 +947,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
             if (lane == leader) base = atomicAdd(&s_pair, (uint32_t)__popcll(im));
             base = __shfl(base, (int)leader);
             const uint32_t pair = base + (uint32_t)__popcll(im & ((1ull << lane) - 1ull));
-            if (idle && pair < 64u * spp) { pu(pool, F_SNEXT, i) = pair; wants_sample = true; }
+            // (stored with the slice's first sample in the sample bits: wf_regenerate and the film's row bins read pixel and sample from it)
+            if (idle && pair < n_pairs) { pu(pool, F_SNEXT, i) = pair + (((tile_idx & ((1u << slice_shift) - 1u)) * s_per) << 6); wants_sample = true; }
         }
     }
     wf_enqueue(pool, queue_r, qctl, 6u, wants_sample, i);
@@ -962,7 +971,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
     }
 #endif
     __syncthreads();   // every wave has taken its pairs
-    if (tid == 0) { chunks[c].tile = s_tile; chunks[c].done = s_done; chunks[c].next_pair = s_pair < 64u * spp ? s_pair : 64u * spp; }
+    if (tid == 0) { chunks[c].tile = s_tile; chunks[c].done = s_done; chunks[c].next_pair = s_pair < n_pairs ? s_pair : n_pairs; }
 }
 
 }  // namespace tr
