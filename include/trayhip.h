@@ -323,8 +323,8 @@ void tray_scene_destroy(TrayDeviceScene* s);
  * Scenes that traverse BVH<Instance> (more than 16 instances) run the wavefront schedule: it polls for completion (the call
  * returns when the tiles are done), uses one internal stream beside `stream` (forked from and joined back to it with events) and
  * returns TRAY_E_UNSUPPORTED for a mesh of more than 8 388 607 BVH nodes or triangles (its traversal keeps a node as a 32-bit word).
- * Its path pool is sized for the device: up to 16 M paths in flight (4.4 GB) and, for a scene with instances that move while the shutter is
- * open, 112 B per path and moving instance of cached transforms within two fifths of the free memory (TRAYHIP_WF_SLOTS /
+ * Its path pool is sized for the device: up to 32 M paths in flight (8.9 GB + 5 GB of queues and film bins) and, for a scene with instances that
+ * move while the shutter is open, 112 B per path and such instance of cached transforms within two fifths of the free memory (TRAYHIP_WF_SLOTS /
  * TRAYHIP_XF_CACHE_BYTES bound both; a failed allocation is TRAY_E_NOMEM). */
 int tray_render_tiles_device(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count,
                              uint32_t spp, uint64_t seed, float* rgbw_dev, void* stream);

@@ -811,7 +811,7 @@ static int upload(TrayDeviceScene* s, const char* key, bool unchanged, const T* 
 
 
 #ifndef WF_SLOTS
-#define WF_SLOTS (16u << 20)  // path pool slots (4.4 GB of pool at 66 fields): measured 78 / 106 / 132 Msamples/s at 2 / 4 / 8 M on the C5 (round 4;
+#define WF_SLOTS (32u << 20)  // path pool slots (8.9 GB of pool at 66 fields): measured 78 / 106 / 132 / 145 / 152 Msamples/s at 2 / 4 / 8 / 16 / 32 M on the C5 (round 4;
 #endif                        // stand-in: every stage kernel ends with the tail of its slowest rays, fewer and larger rounds pay it less often
 #define WF_POLL 16
 #ifndef WF_MAX_SLICES
@@ -863,9 +863,9 @@ static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, ui
 }
 
 // Path pool slots of the wavefront schedule: never more than the film has pixels x 4 x WF_MAX_SLICES (a chunk of 256 per tile slice), and for
-// moving scenes never more than the per-path transform cache (n_moving x 112 B per slot) can hold within two fifths of the device's
-// free memory -- 59 moving instances at 16 M slots are 106 GB; a few hundred thousand slots already fill the chip, but every stage kernel
-// ends with the tail of its slowest rays and fewer, larger rounds pay it less often
+// moving scenes never more than the per-path transform cache (112 B per slot and instance that moves within the frame) can hold within two
+// fifths of the device's free memory; a few hundred thousand slots already fill the chip, but every stage kernel ends with the tail of its
+// slowest rays and fewer, larger rounds pay it less often
 // reclaimable: bytes a frame update's donor still holds that the new frame either takes over or frees (its pool and transform cache):
 // they count as free, or the budget -- and with it the pool size -- would depend on which frame came first
 static uint32_t wf_slot_count(const TrayDeviceScene* s, size_t reclaimable = 0) {
@@ -876,7 +876,7 @@ static uint32_t wf_slot_count(const TrayDeviceScene* s, size_t reclaimable = 0) 
     if (s->animated && s->deferred_n_moving > 0) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
-        uint64_t budget = (free_b + reclaimable) / 5 * 2;   // (two fifths: 59 moving instances at 16 M slots are 106 GB of the 288)
+        uint64_t budget = (free_b + reclaimable) / 5 * 2;   // (two fifths of the free memory: 112 B per slot and instance that moves within the frame -- the C5 stand-in has 2 .. 11 of them, 7 .. 39 GB at 32 M slots)
         if (const char* e = getenv("TRAYHIP_XF_CACHE_BYTES")) budget = (uint64_t)std::max(0ll, atoll(e));
         const uint64_t per_slot = (uint64_t)s->deferred_n_moving * TR_XF_WORDS * sizeof(float);
         const uint64_t fit = budget / per_slot / TR_BLOCK * TR_BLOCK;
@@ -1291,16 +1291,27 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         // share of the memory that was free BEFORE the pool existed)
         const bool keep_lanes = donor && donor->dev.xf_cache_lanes != 0u && donor->wavefront == s->wavefront && (s->wavefront || donor->n_blocks == s->n_blocks);
         const size_t reclaimable = donor ? donor->xf_cache_bytes + (donor->pool.data ? (size_t)F_COUNT * donor->pool.n_slots * sizeof(float) : 0) : 0;
-        const uint32_t lanes = keep_lanes ? donor->dev.xf_cache_lanes : (s->wavefront ? wf_slot_count(s, reclaimable) : (uint32_t)s->n_blocks * TR_BLOCK);
+        uint32_t lanes = keep_lanes ? donor->dev.xf_cache_lanes : (s->wavefront ? wf_slot_count(s, reclaimable) : (uint32_t)s->n_blocks * TR_BLOCK);
         const uint32_t n_moving_for_msg = s->deferred_n_moving;
         void* cache = nullptr;
-        const size_t cache_bytes = (size_t)s->deferred_n_moving * TR_XF_WORDS * lanes * sizeof(float);
+        size_t cache_bytes = (size_t)s->deferred_n_moving * TR_XF_WORDS * lanes * sizeof(float);
+        // (the wavefront schedule's pool follows the cache: if the budget of wf_slot_count -- a share of what hipMemGetInfo calls free -- cannot be
+        // had in one piece, halve the pool rather than fail; the tile kernel's cache has one column per resident thread and cannot shrink)
+        if (s->wavefront && !(keep_lanes && donor->dev.xf_cache && donor->xf_cache_bytes >= cache_bytes)) {
+            while (hipMalloc(&cache, cache_bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                cache = nullptr;
+                if (lanes / 2u < 64u * TR_BLOCK) break;
+                lanes = lanes / 2u / TR_BLOCK * TR_BLOCK;
+                cache_bytes = (size_t)s->deferred_n_moving * TR_XF_WORDS * lanes * sizeof(float);
+            }
+        }
         if (keep_lanes && donor->dev.xf_cache && donor->xf_cache_bytes >= cache_bytes) {   // (every path fills its columns before it reads them)
             cache = donor->dev.xf_cache;
             s->xf_cache_bytes = donor->xf_cache_bytes;
             forget_alloc(donor, cache);
             donor->dev.xf_cache = nullptr; donor->xf_cache_bytes = 0;
-        } else if (hipMalloc(&cache, cache_bytes) == hipSuccess) {
+        } else if (cache != nullptr || hipMalloc(&cache, cache_bytes) == hipSuccess) {
             s->xf_cache_bytes = cache_bytes;
         } else {
             tray_scene_destroy(s);
