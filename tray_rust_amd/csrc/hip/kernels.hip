@@ -1464,7 +1464,8 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     const uint2* tiles = s->d_tiles + tile_start;
     uint32_t launches = 0;
     // the views: equal shares of the chunks in use. Measured on the C5 stand-in at full detail (1 / 2 / 3 / 4 views): see DESIGN.md section 4
-    uint32_t n_views = 2u;
+    // (with rounds of 24 M slots and more one view is ahead: C5 stand-in 155.8 against 152.9 Msamples/s at 32 M; at 16 M two views 146.8 against 144.3)
+    uint32_t n_views = n_chunks >= (24u << 20) / TR_BLOCK ? 1u : 2u;
     if (const char* e = getenv("TRAYHIP_WF_PIPES")) n_views = (uint32_t)std::max(1, std::min(WF_PIPES_MAX, atoi(e)));
     n_views = std::max(1u, std::min(n_views, n_chunks / WF_SEGS));   // (a view of a few chunks would only add launches)
     WfView views[WF_PIPES_MAX];
