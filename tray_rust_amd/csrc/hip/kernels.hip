@@ -815,7 +815,7 @@ static int upload(TrayDeviceScene* s, const char* key, bool unchanged, const T* 
 #endif                        // stand-in: every stage kernel ends with the tail of its slowest rays, fewer and larger rounds pay it less often
 #define WF_POLL 16
 #ifndef WF_MAX_SLICES
-#define WF_MAX_SLICES 4u   // work items a tile's samples are cut into at most (k_wf_advance): the pool may hold that many chunks per tile
+#define WF_MAX_SLICES 16u  // work items a tile's samples are cut into at most (k_wf_advance): the pool may hold that many chunks per tile
 #endif
 // one round of the wavefront schedule: advance -> regen -> trace A -> begin -> trace B -> query -> trace C (compacted ray queues, persistent
 // traversal with dynamic fetch, kind-pure shading over the material sort's queues; scenes with textured materials, whose lobes
