@@ -454,8 +454,8 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     e.d.film_rows = film_rows_ok(f) ? 1u : 0u;
     // launch_wavefront's rule: tiles are cut into slices of their samples while the pool has more chunks than work items (k_wf_advance)
     uint32_t slice_shift = 0u;
-    while ((1u << (slice_shift + 1u)) <= 4u && ((uint64_t)tile_count << slice_shift) * 3u / 2u <= n_chunks && (spp >> (slice_shift + 1u)) >= 16u) ++slice_shift;
-    if (const char* sl = getenv("TRAYHIP_WF_SLICES")) { slice_shift = 0u; while ((2u << slice_shift) <= (uint32_t)std::max(1, atoi(sl)) && (2u << slice_shift) <= 4u && (spp >> (slice_shift + 1u)) >= 1u) ++slice_shift; }
+    while ((1u << (slice_shift + 1u)) <= 16u && ((uint64_t)tile_count << slice_shift) * 3u / 2u <= n_chunks && (spp >> (slice_shift + 1u)) >= 16u) ++slice_shift;
+    if (const char* sl = getenv("TRAYHIP_WF_SLICES")) { slice_shift = 0u; while ((2u << slice_shift) <= (uint32_t)std::max(1, atoi(sl)) && (2u << slice_shift) <= 16u && (spp >> (slice_shift + 1u)) >= 1u) ++slice_shift; }
     const uint32_t n_items = tile_count << slice_shift;
     n_chunks = std::max(1u, std::min(n_chunks, n_items));
     const uint32_t n_slots = n_chunks * TR_BLOCK, n_active = n_slots;
