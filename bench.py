@@ -75,6 +75,7 @@ def device_code_hash():
 VALU_CLOCK_GHZ = 2.33
 VALU_CYCLES_PER_WAVE_INSTRUCTION = 3.8
 VALU_PEAK_TLANE = 256 * 4 * 64 * VALU_CLOCK_GHZ * 1e9 / VALU_CYCLES_PER_WAVE_INSTRUCTION / 1e12   # 40.2e12 lane-instructions/s
+VALU_PEAK_NOMINAL_TLANE = 256 * 4 * 64 * 2.4e9 / 2.0 / 1e12   # 78.6: MI355X_MICROARCH.md's SIMD-32 figure (a wave64 instruction every 2 cycles at 2.4 GHz)
 VALU_PEAK_NOTE = ("peak = MEASURED issue rate of plain VALU instructions: 256 CUs x 4 SIMDs x 64 lanes per 3.8 cycles at 2.33 GHz under load "
                   "(profiles/r04_ubench_valu.txt; the nominal 2 cycles per wave64 instruction at 2.4 GHz would be 78.6)")
 
@@ -113,6 +114,7 @@ def pmc_views(workload, samples, kernel_seconds):
         lane_instr = d["valu_instructions_per_sample"] * 64.0 * d["valu_lane_utilisation"] * samples
         achieved = lane_instr / kernel_seconds / 1e12
         valu = {"achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANE, 2), "unit": "T lane-instructions/s", "frac": round(achieved / VALU_PEAK_TLANE, 4),
+                "peak_nominal": round(VALU_PEAK_NOMINAL_TLANE, 2), "frac_nominal": round(achieved / VALU_PEAK_NOMINAL_TLANE, 4),
                 "wave_instructions_per_sample": round(d["valu_instructions_per_sample"], 1), "lane_utilisation": round(d["valu_lane_utilisation"], 4),
                 "note": VALU_PEAK_NOTE + (f"; the SQ counters show the VALU pipe {d.get('valu_busy', 0.0):.2f} time-busy" if d.get("valu_busy") else "")}
     compute = {"source": "profiles/pmc_latest.json (rocprofv3 --pmc passes around a %d-spp launch of this device code, tools/pmc_workloads.py)" % d.get("spp", 0),
@@ -120,7 +122,8 @@ def pmc_views(workload, samples, kernel_seconds):
                "valu_busy": d.get("valu_busy"), "valu_lane_util": d.get("valu_lane_utilisation"),
                "waves_per_simd": d.get("waves_per_simd"), "waiting_share_of_wave_cycles": d.get("waiting_share_of_wave_cycles"),
                "dominant_kernel_share_of_time": d.get("dominant_kernel_share_of_time"),
-               "hbm_bytes_basis": d.get("hbm_bytes_basis"), "static": static if workload == "cornell_box" else None}
+               "hbm_bytes_basis": d.get("hbm_bytes_basis"), "static": static if workload == "cornell_box" else None,
+               "schedule_of_the_counter_launch": d.get("schedule")}
     return traffic, valu, compute
 
 
@@ -136,7 +139,8 @@ def main():
                     help="cornell_box = BASELINE.json configs[1] (the reported line); smallpt = configs[2] at 4096 spp; "
                          "dragon = configs[3] stand-in (871 200 triangles + MERL) at 2048 spp; tr15_like = configs[4] stand-in "
                          "(59 instances, 3.1 M triangles, moving camera / objects / lights), one frame at 512 spp")
-    ap.add_argument("--frame", type=int, default=330, help="frame of a moving workload (tr15_like)")
+    ap.add_argument("--frame", type=int, default=63, help="first frame of a moving workload (tr15_like). BASELINE.json configs[4] is frames 0..127 (main.rs:91-106); of the stand-in's "
+                    "59 instances 8 move within a frame up to frame 63 and 11 from 64 on (rounds 2-4 benched frames 330-331, where 2 move)")
     ap.add_argument("--frames", type=int, default=1, help="tr15_like only: a step renders the SEQUENCE of frames [frame, frame + frames) -- the device scene moves from "
                     "frame to frame with tray_scene_update_frame (Scene::update_frame, scene.rs:152-176) inside the timed region; with N GPUs the frames are "
                     "dealt round-robin over the ranks (multi.shard_frames, BASELINE.json configs[4]), each rank renders whole frames, no collective")
@@ -236,7 +240,11 @@ def main():
             total_samples, total_vertices = float(cnt[0].item()), float(cnt[1].item())
         else:
             total_samples, total_vertices = float(samples), float(vertices)
-        return {"name": name, "scene": scene, "frame": frame, "spp": spp, "steps": steps, "elapsed": elapsed, "kernel_ms": sum(kernel_ms) / len(kernel_ms),
+        try:
+            sched = hip.schedule(scene)   # pool slots / views / slices of the last launch (tray_last_schedule)
+        except Exception:
+            sched = None
+        return {"name": name, "scene": scene, "frame": frame, "spp": spp, "steps": steps, "elapsed": elapsed, "kernel_ms": sum(kernel_ms) / len(kernel_ms), "schedule": sched,
                 "n_frames": frames if seq else 1,
                 "samples": samples, "vertices": vertices, "launches": launches, "total_samples": total_samples, "total_vertices": total_vertices}
 
@@ -262,6 +270,9 @@ def main():
                     "valu": valu, "compute": compute,
                     "kernel": "7 stage kernels per round (HIP events around the whole schedule)" if wave else "k_path_tiles",
                     "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": int(algo_bytes),
+                    "schedule": m.get("schedule"),
+                    "counters_from_this_schedule": (None if not (compute and compute.get("schedule_of_the_counter_launch") and m.get("schedule")) else
+                                                    all(compute["schedule_of_the_counter_launch"].get(k) == m["schedule"].get(k) for k in ("pool_slots", "views", "slices", "launched_wavefront"))),
                     "note": "achieved / peak / frac are SURVEY 8(d)'s accounting of the WAVEFRONT formulation (368 B per path vertex + 16 B per pixel) over the HIP-event "
                             "time of the launch; `bound` names the resource the launch is closer to, `valu` prices the VALU lane-issue rate from the counters. " +
                             ("Traversal of the 3.1 M-triangle scene is memory-latency bound." if wave
@@ -296,7 +307,7 @@ def main():
             v, ms, cfg, rf = line_of(m)
             entry = {"workload": cfg["workload"], "schedule": cfg["schedule"], "value": round(v, 3), "unit": "Msamples/s", "steps": steps,
                      "warmup": "1 launch at 16 spp", "ms_per_step": round(ms, 3), "vertices_per_sample": cfg["vertices_per_sample"],
-                     "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu", "kernel", "kernel_ms")}}
+                     "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu", "kernel", "kernel_ms", "schedule", "counters_from_this_schedule")}}
             if frames > 1:
                 entry["frames_per_step"] = frames
                 entry["frame_kernel_value"] = round(m["samples"] / (m["kernel_ms"] * 1e-3) / 1e6, 3)

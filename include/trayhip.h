@@ -384,6 +384,30 @@ typedef struct TrayKernelTiming {
 } TrayKernelTiming;
 int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t);
 
+/* Footprint and shape of the wavefront schedule (scenes that traverse BVH<Instance>: more than 16 instances) -- the reference has no
+ * counterpart: its workers keep one path per thread on the stack (exec/multithreaded.rs:72-114); here up to 32 M paths are in flight in a
+ * pool in HBM. pool_slots: paths in flight (0 = the library's rule: 32 M, never more than 4096 per tile, the pool with its queues within a
+ * third of the device's free memory, a moving scene's per-path transform cache within two fifths); views: independent halves / thirds /
+ * quarters of the pool on streams of their own (0 = rule: 1 from 24 M slots, else 2); slices: work items a tile's samples are cut into
+ * (0 = rule; a power of two <= 16). A host that keeps several device scenes on one GPU sets pool_slots so that they fit beside each other
+ * (0.47 KB per slot + 112 B per slot and instance that moves within a frame). Takes effect at the next render call (the buffers are freed
+ * and allocated anew if the pool's size changes); for a moving scene the pool cannot grow beyond the transform cache allocated at
+ * tray_scene_create / tray_scene_update_frame, which follow the setting. If the allocation fails the library halves the pool down to
+ * 16 384 slots before it returns TRAY_E_NOMEM, and the handle stays usable. The environment switches TRAYHIP_WF_SLOTS / _PIPES / _SLICES
+ * (measurement only) override these. TRAY_E_INVALID for views > 4 or slices not a power of two <= 16. */
+int tray_scene_set_wavefront(TrayDeviceScene* s, uint32_t pool_slots, uint32_t views, uint32_t slices);
+/* The schedule the last render call on this scene ran with (what tools/pmc_workloads.py records beside its counters). */
+typedef struct TrayScheduleInfo {
+    uint32_t wavefront;           /* 1: the scene takes the wavefront schedule, 0: the tile kernel */
+    uint32_t launched_wavefront;  /* 1: the last render call ran the wavefront schedule (0 also for the Uniform / Adaptive sampler passes) */
+    uint32_t pool_slots, chunks;  /* paths in flight (0 until the first wavefront launch allocated the pool), chunks of 256 */
+    uint32_t views, slices;       /* of the last wavefront launch */
+    uint32_t n_moving;            /* instances that move within the frame (columns of the per-path transform cache) */
+    uint32_t tile_workgroups;     /* persistent workgroups of the tile kernel */
+    uint64_t pool_bytes, schedule_bytes, xf_cache_bytes;   /* pool alone; pool + queues + bins; per-path transform cache */
+} TrayScheduleInfo;
+int tray_last_schedule(TrayDeviceScene* s, TrayScheduleInfo* out);
+
 /* ---- one frame on several GPUs of this process ------------------------------------------------------
  * The reference's distributed mode hands every worker a slice of the block queue and sums the returned RGBW blocks on the
  * master (src/exec/distrib/master.rs:91-93,124-163; film::Image::add_blocks, src/film/image.rs:36-50). Here the workers are
@@ -398,6 +422,8 @@ int tray_multi_create(const TrayFlatScene* f, int n_dev, const int* dev_ids, Tra
 int tray_render_frame_multi(TrayMultiScene* m, uint32_t spp, uint64_t seed, float* rgbw_host);
 /* tray_scene_set_sampler on every device of m */
 int tray_multi_set_sampler(TrayMultiScene* m, uint32_t kind, uint32_t min_spp, uint32_t max_spp);
+/* tray_scene_set_wavefront on every device of m */
+int tray_multi_set_wavefront(TrayMultiScene* m, uint32_t pool_slots, uint32_t views, uint32_t slices);
 /* tray_scene_update_frame on every device of m; the communicators, films and streams are kept (scene.rs:152-176 per worker) */
 int tray_multi_update_frame(TrayMultiScene* m, const TrayFlatScene* f);
 /* per-device timings of the last tray_render_frame_multi (n_dev entries) and the duration of the reduce (ms) */

@@ -27,7 +27,7 @@ hip = T.Hip(device=0, seed=1)
 for item in sys.argv[4:]:
     name, spp = item.split(":")
     spp = int(spp)
-    frame = 330 if name == "tr15_like" else (3 if name == "moving_box" else 0)
+    frame = int(os.environ.get("TR15_FRAME", "64")) if name == "tr15_like" else (3 if name == "moving_box" else 0)   # (64: inside BASELINE's 0..127, 11 instances move; rounds 2-4 profiled frame 330)
     t0 = time.time()
     scene, rt, _, fi = T.Scene.load_file(os.path.join(d, "tr15" if name == "tr15_like" else "", name + ".json"))
     if frame:
@@ -50,4 +50,10 @@ for item in sys.argv[4:]:
         r = float(np.sqrt(np.mean((rgb - ref) ** 2)))
     else:
         np.save(ref_path, rgb); r = 0.0
+    try:   # the schedule the launch ran with (tools/pmc_workloads.py records it beside the counters)
+        import json
+        sch = hip.schedule(scene); sch["frame"] = frame; sch["spp"] = spp
+        json.dump(sch, open(os.path.join(d, f"schedule_{name}.json"), "w"))
+    except Exception as e:
+        print("no schedule info:", e)
     print(f"{label:8s} {name:12s} {spp:3d} spp  {best:8.1f} Msamples/s  launches {t.launches:4d}  RMSE vs first {r:.2e}  (load+render {time.time() - t0:.1f}s)", flush=True)

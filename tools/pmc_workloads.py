@@ -1,5 +1,7 @@
 """Counter passes of ALL bench workloads for the build in tray_rust_amd/libtrayhip.so (run on the GPU box):
-    python tools/pmc_workloads.py <tag> [workload:spp ...]      default: cornell_box:64 smallpt:64 dragon:32 tr15_like:16 at FULL scene size
+    python tools/pmc_workloads.py <tag> [workload:spp ...]      default: cornell_box:64 smallpt:64 dragon:32 tr15_like:128 at FULL scene size
+(round 5: tr15_like at 128 spp, frame 64 -- the sample count from which the host rules cut tiles into 4 slices, fill a 33 M-slot pool and run ONE view, i.e. the
+schedule of the 512-spp bench launch; 16 spp, rounds 2-4, ran whole tiles in 8 M slots on two views. The schedule of every measured launch is recorded.)
 One rocprofv3 --pmc pass per counter set (utilisation set, FETCH_SIZE, WRITE_SIZE) around a torch-free launch (tools/mini_ab.py), plus the
 FETCH_SIZE / WRITE_SIZE calibration on a scratch pattern of known size (tools/scratch_calib). Writes
     gpurun_out/summary_<tag>/pmc_latest.json           {"device_code_hash", "workloads": {name: derived figures}}  -> copy to profiles/
@@ -9,7 +11,7 @@ import csv, glob, json, os, re, shutil, subprocess, sys
 
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tag = sys.argv[1]
-items = sys.argv[2:] or ["cornell_box:64", "smallpt:64", "dragon:32", "tr15_like:16"]
+items = sys.argv[2:] or ["cornell_box:64", "smallpt:64", "dragon:32", "tr15_like:128"]
 dest = os.path.join(ROOT, "gpurun_out", f"summary_{tag}")
 os.makedirs(dest, exist_ok=True)
 D = "/tmp/mini_full"
@@ -108,6 +110,10 @@ for item in items:
             d["hbm_bytes_per_launch"] = 2 * fr + wr
             d["hbm_bytes_basis"] = "2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md: gfx950 tallies 128-B reads as 64 B; WRITE_SIZE uncalibrated)"
         d["hbm_bytes_per_sample"] = d["hbm_bytes_per_launch"] / samples
+    try:   # slots / views / slices / frame of the measured launch (tools/mini_ab.py writes it after its render calls)
+        d["schedule"] = json.load(open(os.path.join(D, f"schedule_{wl}.json")))
+    except Exception:
+        d["schedule"] = None
     latest["workloads"][wl] = d
     lines = [f"# rocprofv3 --kernel-trace --pmc <set> -- python tools/mini_ab.py run <dir> pmc {item}   ({wl} 1920x1080 at full scene size, {spp} spp); one pass per counter set",
              f"# device code {dev_hash}; values per frame launch, summed over XCDs / SEs", "kernel,ms,counter,value"]

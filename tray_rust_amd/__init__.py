@@ -300,6 +300,16 @@ class Hip:
         except Exception:
             pass
 
+    def schedule(self, scene):
+        """the schedule the last render call of `scene` on this device ran with (tray_last_schedule): pool slots, views, slices, bytes"""
+        info = _lib.TrayScheduleInfo()
+        check(lib().tray_last_schedule(scene.device_scene(scene._dev_frame, self.device), C.byref(info)))
+        return {name: int(getattr(info, name)) for name, _ in info._fields_}
+
+    def set_wavefront(self, scene, pool_slots=0, views=0, slices=0):
+        """tray_scene_set_wavefront on the scene's device copy (0 = the library's own rule)"""
+        check(lib().tray_scene_set_wavefront(scene.device_scene(scene._dev_frame, self.device), int(pool_slots), int(views), int(slices)))
+
     def timing(self, scene):
         t = _lib.TrayKernelTiming()
         check(lib().tray_last_timing(scene.device_scene(scene._dev_frame, self.device), C.byref(t)))

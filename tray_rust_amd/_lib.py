@@ -135,6 +135,12 @@ class TrayKernelTiming(C.Structure):
                 ("rays", C.c_uint64), ("retraced", C.c_uint64)]
 
 
+class TrayScheduleInfo(C.Structure):
+    _fields_ = [("wavefront", C.c_uint32), ("launched_wavefront", C.c_uint32), ("pool_slots", C.c_uint32), ("chunks", C.c_uint32),
+                ("views", C.c_uint32), ("slices", C.c_uint32), ("n_moving", C.c_uint32), ("tile_workgroups", C.c_uint32),
+                ("pool_bytes", C.c_uint64), ("schedule_bytes", C.c_uint64), ("xf_cache_bytes", C.c_uint64)]
+
+
 class TrayRay(C.Structure):
     _fields_ = [("o", C.c_float * 3), ("d", C.c_float * 3), ("min_t", C.c_float), ("max_t", C.c_float), ("time", C.c_float)]
 
@@ -161,6 +167,9 @@ SYMBOLS = {
     "tray_scene_destroy": (None, [C.c_void_p]),
     "tray_scene_set_sampler": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "tray_multi_set_sampler": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "tray_scene_set_wavefront": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "tray_multi_set_wavefront": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "tray_last_schedule": (C.c_int, [C.c_void_p, _P(TrayScheduleInfo)]),
     "tray_adaptive_step": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "tray_render_tiles_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "tray_render_shard_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),

@@ -85,16 +85,18 @@ TR_DEV float beckmann_d(float width, f3 w_h) {
     if (isinf(tan_sqr)) return 0.0f;
     float c2 = cos_theta_sqr(w_h);
     float cos_theta_4 = c2 * c2, width_sqr = width * width;
-    return expf(-tan_sqr / width_sqr) / (kPi * width_sqr * cos_theta_4);
+    return lm_exp(-tan_sqr / width_sqr) / (kPi * width_sqr * cos_theta_4);
 }
 TR_DEV f3 beckmann_sample(float width, float u0, float u1) {
-    float log_sample = logf(1.0f - u0);
+    float log_sample = lm_log(1.0f - u0);
     if (isinf(log_sample)) log_sample = 0.0f;
     float tan_theta_sqr_v = -(width * width) * log_sample;
     float phi = 2.0f * kPi * u1;
     float cos_t = 1.0f / sqrtf(1.0f + tan_theta_sqr_v);
     float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
-    return mk(sin_t * cosf(phi), sin_t * sinf(phi), cos_t);   // linalg::spherical_dir
+    float sn, cs;
+    lm_sincos(phi, sn, cs);
+    return mk(sin_t * cs, sin_t * sn, cos_t);   // linalg::spherical_dir
 }
 TR_DEV float beckmann_pdf(float width, f3 w_h) { return fabsf(w_h.z) * beckmann_d(width, w_h); }
 TR_DEV float beckmann_g1(float width, f3 v) {
@@ -124,7 +126,9 @@ TR_DEV f3 ggx_sample(float width, float u0, float u1) {
     float cos_t = 1.0f / sqrtf(1.0f + tan_theta_sqr_v);
     float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
     float phi = 2.0f * kPi * u1;
-    return mk(sin_t * cosf(phi), sin_t * sinf(phi), cos_t);
+    float sn, cs;
+    lm_sincos(phi, sn, cs);
+    return mk(sin_t * cs, sin_t * sn, cos_t);
 }
 TR_DEV float ggx_g1(float width, f3 v) {
     float t = width * fabsf(tan_theta(v));
@@ -165,14 +169,14 @@ TR_DEV f3 merl_eval(const float* __restrict__ brdf, f3 w_oi, f3 w_ii) {
     if (w_h.z < 0.0f) { w_i = -w_i; w_h = -w_h; }
     if (length_sqr(w_h) == 0.0f) return mk(0.0f, 0.0f, 0.0f);
     w_h = normalized(w_h);
-    float theta_h = acosf(clampf(w_h.z, -1.0f, 1.0f));
+    float theta_h = lm_acos(clampf(w_h.z, -1.0f, 1.0f));
     float cos_phi_h = cos_phi(w_h), sin_phi_h = sin_phi(w_h);
     float cos_theta_h = cos_theta(w_h), sin_theta_h = sin_theta(w_h);
     f3 w_hx = mk(cos_phi_h * cos_theta_h, sin_phi_h * cos_theta_h, -sin_theta_h);
     f3 w_hy = mk(-sin_phi_h, cos_phi_h, 0.0f);
     f3 w_d = mk(dot(w_i, w_hx), dot(w_i, w_hy), dot(w_i, w_h));
-    float theta_d = acosf(clampf(w_d.z, -1.0f, 1.0f));
-    float phi_d = atan2f(w_d.y, w_d.x);
+    float theta_d = lm_acos(clampf(w_d.z, -1.0f, 1.0f));
+    float phi_d = lm_atan2(w_d.y, w_d.x);
     if (phi_d < 0.0f) phi_d = phi_d + kPi * 2.0f;
     if (phi_d > kPi) phi_d = phi_d - kPi;   // quirk Q10
     uint32_t th = merl_index(sqrtf(fmaxf(0.0f, 2.0f * theta_h / kPi)), 1.0f, 90u);

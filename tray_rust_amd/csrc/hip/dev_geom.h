@@ -401,7 +401,7 @@ TR_DEV bool disk_test(float radius, float inner_radius, f3 o, f3 d, float min_t,
     f3 p = o + d * t;
     float dist_sqr = p.x * p.x + p.y * p.y;
     if (dist_sqr > radius * radius || dist_sqr < inner_radius * inner_radius) return false;
-    float phi = atan2f(p.y, p.x);
+    float phi = lm_atan2(p.y, p.x);
     if (phi < 0.0f) phi += kPi * 2.0f;
     if (phi > kPi * 2.0f) return false;
     t_out = t;
@@ -951,14 +951,14 @@ TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, flo
         ng = normalized(mk(0.0f, 0.0f, 1.0f));
     } else if (gt == TRAY_GEOM_SPHERE) {   // sphere.rs:56-81
         float radius = in->geom_params[0];
-        float theta = acosf(clampf(p.z / radius, -1.0f, 1.0f));
+        float theta = lm_acos(clampf(p.z / radius, -1.0f, 1.0f));
         float inv_z = 1.0f / sqrtf(p.x * p.x + p.y * p.y);
         float cos_phi = p.x * inv_z, sin_phi = p.y * inv_z;
-        u = atan2f(p.x, p.y) / (2.0f * kPi);
+        u = lm_atan2(p.x, p.y) / (2.0f * kPi);
         if (u < 0.0f) u = u + 1.0f;
         v = theta / kPi;
         dp_du = mk(-kPi * 2.0f * p.y, kPi * 2.0f * p.x, 0.0f);
-        dp_dv = mk(p.z * cos_phi, p.z * sin_phi, -radius * sinf(theta)) * kPi;
+        dp_dv = mk(p.z * cos_phi, p.z * sin_phi, -radius * lm_sin(theta)) * kPi;
         n = normalized(p);
         ng = n;
     } else if (gt == TRAY_GEOM_MESH || (ANIM == 3 && gt == TRAY_GEOM_ANIMATED_MESH)) {   // mesh.rs:172-197
@@ -1005,7 +1005,7 @@ TR_DEV Hit finish_hit(const DevScene& sc, const Ray& ray, const HitRec& rec, flo
     } else {   // disk.rs:67-75
         float radius = in->geom_params[0], inner_radius = in->geom_params[1];
         float dist_sqr = p.x * p.x + p.y * p.y;
-        float phi = atan2f(p.y, p.x);
+        float phi = lm_atan2(p.y, p.x);
         if (phi < 0.0f) phi += kPi * 2.0f;
         float hit_radius = sqrtf(dist_sqr);
         u = phi / (2.0f * kPi);
@@ -1066,13 +1066,17 @@ TR_DEV f3 uniform_sample_sphere(float u0, float u1) {   // mc.rs:84-89
     float z = 1.0f - 2.0f * u0;
     float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
     float phi = kPi * 2.0f * u1;
-    return mk(cosf(phi) * r, sinf(phi) * r, z);
+    float sn, cs;
+    lm_sincos(phi, sn, cs);
+    return mk(cs * r, sn * r, z);
 }
 TR_DEV f3 uniform_sample_cone_frame(float u0, float u1, float cos_theta_max, f3 wx, f3 wy, f3 wz) {   // mc.rs:76-82
     float cos_theta = lerpf(u0, cos_theta_max, 1.0f);
     float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
     float phi = u1 * kPi * 2.0f;
-    return cosf(phi) * sin_theta * wx + sinf(phi) * sin_theta * wy + cos_theta * wz;
+    float sn, cs;
+    lm_sincos(phi, sn, cs);
+    return cs * sin_theta * wx + sn * sin_theta * wy + cos_theta * wz;
 }
 
 // Sampleable::sample: point + normal on the emitter's geometry as seen from object-space p

@@ -40,6 +40,29 @@ static constexpr float kPiOver4 = 0.785398163397448309616f;
 static constexpr float kEps = 1.1920929e-7f;   // f32::EPSILON
 #define TR_INF __builtin_huge_valf()
 
+}  // namespace tr
+#include "dev_libm.h"
+namespace tr {
+// f32::{sin, cos, acos, atan2, exp, ln} of the reference are the host libm's functions -- none of them correctly rounded, so ocml's differ
+// from them in the last bit for a few per cent of the arguments, and bxdf/merl.rs:63-79 turns such a bit into another table entry. The device
+// calls glibc's algorithms restated (dev_libm.h; tools/libm_port_check.cpp: every bit pattern agrees with the system libm), so a camera sample's
+// radiance is the oracle's bit for bit. -DTR_OCML_LIBM builds rounds 1-4's form (ocml) for the A/B of what that costs.
+#ifdef TR_OCML_LIBM
+TR_DEV void lm_sincos(float x, float& s, float& c) { c = cosf(x); s = sinf(x); }
+TR_DEV float lm_sin(float x) { return sinf(x); }
+TR_DEV float lm_acos(float x) { return acosf(x); }
+TR_DEV float lm_atan2(float y, float x) { return atan2f(y, x); }
+TR_DEV float lm_exp(float x) { return expf(x); }
+TR_DEV float lm_log(float x) { return logf(x); }
+#else
+TR_DEV void lm_sincos(float x, float& s, float& c) { ref_sincosf2(x, s, c); }
+TR_DEV float lm_sin(float x) { float s, c; ref_sincosf2(x, s, c); return s; }
+TR_DEV float lm_acos(float x) { return ref_acosf(x); }
+TR_DEV float lm_atan2(float y, float x) { return ref_atan2f(y, x); }
+TR_DEV float lm_exp(float x) { return ref_expf(x); }
+TR_DEV float lm_log(float x) { return ref_logf(x); }
+#endif
+
 struct f3 {
     float x, y, z;
 };
@@ -151,8 +174,10 @@ TR_DEV void concentric_sample_disk(float u0, float u1, float& dx, float& dy) {  
     } else if (sx <= sy) { radius = -sx; theta = 4.0f + sy / sx; }
     else { radius = -sy; theta = 6.0f - sx / sy; }
     theta = theta * kPiOver4;
-    dx = radius * cosf(theta);
-    dy = radius * sinf(theta);
+    float sn, cs;
+    lm_sincos(theta, sn, cs);
+    dx = radius * cs;
+    dy = radius * sn;
 }
 TR_DEV f3 cos_sample_hemisphere(float u0, float u1) {   // mc.rs:11-16
     float dx, dy;

@@ -300,7 +300,11 @@ __global__ __launch_bounds__(TR_BLOCK, ANIM ? TR_MIN_WAVES_ANIM : TR_MIN_WAVES) 
                 pairs_left = base + n_idle < n_pairs;
                 const uint32_t pair = base + (uint32_t)__popcll(idle_m & ((1ull << lane) - 1ull));
                 if (idle && pair < n_pairs) {
+#ifdef TR_PAIR_BY_PIXEL   // experiment (round 5): consecutive pairs are the samples of ONE pixel, so a wave starts 64 samples of the same pixel
+                    const uint32_t pix = pair / s_per_slice, s = s_lo + (pair % s_per_slice);
+#else
                     const uint32_t pix = pair & 63u, s = s_lo + (pair >> 6);
+#endif
                     const uint32_t px = (uint32_t)x0 + (pix & 7u), py = (uint32_t)y0 + (pix >> 3);
                     const uint32_t kp = key_pixel(kf, py * sc.width + px);
                     float t;
@@ -753,6 +757,11 @@ struct TrayDeviceScene {
     uint32_t trace_lds_depth = 0, trace_lds_bytes = 0;   // LDS part of the dynamic-fetch kernel's stacks; deeper entries go to d_stack_overflow
     uint32_t* d_stack_overflow = nullptr;
     size_t ovf_entries = 0;              // ... per view of the schedule (WF_PIPES_MAX of them)
+    std::vector<void*> wf_allocs;        // the wavefront buffers among `allocs` (tray_scene_set_wavefront frees them to change the pool's size)
+    uint32_t wf_req_slots = 0, wf_req_views = 0, wf_req_slices = 0;   // tray_scene_set_wavefront: 0 = the library's own rule
+    bool wf_shrunk = false;              // the pool came out smaller than asked for (allocation failed, halved): frame updates keep it
+    uint32_t last_views = 0, last_slices = 0;   // shape of the last wavefront launch (tray_last_schedule)
+    bool last_was_wavefront = false;
     hipStream_t wf_streams[WF_PIPES_MAX] = {nullptr, nullptr, nullptr, nullptr};   // streams of views 1.. (view 0 runs on the caller's), created on first use
     hipEvent_t wf_fork = nullptr, wf_join[WF_PIPES_MAX] = {nullptr, nullptr, nullptr, nullptr};
     bool light_filter = false;        // a sphere light or specular lobes: the tile kernel with mis_ray_filter (dev_integrator.h) compiled in
@@ -868,14 +877,30 @@ static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, ui
 // slowest rays and fewer, larger rounds pay it less often
 // reclaimable: bytes a frame update's donor still holds that the new frame either takes over or frees (its pool and transform cache):
 // they count as free, or the budget -- and with it the pool size -- would depend on which frame came first
-static uint32_t wf_slot_count(const TrayDeviceScene* s, size_t reclaimable = 0) {
+// bytes of the schedule's buffers per pool slot (pool fields, three ray queues + regeneration queue, kind queues, fallback word, row bins per chunk)
+static size_t wf_bytes_per_slot() {
+    return (size_t)F_COUNT * sizeof(float) + (3 * WF_RAY_WORDS + 1) * sizeof(uint32_t) + WF_MAT_KINDS * sizeof(uint32_t) + sizeof(uint32_t) +
+           ((size_t)ROWBIN_SIZE * sizeof(float) + sizeof(WfChunk)) / TR_BLOCK;
+}
+// what the caller (tray_scene_set_wavefront), the environment or the default ask for, before memory is looked at
+static uint32_t wf_slot_wish(const TrayDeviceScene* s) {
     uint32_t n_slots = WF_SLOTS;
+    if (s->wf_req_slots) n_slots = std::max<uint32_t>(s->wf_req_slots, 64u * TR_BLOCK) / TR_BLOCK * TR_BLOCK;   // tray_scene_set_wavefront
     if (const char* e = getenv("TRAYHIP_WF_SLOTS")) n_slots = (uint32_t)std::max(256l, atol(e)) / TR_BLOCK * TR_BLOCK;
     const uint64_t by_tiles = (uint64_t)std::max<uint32_t>(s->n_tiles, 1u) * TR_BLOCK * WF_MAX_SLICES;   // (a tile's samples can be cut into that many work items: launch_wavefront)
-    uint64_t slots = std::min<uint64_t>(n_slots, by_tiles);
+    return (uint32_t)std::min<uint64_t>(n_slots, by_tiles);
+}
+static uint32_t wf_slot_count(const TrayDeviceScene* s, size_t reclaimable = 0) {
+    uint64_t slots = wf_slot_wish(s);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)16 << 30; }
+    // the pool with its queues and bins (~0.47 KB per slot: 15 GB at 32 M) stays within a third of what is free now -- static scenes too
+    // (a host that keeps several device scenes gets pools that fit beside each other; launch_wavefront halves on top if hipMalloc refuses)
+    {
+        const uint64_t fit = (uint64_t)(free_b + reclaimable) / 3u / wf_bytes_per_slot() / TR_BLOCK * TR_BLOCK;
+        slots = std::min<uint64_t>(slots, std::max<uint64_t>(fit, (uint64_t)64 * TR_BLOCK));
+    }
     if (s->animated && s->deferred_n_moving > 0) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
         uint64_t budget = (free_b + reclaimable) / 5 * 2;   // (two fifths of the free memory: 112 B per slot and instance that moves within the frame -- the C5 stand-in has 2 .. 11 of them, 7 .. 39 GB at 32 M slots)
         if (const char* e = getenv("TRAYHIP_XF_CACHE_BYTES")) budget = (uint64_t)std::max(0ll, atoll(e));
         const uint64_t per_slot = (uint64_t)s->deferred_n_moving * TR_XF_WORDS * sizeof(float);
@@ -1050,7 +1075,7 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
             all.insert(all.end(), quads.top.begin(), quads.top.end());
             all.resize(s->n_mesh_quads + top_quad_cap, tray::quad_empty_record());
         }
-        rc = upload(s, "quads", true, keep_trees ? static_cast<const tray::QuadNode*>(nullptr) : all.data(), s->n_mesh_quads + top_quad_cap, &dq);
+        rc = upload(s, "quads", keep_trees, keep_trees ? static_cast<const tray::QuadNode*>(nullptr) : all.data(), s->n_mesh_quads + top_quad_cap, &dq);
         if (rc == TRAY_OK && keep_trees && hipMemcpy(const_cast<tray::QuadNode*>(dq) + s->n_mesh_quads, quads.top.data(), quads.top.size() * sizeof(tray::QuadNode), hipMemcpyHostToDevice) != hipSuccess) {
             rc = TRAY_E_DEVICE; set_error("hipMemcpy of the BVH<Instance> records failed");
         }
@@ -1140,6 +1165,9 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         // queues, persistent traversal with dynamic fetch) for scenes that go through BVH<Instance>; TRAYHIP_MODE overrides
         s->wavefront = f->n_instances > TR_FLAT_MAX;
         if (const char* m = getenv("TRAYHIP_MODE")) s->wavefront = std::string(m) == "wave";
+        // a tree the quad-record traversal cannot take (a box with min > max or NaN -- BBox::new() is +inf / -inf in the reference --, a mesh beyond the
+        // 23-bit descriptors) renders through the tile kernel's binary traversal, which is the reference's, instead of failing at render time
+        if (s->wavefront && (!s->narrow_trees || !s->ordered_boxes) && !getenv("TRAYHIP_MODE")) s->wavefront = false;
         if (f->integrator == TRAY_INTEGRATOR_WHITTED) s->wavefront = false;   // the recursion runs inside the tile kernel only (dev_whitted.h)
         if (s->deforming) s->wavefront = false;   // (k_sampler_pass<3> renders these scenes: launch_tiles)
     }
@@ -1326,13 +1354,15 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         s->dev.xf_cache_lanes = lanes;
         s->dev.xf_aos = s->wavefront ? 1u : 0u;
     }
+    s->wf_req_slots = donor ? donor->wf_req_slots : 0u; s->wf_req_views = donor ? donor->wf_req_views : 0u; s->wf_req_slices = donor ? donor->wf_req_slices : 0u;
     if (donor && donor->wf_ready && s->wavefront && donor->stack_bytes == s->stack_bytes && donor->quad_stack_words == s->quad_stack_words && donor->animated == s->animated &&
-        donor->pool.n_slots == ((s->animated && s->dev.xf_cache_lanes) ? s->dev.xf_cache_lanes : wf_slot_count(s))) {
+        donor->pool.n_slots <= ((s->animated && s->dev.xf_cache_lanes) ? s->dev.xf_cache_lanes : wf_slot_wish(s))) {   // (a pool that came out smaller than wished -- memory -- stays as it is)
         // the wavefront schedule's pool, queues, chunk records and row bins (2.2 GB at 8 M slots) serve the next frame as they are:
         // launch_wavefront re-initialises the chunk records and the control words of every launch, the bins are zero between tiles
         for (void* p : {(void*)donor->pool.data, (void*)donor->d_chunks, (void*)donor->d_bins, (void*)donor->d_wf_counters, (void*)donor->d_queues,
                         (void*)donor->d_kind_queues, (void*)donor->d_stack_overflow, (void*)donor->d_fallback})
-            if (p) { forget_alloc(donor, p); s->allocs.push_back(p); }
+            if (p) { forget_alloc(donor, p); s->allocs.push_back(p); s->wf_allocs.push_back(p); }
+        donor->wf_allocs.clear(); s->wf_shrunk = donor->wf_shrunk;
         s->pool = donor->pool; s->d_chunks = donor->d_chunks; s->d_bins = donor->d_bins; s->d_wf_counters = donor->d_wf_counters;
         s->d_queues = donor->d_queues; s->d_kind_queues = donor->d_kind_queues; s->d_stack_overflow = donor->d_stack_overflow; s->d_fallback = donor->d_fallback;
         s->h_done = donor->h_done; donor->h_done = nullptr;
@@ -1387,6 +1417,80 @@ int tray_scene_update_frame(TrayDeviceScene* s, const TrayFlatScene* f) {
 static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride,
                         uint32_t spp, uint64_t seed, float* rgbw_dev, void* stream_);
 
+// every buffer of the wavefront schedule for a pool of n_slots; on failure nothing stays allocated and TRAY_E_NOMEM is returned
+static void wf_free(TrayDeviceScene* s) {
+    for (void* p : s->wf_allocs) { forget_alloc(s, p); (void)hipFree(p); }
+    s->wf_allocs.clear();
+    if (s->h_done) { (void)hipHostFree(s->h_done); s->h_done = nullptr; }
+    s->pool.data = nullptr; s->pool.n_slots = 0; s->d_chunks = nullptr; s->d_bins = nullptr; s->d_wf_counters = nullptr; s->d_queues = nullptr;
+    s->d_kind_queues = nullptr; s->d_stack_overflow = nullptr; s->d_fallback = nullptr; s->n_chunks = 0; s->wf_ready = false;
+}
+static int wf_alloc(TrayDeviceScene* s, uint32_t n_slots) {
+    auto grab = [&](size_t bytes, void** out) -> bool {
+        void* p = nullptr;
+        const hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("hipMalloc of " + std::to_string(bytes >> 20) + " MiB failed: " + hipGetErrorString(e));
+            wf_free(s);
+            return false;
+        }
+        s->allocs.push_back(p); s->wf_allocs.push_back(p);
+        *out = p;
+        return true;
+    };
+    void* p = nullptr;
+    s->n_chunks = n_slots / TR_BLOCK;
+    if (!grab((size_t)F_COUNT * n_slots * sizeof(float), &p)) return TRAY_E_NOMEM;
+    s->pool.data = static_cast<float*>(p); s->pool.n_slots = n_slots; s->pool.seg_cap = wf_seg_cap(s->n_chunks);
+    const size_t q_cap = (size_t)WF_SEGS * s->pool.seg_cap;   // entries of one queue: WF_SEGS segments (wavefront.h)
+    const uint32_t n_chunks = s->n_chunks;                    // (wf_free resets the scene's fields on a failed grab)
+    if (!grab((size_t)n_chunks * sizeof(WfChunk), &p)) return TRAY_E_NOMEM;
+    s->d_chunks = static_cast<WfChunk*>(p);
+    if (!grab((size_t)n_chunks * ROWBIN_SIZE * sizeof(float), &p)) return TRAY_E_NOMEM;
+    s->d_bins = static_cast<float*>(p);
+    if (hipMemset(s->d_bins, 0, (size_t)n_chunks * ROWBIN_SIZE * sizeof(float)) != hipSuccess) { set_error("hipMemset of the row bins failed"); wf_free(s); return TRAY_E_DEVICE; }
+    if (!grab(2 * sizeof(uint32_t), &p)) return TRAY_E_NOMEM;
+    s->d_wf_counters = static_cast<uint32_t*>(p);
+    // ray queues A, B, C, regeneration queue and the control words of their segments, for up to WF_PIPES_MAX views (a view's segments
+    // are sized for its own chunks: WF_SEGS * TR_BLOCK entries of rounding per view and queue)
+    const size_t q_slack = (size_t)WF_PIPES_MAX * WF_SEGS * TR_BLOCK;
+    // (an entry of a ray queue is the ray: WF_RAY_WORDS words; the regeneration queue holds slot indices)
+    if (!grab(((3 * WF_RAY_WORDS + 1) * (q_cap + q_slack) + (size_t)WF_PIPES_MAX * WF_QCTL_WORDS) * sizeof(uint32_t), &p)) return TRAY_E_NOMEM;
+    s->d_queues = static_cast<uint32_t*>(p);
+    s->wf_sort = !(s->feat & FEAT_TEX);   // the kind-pure kernels read lobes from the material table; textured materials have theirs per hit
+    if (s->wf_sort) {   // shading queues of the material sort (slot indices), one per material kind
+        if (!grab((size_t)WF_MAT_KINDS * (q_cap + q_slack) * sizeof(uint32_t), &p)) return TRAY_E_NOMEM;
+        s->d_kind_queues = static_cast<uint32_t*>(p);
+    }
+    {
+        int per_cu = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        // LDS stack entries per lane such that WF_TRACE_WAVES workgroups (4 waves each = one wave per SIMD) fit in the CU's 160 KB
+        // (a node on this kernel's stack is two words: descriptor and entry distance; up to three per expanded record)
+        const uint32_t full_depth = std::max(s->quad_stack_words, 8u);
+        uint32_t lds_depth = std::min<uint32_t>(full_depth, (160u * 1024u / WF_TRACE_WAVES) / (TR_BLOCK * (uint32_t)sizeof(uint32_t)));
+        if (const char* e = getenv("TRAYHIP_WF_LDS_DEPTH")) lds_depth = std::min<uint32_t>(full_depth, (uint32_t)std::max(1, atoi(e)));
+        s->trace_lds_depth = lds_depth;
+        s->trace_lds_bytes = lds_depth * TR_BLOCK * (uint32_t)sizeof(uint32_t);
+        hipError_t oe = s->animated ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, 1>, TR_BLOCK, s->trace_lds_bytes)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, 0>, TR_BLOCK, s->trace_lds_bytes);
+        if (oe != hipSuccess || per_cu < 1) per_cu = 1;
+        s->n_blocks_trace = (uint32_t)(cus * per_cu);
+        const size_t ovf_entries = (size_t)(full_depth - lds_depth + 1u) * s->n_blocks_trace * TR_BLOCK;   // per view: their traversal kernels overlap
+        s->ovf_entries = ovf_entries;
+        if (!grab((size_t)WF_PIPES_MAX * ovf_entries * sizeof(uint32_t), &p)) return TRAY_E_NOMEM;
+        s->d_stack_overflow = static_cast<uint32_t*>(p);
+        if (!grab((size_t)n_slots * sizeof(uint32_t), &p)) return TRAY_E_NOMEM;
+        s->d_fallback = static_cast<uint32_t*>(p);
+        if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] dynamic-fetch traversal: %u of %u stack entries in LDS, %d workgroups per CU\n", lds_depth, full_depth, per_cu);
+    }
+    if (hipHostMalloc(reinterpret_cast<void**>(&s->h_done), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("hipHostMalloc failed"); wf_free(s); return TRAY_E_NOMEM; }
+    s->wf_ready = true;
+    return TRAY_OK;
+}
+
 // Wavefront schedule: rounds of six stage kernels over the path pool until every tile is done.
 // The host only polls a "tiles done" word every WF_POLL rounds; kernels of finished chunks exit at once.
 static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride,
@@ -1394,63 +1498,29 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     if (!s->narrow_trees) { set_error("wavefront schedule: a BVH of more than 8 388 607 nodes or triangles (the traversal keeps a node as a 32-bit descriptor)"); return TRAY_E_UNSUPPORTED; }
     if (!s->ordered_boxes) { set_error("wavefront schedule: a BVH box with min > max (or NaN) on some axis; TRAYHIP_MODE=mega renders such a scene with the tile kernel"); return TRAY_E_UNSUPPORTED; }
     if (!s->wf_ready) {
-        if (s->pool.data) { set_error("the wavefront buffers of this scene could not be allocated by an earlier call"); return TRAY_E_NOMEM; }
-        uint32_t n_slots = (s->animated && s->dev.xf_cache_lanes) ? s->dev.xf_cache_lanes : wf_slot_count(s);   // (the transform cache was sized at creation)
-        s->n_chunks = n_slots / TR_BLOCK;
-        void* p = nullptr;
-        HIP_CHECK(hipMalloc(&p, (size_t)F_COUNT * n_slots * sizeof(float)));
-        s->allocs.push_back(p);
-        s->pool.data = static_cast<float*>(p); s->pool.n_slots = n_slots; s->pool.seg_cap = wf_seg_cap(s->n_chunks);
-        const size_t q_cap = (size_t)WF_SEGS * s->pool.seg_cap;   // entries of one queue: WF_SEGS segments (wavefront.h)
-        HIP_CHECK(hipMalloc(&p, (size_t)s->n_chunks * sizeof(WfChunk)));
-        s->allocs.push_back(p); s->d_chunks = static_cast<WfChunk*>(p);
-        HIP_CHECK(hipMalloc(&p, (size_t)s->n_chunks * ROWBIN_SIZE * sizeof(float)));
-        s->allocs.push_back(p); s->d_bins = static_cast<float*>(p);
-        HIP_CHECK(hipMemset(s->d_bins, 0, (size_t)s->n_chunks * ROWBIN_SIZE * sizeof(float)));
-        HIP_CHECK(hipMalloc(&p, 2 * sizeof(uint32_t)));
-        s->allocs.push_back(p); s->d_wf_counters = static_cast<uint32_t*>(p);
-        // ray queues A, B, C, regeneration queue and the control words of their segments, for up to WF_PIPES_MAX views (a view's segments
-        // are sized for its own chunks: WF_SEGS * TR_BLOCK entries of rounding per view and queue)
-        const size_t q_slack = (size_t)WF_PIPES_MAX * WF_SEGS * TR_BLOCK;
-        // (an entry of a ray queue is the ray: WF_RAY_WORDS words; the regeneration queue holds slot indices)
-        HIP_CHECK(hipMalloc(&p, ((3 * WF_RAY_WORDS + 1) * (q_cap + q_slack) + (size_t)WF_PIPES_MAX * WF_QCTL_WORDS) * sizeof(uint32_t)));
-        s->allocs.push_back(p); s->d_queues = static_cast<uint32_t*>(p);
-        s->wf_sort = !(s->feat & FEAT_TEX);   // the kind-pure kernels read lobes from the material table; textured materials have theirs per hit
-        if (s->wf_sort) {   // shading queues of the material sort (slot indices), one per material kind
-            HIP_CHECK(hipMalloc(&p, (size_t)WF_MAT_KINDS * (q_cap + q_slack) * sizeof(uint32_t)));
-            s->allocs.push_back(p); s->d_kind_queues = static_cast<uint32_t*>(p);
+        // the pool and its queues: as many slots as wf_slot_count grants; if hipMalloc still refuses (fragmentation, another scene's pool
+        // allocated since), everything allocated so far is freed and half the slots are tried, down to 64 chunks -- then TRAY_E_NOMEM,
+        // with the handle left as it was
+        uint32_t n_slots = (s->animated && s->dev.xf_cache_lanes) ? std::min(s->dev.xf_cache_lanes, wf_slot_wish(s)) : wf_slot_count(s);   // (the transform cache was sized at creation)
+        for (;;) {
+            const int rc = wf_alloc(s, n_slots);
+            if (rc == TRAY_OK) break;
+            if (rc != TRAY_E_NOMEM) return rc;
+            if (n_slots / 2u < 64u * TR_BLOCK) {
+                set_error("the wavefront schedule's buffers could not be allocated even for " + std::to_string(n_slots) + " pool slots (" +
+                          std::to_string((n_slots * wf_bytes_per_slot()) >> 20) + " MiB): " + tray_last_error());
+                return TRAY_E_NOMEM;
+            }
+            n_slots = n_slots / 2u / TR_BLOCK * TR_BLOCK;
+            s->wf_shrunk = true;
         }
-        {
-            int per_cu = 0, cus = 256;
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-            // LDS stack entries per lane such that WF_TRACE_WAVES workgroups (4 waves each = one wave per SIMD) fit in the CU's 160 KB
-            // (a node on this kernel's stack is two words: descriptor and entry distance; up to three per expanded record)
-            const uint32_t full_depth = std::max(s->quad_stack_words, 8u);
-            uint32_t lds_depth = std::min<uint32_t>(full_depth, (160u * 1024u / WF_TRACE_WAVES) / (TR_BLOCK * (uint32_t)sizeof(uint32_t)));
-            if (const char* e = getenv("TRAYHIP_WF_LDS_DEPTH")) lds_depth = std::min<uint32_t>(full_depth, (uint32_t)std::max(1, atoi(e)));
-            s->trace_lds_depth = lds_depth;
-            s->trace_lds_bytes = lds_depth * TR_BLOCK * (uint32_t)sizeof(uint32_t);
-            hipError_t oe = s->animated ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, 1>, TR_BLOCK, s->trace_lds_bytes)
-                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_trace_dyn<0, 0>, TR_BLOCK, s->trace_lds_bytes);
-            if (oe != hipSuccess || per_cu < 1) per_cu = 1;
-            s->n_blocks_trace = (uint32_t)(cus * per_cu);
-            const size_t ovf_entries = (size_t)(full_depth - lds_depth + 1u) * s->n_blocks_trace * TR_BLOCK;   // per view: their traversal kernels overlap
-            s->ovf_entries = ovf_entries;
-            HIP_CHECK(hipMalloc(&p, (size_t)WF_PIPES_MAX * ovf_entries * sizeof(uint32_t)));
-            s->allocs.push_back(p); s->d_stack_overflow = static_cast<uint32_t*>(p);
-            HIP_CHECK(hipMalloc(&p, (size_t)n_slots * sizeof(uint32_t)));
-            s->allocs.push_back(p); s->d_fallback = static_cast<uint32_t*>(p);
-            if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] dynamic-fetch traversal: %u of %u stack entries in LDS, %d workgroups per CU\n", lds_depth, full_depth, per_cu);
-        }
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s->h_done), sizeof(uint32_t), hipHostMallocDefault));
-        s->wf_ready = true;
     }
     // tiles are cut into slices of their samples while the pool has at least half again as many chunks as the launch has work items
     // (k_wf_advance; a slice costs its own film resolve: at 8 M slots and 32 400 tiles halving them measured 124 against 132 Msamples/s); a
     // slice keeps at least 16 samples per pixel (TRAYHIP_WF_SLICES overrides: 1, 2, 4)
     uint32_t slice_shift = 0u;
     while ((1u << (slice_shift + 1u)) <= WF_MAX_SLICES && ((uint64_t)tile_count << slice_shift) * 3u / 2u <= s->n_chunks && (spp >> (slice_shift + 1u)) >= 16u) ++slice_shift;
+    if (s->wf_req_slices) { slice_shift = 0u; while ((2u << slice_shift) <= s->wf_req_slices && (2u << slice_shift) <= WF_MAX_SLICES && (spp >> (slice_shift + 1u)) >= 1u) ++slice_shift; }   // tray_scene_set_wavefront
     if (const char* e = getenv("TRAYHIP_WF_SLICES")) { slice_shift = 0u; while ((2u << slice_shift) <= (uint32_t)std::max(1, atoi(e)) && (2u << slice_shift) <= WF_MAX_SLICES && (spp >> (slice_shift + 1u)) >= 1u) ++slice_shift; }
     tile_count <<= slice_shift;   // from here on: work items
     const uint32_t n_chunks = std::min(s->n_chunks, tile_count);
@@ -1466,8 +1536,10 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     // the views: equal shares of the chunks in use. Measured on the C5 stand-in at full detail (1 / 2 / 3 / 4 views): see DESIGN.md section 4
     // (with rounds of 24 M slots and more one view is ahead: C5 stand-in 155.8 against 152.9 Msamples/s at 32 M; at 16 M two views 146.8 against 144.3)
     uint32_t n_views = n_chunks >= (24u << 20) / TR_BLOCK ? 1u : 2u;
+    if (s->wf_req_views) n_views = std::min<uint32_t>(WF_PIPES_MAX, s->wf_req_views);   // tray_scene_set_wavefront
     if (const char* e = getenv("TRAYHIP_WF_PIPES")) n_views = (uint32_t)std::max(1, std::min(WF_PIPES_MAX, atoi(e)));
     n_views = std::max(1u, std::min(n_views, n_chunks / WF_SEGS));   // (a view of a few chunks would only add launches)
+    s->last_views = n_views; s->last_slices = 1u << slice_shift; s->last_was_wavefront = true;
     WfView views[WF_PIPES_MAX];
     {
         const size_t q_total = (size_t)WF_SEGS * s->pool.seg_cap + (size_t)WF_PIPES_MAX * WF_SEGS * TR_BLOCK;   // entries of one queue kind over all views
@@ -1653,6 +1725,7 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     kf = mix(kf ^ (uint32_t)(seed >> 32));
     kf = mix(kf + s->dev.frame);
     if (s->sampler_kind != TRAY_SAMPLER_LOW_DISCREPANCY || s->deforming) return launch_sampler(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
+    s->last_was_wavefront = false;
     if (s->wavefront) return launch_wavefront(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
     // Slices per tile. A slice costs its own film resolve and flush, so tiles are only halved (quartered) when a launch has fewer than
     // 12 (3) of them per workgroup and a slice keeps >= 256 samples per pixel -- measured on one GPU's share of C2 at 8 GPUs (4050
@@ -1879,6 +1952,44 @@ int tray_render_frame_multi(TrayMultiScene* m, uint32_t spp, uint64_t seed, floa
     std::vector<float> tmp(m->n_floats);
     HIP_CHECK(hipMemcpy(tmp.data(), m->films[0], m->n_floats * sizeof(float), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < m->n_floats; ++i) rgbw_host[i] += tmp[i];
+    return TRAY_OK;
+}
+
+int tray_scene_set_wavefront(TrayDeviceScene* s, uint32_t pool_slots, uint32_t views, uint32_t slices) {
+    if (!s) { set_error("tray_scene_set_wavefront: null argument"); return TRAY_E_INVALID; }
+    if (s->broken) { set_error("tray_scene_set_wavefront: the handle is only good for tray_scene_destroy after a failed frame update"); return TRAY_E_INVALID; }
+    if (views > (uint32_t)WF_PIPES_MAX) { set_error("tray_scene_set_wavefront: at most " + std::to_string(WF_PIPES_MAX) + " views"); return TRAY_E_INVALID; }
+    if (slices > WF_MAX_SLICES || (slices & (slices - 1u)) != 0u) { set_error("tray_scene_set_wavefront: slices per tile must be 0 or a power of two up to " + std::to_string(WF_MAX_SLICES)); return TRAY_E_INVALID; }
+    const uint32_t before = wf_slot_wish(s);
+    s->wf_req_slots = pool_slots; s->wf_req_views = views; s->wf_req_slices = slices;
+    if (s->wf_ready && wf_slot_wish(s) != before) {   // another pool size: the buffers go, the next render call allocates them anew
+        HIP_CHECK(hipSetDevice(s->device));
+        HIP_CHECK(hipDeviceSynchronize());
+        wf_free(s);
+        s->wf_shrunk = false;
+    }
+    return TRAY_OK;
+}
+int tray_multi_set_wavefront(TrayMultiScene* m, uint32_t pool_slots, uint32_t views, uint32_t slices) {
+    if (!m) { set_error("tray_multi_set_wavefront: null argument"); return TRAY_E_INVALID; }
+    for (TrayDeviceScene* s : m->scenes) {
+        const int rc = tray_scene_set_wavefront(s, pool_slots, views, slices);
+        if (rc != TRAY_OK) return rc;
+    }
+    return TRAY_OK;
+}
+int tray_last_schedule(TrayDeviceScene* s, TrayScheduleInfo* out) {
+    if (!s || !out) { set_error("tray_last_schedule: null argument"); return TRAY_E_INVALID; }
+    std::memset(out, 0, sizeof *out);
+    out->wavefront = s->wavefront ? 1u : 0u;
+    out->launched_wavefront = s->last_was_wavefront ? 1u : 0u;
+    out->pool_slots = s->pool.n_slots; out->chunks = s->n_chunks;
+    out->views = s->last_was_wavefront ? s->last_views : 0u; out->slices = s->last_was_wavefront ? s->last_slices : 0u;
+    out->pool_bytes = s->pool.data ? (uint64_t)F_COUNT * s->pool.n_slots * sizeof(float) : 0u;
+    out->schedule_bytes = s->pool.data ? (uint64_t)s->pool.n_slots * wf_bytes_per_slot() : 0u;
+    out->xf_cache_bytes = s->xf_cache_bytes;
+    out->n_moving = s->dev.n_moving;
+    out->tile_workgroups = (uint32_t)s->n_blocks;
     return TRAY_OK;
 }
 

@@ -37,7 +37,7 @@ uint32_t tray_abi_sizeof(const char* name) {
 #define TRAY_SZ(T) if (n == #T) return (uint32_t)sizeof(T);
     TRAY_SZ(TrayBvhNode) TRAY_SZ(TrayTriVerts) TRAY_SZ(TrayTriAttrs) TRAY_SZ(TrayMesh) TRAY_SZ(TrayInstance) TRAY_SZ(TrayKeyframe)
     TRAY_SZ(TrayXformLevel) TRAY_SZ(TrayColorKey) TRAY_SZ(TrayMaterial) TRAY_SZ(TrayMerlTable) TRAY_SZ(TrayCamera) TRAY_SZ(TrayFilm)
-    TRAY_SZ(TrayFlatScene) TRAY_SZ(TrayMeshKeys) TRAY_SZ(TrayTexture) TRAY_SZ(TrayTexFrame) TRAY_SZ(TraySceneInfo) TRAY_SZ(TrayKernelTiming) TRAY_SZ(TrayRay) TRAY_SZ(TrayHit)
+    TRAY_SZ(TrayFlatScene) TRAY_SZ(TrayMeshKeys) TRAY_SZ(TrayTexture) TRAY_SZ(TrayTexFrame) TRAY_SZ(TraySceneInfo) TRAY_SZ(TrayKernelTiming) TRAY_SZ(TrayScheduleInfo) TRAY_SZ(TrayRay) TRAY_SZ(TrayHit)
 #undef TRAY_SZ
     return 0;
 }
