@@ -335,14 +335,12 @@ int emu_wf_trace(const TrayFlatScene* f, int stage, uint32_t n, const TrayRay* r
         const f3 o = mk(rays[s].o[0], rays[s].o[1], rays[s].o[2]), dd = mk(rays[s].d[0], rays[s].d[1], rays[s].d[2]);
         wf_put_ray(queue.data(), (size_t)seg * pool.seg_cap + qctl[seg * WF_SEG_STRIDE + stage]++, s, o, dd,
                    LF_ALIVE | (stage == 0 && rays[s].min_t == 0.0f ? WF_CAMERA_RAY : 0u));   // an entry of a ray queue is the ray (wavefront.h)
-        if (stage == 0) { st3(pool, F_O, s, o); st3(pool, F_D, s, dd); pu(pool, F_BOUNCE, s) = rays[s].min_t == 0.0f ? 0u : 1u; }
-        else { st3(pool, F_P, s, o); st3(pool, F_AUX, s, dd); }
-        pu(pool, F_FLAGS, s) = LF_ALIVE;
+        pu(pool, F_FLAGS, s) = LF_ALIVE;   // (the traversal kernels and the fallback kernel read the queue entry alone)
     }
     const uint32_t full = e.quad_words;
     if (lds_depth == 0 || lds_depth > full) lds_depth = full;
     std::vector<uint32_t> overflow((size_t)(full + 64u) * blocks * TR_BLOCK, 0u);
-    std::vector<uint32_t> fallback(n_slots, 0u);
+    std::vector<uint32_t> fallback((size_t)n_slots * WF_RAY_WORDS, 0u);   // records of the deferred rays (on the device: the buffer of a ray queue that is idle during the stage)
     std::vector<DevStats> stats(WF_STAT_SLOTS);
     std::memset(stats.data(), 0, stats.size() * sizeof(DevStats));
     // (the traversal, then the rays it handed to the reference's binary traversal: wf_round of kernels.hip)
@@ -485,7 +483,6 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     if (lds_depth == 0 || lds_depth > full) lds_depth = full;
     trace_blocks = std::max(1u, std::min(trace_blocks, n_chunks));
     std::vector<uint32_t> overflow((size_t)(full + 64u) * trace_blocks * TR_BLOCK, 0u);
-    std::vector<uint32_t> fallback(n_slots, 0u);
     const size_t fb_lds = (size_t)e.depth * TR_BLOCK * 4;
     const size_t dyn_lds = (size_t)lds_depth * TR_BLOCK * 4;
     const int feat = feature_set(e);
@@ -504,20 +501,20 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
         EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_advance<A>(e.d, pool, chunks.data(), bins.data(), tiles.data(), n_items, tile_count, 1u, spp, kf, rgbw, \
                                                          counters, counters + 1, stats.data(), qa, qr, qctl, slice_shift); });                          \
         EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_regen<A>(e.d, pool, chunks.data(), tiles.data(), tile_count, 1u, spp, kf, stats.data(), qr, qa, qctl, slice_shift); }); \
-        EMU_TRACE_STAGE(0, A, qa);                                                                                                          \
+        EMU_TRACE_STAGE(0, A, qa, qb);                                                                                                        \
         EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_begin<A>(e.d, pool, n_active, stats.data(), qb, qctl, sorted ? kind_queues.data() : nullptr); }); \
-        EMU_TRACE_STAGE(1, A, qb);                                                                                                          \
+        EMU_TRACE_STAGE(1, A, qb, qc);                                                                                                        \
         if (sorted) {   /* wf_round of kernels.hip: one kind-pure shading launch per material kind of the scene */                        \
             EMU_QUERY_KIND(A, TRAY_MAT_MATTE); EMU_QUERY_KIND(A, TRAY_MAT_PLASTIC); EMU_QUERY_KIND(A, TRAY_MAT_METAL); EMU_QUERY_KIND(A, TRAY_MAT_GLASS); \
             EMU_QUERY_KIND(A, TRAY_MAT_ROUGH_GLASS); EMU_QUERY_KIND(A, TRAY_MAT_SPECULAR_METAL); EMU_QUERY_KIND(A, TRAY_MAT_MERL);          \
         } else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query<A, FEAT_ALL | FEAT_TEX>(e.d, pool, n_active, qc, qctl, stats.data()); });  \
-        EMU_TRACE_STAGE(2, A, qc);                                                                                                          \
+        EMU_TRACE_STAGE(2, A, qc, qa);                                                                                                        \
     } while (0)
 #define EMU_QUERY_KIND(A, K) do { if (kinds_present & (1u << K)) EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_query_kind<A, K>(e.d, pool, kind_queues.data(), qc, qctl, stats.data()); }); } while (0)
-#define EMU_TRACE_STAGE(S, A, Q)                                                                                                            \
+#define EMU_TRACE_STAGE(S, A, Q, FB) /* FB: the queue buffer that is idle during stage S takes the deferred rays' records (wf_round) */                                                                                                          \
     do {                                                                                                                                    \
-        EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data(), fallback.data()); }, dyn_lds); \
-        EMU_K(1u, TR_BLOCK, [&] { k_wf_trace_fallback<S, A>(e.d, pool, qctl, fallback.data()); }, fb_lds);                                    \
+        EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data(), FB); }, dyn_lds); \
+        EMU_K(1u, TR_BLOCK, [&] { k_wf_trace_fallback<S, A>(e.d, pool, qctl, FB); }, fb_lds);                                    \
         g_wf_deferred += qctl[WF_FB_WORD + S];                                                                                              \
     } while (0)
 #define EMU_ROUND_F(A)                                                                                                                      \

@@ -12,7 +12,8 @@ import os, sys
 sys.path.insert(0, "$ROOT")
 import tray_rust_amd as T
 scene, rt, spp, fi = T.Scene.load_file("/tmp/c5/tr15_like.json")
-fi = T.FrameInfo(fi.frames, fi.time, 330, 330)
+FR = int(os.environ.get("C5_FRAME", "330"))
+fi = T.FrameInfo(fi.frames, fi.time, FR, FR)
 hip = T.Hip(0, seed=1)
 for rep in range(2):
     rt.clear()
@@ -20,7 +21,7 @@ for rep in range(2):
     hip.render(scene, rt, T.Config("/tmp/c5", "tr15_like", $SPP, 1, fi, (0, 0)))
     sys.stdout = sys.__stdout__
     t = hip.last_timing
-print(f"{os.environ.get('LABEL', 'default'):14s} tr15_like full detail frame 330 1080p $SPP spp: {t.samples / t.render_ms / 1e3:7.2f} Msamples/s  {t.render_ms:.1f} ms  launches {t.launches}  V {t.vertices / t.samples:.4f}", flush=True)
+print(f"{os.environ.get('LABEL', 'default'):14s} tr15_like full detail frame {FR} 1080p $SPP spp: {t.samples / t.render_ms / 1e3:7.2f} Msamples/s  {t.render_ms:.1f} ms  launches {t.launches}  V {t.vertices / t.samples:.4f}", flush=True)
 PY
 for spec in "$@"; do
   label=${spec%%=*}; rest=${spec#*=}

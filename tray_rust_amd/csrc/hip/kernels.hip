@@ -854,21 +854,22 @@ static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, ui
                        spp, kf, rgbw_dev, s->d_wf_counters, s->d_wf_counters + 1, s->d_stats, v.qa, v.qr, v.qctl, slice_shift);
     hipLaunchKernelGGL(k_wf_regen<ANIM>, qgrid, block, 0, stream, v.dev, v.pool, v.chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, v.qr, v.qa, v.qctl, slice_shift);
     // (each traversal is followed by the few-thread kernel that traces the rays it handed over to the reference's binary traversal:
-    // direction components that are zero / denormal / not finite -- normally none, the kernel reads one word and exits)
+    // direction components that are zero / denormal / not finite -- normally none, the kernel reads one word and exits. The deferred rays'
+    // records go to the buffer of the ray queue that is idle during the stage: B's during A, C's during B, A's during C)
     const dim3 fgrid(8);
-    hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qa, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.fallback);
-    hipLaunchKernelGGL((k_wf_trace_fallback<0, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.fallback);
+    hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qa, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qb);
+    hipLaunchKernelGGL((k_wf_trace_fallback<0, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qb);
     hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, v.dev, v.pool, n_active, s->d_stats, v.qb, v.qctl, v.kq);
-    hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qb, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.fallback);
-    hipLaunchKernelGGL((k_wf_trace_fallback<1, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.fallback);
+    hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qb, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qc);
+    hipLaunchKernelGGL((k_wf_trace_fallback<1, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qc);
     if (v.kq) {   // kind-pure shading over the sorted queues: one launch per material kind the scene contains
 #define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), qgrid, block, 0, stream, v.dev, v.pool, v.kq, v.qc, v.qctl, s->d_stats)
         WF_QUERY_KIND(TRAY_MAT_MATTE); WF_QUERY_KIND(TRAY_MAT_PLASTIC); WF_QUERY_KIND(TRAY_MAT_METAL); WF_QUERY_KIND(TRAY_MAT_GLASS);
         WF_QUERY_KIND(TRAY_MAT_ROUGH_GLASS); WF_QUERY_KIND(TRAY_MAT_SPECULAR_METAL); WF_QUERY_KIND(TRAY_MAT_MERL);
 #undef WF_QUERY_KIND
     } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT_ALL | FEAT_TEX>), grid, block, 0, stream, v.dev, v.pool, n_active, v.qc, v.qctl, s->d_stats);
-    hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qc, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.fallback);
-    hipLaunchKernelGGL((k_wf_trace_fallback<2, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.fallback);
+    hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qc, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qa);
+    hipLaunchKernelGGL((k_wf_trace_fallback<2, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qa);
 }
 
 // Path pool slots of the wavefront schedule: never more than the film has pixels x 4 x WF_MAX_SLICES (a chunk of 256 per tile slice), and for
@@ -879,7 +880,7 @@ static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, ui
 // they count as free, or the budget -- and with it the pool size -- would depend on which frame came first
 // bytes of the schedule's buffers per pool slot (pool fields, three ray queues + regeneration queue, kind queues, fallback word, row bins per chunk)
 static size_t wf_bytes_per_slot() {
-    return (size_t)F_COUNT * sizeof(float) + (3 * WF_RAY_WORDS + 1) * sizeof(uint32_t) + WF_MAT_KINDS * sizeof(uint32_t) + sizeof(uint32_t) +
+    return (size_t)F_COUNT * sizeof(float) + (3 * WF_RAY_WORDS + 1) * sizeof(uint32_t) + WF_MAT_KINDS * sizeof(uint32_t) +
            ((size_t)ROWBIN_SIZE * sizeof(float) + sizeof(WfChunk)) / TR_BLOCK;
 }
 // what the caller (tray_scene_set_wavefront), the environment or the default ask for, before memory is looked at
@@ -1482,8 +1483,6 @@ static int wf_alloc(TrayDeviceScene* s, uint32_t n_slots) {
         s->ovf_entries = ovf_entries;
         if (!grab((size_t)WF_PIPES_MAX * ovf_entries * sizeof(uint32_t), &p)) return TRAY_E_NOMEM;
         s->d_stack_overflow = static_cast<uint32_t*>(p);
-        if (!grab((size_t)n_slots * sizeof(uint32_t), &p)) return TRAY_E_NOMEM;
-        s->d_fallback = static_cast<uint32_t*>(p);
         if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] dynamic-fetch traversal: %u of %u stack entries in LDS, %d workgroups per CU\n", lds_depth, full_depth, per_cu);
     }
     if (hipHostMalloc(reinterpret_cast<void**>(&s->h_done), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("hipHostMalloc failed"); wf_free(s); return TRAY_E_NOMEM; }
@@ -1554,7 +1553,7 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             v.dev = s->dev;
             if (v.dev.xf_cache) v.dev.xf_cache += (size_t)c0 * TR_BLOCK * v.dev.n_moving * TR_XF_WORDS;   // [slot][moving instance][TR_XF_WORDS]
             v.pool = s->pool;
-            v.pool.data += (size_t)c0 * TR_BLOCK;
+            v.pool.first = c0 * TR_BLOCK;   // (the hit records are slot-major, the other fields field-major: the accessors add the view's first slot)
             v.pool.seg_cap = wf_seg_cap(v.n_chunks);
             v.chunks = s->d_chunks + c0;
             v.bins = s->d_bins + (size_t)c0 * ROWBIN_SIZE;
@@ -1562,7 +1561,6 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             v.qctl = qctl_base + (size_t)k * WF_QCTL_WORDS;
             v.kq = s->wf_sort ? s->d_kind_queues + (size_t)WF_MAT_KINDS * q_off : nullptr;
             v.overflow = s->d_stack_overflow + (size_t)k * s->ovf_entries;
-            v.fallback = s->d_fallback + (size_t)c0 * TR_BLOCK;
             v.stream = stream;
             if (k > 0) {
                 if (!s->wf_streams[k]) HIP_CHECK(hipStreamCreateWithFlags(&s->wf_streams[k], hipStreamNonBlocking));

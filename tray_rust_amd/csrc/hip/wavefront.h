@@ -29,29 +29,71 @@ enum : uint32_t {   // flags that only exist between wavefront stages
     WF_HIT_A = 32u, WF_OCCLUDED = 64u, WF_HIT_C = 128u, WF_INVERTEX = 256u, WF_FINISHED = 512u
 };
 
+// Pool layout (round 5): RECORDS for what is read or written in QUEUE order, field-major arrays for the rest.
+// The kernels that run one thread per pool slot (k_wf_advance, k_wf_begin) read and write consecutive slots; the others take their slots
+// from a queue -- the traversal kernels in octant order, the shading kernels in material order, k_wf_regen in the order samples finished --
+// i.e. scattered over the chunk. Rounds 2-4 kept every field field-major (slot i of field f at pool[f * N + i]): for the queue-ordered
+// kernels every 4-byte access then touched a cache line of its own -- k_wf_trace_dyn<A> wrote 752 B per camera sample for 175 B of results,
+// the query kernels fetched ~430 B per vertex for 148 B of fields (profiles/r05_c5_traffic_by_kernel.txt). Now the words that travel together
+// lie together, one record per slot and group, the records of a group side by side (array of structures per group):
+//   HIT   8 words  flags, hit record of the slot's last closest-hit ray           traversal -> k_wf_begin / k_wf_advance
+//   RAY   8 words  origin, direction of the ray towards the next vertex, bounce, sample key
+//                                                                                 k_wf_regen / query -> k_wf_advance (queue A) / k_wf_begin / query
+//   THRU  8 words  throughput, radiance so far, ray.time                          k_wf_regen / query <-> k_wf_begin / query / k_wf_advance
+//   VERT 20 words  shading frame (p, n, tan), material, the light sample          k_wf_begin -> query
+// A record access of a slot-ordered kernel is as dense as before (a wave covers 64 consecutive records); the queue-ordered kernels move the
+// bytes they use. Everything else (first hit's normal, film position, the extras of the few vertices with a stage C ray, texture
+// coordinates) is touched by slot-ordered kernels only, or rarely, and stays field-major.
+// Not stored at all: `direct` and `t_vertex` between k_wf_begin and the query kernels (vertex_begin sets them to 0 and to the throughput,
+// which the query kernels have), `w_o` (it is -d), the occlusion segment's direction (the queue entry carries it; k_wf_trace_fallback reads
+// the deferred ray's own record).
 enum {
-    F_FLAGS, F_BOUNCE, F_KS, F_SNEXT, F_SX, F_SY,
-    F_O, F_D = F_O + 3, F_T = F_D + 3, F_ILLUM = F_T + 3, F_NG = F_ILLUM + 3,
-    F_REC_T = F_NG + 3, F_REC_INST, F_REC_PRIM, F_REC_B1, F_REC_B2,
-    F_P, F_N = F_P + 3, F_TAN = F_N + 3, F_BITAN = F_TAN + 3, F_MAT = F_BITAN + 3,
-    F_WO, F_LINST = F_WO + 3, F_LI, F_WL = F_LI + 3, F_PDFL = F_WL + 3,
-    F_AUX, F_DIRECT = F_AUX + 3, F_MISF = F_DIRECT + 3, F_TV = F_MISF + 3,
-    F_TIME = F_TV + 3,   // ray.time of the path (moving scenes)
-    F_U, F_V,            // hit.dg.u / v of the vertex (scenes with image textures)
+    F_FLAGS, F_REC_T, F_REC_INST, F_REC_PRIM, F_REC_B1, F_REC_B2, F_HIT_PAD0, F_HIT_PAD1,     // HIT
+    F_O, F_D = F_O + 3, F_BOUNCE = F_D + 3, F_KS,                                            // RAY
+    F_T, F_ILLUM = F_T + 3, F_TIME = F_ILLUM + 3, F_THRU_PAD,                                 // THRU
+    F_P, F_N = F_P + 3, F_TAN = F_N + 3, F_MAT = F_TAN + 3, F_LINST, F_LI, F_WL = F_LI + 3, F_PDFL = F_WL + 3, F_VERT_PAD0, F_VERT_PAD1,   // VERT (bitan = cross(tan, n) is recomputed)
+    F_SOA,                                                                                    // ---- field-major from here on
+    F_SNEXT = F_SOA, F_SX, F_SY, F_NG,
+    F_AUX = F_NG + 3, F_DIRECT = F_AUX + 3, F_MISF = F_DIRECT + 3, F_TV = F_MISF + 3,   // between the query kernels and k_wf_advance, for the few vertices with a stage C ray
+    F_U = F_TV + 3, F_V,   // hit.dg.u / v of the vertex (scenes with image textures)
     F_COUNT
 };
+#define WF_HIT_WORDS 8
+static_assert(F_O == 8 && F_T == 16 && F_P == 24 && F_SOA == 44, "record groups of the pool: 8 + 8 + 8 + 20 words");
 
 struct WfPool {
     float* __restrict__ data;   // F_COUNT * n_slots dwords
     uint32_t n_slots;
     uint32_t seg_cap;           // entries per segment of every queue (wf_seg_cap(chunks of the pool)); a queue holds WF_SEGS * seg_cap
+    uint32_t first = 0u;        // a view's first slot (kernels.hip: WfView): slot i of the view is slot first + i of the pool
 };
 struct WfChunk { uint32_t tile, done, next_pair; };   // tile: index into the work list, WF_TILE_NEED or WF_TILE_IDLE; done: finished samples of the
                                                        // tile; next_pair: first (pixel, sample) pair of the tile not handed to a slot yet
 enum : uint32_t { WF_TILE_NEED = 0xfffffffeu, WF_TILE_IDLE = 0xffffffffu };
 
-TR_DEV float& pf(const WfPool& p, int f, uint32_t i) { return p.data[(size_t)f * p.n_slots + i]; }
-TR_DEV uint32_t& pu(const WfPool& p, int f, uint32_t i) { return reinterpret_cast<uint32_t*>(p.data)[(size_t)f * p.n_slots + i]; }
+// (f is a constant at every call site: the layout test folds)
+TR_DEV size_t pidx(const WfPool& p, int f, uint32_t i) {
+    const size_t n = p.n_slots, k = (size_t)i + p.first;
+    return f < F_O ? k * 8u + (size_t)f
+         : f < F_T ? (size_t)F_O * n + k * 8u + (size_t)(f - F_O)
+         : f < F_P ? (size_t)F_T * n + k * 8u + (size_t)(f - F_T)
+         : f < F_SOA ? (size_t)F_P * n + k * 20u + (size_t)(f - F_P)
+         : (size_t)f * n + k;
+}
+TR_DEV float& pf(const WfPool& p, int f, uint32_t i) { return p.data[pidx(p, f, i)]; }
+TR_DEV uint32_t& pu(const WfPool& p, int f, uint32_t i) { return reinterpret_cast<uint32_t*>(p.data)[pidx(p, f, i)]; }
+// the hit record of slot i as the traversal kernels write it and k_wf_begin / k_wf_advance read it: {flags, t, inst, prim | b1, b2}
+TR_DEV void st_hit(const WfPool& p, uint32_t i, uint32_t flags, const HitRec& rec) {
+    uint32_t* __restrict__ r = reinterpret_cast<uint32_t*>(p.data) + (size_t)(i + p.first) * WF_HIT_WORDS;
+    *reinterpret_cast<uint4*>(r) = make_uint4(flags, __float_as_uint(rec.t), rec.inst, rec.prim);
+    *reinterpret_cast<uint2*>(r + 4) = make_uint2(__float_as_uint(rec.b1), __float_as_uint(rec.b2));
+}
+TR_DEV void ld_hit(const WfPool& p, uint32_t i, HitRec& rec) {
+    const uint32_t* __restrict__ r = reinterpret_cast<const uint32_t*>(p.data) + (size_t)(i + p.first) * WF_HIT_WORDS;
+    const uint4 a = *reinterpret_cast<const uint4*>(r);
+    const uint2 b = *reinterpret_cast<const uint2*>(r + 4);
+    rec.t = __uint_as_float(a.y); rec.inst = a.z; rec.prim = a.w; rec.b1 = __uint_as_float(b.x); rec.b2 = __uint_as_float(b.y);
+}
 TR_DEV f3 ld3(const WfPool& p, int f, uint32_t i) { return mk(pf(p, f, i), pf(p, f + 1, i), pf(p, f + 2, i)); }
 TR_DEV void st3(const WfPool& p, int f, uint32_t i, f3 v) { pf(p, f, i) = v.x; pf(p, f + 1, i) = v.y; pf(p, f + 2, i) = v.z; }
 
@@ -287,8 +329,12 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
     HitRec rec;
     rec.t = 0.0f; rec.inst = 0xffffffffu; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
     // hands the lane's ray to k_wf_trace_fallback (the result is written there)
-#define WF_DEFER() do { const uint32_t k_ = atomicAdd(qctl + WF_FB_WORD + STAGE, 1u); fallback[k_] = slot; } while (0)
+    // (`fallback` is the buffer of a ray queue that is idle while this stage runs -- B's during A, C's during B, A's during C --: the ray's
+    // own record goes there, in the order of the counter, and k_wf_trace_fallback reads nothing else)
+#define WF_DEFER() do { const uint32_t k_ = atomicAdd(qctl + WF_FB_WORD + STAGE, 1u);                                                  \
+                        wf_put_ray(fallback, k_, slot, wo, wd, ray_flags | ((STAGE == 0 && min_t == 0.0f) ? WF_CAMERA_RAY : 0u)); } while (0)
     for (;;) {
+        bool deferred = false;   // the lane's ray goes to k_wf_trace_fallback (ONE hand-over site at the end of the iteration: two cost the kernel 25 spilled VGPRs)
         // ---- refill idle lanes from the queue
         if (!exhausted) {
             const unsigned long long idle = __ballot(!active);
@@ -317,7 +363,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                         rec.t = 0.0f; rec.inst = 0xffffffffu; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
                         ++n_rays;
                         if (wf_regular(inv_dir)) active = true;
-                        else WF_DEFER();
+                        else deferred = true;
                     }
                 }
                 if (base + n_idle >= seg_cnt) {   // this segment is drained (by this refill or by somebody else's)
@@ -327,7 +373,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
             }
         }
         WF_CLK(0);
-        if (!__any(active)) { if (exhausted) break; continue; }
+        if (!__any(active || deferred)) { if (exhausted) break; continue; }
         // ---- traversal, while-while form. A lane is in one of three modes:
         //   TM_NODE  EXPANDS the record `cur` refers to (host/gates.hpp: QuadTrees): up to four (box, descriptor) slots -- the children of
         //            a node, with an interior child replaced by ITS two children -- in one 128-byte fetch. All four boxes are tested with
@@ -432,7 +478,6 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
             if (!finished) WF_POP_NODES();
         }
         WF_CLK(2);
-        bool deferred = false;
         if (active && mode == TM_POP && !finished) {
             bool have_node = false;
             while (sp > 0) {
@@ -486,7 +531,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                 const uint32_t gt = wflags & 7u;
                 if (gt == TRAY_GEOM_MESH) {
                     const f3 inv_obj = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
-                    if (!wf_regular(inv_obj)) { WF_DEFER(); deferred = true; break; }   // (the whole ray: the reference's traversal decides, as at the refill)
+                    if (!wf_regular(inv_obj)) { deferred = true; break; }   // (the whole ray: the reference's traversal decides, as at the refill)
                     WF_PUSH(STK_EXIT_MESH);
                     in_mesh = true;
                     cur_inst = i;
@@ -514,7 +559,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
             if (have_node) mode = cur_count != 0u ? TM_LEAF : TM_NODE;
             else finished = true;
         }
-        if (deferred) { finished = false; active = false; }
+        if (deferred) { WF_DEFER(); finished = false; active = false; }
         WF_CLK(3);
         if (finished) {   // write the result to the ray's own slot
             uint32_t flags = ray_flags;   // (the slot's F_FLAGS, brought by the ray: nobody else touches the slot while its ray is traced)
@@ -523,12 +568,9 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
             } else {
                 const uint32_t bit = STAGE == 0 ? WF_HIT_A : WF_HIT_C;
                 flags = any ? (flags | bit) : (flags & ~bit);
-                if (any) {
-                    pf(pool, F_REC_T, slot) = rec.t; pu(pool, F_REC_INST, slot) = rec.inst; pu(pool, F_REC_PRIM, slot) = rec.prim;
-                    pf(pool, F_REC_B1, slot) = rec.b1; pf(pool, F_REC_B2, slot) = rec.b2;
-                }
             }
-            pu(pool, F_FLAGS, slot) = flags;
+            if (STAGE != 1 && any) st_hit(pool, slot, flags, rec);   // one 24-byte piece of the slot's hit record
+            else pu(pool, F_FLAGS, slot) = flags;
             active = false;
         }
         WF_CLK(4);
@@ -562,18 +604,23 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
 
 // The rays k_wf_trace_dyn<STAGE> did not traverse (direction components that are zero, denormal or not finite; about one ray in 1e7 on
 // the bundled scenes): one thread per entry of `fallback`, the reference's own traversal over the binary trees (trace_bvh), the result
-// written exactly as k_wf_trace_dyn writes it. The ray is rebuilt from the pool fields its producer stored next to the queue entry.
+// written exactly as k_wf_trace_dyn writes it. The ray is the record k_wf_trace_dyn copied there -- origin, direction, slot, flags, camera
+// bit -- whatever the pool holds (round 4 rebuilt it from pool fields its producers happened to store: ADVICE round 4).
 template <int STAGE, int ANIM>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_fallback(const DevScene scv, WfPool pool, const uint32_t* __restrict__ qctl, const uint32_t* __restrict__ fallback) {
     const DevScene& sc = scv;
     TR_DYN_LDS(uint32_t, s_stack);
     const uint32_t n = qctl[WF_FB_WORD + STAGE];
     for (uint32_t k = blockIdx.x * TR_BLOCK + threadIdx.x; k < n; k += gridDim.x * TR_BLOCK) {
-        const uint32_t slot = fallback[k];
-        uint32_t flags = pu(pool, F_FLAGS, slot);
+        const uint4* __restrict__ rr = reinterpret_cast<const uint4*>(fallback + (size_t)k * WF_RAY_WORDS);
+        const uint4 r0 = rr[0], r1 = rr[1];   // the deferred ray's own record (wf_put_ray), flags as its producer left them
+        const uint32_t slot = r0.x;
+        uint32_t flags = r1.w & ~WF_CAMERA_RAY;
         Ray ray;
-        if (STAGE == 0) { ray.o = ld3(pool, F_O, slot); ray.d = ld3(pool, F_D, slot); ray.min_t = pu(pool, F_BOUNCE, slot) == 0u ? 0.0f : 0.001f; ray.max_t = TR_INF; }
-        else { ray.o = ld3(pool, F_P, slot); ray.d = ld3(pool, F_AUX, slot); ray.min_t = 0.001f; ray.max_t = STAGE == 1 ? 0.999f : TR_INF; }
+        ray.o = mk(__uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
+        ray.d = mk(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z));
+        if (STAGE == 0) { ray.min_t = (r1.w & WF_CAMERA_RAY) ? 0.0f : 0.001f; ray.max_t = TR_INF; }
+        else { ray.min_t = 0.001f; ray.max_t = STAGE == 1 ? 0.999f : TR_INF; }
         ray.time = ANIM ? pf(pool, F_TIME, slot) : 0.0f;
         ray.col = slot;
         HitRec rec;
@@ -584,12 +631,9 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_fallback(const DevScene s
         } else {
             const uint32_t bit = STAGE == 0 ? WF_HIT_A : WF_HIT_C;
             flags = any ? (flags | bit) : (flags & ~bit);
-            if (any) {
-                pf(pool, F_REC_T, slot) = rec.t; pu(pool, F_REC_INST, slot) = rec.inst; pu(pool, F_REC_PRIM, slot) = rec.prim;
-                pf(pool, F_REC_B1, slot) = rec.b1; pf(pool, F_REC_B2, slot) = rec.b2;
-            }
         }
-        pu(pool, F_FLAGS, slot) = flags;
+        if (STAGE != 1 && any) st_hit(pool, slot, flags, rec);
+        else pu(pool, F_FLAGS, slot) = flags;
     }
 }
 
@@ -599,8 +643,11 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_fallback(const DevScene s
 // reserves a range in each kind's global queue with ONE atomic per kind present, and the slot INDICES are written there -- a
 // counting sort of 256 jobs, nothing but indices moves. k_wf_query_kind<kind> then shades each queue with full waves of one
 // material kind and only that kind's lobe code compiled in, instead of one thread per pool slot running every kind's code.
+#ifndef WF_SHADE_WAVES
+#define WF_SHADE_WAVES 4   // waves per SIMD the shading stage kernels (k_wf_begin, k_wf_query_kind) are compiled for: they wait on HBM round trips
+#endif                     // for two thirds of their wave cycles, so occupancy is what hides them (round 5: query_kind<matte> had drifted to 131 VGPRs = 3 waves)
 template <int ANIM>
-__global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPool pool, uint32_t n_active, DevStats* __restrict__ stats,
+__global__ __launch_bounds__(TR_BLOCK, WF_SHADE_WAVES) void k_wf_begin(const DevScene scv, WfPool pool, uint32_t n_active, DevStats* __restrict__ stats,
                                                        uint32_t* __restrict__ queue_b, uint32_t* __restrict__ qctl, uint32_t* __restrict__ kind_queues) {
     __shared__ uint32_t s_cnt[8], s_base[8];
     __shared__ uint32_t s_oct_cnt[WF_SORT_KEYS], s_oct_base[WF_SORT_KEYS];
@@ -630,10 +677,10 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
         ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
         LN_O(ln) = ld3(pool, F_O, i); ln.d = ld3(pool, F_D, i);
         ln.throughput = ld3(pool, F_T, i); ln.illum = ld3(pool, F_ILLUM, i);
+        const f3 illum_in = ln.illum;
         ln.first_ng = ld3(pool, F_NG, i);
         HitRec rec;
-        rec.t = pf(pool, F_REC_T, i); rec.inst = pu(pool, F_REC_INST, i); rec.prim = pu(pool, F_REC_PRIM, i);
-        rec.b1 = pf(pool, F_REC_B1, i); rec.b2 = pf(pool, F_REC_B2, i);
+        ld_hit(pool, i, rec);
         Counters cnt;
         cnt.rays = 0; cnt.vertices = 0;
         ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
@@ -660,15 +707,14 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_begin(const DevScene scv, WfPoo
             flags = 0u;
         } else {
         pu(pool, F_FLAGS, i) = ln.flags | WF_INVERTEX;
-        st3(pool, F_ILLUM, i, ln.illum);
+        // (illum changes here only where an emitter was hit by a camera or specular ray, path.rs:72-75; `direct` = 0, `t_vertex` = throughput
+        // and w_o = -d are not stored: the query kernels have what they are made of)
+        if (ln.illum.x != illum_in.x || ln.illum.y != illum_in.y || ln.illum.z != illum_in.z) st3(pool, F_ILLUM, i, ln.illum);
         if (ln.bounce == 0u) st3(pool, F_NG, i, ln.first_ng);
         st_bsdf(sc, pool, i, ln.bsdf);
-        st3(pool, F_WO, i, -ln.d);
         pu(pool, F_LINST, i) = ln.light_inst;
         st3(pool, F_LI, i, ln.li); st3(pool, F_WL, i, ln.wi_l); pf(pool, F_PDFL, i) = ln.pdf_l;
-        if (ln.flags & LF_SHADOW) { st3(pool, F_AUX, i, ln.aux_d); b_oct = wf_octant(ln.aux_d); b_o = ln.bsdf.p; b_d = ln.aux_d; }
-        st3(pool, F_DIRECT, i, ln.direct);
-        st3(pool, F_TV, i, ln.t_vertex);
+        if (ln.flags & LF_SHADOW) { b_oct = wf_octant(ln.aux_d); b_o = ln.bsdf.p; b_d = ln.aux_d; }
         flags = ln.flags;
         kind = ln.bsdf.mat->mat_kind;
         }
@@ -708,8 +754,9 @@ TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, ui
     ln.light_inst = pu(pool, F_LINST, i);
     ln.aux_d = mk(0.0f, 0.0f, 0.0f); ln.mis_f = mk(0.0f, 0.0f, 0.0f);   // (before wi_l is loaded: the two share storage)
     ln.li = ld3(pool, F_LI, i); ln.wi_l = ld3(pool, F_WL, i); ln.pdf_l = pf(pool, F_PDFL, i);
-    ln.direct = ld3(pool, F_DIRECT, i);
-    ln.d = -ld3(pool, F_WO, i);   // (-d is the outgoing direction until the PATH query replaces d)
+    ln.direct = mk(0.0f, 0.0f, 0.0f);   // (as vertex_begin left it)
+    ln.t_vertex = ln.throughput;        // (likewise: the throughput the vertex was reached with, before the PATH query updates it)
+    ln.d = ld3(pool, F_D, i);           // (the ray that reached the vertex: -d is the outgoing direction until the PATH query replaces d)
     ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
     vertex_queries<ANIM, FEAT, KM>(sc, ln, (flags & WF_OCCLUDED) != 0u);
     mis_ray_filter<ANIM>(sc, ln);
@@ -723,11 +770,10 @@ TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, ui
     if (!(ln.flags & LF_LAST)) { st3(pool, F_O, i, LN_O(ln)); st3(pool, F_D, i, ln.d); }
     if (ln.flags & LF_MIS) {   // the vertex ends in k_wf_advance, after stage C has traced the BSDF-sampled light ray
         pu(pool, F_FLAGS, i) = ln.flags;
-        st3(pool, F_DIRECT, i, ln.direct);
+        st3(pool, F_DIRECT, i, ln.direct); st3(pool, F_TV, i, ln.t_vertex);
         st3(pool, F_AUX, i, ln.aux_d); st3(pool, F_MISF, i, ln.mis_f); st3(pool, F_LI, i, ln.li);
     } else {   // no stage C ray (the usual case): vertex_end here, while the vertex is in registers
         ln.illum = ld3(pool, F_ILLUM, i);
-        ln.t_vertex = ld3(pool, F_TV, i);
         HitRec none;
         none.t = 0.0f; none.inst = 0xffffffffu; none.prim = 0u; none.b1 = 0.0f; none.b2 = 0.0f;
         const bool cont = vertex_end<ANIM>(sc, ln, false, none);
@@ -759,7 +805,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(
 // kind lowers to are compiled in (dev_bsdf.h: km_of_material), so the kernels are small (matte 2 lobes' code instead of 9) and
 // every lane of a wave runs the same material's code
 template <int ANIM, int MK>
-__global__ __launch_bounds__(TR_BLOCK) void k_wf_query_kind(const DevScene scv, WfPool pool, const uint32_t* __restrict__ kind_queues,
+__global__ __launch_bounds__(TR_BLOCK, WF_SHADE_WAVES) void k_wf_query_kind(const DevScene scv, WfPool pool, const uint32_t* __restrict__ kind_queues,
                                                             uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl, DevStats* __restrict__ stats) {
     const DevScene& sc = scv;
     __shared__ uint4 s_perm[TR_PERM_BYTES / 16];   // the permutation pool in LDS (as in k_wf_begin)
@@ -862,8 +908,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
             ln.light_inst = pu(pool, F_LINST, i);
             if (flags & LF_MIS) {
                 ln.bsdf.p = ld3(pool, F_P, i); ln.aux_d = ld3(pool, F_AUX, i); ln.mis_f = ld3(pool, F_MISF, i); ln.li = ld3(pool, F_LI, i);
-                rec.t = pf(pool, F_REC_T, i); rec.inst = pu(pool, F_REC_INST, i); rec.prim = pu(pool, F_REC_PRIM, i);
-                rec.b1 = pf(pool, F_REC_B1, i); rec.b2 = pf(pool, F_REC_B2, i);
+                ld_hit(pool, i, rec);
             }
             ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
             const bool cont = vertex_end<ANIM>(sc, ln, (flags & WF_HIT_C) != 0u, rec);
