@@ -57,7 +57,8 @@ TR_DEV DevKey key_interpolate(const DevKey& a, const DevKey& b, float t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) perp[i] = b.q[i] - a.q[i] * cos_theta;
         float len = sqrtf(quat_dot(perp, perp));
-        float c = ref_sincosf(theta_t, 1), sn = ref_sincosf(theta_t, 0);
+        float c, sn;
+        ref_sincosf2(theta_t, sn, c);   // (cos and sin of one angle: reduction and squares shared; bit for bit the two calls, tools/libm_port_check.cpp)
 #pragma unroll
         for (int i = 0; i < 4; ++i) r.q[i] = a.q[i] * c + (perp[i] / len) * sn;
     }

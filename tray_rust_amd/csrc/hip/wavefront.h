@@ -309,6 +309,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
 #endif
     // traversal state (trace_bvh)
     f3 wo = mk(0, 0, 0), wd = mk(0, 0, 0), d = wd;
+    f3 winv = wd;   // 1 / wd, kept for the return from a mesh (three IEEE divisions, ~30 instructions, per mesh left; the kernel has the registers since round 5)
     // origin and reciprocal direction of the ray in the space it is traversing, as the register pairs the node step's packed arithmetic
     // reads them from: (o.x, o.y), (o.z, 1 / d.x), (1 / d.y, 1 / d.z)
     f2 oxy = mk2(0.0f, 0.0f), ozix = oxy, iyz = oxy;
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                         else { min_t = 0.001f; max_t = STAGE == 1 ? 0.999f : TR_INF; }
                         d = wd;
                         const f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        winv = inv_dir;
                         WF_SET_RAY(wo, inv_dir);
                         WF_SIGNS();
                         tree = sc.top_quad_first; cur = 0u; sp = 0; in_mesh = false; any = false; mode = TM_NODE;
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                     in_mesh = false;
                     tree = sc.top_quad_first;
                     d = wd;
-                    WF_SET_RAY(wo, mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z));
+                    WF_SET_RAY(wo, winv);
                     WF_SIGNS();
                     continue;
                 }
