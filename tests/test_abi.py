@@ -53,6 +53,17 @@ def test_version_and_error_channel(built):
     assert e.value.code == T._lib.TRAY_E_IO and "Failed to open scene file" in e.value.message
 
 
+def test_wavefront_entry_points_check_their_arguments(built):
+    import tray_rust_amd as T
+    from tray_rust_amd import _lib as L
+    lib = T.lib()
+    info = L.TrayScheduleInfo()
+    assert lib.tray_scene_set_wavefront(None, 0, 0, 0) == L.TRAY_E_INVALID and b"null" in lib.tray_last_error()
+    assert lib.tray_multi_set_wavefront(None, 0, 0, 0) == L.TRAY_E_INVALID
+    assert lib.tray_last_schedule(None, C.byref(info)) == L.TRAY_E_INVALID
+    assert C.sizeof(L.TrayScheduleInfo) == 8 * 4 + 3 * 8
+
+
 def test_device_calls_fail_loudly_without_gpu(assets):
     """No silent CPU fallback: creating a device scene without a GPU is an error, never a no-op."""
     import torch

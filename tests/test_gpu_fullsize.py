@@ -3,7 +3,10 @@ The whole frames are 2e9 .. 8e9 camera samples -- hours of oracle time -- so eac
 8x8 tiles of its Morton queue (every 64th / 128th tile, 254 .. 507 tiles: the GPU renders shard 0 of N with one-tile chunks through
 tray_render_shard_device, the oracle renders `stride = N`), at the config's full sample count: same tiles, same pixels,
 same seeds, same sampler sequences as in the full frame (the RNG is keyed by pixel and sample index, not by schedule).
-Bar: pixel RMSE < 1e-4 on linear rgb / weight (north_star), vertex counts equal to 1e-4, traversal records bit for bit."""
+Bar: pixel RMSE < 1e-4 on linear rgb / weight (north_star), vertex counts EQUAL, traversal records bit for bit -- and, since round 5, the
+radiance of every camera sample bit for bit: the device calls glibc's sinf / cosf / acosf / atan2f / expf / logf restated
+(tray_rust_amd/csrc/hip/dev_libm.h, every bit pattern checked against the system libm by tools/libm_port_check.cpp), so what is left between
+the two films is the order in which f32 sums the samples of a pixel."""
 import ctypes as C
 import os
 
@@ -42,12 +45,13 @@ def compare(scene, frame, spp, seed, stride, vertex_tol=1e-4, label=""):
     touched = cpu[..., 3] > 0
     assert (touched == (gpu[..., 3] > 0)).all()
     assert np.abs(gpu[..., 3] - cpu[..., 3]).max() < 1e-3 * cpu[..., 3].max()   # filter weights: same positions, f32 sum order differs
-    assert abs(int(tim.vertices) - int(st.vertices)) <= vertex_tol * st.vertices, (tim.vertices, st.vertices)
+    assert int(tim.vertices) == int(st.vertices), (tim.vertices, st.vertices)   # (round 4 allowed 1e-4: ocml's last bits flipped a path in 1e5)
     d = (rgb(gpu) - rgb(cpu))[touched]
     r = float(np.sqrt(np.mean(d ** 2)))
     print(f"{label}: {tiles} tiles x 64 px x {spp} spp = {st.samples} samples, RMSE {r:.3e}, max {np.abs(d).max():.3e}, "
           f"V {st.vertices / st.samples:.4f} (gpu {tim.vertices / tim.samples:.4f}), oracle {st.seconds:.1f}s, retraced {tim.retraced}")
-    assert r < 1e-4
+    assert r < 1e-5   # (the films differ by the order of the f32 sums only; round 4, with ocml's libm: 1.1e-5 .. 2.4e-5)
+    same_samples(scene, frame, spp, seed, label)
     return tim, st
 
 
@@ -99,10 +103,10 @@ def test_c4_dragon_stand_in_full_mesh_1080p_2048spp(tmp_path):
     compare(scene, 0, 2048, 1, 128, label="C4 dragon stand-in (871 200 triangles)")
 
 
-def flip_split(scene, frame, spp, seed, label, n=60000):
-    """Per camera sample, GPU (k_debug_sample_radiance) against the oracle: which share of the samples took ANOTHER path (vertex or ray
-    count differs: a `flip`, e.g. a hit that rounding turned into a miss) and which share of the squared radiance error they carry, against
-    the samples that walked the same path and differ by the rounding of ocml's sin / cos / atan2 / pow ... versus glibc's."""
+def same_samples(scene, frame, spp, seed, label, n=60000):
+    """Per camera sample, GPU (k_debug_sample_radiance) against the oracle: radiance, vertex count and ray count of n random (pixel, sample)
+    pairs of the frame -- every bit. (Round 4, with ocml's sin / cos / atan2 / acos / exp / log on the device: 77 - 84 % of the samples
+    bit-identical, 0.04 - 0.07 % on another path.)"""
     flat = scene.flatten(frame)
     rng = np.random.default_rng(seed)
     px = rng.integers(0, W, n).astype(np.uint32); py = rng.integers(0, H, n).astype(np.uint32); si = rng.integers(0, spp, n).astype(np.uint32)
@@ -113,48 +117,43 @@ def flip_split(scene, frame, spp, seed, label, n=60000):
     flipped = (a[:, 5] != b[:, 5]) | (a[:, 6] != b[:, 6])
     se = ((np.clip(a[:, :3], 0, 1) - np.clip(b[:, :3], 0, 1)) ** 2).sum(axis=1)
     same_bits = (a[:, :3] == b[:, :3]).all(axis=1)
-    print(f"{label}: {n} samples: {100 * same_bits.mean():.1f} % bit-identical radiance, {100 * flipped.mean():.3f} % took another path and carry "
-          f"{100 * se[flipped].sum() / max(se.sum(), 1e-30):.1f} % of the squared per-sample error; per-sample RMSE {np.sqrt(se.mean() / 3):.3e} "
-          f"(same-path samples alone {np.sqrt(se[~flipped].mean() / 3):.3e})")
-    return float(flipped.mean())
+    print(f"   {label}: {n} camera samples: {100 * same_bits.mean():.3f} % bit-identical radiance, {int(flipped.sum())} on another path, per-sample RMSE {np.sqrt(se.mean() / 3):.3e}")
+    assert same_bits.all() and not flipped.any(), (int((~same_bits).sum()), int(flipped.sum()))
+    return 0.0
 
 
 def test_c5_tr15_stand_in_full_detail_1080p_512spp(tmp_path):
     """BASELINE.json configs[4] stand-in at full detail (59 instances, 3.1 M triangles, moving camera / objects / lights): frames of the
-    sequence at the config's film size and sample count (wavefront schedule, per-path spline evaluation) -- the first and the last frame of
-    the 128-frame sequence and frame 330, the latter under two seeds. Since round 4 the spline stacks are evaluated with the reference's
-    bits (dev_libm.h, Q5 for moving instances; the device source on the host returns the oracle's samples bit for bit). What is left
-    between GPU and oracle is NOT paths that flip: per sample (flip_split) 0.04 - 0.07 % of the samples take another path and carry 0 - 4 %
-    of the squared error; 82 - 84 % of the samples are bit-identical and the rest walk the same path with ocml's sin / cos / atan2 / acos /
-    exp / log / pow in the BSDFs where the oracle has glibc's (MERL's angle -> table-bin lookups turn an ulp into another bin).
-    Measured (profiles/r04_*_gpu_suite.log): 8.2e-5 / 5.7e-5 / 0 (lights off) / 7.7e-5 -- the bar stays the north star's 1e-4."""
+    sequence at the config's film size and sample count (wavefront schedule, per-path spline evaluation) -- the first, a middle and the last
+    frame of the 128-frame sequence (8, 11 and 11 instances move within them) and frame 330, the latter under two seeds. Round 4 sat at RMSE
+    8.2e-5 / 5.7e-5 / 7.7e-5 here (82 - 84 % of the samples bit-identical; MERL's angle -> table-bin lookup, bxdf/merl.rs:63-79, turned an ulp
+    of ocml's acos / atan2 into another table entry); with glibc's libm restated on the device every sample is the oracle's, bit for bit, and
+    the films differ by the order of the f32 sums (measured: profiles/r05_*_gpu_suite.log)."""
     p = scenes.write_tr15_like_assets(str(tmp_path), film=(W, H, 512))
     scene, rt, spp, fi = T.Scene.load_file(p if isinstance(p, str) else p[0])
     flat = scene.flatten(330)
     assert flat.contents.n_tris > 3000000 and flat.contents.n_instances == 59 and T.round_spp(spp) == 512
-    worst = 0.0
-    for frame, seed, stride in ((330, 2, 128), (330, 20260926, 256), (0, 2, 256), (127, 2, 256)):
+    for frame, seed, stride in ((330, 2, 128), (330, 20260926, 256), (0, 2, 256), (64, 2, 256), (127, 2, 256)):
         gpu, tim = strided_gpu(scene, frame, 512, seed, stride)
         cpu, st = O.render_tiles(scene.flatten(frame), 512, seed=seed, stride=stride)
         tiles = (N_TILES + stride - 1) // stride
         assert tim.samples == st.samples == tiles * 64 * 512
         touched = cpu[..., 3] > 0
         assert (touched == (gpu[..., 3] > 0)).all()
-        assert abs(int(tim.vertices) - int(st.vertices)) <= 1e-4 * st.vertices, (tim.vertices, st.vertices)
+        assert int(tim.vertices) == int(st.vertices), (tim.vertices, st.vertices)
         d = (rgb(gpu) - rgb(cpu))[touched]
         r = float(np.sqrt(np.mean(d ** 2)))
-        worst = max(worst, r)
         print(f"C5 tr15 stand-in frame {frame} seed {seed}: {tiles} tiles x 64 px x 512 spp = {st.samples} samples, RMSE {r:.3e}, max {np.abs(d).max():.3e}, "
               f"V {st.vertices / st.samples:.4f} (gpu {tim.vertices / tim.samples:.4f}), oracle {st.seconds:.1f}s")
-        flip_split(scene, frame, 512, seed, f"   frame {frame} seed {seed}")
-    assert worst < 1e-4, worst
+        assert r < 1e-5, r
+        same_samples(scene, frame, 512, seed, f"frame {frame} seed {seed}")
 
 
 def test_rank_4_pieces_at_the_film_size_of_the_configs(tmp_path):
     """SURVEY 8f rank 4 at 1920x1080: cornell_box under sampler::Adaptive::new(dim, 16, 128) and under sampler::Uniform, and the AnimatedMesh
     scene at 64 spp -- every 64th tile through the shard entry point against the oracle on the same tiles. Adaptive's per-pixel decisions hang
-    on f32 luminances (ocml vs glibc in the last bits), so its sample total may differ in a pixel or two: 0.2 %, RMSE 1e-3; the other two
-    keep the 1e-4 / per-pixel bars of their small-film tests."""
+    on the f32 luminances of the samples: with the reference's libm on the device they are the oracle's, so the sample totals are EQUAL
+    (round 4 allowed 0.2 % and RMSE 1e-3 for what measured 2.8e-6)."""
     import torch
     scenes.write_assets(str(tmp_path), cornell=(W, H, 1024), small=(W, H, 4096))
     scene, rt, spp, fi = T.Scene.load_file(str(tmp_path / "cornell_box.json"))
@@ -173,11 +172,11 @@ def test_rank_4_pieces_at_the_film_size_of_the_configs(tmp_path):
     touched = cpu[..., 3] > 0
     r = float(np.sqrt(np.mean((rgb(gpu) - rgb(cpu))[touched] ** 2)))
     print(f"Adaptive(16, 128) 1080p, {(N_TILES + 63) // 64} tiles: GPU {tim.samples} samples, oracle {st.samples} (up to {counts.max()} per pixel), RMSE {r:.3e}, {tim.launches} launches")
-    assert abs(int(tim.samples) - int(st.samples)) <= 2e-3 * st.samples and counts.max() > 100 and r < 1e-3
+    assert int(tim.samples) == int(st.samples) and counts.max() > 100 and r < 1e-5
     gpu, tim = strided(O.SAMPLER_UNIFORM, 1, 1, 16, 7)
     cpu, st, _ = O.render_tiles_sampler(flat, O.SAMPLER_UNIFORM, seed=7, stride=16)
     d = np.abs(rgb(gpu) - rgb(cpu)).max(axis=-1)[cpu[..., 3] > 0]
-    assert tim.samples == st.samples and (d > 1e-3).mean() < 2e-3 and np.median(d) < 1e-6
+    assert tim.samples == st.samples and d.max() < 1e-5
     T.check(T.lib().tray_scene_set_sampler(dev, O.SAMPLER_LOW_DISCREPANCY, 1, 1))
     flag_scene, *_ = T.Scene.load_file(scenes.write_waving_flag(str(tmp_path / "flag"), grid=96, n_keys=4, width=W, height=H, samples=64))
     gpu, tim = strided_gpu(flag_scene, 2, 64, 7, 64)
@@ -185,4 +184,4 @@ def test_rank_4_pieces_at_the_film_size_of_the_configs(tmp_path):
     touched = cpu[..., 3] > 0
     r = float(np.sqrt(np.mean((rgb(gpu) - rgb(cpu))[touched] ** 2)))
     print(f"waving_flag (18 432 triangles x 4 keyframes) 1080p 64 spp: RMSE {r:.3e}, V {st.vertices / st.samples:.4f}")
-    assert tim.samples == st.samples and abs(int(tim.vertices) - int(st.vertices)) <= 1e-4 * st.vertices and r < 1e-4
+    assert tim.samples == st.samples and int(tim.vertices) == int(st.vertices) and r < 1e-5

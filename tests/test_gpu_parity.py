@@ -116,6 +116,11 @@ def test_bsdf_eval_pdf_sample(kind, tmp_path):
         a = O.bsdf(flat, mid, flags, dirs, u3)
         b = np.zeros((n, 12), np.float32)
         T.check(T.lib().tray_debug_bsdf(dev, mid, flags, n, dirs.ctypes.data, u3.ctypes.data, b.ctypes.data))
+        if not ggx:   # round 5: the device calls the reference's libm (dev_libm.h): eval, pdf, sampled direction, f and pdf of the sample -- every bit
+            eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+            assert eq.all(), (kind, flags, int((~eq).sum()), np.argwhere(~eq)[:4].tolist())
+            continue
+        # GGX (reachable only through this loader's "microfacet": "ggx" key) calls powf(c, 4), which stays ocml's
         assert (a[:, 11] == b[:, 11]).mean() > 0.999   # sampled lobe type
         same = a[:, 11] == b[:, 11]
         scale = np.maximum(1.0, np.abs(a))
@@ -136,10 +141,10 @@ def test_per_sample_radiance(name, tmp_path):
     a = O.sample_radiance(flat, px, py, si, 64, seed=21)
     b = gpu_radiance(scene, px, py, si, 64, 21)
     assert (a[:, 3:5] == b[:, 3:5]).all()                 # sample positions: integer + exact float ops
-    assert (a[:, 5] == b[:, 5]).mean() > 0.9995           # same number of path vertices
-    d = np.abs(a[:, :3] - b[:, :3]).max(axis=1)
-    assert (d > 1e-3).mean() < 5e-4, (d > 1e-3).mean()    # flipped discrete decisions are rare
-    assert np.median(d) < 1e-6
+    # round 5: radiance, vertex and ray count of every sample are the oracle's bits (rounds 1-4, ocml's libm: 77 % of the samples bit-identical,
+    # a flipped discrete decision in 5e-4 of them)
+    eq = (a[:, :7].view(np.uint32) == b[:, :7].view(np.uint32)).all(axis=1)
+    assert eq.all(), (int((~eq).sum()), a[~eq][:3].tolist(), b[~eq][:3].tolist())
 
 
 @pytest.mark.parametrize("name,spp", [("cornell_box", 64), ("smallpt", 64)])
@@ -334,6 +339,36 @@ def test_wavefront_views_render_the_same_frame(tmp_path, monkeypatch):
     cpu, st = O.render_tiles(scene.flatten(0), 32, seed=9)
     assert timings[0].samples == st.samples
     assert rmse(images[1], cpu) < 1e-4
+
+
+def test_wavefront_pool_through_the_abi(tmp_path, monkeypatch):
+    """tray_scene_set_wavefront / tray_last_schedule (round 5: pool slots, views and slices are part of the ABI, not environment switches):
+    the schedule that ran is the one asked for, a changed pool size re-allocates the buffers, and the film is the same whatever the shape
+    (every sample is keyed by pixel and index) -- on a moving scene, whose transform cache is indexed by pool slot."""
+    monkeypatch.setenv("TRAYHIP_MODE", "wave")
+    scene, rt, _, fi = T.Scene.load_file(scenes.write_moving_box(str(tmp_path), width=128, height=128, samples=64))
+    hip = T.Hip(0, seed=9)
+    images = []
+    for slots, views, slices in ((0, 0, 0), (1 << 16, 2, 4), (1 << 15, 1, 1), (1 << 17, 3, 2)):
+        rt.clear()
+        scene.device_scene(0, 0)
+        hip.set_wavefront(scene, slots, views, slices)
+        hip.render(scene, rt, _config_at(fi, 0, 64))
+        sch = hip.schedule(scene)
+        assert sch["wavefront"] == 1 and sch["launched_wavefront"] == 1 and sch["pool_bytes"] > 0 and sch["schedule_bytes"] > sch["pool_bytes"]
+        if slots:
+            assert sch["pool_slots"] <= slots and sch["pool_slots"] >= min(slots, 64 * 256) and sch["slices"] == slices
+            assert sch["views"] == min(views, max(1, sch["chunks"] // 64))
+        images.append(rt.get_renderf32().reshape(rt.height, rt.width, 4).copy())
+        tim = hip.last_timing
+        assert tim.samples == 128 * 128 * 64
+    for img in images[1:]:
+        assert np.abs(img - images[0]).max() <= 2e-5 * max(1.0, float(np.abs(images[0]).max()))
+    cpu, st = O.render_tiles(scene.flatten(0), 64, seed=9)
+    assert rmse(images[1], cpu) < 1e-5
+    lib = T.lib()
+    dev = scene.device_scene(0, 0)
+    assert lib.tray_scene_set_wavefront(dev, 0, 5, 0) == T._lib.TRAY_E_INVALID and lib.tray_scene_set_wavefront(dev, 0, 0, 3) == T._lib.TRAY_E_INVALID
 
 
 # ---- moving scenes (SURVEY 8f rank 1): per-ray spline evaluation, animated emission and camera ----

@@ -1,6 +1,12 @@
-// glibc's acosf / sinf / cosf restated for the device (and, through tools/libm_port_check.cpp, compiled for the host to be compared
-// with the system libm bit for bit). Plain C++ apart from TR_DEV / __float_as_uint / __uint_as_float, which dev_math.h, the host
-// emulation or the checker provide.
+// glibc's acosf / sinf / cosf / atanf / atan2f / expf / logf restated for the device (and, through tools/libm_port_check.cpp, compiled for the
+// host to be compared with the system libm bit for bit). Plain C++ apart from TR_DEV / __float_as_uint / __uint_as_float, which dev_math.h,
+// the host emulation or the checker provide.
+// Provenance: the algorithms, polynomial coefficients and the two small tables are those of the GNU C Library 2.35 (sysdeps/ieee754/flt-32:
+// e_acosf.c, s_atanf.c, e_atan2f.c -- derived from Sun's fdlibm, "Copyright (C) 1993 by Sun Microsystems, Inc. ... Permission to use, copy,
+// modify, and distribute this software is freely granted, provided that this notice is preserved" --; s_sincosf.h, e_expf.c, e_exp2f_data.c,
+// e_logf.c, e_logf_data.c -- contributed by Arm's optimized-routines, Copyright (C) the Free Software Foundation, distributed under the GNU
+// Lesser General Public License 2.1 or later). They are restated here (not copied: one function per algorithm, branch structure re-cut for
+// SIMT) for ONE purpose: the reference's f32 methods resolve to exactly these functions on Linux, and parity with it is checked bit for bit.
 #pragma once
 #include <stdint.h>
 #include <string.h>

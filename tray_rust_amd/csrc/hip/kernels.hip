@@ -728,6 +728,7 @@ struct TrayDeviceScene {
     TrayInstance* d_instances = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing_valid = false;
+    bool empty_launch = false;           // the last render call had no tiles to render (reported as a launch of zero samples)
     uint32_t launches = 0;
     int n_blocks = 0;
     uint32_t n_materials = 0;
@@ -1713,7 +1714,10 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     if (s->broken) { set_error("this device scene is unusable: a tray_scene_update_frame on it failed"); return TRAY_E_INVALID; }
     HIP_CHECK(hipSetDevice(s->device));
     s->timing_valid = false;
-    if (tile_count == 0) { std::fprintf(stderr, "Warning: This block queue is empty!\n"); return TRAY_OK; }   // block_queue.rs:42-44
+    s->empty_launch = false;
+    // (an empty queue is a valid work item -- a GPU's shard of a small frame dealt to many GPUs: tray_last_timing then reports zeros
+    // instead of "no launch recorded", which made tray_multi_timing fail for 48 tiles on 8 devices: found by tests/test_multi_stub.py)
+    if (tile_count == 0) { std::fprintf(stderr, "Warning: This block queue is empty!\n"); s->empty_launch = true; return TRAY_OK; }   // block_queue.rs:42-44
     HIP_CHECK(hipMemsetAsync(s->d_counter, 0, sizeof(uint32_t), stream));
     HIP_CHECK(hipMemsetAsync(s->d_stats, 0, WF_STAT_SLOTS * sizeof(DevStats), stream));
     HIP_CHECK(hipMemsetAsync(s->d_retraced, 0, sizeof(uint32_t), stream));
@@ -1994,6 +1998,7 @@ int tray_last_schedule(TrayDeviceScene* s, TrayScheduleInfo* out) {
 int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t);
 int tray_multi_timing(TrayMultiScene* m, TrayKernelTiming* per_device, float* reduce_ms) {
     if (!m || !per_device) { set_error("tray_multi_timing: null argument"); return TRAY_E_INVALID; }
+    CurrentDeviceGuard keep_current;   // (tray_last_timing makes each scene's device current: found by tests/test_multi_stub.py)
     for (int d = 0; d < m->n_dev; ++d) {
         const int rc = tray_last_timing(m->scenes[d], per_device + d);
         if (rc != TRAY_OK) return rc;
@@ -2005,6 +2010,7 @@ int tray_multi_timing(TrayMultiScene* m, TrayKernelTiming* per_device, float* re
 int tray_last_timing(TrayDeviceScene* s, TrayKernelTiming* t) {
     if (!s || !t) { set_error("tray_last_timing: null argument"); return TRAY_E_INVALID; }
     std::memset(t, 0, sizeof *t);
+    if (s->empty_launch) return TRAY_OK;
     if (!s->timing_valid) { set_error("tray_last_timing: no launch recorded"); return TRAY_E_INVALID; }
     HIP_CHECK(hipSetDevice(s->device));
     HIP_CHECK(hipEventSynchronize(s->ev1));

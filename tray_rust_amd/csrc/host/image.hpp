@@ -463,6 +463,9 @@ inline bool decode_jpeg(const std::vector<uint8_t>& f, ImageRGBA8& out, std::str
             if (have_frame) { err = "JPEG: more than one frame header"; return false; }   // (a second SOF would meet the first one's sampling factors and planes)
             height = be16(seg + 1); width = be16(seg + 3);
             if ((size_t)width * (size_t)height > ((size_t)1 << 28)) { err = "JPEG: image larger than 2^28 pixels"; return false; }   // (planes are allocated from the header alone)
+            // ... and a file of a few hundred bytes must not make them gigabytes: a coded 8 x 8 block takes at least a few
+            // bits per component, i.e. well under 1024 pixels per byte of file even for a flat image
+            if ((size_t)width * (size_t)height > std::max<size_t>((size_t)1 << 20, f.size() * 1024u)) { err = "JPEG: the frame header announces more pixels than a file of this size can hold"; return false; }
             const int nc = f[seg + 5];
             if ((nc != 1 && nc != 3) || width <= 0 || height <= 0 || seg + 6 + 3 * (size_t)nc > end) { err = "JPEG: unsupported frame (1 or 3 components)"; return false; }
             comps.assign((size_t)nc, JpegComp());
@@ -734,6 +737,7 @@ inline bool decode_gif(const std::vector<uint8_t>& f, ImageRGBA8& out, std::stri
             }
             prev = code;
         }
+        if (idx.size() < (size_t)w * (size_t)h) { err = "GIF: image data ends before the frame is complete"; return false; }   // (image::open fails on a truncated frame; round 4 padded with index 0)
         idx.resize((size_t)w * (size_t)h, 0);
         out.width = (uint32_t)w; out.height = (uint32_t)h;
         out.px.assign((size_t)w * (size_t)h * 4, 0);
