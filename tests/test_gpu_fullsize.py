@@ -50,7 +50,12 @@ def compare(scene, frame, spp, seed, stride, vertex_tol=1e-4, label=""):
     r = float(np.sqrt(np.mean(d ** 2)))
     print(f"{label}: {tiles} tiles x 64 px x {spp} spp = {st.samples} samples, RMSE {r:.3e}, max {np.abs(d).max():.3e}, "
           f"V {st.vertices / st.samples:.4f} (gpu {tim.vertices / tim.samples:.4f}), oracle {st.seconds:.1f}s, retraced {tim.retraced}")
-    assert r < 1e-5   # (the films differ by the order of the f32 sums only; round 4, with ocml's libm: 1.1e-5 .. 2.4e-5)
+    # Every SAMPLE is the oracle's bit for bit (same_samples below); the FILMS differ by the order in which f32 adds them up: a pixel of these
+    # configs is the sum of spp x 64 weighted samples (8 x 8 footprint), each addition rounds to 2^-24 of the running sum, the orders differ
+    # (LDS atomics of 256 threads here, sample order in the oracle) -- a random walk of sqrt(1024 x 64) x 6e-8 = 1.5e-5 relative at C2's 1024 spp.
+    # Measured 1.2e-5 / 2.4e-5 / 1.4e-5 on C2 / C3 / C4 (4096 spp on C3) -- the same figures as in round 4, when a fifth of the samples still
+    # differed in their last bits: the sum order was the whole of it then already. The north star's bar is 1e-4.
+    assert r < 5e-5
     same_samples(scene, frame, spp, seed, label)
     return tim, st
 
@@ -145,7 +150,7 @@ def test_c5_tr15_stand_in_full_detail_1080p_512spp(tmp_path):
         r = float(np.sqrt(np.mean(d ** 2)))
         print(f"C5 tr15 stand-in frame {frame} seed {seed}: {tiles} tiles x 64 px x 512 spp = {st.samples} samples, RMSE {r:.3e}, max {np.abs(d).max():.3e}, "
               f"V {st.vertices / st.samples:.4f} (gpu {tim.vertices / tim.samples:.4f}), oracle {st.seconds:.1f}s")
-        assert r < 1e-5, r
+        assert r < 2e-5, r   # (measured 5.7e-6 / 5.7e-6 / 0 / 8.2e-8 / 2.9e-6: the order of the film's f32 sums; round 4: 8.2e-5 / 5.7e-5 / 0 / - / 7.7e-5)
         same_samples(scene, frame, 512, seed, f"frame {frame} seed {seed}")
 
 
