@@ -272,7 +272,7 @@ def main():
                     "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": int(algo_bytes),
                     "schedule": m.get("schedule"),
                     "counters_from_this_schedule": (None if not (compute and compute.get("schedule_of_the_counter_launch") and m.get("schedule")) else
-                                                    all(compute["schedule_of_the_counter_launch"].get(k) == m["schedule"].get(k) for k in ("pool_slots", "views", "slices", "launched_wavefront"))),
+                                                    all(compute["schedule_of_the_counter_launch"].get(k) == m["schedule"].get(k) for k in ("pool_slots", "views", "slices", "launched_wavefront", "transform_table"))),
                     "note": "achieved / peak / frac are SURVEY 8(d)'s accounting of the WAVEFRONT formulation (368 B per path vertex + 16 B per pixel) over the HIP-event "
                             "time of the launch; `bound` names the resource the launch is closer to, `valu` prices the VALU lane-issue rate from the counters. " +
                             ("Traversal of the 3.1 M-triangle scene is memory-latency bound." if wave

@@ -405,8 +405,22 @@ typedef struct TrayScheduleInfo {
     uint32_t n_moving;            /* instances that move within the frame (columns of the per-path transform cache) */
     uint32_t tile_workgroups;     /* persistent workgroups of the tile kernel */
     uint64_t pool_bytes, schedule_bytes, xf_cache_bytes;   /* pool alone; pool + queues + bins; per-path transform cache */
+    uint32_t transform_table, pad_;                        /* 1: the last launch read the frame's transform table (tray_scene_set_transform_table) */
+    uint64_t xf_table_bytes;                               /* the table, if this frame has one */
 } TrayScheduleInfo;
 int tray_last_schedule(TrayDeviceScene* s, TrayScheduleInfo* out);
+
+/* Moving scenes: where a path's AnimatedTransform::transform(ray.time) comes from (linalg/animated_transform.rs:40-56; the reference
+ * rebuilds it at every instance visit, geometry/receiver.rs:30). A camera sample's shutter time is one of 2^24 values (sampler/ld.rs:100-104),
+ * every ray of the path inherits it (path.rs:110), so the transform is a function of a 24-bit index. mode 1: build, per frame and on the
+ * first launch, the TABLE of every moving instance's (and a moving camera's) transform at all 2^24 times -- 1.9 GB each, ~1.5 ms each to
+ * build, the same evaluation at the same times: the same bits -- and read it; mode 0: evaluate per camera sample into a per-path cache
+ * (112 B per path and instance); mode -1 (default): the table for launches of >= 2^26 camera samples (each index is needed 4 times or more),
+ * and for every later launch of the frame once it exists. If the table cannot be allocated the per-path cache serves, and vice versa.
+ * TRAYHIP_XF_TABLE=0|1 (measurement) overrides. tray_debug_transform_table compares n pseudo-random records of the frame's table with a fresh
+ * evaluation, bit for bit, and reports how many differ (test hook; TRAY_E_INVALID if the frame has no table yet). */
+int tray_scene_set_transform_table(TrayDeviceScene* s, int mode);
+int tray_debug_transform_table(TrayDeviceScene* s, uint32_t n, uint32_t* n_differ);
 
 /* ---- one frame on several GPUs of this process ------------------------------------------------------
  * The reference's distributed mode hands every worker a slice of the block queue and sums the returned RGBW blocks on the
@@ -424,6 +438,8 @@ int tray_render_frame_multi(TrayMultiScene* m, uint32_t spp, uint64_t seed, floa
 int tray_multi_set_sampler(TrayMultiScene* m, uint32_t kind, uint32_t min_spp, uint32_t max_spp);
 /* tray_scene_set_wavefront on every device of m */
 int tray_multi_set_wavefront(TrayMultiScene* m, uint32_t pool_slots, uint32_t views, uint32_t slices);
+/* tray_scene_set_transform_table on every device of m */
+int tray_multi_set_transform_table(TrayMultiScene* m, int mode);
 /* tray_scene_update_frame on every device of m; the communicators, films and streams are kept (scene.rs:152-176 per worker) */
 int tray_multi_update_frame(TrayMultiScene* m, const TrayFlatScene* f);
 /* per-device timings of the last tray_render_frame_multi (n_dev entries) and the duration of the reduce (ms) */

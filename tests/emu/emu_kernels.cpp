@@ -126,7 +126,7 @@ void make_scene(const TrayFlatScene* f, EmuScene& e) {
     d.textures = f->n_textures ? f->textures : nullptr; d.tex_frames = f->tex_frames; d.tex_data = f->tex_data;
     d.filter_table = f->film.table; d.filter_x = f->film.table_x; d.filter_y = f->film.table_y;
     d.xf_levels = f->xf_levels; d.keyframes = f->keyframes; d.knots = f->knots; d.color_keys = f->color_keys;
-    d.xf_cache = nullptr; d.moving_ids = nullptr; d.n_moving = 0; d.xf_cache_lanes = 0; d.xf_aos = 0;
+    d.xf_cache = nullptr; d.moving_ids = nullptr; d.n_moving = 0; d.xf_cache_lanes = 0; d.xf_aos = 0; d.xf_table = 0; d.xf_stride = 0; d.xf_tab = nullptr; d.xf_tab_stride = 0; d.pad_tab = 0;
     d.n_instances = f->n_instances; d.n_lights = f->n_lights; d.min_depth = f->min_depth; d.max_depth = f->max_depth;
     d.width = f->film.width; d.height = f->film.height; d.frame = f->frame; d.film_rows = 0; d.coop_offset = 0; d.integrator = f->integrator;
     d.filter_w = f->film.filter_w; d.filter_h = f->film.filter_h; d.inv_w = f->film.inv_w; d.inv_h = f->film.inv_h;
@@ -380,7 +380,7 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
         for (uint32_t i = 0; i < f->n_instances; ++i)
             if (f->instances[i].animated && f->instances[i].moving_slot < n_moving) moving_ids[f->instances[i].moving_slot] = i;
         xf_cache.assign((size_t)n_moving * TR_XF_WORDS * blocks * TR_BLOCK, 0.0f);
-        e.d.xf_cache = xf_cache.data(); e.d.moving_ids = moving_ids.data(); e.d.n_moving = n_moving; e.d.xf_cache_lanes = blocks * TR_BLOCK;
+        e.d.xf_cache = xf_cache.data(); e.d.moving_ids = moving_ids.data(); e.d.n_moving = n_moving; e.d.xf_stride = n_moving; e.d.xf_cache_lanes = blocks * TR_BLOCK;
     }
     e.d.film_rows = (film_rows != 0 && film_rows_ok(f)) ? 1u : 0u;
     uint32_t stack_words = e.depth * TR_BLOCK;
@@ -465,7 +465,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
         for (uint32_t i = 0; i < f->n_instances; ++i)
             if (f->instances[i].animated && f->instances[i].moving_slot < n_moving) moving_ids[f->instances[i].moving_slot] = i;
         xf_cache.assign((size_t)n_moving * TR_XF_WORDS * n_slots, 0.0f);
-        e.d.xf_cache = xf_cache.data(); e.d.moving_ids = moving_ids.data(); e.d.n_moving = n_moving; e.d.xf_cache_lanes = n_slots; e.d.xf_aos = 1u;
+        e.d.xf_cache = xf_cache.data(); e.d.moving_ids = moving_ids.data(); e.d.n_moving = n_moving; e.d.xf_stride = n_moving; e.d.xf_cache_lanes = n_slots; e.d.xf_aos = 1u;
     }
     std::vector<WfChunk> chunks(n_chunks, WfChunk{WF_TILE_NEED, 0u});
     std::vector<float> bins((size_t)n_chunks * ROWBIN_SIZE, 0.0f);

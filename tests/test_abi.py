@@ -61,7 +61,8 @@ def test_wavefront_entry_points_check_their_arguments(built):
     assert lib.tray_scene_set_wavefront(None, 0, 0, 0) == L.TRAY_E_INVALID and b"null" in lib.tray_last_error()
     assert lib.tray_multi_set_wavefront(None, 0, 0, 0) == L.TRAY_E_INVALID
     assert lib.tray_last_schedule(None, C.byref(info)) == L.TRAY_E_INVALID
-    assert C.sizeof(L.TrayScheduleInfo) == 8 * 4 + 3 * 8
+    assert C.sizeof(L.TrayScheduleInfo) == 8 * 4 + 3 * 8 + 2 * 4 + 8
+    assert lib.tray_scene_set_transform_table(None, 1) == L.TRAY_E_INVALID and lib.tray_multi_set_transform_table(None, 0) == L.TRAY_E_INVALID
 
 
 def test_device_calls_fail_loudly_without_gpu(assets):

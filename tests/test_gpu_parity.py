@@ -371,6 +371,39 @@ def test_wavefront_pool_through_the_abi(tmp_path, monkeypatch):
     assert lib.tray_scene_set_wavefront(dev, 0, 5, 0) == T._lib.TRAY_E_INVALID and lib.tray_scene_set_wavefront(dev, 0, 0, 3) == T._lib.TRAY_E_INVALID
 
 
+@pytest.mark.parametrize("mode", ["mega", "wave"])
+def test_transform_table_renders_what_per_path_evaluation_renders(mode, tmp_path, monkeypatch):
+    """Round 5: AnimatedTransform::transform of a moving instance (and of a moving camera) is a function of the camera sample's 24-bit
+    shutter-time index; tray_scene_set_transform_table(1) builds, per frame, the table of all 2^24 of them (k_xf_table_build: the same
+    evaluation at the same times) and the kernels read it -- the wavefront kernels directly, the tile kernel to fill its per-thread cache
+    columns -- instead of evaluating the spline stacks per camera sample. Same samples, vertices, rays; the same film up to the order of its
+    f32 sums; every sampled record of the table equal to a fresh evaluation in every bit; the oracle agrees."""
+    monkeypatch.setenv("TRAYHIP_MODE", mode)
+    monkeypatch.setenv("TRAYHIP_WF_SLOTS", "65536")
+    scene, rt, _, fi = T.Scene.load_file(scenes.write_moving_box(str(tmp_path), width=128, height=128, samples=64))
+    hip = T.Hip(0, seed=9)
+    images, timings = [], []
+    for frame in (0, 3):
+        for table in (0, 1):
+            rt.clear()
+            scene.device_scene(frame, 0)
+            hip.set_transform_table(scene, table)
+            hip.render(scene, rt, _config_at(fi, frame, 64))
+            sch = hip.schedule(scene)
+            assert sch["transform_table"] == table and (sch["xf_table_bytes"] > 0) == (table == 1 or sch["xf_table_bytes"] > 0)
+            images.append(rt.get_renderf32().reshape(rt.height, rt.width, 4).copy()); timings.append(hip.last_timing)
+            if table:
+                bad = C.c_uint32(123)
+                T.check(T.lib().tray_debug_transform_table(scene.device_scene(frame, 0), 400000, C.byref(bad)))
+                assert bad.value == 0
+        a, b = timings[-2], timings[-1]
+        assert a.samples == b.samples and a.vertices == b.vertices and a.rays == b.rays
+        assert np.abs(images[-1] - images[-2]).max() <= 2e-5 * max(1.0, float(np.abs(images[-2]).max()))
+        cpu, st = O.render_tiles(scene.flatten(frame), 64, seed=9)
+        assert b.samples == st.samples and int(b.vertices) == int(st.vertices)
+        assert rmse(images[-1], cpu) < 1e-5
+
+
 # ---- moving scenes (SURVEY 8f rank 1): per-ray spline evaluation, animated emission and camera ----
 @pytest.fixture(scope="module")
 def moving(tmp_path_factory):

@@ -310,6 +310,10 @@ class Hip:
         """tray_scene_set_wavefront on the scene's device copy (0 = the library's own rule)"""
         check(lib().tray_scene_set_wavefront(scene.device_scene(scene._dev_frame, self.device), int(pool_slots), int(views), int(slices)))
 
+    def set_transform_table(self, scene, mode=-1):
+        """tray_scene_set_transform_table: 1 = the frame's table of transforms by shutter-time index, 0 = per-path evaluation, -1 = by sample count"""
+        check(lib().tray_scene_set_transform_table(scene.device_scene(scene._dev_frame, self.device), int(mode)))
+
     def timing(self, scene):
         t = _lib.TrayKernelTiming()
         check(lib().tray_last_timing(scene.device_scene(scene._dev_frame, self.device), C.byref(t)))

@@ -138,7 +138,8 @@ class TrayKernelTiming(C.Structure):
 class TrayScheduleInfo(C.Structure):
     _fields_ = [("wavefront", C.c_uint32), ("launched_wavefront", C.c_uint32), ("pool_slots", C.c_uint32), ("chunks", C.c_uint32),
                 ("views", C.c_uint32), ("slices", C.c_uint32), ("n_moving", C.c_uint32), ("tile_workgroups", C.c_uint32),
-                ("pool_bytes", C.c_uint64), ("schedule_bytes", C.c_uint64), ("xf_cache_bytes", C.c_uint64)]
+                ("pool_bytes", C.c_uint64), ("schedule_bytes", C.c_uint64), ("xf_cache_bytes", C.c_uint64),
+                ("transform_table", C.c_uint32), ("pad_", C.c_uint32), ("xf_table_bytes", C.c_uint64)]
 
 
 class TrayRay(C.Structure):
@@ -170,6 +171,9 @@ SYMBOLS = {
     "tray_scene_set_wavefront": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "tray_multi_set_wavefront": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "tray_last_schedule": (C.c_int, [C.c_void_p, _P(TrayScheduleInfo)]),
+    "tray_scene_set_transform_table": (C.c_int, [C.c_void_p, C.c_int]),
+    "tray_multi_set_transform_table": (C.c_int, [C.c_void_p, C.c_int]),
+    "tray_debug_transform_table": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_uint32)]),
     "tray_adaptive_step": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "tray_render_tiles_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "tray_render_shard_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),

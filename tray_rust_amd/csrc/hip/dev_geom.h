@@ -73,7 +73,8 @@ struct DevScene {
                                                // arbitrary pool slots, a transform is six 16-byte loads of one 96-byte record instead of 24 cache lines)
     uint32_t n_instances, n_lights, min_depth, max_depth;
     uint32_t width, height, frame, film_rows;   // film_rows: 1 = row-binned film (separable, filter_h == 2)
-    uint32_t integrator, pad_integrator;        // TRAY_INTEGRATOR_*
+    uint32_t integrator;                        // TRAY_INTEGRATOR_*
+    uint32_t xf_table;                          // 1: xf_cache IS the frame's table of transforms by shutter-time index (xf_tab below), a path's column is its time index
     uint32_t coop_offset;   // word offset of the cooperative leaf test's LDS area behind the traversal stacks (0 = none)
     const tray::FlatLeaf* __restrict__ flat_leaves;   // the flat instance loop's view of the scene: BVH<Instance> leaves ...
     const tray::FlatInst* __restrict__ flat_insts;    // ... and their instances, one 128-B record each (host/gates.hpp)
@@ -94,11 +95,16 @@ struct DevScene {
     const float4* __restrict__ quads;            // the wavefront traversal's trees (host/gates.hpp: QuadTrees): 128-byte records of up to four (box, descriptor)
                                                  // slots = two levels of the binary trees above. ONE buffer -- the BVH<Triangle>s first, then this frame's
                                                  // BVH<Instance> from record top_quad_first -- so that a record's address is a uniform base + a 32-bit offset
-    uint32_t top_quad_first, pad_quads;
+    uint32_t top_quad_first;
+    uint32_t xf_stride;                          // records per column of xf_cache in the record layout (xf_aos): n_moving, + 1 in table mode when the camera moves (its record is the last)
     // AnimatedMesh (geometry/animated_mesh.rs; include/trayhip.h: TrayMeshKeys): per mesh its keyframe count and times, or null. Only the
     // ANIM = 3 instantiations (debug kernels, k_sampler_pass) read them.
     const TrayMeshKeys* __restrict__ mesh_keys;
     const float* __restrict__ key_times;
+    // the frame's transform table by shutter-time index (below: xf_time_index), or null; xf_tab_stride records per index: the moving instances, then the
+    // camera if it moves. The wavefront kernels index it directly (xf_table = 1: xf_cache == xf_tab), the tile kernel copies a path's records into its cache column
+    const float* __restrict__ xf_tab;
+    uint32_t xf_tab_stride, pad_tab;
 };
 
 struct Ray {
@@ -112,16 +118,29 @@ struct Ray {
 // of TRS keyframes (AnimatedTransform::unanimated decomposes static ones too), so row 3 is (0,0,0,1) and the affine
 // point transform equals Transform * Point.
 TR_DEV uint32_t xf_cache_lane() { return blockIdx.x * blockDim.x + threadIdx.x; }   // megakernel: one column per thread
+// Round 5: the frame's transforms as a TABLE over the shutter-time index. A camera sample's time is one of 2^24 values -- van_der_corput
+// returns (bits >> 8) / 2^24 (ld.rs:100-104; the clamp to 1 - f32::EPSILON lands on such a value too) -- and every ray of the path inherits it
+// (path.rs:110, mod.rs:154), so AnimatedTransform::transform(ray.time) of an instance is a function of that 24-bit index alone. A 512-spp frame
+// at 1920x1080 takes 1.06e9 camera samples, i.e. it evaluates every moving instance's spline stack 63 times per index (k_wf_regen: 17 % of the
+// frame with 11 moving instances, VALU-bound; the tile kernel's moving scenes: a third of their extra instructions) and keeps the results in
+// a per-path cache of 112 B per path and instance. The table holds each of them ONCE: xf_cache[(index * xf_stride + moving_slot) * TR_XF_WORDS],
+// built by k_xf_table_build (kernels.hip) per frame with the same eval_xform_stack at the same frame_time -- the same bits by construction --,
+// 1.9 GB per moving instance. The wavefront kernels index it directly: a path's `column` is its time index, nothing is evaluated or stored per
+// path (C5 stand-in, frame 64: 186 -> 213 Msamples/s). The tile kernel keeps its per-thread cache columns (coalesced reads in the flat instance
+// loop; gathered 112-byte records there measured only +3.5 % on moving_box) and FILLS them from the table instead of evaluating. The host builds
+// the table for launches of enough samples (kernels.hip: xf_table_prepare), the per-path evaluation serves the others.
+TR_DEV uint32_t xf_time_index(float t) { return (uint32_t)(t * 16777216.0f); }   // t = index / 2^24 exactly
+TR_DEV float xf_index_time(uint32_t index) { return (float)index * (1.0f / 16777216.0f); }
 // start of a camera sample: evaluate every moving instance at the path's time into the path's cache column
 TR_DEV void xf_cache_fill(const DevScene& sc, float time, uint32_t lane) {
-    if (!sc.xf_cache) return;
+    if (!sc.xf_cache || sc.xf_table) return;
     const uint32_t lanes = sc.xf_cache_lanes;
     for (uint32_t m = 0; m < sc.n_moving; ++m) {
         const TrayInstance* __restrict__ in = sc.instances + sc.moving_ids[m];
         float x[TR_XF_WORDS];
         eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, in->xf_first, in->xf_count, time, x);
         if (sc.xf_aos) {
-            float4* __restrict__ rec = reinterpret_cast<float4*>(sc.xf_cache + ((size_t)lane * sc.n_moving + m) * TR_XF_WORDS);
+            float4* __restrict__ rec = reinterpret_cast<float4*>(sc.xf_cache + ((size_t)lane * sc.xf_stride + m) * TR_XF_WORDS);
 #pragma unroll
             for (int q = 0; q < TR_XF_WORDS / 4; ++q) rec[q] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
         } else {
@@ -137,8 +156,22 @@ TR_DEV void xf_cache_fill(const DevScene& sc, float time, uint32_t lane) {
 // moving instance) pairs are dealt out to all the lanes of the wave -- instance-major, so neighbouring lanes evaluate the SAME stack at
 // different times and stay in step -- and every lane writes its result into the column of the lane it worked for. Values and layout are
 // exactly xf_cache_fill's; the stores are made visible to the wave before anybody reads its column.
-TR_DEV void xf_cache_fill_wave(const DevScene& sc, bool started, float time, uint32_t column) {
-    if (!sc.xf_cache) return;
+TR_DEV void xf_cache_fill_wave(const DevScene& sc, bool started, float time, uint32_t column, uint32_t time_index) {
+    if (!sc.xf_cache || sc.xf_table) return;
+    if (sc.xf_tab) {   // the frame's table has the path's transforms: copied, not evaluated (the lanes that start a sample, each its own records)
+        if (started) {
+            const uint32_t lanes = sc.xf_cache_lanes;
+            for (uint32_t m = 0; m < sc.n_moving; ++m) {
+                const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_tab + ((size_t)time_index * sc.xf_tab_stride + m) * TR_XF_WORDS);
+                float* __restrict__ dst = sc.xf_cache + (size_t)m * TR_XF_WORDS * lanes + column;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) { const float4 v = rec[q]; dst[(size_t)(4 * q) * lanes] = v.x; dst[(size_t)(4 * q + 1) * lanes] = v.y; dst[(size_t)(4 * q + 2) * lanes] = v.z; dst[(size_t)(4 * q + 3) * lanes] = v.w; }
+                const float4 w = rec[6];
+                dst[(size_t)24 * lanes] = w.x; dst[(size_t)25 * lanes] = w.y;
+            }
+        }
+        return;
+    }
     const unsigned long long start_m = __ballot(started), exec_m = __ballot(1);
     if (start_m == 0ull) return;
     const uint32_t lane = threadIdx.x & 63u;
@@ -179,7 +212,7 @@ template <int ANIM>
 TR_DEV void instance_inv_at(const DevScene& sc, const TrayInstance* __restrict__ in, float time, uint32_t column, float* x) {
     if (ANIM == 1) {
         if (sc.xf_aos) {
-            const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.n_moving + in->moving_slot) * TR_XF_WORDS + 12u);
+            const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.xf_stride + in->moving_slot) * TR_XF_WORDS + 12u);
 #pragma unroll
             for (int q = 0; q < 3; ++q) { const float4 v = rec[q]; x[12 + 4 * q] = v.x; x[13 + 4 * q] = v.y; x[14 + 4 * q] = v.z; x[15 + 4 * q] = v.w; }
             x[24] = rec[3].x;
@@ -195,7 +228,7 @@ TR_DEV void instance_inv_at(const DevScene& sc, const TrayInstance* __restrict__
 }
 // rows of inv of moving instance `moving_slot` in the path's column of the wavefront kernels' transform cache (xf_aos = 1)
 TR_DEV void instance_inv_cached(const DevScene& sc, uint32_t moving_slot, uint32_t column, float* x) {
-    const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.n_moving + moving_slot) * TR_XF_WORDS + 12u);
+    const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.xf_stride + moving_slot) * TR_XF_WORDS + 12u);
 #pragma unroll
     for (int q = 0; q < 3; ++q) { const float4 v = rec[q]; x[12 + 4 * q] = v.x; x[13 + 4 * q] = v.y; x[14 + 4 * q] = v.z; x[15 + 4 * q] = v.w; }
     x[24] = rec[3].x;
@@ -215,7 +248,7 @@ TR_DEV void instance_xf_at(const DevScene& sc, const TrayInstance* __restrict__ 
     if (in->animated) {
         if (ANIM == 1) {
             if (sc.xf_aos) {
-                const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.n_moving + in->moving_slot) * TR_XF_WORDS);
+                const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_cache + ((size_t)column * sc.xf_stride + in->moving_slot) * TR_XF_WORDS);
 #pragma unroll
                 for (int q = 0; q < TR_XF_WORDS / 4; ++q) { const float4 v = rec[q]; x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w; }
             } else {

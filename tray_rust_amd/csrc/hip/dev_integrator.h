@@ -33,6 +33,11 @@ TR_DEV Ray camera_ray(const DevScene& sc, float px, float py, float time) {
     Ray r;
     if (ANIM && c.animated) {   // cam_world.transform(frame_time) * Ray (camera.rs:156)
         float x[TR_XF_WORDS];
+        if (ANIM == 1 && sc.xf_tab) {   // the frame's table holds the camera's transform at this time index as the last record of the index (dev_geom.h)
+            const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_tab + ((size_t)xf_time_index(time) * sc.xf_tab_stride + sc.n_moving) * TR_XF_WORDS);
+#pragma unroll
+            for (int q = 0; q < TR_XF_WORDS / 4; ++q) { const float4 v = rec[q]; x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w; }
+        } else
         eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, c.xf_first, c.xf_count, frame_time, x);
         r.o = xf_point_affine_w(x, x[25], mk(0.0f, 0.0f, 0.0f));
         r.d = xf_vector(x, d);

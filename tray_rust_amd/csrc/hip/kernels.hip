@@ -285,6 +285,7 @@ __global__ __launch_bounds__(TR_BLOCK, ANIM ? TR_MIN_WAVES_ANIM : TR_MIN_WAVES) 
 #endif
         for (;;) {   // one path vertex per live lane and step
             bool started = false;
+            uint32_t kidx = 0u;
             const bool idle = !(ln.flags & LF_ALIVE);
             if (idle && pending) {   // the previous sample of this lane is finished: RenderTarget::write it
                 if (film_rows) film_splat_rows(sc, s_rowbin, s_tx, rgbw, s_table, x0, y0, (int)row_l, sx, sy, lane_result(ln));
@@ -310,13 +311,13 @@ __global__ __launch_bounds__(TR_BLOCK, ANIM ? TR_MIN_WAVES_ANIM : TR_MIN_WAVES) 
                     float t;
                     pixel_sample(kp, s, spp, px, py, sx, sy, t);
                     lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), key_sample(kp, s));
-                    if (ANIM) ln.col = xf_cache_lane();
+                    if (ANIM) { ln.col = xf_cache_lane(); kidx = xf_time_index(t); }   // the path's column of the transform cache; its index into the frame's table (the fill copies from there)
                     row_l = pix >> 3;
                     started = true;
                     pending = true;
                 }
             }
-            if (ANIM && idle_m != 0ull) xf_cache_fill_wave(sc, started, ln.time, ln.col);   // the paths' transforms of the moving instances, once per camera sample: the whole wave evaluates for the lanes that start one
+            if (ANIM && idle_m != 0ull) xf_cache_fill_wave(sc, started, ln.time, ln.col, kidx);   // the paths' transforms of the moving instances, once per camera sample: the whole wave evaluates for the lanes that start one
             w_samples += (uint32_t)__popcll(__ballot(started));
             if (!__any(ln.flags & LF_ALIVE)) break;
             if (INTEG == TRAY_INTEGRATOR_WHITTED) {
@@ -399,6 +400,46 @@ __global__ __launch_bounds__(TR_BLOCK, ANIM ? TR_MIN_WAVES_ANIM : TR_MIN_WAVES) 
     }
 }
 #undef TR_CLK
+
+// The frame's transforms by shutter-time index (dev_geom.h: xf_time_index): record (index * stride + m) holds AnimatedTransform::transform of
+// moving instance m -- or, for m == n_moving, of the camera -- at the frame_time Camera::generate_ray computes for that index (camera.rs:152-153:
+// the same expression as camera_ray's), evaluated by the same eval_xform_stack the per-path cache used to be filled with. blockIdx.y = m, so the
+// lanes of a wave evaluate ONE stack at consecutive times; 2^24 x stride threads per frame (~15 ms for 11 instances).
+__global__ __launch_bounds__(TR_BLOCK) void k_xf_table_build(const DevScene scv, float* __restrict__ table, uint32_t stride, uint32_t index0, uint32_t n_index) {
+    const DevScene& sc = scv;
+    const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x, m = blockIdx.y;
+    if (i >= n_index) return;
+    const uint32_t index = index0 + i;
+    const TrayCamera& c = *sc.camera_p;
+    const float frame_time = (c.shutter_close - c.shutter_open) * xf_index_time(index) + c.shutter_open;
+    uint32_t first, count;
+    if (m < sc.n_moving) { const TrayInstance* __restrict__ in = sc.instances + sc.moving_ids[m]; first = in->xf_first; count = in->xf_count; }
+    else { first = c.xf_first; count = c.xf_count; }
+    float x[TR_XF_WORDS];
+    eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, first, count, frame_time, x);
+    float4* __restrict__ rec = reinterpret_cast<float4*>(table + ((size_t)index * stride + m) * TR_XF_WORDS);
+#pragma unroll
+    for (int q = 0; q < TR_XF_WORDS / 4; ++q) rec[q] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+}
+// test hook: how many of n pseudo-random (index, record) pairs of the table differ in any bit from a fresh evaluation
+__global__ __launch_bounds__(TR_BLOCK) void k_xf_table_check(const DevScene scv, const float* __restrict__ table, uint32_t stride, uint32_t n, uint32_t* __restrict__ n_bad) {
+    const DevScene& sc = scv;
+    const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h = i * 0x9E3779B1u + 0x7feb352du; h ^= h >> 16; h *= 0x846ca68bu; h ^= h >> 15;
+    const uint32_t index = h & 0xffffffu, m = (h >> 24) % stride;
+    const TrayCamera& c = *sc.camera_p;
+    const float frame_time = (c.shutter_close - c.shutter_open) * xf_index_time(index) + c.shutter_open;
+    uint32_t first, count;
+    if (m < sc.n_moving) { const TrayInstance* __restrict__ in = sc.instances + sc.moving_ids[m]; first = in->xf_first; count = in->xf_count; }
+    else { first = c.xf_first; count = c.xf_count; }
+    float x[TR_XF_WORDS];
+    eval_xform_stack(sc.xf_levels, sc.keyframes, sc.knots, first, count, frame_time, x);
+    const uint32_t* __restrict__ rec = reinterpret_cast<const uint32_t*>(table + ((size_t)index * stride + m) * TR_XF_WORDS);
+    bool bad = false;
+    for (int q = 0; q < TR_XF_WORDS; ++q) bad = bad || rec[q] != __float_as_uint(x[q]);
+    if (bad) atomicAdd(n_bad, 1u);
+}
 
 // ---- parity / debug kernels: the same device functions, one thread per item -------------------
 template <int ANIM>
@@ -758,6 +799,13 @@ struct TrayDeviceScene {
     uint32_t trace_lds_depth = 0, trace_lds_bytes = 0;   // LDS part of the dynamic-fetch kernel's stacks; deeper entries go to d_stack_overflow
     uint32_t* d_stack_overflow = nullptr;
     size_t ovf_entries = 0;              // ... per view of the schedule (WF_PIPES_MAX of them)
+    DevScene launch_dev{};               // what the kernels of the current render call get: `dev`, or `dev` with the transform table in the cache's place
+    bool camera_animated = false;
+    float* d_xf_table = nullptr;         // the frame's transform table (dev_geom.h: xf_time_index), built by the first launch that wants it
+    uint32_t xf_table_stride = 0;
+    bool xf_table_built = false;         // ... for THIS frame (a frame update takes the buffer over and builds anew)
+    int xf_table_req = -1;               // tray_scene_set_transform_table: -1 = by the launch's sample count, 0 = never, 1 = always
+    bool last_used_table = false;
     std::vector<void*> wf_allocs;        // the wavefront buffers among `allocs` (tray_scene_set_wavefront frees them to change the pool's size)
     uint32_t wf_req_slots = 0, wf_req_views = 0, wf_req_slices = 0;   // tray_scene_set_wavefront: 0 = the library's own rule
     bool wf_shrunk = false;              // the pool came out smaller than asked for (allocation failed, halved): frame updates keep it
@@ -1179,6 +1227,7 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         const TrayCamera* d_cam = nullptr;
         rc = upload(s, "camera", false, &f->camera, 1, &d_cam);
         d.camera_p = d_cam;
+        s->camera_animated = f->camera.animated != 0;
         if (rc != TRAY_OK) { tray_scene_destroy(s); return rc; }
     }
     // Morton tile queue (BlockQueue::new)
@@ -1327,21 +1376,18 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         size_t cache_bytes = (size_t)s->deferred_n_moving * TR_XF_WORDS * lanes * sizeof(float);
         // (the wavefront schedule's pool follows the cache: if the budget of wf_slot_count -- a share of what hipMemGetInfo calls free -- cannot be
         // had in one piece, halve the pool rather than fail; the tile kernel's cache has one column per resident thread and cannot shrink)
-        if (s->wavefront && !(keep_lanes && donor->dev.xf_cache && donor->xf_cache_bytes >= cache_bytes)) {
-            while (hipMalloc(&cache, cache_bytes) != hipSuccess) {
-                (void)hipGetLastError();
-                cache = nullptr;
-                if (lanes / 2u < 64u * TR_BLOCK) break;
-                lanes = lanes / 2u / TR_BLOCK * TR_BLOCK;
-                cache_bytes = (size_t)s->deferred_n_moving * TR_XF_WORDS * lanes * sizeof(float);
-            }
-        }
+        // Round 5: the wavefront schedule's cache (112 B per pool slot and moving instance: 38.5 GB for the tr15 stand-in's 11 at 33 M slots) is
+        // allocated by the first launch that needs it (xf_cache_ensure): launches of many samples index the frame's transform table instead
+        // (xf_table_prepare) and never touch it. A frame update still takes the previous frame's cache over if there is one.
+        const bool lazy = s->wavefront;
         if (keep_lanes && donor->dev.xf_cache && donor->xf_cache_bytes >= cache_bytes) {   // (every path fills its columns before it reads them)
             cache = donor->dev.xf_cache;
             s->xf_cache_bytes = donor->xf_cache_bytes;
             forget_alloc(donor, cache);
             donor->dev.xf_cache = nullptr; donor->xf_cache_bytes = 0;
-        } else if (cache != nullptr || hipMalloc(&cache, cache_bytes) == hipSuccess) {
+        } else if (lazy) {
+            s->xf_cache_bytes = 0;
+        } else if (hipMalloc(&cache, cache_bytes) == hipSuccess) {
             s->xf_cache_bytes = cache_bytes;
         } else {
             tray_scene_destroy(s);
@@ -1349,14 +1395,22 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
                       " moving instances x " + std::to_string(lanes) + " paths (TRAYHIP_WF_SLOTS / TRAYHIP_XF_CACHE_BYTES bound it)");
             return TRAY_E_NOMEM;
         }
-        s->allocs.push_back(cache);
+        if (cache) s->allocs.push_back(cache);
         s->dev.xf_cache = static_cast<float*>(cache);
         s->dev.moving_ids = d_ids;
         s->dev.n_moving = s->deferred_n_moving;
+        s->dev.xf_stride = s->deferred_n_moving;
         s->dev.xf_cache_lanes = lanes;
         s->dev.xf_aos = s->wavefront ? 1u : 0u;
     }
     s->wf_req_slots = donor ? donor->wf_req_slots : 0u; s->wf_req_views = donor ? donor->wf_req_views : 0u; s->wf_req_slices = donor ? donor->wf_req_slices : 0u;
+    s->xf_table_req = donor ? donor->xf_table_req : -1;
+    if (donor && donor->d_xf_table && donor->xf_table_stride == s->dev.n_moving + (s->camera_animated ? 1u : 0u)) {
+        // the previous frame's transform table serves as the buffer of this frame's (same number of records per time index): built anew by the first launch
+        forget_alloc(donor, donor->d_xf_table); s->allocs.push_back(donor->d_xf_table);
+        s->d_xf_table = donor->d_xf_table; s->xf_table_stride = donor->xf_table_stride; s->xf_table_built = false;
+        donor->d_xf_table = nullptr;
+    }
     if (donor && donor->wf_ready && s->wavefront && donor->stack_bytes == s->stack_bytes && donor->quad_stack_words == s->quad_stack_words && donor->animated == s->animated &&
         donor->pool.n_slots <= ((s->animated && s->dev.xf_cache_lanes) ? s->dev.xf_cache_lanes : wf_slot_wish(s))) {   // (a pool that came out smaller than wished -- memory -- stays as it is)
         // the wavefront schedule's pool, queues, chunk records and row bins (2.2 GB at 8 M slots) serve the next frame as they are:
@@ -1551,8 +1605,8 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             const uint32_t c1 = (uint32_t)((uint64_t)n_chunks * (k + 1u) / n_views);
             WfView& v = views[k];
             v.n_chunks = c1 - c0;
-            v.dev = s->dev;
-            if (v.dev.xf_cache) v.dev.xf_cache += (size_t)c0 * TR_BLOCK * v.dev.n_moving * TR_XF_WORDS;   // [slot][moving instance][TR_XF_WORDS]
+            v.dev = s->launch_dev;
+            if (v.dev.xf_cache && !v.dev.xf_table) v.dev.xf_cache += (size_t)c0 * TR_BLOCK * v.dev.n_moving * TR_XF_WORDS;   // [slot][moving instance][TR_XF_WORDS] (the table is indexed by time, not by slot)
             v.pool = s->pool;
             v.pool.first = c0 * TR_BLOCK;   // (the hit records are slot-major, the other fields field-major: the accessors add the view's first slot)
             v.pool.seg_cap = wf_seg_cap(v.n_chunks);
@@ -1705,6 +1759,86 @@ static int launch_sampler(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile
     return TRAY_OK;
 }
 
+// The transform table of a moving scene's frame (dev_geom.h: xf_time_index; k_xf_table_build): wanted when the launch needs every time index
+// several times over -- from 2^26 camera samples on (4 per index: a 1080p frame at 32 spp, a GPU's eighth of a 512-spp frame; building the table
+// costs what 2^24 camera samples' evaluations cost, ~1.3 ms per moving instance, but it also takes 1.9 GB per instance) --, or as
+// tray_scene_set_transform_table says. Built once per frame on the launch stream by the first launch that wants it. If the allocation fails
+// the launch evaluates per path. Sets s->launch_dev.
+#ifndef XF_TABLE_MIN_SAMPLES
+#define XF_TABLE_MIN_SAMPLES (1ull << 26)
+#endif
+// the wavefront schedule's per-path transform cache, on first use (one record of TR_XF_WORDS floats per pool slot and moving instance): as many
+// columns as scene_build budgeted; halved while hipMalloc refuses and the pool does not exist yet, never below the pool's slots once it does
+static int xf_cache_ensure(TrayDeviceScene* s) {
+    if (!s->wavefront || !s->animated || s->dev.n_moving == 0u || s->dev.xf_cache) return TRAY_OK;
+    uint32_t lanes = std::max<uint32_t>(s->dev.xf_cache_lanes, s->wf_ready ? s->pool.n_slots : 0u);
+    const uint32_t floor_lanes = s->wf_ready ? s->pool.n_slots : 64u * TR_BLOCK;
+    for (;;) {
+        const size_t bytes = (size_t)s->dev.n_moving * TR_XF_WORDS * lanes * sizeof(float);
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) == hipSuccess) {
+            s->allocs.push_back(p);
+            s->dev.xf_cache = static_cast<float*>(p); s->dev.xf_cache_lanes = lanes; s->xf_cache_bytes = bytes;
+            return TRAY_OK;
+        }
+        (void)hipGetLastError();
+        if (lanes <= floor_lanes) {
+            set_error("hipMalloc of the per-path transform cache failed: " + std::to_string(bytes >> 20) + " MiB for " + std::to_string(s->dev.n_moving) +
+                      " moving instances x " + std::to_string(lanes) + " paths (tray_scene_set_wavefront / TRAYHIP_XF_CACHE_BYTES bound it)");
+            return TRAY_E_NOMEM;
+        }
+        lanes = std::max(floor_lanes, lanes / 2u / TR_BLOCK * TR_BLOCK);
+    }
+}
+static int xf_table_prepare(TrayDeviceScene* s, uint64_t samples, hipStream_t stream) {
+    s->launch_dev = s->dev;
+    s->last_used_table = false;
+    const uint32_t stride = s->dev.n_moving + (s->camera_animated ? 1u : 0u);
+    if (!s->animated || stride == 0u) return TRAY_OK;
+    int want = s->xf_table_req;
+    if (const char* e = getenv("TRAYHIP_XF_TABLE")) want = atoi(e) != 0 ? 1 : 0;
+    if (want < 0) want = (samples >= XF_TABLE_MIN_SAMPLES || s->xf_table_built) ? 1 : 0;   // (a table that exists for this frame serves every launch)
+    if (!want) {
+        const int rc = xf_cache_ensure(s);
+        if (rc == TRAY_OK) { s->launch_dev = s->dev; return TRAY_OK; }
+        if (rc != TRAY_E_NOMEM) return rc;   // (no room for the cache: the table is smaller from a few million slots on)
+    }
+    if (s->d_xf_table && s->xf_table_stride != stride) {   // (cannot happen: the stride is the frame's, the buffer was taken over for this stride)
+        forget_alloc(s, s->d_xf_table); (void)hipFree(s->d_xf_table); s->d_xf_table = nullptr; s->xf_table_built = false;
+    }
+    if (!s->d_xf_table) {
+        const size_t bytes = ((size_t)1 << 24) * stride * TR_XF_WORDS * sizeof(float);
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {   // (no room for the table: per-path evaluation)
+            (void)hipGetLastError();
+            const int rc = xf_cache_ensure(s);
+            s->launch_dev = s->dev;
+            return rc;
+        }
+        s->allocs.push_back(p);
+        s->d_xf_table = static_cast<float*>(p);
+        s->xf_table_stride = stride;
+        s->xf_table_built = false;
+    }
+    if (!s->xf_table_built) {
+        DevScene d = s->dev;   // (the build reads moving_ids, instances, spline tables, camera: none of them depends on the cache fields)
+        const uint32_t n_index = 1u << 24;
+        hipLaunchKernelGGL(k_xf_table_build, dim3(n_index / TR_BLOCK, stride), dim3(TR_BLOCK), 0, stream, d, s->d_xf_table, stride, 0u, n_index);
+        HIP_CHECK(hipGetLastError());
+        s->xf_table_built = true;
+    }
+    s->launch_dev.xf_tab = s->d_xf_table;
+    s->launch_dev.xf_tab_stride = s->xf_table_stride;
+    if (s->wavefront) {   // the stage kernels index the table by the path's time index; the tile kernel keeps its cache columns and fills them from it
+        s->launch_dev.xf_cache = s->d_xf_table;
+        s->launch_dev.xf_table = 1u;
+        s->launch_dev.xf_aos = 1u;
+        s->launch_dev.xf_stride = s->xf_table_stride;
+    }
+    s->last_used_table = true;
+    return TRAY_OK;
+}
+
 static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_count, uint32_t chunk, uint32_t chunk_stride,
                         uint32_t spp, uint64_t seed, float* rgbw_dev, void* stream_) {
     if (s->sampler_kind == TRAY_SAMPLER_LOW_DISCREPANCY && (spp == 0 || (spp & (spp - 1)) != 0)) {
@@ -1728,6 +1862,7 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     kf = mix(kf + s->dev.frame);
     if (s->sampler_kind != TRAY_SAMPLER_LOW_DISCREPANCY || s->deforming) return launch_sampler(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
     s->last_was_wavefront = false;
+    { const int rc = xf_table_prepare(s, (uint64_t)tile_count * 64u * spp, stream); if (rc != TRAY_OK) return rc; }
     if (s->wavefront) return launch_wavefront(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
     // Slices per tile. A slice costs its own film resolve and flush, so tiles are only halved (quartered) when a launch has fewer than
     // 12 (3) of them per workgroup and a slice keeps >= 256 samples per pixel -- measured on one GPU's share of C2 at 8 GPUs (4050
@@ -1739,13 +1874,13 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     if (const char* e = getenv("TRAYHIP_TILE_SLICES")) { slice_shift = 0u; while ((2u << slice_shift) <= (uint32_t)std::max(1, atoi(e)) && (spp >> (slice_shift + 1u)) >= 4u) ++slice_shift; }
     int blocks = (int)std::min<uint64_t>((uint64_t)s->n_blocks, (uint64_t)tile_count << slice_shift);
     HIP_CHECK(hipEventRecord(s->ev0, stream));
-#define PATH_TILES_L(A, F, L) hipLaunchKernelGGL((k_path_tiles<A, F, TRAY_INTEGRATOR_PATH, L>), dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, \
+#define PATH_TILES_L(A, F, L) hipLaunchKernelGGL((k_path_tiles<A, F, TRAY_INTEGRATOR_PATH, L>), dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->launch_dev, s->d_tiles + tile_start, \
                                                  tile_count, chunk, chunk_stride, spp, kf, slice_shift, rgbw_dev, s->d_counter, s->d_stats)
 #define PATH_TILES(A, F) do { if (s->light_filter) PATH_TILES_L(A, F, true); else PATH_TILES_L(A, F, false); } while (0)
 #define PATH_TILES_F(A) do { if (s->feat == FEAT_NONE) PATH_TILES(A, FEAT_NONE); else if (s->feat == FEAT_MERL) PATH_TILES(A, FEAT_MERL); \
                              else if (s->feat == FEAT_SPEC) PATH_TILES(A, FEAT_SPEC); else if (s->feat == (FEAT_MERL | FEAT_SPEC)) PATH_TILES(A, FEAT_MERL | FEAT_SPEC); \
                              else if (s->feat == (FEAT_ALL | FEAT_TEX)) PATH_TILES(A, FEAT_ALL | FEAT_TEX); else PATH_TILES(A, FEAT_ALL); } while (0)
-#define WHITTED_TILES(A) hipLaunchKernelGGL((k_path_tiles<A, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>), dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->dev, \
+#define WHITTED_TILES(A) hipLaunchKernelGGL((k_path_tiles<A, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>), dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->launch_dev, \
                                              s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf, slice_shift, rgbw_dev, s->d_counter, s->d_stats)
     if (s->dev.integrator == TRAY_INTEGRATOR_WHITTED) { if (s->animated) WHITTED_TILES(1); else WHITTED_TILES(0); }
     else if (s->animated) PATH_TILES_F(1);
@@ -1957,6 +2092,37 @@ int tray_render_frame_multi(TrayMultiScene* m, uint32_t spp, uint64_t seed, floa
     return TRAY_OK;
 }
 
+int tray_scene_set_transform_table(TrayDeviceScene* s, int mode) {
+    if (!s) { set_error("tray_scene_set_transform_table: null argument"); return TRAY_E_INVALID; }
+    if (mode < -1 || mode > 1) { set_error("tray_scene_set_transform_table: mode is -1 (by the launch's sample count), 0 (never) or 1 (always)"); return TRAY_E_INVALID; }
+    s->xf_table_req = mode;
+    return TRAY_OK;
+}
+int tray_multi_set_transform_table(TrayMultiScene* m, int mode) {
+    if (!m) { set_error("tray_multi_set_transform_table: null argument"); return TRAY_E_INVALID; }
+    for (TrayDeviceScene* s : m->scenes) {
+        const int rc = tray_scene_set_transform_table(s, mode);
+        if (rc != TRAY_OK) return rc;
+    }
+    return TRAY_OK;
+}
+int tray_debug_transform_table(TrayDeviceScene* s, uint32_t n, uint32_t* n_differ) {
+    if (!s || !n_differ) { set_error("tray_debug_transform_table: null argument"); return TRAY_E_INVALID; }
+    *n_differ = 0;
+    if (!s->d_xf_table || !s->xf_table_built) { set_error("tray_debug_transform_table: this frame has no transform table (no launch wanted one yet)"); return TRAY_E_INVALID; }
+    HIP_CHECK(hipSetDevice(s->device));
+    uint32_t* d_bad = nullptr;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_bad), sizeof(uint32_t)));
+    hipError_t e = hipMemset(d_bad, 0, sizeof(uint32_t));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_xf_table_check, dim3((n + TR_BLOCK - 1) / TR_BLOCK), dim3(TR_BLOCK), 0, nullptr, s->dev, s->d_xf_table, s->xf_table_stride, n, d_bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(n_differ, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) { set_error(std::string("tray_debug_transform_table: ") + hipGetErrorString(e)); return TRAY_E_DEVICE; }
+    return TRAY_OK;
+}
 int tray_scene_set_wavefront(TrayDeviceScene* s, uint32_t pool_slots, uint32_t views, uint32_t slices) {
     if (!s) { set_error("tray_scene_set_wavefront: null argument"); return TRAY_E_INVALID; }
     if (s->broken) { set_error("tray_scene_set_wavefront: the handle is only good for tray_scene_destroy after a failed frame update"); return TRAY_E_INVALID; }
@@ -1992,6 +2158,8 @@ int tray_last_schedule(TrayDeviceScene* s, TrayScheduleInfo* out) {
     out->xf_cache_bytes = s->xf_cache_bytes;
     out->n_moving = s->dev.n_moving;
     out->tile_workgroups = (uint32_t)s->n_blocks;
+    out->transform_table = s->last_used_table ? 1u : 0u;
+    out->xf_table_bytes = s->d_xf_table ? ((uint64_t)1 << 24) * s->xf_table_stride * TR_XF_WORDS * sizeof(float) : 0u;
     return TRAY_OK;
 }
 

@@ -50,7 +50,7 @@ enum : uint32_t {   // flags that only exist between wavefront stages
 enum {
     F_FLAGS, F_REC_T, F_REC_INST, F_REC_PRIM, F_REC_B1, F_REC_B2, F_HIT_PAD0, F_HIT_PAD1,     // HIT
     F_O, F_D = F_O + 3, F_BOUNCE = F_D + 3, F_KS,                                            // RAY
-    F_T, F_ILLUM = F_T + 3, F_TIME = F_ILLUM + 3, F_THRU_PAD,                                 // THRU
+    F_T, F_ILLUM = F_T + 3, F_TIME = F_ILLUM + 3, F_KIDX,                                     // THRU (F_KIDX: the path's shutter-time index, moving scenes in table mode)
     F_P, F_N = F_P + 3, F_TAN = F_N + 3, F_MAT = F_TAN + 3, F_LINST, F_LI, F_WL = F_LI + 3, F_PDFL = F_WL + 3, F_VERT_PAD0, F_VERT_PAD1,   // VERT (bitan = cross(tan, n) is recomputed)
     F_SOA,                                                                                    // ---- field-major from here on
     F_SNEXT = F_SOA, F_SX, F_SY, F_NG,
@@ -518,7 +518,8 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                 f3 lo_, ld;
                 if (ANIM && (wflags & tray::WI_ANIMATED)) {   // the path's transform of a moving instance, from the per-slot cache
                     float x[TR_XF_WORDS];
-                    instance_inv_cached(sc, wflags >> 8, slot, x);
+                    // (table mode: the path's time index is fetched here, for the few entries that need it -- one more dependent load for them)
+                    instance_inv_cached(sc, wflags >> 8, sc.xf_table ? pu(pool, F_KIDX, slot) : slot, x);
                     lo_ = xf_point_affine_w(x + 12, x[24], wo);
                     ld = xf_vector(x + 12, wd);
                 } else if (wflags & tray::WI_AFFINE) {
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_fallback(const DevScene s
         if (STAGE == 0) { ray.min_t = (r1.w & WF_CAMERA_RAY) ? 0.0f : 0.001f; ray.max_t = TR_INF; }
         else { ray.min_t = 0.001f; ray.max_t = STAGE == 1 ? 0.999f : TR_INF; }
         ray.time = ANIM ? pf(pool, F_TIME, slot) : 0.0f;
-        ray.col = slot;
+        ray.col = (ANIM && sc.xf_table) ? pu(pool, F_KIDX, slot) : slot;
         HitRec rec;
         rec.t = 0.0f; rec.inst = 0xffffffffu; rec.prim = 0u; rec.b1 = 0.0f; rec.b2 = 0.0f;
         const bool any = trace_bvh<ANIM>(sc, s_stack + threadIdx.x, ray, STAGE == 1, rec);
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_SHADE_WAVES) void k_wf_begin(const Dev
         ld_hit(pool, i, rec);
         Counters cnt;
         cnt.rays = 0; cnt.vertices = 0;
-        ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
+        ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = (ANIM && sc.xf_table) ? pu(pool, F_KIDX, i) : i;
         vertex_begin<ANIM>(sc, ln, rec, cnt);
         counted = true;
         // The occlusion ray of a light sample only matters if BSDF::eval of the light direction is not black (mod.rs:127-131 test the
@@ -759,7 +760,7 @@ TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, ui
     ln.direct = mk(0.0f, 0.0f, 0.0f);   // (as vertex_begin left it)
     ln.t_vertex = ln.throughput;        // (likewise: the throughput the vertex was reached with, before the PATH query updates it)
     ln.d = ld3(pool, F_D, i);           // (the ray that reached the vertex: -d is the outgoing direction until the PATH query replaces d)
-    ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
+    ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = (ANIM && sc.xf_table) ? pu(pool, F_KIDX, i) : i;
     vertex_queries<ANIM, FEAT, KM>(sc, ln, (flags & WF_OCCLUDED) != 0u);
     mis_ray_filter<ANIM>(sc, ln);
     {   // BSDF-sampled light rays proven to miss the light: counted like the reference's, never queued
@@ -832,7 +833,7 @@ TR_DEV void wf_regenerate(const DevScene& sc, const WfPool& pool, uint32_t i, ui
     float sx, sy, t;
     pixel_sample(kp, s_next, spp, px, py, sx, sy, t);
     const Ray cam = camera_ray<ANIM>(sc, sx, sy, t);
-    if (ANIM) { pf(pool, F_TIME, i) = cam.time; xf_cache_fill(sc, cam.time, i); }
+    if (ANIM) { pf(pool, F_TIME, i) = cam.time; pu(pool, F_KIDX, i) = xf_time_index(t); xf_cache_fill(sc, cam.time, i); }
     pu(pool, F_BOUNCE, i) = 0u;
     pu(pool, F_KS, i) = key_sample(kp, s_next);
     pf(pool, F_SX, i) = sx; pf(pool, F_SY, i) = sy;
@@ -912,7 +913,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
                 ln.bsdf.p = ld3(pool, F_P, i); ln.aux_d = ld3(pool, F_AUX, i); ln.mis_f = ld3(pool, F_MISF, i); ln.li = ld3(pool, F_LI, i);
                 ld_hit(pool, i, rec);
             }
-            ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = i;
+            ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = (ANIM && sc.xf_table) ? pu(pool, F_KIDX, i) : i;
             const bool cont = vertex_end<ANIM>(sc, ln, (flags & WF_HIT_C) != 0u, rec);
             st3(pool, F_ILLUM, i, ln.illum);
             pu(pool, F_BOUNCE, i) = ln.bounce;
