@@ -1760,12 +1760,12 @@ static int launch_sampler(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile
 }
 
 // The transform table of a moving scene's frame (dev_geom.h: xf_time_index; k_xf_table_build): wanted when the launch needs every time index
-// several times over -- from 2^26 camera samples on (4 per index: a 1080p frame at 32 spp, a GPU's eighth of a 512-spp frame; building the table
-// costs what 2^24 camera samples' evaluations cost, ~1.3 ms per moving instance, but it also takes 1.9 GB per instance) --, or as
+// about twice over -- from 3e7 camera samples on (a 1080p frame at 16 spp; a GPU's eighth of a 512-spp frame is 1.3e8; building the table costs
+// what 2^24 = 1.7e7 camera samples' evaluations cost, ~1.4 ms per moving instance, but it also takes 1.9 GB per instance) --, or as
 // tray_scene_set_transform_table says. Built once per frame on the launch stream by the first launch that wants it. If the allocation fails
 // the launch evaluates per path. Sets s->launch_dev.
 #ifndef XF_TABLE_MIN_SAMPLES
-#define XF_TABLE_MIN_SAMPLES (1ull << 26)
+#define XF_TABLE_MIN_SAMPLES 30000000ull
 #endif
 // the wavefront schedule's per-path transform cache, on first use (one record of TR_XF_WORDS floats per pool slot and moving instance): as many
 // columns as scene_build budgeted; halved while hipMalloc refuses and the pool does not exist yet, never below the pool's slots once it does
