@@ -36,7 +36,7 @@ enum : uint32_t {   // flags that only exist between wavefront stages
 // kernels every 4-byte access then touched a cache line of its own -- k_wf_trace_dyn<A> wrote 752 B per camera sample for 175 B of results,
 // the query kernels fetched ~430 B per vertex for 148 B of fields (profiles/r05_c5_traffic_by_kernel.txt). Now the words that travel together
 // lie together, one record per slot and group, the records of a group side by side (array of structures per group):
-//   HIT   8 words  flags, hit record of the slot's last closest-hit ray           traversal -> k_wf_begin / k_wf_advance
+//   HIT   8 words  hit record of the slot's last closest-hit ray                  traversal -> k_wf_begin / k_wf_advance
 //   RAY   8 words  origin, direction of the ray towards the next vertex, bounce, sample key
 //                                                                                 k_wf_regen / query -> k_wf_advance (queue A) / k_wf_begin / query
 //   THRU  8 words  throughput, radiance so far, ray.time                          k_wf_regen / query <-> k_wf_begin / query / k_wf_advance
@@ -48,12 +48,14 @@ enum : uint32_t {   // flags that only exist between wavefront stages
 // which the query kernels have), `w_o` (it is -d), the occlusion segment's direction (the queue entry carries it; k_wf_trace_fallback reads
 // the deferred ray's own record).
 enum {
-    F_FLAGS, F_REC_T, F_REC_INST, F_REC_PRIM, F_REC_B1, F_REC_B2, F_HIT_PAD0, F_HIT_PAD1,     // HIT
+    F_REC_T, F_REC_INST, F_REC_PRIM, F_REC_B1, F_REC_B2, F_HIT_PAD0, F_HIT_PAD1, F_HIT_PAD2,   // HIT
     F_O, F_D = F_O + 3, F_BOUNCE = F_D + 3, F_KS,                                            // RAY
     F_T, F_ILLUM = F_T + 3, F_TIME = F_ILLUM + 3, F_KIDX,                                     // THRU (F_KIDX: the path's shutter-time index, moving scenes in table mode)
     F_P, F_N = F_P + 3, F_TAN = F_N + 3, F_MAT = F_TAN + 3, F_LINST, F_LI, F_WL = F_LI + 3, F_PDFL = F_WL + 3, F_VERT_PAD0, F_VERT_PAD1,   // VERT (bitan = cross(tan, n) is recomputed)
     F_SOA,                                                                                    // ---- field-major from here on
-    F_SNEXT = F_SOA, F_SX, F_SY, F_NG,
+    F_FLAGS = F_SOA,   // (field-major: k_wf_advance scans the flags of EVERY slot every round -- as a word of the hit record that was 32 bytes read and 32 written
+                       // per slot and round for 4, 44 % of the kernel's traffic; the traversal's result write is two pieces instead of one for it)
+    F_SNEXT, F_SX, F_SY, F_NG,
     F_AUX = F_NG + 3, F_DIRECT = F_AUX + 3, F_MISF = F_DIRECT + 3, F_TV = F_MISF + 3,   // between the query kernels and k_wf_advance, for the few vertices with a stage C ray
     F_U = F_TV + 3, F_V,   // hit.dg.u / v of the vertex (scenes with image textures)
     F_COUNT
@@ -82,17 +84,17 @@ TR_DEV size_t pidx(const WfPool& p, int f, uint32_t i) {
 }
 TR_DEV float& pf(const WfPool& p, int f, uint32_t i) { return p.data[pidx(p, f, i)]; }
 TR_DEV uint32_t& pu(const WfPool& p, int f, uint32_t i) { return reinterpret_cast<uint32_t*>(p.data)[pidx(p, f, i)]; }
-// the hit record of slot i as the traversal kernels write it and k_wf_begin / k_wf_advance read it: {flags, t, inst, prim | b1, b2}
+// the hit record of slot i as the traversal kernels write it and k_wf_begin / k_wf_advance read it: {t, inst, prim, b1 | b2}; the flags word apart
 TR_DEV void st_hit(const WfPool& p, uint32_t i, uint32_t flags, const HitRec& rec) {
     uint32_t* __restrict__ r = reinterpret_cast<uint32_t*>(p.data) + (size_t)(i + p.first) * WF_HIT_WORDS;
-    *reinterpret_cast<uint4*>(r) = make_uint4(flags, __float_as_uint(rec.t), rec.inst, rec.prim);
-    *reinterpret_cast<uint2*>(r + 4) = make_uint2(__float_as_uint(rec.b1), __float_as_uint(rec.b2));
+    *reinterpret_cast<uint4*>(r) = make_uint4(__float_as_uint(rec.t), rec.inst, rec.prim, __float_as_uint(rec.b1));
+    r[4] = __float_as_uint(rec.b2);
+    reinterpret_cast<uint32_t*>(p.data)[pidx(p, F_FLAGS, i)] = flags;
 }
 TR_DEV void ld_hit(const WfPool& p, uint32_t i, HitRec& rec) {
     const uint32_t* __restrict__ r = reinterpret_cast<const uint32_t*>(p.data) + (size_t)(i + p.first) * WF_HIT_WORDS;
     const uint4 a = *reinterpret_cast<const uint4*>(r);
-    const uint2 b = *reinterpret_cast<const uint2*>(r + 4);
-    rec.t = __uint_as_float(a.y); rec.inst = a.z; rec.prim = a.w; rec.b1 = __uint_as_float(b.x); rec.b2 = __uint_as_float(b.y);
+    rec.t = __uint_as_float(a.x); rec.inst = a.y; rec.prim = a.z; rec.b1 = __uint_as_float(a.w); rec.b2 = __uint_as_float(r[4]);
 }
 TR_DEV f3 ld3(const WfPool& p, int f, uint32_t i) { return mk(pf(p, f, i), pf(p, f + 1, i), pf(p, f + 2, i)); }
 TR_DEV void st3(const WfPool& p, int f, uint32_t i, f3 v) { pf(p, f, i) = v.x; pf(p, f + 1, i) = v.y; pf(p, f + 2, i) = v.z; }
