@@ -683,7 +683,8 @@ __global__ __launch_bounds__(TR_BLOCK, WF_SHADE_WAVES) void k_wf_begin(const Dev
         LN_O(ln) = ld3(pool, F_O, i); ln.d = ld3(pool, F_D, i);
         ln.throughput = ld3(pool, F_T, i); ln.illum = ld3(pool, F_ILLUM, i);
         const f3 illum_in = ln.illum;
-        ln.first_ng = ld3(pool, F_NG, i);
+        // (hit.dg.ng of the camera ray's hit, quirk Q1: read by vertex_begin only on a specular chain -- at bounce 0 it is what vertex_begin writes)
+        ln.first_ng = (ln.bounce != 0u && (flags & LF_SPECULAR)) ? ld3(pool, F_NG, i) : mk(0.0f, 0.0f, 0.0f);
         HitRec rec;
         ld_hit(pool, i, rec);
         Counters cnt;
