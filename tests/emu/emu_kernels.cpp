@@ -492,7 +492,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     std::vector<uint32_t> kind_queues((size_t)WF_MAT_KINDS * q_cap, 0u);
     uint32_t kinds_present = 0;
     for (const DevMaterial& dm : e.mats) kinds_present |= 1u << dm.mat_kind;
-    const uint64_t max_rounds = (uint64_t)((n_items + n_chunks - 1) / n_chunks) * (((uint64_t)spp + 3) / 4 * (e.d.max_depth + 3) + 4) + 32;
+    const uint64_t max_rounds = (uint64_t)((n_items + n_chunks - 1) / n_chunks) * (((uint64_t)spp + 3) / 4 * ((WF_FOLD_C ? 2u : 1u) * e.d.max_depth + 3) + 4) + 32;
     int rc = 0;
     uint64_t rounds = 0;
 #define EMU_K(...) do { if (rc == 0) rc = launch_simt(__VA_ARGS__); } while (0)
@@ -507,10 +507,10 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
         if (sorted) {   /* wf_round of kernels.hip: one kind-pure shading launch per material kind of the scene */                        \
             EMU_QUERY_KIND(A, TRAY_MAT_MATTE); EMU_QUERY_KIND(A, TRAY_MAT_PLASTIC); EMU_QUERY_KIND(A, TRAY_MAT_METAL); EMU_QUERY_KIND(A, TRAY_MAT_GLASS); \
             EMU_QUERY_KIND(A, TRAY_MAT_ROUGH_GLASS); EMU_QUERY_KIND(A, TRAY_MAT_SPECULAR_METAL); EMU_QUERY_KIND(A, TRAY_MAT_MERL);          \
-        } else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query<A, FEAT_ALL | FEAT_TEX>(e.d, pool, n_active, qc, qctl, stats.data()); });  \
-        EMU_TRACE_STAGE(2, A, qc, qa);                                                                                                        \
+        } else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query<A, FEAT_ALL | FEAT_TEX>(e.d, pool, n_active, WF_FOLD_C ? nullptr : qc, qctl, stats.data()); });  \
+        if (!WF_FOLD_C) EMU_TRACE_STAGE(2, A, qc, qa);                                                                                                        \
     } while (0)
-#define EMU_QUERY_KIND(A, K) do { if (kinds_present & (1u << K)) EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_query_kind<A, K>(e.d, pool, kind_queues.data(), qc, qctl, stats.data()); }); } while (0)
+#define EMU_QUERY_KIND(A, K) do { if (kinds_present & (1u << K)) EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_query_kind<A, K>(e.d, pool, kind_queues.data(), WF_FOLD_C ? nullptr : qc, qctl, stats.data()); }); } while (0)
 #define EMU_TRACE_STAGE(S, A, Q, FB) /* FB: the queue buffer that is idle during stage S takes the deferred rays' records (wf_round) */                                                                                                          \
     do {                                                                                                                                    \
         EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data(), FB); }, dyn_lds); \

@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 5, GPU call 10: stage C rays folded into the next round's stage A launch (WF_FOLD_C)
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}; cd "$ROOT"; mkdir -p gpurun_out
+{
+for fr in 64 127; do
+  echo "== C5 full detail, frame $fr, 128 spp"; C5_FRAME=$fr bash tools/c5_libs.sh 128 libtrayhip_d.so libtrayhip.so libtrayhip_d.so libtrayhip.so
+done
+echo "== bit check"; python tools/r5_bitcheck.py /tmp/mini_ab 20000 2>&1 | grep "tr15"
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "wavefront or tr15 or textured or views or pool or transform_table" 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl\|rendering took" | tail -3
+} 2>&1 | tee gpurun_out/r05_call10.txt

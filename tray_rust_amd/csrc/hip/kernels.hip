@@ -911,12 +911,14 @@ static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, ui
     hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, v.dev, v.pool, n_active, s->d_stats, v.qb, v.qctl, v.kq);
     hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qb, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qc);
     hipLaunchKernelGGL((k_wf_trace_fallback<1, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qc);
+    uint32_t* const qc = WF_FOLD_C ? nullptr : v.qc;   // (WF_FOLD_C: stage C rays travel with the next round's stage A rays, no queue and no launch of their own)
     if (v.kq) {   // kind-pure shading over the sorted queues: one launch per material kind the scene contains
-#define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), qgrid, block, 0, stream, v.dev, v.pool, v.kq, v.qc, v.qctl, s->d_stats)
+#define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), qgrid, block, 0, stream, v.dev, v.pool, v.kq, qc, v.qctl, s->d_stats)
         WF_QUERY_KIND(TRAY_MAT_MATTE); WF_QUERY_KIND(TRAY_MAT_PLASTIC); WF_QUERY_KIND(TRAY_MAT_METAL); WF_QUERY_KIND(TRAY_MAT_GLASS);
         WF_QUERY_KIND(TRAY_MAT_ROUGH_GLASS); WF_QUERY_KIND(TRAY_MAT_SPECULAR_METAL); WF_QUERY_KIND(TRAY_MAT_MERL);
 #undef WF_QUERY_KIND
-    } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT_ALL | FEAT_TEX>), grid, block, 0, stream, v.dev, v.pool, n_active, v.qc, v.qctl, s->d_stats);
+    } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT_ALL | FEAT_TEX>), grid, block, 0, stream, v.dev, v.pool, n_active, qc, v.qctl, s->d_stats);
+    if (WF_FOLD_C) return;
     hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qc, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qa);
     hipLaunchKernelGGL((k_wf_trace_fallback<2, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qa);
 }
@@ -1633,7 +1635,7 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     }
     // every chunk needs at most (spp/4 rounded up) samples x (max_depth + 2) rounds per tile, plus one round per tile switch
     const uint64_t tiles_per_chunk = (tile_count + n_chunks - 1) / n_chunks;
-    const uint64_t max_rounds = tiles_per_chunk * (((uint64_t)(spp >> slice_shift) + 3) / 4 * (s->dev.max_depth + 3) + 4) + 2 * WF_POLL;
+    const uint64_t max_rounds = tiles_per_chunk * (((uint64_t)(spp >> slice_shift) + 3) / 4 * ((WF_FOLD_C ? 2u : 1u) * s->dev.max_depth + 3) + 4) + 2 * WF_POLL;   // (WF_FOLD_C: a vertex with a stage C ray takes two rounds)
     bool done = false;
     for (uint32_t round = 0; !done; ++round) {
         for (uint32_t k = 0; k < n_views; ++k) {
@@ -1641,7 +1643,7 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             HIP_CHECK(hipMemsetAsync(v.qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), v.stream));
             if (s->animated) wf_round<1>(s, v, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, slice_shift);
             else wf_round<0>(s, v, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, slice_shift);
-            launches += 10;
+            launches += WF_FOLD_C ? 8 : 10;
         }
         if (round % WF_POLL == WF_POLL - 1) {
             HIP_CHECK(hipGetLastError());

@@ -26,8 +26,18 @@ namespace tr {
 // counters are spread over WF_STAT_SLOTS records (one hot word would serialise 65536 wave atomics per launch)
 #define WF_STAT_SLOTS 1024
 enum : uint32_t {   // flags that only exist between wavefront stages
-    WF_HIT_A = 32u, WF_OCCLUDED = 64u, WF_HIT_C = 128u, WF_INVERTEX = 256u, WF_FINISHED = 512u
+    WF_HIT_A = 32u, WF_OCCLUDED = 64u, WF_HIT_C = 128u, WF_INVERTEX = 256u, WF_FINISHED = 512u,
+    WF_CFLIGHT = 4096u   // the vertex's BSDF-sampled light ray (stage C) travels with this round's stage A rays (WF_FOLD_C)
 };
+// Round 5: no traversal launch of its own for stage C. A few thousand of a round's millions of vertices trace a BSDF-sampled light ray
+// (estimate_direct's second half, mod.rs:141-166, for the samples mis_ray_filter could not dismiss); their launch was 95 % tail -- 0.5 ms per round
+// for the longest chain of dependent fetches, 3.3 % of a frame with its fallback launch. Now k_wf_advance of the NEXT round puts such a ray into
+// queue A beside the continuation rays (marked WF_CFLIGHT; the vertex stays open), k_wf_trace_dyn<A> writes its result as WF_HIT_C, k_wf_begin and
+// the query kernels pass the slot by, and k_wf_advance of the round after closes the vertex (vertex_end) as before. The slot spends one round more
+// on that vertex; every value is what it was -- both traversals are the same closest-hit search over [0.001, inf).
+#ifndef WF_FOLD_C
+#define WF_FOLD_C 1
+#endif
 
 // Pool layout (round 5): RECORDS for what is read or written in QUEUE order, field-major arrays for the rest.
 // The kernels that run one thread per pool slot (k_wf_advance, k_wf_begin) read and write consecutive slots; the others take their slots
@@ -571,10 +581,10 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
             if (STAGE == 1) {
                 flags = any ? (flags | WF_OCCLUDED) : (flags & ~WF_OCCLUDED);
             } else {
-                const uint32_t bit = STAGE == 0 ? WF_HIT_A : WF_HIT_C;
+                const uint32_t bit = (STAGE == 0 && !(flags & WF_CFLIGHT)) ? WF_HIT_A : WF_HIT_C;   // (a stage C ray that travels with the A rays: WF_FOLD_C)
                 flags = any ? (flags | bit) : (flags & ~bit);
             }
-            if (STAGE != 1 && any) st_hit(pool, slot, flags, rec);   // one 24-byte piece of the slot's hit record
+            if (STAGE != 1 && any) st_hit(pool, slot, flags, rec);   // one 20-byte piece of the slot's hit record + the flags word
             else pu(pool, F_FLAGS, slot) = flags;
             active = false;
         }
@@ -634,7 +644,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_fallback(const DevScene s
         if (STAGE == 1) {
             flags = any ? (flags | WF_OCCLUDED) : (flags & ~WF_OCCLUDED);
         } else {
-            const uint32_t bit = STAGE == 0 ? WF_HIT_A : WF_HIT_C;
+            const uint32_t bit = (STAGE == 0 && !(flags & WF_CFLIGHT)) ? WF_HIT_A : WF_HIT_C;
             flags = any ? (flags | bit) : (flags & ~bit);
         }
         if (STAGE != 1 && any) st_hit(pool, slot, flags, rec);
@@ -673,7 +683,9 @@ __global__ __launch_bounds__(TR_BLOCK, WF_SHADE_WAVES) void k_wf_begin(const Dev
     bool dark = false;              // the slot's occlusion ray cannot matter: counted, not queued
     bool counted = false;
     uint32_t flags = i < n_active ? pu(pool, F_FLAGS, i) : 0u;
-    if ((flags & LF_ALIVE) && !(flags & WF_HIT_A)) {   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
+    if (flags & WF_INVERTEX) {   // (WF_FOLD_C: the vertex is waiting for its stage C ray, which this round's traversal A carried: k_wf_advance closes it)
+        flags = 0u;
+    } else if ((flags & LF_ALIVE) && !(flags & WF_HIT_A)) {   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
         pu(pool, F_FLAGS, i) = (flags & ~(LF_ALIVE | WF_INVERTEX)) | WF_FINISHED;
     } else if (flags & LF_ALIVE) {
         Lane ln;
@@ -803,7 +815,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(
     const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
     if (i >= n_active) return;
     const uint32_t flags = pu(pool, F_FLAGS, i);
-    if ((flags & (LF_ALIVE | WF_INVERTEX)) != (LF_ALIVE | WF_INVERTEX)) return;
+    if ((flags & (LF_ALIVE | WF_INVERTEX)) != (LF_ALIVE | WF_INVERTEX) || (flags & (LF_MIS | WF_CFLIGHT)) != 0u) return;   // (a vertex whose queries ran in an earlier round waits for its stage C ray: WF_FOLD_C)
     wf_query_slot<ANIM, FEAT, KM_ALL>(sc, pool, i, flags, queue_c, qctl, stats, TR_LDS_B(s_perm));
 }
 
@@ -896,13 +908,18 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
     __syncthreads();
     uint32_t tile_idx = s_tile;
     if (tile_idx == WF_TILE_IDLE) return;
+    bool c_ray = false;   // the slot's stage C ray joins this round's queue A (WF_FOLD_C)
     const bool film_rows = sc.film_rows != 0u;
     if (tile_idx != WF_TILE_NEED) {
         const uint32_t tile_of = tile_idx >> slice_shift;
         const uint2 tile = tiles[(tile_of / chunk) * chunk_stride * chunk + (tile_of % chunk)];
         const int x0 = (int)tile.x * 8, y0 = (int)tile.y * 8;
         // ---- stage C shading of the previous round
-        if ((flags & (LF_ALIVE | WF_INVERTEX)) == (LF_ALIVE | WF_INVERTEX)) {
+        if (WF_FOLD_C && (flags & (LF_ALIVE | WF_INVERTEX | LF_MIS | WF_CFLIGHT)) == (LF_ALIVE | WF_INVERTEX | LF_MIS)) {
+            // the query kernels left a BSDF-sampled light ray (origin F_P, direction F_AUX): it goes into THIS round's queue A below
+            c_ray = true;
+            flags |= WF_CFLIGHT;
+        } else if ((flags & (LF_ALIVE | WF_INVERTEX)) == (LF_ALIVE | WF_INVERTEX)) {
             Lane ln;
             ln.flags = flags;
             HitRec rec;
@@ -920,7 +937,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
             const bool cont = vertex_end<ANIM>(sc, ln, (flags & WF_HIT_C) != 0u, rec);
             st3(pool, F_ILLUM, i, ln.illum);
             pu(pool, F_BOUNCE, i) = ln.bounce;
-            flags = ln.flags & ~(WF_INVERTEX | WF_HIT_A | WF_HIT_C | WF_OCCLUDED | LF_SHADOW | LF_MIS | LF_LAST);
+            flags = ln.flags & ~(WF_INVERTEX | WF_HIT_A | WF_HIT_C | WF_OCCLUDED | LF_SHADOW | LF_MIS | LF_LAST | WF_CFLIGHT);
             if (!cont) flags = (flags & ~LF_ALIVE) | WF_FINISHED;
         }
         // ---- RenderTarget::write of the samples that finished (here or in k_wf_begin)
@@ -1009,7 +1026,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
         const bool cont_ray = (flags & LF_ALIVE) != 0u;
         f3 ro = mk(0.0f, 0.0f, 0.0f), rd = ro;
         uint32_t rf = flags;
-        if (cont_ray) { ro = ld3(pool, F_O, i); rd = ld3(pool, F_D, i); if (pu(pool, F_BOUNCE, i) == 0u) rf |= WF_CAMERA_RAY; }
+        if (c_ray) { ro = ld3(pool, F_P, i); rd = ld3(pool, F_AUX, i); }   // Ray::segment(p, w_i, 0.001, inf) (mod.rs:154): never a camera ray
+        else if (cont_ray) { ro = ld3(pool, F_O, i); rd = ld3(pool, F_D, i); if (pu(pool, F_BOUNCE, i) == 0u) rf |= WF_CAMERA_RAY; }
         wf_enqueue_ray_by_key(pool, queue_a, qctl, 0u, cont_ray, i, ro, rd, rf, cont_ray ? wf_octant(rd) : 0u, s_oct_cnt, s_oct_base);
     }
 #else
@@ -1017,7 +1035,8 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
         const bool cont_ray = (flags & LF_ALIVE) != 0u;
         f3 ro = mk(0.0f, 0.0f, 0.0f), rd = ro;
         uint32_t rf = flags;
-        if (cont_ray) { ro = ld3(pool, F_O, i); rd = ld3(pool, F_D, i); if (pu(pool, F_BOUNCE, i) == 0u) rf |= WF_CAMERA_RAY; }
+        if (c_ray) { ro = ld3(pool, F_P, i); rd = ld3(pool, F_AUX, i); }   // Ray::segment(p, w_i, 0.001, inf) (mod.rs:154): never a camera ray
+        else if (cont_ray) { ro = ld3(pool, F_O, i); rd = ld3(pool, F_D, i); if (pu(pool, F_BOUNCE, i) == 0u) rf |= WF_CAMERA_RAY; }
         wf_enqueue_ray(pool, queue_a, qctl, 0u, cont_ray, i, ro, rd, rf);
     }
 #endif
