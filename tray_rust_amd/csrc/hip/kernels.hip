@@ -41,6 +41,9 @@ using namespace tr;
 #ifndef TR_MIN_WAVES_ANIM   // waves per SIMD the instantiations for moving scenes are compiled for (they carry the two-level traversal and the cached transforms)
 #define TR_MIN_WAVES_ANIM 3
 #endif
+#ifndef TR_MIN_WAVES_SIDE   // the every-lobe instantiations (textured / GGX materials) and Whitted. At 2 (256 VGPRs) the per-hit copy of a textured material and
+#define TR_MIN_WAVES_SIDE 3 // Whitted's locals stop spilling (105 - 145 spilled VGPRs -> 0 - 3) and the kernels get SLOWER: textured_box 646 -> 597, smallpt Whitted 3884 -> 3324
+#endif                      // Msamples/s (profiles/r05_side_instantiations_ab.txt): the third wave per SIMD is worth more than the scratch traffic costs
 #define WIN_MAX 17          // 8 + 2*4 + 1 window columns/rows
 #define WIN_STRIDE 24       // row stride in floats: 4 rows of 8 lanes land on 32 distinct banks
 #define WIN_PLANE (WIN_MAX * WIN_STRIDE)
@@ -218,7 +221,7 @@ TR_DEV const float* sc_filter_table(const DevScene& sc) { return sc.filter_table
 // LFILT: compile mis_ray_filter in (scenes with a sphere light or specular lobes: the only ones it can act on; its mere presence costs
 // the others 2 %: cornell_box 755 -> 740 Msamples/s at 64 spp).
 template <int ANIM, int FEAT, int INTEG = TRAY_INTEGRATOR_PATH, bool LFILT = false>
-__global__ __launch_bounds__(TR_BLOCK, ANIM ? TR_MIN_WAVES_ANIM : TR_MIN_WAVES) void k_path_tiles(const DevScene scv, const uint2* __restrict__ tiles, uint32_t tile_count,
+__global__ __launch_bounds__(TR_BLOCK, (FEAT == 15 || INTEG != TRAY_INTEGRATOR_PATH) ? TR_MIN_WAVES_SIDE : ANIM ? TR_MIN_WAVES_ANIM : TR_MIN_WAVES) void k_path_tiles(const DevScene scv, const uint2* __restrict__ tiles, uint32_t tile_count,
                                                          uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf, uint32_t slice_shift,
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ counter,
                                                          DevStats* __restrict__ stats) {
