@@ -230,3 +230,35 @@ def test_moving_emitter_covers_a_ray_for_the_right_share_of_the_shutter(tmp_path
     hit = out[:, 5] == 1
     assert abs(hit.mean() - 1.0 / 3.0) < 0.01
     assert np.allclose(out[hit, 0], 0.75) and (out[~hit, 0] == 0).all()
+
+
+def _flat_bytes(fs):
+    """every array of a TrayFlatScene the device reads, as bytes"""
+    def arr(ptr, n, size=None):
+        if not n:
+            return b""
+        return C.string_at(C.cast(ptr, C.c_void_p), n * (size or C.sizeof(ptr._type_)))
+    return {
+        "instances": arr(fs.instances, fs.n_instances), "top_nodes": arr(fs.top_nodes, fs.n_top_nodes), "top_order": arr(fs.top_order, fs.n_top_order),
+        "meshes": arr(fs.meshes, fs.n_meshes), "mesh_nodes": arr(fs.mesh_nodes, fs.n_mesh_nodes), "tri_verts": arr(fs.tri_verts, fs.n_tris),
+        "tri_attrs": arr(fs.tri_attrs, fs.n_tris), "lights": arr(fs.lights, fs.n_lights), "xf_levels": arr(fs.xf_levels, fs.n_xf_levels),
+        "keyframes": arr(fs.keyframes, fs.n_keyframes), "knots": arr(fs.knots, fs.n_knots), "color_keys": arr(fs.color_keys, fs.n_color_keys),
+        "camera": bytes(fs.camera), "counts": (fs.n_mesh_keys, fs.n_key_times, fs.animated, fs.frame),
+    }
+
+
+def test_a_scene_walked_through_frames_flattens_like_a_fresh_one(tmp_path, built):
+    """Scene::update_frame (scene.rs:152-176) is stateless here: flatten(frame) of a host scene that has been at other frames before gives the bytes
+    of a freshly loaded scene's flatten(frame). (Round 5: the mesh arrays -- which do not depend on the frame -- are filled by the first flatten and
+    kept, their trees walked by the validation once.)"""
+    path = scenes.write_moving_box(str(tmp_path), width=64, height=48, samples=8)
+    walked = T.Scene.load_file(path)[0]
+    for frame in (0, 5, 2):
+        walked.flatten(frame)
+    for frame in (3, 7, 0):
+        fresh = T.Scene.load_file(path)[0]
+        a, b = _flat_bytes(walked.flatten(frame).contents), _flat_bytes(fresh.flatten(frame).contents)
+        assert a.keys() == b.keys()
+        for k in a:
+            assert a[k] == b[k], (frame, k)
+        assert len(a["tri_verts"]) > 0 and len(a["mesh_nodes"]) > 0

@@ -175,6 +175,7 @@ struct TrayHostScene {
     std::vector<TrayTriAttrs> f_attrs;
     std::vector<TrayMeshKeys> f_mesh_keys;
     std::vector<float> f_key_times;
+    bool f_meshes_done = false, f_any_keys = false, f_trees_checked = false;   // the mesh arrays above are filled by the first flatten and kept
     std::vector<TrayXformLevel> f_levels;
     std::vector<TrayKeyframe> f_keyframes;
     std::vector<float> f_knots;
@@ -1205,9 +1206,10 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
     s.f_top_nodes = top.nodes;
     s.f_top_order = top.ordered;
 
-    // Meshes
-    s.f_meshes.clear(); s.f_mesh_nodes.clear(); s.f_verts.clear(); s.f_attrs.clear(); s.f_mesh_keys.clear(); s.f_key_times.clear();
-    bool any_keys = false;
+    // Meshes: nothing in them depends on the frame (the loader's meshes are immutable), so the arrays of the first flatten serve every later one --
+    // copying 3.1 M triangles and their trees anew was 0.1 s per frame of the tr15 stand-in, most of what a frame update cost beside its kernels
+    bool any_keys = s.f_any_keys;
+    if (!s.f_meshes_done)
     for (auto& m : s.meshes) {
         TrayMesh tm{};
         const size_t n_keys = std::max<size_t>(m.key_times.size(), 1);
@@ -1222,6 +1224,7 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
         s.f_attrs.insert(s.f_attrs.end(), m.attrs.begin(), m.attrs.end());
         s.f_meshes.push_back(tm);
     }
+    s.f_meshes_done = true; s.f_any_keys = any_keys;
 
     f.n_instances = (uint32_t)s.f_instances.size(); f.instances = s.f_instances.data();
     f.n_top_nodes = (uint32_t)s.f_top_nodes.size(); f.top_nodes = s.f_top_nodes.data();
@@ -1307,7 +1310,8 @@ int tray_host_scene_flatten(TrayHostScene* s, uint32_t frame, const TrayFlatScen
     *out = nullptr;
     int rc = guarded([&] { flatten(*s, frame); });
     if (rc == TRAY_OK) {   // the loader's own output goes through the check tray_scene_create applies to any caller's scene
-        const std::string bad = tray::validate_flat_scene(&s->flat);
+        const std::string bad = tray::validate_flat_scene(&s->flat, !s->f_trees_checked);   // (the mesh arrays are the first flatten's: walked once)
+        s->f_trees_checked = s->f_trees_checked || bad.empty();
         if (!bad.empty()) { set_error("internal error: the flattened scene is inconsistent: " + bad); return TRAY_E_INVALID; }
         *out = &s->flat;
     }

@@ -28,7 +28,19 @@ inline std::string validate_bvh(const TrayBvhNode* nodes, uint64_t n, uint64_t n
     return "";
 }
 
-inline std::string validate_flat_scene(const TrayFlatScene* f) {
+// the walk validate_flat_scene(f, false) left out
+inline std::string validate_mesh_trees(const TrayFlatScene* f) {
+    for (uint32_t m = 0; m < f->n_meshes; ++m) {
+        const TrayMesh& me = f->meshes[m];
+        if (std::string e = validate_bvh(f->mesh_nodes + me.node_offset, me.node_count, me.tri_count, 16u, "BVH<Triangle>"); !e.empty())
+            return "mesh " + std::to_string(m) + ": " + e;
+    }
+    return "";
+}
+
+// `walk_mesh_trees = false` leaves out the node-by-node walk of the BVH<Triangle>s (millions of nodes): for a caller that has checked these very
+// arrays before (the loader's later frames; a frame update that keeps the device's trees and never reads the new ones).
+inline std::string validate_flat_scene(const TrayFlatScene* f, bool walk_mesh_trees = true) {
     auto need = [](const void* p, uint64_t n) { return n == 0 || p != nullptr; };
     if (!need(f->instances, f->n_instances) || !need(f->top_nodes, f->n_top_nodes) || !need(f->top_order, f->n_top_order) ||
         !need(f->meshes, f->n_meshes) || !need(f->mesh_nodes, f->n_mesh_nodes) || !need(f->tri_verts, f->n_tris) ||
@@ -61,6 +73,7 @@ inline std::string validate_flat_scene(const TrayFlatScene* f) {
         if ((uint64_t)me.node_offset + me.node_count > f->n_mesh_nodes || (uint64_t)me.tri_offset + n_keys * me.tri_count > f->n_tris)
             return "mesh " + std::to_string(m) + " refers to nodes or triangles outside the arrays";
         if (me.node_count == 0 || me.tri_count == 0) return "mesh " + std::to_string(m) + " is empty";
+        if (!walk_mesh_trees) continue;
         if (std::string e = validate_bvh(f->mesh_nodes + me.node_offset, me.node_count, me.tri_count, 16u, "BVH<Triangle>"); !e.empty())
             return "mesh " + std::to_string(m) + ": " + e;
     }
