@@ -571,3 +571,169 @@ def test_whitted_on_random_scenes(tmp_path, built):
         b = E.sample_radiance(flat, px, py, si, 8, seed + 1)
         same = (a == b).all(axis=1) | (np.isnan(a).any(axis=1) & np.isnan(b).any(axis=1))
         assert same.all(), f"seed {seed}: {int((~same).sum())} of {n} samples differ"
+
+
+@pytest.mark.parametrize("kind", ["rgb_raw", "rgb_lzw_noise", "rgb_packbits", "rgba_lzw", "grey8", "grey16_lzw", "palette", "rgb_lzw_predictor", "big_endian_by_hand", "bilevel"])
+def test_tiff_decoder_against_pillow_written_files(kind, tmp_path, built):
+    """image::open of a .tif (VERDICT round 4, missing 5): baseline strips -- uncompressed, LZW (codes growing to 12 bits and table resets on a noisy
+    picture, several strips), PackBits, the horizontal predictor, 16-bit samples (high byte), palette, both byte orders -- against Pillow's reading."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(5)
+    w, h = (211, 157) if "noise" in kind else (37, 23)
+    yy, xx = np.mgrid[0:h, 0:w]
+    smooth = np.stack([(xx * 3 + yy) % 256, (xx + yy * 5) % 256, (xx * yy) % 256, 255 - (xx + yy) % 200], axis=2).astype(np.uint8)
+    path = str(tmp_path / "textures" / "x.tif")
+    os.makedirs(tmp_path / "textures", exist_ok=True)
+    if kind == "rgb_raw":
+        Image.fromarray(smooth[..., :3]).save(path, compression="raw")
+    elif kind == "rgb_lzw_noise":
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(path, compression="tiff_lzw")
+    elif kind == "rgb_packbits":
+        Image.fromarray((smooth[..., :3] // 64 * 64).astype(np.uint8)).save(path, compression="packbits")
+    elif kind == "rgba_lzw":
+        Image.fromarray(smooth, "RGBA").save(path, compression="tiff_lzw")
+    elif kind == "grey8":
+        Image.fromarray(smooth[..., 0], "L").save(path, compression="tiff_lzw")
+    elif kind == "grey16_lzw":
+        Image.fromarray((smooth[..., 0].astype(np.uint16) * 257 + 13).astype(np.uint16)).save(path, compression="tiff_lzw")
+    elif kind == "palette":
+        im = Image.fromarray((smooth[..., 0] % 17).astype(np.uint8), "P")
+        im.putpalette([int(v) for v in rng.integers(0, 256, 51)] + [0] * (768 - 51))
+        im.save(path, compression="tiff_lzw")
+    elif kind == "rgb_lzw_predictor":
+        Image.fromarray(smooth[..., :3]).save(path, compression="tiff_lzw", tiffinfo={317: 2})
+    elif kind == "bilevel":
+        Image.fromarray(((xx // 3 + yy // 2) % 2 * 255).astype(np.uint8)).convert("1").save(path, compression="raw")
+    else:   # a big-endian file, two strips, written here: header, pixel data, then the directory
+        pix = smooth[..., :3]
+        rows0 = 12
+        strips = [pix[:rows0].tobytes(), pix[rows0:].tobytes()]
+        data_at = 8
+        offs = [data_at, data_at + len(strips[0])]
+        ifd_at = data_at + len(strips[0]) + len(strips[1])
+        extra_at = ifd_at + 2 + 10 * 12 + 4
+        extra = struct.pack(">HHH", 8, 8, 8) + struct.pack(">II", *offs) + struct.pack(">II", len(strips[0]), len(strips[1]))
+        def ent(tag, typ, count, val):
+            return struct.pack(">HHI", tag, typ, count) + (struct.pack(">HH", val, 0) if typ == 3 and count == 1 else struct.pack(">I", val))
+        ifd = struct.pack(">H", 10) + b"".join([ent(256, 3, 1, w), ent(257, 3, 1, h), ent(258, 3, 3, extra_at), ent(259, 3, 1, 1), ent(262, 3, 1, 2),
+                                                ent(273, 4, 2, extra_at + 6), ent(277, 3, 1, 3), ent(278, 3, 1, rows0), ent(279, 4, 2, extra_at + 14),
+                                                ent(284, 3, 1, 1)]) + struct.pack(">I", 0)
+        open(path, "wb").write(b"MM\x00\x2a" + struct.pack(">I", ifd_at) + strips[0] + strips[1] + ifd + extra)
+    data = open(path, "rb").read()
+    assert data[:2] == (b"MM" if kind == "big_endian_by_hand" else b"II")
+    im = Image.open(path)
+    if kind == "rgb_lzw_predictor":
+        assert im.tag_v2.get(317) == 2
+    if kind == "rgb_lzw_noise":
+        assert len(im.tag_v2[273]) > 1   # several strips
+    if kind == "grey16_lzw":
+        a = np.asarray(im).astype(np.uint16)
+        ref = np.stack([(a >> 8).astype(np.uint8)] * 3 + [np.full(a.shape, 255, np.uint8)], axis=2)
+    else:
+        ref = np.asarray(im.convert("RGBA"))
+    scene, *_ = load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/x.tif"}])
+    got, fr = frame_pixels(scene.flatten(0).contents, 0)
+    assert (fr.width, fr.height) == (w, h)
+    assert np.array_equal(got, ref)
+
+
+def test_tiff_files_the_decoder_refuses(tmp_path, built):
+    Image = pytest.importorskip("PIL.Image")
+    os.makedirs(tmp_path / "textures", exist_ok=True)
+    path = str(tmp_path / "textures" / "x.tif")
+    Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(path, compression="tiff_adobe_deflate")
+    with pytest.raises(T.TrayError) as e:
+        load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/x.tif"}])
+    assert "compression" in str(e.value) and "x.tif" in str(e.value)
+    data = bytearray(open(path, "rb").read())
+    for cut in (6, 40, len(data) - 20):
+        open(path, "wb").write(bytes(data[:cut]))
+        with pytest.raises(T.TrayError):
+            load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/x.tif"}])
+
+
+@pytest.mark.parametrize("kind", ["png_payload", "bmp32_payload", "bmp8_with_mask_by_hand"])
+def test_ico_best_entry(kind, tmp_path, built):
+    """image::open of a .ico: the entry with the most bits per pixel, then the largest; PNG or headerless-BMP payload, the AND mask as alpha."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(6)
+    os.makedirs(tmp_path / "textures", exist_ok=True)
+    path = str(tmp_path / "textures" / "x.ico")
+    if kind != "bmp8_with_mask_by_hand":
+        big = rng.integers(0, 256, (48, 48, 4), dtype=np.uint8)
+        Image.fromarray(big, "RGBA").save(path, sizes=[(16, 16), (48, 48), (32, 32)], **({"bitmap_format": "bmp"} if kind == "bmp32_payload" else {}))
+        ref = np.asarray(Image.open(path).convert("RGBA"))
+        assert ref.shape[:2] == (48, 48)
+    else:
+        w = h = 10
+        idx = rng.integers(0, 5, (h, w), dtype=np.uint8)
+        pal = rng.integers(0, 256, (5, 3), dtype=np.uint8)
+        mask = rng.integers(0, 2, (h, w), dtype=np.uint8)
+        stride, mstride = (w + 3) & ~3, 4
+        xor = b"".join(idx[y].tobytes() + bytes(stride - w) for y in range(h - 1, -1, -1))
+        andm = b"".join(np.packbits(mask[y]).tobytes().ljust(mstride, b"\0") for y in range(h - 1, -1, -1))
+        dib = struct.pack("<IiiHHIIiiII", 40, w, 2 * h, 1, 8, 0, len(xor) + len(andm), 0, 0, 5, 0) + b"".join(bytes([p[2], p[1], p[0], 0]) for p in pal) + xor + andm
+        small = struct.pack("<IiiHHIIiiII", 40, 4, 8, 1, 1, 0, 0, 0, 0, 2, 0) + bytes(8) + bytes(16) + bytes(16)   # a 1-bit 4x4 entry that must lose
+        entries = [(w, h, 8, dib), (4, 4, 1, small)]
+        at = 6 + 16 * len(entries)
+        out = struct.pack("<HHH", 0, 1, len(entries))
+        for (ew, eh, bpp, blob) in entries:
+            out += struct.pack("<BBBBHHII", ew, eh, 0, 0, 1, bpp, len(blob), at)
+            at += len(blob)
+        open(path, "wb").write(out + b"".join(b for *_, b in entries))
+        ref = np.concatenate([pal[idx], np.where(mask, 0, 255).astype(np.uint8)[..., None]], axis=2)
+    scene, *_ = load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/x.ico"}])
+    got, fr = frame_pixels(scene.flatten(0).contents, 0)
+    assert (fr.height, fr.width) == ref.shape[:2]
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("rle", [True, False])
+def test_radiance_hdr_is_tone_mapped_like_the_image_crate(rle, tmp_path, built):
+    """image::open of a .hdr hands out 8-bit RGB: mantissa * 2^(e - 136), then powf(v, 2.2) * 255 + 0.5, clamped, truncated (image 0.18 hdr/hdr_decoder.rs:
+    RGBE8Pixel::to_ldr; restated, not pinned). Run-length scanlines (2, 2, width) with runs and literals, and flat scanlines."""
+    rng = np.random.default_rng(7)
+    w, h = 24, 9
+    rgbe = np.zeros((h, w, 4), np.uint8)
+    rgbe[..., :3] = rng.integers(0, 256, (h, w, 3))
+    rgbe[..., 3] = rng.integers(120, 131, (h, w))
+    rgbe[0, :5, 3] = 0                       # e = 0: black whatever the mantissas say
+    rgbe[2, 4:20] = rgbe[2, 4]               # a long run in every channel
+    body = b""
+    for y in range(h):
+        if not rle:
+            body += rgbe[y].tobytes()
+            continue
+        body += bytes([2, 2, w >> 8, w & 255])
+        for ch in range(4):
+            row, x = rgbe[y, :, ch], 0
+            while x < w:
+                run = 1
+                while x + run < w and row[x + run] == row[x] and run < 127:
+                    run += 1
+                if run >= 3:
+                    body += bytes([128 + run, int(row[x])]); x += run
+                else:
+                    lit = min(5, w - x)
+                    body += bytes([lit]) + row[x:x + lit].tobytes(); x += lit
+    os.makedirs(tmp_path / "textures", exist_ok=True)
+    open(tmp_path / "textures" / "x.hdr", "wb").write(b"#?RADIANCE\n# made by the test\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n-Y %d +X %d\n" % (h, w) + body)
+    f32 = np.float32
+    scale = np.where(rgbe[..., 3:4] == 0, f32(0), np.ldexp(f32(1), rgbe[..., 3:4].astype(np.int32) - 136)).astype(f32)
+    v = (scale * rgbe[..., :3].astype(f32)).astype(f32)
+    fv = (np.power(v, f32(2.2), dtype=f32) * f32(255) + f32(0.5)).astype(f32)
+    want = np.clip(fv, 0, 255).astype(np.uint8)
+    scene, *_ = load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/x.hdr"}])
+    got, fr = frame_pixels(scene.flatten(0).contents, 0)
+    assert (fr.width, fr.height) == (w, h)
+    assert (got[..., 3] == 255).all()
+    assert np.abs(got[..., :3].astype(int) - want.astype(int)).max() <= 1   # (numpy's powf against the C library's: an LSB at most)
+    assert (got[0, :5, :3] == 0).all() and got[..., :3].max() == 255 and 0 < np.median(got[..., :3]) < 255
+
+
+def test_webp_is_refused_by_name(tmp_path, built):
+    os.makedirs(tmp_path / "textures", exist_ok=True)
+    open(tmp_path / "textures" / "x.webp", "wb").write(b"RIFF\x1a\0\0\0WEBPVP8 \x0e\0\0\0" + bytes(14))
+    with pytest.raises(T.TrayError) as e:
+        load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/x.webp"}])
+    assert "WebP" in str(e.value)

@@ -1,4 +1,4 @@
-"""Mutated PNG / JPEG (baseline, progressive) / GIF / BMP / TGA files through tools/image_decode_check (image.hpp built with
+"""Mutated PNG / JPEG (baseline, progressive) / GIF / BMP / TGA / TIFF / ICO / Radiance HDR files through tools/image_decode_check (image.hpp built with
 -fsanitize=address,undefined): any memory error or undefined arithmetic aborts the harness and is reported with the file that caused it.
     g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all tools/image_decode_check.cpp -o /tmp/image_decode_check
     python tools/fuzz_images_asan.py <seed> <n> [harness]"""
@@ -17,6 +17,19 @@ save("a.jpg", quality=85, subsampling=2); save("p.jpg", quality=85, subsampling=
 save("r.jpg", quality=60, subsampling=0, progressive=True, restart_marker_blocks=2); save("q.jpg", quality=30, subsampling=1, progressive=True)
 save("c.png"); save("g.gif", img=im.quantize(64)); save("i.gif", img=im.quantize(200), interlace=1, transparency=5)
 save("b.bmp"); save("t.tga"); save("l.jpg", img=Image.fromarray(pix[...,0],"L"), progressive=True)
+save("u.tif", compression="raw"); save("z.tif", compression="tiff_lzw"); save("k.tif", compression="packbits"); save("d.tif", compression="tiff_lzw", tiffinfo={317: 2})
+save("m.tif", img=im.quantize(40), compression="tiff_lzw"); save("w.tif", img=Image.fromarray((pix[...,0].astype(np.uint16)*257)), compression="tiff_lzw")
+save("n.ico", img=im.convert("RGBA").resize((32,32)), sizes=[(16,16),(32,32)]); save("o.ico", img=im.convert("RGBA").resize((32,32)), sizes=[(16,16),(32,32)], bitmap_format="bmp")
+def hdr_bytes():
+    w,h=pix.shape[1],pix.shape[0]; out=b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n"%(h,w)
+    for y in range(h):
+        out+=bytes([2,2,w>>8,w&255])
+        for ch in range(4):
+            row=(pix[y,:,ch] if ch<3 else np.full(w,129,np.uint8)); x=0
+            while x<w:
+                n=min(9,w-x); out+=(bytes([128+n,int(row[x])]) if (x//9)%2 else bytes([n])+row[x:x+n].tobytes()); x+=n
+    return out
+files["h.hdr"]=hdr_bytes()
 rng=random.Random(seed)
 names=sorted(files)
 stats={'ok':0,'err':0}
@@ -36,12 +49,12 @@ for i in range(N):
         k=rng.randrange(len(b)); del b[k:k+rng.randrange(1,60)]
     p=os.path.join(d,"m%05d"%i+os.path.splitext(v)[1]); open(p,'wb').write(bytes(b)); batch.append(p)
     if len(batch)==50 or i==N-1:
-        r=subprocess.run([HARNESS]+batch,capture_output=True,text=True,timeout=600)
+        r=subprocess.run([HARNESS]+batch,capture_output=True,text=True,errors='replace',timeout=600)
         for line in r.stdout.splitlines(): stats[line.split()[0]]+=1
         if r.returncode!=0:
             fails+=1
             for q in batch:
-                rr=subprocess.run([HARNESS,q],capture_output=True,text=True,timeout=60)
+                rr=subprocess.run([HARNESS,q],capture_output=True,text=True,errors='replace',timeout=60)
                 if rr.returncode!=0:
                     print("FAIL",q, [l for l in rr.stderr.splitlines() if 'runtime error' in l or 'ERROR' in l][:2]); break
             if fails>=3: break

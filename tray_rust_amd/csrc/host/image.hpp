@@ -3,10 +3,14 @@
 // row 0 on top, grey expanded to (l, l, l, 255), RGB given alpha 255 (texture/image.rs:18-32 reads px.data[0..4]).
 // Formats: PNG (non-interlaced; grey / grey+alpha / RGB / RGBA / palette with tRNS; 1-16 bits, 16-bit samples keep their high
 // byte), binary PPM / PGM (P6 / P5, maxval <= 255), BMP (uncompressed 24 / 32 bit), TGA (uncompressed true colour 24 / 32 bit and
-// grey 8 bit), baseline and progressive JPEG (see decode_jpeg), GIF (first frame, see decode_gif). No third-party code: the inflate below
-// is the textbook RFC 1951 decoder.
+// grey 8 bit), baseline and progressive JPEG (see decode_jpeg), GIF (first frame, see decode_gif), TIFF (baseline strips: uncompressed / LZW / PackBits,
+// see decode_tiff), Radiance HDR (tone-mapped to 8 bit as the crate does, see decode_hdr), ICO (the best entry, PNG or BMP payload). WebP is refused
+// by name. No third-party code: the inflate below is the textbook RFC 1951 decoder.
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <string>
@@ -758,6 +762,254 @@ inline bool decode_gif(const std::vector<uint8_t>& f, ImageRGBA8& out, std::stri
     return false;
 }
 
+
+// ---- TIFF (baseline, strips). image 0.18 carries its own tiff decoder (not vendored by the reference: PARITY UNPINNED): grey / RGB(A) strips of 8 or 16 bits,
+// uncompressed, LZW or PackBits, horizontal predictor. Restated from the TIFF 6.0 specification; accepted beyond that crate: palette images, grey with
+// 1 / 4 bits. Tiles, planar-separate samples, JPEG / deflate compression are refused with a message. 16-bit samples keep their high byte (as PNG above).
+inline bool tiff_lzw(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t expect) {   // TIFF 6.0 section 13: MSB-first codes, 9 - 12 bits, "early change"
+    std::vector<uint16_t> prefix(4096, 0);
+    std::vector<uint8_t> suffix(4096, 0), tmp;
+    for (int i = 0; i < 256; ++i) suffix[i] = (uint8_t)i;
+    uint32_t acc = 0; int have = 0, width = 9; uint32_t next = 258; int old = -1;
+    size_t pos = 0;
+    auto first_of = [&](int c) { while (c >= 258) c = prefix[c]; return suffix[c]; };
+    auto emit = [&](int c) {
+        tmp.clear();
+        while (c >= 258) { tmp.push_back(suffix[c]); c = prefix[c]; if (tmp.size() > 4096) return false; }
+        tmp.push_back(suffix[c]);
+        out.insert(out.end(), tmp.rbegin(), tmp.rend());
+        return true;
+    };
+    while (out.size() < expect) {
+        while (have < width) { if (pos >= n) return out.size() >= expect; acc = (acc << 8) | src[pos++]; have += 8; }
+        const int code = (int)((acc >> (have - width)) & ((1u << width) - 1u));
+        have -= width;
+        if (code == 257) break;
+        if (code == 256) { width = 9; next = 258; old = -1; continue; }
+        if (old < 0) { if (code >= 256) return false; out.push_back((uint8_t)code); old = code; continue; }
+        if ((uint32_t)code < next) {
+            if (code >= 256 && code < 258) return false;
+            if (!emit(code)) return false;
+            if (next < 4096) { prefix[next] = (uint16_t)old; suffix[next] = first_of(code); ++next; }
+        } else if ((uint32_t)code == next && next < 4096) {
+            prefix[next] = (uint16_t)old; suffix[next] = first_of(old); ++next;
+            if (!emit(code)) return false;
+        } else return false;
+        old = code;
+        if (next + 1 >= (1u << width) && width < 12) ++width;
+    }
+    return true;
+}
+
+inline bool decode_tiff(const std::vector<uint8_t>& f, ImageRGBA8& out, std::string& err) {
+    if (f.size() < 8) { err = "truncated TIFF file"; return false; }
+    const bool le = f[0] == 'I';
+    bool bad = false;
+    auto u16 = [&](size_t o) -> uint32_t { if (o + 2 > f.size()) { bad = true; return 0; } return le ? (uint32_t)(f[o] | f[o + 1] << 8) : (uint32_t)(f[o] << 8 | f[o + 1]); };
+    auto u32 = [&](size_t o) -> uint32_t { if (o + 4 > f.size()) { bad = true; return 0; }
+        return le ? (uint32_t)f[o] | (uint32_t)f[o + 1] << 8 | (uint32_t)f[o + 2] << 16 | (uint32_t)f[o + 3] << 24
+                  : (uint32_t)f[o] << 24 | (uint32_t)f[o + 1] << 16 | (uint32_t)f[o + 2] << 8 | (uint32_t)f[o + 3]; };
+    if (u16(2) != 42) { err = "not a TIFF file (BigTIFF is not supported)"; return false; }
+    const size_t ifd = u32(4);
+    const uint32_t n_entries = u16(ifd);
+    if (bad || ifd + 2 + (size_t)n_entries * 12 > f.size()) { err = "truncated TIFF directory"; return false; }
+    struct Entry { uint32_t type = 0, count = 0; size_t at = 0; bool present = false; };
+    auto find = [&](uint32_t tag) {
+        Entry e;
+        for (uint32_t i = 0; i < n_entries; ++i) {
+            const size_t o = ifd + 2 + (size_t)i * 12;
+            if (u16(o) != tag) continue;
+            e.type = u16(o + 2); e.count = u32(o + 4);
+            const size_t size = e.type == 3 ? 2 : (e.type == 4 ? 4 : 1);
+            e.at = (size * e.count <= 4) ? o + 8 : (size_t)u32(o + 8);
+            e.present = e.type == 1 || e.type == 3 || e.type == 4;
+            break;
+        }
+        return e;
+    };
+    auto value = [&](const Entry& e, uint32_t k) -> uint32_t { return e.type == 3 ? u16(e.at + 2 * (size_t)k) : (e.type == 4 ? u32(e.at + 4 * (size_t)k) : (e.at + k < f.size() ? f[e.at + k] : (bad = true, 0u))); };
+    auto scalar = [&](uint32_t tag, uint32_t dflt) { const Entry e = find(tag); return e.present && e.count ? value(e, 0) : dflt; };
+    const uint32_t w = scalar(256, 0), h = scalar(257, 0), comp = scalar(259, 1), photo = scalar(262, 0xffffu), spp = scalar(277, 1);
+    const uint32_t rows_per_strip = std::max(1u, std::min(scalar(278, h), h)), planar = scalar(284, 1), predictor = scalar(317, 1);
+    const Entry bps = find(258), offs = find(273), counts = find(279), cmap = find(320);
+    if (find(322).present || find(324).present) { err = "tiled TIFF files are not supported"; return false; }
+    uint32_t bits = 1;
+    if (bps.present) { bits = value(bps, 0); for (uint32_t k = 1; k < bps.count && k < spp; ++k) if (value(bps, k) != bits) { err = "TIFF: samples of different widths are not supported"; return false; } }
+    if (bad || w == 0 || h == 0 || w > 32768 || h > 32768 || !offs.present) { err = "TIFF without usable dimensions / strips"; return false; }
+    if ((uint64_t)w * h > std::max<uint64_t>(1u << 20, (uint64_t)f.size() * 1024u)) { err = "TIFF dimensions out of proportion to the file size"; return false; }   // (no allocation from a forged header)
+    if (comp != 1 && comp != 5 && comp != 32773) { err = "TIFF compression " + std::to_string(comp) + " is not supported (uncompressed, LZW, PackBits)"; return false; }
+    if (planar != 1 && spp > 1) { err = "TIFF with separate sample planes is not supported"; return false; }
+    const bool grey = photo == 0 || photo == 1, rgb = photo == 2, pal = photo == 3;
+    const bool shape_ok = (grey && (spp == 1 || spp == 2) && (bits == 8 || bits == 16 || (spp == 1 && (bits == 1 || bits == 4)))) ||
+                          (rgb && (spp == 3 || spp == 4) && (bits == 8 || bits == 16)) ||
+                          (pal && spp == 1 && (bits == 4 || bits == 8) && cmap.present && cmap.type == 3 && cmap.count >= 3u << bits);
+    if (!shape_ok) { err = "unsupported TIFF photometric interpretation / sample layout"; return false; }
+    if (predictor != 1 && (predictor != 2 || bits < 8)) { err = "unsupported TIFF predictor"; return false; }
+    const size_t row_bytes = ((size_t)w * spp * bits + 7) / 8;
+    const uint32_t n_strips = (h + rows_per_strip - 1) / rows_per_strip;
+    if (offs.count < n_strips || (counts.present && counts.count < n_strips)) { err = "TIFF strip tables are shorter than the image"; return false; }
+    out.width = w; out.height = h;
+    out.px.assign((size_t)w * h * 4, 255);
+    std::vector<uint8_t> raw;
+    for (uint32_t s = 0; s < n_strips; ++s) {
+        const uint32_t y0 = s * rows_per_strip, rows = std::min(rows_per_strip, h - y0);
+        const size_t expect = row_bytes * rows, at = value(offs, s);
+        size_t len = counts.present ? (size_t)value(counts, s) : (comp == 1 ? expect : f.size() - std::min(f.size(), at));
+        if (bad || at > f.size() || len > f.size() - at) { err = "TIFF strip outside the file"; return false; }
+        raw.clear();
+        if (comp == 1) { if (len < expect) { err = "truncated TIFF strip"; return false; } raw.assign(f.begin() + (long)at, f.begin() + (long)(at + expect)); }
+        else if (comp == 5) { raw.reserve(expect); if (!tiff_lzw(&f[at], len, raw, expect) || raw.size() < expect) { err = "corrupt LZW data in a TIFF strip"; return false; } }
+        else {   // PackBits
+            size_t p = at; const size_t end = at + len;
+            while (raw.size() < expect && p < end) {
+                const int nb = (int8_t)f[p++];
+                if (nb >= 0) { if (p + (size_t)nb + 1 > end) break; raw.insert(raw.end(), f.begin() + (long)p, f.begin() + (long)(p + (size_t)nb + 1)); p += (size_t)nb + 1; }
+                else if (nb != -128) { if (p >= end) break; raw.insert(raw.end(), (size_t)(1 - nb), f[p++]); }
+            }
+            if (raw.size() < expect) { err = "truncated PackBits data in a TIFF strip"; return false; }
+        }
+        for (uint32_t r = 0; r < rows; ++r) {
+            uint8_t* line = &raw[row_bytes * r];
+            if (predictor == 2) {
+                if (bits == 8) for (size_t i = spp; i < (size_t)w * spp; ++i) line[i] = (uint8_t)(line[i] + line[i - spp]);
+                else for (size_t i = spp; i < (size_t)w * spp; ++i) {
+                    const size_t a = 2 * i, b = 2 * (i - spp);
+                    const uint32_t cur = le ? (uint32_t)(line[a] | line[a + 1] << 8) : (uint32_t)(line[a] << 8 | line[a + 1]);
+                    const uint32_t prv = le ? (uint32_t)(line[b] | line[b + 1] << 8) : (uint32_t)(line[b] << 8 | line[b + 1]);
+                    const uint32_t v = (cur + prv) & 0xffffu;
+                    if (le) { line[a] = (uint8_t)v; line[a + 1] = (uint8_t)(v >> 8); } else { line[a] = (uint8_t)(v >> 8); line[a + 1] = (uint8_t)v; }
+                }
+            }
+            uint8_t* o = &out.px[(size_t)(y0 + r) * w * 4];
+            for (uint32_t x = 0; x < w; ++x) {
+                uint32_t sm[4] = {0, 0, 0, 255};
+                for (uint32_t ch = 0; ch < spp; ++ch) {
+                    if (bits == 8) sm[ch] = line[(size_t)x * spp + ch];
+                    else if (bits == 16) sm[ch] = line[((size_t)x * spp + ch) * 2 + (le ? 1 : 0)];   // high byte
+                    else { const size_t bit = (size_t)x * bits; sm[ch] = (line[bit / 8] >> (8 - bits - bit % 8)) & ((1u << bits) - 1u); }
+                }
+                if (pal) {
+                    const uint32_t n = 1u << bits;
+                    o[4 * x] = (uint8_t)(value(cmap, sm[0]) >> 8); o[4 * x + 1] = (uint8_t)(value(cmap, n + sm[0]) >> 8); o[4 * x + 2] = (uint8_t)(value(cmap, 2 * n + sm[0]) >> 8);
+                } else if (grey) {
+                    uint32_t l = sm[0];
+                    if (bits < 8) l = l * 255u / ((1u << bits) - 1u);
+                    if (photo == 0) l = 255u - l;   // WhiteIsZero
+                    o[4 * x] = o[4 * x + 1] = o[4 * x + 2] = (uint8_t)l;
+                    if (spp == 2) o[4 * x + 3] = (uint8_t)sm[1];
+                } else {
+                    o[4 * x] = (uint8_t)sm[0]; o[4 * x + 1] = (uint8_t)sm[1]; o[4 * x + 2] = (uint8_t)sm[2];
+                    if (spp == 4) o[4 * x + 3] = (uint8_t)sm[3];
+                }
+            }
+        }
+    }
+    if (bad) { err = "TIFF tables outside the file"; return false; }
+    return true;
+}
+
+// ---- Radiance HDR (.hdr / .pic). image 0.18 opens these through its HDRAdapter, which hands out 8-bit RGB: RGBE -> f32 (mantissa * 2^(e - 136), e = 0 is
+// black), then `powf(v, 2.2) * 255 + 0.5`, clamped and truncated (RGBE8Pixel::to_ldr = to_ldr_scale_gamma(1.0, 2.2), as that crate wrote it; restated from
+// the crate's published source, PARITY UNPINNED). Scanlines: the new run-length form (2, 2, width; four channel planes) or flat pixels; "-Y h +X w" only.
+inline bool decode_hdr(const std::vector<uint8_t>& f, ImageRGBA8& out, std::string& err) {
+    size_t pos = 0;
+    auto line = [&](std::string& l) { l.clear(); while (pos < f.size() && f[pos] != '\n') l.push_back((char)f[pos++]); if (pos >= f.size()) return false; ++pos; return true; };
+    std::string l;
+    if (!line(l) || (l != "#?RADIANCE" && l != "#?RGBE")) { err = "not a Radiance HDR file"; return false; }
+    for (;;) {
+        if (!line(l)) { err = "truncated HDR header"; return false; }
+        if (l.empty()) break;
+        if (l.rfind("FORMAT=", 0) == 0 && l != "FORMAT=32-bit_rle_rgbe") { err = "the HDR file's pixel format is not supported (32-bit_rle_rgbe only)"; return false; }
+    }
+    if (!line(l)) { err = "HDR file without a resolution line"; return false; }
+    unsigned long hh = 0, ww = 0;
+    if (std::sscanf(l.c_str(), "-Y %lu +X %lu", &hh, &ww) != 2 || ww == 0 || hh == 0 || ww > 32768 || hh > 32768) { err = "unsupported HDR resolution line (only -Y h +X w)"; return false; }
+    const uint32_t w = (uint32_t)ww, h = (uint32_t)hh;
+    if ((uint64_t)w * h > std::max<uint64_t>(1u << 20, (uint64_t)f.size() * 1024u)) { err = "HDR dimensions out of proportion to the file size"; return false; }
+    out.width = w; out.height = h;
+    out.px.assign((size_t)w * h * 4, 255);
+    std::vector<uint8_t> scan((size_t)w * 4);
+    auto ldr = [](float v) { const float fv = std::pow(v, 2.2f) * 255.0f + 0.5f; return (uint8_t)(fv < 0.0f ? 0.0f : (fv > 255.0f ? 255.0f : fv)); };
+    for (uint32_t y = 0; y < h; ++y) {
+        if (pos + 4 > f.size()) { err = "truncated HDR scanline"; return false; }
+        if (w >= 8 && w <= 32767 && f[pos] == 2 && f[pos + 1] == 2 && (f[pos + 2] & 0x80) == 0 && ((uint32_t)f[pos + 2] << 8 | f[pos + 3]) == w) {
+            pos += 4;
+            for (int ch = 0; ch < 4; ++ch) {
+                uint32_t x = 0;
+                while (x < w) {
+                    if (pos >= f.size()) { err = "truncated HDR scanline"; return false; }
+                    uint32_t c = f[pos++];
+                    if (c > 128) {
+                        c -= 128;
+                        if (pos >= f.size() || x + c > w) { err = "corrupt HDR run"; return false; }
+                        const uint8_t v = f[pos++];
+                        for (uint32_t k = 0; k < c; ++k) scan[(size_t)(x + k) * 4 + ch] = v;
+                    } else {
+                        if (c == 0 || pos + c > f.size() || x + c > w) { err = "corrupt HDR run"; return false; }
+                        for (uint32_t k = 0; k < c; ++k) scan[(size_t)(x + k) * 4 + ch] = f[pos++];
+                    }
+                    x += c;
+                }
+            }
+        } else {
+            if (pos + (size_t)w * 4 > f.size()) { err = "truncated HDR scanline"; return false; }
+            std::memcpy(scan.data(), &f[pos], (size_t)w * 4);
+            pos += (size_t)w * 4;
+        }
+        uint8_t* o = &out.px[(size_t)y * w * 4];
+        for (uint32_t x = 0; x < w; ++x) {
+            const uint8_t* p = &scan[(size_t)x * 4];
+            const float scale = p[3] == 0 ? 0.0f : std::ldexp(1.0f, (int)p[3] - 136);
+            o[4 * x] = ldr(scale * (float)p[0]); o[4 * x + 1] = ldr(scale * (float)p[1]); o[4 * x + 2] = ldr(scale * (float)p[2]);
+        }
+    }
+    return true;
+}
+
+// ---- ICO: the directory's best entry as image 0.18 picks it (ico/decoder.rs best_entry: the highest (bits per pixel, width x height), the LAST entry
+// among equals only if nothing before it is strictly better), its payload a PNG file or a BMP without the file header (height doubled: colour rows, then
+// the 1-bit AND mask; a set mask bit makes the pixel transparent). PARITY UNPINNED.
+inline bool decode_ico(const std::vector<uint8_t>& f, ImageRGBA8& out, std::string& err) {
+    auto le16 = [&](size_t o) { return (uint32_t)(f[o] | f[o + 1] << 8); };
+    auto le32 = [&](size_t o) { return (uint32_t)f[o] | (uint32_t)f[o + 1] << 8 | (uint32_t)f[o + 2] << 16 | (uint32_t)f[o + 3] << 24; };
+    if (f.size() < 6 || le16(0) != 0 || le16(2) != 1) { err = "not an ICO file"; return false; }
+    const uint32_t n = le16(4);
+    if (n == 0 || 6 + (size_t)n * 16 > f.size()) { err = "ICO file without a usable directory"; return false; }
+    auto score = [&](uint32_t i) { const size_t o = 6 + (size_t)i * 16; const uint64_t ew = f[o] ? f[o] : 256u, eh = f[o + 1] ? f[o + 1] : 256u; return ((uint64_t)le16(o + 6) << 32) | (ew * eh); };
+    uint32_t best = n - 1;
+    for (uint32_t i = 0; i + 1 < n; ++i) if (score(i) > score(best)) best = i;
+    const size_t eo = 6 + (size_t)best * 16, size = le32(eo + 8), at = le32(eo + 12);
+    if (at > f.size() || size > f.size() - at || size < 40) { err = "ICO entry outside the file"; return false; }
+    static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (!std::memcmp(&f[at], png_sig, 8)) { const std::vector<uint8_t> sub(f.begin() + (long)at, f.begin() + (long)(at + size)); return decode_png(sub, out, err); }
+    const uint32_t hdr = le32(at), w = le32(at + 4), h2 = le32(at + 8), bpp = le16(at + 14), comp = le32(at + 16), used = le32(at + 32);
+    const uint32_t h = h2 / 2;
+    if (hdr < 40 || comp != 0 || w == 0 || h == 0 || w > 256 || h > 256 || (bpp != 1 && bpp != 4 && bpp != 8 && bpp != 24 && bpp != 32)) { err = "unsupported ICO bitmap"; return false; }
+    const uint32_t n_pal = bpp <= 8 ? (used ? used : 1u << bpp) : 0u;
+    const size_t pal_at = at + hdr, xor_at = pal_at + (size_t)n_pal * 4, stride = ((size_t)w * bpp + 31) / 32 * 4, and_stride = ((size_t)w + 31) / 32 * 4, and_at = xor_at + stride * h;
+    if (n_pal > 256 || xor_at + stride * h > at + size) { err = "truncated ICO bitmap"; return false; }
+    const bool has_mask = and_at + and_stride * h <= at + size;
+    out.width = w; out.height = h;
+    out.px.assign((size_t)w * h * 4, 255);
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t* row = &f[xor_at + stride * (h - 1 - y)];
+        const uint8_t* mrow = has_mask ? &f[and_at + and_stride * (h - 1 - y)] : nullptr;
+        for (uint32_t x = 0; x < w; ++x) {
+            uint8_t* o = &out.px[((size_t)y * w + x) * 4];
+            if (bpp >= 24) { const uint8_t* p = row + (size_t)x * bpp / 8; o[0] = p[2]; o[1] = p[1]; o[2] = p[0]; o[3] = bpp == 32 ? p[3] : 255; }
+            else {
+                const size_t bit = (size_t)x * bpp;
+                const uint32_t idx = (row[bit / 8] >> (8 - bpp - bit % 8)) & ((1u << bpp) - 1u);
+                if (idx >= n_pal) { err = "ICO palette index out of range"; return false; }
+                const uint8_t* p = &f[pal_at + (size_t)idx * 4];
+                o[0] = p[2]; o[1] = p[1]; o[2] = p[0]; o[3] = 255;
+            }
+            if (mrow && (mrow[x / 8] >> (7 - x % 8) & 1)) o[3] = 0;
+        }
+    }
+    return true;
+}
+
 }  // namespace img_detail
 
 // image::open: the format is taken from the file's content
@@ -773,8 +1025,12 @@ inline bool load_image(const std::string& path, ImageRGBA8& out, std::string& er
     else if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') ok = img_detail::decode_bmp(f, out, err);
     else if (f.size() >= 3 && f[0] == 0xff && f[1] == 0xd8) ok = img_detail::decode_jpeg(f, out, err);
     else if (f.size() >= 6 && !std::memcmp(f.data(), "GIF8", 4)) ok = img_detail::decode_gif(f, out, err);
+    else if (f.size() >= 4 && ((f[0] == 'I' && f[1] == 'I' && f[2] == 42 && f[3] == 0) || (f[0] == 'M' && f[1] == 'M' && f[2] == 0 && f[3] == 42))) ok = img_detail::decode_tiff(f, out, err);
+    else if (f.size() >= 10 && (!std::memcmp(f.data(), "#?RADIANCE", 10) || !std::memcmp(f.data(), "#?RGBE", 6))) ok = img_detail::decode_hdr(f, out, err);
+    else if (f.size() >= 12 && !std::memcmp(f.data(), "RIFF", 4) && !std::memcmp(f.data() + 8, "WEBP", 4)) { ok = false; err = "WebP files are not supported (image 0.18 decodes their luma plane only)"; }
+    else if (dot != std::string::npos && (path.substr(dot) == ".ico" || path.substr(dot) == ".ICO")) ok = img_detail::decode_ico(f, out, err);
     else if (dot != std::string::npos && (path.substr(dot) == ".tga" || path.substr(dot) == ".TGA")) ok = img_detail::decode_tga(f, out, err);
-    else { ok = false; err = "unrecognised image format (PNG, JPEG, GIF, binary PPM / PGM, BMP and TGA are supported)"; }
+    else { ok = false; err = "unrecognised image format (PNG, JPEG, GIF, TIFF, Radiance HDR, ICO, binary PPM / PGM, BMP and TGA are supported)"; }
     if (!ok) err = path + ": " + err;   // (which file: a scene names dozens of textures)
     return ok;
 }
