@@ -36,8 +36,10 @@ def quad_trees(flat, bfs_levels=-1):
     return top, mesh, first, int(counts[3]), int(counts[4]), bool(narrow.value)
 
 
-def check_quad_tree(ref, recs, collapsed=True):
-    """ref: the reference's preorder array; recs: the quad records of the same tree, entry record first. Returns the number of records."""
+def check_quad_tree(ref, recs, collapsed=True, leaf_records=False):
+    """ref: the reference's preorder array; recs: the quad records of the same tree, entry record first. Returns the number of records.
+    leaf_records (BVH<Instance>, round 5): a leaf's slot refers to one more record that holds the leaf's primitives one per slot, in leaf order, each
+    behind a box of its own, visited in slot order whatever the direction (order word 0)."""
     n = len(ref)
     seen_nodes, seen_recs = set(), set()
     empty_lo, empty_hi = np.float32(np.inf), np.float32(np.inf)      # every plane at +inf: nothing enters
@@ -48,6 +50,19 @@ def check_quad_tree(ref, recs, collapsed=True):
         assert (rec["lo"][:, s] == ref[x]["bmin"]).all() and (rec["hi"][:, s] == ref[x]["bmax"]).all()
         d = int(rec["desc"][s])
         assert d >> 28 == 0
+        if ref[x]["count"] > 0 and leaf_records:
+            assert (d >> 23) == 0 and d < len(recs) and d not in seen_recs
+            seen_recs.add(d)
+            leaf = recs[d]
+            cnt, off = int(ref[x]["count"]), int(ref[x]["offset"])
+            assert 1 <= cnt <= 4 and int(leaf["meta"][0]) == 0 and int(leaf["meta"][1]) == 0
+            for k in range(4):
+                if k < cnt:
+                    assert int(leaf["desc"][k]) == (off + k) | (1 << 23)
+                    assert (leaf["lo"][:, k] <= leaf["hi"][:, k]).all()
+                else:
+                    slot_empty(leaf, k)
+            return None
         if ref[x]["count"] > 0:
             assert d == int(ref[x]["offset"]) | (int(ref[x]["count"]) << 23)
             return None
@@ -176,7 +191,7 @@ def test_quad_records_are_the_same_tree(tmp_path, bfs_levels):
         f = flat.contents
         top, mesh, first, top_pend, mesh_pend, narrow = quad_trees(flat, bfs_levels)
         assert narrow
-        assert check_quad_tree(as_array(f.top_nodes, f.n_top_nodes, REF), top) == len(top)
+        assert check_quad_tree(as_array(f.top_nodes, f.n_top_nodes, REF), top, leaf_records=True) == len(top)
         ref_meshes = as_array(f.meshes, f.n_meshes, MESH)
         ref_nodes = as_array(f.mesh_nodes, f.n_mesh_nodes, REF)
         assert len(first) == f.n_meshes

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -147,7 +148,12 @@ inline QuadNode quad_empty_record() {
 }
 // appends the quad records of the reference-order tree ref[0 .. n) (a tree: pair_tree has accepted it); the entry record is the
 // first one appended. Returns the largest number of node entries a traversal of this tree can have pending at once.
-inline uint32_t quad_tree(const TrayBvhNode* ref, uint32_t n, std::vector<QuadNode>& out, bool& narrow, bool& ordered, uint32_t bfs_levels = TRAY_QUAD_BFS_LEVELS) {
+// `prim_box` (BVH<Instance> only; [lo x y z, hi x y z] per ordered primitive, or null): a leaf becomes one more record whose slots are the leaf's
+// primitives, in leaf order, each behind a CONSERVATIVE box of its own (instance_gate_box) -- the reference enters every instance of a leaf it reaches
+// (bvh.rs:96-104), the ones whose box the ray misses cannot be hit, and skipping them here saves the traversal an instance entry each (record fetch, ray
+// transform, three divisions, the mesh's entry record). The leaf's own box stays in its parent's slot: the reference tests it.
+inline uint32_t quad_tree(const TrayBvhNode* ref, uint32_t n, std::vector<QuadNode>& out, bool& narrow, bool& ordered, uint32_t bfs_levels = TRAY_QUAD_BFS_LEVELS,
+                          const float (*prim_box)[6] = nullptr) {
     if (n == 0u) { out.push_back(quad_empty_record()); return 1u; }
     const size_t base = out.size();
     const uint32_t none = 0xffffffffu;
@@ -191,7 +197,19 @@ inline uint32_t quad_tree(const TrayBvhNode* ref, uint32_t n, std::vector<QuadNo
             const uint32_t x = slot_node[s];
             if (x == none) continue;
             uint32_t desc;
-            if (is_leaf(x)) {
+            if (is_leaf(x) && prim_box && ref[x].count <= 4u && ref[x].offset <= 0x7fffffu - 4u) {
+                const uint32_t r = alloc();   // the leaf's primitives, one slot each, visited in slot order whatever the ray's direction (order word 0)
+                if (r > 0x7fffffu) narrow = false;
+                desc = r & 0x7fffffu;
+                QuadNode& lq = out[base + r];
+                for (uint32_t k = 0; k < ref[x].count; ++k) {
+                    const float* b = prim_box[ref[x].offset + k];
+                    for (int a = 0; a < 3; ++a) { lq.lo[a][k] = b[a]; lq.hi[a][k] = b[3 + a]; if (!(b[a] <= b[3 + a])) ordered = false; }
+                    lq.desc[k] = (ref[x].offset + k) | (1u << 23);
+                }
+                lq.meta[0] = 0u; lq.meta[1] = 0u;
+                worst = std::max(worst, pend + ref[x].count - 1u);
+            } else if (is_leaf(x)) {
                 if (ref[x].offset > 0x7fffffu || ref[x].count > 31u) narrow = false;
                 desc = (ref[x].offset & 0x7fffffu) | ((uint32_t)std::min<uint32_t>(ref[x].count, 31u) << 23);
             } else {
@@ -237,9 +255,17 @@ inline uint32_t quad_tree(const TrayBvhNode* ref, uint32_t n, std::vector<QuadNo
     }
     return worst + 1u;
 }
+inline void instance_gate_box(const TrayFlatScene* f, const TrayInstance& in, float lo[3], float hi[3]);   // (below)
 inline void quad_trees(const TrayFlatScene* f, QuadTrees& q, bool top_only = false, uint32_t bfs_levels = TRAY_QUAD_BFS_LEVELS) {
     q.top.clear();
-    q.top_pend = quad_tree(f->top_nodes, f->n_top_nodes, q.top, q.narrow, q.ordered, bfs_levels);
+    std::vector<float> boxes((size_t)f->n_top_order * 6u, 0.0f);   // per BVH<Instance> leaf slot: the instance's conservative box (TRAYHIP_NO_INSTANCE_BOXES: leaves as the reference has them)
+    for (uint32_t k = 0; k < f->n_top_order; ++k) {
+        float* b = &boxes[(size_t)k * 6u];
+        if (f->top_order[k] < f->n_instances) instance_gate_box(f, f->instances[f->top_order[k]], b, b + 3);
+        else for (int a = 0; a < 3; ++a) { b[a] = -INFINITY; b[3 + a] = INFINITY; }
+    }
+    const bool per_instance = !getenv("TRAYHIP_NO_INSTANCE_BOXES") && f->n_top_order != 0u;
+    q.top_pend = quad_tree(f->top_nodes, f->n_top_nodes, q.top, q.narrow, q.ordered, bfs_levels, per_instance ? reinterpret_cast<const float (*)[6]>(boxes.data()) : nullptr);
     if (top_only) return;
     q.mesh.clear();
     q.mesh_first.assign(f->n_meshes, 0u);
@@ -287,6 +313,41 @@ inline void wf_inst_records(const TrayFlatScene* f, const std::vector<uint32_t>&
     }
 }
 
+// A conservative world-space box of an instance's geometry at this frame: the object-space bounds through `mat` in double precision, widened by
+// 1e-4 of the scene's scale (far above what f32 rounding of the ray transform and of the intersection tests can move a hit) -- a ray that misses it
+// cannot hit the instance. Infinite for an instance that moves within the frame and for a projective transform (no cull).
+inline void instance_gate_box(const TrayFlatScene* f, const TrayInstance& in, float lo[3], float hi[3]) {
+    // object-space bounds of the geometry
+    float olo[3] = {0, 0, 0}, ohi[3] = {0, 0, 0};
+    if (in.geom_type == TRAY_GEOM_RECT) { olo[0] = -0.5f * std::fabs(in.geom_params[0]); ohi[0] = -olo[0]; olo[1] = -0.5f * std::fabs(in.geom_params[1]); ohi[1] = -olo[1]; }
+    else if (in.geom_type == TRAY_GEOM_SPHERE) { for (int k = 0; k < 3; ++k) { olo[k] = -std::fabs(in.geom_params[0]); ohi[k] = std::fabs(in.geom_params[0]); } }
+    else if (in.geom_type == TRAY_GEOM_DISK) { for (int k = 0; k < 2; ++k) { olo[k] = -std::fabs(in.geom_params[0]); ohi[k] = std::fabs(in.geom_params[0]); } }
+    else if ((in.geom_type == TRAY_GEOM_MESH || in.geom_type == TRAY_GEOM_ANIMATED_MESH) && in.mesh_id < f->n_meshes && f->meshes[in.mesh_id].node_count) {   // (an AnimatedMesh: the root of its one tree -- nothing outside it is ever reached, quirk Q13)
+        const TrayBvhNode& root = f->mesh_nodes[f->meshes[in.mesh_id].node_offset];
+        for (int k = 0; k < 3; ++k) { olo[k] = root.bmin[k]; ohi[k] = root.bmax[k]; }
+    }
+    double wlo[3] = {INFINITY, INFINITY, INFINITY}, whi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool finite = true;
+    for (int c = 0; c < 8; ++c) {
+        const double p[3] = {(c & 1) ? ohi[0] : olo[0], (c & 2) ? ohi[1] : olo[1], (c & 4) ? ohi[2] : olo[2]};
+        for (int r = 0; r < 3; ++r) {
+            const double v = (double)in.mat[4 * r] * p[0] + (double)in.mat[4 * r + 1] * p[1] + (double)in.mat[4 * r + 2] * p[2] + (double)in.mat[4 * r + 3];
+            finite = finite && std::isfinite(v);
+            wlo[r] = std::min(wlo[r], v); whi[r] = std::max(whi[r], v);
+        }
+    }
+    // row 3 other than (0 0 0 1) would make the transform projective: no cull then; nor for an instance that moves within the frame
+    // (its own box would have to be its swept one; the gate that counts -- the BVH<Instance> leaf's box -- is the reference's either way)
+    finite = finite && in.mat[12] == 0.0f && in.mat[13] == 0.0f && in.mat[14] == 0.0f && in.mat[15] == 1.0f && !in.animated;
+    double scale = 0.0;
+    for (int r = 0; r < 3; ++r) scale = std::max({scale, std::fabs(wlo[r]), std::fabs(whi[r])});
+    const double margin = 1e-4 * scale + 1e-6;
+    for (int r = 0; r < 3; ++r) {
+        lo[r] = finite ? (float)(wlo[r] - margin) : -INFINITY;
+        hi[r] = finite ? (float)(whi[r] + margin) : INFINITY;
+    }
+}
+
 inline void flat_loop_gates(const TrayFlatScene* f, const PairedTrees& paired, uint32_t coop_max_tris, std::vector<FlatLeaf>& leaves, std::vector<FlatInst>& insts,
                             std::vector<uint8_t>& tri_leaf) {
     leaves.clear(); insts.clear();
@@ -306,35 +367,7 @@ inline void flat_loop_gates(const TrayFlatScene* f, const PairedTrees& paired, u
             std::memcpy(fi.inv, in.inv, sizeof fi.inv);
             fi.gp0 = in.geom_params[0]; fi.gp1 = in.geom_params[1];
             fi.geom_type = in.geom_type; fi.mesh_id = in.mesh_id; fi.inst = i; fi.animated = in.animated ? 1u : 0u;
-            // object-space bounds of the geometry
-            float olo[3] = {0, 0, 0}, ohi[3] = {0, 0, 0};
-            if (in.geom_type == TRAY_GEOM_RECT) { olo[0] = -0.5f * std::fabs(in.geom_params[0]); ohi[0] = -olo[0]; olo[1] = -0.5f * std::fabs(in.geom_params[1]); ohi[1] = -olo[1]; }
-            else if (in.geom_type == TRAY_GEOM_SPHERE) { for (int k = 0; k < 3; ++k) { olo[k] = -std::fabs(in.geom_params[0]); ohi[k] = std::fabs(in.geom_params[0]); } }
-            else if (in.geom_type == TRAY_GEOM_DISK) { for (int k = 0; k < 2; ++k) { olo[k] = -std::fabs(in.geom_params[0]); ohi[k] = std::fabs(in.geom_params[0]); } }
-            else if ((in.geom_type == TRAY_GEOM_MESH || in.geom_type == TRAY_GEOM_ANIMATED_MESH) && in.mesh_id < f->n_meshes && f->meshes[in.mesh_id].node_count) {   // (an AnimatedMesh: the root of its one tree -- nothing outside it is ever reached, quirk Q13)
-                const TrayBvhNode& root = f->mesh_nodes[f->meshes[in.mesh_id].node_offset];
-                for (int k = 0; k < 3; ++k) { olo[k] = root.bmin[k]; ohi[k] = root.bmax[k]; }
-            }
-            double wlo[3] = {INFINITY, INFINITY, INFINITY}, whi[3] = {-INFINITY, -INFINITY, -INFINITY};
-            bool finite = true;
-            for (int c = 0; c < 8; ++c) {
-                const double p[3] = {(c & 1) ? ohi[0] : olo[0], (c & 2) ? ohi[1] : olo[1], (c & 4) ? ohi[2] : olo[2]};
-                for (int r = 0; r < 3; ++r) {
-                    const double v = (double)in.mat[4 * r] * p[0] + (double)in.mat[4 * r + 1] * p[1] + (double)in.mat[4 * r + 2] * p[2] + (double)in.mat[4 * r + 3];
-                    finite = finite && std::isfinite(v);
-                    wlo[r] = std::min(wlo[r], v); whi[r] = std::max(whi[r], v);
-                }
-            }
-            // row 3 other than (0 0 0 1) would make the transform projective: no cull then; nor for an instance that moves within the frame
-            // (its own box would have to be its swept one; the gate that counts -- the BVH<Instance> leaf's box -- is the reference's either way)
-            finite = finite && in.mat[12] == 0.0f && in.mat[13] == 0.0f && in.mat[14] == 0.0f && in.mat[15] == 1.0f && !in.animated;
-            double scale = 0.0;
-            for (int r = 0; r < 3; ++r) scale = std::max({scale, std::fabs(wlo[r]), std::fabs(whi[r])});
-            const double margin = 1e-4 * scale + 1e-6;
-            for (int r = 0; r < 3; ++r) {
-                fi.lo[r] = finite ? (float)(wlo[r] - margin) : -INFINITY;
-                fi.hi[r] = finite ? (float)(whi[r] + margin) : INFINITY;
-            }
+            instance_gate_box(f, in, fi.lo, fi.hi);
             insts.push_back(fi);
         }
         lf.count = (uint32_t)insts.size() - lf.first;
