@@ -129,7 +129,11 @@ TR_DEV uint32_t xf_cache_lane() { return blockIdx.x * blockDim.x + threadIdx.x; 
 // path (C5 stand-in, frame 64: 186 -> 213 Msamples/s). The tile kernel keeps its per-thread cache columns (coalesced reads in the flat instance
 // loop; gathered 112-byte records there measured only +3.5 % on moving_box) and FILLS them from the table instead of evaluating. The host builds
 // the table for launches of enough samples (kernels.hip: xf_table_prepare), the per-path evaluation serves the others.
+#ifdef TR_XF_KIDX_MASK   // experiment (round 5, profiles/r05_xf_table_locality_ceiling.txt): every path reads one of a few table records -- WRONG pictures, the time a perfectly cache-resident table would give
+TR_DEV uint32_t xf_time_index(float t) { return (uint32_t)(t * 16777216.0f) & (uint32_t)(TR_XF_KIDX_MASK); }
+#else
 TR_DEV uint32_t xf_time_index(float t) { return (uint32_t)(t * 16777216.0f); }   // t = index / 2^24 exactly
+#endif
 TR_DEV float xf_index_time(uint32_t index) { return (float)index * (1.0f / 16777216.0f); }
 // start of a camera sample: evaluate every moving instance at the path's time into the path's cache column
 TR_DEV void xf_cache_fill(const DevScene& sc, float time, uint32_t lane) {
