@@ -244,6 +244,9 @@ TR_DEV uint32_t wf_next_segment(const uint32_t* __restrict__ qctl, uint32_t stag
 #ifndef WF_REFILL_MIN
 #define WF_REFILL_MIN 24
 #endif
+#ifndef WF_REFILL_MIN_B
+#define WF_REFILL_MIN_B WF_REFILL_MIN   // ... of the occlusion stage (its rays end at the first hit: measured apart, profiles/r05_c5_stage_b_thresholds.txt)
+#endif
 #ifndef WF_TRACE_WAVES
 #define WF_TRACE_WAVES 4   // waves per SIMD the traversal kernel is compiled for
 #endif
@@ -252,6 +255,9 @@ TR_DEV uint32_t wf_next_segment(const uint32_t* __restrict__ qctl, uint32_t stag
 #endif
 #ifndef WF_NODE_MIN
 #define WF_NODE_MIN 16     // ... as long as this many lanes still have node work (or nobody waits for the leaf / pop phase)
+#endif
+#ifndef WF_NODE_MIN_B
+#define WF_NODE_MIN_B WF_NODE_MIN
 #endif
 // Control words 16 + STAGE of segment 0: rays of the stage handed to k_wf_trace_fallback (below); their slots are listed in `fallback`.
 #define WF_FB_WORD 16u
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
         if (!exhausted) {
             const unsigned long long idle = __ballot(!active);
             const uint32_t n_idle = (uint32_t)__popcll(idle);
-            if (n_idle >= WF_REFILL_MIN || n_idle == (uint32_t)__popcll(__ballot(1))) {
+            if (n_idle >= (STAGE == 1 ? WF_REFILL_MIN_B : WF_REFILL_MIN) || n_idle == (uint32_t)__popcll(__ballot(1))) {
                 const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
                 uint32_t base = 0u;
                 if (lane == leader) base = atomicAdd(qctl + seg * WF_SEG_STRIDE + 3u + STAGE, n_idle);
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
             const bool in_node = active && mode == TM_NODE;
             const uint32_t n_node = (uint32_t)__popcll(__ballot(in_node));
             if (n_node == 0u) break;
-            if (it > 0 && n_node < WF_NODE_MIN && __any(active && mode != TM_NODE)) break;
+            if (it > 0 && n_node < (STAGE == 1 ? WF_NODE_MIN_B : WF_NODE_MIN) && __any(active && mode != TM_NODE)) break;
             if (in_node) {
                 WF_COUNT(c_iter);
                 // the record's planes are fetched as the ray meets them: per axis the plane it enters through and the one it leaves through
