@@ -71,7 +71,7 @@ enum {
     F_COUNT
 };
 #define WF_HIT_WORDS 8
-static_assert(F_O == 8 && F_T == 16 && F_P == 24 && F_SOA == 44, "record groups of the pool: 8 + 8 + 8 + 20 words");
+static_assert(F_O == 8 && F_T == 16 && F_P == 24 && F_SOA == 44, "record groups of the pool: 8 (hit) + 16 (ray | throughput: one 64-byte record, pidx) + 20 (vertex) words");
 
 struct WfPool {
     float* __restrict__ data;   // F_COUNT * n_slots dwords
@@ -86,10 +86,17 @@ enum : uint32_t { WF_TILE_NEED = 0xfffffffeu, WF_TILE_IDLE = 0xffffffffu };
 // (f is a constant at every call site: the layout test folds)
 TR_DEV size_t pidx(const WfPool& p, int f, uint32_t i) {
     const size_t n = p.n_slots, k = (size_t)i + p.first;
+#ifdef WF_SPLIT_RAY_THRU   // (the layout up to cycle f of round 5: the ray and the throughput group as 32-byte records of their own)
     return f < F_O ? k * 8u + (size_t)f
          : f < F_T ? (size_t)F_O * n + k * 8u + (size_t)(f - F_O)
          : f < F_P ? (size_t)F_T * n + k * 8u + (size_t)(f - F_T)
          : f < F_SOA ? (size_t)F_P * n + k * 20u + (size_t)(f - F_P)
+#else
+    // the ray and the throughput group side by side in ONE 64-byte record: k_wf_begin and the query kernels read both, and a 32-byte record costs a 64-byte fetch
+    return f < F_O ? k * 8u + (size_t)f
+         : f < F_P ? (size_t)F_O * n + k * 16u + (size_t)(f - F_O)
+         : f < F_SOA ? (size_t)F_P * n + k * 20u + (size_t)(f - F_P)
+#endif
          : (size_t)f * n + k;
 }
 TR_DEV float& pf(const WfPool& p, int f, uint32_t i) { return p.data[pidx(p, f, i)]; }
