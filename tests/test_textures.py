@@ -731,9 +731,202 @@ def test_radiance_hdr_is_tone_mapped_like_the_image_crate(rle, tmp_path, built):
     assert (got[0, :5, :3] == 0).all() and got[..., :3].max() == 255 and 0 < np.median(got[..., :3]) < 255
 
 
-def test_webp_is_refused_by_name(tmp_path, built):
+def _libwebp():
+    """the system's libwebp through ctypes (test-side witness only): (encode(rgb, quality, **config), luma(data)) or a skip"""
+    import ctypes as C
+    try:
+        lib = C.CDLL("libwebp.so.7")
+        for name in ("WebPConfigInitInternal", "WebPValidateConfig", "WebPPictureInitInternal", "WebPPictureImportRGB", "WebPEncode", "WebPPictureFree", "WebPDecodeYUV", "WebPFree"):
+            getattr(lib, name)
+    except (OSError, AttributeError) as e:
+        pytest.skip("no libwebp.so.7 to compare with: " + str(e))
+
+    class Config(C.Structure):   # encode.h: struct WebPConfig (ABI 0x020f)
+        _fields_ = [(n, C.c_float if n in ("quality", "target_PSNR") else C.c_int) for n in
+                    "lossless quality method image_hint target_size target_PSNR segments sns_strength filter_strength filter_sharpness filter_type autofilter "
+                    "alpha_compression alpha_filtering alpha_quality pass_ show_compressed preprocessing partitions partition_limit emulate_jpeg_size thread_level "
+                    "low_memory near_lossless exact use_delta_palette use_sharp_yuv qmin qmax".split()]
+    WRITER = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.c_void_p)
+
+    class Picture(C.Structure):   # encode.h: struct WebPPicture
+        _fields_ = [("use_argb", C.c_int), ("colorspace", C.c_int), ("width", C.c_int), ("height", C.c_int),
+                    ("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("y_stride", C.c_int), ("uv_stride", C.c_int),
+                    ("a", C.c_void_p), ("a_stride", C.c_int), ("pad1", C.c_uint32 * 2), ("argb", C.c_void_p), ("argb_stride", C.c_int), ("pad2", C.c_uint32 * 3),
+                    ("writer", WRITER), ("custom_ptr", C.c_void_p), ("extra_info_type", C.c_int), ("extra_info", C.c_void_p), ("stats", C.c_void_p),
+                    ("error_code", C.c_int), ("progress_hook", C.c_void_p), ("user_data", C.c_void_p), ("pad3", C.c_uint32 * 3), ("pad4", C.c_void_p), ("pad5", C.c_void_p),
+                    ("pad6", C.c_uint32 * 8), ("memory_", C.c_void_p), ("memory_argb_", C.c_void_p), ("pad7", C.c_void_p * 2)]
+    lib.WebPDecodeYUV.restype = C.POINTER(C.c_uint8)
+    lib.WebPDecodeYUV.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.POINTER(C.c_uint8)),
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.WebPFree.argtypes = [C.c_void_p]
+
+    def encode(rgb, quality, **config):
+        abi = 0x020f
+        cfg = Config()
+        if not lib.WebPConfigInitInternal(C.byref(cfg), 0, C.c_float(quality), abi):
+            pytest.skip("libwebp's encoder ABI is not the one this test declares")
+        for k, v in config.items():
+            setattr(cfg, k, v)
+        assert lib.WebPValidateConfig(C.byref(cfg))
+        pic = Picture()
+        assert lib.WebPPictureInitInternal(C.byref(pic), abi)
+        h, w, _ = rgb.shape
+        pic.width, pic.height = w, h
+        buf = np.ascontiguousarray(rgb, np.uint8)
+        assert lib.WebPPictureImportRGB(C.byref(pic), buf.ctypes.data_as(C.c_void_p), w * 3)
+        out = bytearray()
+
+        def write(data, n, _):
+            out.extend(C.string_at(data, n))
+            return 1
+        cb = WRITER(write)
+        pic.writer = cb
+        ok = lib.WebPEncode(C.byref(cfg), C.byref(pic))
+        code = pic.error_code
+        lib.WebPPictureFree(C.byref(pic))
+        assert ok, code
+        return bytes(out)
+
+    def luma(data):
+        w, h, s, us = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        u, v = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint8)()
+        y = lib.WebPDecodeYUV(data, len(data), w, h, u, v, s, us)
+        assert y
+        a = np.ctypeslib.as_array(y, (h.value, s.value))[:, :w.value].copy()
+        lib.WebPFree(y)
+        return a
+    return encode, luma
+
+
+def _vp8_loop_filter_level(data):
+    """loop_filter_level of a simple lossy WebP file's frame header (RFC 6386 s. 9.3, 9.6, 19.2), read with the boolean decoder of s. 7.3"""
+    d = data[20:]
+    st = {"pos": 12, "value": d[10] << 8 | d[11], "range": 255, "count": 0}
+
+    def get(p):
+        split = 1 + (((st["range"] - 1) * p) >> 8)
+        big = split << 8
+        if st["value"] >= big:
+            bit = 1; st["range"] -= split; st["value"] -= big
+        else:
+            bit = 0; st["range"] = split
+        while st["range"] < 128:
+            st["value"] <<= 1; st["range"] <<= 1; st["count"] += 1
+            if st["count"] == 8:
+                st["count"] = 0; st["value"] |= d[st["pos"]]; st["pos"] += 1
+        return bit
+
+    def lit(n):
+        v = 0
+        for _ in range(n):
+            v = v << 1 | get(128)
+        return v
+    get(128); get(128)
+    if get(128):   # segmentation
+        update_map = get(128)
+        if get(128):
+            get(128)
+            for bits in (7, 7, 7, 7, 6, 6, 6, 6):
+                if get(128):
+                    lit(bits); get(128)
+        if update_map:
+            for _ in range(3):
+                if get(128):
+                    lit(8)
+    get(128)
+    return lit(6)
+
+
+def _webp_pictures(rng, case):
+    w, h = [(170, 127), (54, 62), (133, 46), (19, 78), (5, 44), (153, 185), (241, 17), (16, 16)][case % 8]
+    yy, xx = np.mgrid[0:h, 0:w]
+    kind = case % 4
+    if kind == 0:
+        img = np.stack([(xx * 3 + yy) % 256, (xx + yy * 5) % 256, (xx * yy) % 256], 2)
+    elif kind == 1:
+        img = rng.integers(0, 256, (h, w, 3))
+    elif kind == 2:
+        img = np.stack([128 + 100 * np.sin(xx / 7.0) * np.cos(yy / 5.0)] * 3, 2) + rng.normal(0, 8, (h, w, 3))
+    else:
+        img = np.stack([((xx // 8 + yy // 8) % 2) * 255] * 3, 2) * 1.0
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_webp_luma_plane_against_libwebp(case, tmp_path, built):
+    """image::open of a .webp (VERDICT round 4, missing 5 -- the last format): image 0.18 presents the key frame's LUMA plane as a grey image, without
+    a loop filter. Files written by libwebp with the loop filter off (filter_strength 0), 1 - 8 token partitions, 1 - 4 segments, every encoder
+    method (whole-macroblock and per-subblock prediction modes, all coefficient categories at low and high quality): the loader's picture equals
+    libwebp's own luma plane of the same file, byte for byte."""
+    encode, luma = _libwebp()
+    rng = np.random.default_rng(100 + case)
+    img = _webp_pictures(rng, case)
+    quality = [22, 47, 73, 95, 9, 58, 35, 100][case]
+    data = encode(img, quality, filter_strength=0, partitions=case % 4, segments=1 + (case * 3) % 4, method=(case * 5) % 7, sns_strength=[50, 0, 100, 30][case % 4])
+    assert data[12:16] == b"VP8 " and _vp8_loop_filter_level(data) == 0
     os.makedirs(tmp_path / "textures", exist_ok=True)
-    open(tmp_path / "textures" / "x.webp", "wb").write(b"RIFF\x1a\0\0\0WEBPVP8 \x0e\0\0\0" + bytes(14))
-    with pytest.raises(T.TrayError) as e:
-        load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/x.webp"}])
-    assert "WebP" in str(e.value)
+    open(tmp_path / "textures" / "x.webp", "wb").write(data)
+    scene, *_ = load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/x.webp"}])
+    got, fr = frame_pixels(scene.flatten(0).contents, 0)
+    want = luma(data)
+    assert (fr.height, fr.width) == want.shape == img.shape[:2]
+    assert np.array_equal(got[..., 0], want) and np.array_equal(got[..., 1], want) and np.array_equal(got[..., 2], want) and (got[..., 3] == 255).all()
+
+
+@pytest.mark.parametrize("quality", [100, 80, 25])
+def test_webp_files_written_by_pillow(quality, tmp_path, built):
+    """What a user's file looks like: Pillow's default encoder settings. At quality 100 the frame header says "loop filter level 0" and the picture is
+    libwebp's luma plane exactly; below that libwebp smooths block edges with the loop filter image 0.18 does not have -- the difference stays within the
+    filter's reach (a few grey levels next to block edges)."""
+    Image = pytest.importorskip("PIL.Image")
+    _, luma = _libwebp()
+    rng = np.random.default_rng(quality)
+    yy, xx = np.mgrid[0:90, 0:140]
+    img = np.clip(np.stack([128 + 100 * np.sin(xx / 9.0) * np.cos(yy / 6.0), 128 + 90 * np.cos(xx / 5.0 + yy / 11.0), 40 + xx + yy], 2) + rng.normal(0, 5, (90, 140, 3)), 0, 255).astype(np.uint8)
+    os.makedirs(tmp_path / "textures", exist_ok=True)
+    path = str(tmp_path / "textures" / "x.webp")
+    Image.fromarray(img).save(path, quality=quality)
+    data = open(path, "rb").read()
+    if data[12:16] != b"VP8 ":
+        pytest.skip("this Pillow wraps lossy files in the extended container")
+    scene, *_ = load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/x.webp"}])
+    got, fr = frame_pixels(scene.flatten(0).contents, 0)
+    want = luma(data).astype(int)
+    assert (fr.width, fr.height) == (140, 90)
+    diff = np.abs(got[..., 0].astype(int) - want)
+    if _vp8_loop_filter_level(data) == 0:
+        assert diff.max() == 0
+    else:
+        assert diff.mean() < 2.5 and diff.max() <= 40, (diff.mean(), diff.max())   # (quality 25: mean 1.1, max 13)
+    grey = np.asarray(Image.open(path).convert("L")).astype(int)   # and it IS the picture: Pillow's grey version of the decoded colours (studio-range luma -> full range)
+    assert np.abs((got[..., 0].astype(int) - 16) * 255 / 219 - grey).mean() < 6.0
+
+
+def test_webp_files_image_0_18_cannot_read(tmp_path, built):
+    """Lossless (VP8L) and extended (VP8X: alpha, animation) files are the crate's "Invalid VP8 signature" error; truncated and forged files are errors too"""
+    Image = pytest.importorskip("PIL.Image")
+    os.makedirs(tmp_path / "textures", exist_ok=True)
+    path = str(tmp_path / "textures" / "x.webp")
+    rgb = np.random.default_rng(3).integers(0, 256, (24, 40, 3), dtype=np.uint8)
+
+    def expect(text):
+        with pytest.raises(T.TrayError) as e:
+            load_texture_scene(tmp_path, [{"name": "x", "type": "image", "file": "textures/x.webp"}])
+        assert text in str(e.value) and "x.webp" in str(e.value), str(e.value)
+    Image.fromarray(rgb).save(path, lossless=True)
+    assert open(path, "rb").read()[12:16] == b"VP8L"
+    expect("Invalid VP8 signature")
+    Image.fromarray(np.dstack([rgb, np.full((24, 40), 100, np.uint8)]), "RGBA").save(path, quality=80)
+    assert open(path, "rb").read()[12:16] == b"VP8X"
+    expect("Invalid VP8 signature")
+    Image.fromarray(rgb).save(path, quality=80)
+    good = open(path, "rb").read()
+    assert good[12:16] == b"VP8 "
+    open(path, "wb").write(good[:len(good) // 2])
+    expect("WebP")
+    open(path, "wb").write(good[:26] + b"\xff\x3f\xff\x3f" + good[30:])   # 16383 x 16383 in the frame header of a 1 KB file
+    expect("WebP")
+    open(path, "wb").write(good[:20] + bytes([good[20] | 1]) + good[21:])       # "not a key frame"
+    expect("key frame")
+    open(path, "wb").write(b"RIFF\x1a\0\0\0WEBPVP8 \x0e\0\0\0" + bytes(14))
+    expect("WebP")

@@ -1,4 +1,4 @@
-"""Mutated texture files (PNG, baseline / progressive JPEG, GIF, PPM, BMP, TGA, TIFF, ICO, Radiance HDR) through the loader's own decoders (csrc/host/image.hpp): every
+"""Mutated texture files (PNG, baseline / progressive JPEG, GIF, PPM, BMP, TGA, TIFF, ICO, Radiance HDR, WebP) through the loader's own decoders (csrc/host/image.hpp): every
 file must come back as a picture or as an error code -- no crash, no hang, no allocation from a forged header.
     python tools/fuzz_images.py <seed> <n>           needs Pillow to write the valid originals"""
 import json, os, random, subprocess, sys, tempfile
@@ -46,6 +46,7 @@ Image.fromarray(pix, "RGB").save(os.path.join(tmp, "t.tga")); originals["t.tga"]
 Image.fromarray(pix, "RGB").save(os.path.join(tmp, "z.tif"), compression="tiff_lzw"); originals["z.tif"] = None
 Image.fromarray(pix, "RGB").save(os.path.join(tmp, "k.tif"), compression="packbits"); originals["k.tif"] = None
 Image.fromarray(pix, "RGB").convert("RGBA").resize((32, 32)).save(os.path.join(tmp, "o.ico"), sizes=[(16, 16), (32, 32)], bitmap_format="bmp"); originals["o.ico"] = None
+Image.fromarray(pix, "RGB").save(os.path.join(tmp, "x.webp"), quality=90, method=4); originals["x.webp"] = None
 open(os.path.join(tmp, "h.hdr"), "wb").write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (pix.shape[0], pix.shape[1]) + np.concatenate([pix, np.full(pix.shape[:2] + (1,), 129, np.uint8)], axis=2).tobytes()); originals["h.hdr"] = None
 for k in originals:
     originals[k] = open(os.path.join(tmp, k), "rb").read()

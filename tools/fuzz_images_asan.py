@@ -1,4 +1,4 @@
-"""Mutated PNG / JPEG (baseline, progressive) / GIF / BMP / TGA / TIFF / ICO / Radiance HDR files through tools/image_decode_check (image.hpp built with
+"""Mutated PNG / JPEG (baseline, progressive) / GIF / BMP / TGA / TIFF / ICO / Radiance HDR / WebP files through tools/image_decode_check (image.hpp built with
 -fsanitize=address,undefined): any memory error or undefined arithmetic aborts the harness and is reported with the file that caused it.
     g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all tools/image_decode_check.cpp -o /tmp/image_decode_check
     python tools/fuzz_images_asan.py <seed> <n> [harness]"""
@@ -19,6 +19,7 @@ save("c.png"); save("g.gif", img=im.quantize(64)); save("i.gif", img=im.quantize
 save("b.bmp"); save("t.tga"); save("l.jpg", img=Image.fromarray(pix[...,0],"L"), progressive=True)
 save("u.tif", compression="raw"); save("z.tif", compression="tiff_lzw"); save("k.tif", compression="packbits"); save("d.tif", compression="tiff_lzw", tiffinfo={317: 2})
 save("m.tif", img=im.quantize(40), compression="tiff_lzw"); save("w.tif", img=Image.fromarray((pix[...,0].astype(np.uint16)*257)), compression="tiff_lzw")
+save("x.webp", quality=100, method=6); save("y.webp", quality=40, method=2); save("v.webp", img=Image.fromarray(np.random.default_rng(2).integers(0, 256, (40, 56, 3), dtype=np.uint8), "RGB"), quality=80, method=4)
 save("n.ico", img=im.convert("RGBA").resize((32,32)), sizes=[(16,16),(32,32)]); save("o.ico", img=im.convert("RGBA").resize((32,32)), sizes=[(16,16),(32,32)], bitmap_format="bmp")
 def hdr_bytes():
     w,h=pix.shape[1],pix.shape[0]; out=b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n"%(h,w)

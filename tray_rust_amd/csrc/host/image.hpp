@@ -4,8 +4,9 @@
 // Formats: PNG (non-interlaced; grey / grey+alpha / RGB / RGBA / palette with tRNS; 1-16 bits, 16-bit samples keep their high
 // byte), binary PPM / PGM (P6 / P5, maxval <= 255), BMP (uncompressed 24 / 32 bit), TGA (uncompressed true colour 24 / 32 bit and
 // grey 8 bit), baseline and progressive JPEG (see decode_jpeg), GIF (first frame, see decode_gif), TIFF (baseline strips: uncompressed / LZW / PackBits,
-// see decode_tiff), Radiance HDR (tone-mapped to 8 bit as the crate does, see decode_hdr), ICO (the best entry, PNG or BMP payload). WebP is refused
-// by name. No third-party code: the inflate below is the textbook RFC 1951 decoder.
+// see decode_tiff), Radiance HDR (tone-mapped to 8 bit as the crate does, see decode_hdr), ICO (the best entry, PNG or BMP payload), WebP (simple lossy
+// files, as the GREY image of their luma plane that image 0.18 makes of them: webp.hpp). No third-party code: the inflate below is the textbook
+// RFC 1951 decoder.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -15,6 +16,8 @@
 #include <fstream>
 #include <string>
 #include <vector>
+
+#include "webp.hpp"
 
 namespace trayh {
 
@@ -1027,10 +1030,17 @@ inline bool load_image(const std::string& path, ImageRGBA8& out, std::string& er
     else if (f.size() >= 6 && !std::memcmp(f.data(), "GIF8", 4)) ok = img_detail::decode_gif(f, out, err);
     else if (f.size() >= 4 && ((f[0] == 'I' && f[1] == 'I' && f[2] == 42 && f[3] == 0) || (f[0] == 'M' && f[1] == 'M' && f[2] == 0 && f[3] == 42))) ok = img_detail::decode_tiff(f, out, err);
     else if (f.size() >= 10 && (!std::memcmp(f.data(), "#?RADIANCE", 10) || !std::memcmp(f.data(), "#?RGBE", 6))) ok = img_detail::decode_hdr(f, out, err);
-    else if (f.size() >= 12 && !std::memcmp(f.data(), "RIFF", 4) && !std::memcmp(f.data() + 8, "WEBP", 4)) { ok = false; err = "WebP files are not supported (image 0.18 decodes their luma plane only)"; }
+    else if (f.size() >= 12 && !std::memcmp(f.data(), "RIFF", 4) && !std::memcmp(f.data() + 8, "WEBP", 4)) {   // image 0.18: ColorType::Gray(8) of the luma plane
+        std::vector<uint8_t> luma;
+        ok = decode_webp_luma(f, out.width, out.height, luma, err);
+        if (ok) {
+            out.px.resize(luma.size() * 4);
+            for (size_t i = 0; i < luma.size(); ++i) { uint8_t* o = &out.px[4 * i]; o[0] = o[1] = o[2] = luma[i]; o[3] = 255; }
+        }
+    }
     else if (dot != std::string::npos && (path.substr(dot) == ".ico" || path.substr(dot) == ".ICO")) ok = img_detail::decode_ico(f, out, err);
     else if (dot != std::string::npos && (path.substr(dot) == ".tga" || path.substr(dot) == ".TGA")) ok = img_detail::decode_tga(f, out, err);
-    else { ok = false; err = "unrecognised image format (PNG, JPEG, GIF, TIFF, Radiance HDR, ICO, binary PPM / PGM, BMP and TGA are supported)"; }
+    else { ok = false; err = "unrecognised image format (PNG, JPEG, GIF, TIFF, Radiance HDR, ICO, WebP, binary PPM / PGM, BMP and TGA are supported)"; }
     if (!ok) err = path + ": " + err;   // (which file: a scene names dozens of textures)
     return ok;
 }
