@@ -1,6 +1,10 @@
 // TEST INFRASTRUCTURE ONLY: the device source of libtrayhip.so compiled for the host (hip_emu.h) and driven one thread at a
 // time. Entry points mirror what the library does around the same kernels (scene upload, pool fields, queues, launch geometry).
 #include "hip_emu.h"
+#ifdef TR_COOP_HIST   // tools/coop_histogram.py: [rays staged][lanes that asked] of every cooperative small-mesh test (dev_geom.h: mesh_leaf_coop)
+namespace tr { unsigned long long tr_coop_hist[65 * 65]; }
+extern "C" unsigned long long* emu_coop_hist(void) { return tr::tr_coop_hist; }
+#endif
 
 #ifdef TR_EMU_PROFILE   // divergence profile: see hip_emu.h; block barriers are ignored (they separate tiles, not stages)
 #include <dlfcn.h>
@@ -59,6 +63,14 @@ NOINSTR int emu_profile_dump(const char* path) {
         std::fprintf(f, "%llu %llu %llu %llu %s\n", (unsigned long long)kv.second.lane_calls, (unsigned long long)kv.second.wave_calls,
                      (unsigned long long)kv.second.lanes, (unsigned long long)kv.second.segments, name);
     }
+    if (std::getenv("TR_PROFILE_PHASES"))   // the same rows per phase (TR_EMU_PHASE: the query passes LIGHT = 1, MIS = 2, PATH = 3; 0 = everything else), name suffixed "@phase"
+        for (auto& kv : p.total) {
+            Dl_info info;
+            void* fn = reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(kv.first) >> 3);
+            const char* name = (dladdr(fn, &info) && info.dli_sname) ? info.dli_sname : "?";
+            std::fprintf(f, "%llu %llu %llu %llu %s@%u\n", (unsigned long long)kv.second.lane_calls, (unsigned long long)kv.second.wave_calls,
+                         (unsigned long long)kv.second.lanes, (unsigned long long)kv.second.segments, name, (unsigned)(reinterpret_cast<uintptr_t>(kv.first) & 7u));
+        }
     std::fclose(f);
     return (int)by_fn.size();
 }

@@ -28,6 +28,7 @@ ap.add_argument("--wavefront", action="store_true", help="profile the wavefront 
 ap.add_argument("--define", action="append", default=[])
 ap.add_argument("--size", default="48x32x16")
 ap.add_argument("--top", type=int, default=32)
+ap.add_argument("--tiles", type=int, default=0, help="render only this many tiles, spread evenly over the Morton queue (a 1920x1080 film's tiles see coherent camera rays: what the bench runs)")
 ap.add_argument("--min-bytes", type=int, default=250, help="hide helpers smaller than this (vector operators: their call overhead is not device work)")
 args = ap.parse_args()
 w, h, spp = (int(x) for x in args.size.split("x"))
@@ -52,6 +53,8 @@ if args.scene == "dragon":
 scene, *_ = T.Scene.load_file(os.path.join(d, args.scene + ".json"))
 flat = scene.flatten(0)
 tiles = np.array(T.BlockQueue((w, h), (8, 8)).blocks, np.uint32).reshape(-1, 2)
+if args.tiles:
+    tiles = np.ascontiguousarray(tiles[(np.arange(args.tiles) * 2 + 1) * len(tiles) // (2 * args.tiles)])
 img = np.zeros((h, w, 4), np.float32)
 stats = np.zeros(4, np.uint64)
 lib.emu_profile_start()
@@ -70,8 +73,12 @@ for line in subprocess.run(["nm", "-S", "--defined-only", so], capture_output=Tr
     if len(f) == 4:
         sizes[f[3]] = int(f[1], 16)
 rows = []
+phase_rows = []
 for line in open(dump):
     lane_calls, wave_calls, lanes, segments, name = line.split()
+    if "@" in name:
+        phase_rows.append((name, int(lane_calls), int(wave_calls)))
+        continue
     rows.append((name, int(lane_calls), int(wave_calls), sizes.get(name, 0)))
 names = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.splitlines()
 rows = [r for r in rows]
@@ -87,3 +94,11 @@ for i in order[:args.top]:
     name, lane_calls, wave_calls, size = rows[i]
     short = names[i].split("(")[0].replace("tr::", "")
     print(f"{100 * wave_calls * size / total:5.1f}% {wave_calls / steps:16.2f} {100 * lane_calls / (64 * wave_calls):5.0f}% {size:6d}  {short}")
+
+if phase_rows:   # TR_PROFILE_PHASES=1: the query passes one by one (1 = LIGHT, 2 = MIS, 3 = PATH)
+    pn = subprocess.run(["c++filt"], input="\n".join(r[0].split("@")[0] for r in phase_rows), capture_output=True, text=True).stdout.splitlines()
+    print("per query pass (phase 1 = LIGHT, 2 = MIS, 3 = PATH):")
+    for (name, lane_calls, wave_calls), dn in sorted(zip(phase_rows, pn), key=lambda x: (x[1], x[0][0])):
+        ph = name.split("@")[1]
+        if ph != "0" and sizes.get(name.split("@")[0], 0) >= args.min_bytes:
+            print(f"  pass {ph}  {wave_calls / steps:8.2f} wave calls/step  {100 * lane_calls / (64 * max(wave_calls, 1)):5.0f}% lanes  {dn.split('(')[0].replace('tr::', '')}")

@@ -582,6 +582,16 @@ TR_DEV float quad_xor(float v, int step) {
     return __int_as_float(step == 1 ? __builtin_amdgcn_mov_dpp(i, 0xB1, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(i, 0x4E, 0xf, 0xf, true));
 #endif
 }
+// value of lane (l ^ 7) (wide == 8: DPP row_half_mirror, lane i of an aligned group of eight <-> lane 7 - i) or of lane (l ^ 15) (wide == 16: row_mirror):
+// once the four lanes of every quad agree, these pair quad with quad and half-row with half-row
+TR_DEV float row_xor(float v, int wide) {
+#ifdef TR_HOST_EMU
+    return __shfl_xor(v, wide - 1);
+#else
+    const int i = __float_as_int(v);
+    return __int_as_float(wide == 8 ? __builtin_amdgcn_mov_dpp(i, 0x141, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(i, 0x140, 0xf, 0xf, true));
+#endif
+}
 TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, LdsF w_lds, bool participate, f3 o, f3 d, float min_t,
                            float gate_max_t, float accept_max_t, float& t_out, uint32_t& prim, float& b1, float& b2, float& leaf_tmin, bool& hazard) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -597,6 +607,9 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, LdsF w_lds, boo
     if (mask == 0ull) return false;
     const uint32_t n = (uint32_t)__popcll(mask);
     const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+#if defined(TR_HOST_EMU) && defined(TR_COOP_HIST)   // tools/coop_histogram.py: how many rays of a wave reach a small mesh's triangles, how many lanes asked
+    { extern unsigned long long tr_coop_hist[65 * 65]; const uint32_t asked = (uint32_t)__popcll(__ballot(participate)); if (lane == (uint32_t)__ffsll((long long)mask) - 1u) tr_coop_hist[n * 65 + asked]++; }
+#endif
     if (need) {
         w_lds[0 * 64 + rank] = o.x; w_lds[1 * 64 + rank] = o.y; w_lds[2 * 64 + rank] = o.z;
         w_lds[3 * 64 + rank] = d.x; w_lds[4 * 64 + rank] = d.y; w_lds[5 * 64 + rank] = d.z;
@@ -604,9 +617,19 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, LdsF w_lds, boo
         w_lds[8 * 64 + rank] = -1.0f;   // no candidate yet
     }
     TR_WAVE_SYNC();
-    const uint32_t per = (T + 3u) >> 2, g = lane & 3u;
-    for (uint32_t base = 0; base < n; base += 16u) {
-        const uint32_t r = base + (lane >> 2);
+    // Lanes per ray by the number of staged rays (wave-uniform): a wave of incoherent paths stages 5 rays on average, four or fewer in 61 % of the
+    // calls and eight or fewer in 88 % (tools/coop_histogram.py, cornell_box at 1080p) -- with four lanes per ray such a call runs ceil(T / 4)
+    // triangle tests in sequence on a quarter of the wave. Sixteen lanes per ray (n <= 4) test a cube's twelve triangles at once, eight (n <= 8) in two
+    // rounds. The result is the same set function of the ray's valid triangles whatever the width: the minimal t with its triangle, and the smallest
+    // other t (c2); between equal t's the choice differs, and a tie sets `hazard` (c2 == t) either way.
+#ifdef TR_COOP_QUADS_ONLY
+    const uint32_t lsh = 2u;
+#else
+    const uint32_t lsh = n <= 4u ? 4u : n <= 8u ? 3u : 2u;
+#endif
+    const uint32_t lpr = 1u << lsh, per = (T + lpr - 1u) >> lsh, g = lane & (lpr - 1u);
+    for (uint32_t base = 0; base < n; base += 64u >> lsh) {
+        const uint32_t r = base + (lane >> lsh);
         // best candidate of this lane's quarter and the smallest t among its other candidates
         float ct = 0.0f, cb1 = 0.0f, cb2 = 0.0f, ck = -1.0f, c2 = TR_INF;
         if (r < n) {
@@ -624,7 +647,7 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, LdsF w_lds, boo
                 }
             }
         }
-        // quad reduction (all four lanes of a quad are active together)
+        // reduction over the ray's lanes: inside the quads first (all lanes of an aligned group of `lpr` are active together), then quad with quad
 #pragma unroll
         for (int step = 1; step <= 2; step <<= 1) {
             const float ot = quad_xor(ct, step), ok = quad_xor(ck, step), ob1 = quad_xor(cb1, step), ob2 = quad_xor(cb2, step),
@@ -635,6 +658,20 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, LdsF w_lds, boo
             if (both) c2 = fminf(c2, take ? ct : ot);   // the loser of the two bests is the other side's closest rival
             if (take) { ct = ot; ck = ok; cb1 = ob1; cb2 = ob2; }
         }
+#ifndef TR_COOP_QUADS_ONLY
+        if (lsh >= 3u) {
+#pragma unroll
+            for (int wide = 8; wide <= 16; wide <<= 1) {
+                if (wide == 16 && lsh < 4u) break;
+                const float ot = row_xor(ct, wide), ok = row_xor(ck, wide), ob1 = row_xor(cb1, wide), ob2 = row_xor(cb2, wide), o2 = row_xor(c2, wide);
+                const bool both = ok >= 0.0f && ck >= 0.0f;
+                const bool take = ok >= 0.0f && (ck < 0.0f || ot < ct);
+                c2 = fminf(c2, o2);
+                if (both) c2 = fminf(c2, take ? ct : ot);
+                if (take) { ct = ot; ck = ok; cb1 = ob1; cb2 = ob2; }
+            }
+        }
+#endif
         if (r < n && g == 0u && ck >= 0.0f) {   // (the four lanes of the quad have read column r above; DPP moves below are register-only)
             w_lds[0 * 64 + r] = ct; w_lds[8 * 64 + r] = ck; w_lds[1 * 64 + r] = cb1; w_lds[2 * 64 + r] = cb2; w_lds[3 * 64 + r] = c2;
         }
