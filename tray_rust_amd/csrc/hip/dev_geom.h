@@ -356,7 +356,7 @@ TR_DEV bool triangle_test(const TrayTriVerts* __restrict__ tv, f3 o, f3 d, float
     // straight-line form of mesh.rs:136-171: the early `return None`s only skip work, so every quantity is computed and the verdicts
     // are and-ed (after a rejected test the later values are garbage that nobody reads) -- the lanes of a wave test different
     // triangles, so the four exits were four divergent branches per test
-    float div = 1.0f / dv;
+    float div = rcp_rn(dv);
     f3 dd = o - pa;
     float b1 = dot(dd, s0) * div;
     f3 s1 = cross(dd, e0);
@@ -488,7 +488,7 @@ TR_DEV bool mesh_traverse_ww(const DevScene& sc, uint32_t* __restrict__ stack, c
                              bool any_hit, uint32_t& prim, float& b1, float& b2, float& leaf_tmin, KeyPair keys = KeyPair{0u, 0u, 0.0f}) {
     const TrayBvhNode* __restrict__ tree = sc.mesh_nodes + m.node_offset;
     const TrayTriVerts* __restrict__ tris = sc.tri_verts + m.tri_offset;
-    const f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 inv_dir = rcp_rn3(d);
     const bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
     enum : uint32_t { MW_NODE = 0u, MW_LEAF = 1u, MW_DONE = 2u };
     int sp = 0;
@@ -582,6 +582,13 @@ TR_DEV float quad_xor(float v, int step) {
     return __int_as_float(step == 1 ? __builtin_amdgcn_mov_dpp(i, 0xB1, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(i, 0x4E, 0xf, 0xf, true));
 #endif
 }
+TR_DEV uint32_t quad_xor(uint32_t v, int step) {
+#ifdef TR_HOST_EMU
+    return __shfl_xor(v, step);
+#else
+    return (uint32_t)(step == 1 ? __builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));
+#endif
+}
 // value of lane (l ^ 7) (wide == 8: DPP row_half_mirror, lane i of an aligned group of eight <-> lane 7 - i) or of lane (l ^ 15) (wide == 16: row_mirror):
 // once the four lanes of every quad agree, these pair quad with quad and half-row with half-row
 TR_DEV float row_xor(float v, int wide) {
@@ -592,6 +599,13 @@ TR_DEV float row_xor(float v, int wide) {
     return __int_as_float(wide == 8 ? __builtin_amdgcn_mov_dpp(i, 0x141, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(i, 0x140, 0xf, 0xf, true));
 #endif
 }
+TR_DEV uint32_t row_xor(uint32_t v, int wide) {
+#ifdef TR_HOST_EMU
+    return __shfl_xor(v, wide - 1);
+#else
+    return (uint32_t)(wide == 8 ? __builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true));
+#endif
+}
 TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, LdsF w_lds, bool participate, f3 o, f3 d, float min_t,
                            float gate_max_t, float accept_max_t, float& t_out, uint32_t& prim, float& b1, float& b2, float& leaf_tmin, bool& hazard) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -600,7 +614,7 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, LdsF w_lds, boo
     const float4 lo = nq[0], hi = nq[1];
     const uint32_t T = m.tri_count;
     const TrayTriVerts* __restrict__ tris = sc.tri_verts + m.tri_offset;
-    const f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 inv_dir = rcp_rn3(d);   // (every lane holds a transformed ray here, wanted or not)
     const bool dnx = d.x < 0.0f, dny = d.y < 0.0f, dnz = d.z < 0.0f;
     const bool need = participate && bbox_hit(lo, hi, o, inv_dir, dnx, dny, dnz, min_t, gate_max_t);
     const unsigned long long mask = __ballot(need);
@@ -610,6 +624,7 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, LdsF w_lds, boo
 #if defined(TR_HOST_EMU) && defined(TR_COOP_HIST)   // tools/coop_histogram.py: how many rays of a wave reach a small mesh's triangles, how many lanes asked
     { extern unsigned long long tr_coop_hist[65 * 65]; const uint32_t asked = (uint32_t)__popcll(__ballot(participate)); if (lane == (uint32_t)__ffsll((long long)mask) - 1u) tr_coop_hist[n * 65 + asked]++; }
 #endif
+#ifdef TR_COOP_WIDE_PAYLOAD
     if (need) {
         w_lds[0 * 64 + rank] = o.x; w_lds[1 * 64 + rank] = o.y; w_lds[2 * 64 + rank] = o.z;
         w_lds[3 * 64 + rank] = d.x; w_lds[4 * 64 + rank] = d.y; w_lds[5 * 64 + rank] = d.z;
@@ -694,6 +709,81 @@ TR_DEV bool mesh_leaf_coop(const DevScene& sc, const TrayMesh m, LdsF w_lds, boo
             hit = true;
         }
     }
+#else
+    // The candidate of a lane / of a group of lanes is the pair (t, k) in lexicographic order, "none" = (+inf, COOP_NONE) -- a valid t lies below the
+    // ray's max_t, so "none" loses against every candidate and two of them compare equal; c2 = the smallest t among the ray's OTHER valid triangles.
+    // The lanes exchange (t, k, c2) only: the barycentrics stay with the lane that found them, which recognises itself as the winner afterwards.
+    constexpr uint32_t COOP_NONE = 0x7fffffffu;
+    if (need) {
+        w_lds[0 * 64 + rank] = o.x; w_lds[1 * 64 + rank] = o.y; w_lds[2 * 64 + rank] = o.z;
+        w_lds[3 * 64 + rank] = d.x; w_lds[4 * 64 + rank] = d.y; w_lds[5 * 64 + rank] = d.z;
+        w_lds[6 * 64 + rank] = min_t; w_lds[7 * 64 + rank] = gate_max_t;
+        w_lds[8 * 64 + rank] = __uint_as_float(COOP_NONE);   // no candidate yet
+    }
+    TR_WAVE_SYNC();
+    // Lanes per ray by the number of staged rays (wave-uniform): a wave of incoherent paths stages 5 rays on average, four or fewer in 61 % of the
+    // calls and eight or fewer in 88 % (tools/coop_histogram.py, cornell_box at 1080p) -- with four lanes per ray such a call runs ceil(T / 4)
+    // triangle tests in sequence on a quarter of the wave. Sixteen lanes per ray (n <= 4) test a cube's twelve triangles at once, eight (n <= 8) in two
+    // rounds. The result is the same set function of the ray's valid triangles whatever the width: the minimal (t, k), and the smallest other t (c2);
+    // a tie in t sets `hazard` (c2 == t).
+    const uint32_t lsh = n <= 4u ? 4u : n <= 8u ? 3u : 2u;
+    const uint32_t lpr = 1u << lsh, per = (T + lpr - 1u) >> lsh, g = lane & (lpr - 1u);
+    for (uint32_t base = 0; base < n; base += 64u >> lsh) {
+        const uint32_t r = base + (lane >> lsh);
+        float ct = TR_INF, cb1 = 0.0f, cb2 = 0.0f, c2 = TR_INF;
+        uint32_t ck = COOP_NONE;
+        if (r < n) {
+            const f3 ro = mk(w_lds[0 * 64 + r], w_lds[1 * 64 + r], w_lds[2 * 64 + r]);
+            const f3 rd = mk(w_lds[3 * 64 + r], w_lds[4 * 64 + r], w_lds[5 * 64 + r]);
+            const float rmin = w_lds[6 * 64 + r], rmax = w_lds[7 * 64 + r];
+            for (uint32_t j = 0; j < per; ++j) {
+                const uint32_t k = g * per + j;
+                if (k < T) {
+                    float t, bb1, bb2;
+                    if (triangle_test(tris + k, ro, rd, rmin, rmax, t, bb1, bb2)) {
+                        if (t < ct) { c2 = fminf(c2, ct); ct = t; cb1 = bb1; cb2 = bb2; ck = k; }   // (k ascends: of equal t's the first stays)
+                        else c2 = fminf(c2, t);
+                    }
+                }
+            }
+        }
+        const uint32_t own_k = ck;
+        // reduction over the ray's lanes: inside the quads first (all lanes of an aligned group of `lpr` are active together), then quad with quad
+#define TR_COOP_MERGE(MOVE, ARG) do { \
+            const float ot = MOVE(ct, ARG), o2 = MOVE(c2, ARG); const uint32_t ok = MOVE(ck, ARG); \
+            const bool take = ot < ct || (ot == ct && ok < ck); \
+            c2 = fminf(fminf(c2, o2), take ? ct : ot);   /* the loser of the two bests is a rival of the winner (+inf if there is none) */ \
+            if (take) { ct = ot; ck = ok; } } while (0)
+        TR_COOP_MERGE(quad_xor, 1);
+        TR_COOP_MERGE(quad_xor, 2);
+        if (lsh >= 3u) {
+            TR_COOP_MERGE(row_xor, 8);
+            if (lsh >= 4u) TR_COOP_MERGE(row_xor, 16);
+        }
+#undef TR_COOP_MERGE
+        if (r < n && ck != COOP_NONE) {   // (the lanes of the group have read column r above; the moves are register-only)
+            if (g == 0u) { w_lds[0 * 64 + r] = ct; w_lds[8 * 64 + r] = __uint_as_float(ck); w_lds[3 * 64 + r] = c2; }
+            if (own_k == ck) { w_lds[1 * 64 + r] = cb1; w_lds[2 * 64 + r] = cb2; }   // exactly one lane of the group holds triangle ck
+        }
+    }
+    TR_WAVE_SYNC();
+    bool hit = false;
+    if (need) {
+        const uint32_t k = __float_as_uint(w_lds[8 * 64 + rank]);
+        if (k != COOP_NONE && w_lds[0 * 64 + rank] <= accept_max_t) {
+            const float t = w_lds[0 * 64 + rank], c2 = w_lds[3 * 64 + rank];
+            // the survivor's gate: the box of its BVH<Triangle> leaf, with the ray's original max_t
+            const float4* lq = reinterpret_cast<const float4*>(tree + sc.tri_leaf[m.tri_offset + k]);
+            float cbox;
+            const bool gate = bbox_hit_t(lq[0], lq[1], o, inv_dir, dnx, dny, dnz, min_t, gate_max_t, cbox);
+            t_out = t; prim = m.tri_offset + k;
+            b1 = w_lds[1 * 64 + rank]; b2 = w_lds[2 * 64 + rank];
+            leaf_tmin = cbox;
+            hazard = !gate || !(c2 > t && c2 > cbox);   // (also true when cbox is NaN)
+            hit = true;
+        }
+    }
+#endif
     return hit;
 }
 
@@ -746,13 +836,16 @@ TR_DEV bool own_box_pass(const float* __restrict__ lo, const float* __restrict__
 // loop over leaves and instances stays wave-uniform, only the world -> object transform is per lane. Its gate is the box of its
 // BVH<Instance> leaf exactly as for the others (the reference's swept bounds with quirk Q12, whatever they cover: the reference reaches
 // the instance through nothing else); the own-box cull of occlusion rays is off for it (host/gates.hpp).
-template <int ANIM>
+// GUARD_ACTIVE: the range guard of the world-space reciprocal direction (dev_math.h: rcp_rn3) looks at the lanes that hold a ray only. Measured per
+// instantiation of the tile kernel (profiles/r05_c2_exact_reciprocal_ab.txt): the LFILT kernels (smallpt) lose 1.2 % of their instructions to the
+// compiler's division without it, the others (cornell_box) pay 1.3 % for the mask's scalar registers with it.
+template <int ANIM, bool GUARD_ACTIVE = false>
 TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, bool active, HitRec& rec, bool& hazard) {
     const float min_t = ray.min_t, gate_max_t = ray.max_t;
     float max_t = ray.max_t;          // closest accepted candidate so far
     float best_gate = -TR_INF;        // G of that candidate
     bool any = false, done = !active;   // lanes without a ray run along: the cooperative leaf test uses their ALUs
-    const f3 w_inv_dir = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    const f3 w_inv_dir = rcp_rn3(ray.d, !GUARD_ACTIVE || active);
     const bool wnx = ray.d.x < 0.0f, wny = ray.d.y < 0.0f, wnz = ray.d.z < 0.0f;
 #ifdef TR_FLAT_PK
     const f2 wpx = mk2(ray.o.x, ray.d.x), wpy = mk2(ray.o.y, ray.d.y), wpz = mk2(ray.o.z, ray.d.z);
@@ -778,7 +871,12 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
             // occlusion segments are short and end at the light: most instances lie outside the segment's reach for every lane of the
             // wave, and the own-box cull skips them wholesale (measured: trace B 17.3 -> 15.3 % of the tile kernel's wave cycles);
             // unbounded rays pass most boxes, the cull would only cost them its slab test
-            const bool wanted = gate && !done && (!any_hit || own_box_pass(own_lo, own_hi, ray.o, w_inv_dir, wnx, wny, wnz, min_t, gate_max_t));
+            #ifdef TR_OWN_BOX_ALWAYS
+            const bool own_redundant = false;
+#else
+            const bool own_redundant = count == 1u && !(ANIM && in->animated != 0u);   // the leaf holds this instance alone: its box lies inside the instance's own inflated box, the gate has said it all
+#endif
+            const bool wanted = gate && !done && (!any_hit || own_redundant || own_box_pass(own_lo, own_hi, ray.o, w_inv_dir, wnx, wny, wnz, min_t, gate_max_t));
             if (!__any(wanted)) continue;   // nobody's ray comes near this instance
             const uint32_t gt = in->geom_type, mesh_id = in->mesh_id, inst_id = in->inst;
             float inv[16];
@@ -854,7 +952,7 @@ template <int ANIM>
 TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, HitRec& rec) {
     const TrayBvhNode* __restrict__ tree = sc.top_nodes;
     f3 o = ray.o, d = ray.d;
-    f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    f3 inv_dir = rcp_rn3(d);
     bool nx = d.x < 0.0f, ny = d.y < 0.0f, nz = d.z < 0.0f;
     const float min_t = ray.min_t;
     float max_t = ray.max_t;
@@ -916,7 +1014,7 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
                 in_mesh = false;
                 tree = sc.top_nodes;
                 o = ray.o; d = ray.d;
-                inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                inv_dir = rcp_rn3(d);
                 nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
                 continue;
             }
@@ -950,7 +1048,7 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
                 tris = sc.tri_verts + m.tri_offset;
                 tri_base = m.tri_offset;
                 o = lo_; d = ld;
-                inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                inv_dir = rcp_rn3(d);
                 nx = d.x < 0.0f; ny = d.y < 0.0f; nz = d.z < 0.0f;
                 current = 0;
                 have_node = true;
@@ -977,7 +1075,7 @@ TR_DEV bool trace_bvh(const DevScene& sc, uint32_t* __restrict__ stack, const Ra
 // lane traces one ray per step of its phase machine), so it is inlined there.
 struct TraceResult { HitRec rec; bool hit; };
 // Called by ALL lanes of a wave that has at least one ray; `active` = this lane has one.
-template <int ANIM>
+template <int ANIM, bool GUARD_ACTIVE = false>
 TR_DEV TraceResult trace(const DevScene* __restrict__ scp, uint32_t* __restrict__ stack, Ray ray, bool any_hit, bool active) {
     const DevScene& sc = *scp;
     TraceResult r;
@@ -986,7 +1084,7 @@ TR_DEV TraceResult trace(const DevScene* __restrict__ scp, uint32_t* __restrict_
     // swept bounds of animated_transform.rs:58-71 with quirk Q12 -- so it reaches exactly the instances the reference's traversal can reach)
     if (sc.n_instances <= TR_FLAT_MAX) {
         bool hazard = false;
-        r.hit = trace_flat<ANIM>(sc, stack, ray, any_hit, active, r.rec, hazard);
+        r.hit = trace_flat<ANIM, GUARD_ACTIVE>(sc, stack, ray, any_hit, active, r.rec, hazard);
         if (__any(hazard)) {   // (about one ray in 1e7: tied candidates, or a box entered behind its own hit) the reference's traversal decides
             if (hazard) {
                 if (sc.retraced) atomicAdd(sc.retraced, 1u);

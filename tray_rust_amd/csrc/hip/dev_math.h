@@ -79,6 +79,28 @@ TR_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   // 
 TR_DEV f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 TR_DEV float length_sqr(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 TR_DEV f3 normalized(f3 a) { float l = sqrtf(length_sqr(a)); return mk(a.x / l, a.y / l, a.z / l); }   // vector.rs:33-36
+// 1.0f / x. The compiler builds the correctly rounded quotient from v_div_scale x 2, v_rcp_f32, five v_fma, v_div_fmas and v_div_fixup (~11 VALU
+// instructions, 42 cycles: profiles/r04_ubench_valu.txt). gfx950's v_rcp_f32 followed by ONE Newton step in fma form gives the same bits for EVERY x
+// with 2^-126 <= |x| < 2^126 -- tools/ubench_rcp.hip compares all 2^32 arguments on the MI355X (profiles/r05_rcp_exhaustive.txt: the only arguments
+// that differ have a biased exponent of 0 or >= 253) -- so the wave takes the three-instruction form when all of its active lanes are inside that
+// range and the compiler's division otherwise (a wave-uniform branch). -DTR_IEEE_RCP: the compiler's division everywhere, as before.
+TR_DEV bool rcp_in_range(float x) { return ((__float_as_uint(x) & 0x7fffffffu) - 0x00800000u) < 0x7e000000u; }   // biased exponent 1 ... 252
+// `relevant`: the lane's quotient will be read (lanes that only run along -- no ray, no path -- hold stale or zero arguments and must not send the wave
+// down the slow branch; what they compute is never used)
+#if defined(TR_HOST_EMU) || defined(TR_IEEE_RCP)
+TR_DEV float rcp_rn(float x, bool relevant = true) { (void)relevant; return 1.0f / x; }
+TR_DEV f3 rcp_rn3(f3 d, bool relevant = true) { (void)relevant; return mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+#else
+TR_DEV float rcp_newton(float x) { const float r = __builtin_amdgcn_rcpf(x); return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r); }
+TR_DEV float rcp_rn(float x, bool relevant = true) {
+    if (__all(!relevant || rcp_in_range(x))) return rcp_newton(x);
+    return 1.0f / x;
+}
+TR_DEV f3 rcp_rn3(f3 d, bool relevant = true) {
+    if (__all(!relevant || (rcp_in_range(d.x) && rcp_in_range(d.y) && rcp_in_range(d.z)))) return mk(rcp_newton(d.x), rcp_newton(d.y), rcp_newton(d.z));
+    return mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+}
+#endif
 TR_DEV bool is_black(f3 c) { return c.x == 0.0f && c.y == 0.0f && c.z == 0.0f; }   // color.rs:47-49
 TR_DEV float luminance(f3 c) { return 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z; }
 TR_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }   // linalg/mod.rs:51-53

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(TR_BLOCK, (FEAT == 15 || INTEG != TRAY_INTEGRATOR_P
                 if (LFILT && stage == 2) w_rays += (uint32_t)__popcll(__ballot(alive && (ln.flags & LF_MIS_MISS) != 0u));   // rays proven to miss the light (query_stage): counted like the reference's
                 if (wr_ != 0ull) {
                     const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
-                    tr_ = trace<ANIM>(scp, my_stack, r, stage == 1, want_ray);
+                    tr_ = trace<ANIM, LFILT>(scp, my_stack, r, stage == 1, want_ray);
                 }
                 TR_CLK(stage);   // trace A / B / C
                 if (stage == 0) w_vertices += (uint32_t)__popcll(__ballot(alive && tr_.hit));

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                         if (STAGE == 0) { min_t = (r1.w & WF_CAMERA_RAY) ? 0.0f : 0.001f; max_t = TR_INF; }
                         else { min_t = 0.001f; max_t = STAGE == 1 ? 0.999f : TR_INF; }
                         d = wd;
-                        const f3 inv_dir = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        const f3 inv_dir = rcp_rn3(d);
                         winv = inv_dir;
                         WF_SET_RAY(wo, inv_dir);
                         WF_SIGNS();
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                 }
                 const uint32_t gt = wflags & 7u;
                 if (gt == TRAY_GEOM_MESH) {
-                    const f3 inv_obj = mk(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+                    const f3 inv_obj = rcp_rn3(ld);
                     if (!wf_regular(inv_obj)) { deferred = true; break; }   // (the whole ray: the reference's traversal decides, as at the refill)
                     WF_PUSH(STK_EXIT_MESH);
                     in_mesh = true;
