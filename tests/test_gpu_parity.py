@@ -911,3 +911,43 @@ def test_gpu_other_samplers_with_every_lobe_and_with_whitted(tmp_path):
         gpu, tim = gpu_render_sampler(scene, rt, make, fi, seed=8)
         cpu, st, _ = O.render_tiles_sampler(flat, kind, *args, seed=8)
         assert abs(int(tim.samples) - int(st.samples)) <= 0.01 * st.samples and rmse(gpu, cpu) < bar, (kind, rmse(gpu, cpu))
+
+
+def _wave_rays_at_cubes(rng, counts):
+    """one wave (64 rays) per entry of `counts`: the first n rays aim at points inside cornell_box's cubes from random places in the room, the others
+    start above the cubes and point up at the ceiling (they miss both cubes' boxes)"""
+    cubes = [(np.array([-6.0, 5.0, 6.0]), np.array([2.0, 5.0, 2.0])), (np.array([4.0, 2.5, -3.0]), np.array([2.0, 2.5, 2.0]))]   # centre, half extent before the rotation
+    rays = []
+    for n in counts:
+        for lane in range(64):
+            if lane < n:
+                c, h = cubes[(lane + n) % 2]
+                target = c + rng.uniform(-0.9, 0.9, 3) * h * 0.6
+                o = np.array([rng.uniform(-13, 13), rng.uniform(12, 22), rng.uniform(-17, 18)])
+                d = target - o
+            else:
+                o = np.array([rng.uniform(-13, 13), rng.uniform(16, 22), rng.uniform(-17, 18)])
+                d = np.array([rng.uniform(-0.2, 0.2), 1.0, rng.uniform(-0.2, 0.2)])
+            d = d / np.linalg.norm(d)
+            rays.append(np.concatenate([o, d, [0.001, np.inf, 0.0]]))
+    return np.array(rays, np.float32)
+
+
+def test_cooperative_small_mesh_test_at_every_width(tmp_path):
+    """mesh_leaf_coop picks 16 / 8 / 4 lanes per staged ray by the number of rays of the wave that pass the mesh's root box (dev_geom.h): waves built
+    to stage exactly 1 ... 17, 33 and 64 rays at cornell_box's cubes -- every width, full and ragged passes -- return the oracle's hit records bit for bit"""
+    scene, *_ = load(scenes.cornell_box(64, 64, 4), tmp_path)
+    flat = scene.flatten(0)
+    counts = list(range(0, 18)) + [24, 32, 33, 48, 63, 64]
+    rays = _wave_rays_at_cubes(np.random.default_rng(11), counts * 3)
+    a, b = O.intersect(flat, rays), gpu_intersect(scene, rays)
+    assert (a["inst"] == b["inst"]).all() and (a["prim"] == b["prim"]).all() and (a["t"] == b["t"]).all()
+    hit = a["inst"] != 0xffffffff
+    for f in ("p", "n", "ng", "dp_du", "dp_dv", "u", "v"):
+        assert (a[f][hit] == b[f][hit]).all(), f
+    # the waves are what they were built to be: the aimed rays hit a cube (a mesh instance: prim counts triangles), the others the ceiling or the light
+    is_cube = np.array([flat.contents.instances[int(i)].geom_type == T._lib.GEOM_MESH if i != 0xffffffff else False for i in a["inst"]])
+    per_wave = is_cube.reshape(-1, 64).sum(axis=1)
+    want = np.array(counts * 3)
+    assert (per_wave <= want).all() and (per_wave >= want - 2).all(), per_wave   # (an aimed ray may start behind a cube's face and leave through a wall)
+    assert {int(c) for c in per_wave} >= set(range(0, 15)) | {24, 32, 33, 48}
