@@ -43,7 +43,7 @@ NOINSTR void prof_wave_done(uint32_t wave) {
 }
 }  // namespace hip_emu
 extern "C" {
-NOINSTR void __cyg_profile_func_enter(void* fn, void*) { hip_emu::ProfState& p = hip_emu::prof(); if (p.on && hip_emu::block().simt) ++p.lane[reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(fn) << 3) | (hip_emu::prof_phase & 7u))]; }
+NOINSTR void __cyg_profile_func_enter(void* fn, void*) { hip_emu::ProfState& p = hip_emu::prof(); if (p.on && hip_emu::block().simt) ++p.lane[reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(fn) << 3) | (hip_emu::prof_phase_of[hip_emu::block().current & 1023u] & 7u))]; }
 NOINSTR void __cyg_profile_func_exit(void*, void*) {}
 NOINSTR void emu_profile_start(void) { hip_emu::ProfState& p = hip_emu::prof(); p.total.clear(); p.on = true; }
 // writes "lane_calls wave_calls lanes segments symbol" lines; returns the number of functions

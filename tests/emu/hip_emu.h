@@ -34,8 +34,8 @@
 #define __launch_bounds__(...)
 #define TR_DYN_LDS(T, name) T* const name = reinterpret_cast<T*>(hip_emu::dyn_lds())
 #ifdef TR_EMU_PROFILE
-namespace hip_emu { static uint32_t prof_phase = 0; }
-#define TR_EMU_PHASE(k) (hip_emu::prof_phase = (uint32_t)(k))   // calls made in different phases of a segment are not executed together
+namespace hip_emu { static uint32_t prof_phase_of[1024]; }   // per fiber: the lanes of a wave run one after the other between two rendezvous
+#define TR_EMU_PHASE(k) (hip_emu::prof_phase_of[threadIdx.x & 1023u] = (uint32_t)(k))   // calls made in different phases of a segment are not executed together
 #else
 #define TR_EMU_PHASE(k) ((void)0)
 #endif
