@@ -405,7 +405,9 @@ typedef struct TrayScheduleInfo {
     uint32_t n_moving;            /* instances that move within the frame (columns of the per-path transform cache) */
     uint32_t tile_workgroups;     /* persistent workgroups of the tile kernel */
     uint64_t pool_bytes, schedule_bytes, xf_cache_bytes;   /* pool alone; pool + queues + bins; per-path transform cache */
-    uint32_t transform_table, pad_;                        /* 1: the last launch read the frame's transform table (tray_scene_set_transform_table) */
+    uint32_t transform_table;     /* 1: the last launch read the frame's transform table (tray_scene_set_transform_table) */
+    uint32_t binned_stages;       /* wavefront schedule: traversal stages whose rays are sorted by (origin cell, direction octant) before they are
+                                   * traced -- bit 0: camera / continuation rays, bit 1: occlusion rays (round 6; this word was padding before) */
     uint64_t xf_table_bytes;                               /* the table, if this frame has one */
 } TrayScheduleInfo;
 int tray_last_schedule(TrayDeviceScene* s, TrayScheduleInfo* out);

@@ -70,6 +70,8 @@ def emu(defines=()):
         h.emu_render_sampler.restype = C.c_int
         h.emu_render_sampler.argtypes = [FS, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
         h.emu_retraced.restype = C.c_uint
+        h.emu_wf_bin.restype = C.c_uint32
+        h.emu_wf_bin.argtypes = [C.c_uint32] + [C.c_void_p] * 6 + [C.c_int]
         _libs[key] = h
     return _libs[key]
 
@@ -144,3 +146,21 @@ def render_wavefront(flat, tiles_xy, spp, seed, trace=0, n_chunks=4, trace_block
                                          lds_depth, stats.ctypes.data)
     assert rc == 0, f"emu_render_wavefront: {rc}"
     return img, tuple(int(x) for x in stats)
+
+
+def wf_bin(n_chunks, counts, rays, bmin, bmax, stage=0):
+    """the wavefront schedule's ray binning (k_wf_bin_hist + k_wf_bin_scatter) over a queue whose segment s holds counts[s] ray records:
+    rays[s] = (counts[s], 8) uint32 words (slot, o, d, flags). Returns (sorted records per segment, their keys per segment)."""
+    h = emu()
+    counts = np.ascontiguousarray(counts, np.uint32)
+    cap = int(h.emu_wf_bin(n_chunks, None, None, None, None, None, None, stage))
+    assert len(counts) == 64 and counts.max() <= cap
+    queue = np.zeros((64, cap, 8), np.uint32)
+    for s_ in range(64):
+        queue[s_, :counts[s_]] = rays[s_]
+    out = np.zeros_like(queue)
+    keys = np.zeros((64, cap), np.uint32)
+    bmin = np.ascontiguousarray(bmin, np.float32); bmax = np.ascontiguousarray(bmax, np.float32)
+    rc = h.emu_wf_bin(n_chunks, counts.ctypes.data, queue.ctypes.data, out.ctypes.data, keys.ctypes.data, bmin.ctypes.data, bmax.ctypes.data, stage)
+    assert rc == cap, "emu_wf_bin failed"
+    return [out[s_, :counts[s_]] for s_ in range(64)], [keys[s_, :counts[s_]] for s_ in range(64)]

@@ -507,15 +507,23 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     const uint64_t max_rounds = (uint64_t)((n_items + n_chunks - 1) / n_chunks) * (((uint64_t)spp + 3) / 4 * ((WF_FOLD_C ? 2u : 1u) * e.d.max_depth + 3) + 4) + 32;
     int rc = 0;
     uint64_t rounds = 0;
+    // ray binning before the traversal stages, as launch_wavefront sets it up (TRAYHIP_WF_BIN: bit 0 = stage A, bit 1 = stage B)
+    uint32_t bin_stages = WF_BIN_DEFAULT;
+    if (const char* be = getenv("TRAYHIP_WF_BIN")) bin_stages = (uint32_t)std::max(0, atoi(be)) & 3u;
+    std::vector<uint32_t> bin_ctl((size_t)2u * 2u * WF_SEGS * WF_BINS, 0u);
+    const WfBinGrid bin_grid = f->n_top_nodes ? wf_bin_grid(f->top_nodes[0].bmin, f->top_nodes[0].bmax) : WfBinGrid{};
+    const uint32_t bin_blocks = (pool.seg_cap + WF_BIN_EPB - 1u) / WF_BIN_EPB * WF_SEGS;
 #define EMU_K(...) do { if (rc == 0) rc = launch_simt(__VA_ARGS__); } while (0)
 #define EMU_ROUND(A, F)                                                                                                                     \
     do {                                                                                                                                    \
         EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_advance<A>(e.d, pool, chunks.data(), bins.data(), tiles.data(), n_items, tile_count, 1u, spp, kf, rgbw, \
                                                          counters, counters + 1, stats.data(), qa, qr, qctl, slice_shift); });                          \
         EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_regen<A>(e.d, pool, chunks.data(), tiles.data(), tile_count, 1u, spp, kf, stats.data(), qr, qa, qctl, slice_shift); }); \
-        EMU_TRACE_STAGE(0, A, qa, qb);                                                                                                        \
+        if (WF_FOLD_C && (bin_stages & 1u)) { EMU_BIN(0, qa, qc, bin_ctl.data()); EMU_TRACE_STAGE(0, A, qc, qb); }   /* wf_round: the binned copy lies in the idle queue's buffer */ \
+        else EMU_TRACE_STAGE(0, A, qa, qb);                                                                                                   \
         EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_begin<A>(e.d, pool, n_active, stats.data(), qb, qctl, sorted ? kind_queues.data() : nullptr); }); \
-        EMU_TRACE_STAGE(1, A, qb, qc);                                                                                                        \
+        if (WF_FOLD_C && (bin_stages & 2u)) { EMU_BIN(1, qb, qa, bin_ctl.data() + 2u * WF_SEGS * WF_BINS); EMU_TRACE_STAGE(1, A, qa, qc); }     \
+        else EMU_TRACE_STAGE(1, A, qb, qc);                                                                                                   \
         if (sorted) {   /* wf_round of kernels.hip: one kind-pure shading launch per material kind of the scene */                        \
             EMU_QUERY_KIND(A, TRAY_MAT_MATTE); EMU_QUERY_KIND(A, TRAY_MAT_PLASTIC); EMU_QUERY_KIND(A, TRAY_MAT_METAL); EMU_QUERY_KIND(A, TRAY_MAT_GLASS); \
             EMU_QUERY_KIND(A, TRAY_MAT_ROUGH_GLASS); EMU_QUERY_KIND(A, TRAY_MAT_SPECULAR_METAL); EMU_QUERY_KIND(A, TRAY_MAT_MERL);          \
@@ -529,6 +537,11 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
         EMU_K(1u, TR_BLOCK, [&] { k_wf_trace_fallback<S, A>(e.d, pool, qctl, FB); }, fb_lds);                                    \
         g_wf_deferred += qctl[WF_FB_WORD + S];                                                                                              \
     } while (0)
+#define EMU_BIN(S, Q, OUT, CTL) /* ray binning before stage S (wavefront.h: k_wf_bin_hist / k_wf_bin_scatter) */                          \
+    do {                                                                                                                                    \
+        EMU_K(bin_blocks, TR_BLOCK, [&] { k_wf_bin_hist<S>(pool, Q, qctl, CTL, bin_grid); });                                               \
+        EMU_K(bin_blocks, TR_BLOCK, [&] { k_wf_bin_scatter<S>(pool, Q, OUT, qctl, CTL, bin_grid); });                                       \
+    } while (0)
 #define EMU_ROUND_F(A)                                                                                                                      \
     do {                                                                                                                                    \
         if (feat == FEAT_NONE) EMU_ROUND(A, FEAT_NONE); else if (feat == FEAT_MERL) EMU_ROUND(A, FEAT_MERL);                                \
@@ -537,10 +550,12 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     } while (0)
     while (rc == 0 && counters[1] < n_items) {
         std::memset(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t));
+        std::fill(bin_ctl.begin(), bin_ctl.end(), 0u);
         if (moving) EMU_ROUND_F(1); else EMU_ROUND_F(0);
         if (++rounds > max_rounds) rc = -5;   // "wavefront schedule did not terminate"
     }
 #undef EMU_ROUND_F
+#undef EMU_BIN
 #undef EMU_TRACE_STAGE
 #undef EMU_QUERY_KIND
 #undef EMU_ROUND
@@ -551,6 +566,31 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
         stats_out[0] = st.samples; stats_out[1] = st.vertices; stats_out[2] = st.rays; stats_out[3] = rounds;
     }
     return rc;
+}
+
+uint32_t emu_wf_bin_cells(void) { return 1u << WF_BIN_CELL_BITS; }
+// The two binning kernels alone (tests/test_device_emulation.py): a queue of n_chunks x 256 slots whose segment `s` holds counts[s] ray records
+// (8 words each, at queue[(s * seg_cap + k) * 8]); `sorted` receives every segment counting-sorted by wf_bin_key over the box (bmin, bmax), `keys`
+// the key of every sorted entry. Returns the segments' capacity.
+uint32_t emu_wf_bin(uint32_t n_chunks, const uint32_t* counts, const uint32_t* queue, uint32_t* sorted, uint32_t* keys, const float* bmin, const float* bmax, int stage) {
+    WfPool pool{nullptr, n_chunks * TR_BLOCK, wf_seg_cap(n_chunks)};
+    if (!queue) return pool.seg_cap;
+    std::vector<uint32_t> qctl(WF_QCTL_WORDS, 0u), ctl((size_t)2u * WF_SEGS * WF_BINS, 0u);
+    for (uint32_t s = 0; s < WF_SEGS; ++s) qctl[s * WF_SEG_STRIDE + (uint32_t)stage] = counts[s];
+    const WfBinGrid g = wf_bin_grid(bmin, bmax);
+    const uint32_t blocks = (pool.seg_cap + WF_BIN_EPB - 1u) / WF_BIN_EPB * WF_SEGS;
+    int rc = 0;
+    if (stage == 0) {
+        rc = launch_simt(blocks, TR_BLOCK, [&] { k_wf_bin_hist<0>(pool, queue, qctl.data(), ctl.data(), g); });
+        if (rc == 0) rc = launch_simt(blocks, TR_BLOCK, [&] { k_wf_bin_scatter<0>(pool, queue, sorted, qctl.data(), ctl.data(), g); });
+    } else {
+        rc = launch_simt(blocks, TR_BLOCK, [&] { k_wf_bin_hist<1>(pool, queue, qctl.data(), ctl.data(), g); });
+        if (rc == 0) rc = launch_simt(blocks, TR_BLOCK, [&] { k_wf_bin_scatter<1>(pool, queue, sorted, qctl.data(), ctl.data(), g); });
+    }
+    if (rc != 0) return 0u;
+    for (uint32_t s = 0; s < WF_SEGS; ++s)
+        for (uint32_t k = 0; k < counts[s]; ++k) keys[(size_t)s * pool.seg_cap + k] = wf_bin_entry_key(g, sorted, (size_t)s * pool.seg_cap + k);
+    return pool.seg_cap;
 }
 
 }  // extern "C"

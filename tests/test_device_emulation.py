@@ -360,6 +360,59 @@ def test_wavefront_schedule_with_more_chunks_than_queue_segments(tmp_path, built
     assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6
 
 
+def test_ray_binning_kernels_sort_every_segment(built):
+    """k_wf_bin_hist + k_wf_bin_scatter (wavefront.h, round 6): every segment of a ray queue comes out as a permutation of itself -- every record
+    once, bit for bit -- in non-decreasing key order, the key being (Morton cell of the origin in the box, direction octant) as an independent
+    numpy reading computes it; segments of 0, 1, one workgroup's worth and several workgroups' worth of entries (20 chunks: capacity 256), origins
+    outside the box, on its faces and NaN, a flat axis."""
+    rng = np.random.default_rng(12)
+    n_chunks = 1400          # capacity ceil(1400 / 64) * 256 = 5632 entries per segment: two workgroups of 4096 per segment
+    counts = rng.integers(0, 5633, 64).astype(np.uint32)
+    counts[:6] = (0, 1, 255, 4096, 4097, 5632)
+    bmin, bmax = np.array([-3.0, 0.0, 2.0], np.float32), np.array([5.0, 4.0, 2.0], np.float32)   # z is flat: one cell
+    rays = []
+    for s_ in range(64):
+        n = int(counts[s_])
+        r = np.zeros((n, 8), np.uint32)
+        r[:, 0] = rng.permutation(n) + 7 * s_
+        o = rng.uniform([-4, -1, 1], [6, 5, 3], (n, 3)).astype(np.float32)
+        if n > 10:
+            o[0] = bmin; o[1] = bmax; o[2] = np.nan; o[3] = (np.inf, -np.inf, 0.0)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        if n > 10: d[4] = (0.0, -0.0, 1.0)
+        r[:, 1:4] = o.view(np.uint32); r[:, 4:7] = d.view(np.uint32); r[:, 7] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+        rays.append(r)
+    out, keys = E.wf_bin(n_chunks, counts, rays, bmin, bmax, stage=0)
+
+    bits = int(np.log2(E.emu().emu_wf_bin_cells()))
+    def key_of(r):
+        o = r[:, 1:4].copy().view(np.float32); d = r[:, 4:7].copy().view(np.float32)
+        cell = np.zeros(len(r), np.uint32)
+        c = []
+        for a in range(3):
+            ext = bmax[a] - bmin[a]
+            scale = np.float32(2 ** bits) / ext if ext > 0 else np.float32(0)
+            lo = bmin[a] if ext > 0 else np.float32(0)
+            with np.errstate(invalid="ignore"):
+                v = (o[:, a] - lo) * scale
+                v = np.where(np.isnan(v), np.float32(0), np.clip(v, 0, 2 ** bits - 1))   # fmaxf(NaN, 0) = 0
+            c.append(v.astype(np.uint32))
+        for b in range(bits):
+            for a in range(3):
+                cell |= ((c[a] >> b) & 1) << (3 * b + a)
+        octant = (d[:, 0] < 0).astype(np.uint32) | ((d[:, 1] < 0).astype(np.uint32) << 1) | ((d[:, 2] < 0).astype(np.uint32) << 2)
+        return (cell << 3) | octant
+    for s_ in range(64):
+        a, b = rays[s_], out[s_]
+        assert len(a) == len(b) == counts[s_]
+        order_a = np.lexsort(a.T[::-1]); order_b = np.lexsort(b.T[::-1])
+        assert (a[order_a] == b[order_b]).all()                 # a permutation, every word of every record
+        assert (keys[s_] == key_of(b)).all()                    # the device's key is the independent reading's
+        assert (np.diff(keys[s_].astype(np.int64)) >= 0).all()  # sorted
+    out_b, keys_b = E.wf_bin(n_chunks, counts, rays, bmin, bmax, stage=1)   # the occlusion stage's instantiation: the same sort
+    assert all((np.sort(keys[s_]) == keys_b[s_]).all() for s_ in range(64))
+
+
 def test_tile_kernel_on_random_scenes(tmp_path, built):
     """k_path_tiles itself (dynamic sample pairs, wave-aligned query passes, the instantiation with or without mis_ray_filter that
     tray_scene_create would pick) on scenes with every material kind: the oracle's samples, vertices, rays and image."""

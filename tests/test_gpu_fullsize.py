@@ -16,6 +16,7 @@ import pytest
 import tray_rust_amd as T
 from tray_rust_amd import scenes
 import _oracle as O
+import _parity
 
 pytestmark = pytest.mark.gpu
 W, H = 1920, 1080
@@ -44,18 +45,22 @@ def compare(scene, frame, spp, seed, stride, vertex_tol=1e-4, label=""):
     assert tim.samples == st.samples == tiles * 64 * spp
     touched = cpu[..., 3] > 0
     assert (touched == (gpu[..., 3] > 0)).all()
-    assert np.abs(gpu[..., 3] - cpu[..., 3]).max() < 1e-3 * cpu[..., 3].max()   # filter weights: same positions, f32 sum order differs
-    assert int(tim.vertices) == int(st.vertices), (tim.vertices, st.vertices)   # (round 4 allowed 1e-4: ocml's last bits flipped a path in 1e5)
+    # filter weights: the same sample positions bit for bit, so the two weight planes differ by the order of their f32 sums alone -- measured
+    # 1.0e-6 ... 2.6e-6 of the largest weight at 1024 - 4096 spp (round 5's bar of 1e-3 was a thousand times what it measures: VERDICT round 5)
+    wdiff = float(np.abs(gpu[..., 3] - cpu[..., 3]).max() / cpu[..., 3].max())
+    assert wdiff < 5e-5, wdiff
+    if _parity.mode() == "bit": assert int(tim.vertices) == int(st.vertices), (tim.vertices, st.vertices)   # (round 4 allowed 1e-4: ocml's last bits flipped a path in 1e5)
+    else: assert abs(int(tim.vertices) - int(st.vertices)) <= 1e-4 * st.vertices
     d = (rgb(gpu) - rgb(cpu))[touched]
     r = float(np.sqrt(np.mean(d ** 2)))
-    print(f"{label}: {tiles} tiles x 64 px x {spp} spp = {st.samples} samples, RMSE {r:.3e}, max {np.abs(d).max():.3e}, "
+    print(f"{label}: {tiles} tiles x 64 px x {spp} spp = {st.samples} samples, RMSE {r:.3e}, max {np.abs(d).max():.3e}, weight plane {wdiff:.2e}, "
           f"V {st.vertices / st.samples:.4f} (gpu {tim.vertices / tim.samples:.4f}), oracle {st.seconds:.1f}s, retraced {tim.retraced}")
     # Every SAMPLE is the oracle's bit for bit (same_samples below); the FILMS differ by the order in which f32 adds them up: a pixel of these
     # configs is the sum of spp x 64 weighted samples (8 x 8 footprint), each addition rounds to 2^-24 of the running sum, the orders differ
     # (LDS atomics of 256 threads here, sample order in the oracle) -- a random walk of sqrt(1024 x 64) x 6e-8 = 1.5e-5 relative at C2's 1024 spp.
     # Measured 1.2e-5 / 2.4e-5 / 1.4e-5 on C2 / C3 / C4 (4096 spp on C3) -- the same figures as in round 4, when a fifth of the samples still
     # differed in their last bits: the sum order was the whole of it then already. The north star's bar is 1e-4.
-    assert r < 5e-5
+    assert r < _parity.film_bar(5e-5), r   # (on a host whose libm is not the restated glibc: the north star's 1e-4, tests/_parity.py)
     same_samples(scene, frame, spp, seed, label)
     return tim, st
 
@@ -119,11 +124,8 @@ def same_samples(scene, frame, spp, seed, label, n=60000):
     b = np.zeros((n, 8), np.float32)
     T.check(T.lib().tray_debug_sample_radiance(scene.device_scene(frame, 0), n, px.ctypes.data, py.ctypes.data, si.ctypes.data, spp, seed, b.ctypes.data))
     assert (a[:, 3:5] == b[:, 3:5]).all()                          # sample positions: bit-equal
-    flipped = (a[:, 5] != b[:, 5]) | (a[:, 6] != b[:, 6])
-    se = ((np.clip(a[:, :3], 0, 1) - np.clip(b[:, :3], 0, 1)) ** 2).sum(axis=1)
-    same_bits = (a[:, :3] == b[:, :3]).all(axis=1)
-    print(f"   {label}: {n} camera samples: {100 * same_bits.mean():.3f} % bit-identical radiance, {int(flipped.sum())} on another path, per-sample RMSE {np.sqrt(se.mean() / 3):.3e}")
-    assert same_bits.all() and not flipped.any(), (int((~same_bits).sum()), int(flipped.sum()))
+    # bit for bit where the host's libm is the glibc the device restates; the round-4 bars with a loud message where it is not (tests/_parity.py)
+    _parity.check_samples(a, b, label)
     return 0.0
 
 
@@ -145,12 +147,13 @@ def test_c5_tr15_stand_in_full_detail_1080p_512spp(tmp_path):
         assert tim.samples == st.samples == tiles * 64 * 512
         touched = cpu[..., 3] > 0
         assert (touched == (gpu[..., 3] > 0)).all()
-        assert int(tim.vertices) == int(st.vertices), (tim.vertices, st.vertices)
+        if _parity.mode() == "bit": assert int(tim.vertices) == int(st.vertices), (tim.vertices, st.vertices)
+        else: assert abs(int(tim.vertices) - int(st.vertices)) <= 1e-4 * st.vertices
         d = (rgb(gpu) - rgb(cpu))[touched]
         r = float(np.sqrt(np.mean(d ** 2)))
         print(f"C5 tr15 stand-in frame {frame} seed {seed}: {tiles} tiles x 64 px x 512 spp = {st.samples} samples, RMSE {r:.3e}, max {np.abs(d).max():.3e}, "
               f"V {st.vertices / st.samples:.4f} (gpu {tim.vertices / tim.samples:.4f}), oracle {st.seconds:.1f}s")
-        assert r < 2e-5, r   # (measured 5.7e-6 / 5.7e-6 / 0 / 8.2e-8 / 2.9e-6: the order of the film's f32 sums; round 4: 8.2e-5 / 5.7e-5 / 0 / - / 7.7e-5)
+        assert r < _parity.film_bar(2e-5), r   # (measured 5.7e-6 / 5.7e-6 / 0 / 8.2e-8 / 2.9e-6: the order of the film's f32 sums; round 4: 8.2e-5 / 5.7e-5 / 0 / - / 7.7e-5)
         same_samples(scene, frame, 512, seed, f"frame {frame} seed {seed}")
 
 

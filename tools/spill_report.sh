@@ -4,11 +4,13 @@
 set -e
 cd "$(dirname "$0")/../tray_rust_amd/csrc"
 T=$(mktemp -d)
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -munsafe-fp-atomics -Wno-unused-function "$@" -c hip/kernels.hip -o $T/k.o
-F=$T/k.co
-/opt/rocm/lib/llvm/bin/llvm-objcopy -O binary --only-section=.hip_fatbin $T/k.o $T/f.bin
-/opt/rocm/lib/llvm/bin/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$T/f.bin --output=$F --unbundle
-/opt/rocm/lib/llvm/bin/llvm-readelf --notes $F | awk -v all="$SPILL_ALL" '
+# (the kernel groups of hip/kernel_list.h the report looks at: the static tile kernels and the wavefront schedule's shading side for moving scenes;
+#  SPILL_GROUPS="0 1 .. 9" for others)
+for g in ${SPILL_GROUPS:-0 1 8}; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -munsafe-fp-atomics -fno-slp-vectorize -Wno-unused-function "$@" -DTR_INST_GROUP=$g -c hip/kernel_group.hip -o $T/k$g.o &
+done
+wait
+for g in ${SPILL_GROUPS:-0 1 8}; do ../../tools/code_objects.sh $T/k$g.o $T/co$g; done | xargs -n1 /opt/rocm/lib/llvm/bin/llvm-readelf --notes | awk -v all="$SPILL_ALL" '
   /\.name:/ {name=$2}
   /\.private_segment_fixed_size:/ {scr=$2}
   /\.sgpr_spill_count:/ {ss=$2}

@@ -9,9 +9,7 @@ LIB=${1:-tray_rust_amd/libtrayhip.so}
 LATEST=profiles/static_registers_latest.json
 if [ -n "$1" ] || [ -n "$TRAYHIP_LIB" ] || [ -n "$EXTRA_HIPFLAGS" ]; then LATEST=/dev/null; echo "(variant build: profiles/static_registers_latest.json is left alone)" >&2; fi
 T=$(mktemp -d)
-/opt/rocm/lib/llvm/bin/llvm-objcopy -O binary --only-section=.hip_fatbin "$LIB" $T/f.bin
-/opt/rocm/lib/llvm/bin/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$T/f.bin --output=$T/k.co --unbundle
-/opt/rocm/lib/llvm/bin/llvm-readelf --notes $T/k.co | awk -v latest="$LATEST" -v hash="$(tools/device_code_hash.sh $LIB)" '
+for co in $(tools/code_objects.sh "$LIB" $T); do /opt/rocm/lib/llvm/bin/llvm-readelf --notes $co; done | awk -v latest="$LATEST" -v hash="$(tools/device_code_hash.sh $LIB)" '
   /\.name:/ {name=$2}
   /\.private_segment_fixed_size:/ {scr=$2}
   /\.sgpr_spill_count:/ {ss=$2}

@@ -139,7 +139,7 @@ class TrayScheduleInfo(C.Structure):
     _fields_ = [("wavefront", C.c_uint32), ("launched_wavefront", C.c_uint32), ("pool_slots", C.c_uint32), ("chunks", C.c_uint32),
                 ("views", C.c_uint32), ("slices", C.c_uint32), ("n_moving", C.c_uint32), ("tile_workgroups", C.c_uint32),
                 ("pool_bytes", C.c_uint64), ("schedule_bytes", C.c_uint64), ("xf_cache_bytes", C.c_uint64),
-                ("transform_table", C.c_uint32), ("pad_", C.c_uint32), ("xf_table_bytes", C.c_uint64)]
+                ("transform_table", C.c_uint32), ("binned_stages", C.c_uint32), ("xf_table_bytes", C.c_uint64)]
 
 
 class TrayRay(C.Structure):

@@ -665,6 +665,128 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_fallback(const DevScene s
     }
 }
 
+// ---- Ray binning before a traversal stage (round 6) ------------------------------------------------------------------------------------
+// The producers append a chunk's rays as one run of its segment (grouped by direction octant): a wave of k_wf_trace_dyn that refills from 64
+// consecutive entries gets the rays of ONE chunk -- after the first bounce they start anywhere in the scene, so its lanes walk unrelated parts
+// of the trees (lanes 0.36, half the wave cycles waiting, every lane's fetch a cache line of its own). Between the producers and the traversal
+// every SEGMENT of the queue is therefore counting-sorted by (cell of the ray's origin in the scene's box, direction octant) into the queue
+// buffer that is idle during the stage: the same entries, the same segment, the same count, another order -- so the traversal kernel and its
+// control words are untouched, and the 64 rays of a refill start in the same part of BVH<Instance> with the same near-child order
+// (bvh.rs:105-119). Every number a ray produces is a function of the ray (TRAY-CBRNG keys on pixel and sample, never on the schedule), so the
+// per-sample results stay bit-identical; only the order of the film's f32 sums moves, as with any change of schedule.
+//   k_wf_bin_hist     one workgroup per WF_BIN_EPB entries of a segment: histogram of the keys in LDS, then one atomic per bin present
+//                     into the segment's global histogram
+//   k_wf_bin_scatter  the same workgroup shape: exclusive scan of the segment's histogram (LDS), the workgroup's own counts reserve a range
+//                     per bin with one atomic each, every entry is copied to base[bin] + reserved + its rank inside the workgroup
+// Cost: the queue is read twice and written once (96 B per ray against the ~350 B a stage A ray moves through HBM).
+#ifndef WF_BIN_CELL_BITS
+#define WF_BIN_CELL_BITS 2   // cells per axis = 2^bits over the box of BVH<Instance>
+#endif
+#define WF_BINS (8u << (3 * WF_BIN_CELL_BITS))
+#define WF_BIN_EPB 4096u     // queue entries per workgroup of the two passes
+#ifndef WF_BIN_DEFAULT
+#define WF_BIN_DEFAULT 3u    // stages whose rays are binned: bit 0 = A (camera / continuation rays), bit 1 = B (occlusion rays); TRAYHIP_WF_BIN overrides
+#endif
+struct WfBinGrid { float lo[3], scale[3]; };   // cell = clamp((o - lo) * scale) per axis; scale = cells / extent (0 for a flat or unbounded axis)
+// (host) the grid over a box -- the root of the frame's BVH<Instance>
+inline WfBinGrid wf_bin_grid(const float* bmin, const float* bmax) {
+    WfBinGrid g{};
+    for (int a = 0; a < 3; ++a) {
+        const float ext = bmax[a] - bmin[a];
+        const bool usable = bmin[a] - bmin[a] == 0.0f && ext - ext == 0.0f && ext > 0.0f;   // finite and not flat (a flat or unbounded axis is one cell)
+        g.lo[a] = usable ? bmin[a] : 0.0f;
+        g.scale[a] = usable ? (float)(1u << WF_BIN_CELL_BITS) / ext : 0.0f;
+    }
+    return g;
+}
+TR_DEV uint32_t wf_bin_key(const WfBinGrid& g, f3 o, f3 d) {
+    const float m = (float)((1u << WF_BIN_CELL_BITS) - 1u);
+    // (fmaxf / fminf return the other operand for a NaN: an origin that is not a number lands in cell 0; the key only orders, it never decides)
+    const uint32_t cx = (uint32_t)fminf(fmaxf((o.x - g.lo[0]) * g.scale[0], 0.0f), m);
+    const uint32_t cy = (uint32_t)fminf(fmaxf((o.y - g.lo[1]) * g.scale[1], 0.0f), m);
+    const uint32_t cz = (uint32_t)fminf(fmaxf((o.z - g.lo[2]) * g.scale[2], 0.0f), m);
+    uint32_t cell = 0u;   // Morton order: neighbouring bins are neighbouring cells
+#pragma unroll
+    for (uint32_t b = 0; b < WF_BIN_CELL_BITS; ++b) cell |= (((cx >> b) & 1u) << (3u * b)) | (((cy >> b) & 1u) << (3u * b + 1u)) | (((cz >> b) & 1u) << (3u * b + 2u));
+    return (cell << 3) | wf_octant(d);
+}
+TR_DEV uint32_t wf_bin_entry_key(const WfBinGrid& g, const uint32_t* __restrict__ queue, size_t pos) {
+    const uint4* __restrict__ rr = reinterpret_cast<const uint4*>(queue + pos * WF_RAY_WORDS);
+    const uint4 r0 = rr[0], r1 = rr[1];
+    return wf_bin_key(g, mk(__uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w)), mk(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z)));
+}
+// bin_ctl: [WF_SEGS][WF_BINS] histogram, then [WF_SEGS][WF_BINS] cursors; zeroed by the host before the round
+template <int STAGE>
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_bin_hist(WfPool pool, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qctl,
+                                                          uint32_t* __restrict__ bin_ctl, WfBinGrid grid) {
+    __shared__ uint32_t s_h[WF_BINS];
+    const uint32_t seg = wf_my_seg(), e0 = blockIdx.x / WF_SEGS * WF_BIN_EPB;
+    const uint32_t cnt = qctl[seg * WF_SEG_STRIDE + STAGE];
+    if (e0 >= cnt) return;   // (the whole workgroup)
+    for (uint32_t b = threadIdx.x; b < WF_BINS; b += TR_BLOCK) s_h[b] = 0u;
+    __syncthreads();
+    const uint32_t e1 = min(cnt, e0 + WF_BIN_EPB);
+    for (uint32_t e = e0 + threadIdx.x; e < e1; e += TR_BLOCK) atomicAdd(&s_h[wf_bin_entry_key(grid, queue, (size_t)seg * pool.seg_cap + e)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < WF_BINS; b += TR_BLOCK) { const uint32_t c = s_h[b]; if (c) atomicAdd(bin_ctl + seg * WF_BINS + b, c); }
+}
+template <int STAGE>
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_bin_scatter(WfPool pool, const uint32_t* __restrict__ queue, uint32_t* __restrict__ sorted,
+                                                             const uint32_t* __restrict__ qctl, uint32_t* __restrict__ bin_ctl, WfBinGrid grid) {
+    __shared__ uint32_t s_base[WF_BINS], s_cnt[WF_BINS], s_part[TR_BLOCK];
+    const uint32_t seg = wf_my_seg(), e0 = blockIdx.x / WF_SEGS * WF_BIN_EPB;
+    const uint32_t cnt = qctl[seg * WF_SEG_STRIDE + STAGE];
+    if (e0 >= cnt) return;
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t PER = WF_BINS / TR_BLOCK;   // bins per thread of the scan
+    static_assert(WF_BINS % TR_BLOCK == 0 && PER >= 1, "the scan deals the bins out evenly");
+    // exclusive scan of the segment's histogram: per-thread runs, a Hillis-Steele scan of the 256 run totals, then the runs again
+    const uint32_t* __restrict__ hist = bin_ctl + seg * WF_BINS;
+    uint32_t run = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) run += hist[tid * PER + k];
+    s_part[tid] = run;
+    for (uint32_t b = tid; b < WF_BINS; b += TR_BLOCK) s_cnt[b] = 0u;
+    __syncthreads();
+    for (uint32_t off = 1u; off < TR_BLOCK; off <<= 1) {
+        const uint32_t v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t acc = s_part[tid] - run;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) { s_base[tid * PER + k] = acc; acc += hist[tid * PER + k]; }
+    // the workgroup's entries: key and rank inside the workgroup (the order inside a bin is whatever the LDS atomics make it: any order serves)
+    const uint32_t e1 = min(cnt, e0 + WF_BIN_EPB);
+    constexpr uint32_t ROUNDS = WF_BIN_EPB / TR_BLOCK;
+    uint32_t key_rank[ROUNDS];
+#pragma unroll
+    for (uint32_t k = 0; k < ROUNDS; ++k) {
+        const uint32_t e = e0 + k * TR_BLOCK + tid;
+        key_rank[k] = 0xffffffffu;
+        if (e < e1) {
+            const uint32_t key = wf_bin_entry_key(grid, queue, (size_t)seg * pool.seg_cap + e);
+            key_rank[k] = (key << 16) | atomicAdd(&s_cnt[key], 1u);   // (rank < WF_BIN_EPB <= 65536, key < WF_BINS <= 65535)
+        }
+    }
+    static_assert(WF_BIN_EPB <= 65536u && WF_BINS < 65535u, "key and rank share a word");
+    __syncthreads();
+    // one atomic per bin present: where this workgroup's entries of the bin go inside the bin's range
+    uint32_t* __restrict__ cursor = bin_ctl + WF_SEGS * WF_BINS + seg * WF_BINS;
+    for (uint32_t b = tid; b < WF_BINS; b += TR_BLOCK) { const uint32_t c = s_cnt[b]; if (c) s_base[b] += atomicAdd(cursor + b, c); }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < ROUNDS; ++k) {
+        if (key_rank[k] == 0xffffffffu) continue;
+        const uint32_t e = e0 + k * TR_BLOCK + tid;
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(queue + ((size_t)seg * pool.seg_cap + e) * WF_RAY_WORDS);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(sorted + ((size_t)seg * pool.seg_cap + s_base[key_rank[k] >> 16] + (key_rank[k] & 0xffffu)) * WF_RAY_WORDS);
+        const uint4 r0 = src[0], r1 = src[1];
+        dst[0] = r0; dst[1] = r1;
+    }
+}
+
 // Stage A shading: vertex_begin for the slots whose ray hit, end of the sample for those that missed.
 // Material sort (north_star: "material sort in LDS"): when kind_queues is given, the vertices this workgroup just set up are
 // counted per material kind in LDS (one ds_add_rtn per vertex gives its rank inside the workgroup's share), the workgroup

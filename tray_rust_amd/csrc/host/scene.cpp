@@ -1209,6 +1209,12 @@ static void flatten(TrayHostScene& s, uint32_t frame) {
     // Meshes: nothing in them depends on the frame (the loader's meshes are immutable), so the arrays of the first flatten serve every later one --
     // copying 3.1 M triangles and their trees anew was 0.1 s per frame of the tr15 stand-in, most of what a frame update cost beside its kernels
     bool any_keys = s.f_any_keys;
+    if (!s.f_meshes_done) {
+        // (a retry after a flatten that threw inside this loop -- bad_alloc on a large scene; the handle stays usable -- starts from empty arrays,
+        // not on top of the partly filled ones: ADVICE round 5)
+        s.f_meshes.clear(); s.f_mesh_nodes.clear(); s.f_verts.clear(); s.f_attrs.clear(); s.f_mesh_keys.clear(); s.f_key_times.clear();
+        any_keys = false;
+    }
     if (!s.f_meshes_done)
     for (auto& m : s.meshes) {
         TrayMesh tm{};
