@@ -419,18 +419,17 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
     std::memset(&stats, 0, sizeof stats);
     const uint32_t kf = key_frame_host(seed, e.d.frame);
     const int feat = feature_set(e);
-    uint32_t slice_shift = 0u;   // launch_tiles' rule: tiles are cut into sample slices when there are few of them per workgroup
-    if ((spp >> 1) >= 256u && work < 12u * blocks) slice_shift = 1u;
-    if ((spp >> 2) >= 256u && work < 3u * blocks) slice_shift = 2u;
-    if (const char* e_ = getenv("TRAYHIP_TILE_SLICES")) { slice_shift = 0u; while ((2u << slice_shift) <= (uint32_t)std::max(1, atoi(e_)) && (spp >> (slice_shift + 1u)) >= 4u) ++slice_shift; }
+    uint32_t levels = 1u;   // launch_tiles' rule: tiles are cut into progressive sample slices when there are few of them per workgroup
+    { const uint32_t most = work < 12u * blocks ? 5u : 3u; while (levels < most && (spp >> levels) >= 64u) ++levels; }
+    if (const char* e_ = getenv("TRAYHIP_TILE_SLICES")) { levels = 1u; const uint32_t want = (uint32_t)std::max(1, atoi(e_)); while (levels < want && (spp >> levels) >= 1u) ++levels; }
     int rc;
     // tray_scene_create: the instantiation with mis_ray_filter for scenes with a sphere light or specular lobes
     bool light_filter = (feat & FEAT_SPEC) != 0;
     for (uint32_t l = 0; l < f->n_lights; ++l)
         if (f->instances[f->lights[l]].kind != TRAY_INST_POINT_EMITTER && f->instances[f->lights[l]].geom_type == TRAY_GEOM_SPHERE) light_filter = true;
-#define EMU_TILES_L(A, F, L) launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<A, F, TRAY_INTEGRATOR_PATH, L>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, slice_shift, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
+#define EMU_TILES_L(A, F, L) launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<A, F, TRAY_INTEGRATOR_PATH, L>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, levels, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
 #define EMU_TILES(F) rc = moving ? (light_filter ? EMU_TILES_L(1, F, true) : EMU_TILES_L(1, F, false)) : (light_filter ? EMU_TILES_L(0, F, true) : EMU_TILES_L(0, F, false))
-#define EMU_WHITTED(A) launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<A, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, slice_shift, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
+#define EMU_WHITTED(A) launch_simt(blocks, TR_BLOCK, [&] { k_path_tiles<A, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>(e.d, tiles.data() + tile_start, work, chunk, chunk_stride, spp, kf, levels, rgbw, &counter, &stats); }, (size_t)stack_words * 4)
     if (e.d.integrator == TRAY_INTEGRATOR_WHITTED) rc = moving ? EMU_WHITTED(1) : EMU_WHITTED(0);   // launch_tiles: one instantiation per ANIM
     else if (feat == FEAT_NONE) EMU_TILES(FEAT_NONE);
     else if (feat == FEAT_MERL) EMU_TILES(FEAT_MERL);
@@ -521,16 +520,17 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
         EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_regen<A>(e.d, pool, chunks.data(), tiles.data(), tile_count, 1u, spp, kf, stats.data(), qr, qa, qctl, slice_shift); }); \
         if (WF_FOLD_C && (bin_stages & 1u)) { EMU_BIN(0, qa, qc, bin_ctl.data()); EMU_TRACE_STAGE(0, A, qc, qb); }   /* wf_round: the binned copy lies in the idle queue's buffer */ \
         else EMU_TRACE_STAGE(0, A, qa, qb);                                                                                                   \
+        std::memset(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t));   /* wf_round: the control words are cleared between trace A and k_wf_begin */ \
         EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_begin<A>(e.d, pool, n_active, stats.data(), qb, qctl, sorted ? kind_queues.data() : nullptr); }); \
         if (WF_FOLD_C && (bin_stages & 2u)) { EMU_BIN(1, qb, qa, bin_ctl.data() + 2u * WF_SEGS * WF_BINS); EMU_TRACE_STAGE(1, A, qa, qc); }     \
         else EMU_TRACE_STAGE(1, A, qb, qc);                                                                                                   \
         if (sorted) {   /* wf_round of kernels.hip: one kind-pure shading launch per material kind of the scene */                        \
             EMU_QUERY_KIND(A, TRAY_MAT_MATTE); EMU_QUERY_KIND(A, TRAY_MAT_PLASTIC); EMU_QUERY_KIND(A, TRAY_MAT_METAL); EMU_QUERY_KIND(A, TRAY_MAT_GLASS); \
             EMU_QUERY_KIND(A, TRAY_MAT_ROUGH_GLASS); EMU_QUERY_KIND(A, TRAY_MAT_SPECULAR_METAL); EMU_QUERY_KIND(A, TRAY_MAT_MERL);          \
-        } else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query<A, FEAT_ALL | FEAT_TEX>(e.d, pool, n_active, WF_FOLD_C ? nullptr : qc, qctl, stats.data()); });  \
-        if (!WF_FOLD_C) EMU_TRACE_STAGE(2, A, qc, qa);                                                                                                        \
+        } else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query<A, FEAT_ALL | FEAT_TEX>(e.d, pool, n_active, WF_FOLD_C ? nullptr : qc, qctl, stats.data(), qa); });  \
+        if (!WF_FOLD_C) EMU_TRACE_STAGE(2, A, qc, qb);                                                                                                        \
     } while (0)
-#define EMU_QUERY_KIND(A, K) do { if (kinds_present & (1u << K)) EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_query_kind<A, K>(e.d, pool, kind_queues.data(), WF_FOLD_C ? nullptr : qc, qctl, stats.data()); }); } while (0)
+#define EMU_QUERY_KIND(A, K) do { if (kinds_present & (1u << K)) EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_query_kind<A, K>(e.d, pool, kind_queues.data(), WF_FOLD_C ? nullptr : qc, qctl, stats.data(), qa); }); } while (0)
 #define EMU_TRACE_STAGE(S, A, Q, FB) /* FB: the queue buffer that is idle during stage S takes the deferred rays' records (wf_round) */                                                                                                          \
     do {                                                                                                                                    \
         EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data(), FB); }, dyn_lds); \
@@ -548,8 +548,8 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
         else if (feat == FEAT_SPEC) EMU_ROUND(A, FEAT_SPEC); else if (feat == (FEAT_MERL | FEAT_SPEC)) EMU_ROUND(A, FEAT_MERL | FEAT_SPEC);  \
         else if (feat == (FEAT_ALL | FEAT_TEX)) EMU_ROUND(A, FEAT_ALL | FEAT_TEX); else EMU_ROUND(A, FEAT_ALL);                                                                                                        \
     } while (0)
+    std::memset(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t));
     while (rc == 0 && counters[1] < n_items) {
-        std::memset(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t));
         std::fill(bin_ctl.begin(), bin_ctl.end(), 0u);
         if (moving) EMU_ROUND_F(1); else EMU_ROUND_F(0);
         if (++rounds > max_rounds) rc = -5;   // "wavefront schedule did not terminate"

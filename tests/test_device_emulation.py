@@ -360,6 +360,22 @@ def test_wavefront_schedule_with_more_chunks_than_queue_segments(tmp_path, built
     assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6
 
 
+def test_wavefront_schedule_with_binned_rays(tmp_path, built, monkeypatch):
+    """TRAYHIP_WF_BIN=3 (off by default: profiles/r06_c5_ray_binning_ab.txt): the rays of stages A and B pass through k_wf_bin_hist / k_wf_bin_scatter
+    before they are traced -- another order, the same rays: the oracle's counts and image, on a static and on a moving scene."""
+    monkeypatch.setenv("TRAYHIP_WF_BIN", "3")
+    w, h, spp = 96, 64, 4
+    scenes.write_assets(str(tmp_path), cornell=(w, h, spp), small=(w, h, spp))
+    scenes.write_moving_box(str(tmp_path), width=w, height=h, samples=spp)
+    for name, frame in (("smallpt", 0), ("moving_box", 3)):
+        scene, *_ = T.Scene.load_file(str(tmp_path / (name + ".json")))
+        flat = scene.flatten(frame)
+        img, (samples, vertices, rays, rounds) = E.render_wavefront(flat, tile_queue(w, h), spp, 8, trace=0, n_chunks=70, trace_blocks=3, lds_depth=4)
+        ref, st = O.render_tiles(flat, spp, seed=8)
+        assert (samples, vertices, rays) == (st.samples, st.vertices, st.rays), name
+        assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6, name
+
+
 def test_ray_binning_kernels_sort_every_segment(built):
     """k_wf_bin_hist + k_wf_bin_scatter (wavefront.h, round 6): every segment of a ray queue comes out as a permutation of itself -- every record
     once, bit for bit -- in non-decreasing key order, the key being (Morton cell of the origin in the box, direction octant) as an independent
@@ -463,7 +479,7 @@ def test_tile_slices_are_the_same_samples(tmp_path, built, monkeypatch):
     scene, *_ = T.Scene.load_file(str(tmp_path / "smallpt.json"))
     flat = scene.flatten(0)
     ref, st = O.render_tiles(flat, spp, seed=4)
-    for slices in ("1", "4"):   # 4 slices of 4 samples: one sample per wave and slice
+    for slices in ("1", "3", "4", "5"):   # items per tile: whole tiles; 8 + 4 + 4 samples; 8 + 4 + 2 + 2; 8 + 4 + 2 + 1 + 1 (progressive, level-major)
         monkeypatch.setenv("TRAYHIP_TILE_SLICES", slices)
         img, s_ = E.render_tiles(flat, tile_queue(w, h), spp, 4, blocks=3)
         assert s_[:3] == (st.samples, st.vertices, st.rays)

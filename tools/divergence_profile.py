@@ -29,6 +29,8 @@ ap.add_argument("--define", action="append", default=[])
 ap.add_argument("--size", default="48x32x16")
 ap.add_argument("--top", type=int, default=32)
 ap.add_argument("--tiles", type=int, default=0, help="render only this many tiles, spread evenly over the Morton queue (a 1920x1080 film's tiles see coherent camera rays: what the bench runs)")
+ap.add_argument("--grid", type=int, default=48, help="dragon: quads per side of the stand-in's grid (660 = the 871 200 triangles of C4)")
+ap.add_argument("--extent", type=float, default=1.0, help="dragon: size of the mesh (0.2 = the bench workload)")
 ap.add_argument("--min-bytes", type=int, default=250, help="hide helpers smaller than this (vector operators: their call overhead is not device work)")
 args = ap.parse_args()
 w, h, spp = (int(x) for x in args.size.split("x"))
@@ -49,7 +51,7 @@ lib.emu_profile_dump.argtypes = [C.c_char_p]
 d = tempfile.mkdtemp(prefix="divprof")
 scenes.write_assets(d, cornell=(w, h, spp), small=(w, h, spp))
 if args.scene == "dragon":
-    scenes.write_dragon_assets(d, film=(w, h, spp), grid=48, extent=1.0)
+    scenes.write_dragon_assets(d, film=(w, h, spp), grid=args.grid, extent=args.extent)
 scene, *_ = T.Scene.load_file(os.path.join(d, args.scene + ".json"))
 flat = scene.flatten(0)
 tiles = np.array(T.BlockQueue((w, h), (8, 8)).blocks, np.uint32).reshape(-1, 2)

@@ -30,11 +30,11 @@ for name, spp, frame in (("cornell_box", 1024, 0), ("smallpt", 4096, 0), ("drago
     else: scenes.write_assets(d, cornell=(W, H, spp), small=(W, H, spp))
     scene, rt, _, fi = T.Scene.load_file(os.path.join(d, name + ".json"))
 
-    def shard_ms(n, reps=2):
+    def shard_ms(n, reps=2, shard=0, chunk=16):
         best = 1e30
         for _ in range(reps):
             assert hiprt.hipMemset(buf, 0, ctypes.c_size_t(nbytes)) == 0
-            hip.render_shard_device(scene, frame, 0, n, spp, buf.value)
+            hip.render_shard_device(scene, frame, shard, n, spp, buf.value, chunk_tiles=chunk)
             hiprt.hipDeviceSynchronize()
             t = hip.timing(scene)
             best = min(best, t.render_ms)
@@ -44,3 +44,8 @@ for name, spp, frame in (("cornell_box", 1024, 0), ("smallpt", 4096, 0), ("drago
     for n in ns:
         ms, sn = shard_ms(n)
         print(f"{name + ' ' + str(spp) + ' spp' + (' frame ' + str(frame) if frame else ''):34s} {n:2d} {whole:15.1f} {ms:16.1f} {sn / ms / 1e3:23.1f} {whole / n / ms * (sn * n / s1):19.3f}", flush=True)
+    if os.environ.get("EIGHTH_ALL_SHARDS"):   # every shard of 8 (the slowest rank sets the frame's time), for several chunk sizes of the round-robin deal
+        for chunk in (16, 4, 1):
+            times = [shard_ms(8, reps=1, shard=k, chunk=chunk)[0] for k in range(8)]
+            print(f"{name:12s} N = 8, chunks of {chunk:2d} tiles: shard times {' '.join(f'{t:7.1f}' for t in times)} ms -> efficiency {whole / 8 / max(times):.3f} (slowest shard), "
+                  f"{whole / sum(times):.3f} (sum of the shards against the whole frame)", flush=True)

@@ -105,6 +105,9 @@ struct DevScene {
     // camera if it moves. The wavefront kernels index it directly (xf_table = 1: xf_cache == xf_tab), the tile kernel copies a path's records into its cache column
     const float* __restrict__ xf_tab;
     uint32_t xf_tab_stride, pad_tab;
+#ifdef TR_SAMPLE_DUMP   // instrumented builds only: [pixel][sample] records the tile kernel writes when a sample is finished (kernels.hip)
+    float4* __restrict__ sample_dump;
+#endif
 };
 
 struct Ray {
@@ -839,12 +842,44 @@ TR_DEV bool own_box_pass(const float* __restrict__ lo, const float* __restrict__
 // GUARD_ACTIVE: the range guard of the world-space reciprocal direction (dev_math.h: rcp_rn3) looks at the lanes that hold a ray only. Measured per
 // instantiation of the tile kernel (profiles/r05_c2_exact_reciprocal_ab.txt): the LFILT kernels (smallpt) lose 1.2 % of their instructions to the
 // compiler's division without it, the others (cornell_box) pay 1.3 % for the mask's scalar registers with it.
+// Round 6: FLAT instances (a rectangle or disk that is alone in a flat BVH<Instance> leaf box and does not move: FlatInst::lane_pass, host/gates.hpp)
+// are not tested where the wave-uniform loop meets them. The loop only notes, per
+// lane, which of them the lane's ray has to test (`pend`, a bit per FlatInst: its gate passed, for occlusion rays its own box too), and a second,
+// PER-LANE pass runs transform + primitive test once per noted instance: every lane takes its lowest pending instance, fetches that instance's record
+// itself, and the pass repeats while any lane has one left. Why: a BVH<Instance> leaf box of an axis-aligned wall is flat -- a ray passes it only
+// where it crosses the wall's rectangle --, so of cornell_box's six rectangles a ray has ONE pending (sometimes the light as well), while the uniform
+// loop ran the object-space transform for the whole wave and the rectangle test at 14 - 33 % of the lanes six times per trace
+// (profiles/r05_divergence_profiles.txt); the per-lane pass runs 1 - 2 times. Exactness: the accept rule below is the one of the uniform loop and does
+// not depend on the order in which a lane meets its candidates (see the argument above: whatever order the reference or this loop visits them in, the
+// unique closest candidate wins or `hazard` is set), meshes are still met in loop order, and the gate's entry distance is recomputed from the same
+// box with the same arithmetic.
+#ifndef TR_FLAT_PEND
+#define TR_FLAT_PEND 1
+#endif
 template <int ANIM, bool GUARD_ACTIVE = false>
 TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, bool active, HitRec& rec, bool& hazard) {
     const float min_t = ray.min_t, gate_max_t = ray.max_t;
     float max_t = ray.max_t;          // closest accepted candidate so far
     float best_gate = -TR_INF;        // G of that candidate
     bool any = false, done = !active;   // lanes without a ray run along: the cooperative leaf test uses their ALUs
+    uint32_t pend = 0u;               // simple instances this lane's ray still has to test (bit = FlatInst index; TR_FLAT_MAX <= 32)
+    static_assert(TR_FLAT_MAX <= 32, "one bit per instance of the flat loop");
+    // the accept rule of a candidate (R1 / R2 above), shared by the uniform loop and the per-lane pass
+#define TR_FLAT_ACCEPT(t_, prim_, b1_, b2_, leaf_t_, hz_, box_t_, inst_id_) do {                                                          \
+        const float gate_new_ = fmaxf((box_t_), (leaf_t_));                                                                                \
+        const bool closer_ = !any || (t_) < max_t;                                                                                         \
+        if (!any_hit) {                                                                                                                    \
+            if (!closer_) hazard = true;                              /* R1: a second candidate inside the window of the closest one */    \
+            else if (any && !(gate_new_ < max_t)) hazard = true;      /* R2: the previous closest one lies inside the window of the new one */ \
+            if ((hz_) || (box_t_) != (box_t_) || (leaf_t_) != (leaf_t_)) hazard = true;   /* rivals inside a small mesh; NaN entry distances */ \
+        }                                                                                                                                  \
+        if (closer_) {                                                                                                                     \
+            max_t = (t_); best_gate = gate_new_;                                                                                           \
+            rec.t = (t_); rec.inst = (inst_id_); rec.prim = (prim_); rec.b1 = (b1_); rec.b2 = (b2_);                                       \
+        }                                                                                                                                  \
+        any = true;                                                                                                                        \
+        done = any_hit;                                                                                                                    \
+    } while (0)
     const f3 w_inv_dir = rcp_rn3(ray.d, !GUARD_ACTIVE || active);
     const bool wnx = ray.d.x < 0.0f, wny = ray.d.y < 0.0f, wnz = ray.d.z < 0.0f;
 #ifdef TR_FLAT_PK
@@ -879,6 +914,10 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
             const bool wanted = gate && !done && (!any_hit || own_redundant || own_box_pass(own_lo, own_hi, ray.o, w_inv_dir, wnx, wny, wnz, min_t, gate_max_t));
             if (!__any(wanted)) continue;   // nobody's ray comes near this instance
             const uint32_t gt = in->geom_type, mesh_id = in->mesh_id, inst_id = in->inst;
+            if (TR_FLAT_PEND && in->lane_pass != 0u) {   // (host/gates.hpp: a rectangle / disk alone behind a flat gate, not moving)
+                if (wanted) pend |= 1u << (first + k);   // the per-lane pass below tests it
+                continue;
+            }
             float inv[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) inv[c] = in->inv[c];
@@ -924,24 +963,38 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
                 else if (gt == TRAY_GEOM_SPHERE) hit = sphere_test(gp0, o, d, min_t, bound, t);
                 else hit = disk_test(gp0, gp1, o, d, min_t, bound, t);
             }
-            if (hit) {
-                const float gate_new = fmaxf(box_t, leaf_t);
-                const bool closer = !any || t < max_t;
-                if (!any_hit) {
-                    if (!closer) hazard = true;                              // R1: a second candidate inside the window of the closest one
-                    else if (any && !(gate_new < max_t)) hazard = true;      // R2: the previous closest one lies inside the window of the new one
-                    if (hz || box_t != box_t || leaf_t != leaf_t) hazard = true;   // rivals inside a small mesh; NaN entry distances
-                }
-                if (closer) {
-                    max_t = t; best_gate = gate_new;
-                    rec.t = t; rec.inst = inst_id; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
-                }
-                any = true;
-                done = any_hit;
-            }
+            if (hit) TR_FLAT_ACCEPT(t, prim, b1, b2, leaf_t, hz, box_t, inst_id);
         }
         if (__all(done)) break;
     }
+    // the per-lane pass over the simple instances noted above
+    while (TR_FLAT_PEND && __any(pend != 0u && !done)) {
+        if (pend != 0u && !done) {
+            const uint32_t k = (uint32_t)__ffsll((long long)pend) - 1u;
+            pend &= pend - 1u;
+            const tray::FlatInst* __restrict__ in = sc.flat_insts + k;   // (the lane's own record: vector loads; sixteen records at most, cache resident)
+            const float4* __restrict__ q = reinterpret_cast<const float4*>(in);
+            const float4 m0 = q[0], m1 = q[1], m2 = q[2], m3 = q[3], g1 = q[5], g2 = q[6];   // inv rows 0 .. 3; (hi.y, hi.z, gp0, gp1); (geom_type, mesh_id, inst, animated)
+            const uint32_t leaf = in->leaf;
+            static_assert(offsetof(tray::FlatInst, gp0) == 88 && offsetof(tray::FlatInst, geom_type) == 96 && offsetof(tray::FlatInst, inst) == 104, "the quarters of a FlatInst record");
+            const float inv[16] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w, m3.x, m3.y, m3.z, m3.w};
+            const float gp0 = g1.z, gp1 = g1.w;
+            const uint32_t gt = __float_as_uint(g2.x), inst_id = __float_as_uint(g2.z);
+            const float4* __restrict__ lq = reinterpret_cast<const float4*>(sc.flat_leaves + leaf);
+            const float4 l0 = lq[0], l1 = lq[1];   // (bmin, bmax.x), (bmax.y, bmax.z, first, count)
+            float box_t = 0.0f;
+            // (the gate passed in the uniform loop -- that is why the instance is pending --; this is its entry distance again: same box, same ray, same arithmetic)
+            (void)bbox_hit_t(l0, make_float4(l1.x, l1.y, 0.0f, 0.0f), ray.o, w_inv_dir, wnx, wny, wnz, min_t, gate_max_t, box_t);
+            const f3 o = xf_point(inv, ray.o), d = xf_vector(inv, ray.d);   // Instance::intersect (receiver.rs:29-35)
+            const float bound = fmaxf(max_t, best_gate);
+            float t = bound;
+            bool hit;
+            if (gt == TRAY_GEOM_RECT) hit = rect_test(gp0, gp1, o, d, min_t, bound, t);
+            else hit = disk_test(gp0, gp1, o, d, min_t, bound, t);
+            if (hit) TR_FLAT_ACCEPT(t, 0u, 0.0f, 0.0f, -TR_INF, false, box_t, inst_id);
+        }
+    }
+#undef TR_FLAT_ACCEPT
     return any;
 }
 

@@ -196,7 +196,7 @@ static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, ui
     hipLaunchKernelGGL(k_wf_regen<ANIM>, qgrid, block, 0, stream, v.dev, v.pool, v.chunks, tiles, chunk, chunk_stride, spp, kf, s->d_stats, v.qr, v.qa, v.qctl, slice_shift);
     // (each traversal is followed by the few-thread kernel that traces the rays it handed over to the reference's binary traversal:
     // direction components that are zero / denormal / not finite -- normally none, the kernel reads one word and exits. The deferred rays'
-    // records go to the buffer of the ray queue that is idle during the stage: B's during A, C's during B, A's during C)
+    // records go to the buffer of a ray queue that is idle during the stage: B's during A, C's during B, B's during C)
     const dim3 fgrid(8);
     // ray binning (wavefront.h: k_wf_bin_hist / k_wf_bin_scatter): the stage's queue, every segment sorted by (origin cell, direction octant) into the
     // ray queue that is idle during the stage -- C's for stage A (WF_FOLD_C: nobody fills it), A's for stage B (consumed by then) --, which is what
@@ -210,6 +210,10 @@ static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, ui
     }
     hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, trace_a, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qb);
     hipLaunchKernelGGL((k_wf_trace_fallback<0, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qb);
+    // the control words of every queue are cleared HERE, between the traversal of stage A and the first shading kernel: queue A, its cursors, the
+    // regeneration queue and stage A's fallback counter are consumed, stage B's and the material kinds' are not produced yet -- and the count of
+    // queue A must survive from the query kernels below (which append the NEXT round's continuation rays) to the next round's traversal
+    (void)hipMemsetAsync(v.qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), stream);
     hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, v.dev, v.pool, n_active, s->d_stats, v.qb, v.qctl, v.kq);
     const uint32_t* trace_b = v.qb;
     if (WF_FOLD_C && v.bin_ctl && (s->wf_bin_stages & 2u)) {
@@ -222,14 +226,15 @@ static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, ui
     hipLaunchKernelGGL((k_wf_trace_fallback<1, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qc);
     uint32_t* const qc = WF_FOLD_C ? nullptr : v.qc;   // (WF_FOLD_C: stage C rays travel with the next round's stage A rays, no queue and no launch of their own)
     if (v.kq) {   // kind-pure shading over the sorted queues: one launch per material kind the scene contains
-#define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), qgrid, block, 0, stream, v.dev, v.pool, v.kq, qc, v.qctl, s->d_stats)
+#define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), qgrid, block, 0, stream, v.dev, v.pool, v.kq, qc, v.qctl, s->d_stats, v.qa)
         WF_QUERY_KIND(TRAY_MAT_MATTE); WF_QUERY_KIND(TRAY_MAT_PLASTIC); WF_QUERY_KIND(TRAY_MAT_METAL); WF_QUERY_KIND(TRAY_MAT_GLASS);
         WF_QUERY_KIND(TRAY_MAT_ROUGH_GLASS); WF_QUERY_KIND(TRAY_MAT_SPECULAR_METAL); WF_QUERY_KIND(TRAY_MAT_MERL);
 #undef WF_QUERY_KIND
-    } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT_ALL | FEAT_TEX>), grid, block, 0, stream, v.dev, v.pool, n_active, qc, v.qctl, s->d_stats);
+    } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT_ALL | FEAT_TEX>), grid, block, 0, stream, v.dev, v.pool, n_active, qc, v.qctl, s->d_stats, v.qa);
     if (WF_FOLD_C) return;
-    hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qc, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qa);
-    hipLaunchKernelGGL((k_wf_trace_fallback<2, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qa);
+    // (builds without WF_FOLD_C: the deferred rays of stage C go to B's buffer -- A's holds the next round's continuation rays by now)
+    hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qc, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qb);
+    hipLaunchKernelGGL((k_wf_trace_fallback<2, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qb);
 }
 
 // Path pool slots of the wavefront schedule: never more than the film has pixels x 4 x WF_MAX_SLICES (a chunk of 256 per tile slice), and for
@@ -968,10 +973,10 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
     const uint64_t tiles_per_chunk = (tile_count + n_chunks - 1) / n_chunks;
     const uint64_t max_rounds = tiles_per_chunk * (((uint64_t)(spp >> slice_shift) + 3) / 4 * ((WF_FOLD_C ? 2u : 1u) * s->dev.max_depth + 3) + 4) + 2 * WF_POLL;   // (WF_FOLD_C: a vertex with a stage C ray takes two rounds)
     bool done = false;
+    for (uint32_t k = 0; k < n_views; ++k) HIP_CHECK(hipMemsetAsync(views[k].qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), views[k].stream));   // (later: inside wf_round)
     for (uint32_t round = 0; !done; ++round) {
         for (uint32_t k = 0; k < n_views; ++k) {
             const WfView& v = views[k];
-            HIP_CHECK(hipMemsetAsync(v.qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), v.stream));
             if (v.bin_ctl && s->wf_bin_stages) HIP_CHECK(hipMemsetAsync(v.bin_ctl, 0, (size_t)2u * 2u * WF_SEGS * WF_BINS * sizeof(uint32_t), v.stream));
             if (s->animated) wf_round<1>(s, v, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, slice_shift);
             else wf_round<0>(s, v, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, slice_shift);
@@ -1212,24 +1217,38 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     s->last_was_wavefront = false;
     { const int rc = xf_table_prepare(s, (uint64_t)tile_count * 64u * spp, stream); if (rc != TRAY_OK) return rc; }
     if (s->wavefront) return launch_wavefront(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
-    // Slices per tile. A slice costs its own film resolve and flush, so tiles are only halved (quartered) when a launch has fewer than
-    // 12 (3) of them per workgroup and a slice keeps >= 256 samples per pixel -- measured on one GPU's share of C2 at 8 GPUs (4050
-    // tiles, tools/shard_tail.py): 1 / 2 / 4 / 8 / 16 slices = 797.8 / 836.6 / 819.1 / 809.5 / 772.7 Msamples/s; at 4 GPUs 851.8 /
-    // 859.2 / 846.2 / 819.1; the whole frame on one GPU loses 1 % with 2. TRAYHIP_TILE_SLICES overrides.
-    uint32_t slice_shift = 0u;
-    if ((spp >> 1) >= 256u && tile_count < 12u * (uint32_t)s->n_blocks) slice_shift = 1u;
-    if ((spp >> 2) >= 256u && tile_count < 3u * (uint32_t)s->n_blocks) slice_shift = 2u;
-    if (const char* e = getenv("TRAYHIP_TILE_SLICES")) { slice_shift = 0u; while ((2u << slice_shift) <= (uint32_t)std::max(1, atoi(e)) && (spp >> (slice_shift + 1u)) >= 4u) ++slice_shift; }
-    int blocks = (int)std::min<uint64_t>((uint64_t)s->n_blocks, (uint64_t)tile_count << slice_shift);
+    // Items per tile (k_path_tiles: progressive slices, level-major: the launch ends with its smallest items). A slice costs its own film resolve and
+    // flush and keeps >= 64 samples per pixel. Measured (profiles/r06_tile_slices_progressive_ab.txt, items per tile 1 / 2 / 3 / 4 / 5): the whole
+    // dragon frame 718.5 / 740.6 / 750.3 / 752.7 / 755.1 Msamples/s (tiles that show the mesh cost several times a wall tile: with whole tiles the last
+    // round of the 768 workgroups is one such tile), the whole cornell_box frame 1160.9 / 1163.5 / 1163.6 / 1159.9 / 1154.3; a GPU's eighth of the
+    // frame (4050 tiles, slowest of the eight shards against an eighth of the whole frame): dragon 0.449 / 0.632 / 0.784 / 0.862 / 0.872,
+    // cornell_box 0.895 / 0.942 / 0.960 / 0.971 / 0.975. So: three items per tile for a launch with many tiles per workgroup, up to five for a small one.
+    // TRAYHIP_TILE_SLICES=<items per tile> overrides.
+    uint32_t levels = 1u;
+    {
+        const uint32_t most = tile_count < 12u * (uint32_t)s->n_blocks ? 5u : 3u;
+        while (levels < most && (spp >> levels) >= 64u) ++levels;   // (the last two slices are spp >> (levels - 1) samples each)
+    }
+    if (const char* e = getenv("TRAYHIP_TILE_SLICES")) { levels = 1u; const uint32_t want = (uint32_t)std::max(1, atoi(e)); while (levels < want && (spp >> levels) >= 1u) ++levels; }
+    int blocks = (int)std::min<uint64_t>((uint64_t)s->n_blocks, (uint64_t)tile_count * levels);
+#ifdef TR_SAMPLE_DUMP
+    void* dump_buf = nullptr;
+    const size_t dump_bytes = (size_t)s->dev.width * s->dev.height * spp * 8 * sizeof(float);
+    if (getenv("TRAYHIP_SAMPLE_DUMP")) {
+        HIP_CHECK(hipMalloc(&dump_buf, dump_bytes));
+        HIP_CHECK(hipMemset(dump_buf, 0, dump_bytes));
+    }
+    s->launch_dev.sample_dump = static_cast<float4*>(dump_buf);
+#endif
     HIP_CHECK(hipEventRecord(s->ev0, stream));
 #define PATH_TILES_L(A, F, L) hipLaunchKernelGGL((k_path_tiles<A, F, TRAY_INTEGRATOR_PATH, L>), dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->launch_dev, s->d_tiles + tile_start, \
-                                                 tile_count, chunk, chunk_stride, spp, kf, slice_shift, rgbw_dev, s->d_counter, s->d_stats)
+                                                 tile_count, chunk, chunk_stride, spp, kf, levels, rgbw_dev, s->d_counter, s->d_stats)
 #define PATH_TILES(A, F) do { if (s->light_filter) PATH_TILES_L(A, F, true); else PATH_TILES_L(A, F, false); } while (0)
 #define PATH_TILES_F(A) do { if (s->feat == FEAT_NONE) PATH_TILES(A, FEAT_NONE); else if (s->feat == FEAT_MERL) PATH_TILES(A, FEAT_MERL); \
                              else if (s->feat == FEAT_SPEC) PATH_TILES(A, FEAT_SPEC); else if (s->feat == (FEAT_MERL | FEAT_SPEC)) PATH_TILES(A, FEAT_MERL | FEAT_SPEC); \
                              else if (s->feat == (FEAT_ALL | FEAT_TEX)) PATH_TILES(A, FEAT_ALL | FEAT_TEX); else PATH_TILES(A, FEAT_ALL); } while (0)
 #define WHITTED_TILES(A) hipLaunchKernelGGL((k_path_tiles<A, FEAT_ALL | FEAT_TEX, TRAY_INTEGRATOR_WHITTED>), dim3(blocks), dim3(TR_BLOCK), s->stack_bytes, stream, s->launch_dev, \
-                                             s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf, slice_shift, rgbw_dev, s->d_counter, s->d_stats)
+                                             s->d_tiles + tile_start, tile_count, chunk, chunk_stride, spp, kf, levels, rgbw_dev, s->d_counter, s->d_stats)
     if (s->dev.integrator == TRAY_INTEGRATOR_WHITTED) { if (s->animated) WHITTED_TILES(1); else WHITTED_TILES(0); }
     else if (s->animated) PATH_TILES_F(1);
     else PATH_TILES_F(0);
@@ -1241,6 +1260,15 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     HIP_CHECK(hipEventRecord(s->ev1, stream));
     s->timing_valid = true;
     s->launches = 1;
+#ifdef TR_SAMPLE_DUMP   // instrumented builds only: TRAYHIP_SAMPLE_DUMP=<file> receives width x height x spp records of two float4 (radiance, vertices | final throughput, bounce) of the launch
+    if (dump_buf) {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        std::vector<float> host(dump_bytes / sizeof(float));
+        HIP_CHECK(hipMemcpy(host.data(), dump_buf, dump_bytes, hipMemcpyDeviceToHost));
+        (void)hipFree(dump_buf);
+        if (FILE* fp = std::fopen(getenv("TRAYHIP_SAMPLE_DUMP"), "wb")) { std::fwrite(host.data(), 1, dump_bytes, fp); std::fclose(fp); }
+    }
+#endif
     return TRAY_OK;
 }
 

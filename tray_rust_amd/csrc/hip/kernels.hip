@@ -222,7 +222,7 @@ TR_DEV const float* sc_filter_table(const DevScene& sc) { return sc.filter_table
 // the others 2 %: cornell_box 755 -> 740 Msamples/s at 64 spp).
 template <int ANIM, int FEAT, int INTEG = TRAY_INTEGRATOR_PATH, bool LFILT = false>
 __global__ __launch_bounds__(TR_BLOCK, (FEAT == 15 || INTEG != TRAY_INTEGRATOR_PATH) ? TR_MIN_WAVES_SIDE : ANIM ? TR_MIN_WAVES_ANIM : TR_MIN_WAVES) void k_path_tiles(const DevScene scv, const uint2* __restrict__ tiles, uint32_t tile_count,
-                                                         uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf, uint32_t slice_shift,
+                                                         uint32_t chunk, uint32_t chunk_stride, uint32_t spp, uint32_t kf, uint32_t levels,
                                                          float* __restrict__ rgbw, uint32_t* __restrict__ counter,
                                                          DevStats* __restrict__ stats) {
     const float* __restrict__ const s_table = sc_filter_table(scv);   // the 16 x 16 table stays in global memory (1 KB, cache resident): with the row-binned film only
@@ -260,13 +260,17 @@ __global__ __launch_bounds__(TR_BLOCK, (FEAT == 15 || INTEG != TRAY_INTEGRATOR_P
         if (film_rows) { for (uint32_t i = tid; i < ROWBIN_SIZE; i += TR_BLOCK) s_rowbin[i] = 0.0f; }
         else for (uint32_t i = tid; i < 4 * WIN_PLANE; i += TR_BLOCK) s_win[i] = 0.0f;
         __syncthreads();
-        // a work item is one SLICE of a tile: samples [sl, sl + 1) * (spp >> slice_shift) of its 64 pixels. The film is a sum, so the
-        // slices of a tile are independent; launch_tiles cuts tiles when there are too few of them per workgroup for an even finish
-        // (a GPU's share of the frame at 8 GPUs is 5.3 tiles per workgroup: 6 rounds of whole tiles, or 5.3 rounds of sixteenths)
+        // A work item is one SLICE of a tile's samples. The film is a sum and every sample is keyed by pixel and index, so the slices of a tile are
+        // independent. Round 6: the slices are PROGRESSIVE and the queue is level-major -- with `levels` = L items per tile, level 0 of every tile
+        // (the first half of its samples) comes first, then level 1 of every tile (the next quarter), ..., the last two levels are spp / 2^(L-1)
+        // samples each: the launch starts with large items (one film resolve per item) and ENDS with small ones, so the last round of the persistent
+        // workgroups is 1 / 2^(L-1) of a tile instead of a whole one. That is what a GPU's share of a frame needs when tiles differ in cost: one
+        // eighth of the dragon frame ran at 0.70 of the whole frame's rate with two equal slices per tile, because a workgroup that drew a
+        // mesh tile last kept the launch alive for half a heavy tile (profiles/r06_eighth_rate_all_shards.txt). L = 1: whole tiles.
         const uint32_t item = s_tile;
-        if ((item >> slice_shift) >= tile_count) break;
-        const uint32_t ti = item >> slice_shift;
-        const uint32_t s_per_slice = spp >> slice_shift, s_lo = (item & ((1u << slice_shift) - 1u)) * s_per_slice;
+        if (item >= tile_count * levels) break;
+        const uint32_t level = item / tile_count, ti = item - level * tile_count, last = levels - 1u;
+        const uint32_t s_per_slice = level < last ? spp >> (level + 1u) : spp >> last, s_lo = level < last ? spp - (spp >> level) : spp - (spp >> last);
         const uint2 tile = tiles[(ti / chunk) * chunk_stride * chunk + (ti % chunk)];
         const int x0 = (int)tile.x * 8, y0 = (int)tile.y * 8;
         // The (pixel, sample) pairs of the slice are handed out dynamically: a lane whose path ended takes the next pair of the
@@ -279,6 +283,9 @@ __global__ __launch_bounds__(TR_BLOCK, (FEAT == 15 || INTEG != TRAY_INTEGRATOR_P
         uint32_t row_l = 0u;       // pixel row (0..7) of the lane's current sample: row bin of the film
         bool pending = false;
         float sx = 0.0f, sy = 0.0f;
+#ifdef TR_SAMPLE_DUMP
+        size_t dump_idx = 0; uint32_t dump_v = 0u;
+#endif
         Lane ln;
         ln.flags = 0u;
         ln.illum = mk(0.0f, 0.0f, 0.0f);
@@ -291,6 +298,12 @@ __global__ __launch_bounds__(TR_BLOCK, (FEAT == 15 || INTEG != TRAY_INTEGRATOR_P
             uint32_t kidx = 0u;
             const bool idle = !(ln.flags & LF_ALIVE);
             if (idle && pending) {   // the previous sample of this lane is finished: RenderTarget::write it
+#ifdef TR_SAMPLE_DUMP   // instrumented builds only (tools/tile_sample_dump.py): the tile kernel's OWN per-sample radiance, unclamped, + the number of vertices shaded
+                if (sc.sample_dump) {
+                    sc.sample_dump[2 * dump_idx] = make_float4(ln.illum.x, ln.illum.y, ln.illum.z, (float)dump_v);
+                    sc.sample_dump[2 * dump_idx + 1] = make_float4(ln.throughput.x, ln.throughput.y, ln.throughput.z, (float)ln.bounce);   // (where the path stopped)
+                }
+#endif
                 if (film_rows) film_splat_rows(sc, s_rowbin, s_tx, rgbw, s_table, x0, y0, (int)row_l, sx, sy, lane_result(ln));
                 else film_splat(sc, s_win, s_table, x0, y0, sx, sy, lane_result(ln));
                 pending = false;
@@ -318,6 +331,9 @@ __global__ __launch_bounds__(TR_BLOCK, (FEAT == 15 || INTEG != TRAY_INTEGRATOR_P
                     row_l = pix >> 3;
                     started = true;
                     pending = true;
+#ifdef TR_SAMPLE_DUMP
+                    dump_idx = (size_t)(py * sc.width + px) * spp + s; dump_v = 0u;
+#endif
                 }
             }
             if (ANIM && idle_m != 0ull) xf_cache_fill_wave(sc, started, ln.time, ln.col, kidx);   // the paths' transforms of the moving instances, once per camera sample: the whole wave evaluates for the lanes that start one
@@ -353,6 +369,9 @@ __global__ __launch_bounds__(TR_BLOCK, (FEAT == 15 || INTEG != TRAY_INTEGRATOR_P
                 }
                 TR_CLK(stage);   // trace A / B / C
                 if (stage == 0) w_vertices += (uint32_t)__popcll(__ballot(alive && tr_.hit));
+#ifdef TR_SAMPLE_DUMP
+                if (stage == 0 && alive && tr_.hit) ++dump_v;
+#endif
                 if (stage == 1) {
                     vertex_queries<ANIM, FEAT>(sc, ln, tr_.hit, alive);   // (the whole wave enters: wave-aligned query passes)
                 } else if (alive) {

@@ -212,6 +212,40 @@ TR_DEV void wf_enqueue_ray_by_key(const WfPool& pool, uint32_t* __restrict__ que
     if (want) wf_put_ray(queue, (size_t)wf_my_seg() * pool.seg_cap + s_base[key & (WF_SORT_KEYS - 1u)] + rank, slot, o, d, flags);
 }
 #endif
+// The shading kernels' append to the NEXT round's stage A queue: grouped by direction octant like k_wf_advance's own appends. Every thread of the workgroup calls.
+TR_DEV void wf_append_next_a(const WfPool& pool, uint32_t* __restrict__ queue_a, uint32_t* __restrict__ qctl, bool want, uint32_t slot, f3 o, f3 d, uint32_t flags,
+                             uint32_t* s_cnt, uint32_t* s_base) {
+#ifndef WF_NO_OCTANT_SORT
+    wf_enqueue_ray_by_key(pool, queue_a, qctl, 0u, want, slot, o, d, flags, want ? wf_octant(d) : 0u, s_cnt, s_base);
+#else
+    (void)s_cnt; (void)s_base;
+    wf_enqueue_ray(pool, queue_a, qctl, 0u, want, slot, o, d, flags);
+#endif
+}
+// ... from a workgroup some of whose threads have RETURNED already (the one-thread-per-entry shading kernels: threads without an entry leave before
+// the vertex is shaded, and the device functions in between vote over the lanes that are left): the barriers below count the threads that are still
+// there (a terminated wave is not waited for, a terminated lane is masked), so nothing may hang on a particular thread -- the counts s_cnt[0 .. 7] and
+// the ticket s_cnt[8] were zeroed while every thread was present; whoever draws ticket 0 reserves the workgroup's range.
+TR_DEV void wf_append_next_a_live(const WfPool& pool, uint32_t* __restrict__ queue_a, uint32_t* __restrict__ qctl, bool want, uint32_t slot, f3 o, f3 d, uint32_t flags,
+                                  uint32_t* s_cnt /* WF_SORT_KEYS + 1, zeroed */, uint32_t* s_base /* WF_SORT_KEYS */) {
+#ifndef WF_NO_OCTANT_SORT
+    const uint32_t key = wf_octant(d);
+    uint32_t rank = 0u;
+    if (want) rank = atomicAdd(&s_cnt[key], 1u);
+    __syncthreads();
+    if (atomicAdd(&s_cnt[WF_SORT_KEYS], 1u) == 0u) {
+        uint32_t total = 0u;
+        for (uint32_t b = 0; b < WF_SORT_KEYS; ++b) { const uint32_t c = s_cnt[b]; s_base[b] = total; total += c; }
+        const uint32_t base = total ? atomicAdd(qctl + wf_my_seg() * WF_SEG_STRIDE + 0u, total) : 0u;
+        for (uint32_t b = 0; b < WF_SORT_KEYS; ++b) s_base[b] += base;
+    }
+    __syncthreads();
+    if (want) wf_put_ray(queue_a, (size_t)wf_my_seg() * pool.seg_cap + s_base[key] + rank, slot, o, d, flags);
+#else
+    (void)s_cnt; (void)s_base;
+    wf_enqueue_ray(pool, queue_a, qctl, 0u, want, slot, o, d, flags);
+#endif
+}
 // one thread per queue entry: the entry this thread owns, or false
 TR_DEV bool wf_my_entry(const WfPool& pool, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ qctl, uint32_t k, uint32_t& slot) {
     const uint32_t seg = wf_my_seg(), q = (blockIdx.x / WF_SEGS) * TR_BLOCK + threadIdx.x;
@@ -679,13 +713,17 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_fallback(const DevScene s
 //   k_wf_bin_scatter  the same workgroup shape: exclusive scan of the segment's histogram (LDS), the workgroup's own counts reserve a range
 //                     per bin with one atomic each, every entry is copied to base[bin] + reserved + its rank inside the workgroup
 // Cost: the queue is read twice and written once (96 B per ray against the ~350 B a stage A ray moves through HBM).
+// MEASURED (profiles/r06_c5_ray_binning_ab.txt, C5 stand-in at full detail, 128 spp): frame 64 228.2 -> 215.7 Msamples/s, frame 127 163.3 -> 154.6
+// with both stages binned, the same with 8 cells per axis, stage A alone no better: the passes cost their ~0.9 ms per round and the traversal
+// gains nothing -- below the first levels of the trees (cache-resident for every wave anyway) the diffuse rays of one cell fan out like any
+// others. OFF by default (WF_BIN_DEFAULT); TRAYHIP_WF_BIN=1|2|3 runs it, tests/test_device_emulation.py keeps it correct.
 #ifndef WF_BIN_CELL_BITS
 #define WF_BIN_CELL_BITS 2   // cells per axis = 2^bits over the box of BVH<Instance>
 #endif
 #define WF_BINS (8u << (3 * WF_BIN_CELL_BITS))
 #define WF_BIN_EPB 4096u     // queue entries per workgroup of the two passes
 #ifndef WF_BIN_DEFAULT
-#define WF_BIN_DEFAULT 3u    // stages whose rays are binned: bit 0 = A (camera / continuation rays), bit 1 = B (occlusion rays); TRAYHIP_WF_BIN overrides
+#define WF_BIN_DEFAULT 0u    // stages whose rays are binned: bit 0 = A (camera / continuation rays), bit 1 = B (occlusion rays); TRAYHIP_WF_BIN overrides. Measured: -5 ... -6 % on the C5 stand-in (profiles/r06_c5_ray_binning_ab.txt), so off
 #endif
 struct WfBinGrid { float lo[3], scale[3]; };   // cell = clamp((o - lo) * scale) per axis; scale = cells / extent (0 for a flat or unbounded axis)
 // (host) the grid over a box -- the root of the frame's BVH<Instance>
@@ -895,9 +933,13 @@ __global__ __launch_bounds__(TR_BLOCK, WF_SHADE_WAVES) void k_wf_begin(const Dev
 }
 
 // Stage B shading of pool slot i: the BSDF queries of the vertex (light half, BSDF half, continuation)
+// Returns true when the path goes on from this vertex WITHOUT a stage C ray: (ray_o, ray_d, ray_flags) is then the ray towards the next vertex and
+// the slot's flags word as stored -- the caller appends it to the NEXT round's queue A (round 6: k_wf_advance used to re-read origin, direction and
+// bounce of every continuing slot from the pool to do that, 64 bytes fetched per slot and round for a ray this kernel holds in registers).
 template <int ANIM, int FEAT, uint32_t KM>
-TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, uint32_t flags, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl,
-                           DevStats* __restrict__ stats, LdsB perm_lds) {
+TR_DEV bool wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, uint32_t flags, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl,
+                           DevStats* __restrict__ stats, LdsB perm_lds, f3& ray_o, f3& ray_d, uint32_t& ray_flags) {
+    bool goes_on = false;
     Lane ln;
     ln.perm_lds = perm_lds;
     ln.flags = flags;
@@ -935,23 +977,33 @@ TR_DEV void wf_query_slot(const DevScene& sc, const WfPool& pool, uint32_t i, ui
         uint32_t f2 = ln.flags & ~(WF_INVERTEX | WF_HIT_A | WF_HIT_C | WF_OCCLUDED | LF_SHADOW | LF_MIS | LF_LAST);
         if (!cont) f2 = (f2 & ~LF_ALIVE) | WF_FINISHED;
         pu(pool, F_FLAGS, i) = f2;
+        if (cont) { goes_on = true; ray_o = LN_O(ln); ray_d = ln.d; ray_flags = f2; }
     }
     if (queue_c) wf_enqueue_ray(pool, queue_c, qctl, 2u, (ln.flags & LF_MIS) != 0u, i, ln.bsdf.p, ln.aux_d, ln.flags);
+    return goes_on;
 }
 
 // one thread per pool slot, every material kind's code: scenes with textured materials (their lobes exist per hit only, so there is no table to sort by)
+// queue_a: the NEXT round's stage A queue -- the rays of the paths that go on from here, appended by the whole workgroup in direction-octant order
+// (wf_enqueue_ray_by_key; its count word survives until the next round's traversal: the host clears the control words between trace A and k_wf_begin)
 template <int ANIM, int FEAT>
 __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(
-    const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl, DevStats* __restrict__ stats) {
+    const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl, DevStats* __restrict__ stats,
+    uint32_t* __restrict__ queue_a) {
     const DevScene& sc = scv;
     __shared__ uint4 s_perm[TR_PERM_BYTES / 16];   // the permutation pool in LDS (as in k_wf_begin)
+    __shared__ uint32_t s_oct_cnt[WF_SORT_KEYS + 1u], s_oct_base[WF_SORT_KEYS];
     s_perm[threadIdx.x] = reinterpret_cast<const uint4*>(sc.perm_pool)[threadIdx.x];
+    if (threadIdx.x <= WF_SORT_KEYS) s_oct_cnt[threadIdx.x] = 0u;   // (the octant counts and the ticket of wf_append_next_a_live: while every thread is still here)
     __syncthreads();
     const uint32_t i = blockIdx.x * TR_BLOCK + threadIdx.x;
     if (i >= n_active) return;
     const uint32_t flags = pu(pool, F_FLAGS, i);
     if ((flags & (LF_ALIVE | WF_INVERTEX)) != (LF_ALIVE | WF_INVERTEX) || (flags & (LF_MIS | WF_CFLIGHT)) != 0u) return;   // (a vertex whose queries ran in an earlier round waits for its stage C ray: WF_FOLD_C)
-    wf_query_slot<ANIM, FEAT, KM_ALL>(sc, pool, i, flags, queue_c, qctl, stats, TR_LDS_B(s_perm));
+    f3 ro = mk(0.0f, 0.0f, 0.0f), rd = ro;
+    uint32_t rf = 0u;
+    const bool goes_on = wf_query_slot<ANIM, FEAT, KM_ALL>(sc, pool, i, flags, queue_c, qctl, stats, TR_LDS_B(s_perm), ro, rd, rf);
+    wf_append_next_a_live(pool, queue_a, qctl, goes_on, i, ro, rd, rf, s_oct_cnt, s_oct_base);
 }
 
 // kind-pure shading: one thread per entry of material kind MK's queue (filled by k_wf_begin's counting sort); only the lobes that
@@ -959,15 +1011,21 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_query(
 // every lane of a wave runs the same material's code
 template <int ANIM, int MK>
 __global__ __launch_bounds__(TR_BLOCK, WF_SHADE_WAVES) void k_wf_query_kind(const DevScene scv, WfPool pool, const uint32_t* __restrict__ kind_queues,
-                                                            uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl, DevStats* __restrict__ stats) {
+                                                            uint32_t* __restrict__ queue_c, uint32_t* __restrict__ qctl, DevStats* __restrict__ stats,
+                                                            uint32_t* __restrict__ queue_a) {
     const DevScene& sc = scv;
     __shared__ uint4 s_perm[TR_PERM_BYTES / 16];   // the permutation pool in LDS (as in k_wf_begin)
+    __shared__ uint32_t s_oct_cnt[WF_SORT_KEYS + 1u], s_oct_base[WF_SORT_KEYS];
     if (blockIdx.x / WF_SEGS * TR_BLOCK >= qctl[wf_my_seg() * WF_SEG_STRIDE + 8u + MK]) return;   // (the whole workgroup lies past the queue's end)
     s_perm[threadIdx.x] = reinterpret_cast<const uint4*>(sc.perm_pool)[threadIdx.x];
+    if (threadIdx.x <= WF_SORT_KEYS) s_oct_cnt[threadIdx.x] = 0u;   // (the octant counts and the ticket of wf_append_next_a_live: while every thread is still here)
     __syncthreads();
     uint32_t i;
     if (!wf_my_entry(pool, kind_queues + (size_t)MK * WF_SEGS * pool.seg_cap, qctl, 8u + MK, i)) return;
-    wf_query_slot<ANIM, feat_of_material(MK), km_of_material(MK)>(sc, pool, i, pu(pool, F_FLAGS, i), queue_c, qctl, stats, TR_LDS_B(s_perm));
+    f3 ro = mk(0.0f, 0.0f, 0.0f), rd = ro;
+    uint32_t rf = 0u;
+    const bool goes_on = wf_query_slot<ANIM, feat_of_material(MK), km_of_material(MK)>(sc, pool, i, pu(pool, F_FLAGS, i), queue_c, qctl, stats, TR_LDS_B(s_perm), ro, rd, rf);
+    wf_append_next_a_live(pool, queue_a, qctl, goes_on, i, ro, rd, rf, s_oct_cnt, s_oct_base);
 }
 
 // New camera sample for pool slot i of a chunk that works on tile `tile_idx` (multithreaded.rs:90-96)
@@ -1043,7 +1101,9 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
     __syncthreads();
     uint32_t tile_idx = s_tile;
     if (tile_idx == WF_TILE_IDLE) return;
+    const uint32_t flags_in = flags;
     bool c_ray = false;   // the slot's stage C ray joins this round's queue A (WF_FOLD_C)
+    bool closed_here = false;   // this kernel ran the slot's vertex_end (the vertex had a stage C ray): if the path goes on, its ray is queued here
     const bool film_rows = sc.film_rows != 0u;
     if (tile_idx != WF_TILE_NEED) {
         const uint32_t tile_of = tile_idx >> slice_shift;
@@ -1074,6 +1134,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
             pu(pool, F_BOUNCE, i) = ln.bounce;
             flags = ln.flags & ~(WF_INVERTEX | WF_HIT_A | WF_HIT_C | WF_OCCLUDED | LF_SHADOW | LF_MIS | LF_LAST | WF_CFLIGHT);
             if (!cont) flags = (flags & ~LF_ALIVE) | WF_FINISHED;
+            closed_here = true;
         }
         // ---- RenderTarget::write of the samples that finished (here or in k_wf_begin)
         if (flags & WF_FINISHED) {
@@ -1155,26 +1216,16 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
         }
     }
     wf_enqueue(pool, queue_r, qctl, 6u, wants_sample, i);
-    pu(pool, F_FLAGS, i) = flags;
-#ifndef WF_NO_OCTANT_SORT
-    {   // the continuation rays of this chunk, grouped by direction octant
-        const bool cont_ray = (flags & LF_ALIVE) != 0u;
+    if (flags != flags_in) pu(pool, F_FLAGS, i) = flags;   // (a slot that simply goes on is not touched beyond the read of this word)
+    {   // Round 6: the ray of a path that goes on was put into this round's queue A by the shading kernel that sampled it (k_wf_query_kind, last
+        // round: it has origin and direction in registers -- this kernel used to fetch the slot's 64-byte ray record for them, per slot and
+        // round). What is queued HERE: the stage C rays (WF_FOLD_C) and the rays of the few paths whose vertex this kernel just closed.
+        const bool cont_ray = c_ray || (closed_here && (flags & LF_ALIVE) != 0u);
         f3 ro = mk(0.0f, 0.0f, 0.0f), rd = ro;
-        uint32_t rf = flags;
         if (c_ray) { ro = ld3(pool, F_P, i); rd = ld3(pool, F_AUX, i); }   // Ray::segment(p, w_i, 0.001, inf) (mod.rs:154): never a camera ray
-        else if (cont_ray) { ro = ld3(pool, F_O, i); rd = ld3(pool, F_D, i); if (pu(pool, F_BOUNCE, i) == 0u) rf |= WF_CAMERA_RAY; }
-        wf_enqueue_ray_by_key(pool, queue_a, qctl, 0u, cont_ray, i, ro, rd, rf, cont_ray ? wf_octant(rd) : 0u, s_oct_cnt, s_oct_base);
+        else if (cont_ray) { ro = ld3(pool, F_O, i); rd = ld3(pool, F_D, i); }   // (never a camera ray either: bounce >= 1 after a vertex_end; k_wf_regen queues those)
+        wf_append_next_a(pool, queue_a, qctl, cont_ray, i, ro, rd, flags, s_oct_cnt, s_oct_base);
     }
-#else
-    {
-        const bool cont_ray = (flags & LF_ALIVE) != 0u;
-        f3 ro = mk(0.0f, 0.0f, 0.0f), rd = ro;
-        uint32_t rf = flags;
-        if (c_ray) { ro = ld3(pool, F_P, i); rd = ld3(pool, F_AUX, i); }   // Ray::segment(p, w_i, 0.001, inf) (mod.rs:154): never a camera ray
-        else if (cont_ray) { ro = ld3(pool, F_O, i); rd = ld3(pool, F_D, i); if (pu(pool, F_BOUNCE, i) == 0u) rf |= WF_CAMERA_RAY; }
-        wf_enqueue_ray(pool, queue_a, qctl, 0u, cont_ray, i, ro, rd, rf);
-    }
-#endif
     __syncthreads();   // every wave has taken its pairs
     if (tid == 0) { chunks[c].tile = s_tile; chunks[c].done = s_done; chunks[c].next_pair = s_pair < n_pairs ? s_pair : n_pairs; }
 }

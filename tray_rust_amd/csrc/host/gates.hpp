@@ -37,7 +37,10 @@ struct FlatInst {   // 128 B
     float gp0, gp1;
     uint32_t geom_type, mesh_id, inst;
     uint32_t animated;        // the instance moves while the shutter is open: its transform is the path's (per-path cache), `inv` above is not used
-    uint32_t pad[4];
+    uint32_t leaf;            // index of its FlatLeaf (the per-lane pass of trace_flat re-derives the gate's entry distance from that box)
+    uint32_t lane_pass;       // 1: tested in trace_flat's per-lane pass -- a rectangle or disk alone in a FLAT leaf box (thinnest side <= 1 % of the longest),
+                              // which a ray passes only where it crosses the surface; everything else stays in the wave-uniform loop
+    uint32_t pad[2];
 };
 static_assert(sizeof(FlatLeaf) == 32 && sizeof(FlatInst) == 128, "records are read with aligned scalar loads");
 
@@ -368,6 +371,13 @@ inline void flat_loop_gates(const TrayFlatScene* f, const PairedTrees& paired, u
             fi.gp0 = in.geom_params[0]; fi.gp1 = in.geom_params[1];
             fi.geom_type = in.geom_type; fi.mesh_id = in.mesh_id; fi.inst = i; fi.animated = in.animated ? 1u : 0u;
             instance_gate_box(f, in, fi.lo, fi.hi);
+            fi.leaf = (uint32_t)leaves.size();   // (this leaf is pushed below: it holds at least this instance)
+            {
+                float emin = INFINITY, emax = 0.0f;
+                for (int c = 0; c < 3; ++c) { const float e = node.bmax[c] - node.bmin[c]; emin = std::min(emin, e); emax = std::max(emax, e); }
+                const bool flat_box = std::isfinite(emax) && emin >= 0.0f && emin <= 0.01f * emax;
+                fi.lane_pass = (node.count == 1 && flat_box && !in.animated && (in.geom_type == TRAY_GEOM_RECT || in.geom_type == TRAY_GEOM_DISK)) ? 1u : 0u;
+            }
             insts.push_back(fi);
         }
         lf.count = (uint32_t)insts.size() - lf.first;
