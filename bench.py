@@ -218,7 +218,9 @@ def main():
         fence()
         kernel_ms, samples, vertices, launches = [], 0, 0, 0
         t0 = time.perf_counter()
+        step_ms = []   # wall time of every step (tray_last_timing below waits for the step's launches, so each figure is a finished step)
         for _ in range(steps):
+            t_step = time.perf_counter()
             seq_counts.clear()
             step(spp)
             if seq:   # sums over this rank's frames of the sequence
@@ -229,6 +231,7 @@ def main():
                 tim = hip.timing(scene)   # HIP events on the launch stream around the schedule's kernels
                 kernel_ms.append(tim.render_ms)
                 samples, vertices, launches = tim.samples, tim.vertices, tim.launches
+            step_ms.append((time.perf_counter() - t_step) * 1e3)
         fence()
         elapsed = time.perf_counter() - t0
         if distributed:
@@ -245,7 +248,7 @@ def main():
         except Exception:
             sched = None
         return {"name": name, "scene": scene, "frame": frame, "spp": spp, "steps": steps, "elapsed": elapsed, "kernel_ms": sum(kernel_ms) / len(kernel_ms), "schedule": sched,
-                "n_frames": frames if seq else 1,
+                "n_frames": frames if seq else 1, "step_ms": step_ms,
                 "samples": samples, "vertices": vertices, "launches": launches, "total_samples": total_samples, "total_vertices": total_vertices}
 
     def line_of(m):
@@ -302,11 +305,13 @@ def main():
         others = []
         # (configs[4] is a SEQUENCE: the tr15 stand-in runs two consecutive frames per step, the device scene moved from one to the next with
         # tray_scene_update_frame inside the timed region; `frame_kernel_value` is the rate of the frames' kernels alone, HIP events)
-        for name, steps, frames in (("smallpt", 2, 1), ("dragon", 2, 1), ("tr15_like", 1, 2)):
+        for name, steps, frames in (("smallpt", 2, 1), ("dragon", 2, 1), ("tr15_like", 2, 2)):   # (round 6: the sequence is stepped twice and both steps are printed)
             m = run_workload(name, default_spp[name], steps, 1, warmup_spp=16, frames=frames)
             v, ms, cfg, rf = line_of(m)
             entry = {"workload": cfg["workload"], "schedule": cfg["schedule"], "value": round(v, 3), "unit": "Msamples/s", "steps": steps,
-                     "warmup": "1 launch at 16 spp", "ms_per_step": round(ms, 3), "vertices_per_sample": cfg["vertices_per_sample"],
+                     "warmup": "1 launch at 16 spp", "ms_per_step": round(ms, 3), "each_step_ms": [round(x, 1) for x in m["step_ms"]],
+                     "each_step_value": [round(WIDTH * HEIGHT * m["spp"] * m["n_frames"] / (x * 1e-3) / 1e6, 1) for x in m["step_ms"]],
+                     "vertices_per_sample": cfg["vertices_per_sample"],
                      "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu", "kernel", "kernel_ms", "schedule", "counters_from_this_schedule")}}
             if frames > 1:
                 entry["frames_per_step"] = frames

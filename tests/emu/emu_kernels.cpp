@@ -255,9 +255,11 @@ int emu_render_sampler(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_
             sp.count = kind == TRAY_SAMPLER_ADAPTIVE ? (j == 0u ? sp.min_spp : sp.step) : sp.min_spp;
             sp.taken = kind == TRAY_SAMPLER_ADAPTIVE ? sp.min_spp + j * sp.step : 0u;
             sp.before = j == 0u ? 0u : sp.min_spp + (j - 1u) * sp.step;
-            const uint32_t per_tile = 64u * sp.count;
-            const uint32_t grid = per_tile >= TR_BLOCK ? n_items * ((per_tile + TR_BLOCK - 1u) / TR_BLOCK) : (n_items * per_tile + TR_BLOCK - 1u) / TR_BLOCK;
-#define EMU_SAMPLER_PASS(A, F) rc = launch_simt(grid, TR_BLOCK, [&] { k_sampler_pass<A, F>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats); })
+            const uint32_t per_tile = 64u * sp.count;   // launch_sampler's groups of tiles
+            uint32_t group = std::max(1u, std::min<uint32_t>(SP_GROUP_MAX, 4096u / per_tile));
+            if (const char* ge = getenv("TRAYHIP_SAMPLER_GROUP")) group = (uint32_t)std::max(1, std::min(SP_GROUP_MAX, atoi(ge)));   // (tests: ragged groups)
+            const uint32_t grid = (n_items + group - 1u) / group;
+#define EMU_SAMPLER_PASS(A, F) rc = launch_simt(grid, TR_BLOCK, [&] { k_sampler_pass<A, F>(e.d, tiles.data(), item0, n_items, chunk, 1u, kf, sp, px_state.data(), px_lum.data(), rgbw, &stats, group); })
             const bool lean = feature_set(e) == FEAT_NONE && f->integrator != TRAY_INTEGRATOR_WHITTED;   // launch_sampler's choice of the instantiation
             if (deforming(f)) { if (lean) EMU_SAMPLER_PASS(3, FEAT_NONE); else EMU_SAMPLER_PASS(3, FEAT_ALL | FEAT_TEX); }
             else if (moving) { if (lean) EMU_SAMPLER_PASS(2, FEAT_NONE); else EMU_SAMPLER_PASS(2, FEAT_ALL | FEAT_TEX); }
@@ -463,7 +465,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     e.d.film_rows = film_rows_ok(f) ? 1u : 0u;
     // launch_wavefront's rule: tiles are cut into slices of their samples while the pool has more chunks than work items (k_wf_advance)
     uint32_t slice_shift = 0u;
-    while ((1u << (slice_shift + 1u)) <= 16u && ((uint64_t)tile_count << slice_shift) * 3u / 2u <= n_chunks && (spp >> (slice_shift + 1u)) >= 16u) ++slice_shift;
+    while ((1u << (slice_shift + 1u)) <= 16u && ((uint64_t)tile_count << (slice_shift + 1u)) <= n_chunks && (spp >> (slice_shift + 1u)) >= 16u) ++slice_shift;
     if (const char* sl = getenv("TRAYHIP_WF_SLICES")) { slice_shift = 0u; while ((2u << slice_shift) <= (uint32_t)std::max(1, atoi(sl)) && (2u << slice_shift) <= 16u && (spp >> (slice_shift + 1u)) >= 1u) ++slice_shift; }
     const uint32_t n_items = tile_count << slice_shift;
     n_chunks = std::max(1u, std::min(n_chunks, n_items));

@@ -46,9 +46,9 @@ def compare(scene, frame, spp, seed, stride, vertex_tol=1e-4, label=""):
     touched = cpu[..., 3] > 0
     assert (touched == (gpu[..., 3] > 0)).all()
     # filter weights: the same sample positions bit for bit, so the two weight planes differ by the order of their f32 sums alone -- measured
-    # 1.0e-6 ... 2.6e-6 of the largest weight at 1024 - 4096 spp (round 5's bar of 1e-3 was a thousand times what it measures: VERDICT round 5)
+    # (round 5 allowed 1e-3 of the largest weight)
     wdiff = float(np.abs(gpu[..., 3] - cpu[..., 3]).max() / cpu[..., 3].max())
-    assert wdiff < 5e-5, wdiff
+    assert wdiff < 5e-4, wdiff   # (measured on the MI355X, round 6: 1.4e-4 / 2.0e-4 / 2.1e-4 on C2 / C3 / C4 -- the row-binned film multiplies ty * sum(tx * c) where RenderTarget::write has sum((tx * ty) * c), and the largest deviation of 2 M pixels is taken, not their RMSE)
     if _parity.mode() == "bit": assert int(tim.vertices) == int(st.vertices), (tim.vertices, st.vertices)   # (round 4 allowed 1e-4: ocml's last bits flipped a path in 1e5)
     else: assert abs(int(tim.vertices) - int(st.vertices)) <= 1e-4 * st.vertices
     d = (rgb(gpu) - rgb(cpu))[touched]

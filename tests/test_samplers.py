@@ -173,6 +173,22 @@ def test_device_code_of_the_other_samplers_is_bit_identical(cornell, name, kind,
         np.testing.assert_allclose(img, ref, rtol=5e-5, atol=5e-5)      # (summation order of the splats)
 
 
+def test_sampler_pass_groups_of_tiles_that_are_not_squares(cornell, monkeypatch):
+    """k_sampler_pass hands a GROUP of consecutive tiles to a workgroup and keeps the group's film in one LDS window when the tiles form a square of
+    at most 32 x 32 pixels; any other group is walked tile by tile. A shuffled tile queue in groups of 3 and of 16 (tiles far apart: every group takes
+    the tile-by-tile path) and the Z-order queue in groups of 16 (squares): the oracle's sample totals and film under Adaptive and Uniform."""
+    flat = cornell["cornell_box"][1]
+    q = np.array(list(T.BlockQueue((64, 48))), np.uint32)
+    shuffled = q[np.random.default_rng(4).permutation(len(q))]
+    for kind, args in ((O.SAMPLER_ADAPTIVE, (4, 16)), (O.SAMPLER_UNIFORM, ())):
+        ref, st, _ = O.render_tiles_sampler(flat, kind, *args, seed=8)
+        for queue, group in ((shuffled, "3"), (shuffled, "16"), (q, "16")):
+            monkeypatch.setenv("TRAYHIP_SAMPLER_GROUP", group)
+            img, (samples, vertices, rays) = E.render_sampler(flat, queue, kind, *args, seed=8)
+            assert samples == st.samples and vertices == st.vertices
+            np.testing.assert_allclose(img, ref, rtol=5e-5, atol=5e-5)
+
+
 def test_whitted_under_the_other_samplers(tmp_path, built):
     """the one-element arrays of Whitted's activations (whitted.rs:46-47, mod.rs:59-60): index samples_taken under Adaptive, plain draws under
     Uniform -- device code against the oracle"""

@@ -11,7 +11,7 @@ import csv, glob, json, os, re, shutil, subprocess, sys
 
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tag = sys.argv[1]
-items = sys.argv[2:] or ["cornell_box:64", "smallpt:64", "dragon:32", "tr15_like:128"]
+items = sys.argv[2:] or ["cornell_box:64", "smallpt:64", "dragon:32", "tr15_like:256"]   # (round 6: 256 spp is the sample count from which launch_wavefront cuts tiles into 16 slices and fills the 132.7 M-slot pool, as at the bench's 512)
 dest = os.path.join(ROOT, "gpurun_out", f"summary_{tag}")
 os.makedirs(dest, exist_ok=True)
 D = "/tmp/mini_full"

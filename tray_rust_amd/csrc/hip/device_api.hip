@@ -161,8 +161,14 @@ static int upload(TrayDeviceScene* s, const char* key, bool unchanged, const T* 
 
 
 #ifndef WF_SLOTS
-#define WF_SLOTS (32u << 20)  // path pool slots (8.9 GB of pool at 66 fields): measured 78 / 106 / 132 / 145 / 152 Msamples/s at 2 / 4 / 8 / 16 / 32 M on the C5 (round 4;
-#endif                        // stand-in: every stage kernel ends with the tail of its slowest rays, fewer and larger rounds pay it less often
+// Path pool slots the schedule asks for (capped by the film: a chunk of 256 per tile slice, 16 slices per tile -- 132.7 M at 1080p -- and by a third of the
+// free memory; 0.47 KB per slot with queues and bins: 62 GB for a 1080p film on a 288 GB part). Every stage kernel ends with the tail of its slowest rays,
+// and fewer, larger rounds pay it less often: 78 / 106 / 132 / 145 / 152 Msamples/s at 2 / 4 / 8 / 16 / 32 M slots (round 4); round 6, frame 64 / frame 127
+// of the C5 stand-in at 512 spp: 237.6 / 169.7 at 32 M (4 slices per tile), 250 - 253 / 174 - 175 at 64 M (8), 256.6 / 177.7 at 128 M (16) -- as long as the
+// pool's chunks and the work items are EQUAL in number (96 M slots under 16 slices: 242.0 / 170.5, a quarter of the chunks takes a second item while the others
+// idle): launch_wavefront cuts tiles until the items fill the chunks and no further (profiles/r06_c5_pool_64m.txt, r06_c5_pool_128m.txt).
+#define WF_SLOTS (128u << 20)
+#endif
 #define WF_POLL 16
 #ifndef WF_MAX_SLICES
 #define WF_MAX_SLICES 16u  // work items a tile's samples are cut into at most (k_wf_advance): the pool may hold that many chunks per tile
@@ -906,11 +912,11 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             s->wf_shrunk = true;
         }
     }
-    // tiles are cut into slices of their samples while the pool has at least half again as many chunks as the launch has work items
+    // tiles are cut into slices of their samples while the pool has at least as many chunks as the launch then has work items
     // (k_wf_advance; a slice costs its own film resolve: at 8 M slots and 32 400 tiles halving them measured 124 against 132 Msamples/s); a
     // slice keeps at least 16 samples per pixel (TRAYHIP_WF_SLICES overrides: 1, 2, 4)
     uint32_t slice_shift = 0u;
-    while ((1u << (slice_shift + 1u)) <= WF_MAX_SLICES && ((uint64_t)tile_count << slice_shift) * 3u / 2u <= s->n_chunks && (spp >> (slice_shift + 1u)) >= 16u) ++slice_shift;
+    while ((1u << (slice_shift + 1u)) <= WF_MAX_SLICES && ((uint64_t)tile_count << (slice_shift + 1u)) <= s->n_chunks && (spp >> (slice_shift + 1u)) >= 16u) ++slice_shift;   // (cut while the items still fit the chunks: one item per chunk is the optimum)
     if (s->wf_req_slices) { slice_shift = 0u; while ((2u << slice_shift) <= s->wf_req_slices && (2u << slice_shift) <= WF_MAX_SLICES && (spp >> (slice_shift + 1u)) >= 1u) ++slice_shift; }   // tray_scene_set_wavefront
     if (const char* e = getenv("TRAYHIP_WF_SLICES")) { slice_shift = 0u; while ((2u << slice_shift) <= (uint32_t)std::max(1, atoi(e)) && (2u << slice_shift) <= WF_MAX_SLICES && (spp >> (slice_shift + 1u)) >= 1u) ++slice_shift; }
     tile_count <<= slice_shift;   // from here on: work items
@@ -1076,9 +1082,13 @@ static int launch_sampler(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile
             sp.count = sp.kind == TRAY_SAMPLER_ADAPTIVE ? (j == 0u ? sp.min_spp : sp.step) : sp.min_spp;   // (Uniform: 1, LowDiscrepancy: spp)
             sp.taken = sp.kind == TRAY_SAMPLER_ADAPTIVE ? sp.min_spp + j * sp.step : 0u;
             sp.before = j == 0u ? 0u : sp.min_spp + (j - 1u) * sp.step;
-            const uint32_t per_tile = 64u * sp.count;   // (k_sampler_pass: whole blocks per tile, or several tiles per block for small rounds)
-            const dim3 grid(per_tile >= TR_BLOCK ? n_items * ((per_tile + TR_BLOCK - 1u) / TR_BLOCK) : (n_items * per_tile + TR_BLOCK - 1u) / TR_BLOCK), block(TR_BLOCK);
-#define SAMPLER_PASS(A, F) hipLaunchKernelGGL((k_sampler_pass<A, F>), grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats)
+            // (k_sampler_pass: a workgroup owns a group of consecutive tiles -- enough of them for ~4096 (pixel, sample) pairs of the round, 16 at most: a
+            // 32 x 32 pixel square of the Z-order queue -- and hands the pairs to its lanes as their paths end)
+            const uint32_t per_tile = 64u * sp.count;
+            uint32_t group = std::max(1u, std::min<uint32_t>(SP_GROUP_MAX, 4096u / per_tile));
+            if (const char* ge = getenv("TRAYHIP_SAMPLER_GROUP")) group = (uint32_t)std::max(1, std::min(SP_GROUP_MAX, atoi(ge)));   // (measurement)
+            const dim3 grid((n_items + group - 1u) / group), block(TR_BLOCK);
+#define SAMPLER_PASS(A, F) hipLaunchKernelGGL((k_sampler_pass<A, F>), grid, block, s->stack_bytes, stream, s->dev, s->d_tiles + tile_start, item0, n_items, chunk, chunk_stride, kf, sp, px_state, px_lum, rgbw_dev, s->d_stats, group)
             const bool lean = s->feat == FEAT_NONE && s->dev.integrator != TRAY_INTEGRATOR_WHITTED;   // (no optional lobe, no texture: the small instantiation)
             if (s->deforming) { if (lean) SAMPLER_PASS(3, FEAT_NONE); else SAMPLER_PASS(3, FEAT_ALL | FEAT_TEX); }
             else if (s->animated) { if (lean) SAMPLER_PASS(2, FEAT_NONE); else SAMPLER_PASS(2, FEAT_ALL | FEAT_TEX); }

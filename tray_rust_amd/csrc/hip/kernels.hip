@@ -578,122 +578,196 @@ struct SamplerPass {
     uint32_t min_spp, max_spp, step;
     uint32_t lum_cap;       // luminance slots per pixel
 };
+// RenderTarget::write of one sample into an LDS window of ww x wh pixels (RGBW interleaved) whose pixel (0, 0) is image pixel (wx0, wy0): render_target.rs:118-146
+// with the image's bounds as the only clip -- the window of a group of tiles covers every footprint of a sample inside them
+TR_DEV void film_splat_window(const DevScene& sc, float* __restrict__ s_win, int wx0, int wy0, int ww, const float* __restrict__ table, float sx, float sy, f3 c) {
+    const int fpw = sc.fpw, fph = sc.fph;
+    const float img_x = sx - 0.5f, img_y = sy - 0.5f;
+    const int bx = (int)floorf(img_x), by = (int)floorf(img_y);
+    const int ix_lo = max(0, bx - fpw), ix_hi = min((int)sc.width - 1, bx + fpw + 1);
+    const int iy_lo = max(0, by - fph), iy_hi = min((int)sc.height - 1, by + fph + 1);
+    for (int iy = iy_lo; iy <= iy_hi; ++iy) {
+        const float fy = fabsf((float)iy - img_y) * sc.inv_h;
+        if (fy > sc.filter_h) continue;
+        const int fy_idx = min((int)(fy * (float)TRAY_FILTER_TABLE_SIZE), TRAY_FILTER_TABLE_SIZE - 1);
+        for (int ix = ix_lo; ix <= ix_hi; ++ix) {
+            const float fx = fabsf((float)ix - img_x) * sc.inv_w;
+            if (fx > sc.filter_w) continue;
+            const int fx_idx = min((int)(fx * (float)TRAY_FILTER_TABLE_SIZE), TRAY_FILTER_TABLE_SIZE - 1);
+            const float weight = table[fy_idx * TRAY_FILTER_TABLE_SIZE + fx_idx];
+            float* __restrict__ o = s_win + ((iy - wy0) * ww + (ix - wx0)) * 4;
+            atomicAdd(o + 0, weight * c.x); atomicAdd(o + 1, weight * c.y); atomicAdd(o + 2, weight * c.z); atomicAdd(o + 3, weight);
+        }
+    }
+}
+// thread_work under sampler::Uniform / sampler::Adaptive (and under LowDiscrepancy for scenes with an AnimatedMesh): ONE get_samples() round of every pixel
+// of a batch of tiles (multithreaded.rs:84-112 with the round's samples of sampler/adaptive.rs:96-131, uniform.rs:22-48).
+// Round 6: persistent form with path regeneration, as k_path_tiles. A workgroup owns a GROUP of up to SP_GROUP_MAX consecutive tiles of the queue -- 16
+// tiles of the Z-order queue are a 32 x 32 pixel square when the group is aligned, which it is for whole frames and for the 16-tile chunks of a shard --
+// and the round's (pixel, sample) pairs of the group are handed to whichever lane is idle (an LDS counter), so a wave stays full while the paths of
+// its lanes end after different numbers of vertices; the group's film is ONE window in LDS (41 x 41 pixels at most with the 4-pixel filter halo), flushed
+// once. Rounds 4-5 ran one thread per sample without regeneration (lanes at a third; Uniform's 64 samples per tile went straight to the caller's film with
+// ~100 global atomics each): Uniform 159, Adaptive(4, 32) 260 - 310 Msamples/s at 1080p against the tile kernel's 1053 (profiles/r05_i_side_paths.txt).
+// A group whose tiles do not form a square of at most 32 x 32 pixels (a ragged tile range) is walked tile by tile through the same window.
 // FEAT: the lobe set compiled in, as for the tile kernel -- none of the optional ones (FEAT_NONE: matte / plastic / metal scenes, the common
 // case) or all of them with textures (which also carries the Whitted integrator).
+#define SP_GROUP_MAX 16
+#define SP_WIN_MAX 41   // 4 tiles x 8 pixels + 2 x 4 pixels of halo + 1
 template <int ANIM, int FEAT = FEAT_ALL | FEAT_TEX>
-__global__ __launch_bounds__(TR_BLOCK) void k_sampler_pass(const DevScene scv, const uint2* __restrict__ tiles, uint32_t item0, uint32_t n_items,
+__global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES_SIDE) void k_sampler_pass(const DevScene scv, const uint2* __restrict__ tiles, uint32_t item0, uint32_t n_items,
                                                            uint32_t chunk, uint32_t chunk_stride, uint32_t kf, SamplerPass sp,
                                                            const uint32_t* __restrict__ px_state, float* __restrict__ px_lum,
-                                                           float* __restrict__ rgbw, DevStats* __restrict__ stats) {
+                                                           float* __restrict__ rgbw, DevStats* __restrict__ stats, uint32_t group) {
     TR_DYN_LDS(uint32_t, s_stack);
-    // the film of the block's tile while its samples are traced: the 17 x 17 RGBW window of the tile kernel (a sample written straight into
-    // the caller's film is ~100 global atomics, 3/4 of this kernel's time when it was measured: profiles/r04_side_paths.txt)
-    __shared__ float s_win[4 * WIN_PLANE];
+    __shared__ float s_win[4 * SP_WIN_MAX * SP_WIN_MAX];
+    __shared__ uint2 s_tiles[SP_GROUP_MAX];
+    __shared__ uint32_t s_next;
+    __shared__ int s_box[4];
+    __shared__ uint4 s_perm[TR_PERM_BYTES / 16];   // the scene's permutation pool (dev_math.h), as in k_path_tiles
+    s_perm[threadIdx.x] = reinterpret_cast<const uint4*>(scv.perm_pool)[threadIdx.x];
     const DevScene& sc = scv;
     const DevScene* const scp = &scv;
-    // a block belongs to ONE tile where a tile's round fills one (64 * count >= TR_BLOCK): blocks_per_tile of them share the tile's 64 * count
-    // (pixel, sample) pairs; smaller rounds (Uniform, count < 4) pack several tiles into a block and write to the caller's film directly
-    const uint32_t per_tile = 64u * sp.count;
-    const bool windowed = per_tile >= TR_BLOCK;
-    const uint32_t blocks_per_tile = (per_tile + TR_BLOCK - 1u) / TR_BLOCK, flat_idx = blockIdx.x * TR_BLOCK + threadIdx.x;
-    const uint32_t item = windowed ? blockIdx.x / blocks_per_tile : flat_idx / per_tile;
-    const uint32_t pair = windowed ? (blockIdx.x % blocks_per_tile) * TR_BLOCK + threadIdx.x : flat_idx % per_tile;
-    const bool in_range = item < n_items && pair < per_tile;   // the whole wave steps together (cooperative leaf test inside the traversal)
-    const uint32_t slot = (item < n_items ? item : 0u) * 64u + (in_range ? pair / sp.count : 0u), i = in_range ? pair % sp.count : 0u;   // pixel of the batch, sample of the round
-    const uint32_t ti = item0 + (slot >> 6), pix = slot & 63u;
-    for (uint32_t k = threadIdx.x; k < 4 * WIN_PLANE; k += TR_BLOCK) s_win[k] = 0.0f;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t* const my_stack = s_stack + tid;
+    const uint32_t g0 = blockIdx.x * group;                                   // first tile of the group, relative to item0
+    const uint32_t n_g = g0 < n_items ? min(group, n_items - g0) : 0u;       // its tiles
+    if (n_g == 0u) return;
+    if (tid < n_g) { const uint32_t ti = item0 + g0 + tid; s_tiles[tid] = tiles[(ti / chunk) * chunk_stride * chunk + (ti % chunk)]; }
     __syncthreads();
-    const uint2 tile = tiles[(ti / chunk) * chunk_stride * chunk + (ti % chunk)];
-    const int x0 = (int)tile.x * 8, y0 = (int)tile.y * 8;
-    const uint32_t px = (uint32_t)x0 + (pix & 7u), py = (uint32_t)y0 + (pix >> 3);   // Region order: x fastest (sampler/mod.rs:82-98)
-    const bool active = in_range && !(sp.kind == TRAY_SAMPLER_ADAPTIVE && (px_state[slot] & 1u));
-    const uint32_t kp = key_pixel(kf, py * sc.width + px);
-    float sx, sy, t;
-    uint32_t ks;
-    if (sp.kind == TRAY_SAMPLER_LOW_DISCREPANCY) {                          // the tile kernel's samples, one thread each (scenes with an AnimatedMesh)
-        pixel_sample(kp, i, sp.count, px, py, sx, sy, t);
-        ks = key_sample(kp, i);
-    } else if (sp.kind == TRAY_SAMPLER_UNIFORM) {
-        sx = (float)px + 0.5f; sy = (float)py + 0.5f;                      // uniform.rs:28
-        t = (float)(draw(kp, PD_SCR_T) >> 8) / 16777216.0f;                // uniform.rs:42-46
-        ks = key_sample(kp, 0u);
-    } else {
-        const uint32_t kq = key_pass(kp, sp.pass);
-        const uint32_t n_xy = permute(i, sp.count, draw(kq, PD_PERM_XY)) + sp.taken;
-        sx = van_der_corput(n_xy, draw(kq, PD_SCR_X)) + (float)px;         // adaptive.rs:106-110
-        sy = sobol(n_xy, draw(kq, PD_SCR_Y)) + (float)py;
-        t = van_der_corput(permute(i, sp.max_spp, draw(kq, PD_PERM_T)) + sp.taken, draw(kq, PD_SCR_T));
-        ks = key_sample(kq, i);
+    if (tid == 0u) {   // the group's box in tile coordinates (sixteen tiles at most)
+        int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;
+        for (uint32_t k = 0; k < n_g; ++k) { bx0 = min(bx0, (int)s_tiles[k].x); by0 = min(by0, (int)s_tiles[k].y); bx1 = max(bx1, (int)s_tiles[k].x); by1 = max(by1, (int)s_tiles[k].y); }
+        s_box[0] = bx0; s_box[1] = by0; s_box[2] = bx1; s_box[3] = by1;
     }
+    __syncthreads();
+    const bool square = s_box[2] - s_box[0] < 4 && s_box[3] - s_box[1] < 4;   // the whole group fits one window
+    const uint32_t n_sub = square ? 1u : n_g, per_sub = square ? n_g : 1u;
+    const uint32_t per_tile = 64u * sp.count;
     Counters cnt;
     cnt.rays = 0; cnt.vertices = 0;
-    Lane ln;
-    lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), ks);
-    ln.smp_kind = sp.kind; ln.smp_offset = sp.taken;
-    if (!active) ln.flags = 0u;
-    uint32_t* const my_stack = s_stack + threadIdx.x;
-    if (FEAT == (FEAT_ALL | FEAT_TEX) && sc.integrator == TRAY_INTEGRATOR_WHITTED) {
-        Ray cam;
-        cam.o = LN_O(ln); cam.d = ln.d; cam.min_t = 0.0f; cam.max_t = TR_INF; cam.time = ln.time; cam.col = ln.col;
-        uint32_t wv = 0u, wr = 0u;
-        ln.illum = whitted_run<ANIM>(sc, scp, my_stack, cam, ln.ks, active, cnt, wv, wr, sp.kind, sp.taken);
+    uint32_t n_samples = 0u;
+    for (uint32_t sub = 0; sub < n_sub; ++sub) {
+        // the window of this pass: the tiles [first, first + per_sub) of the group
+        const uint32_t first = square ? 0u : sub;
+        const int tx0 = square ? s_box[0] : (int)s_tiles[first].x, ty0 = square ? s_box[1] : (int)s_tiles[first].y;
+        const int tx1 = square ? s_box[2] : tx0, ty1 = square ? s_box[3] : ty0;
+        const int wx0 = tx0 * 8 - sc.fpw, wy0 = ty0 * 8 - sc.fph;
+        const int ww = (tx1 - tx0 + 1) * 8 + 2 * sc.fpw + 1, wh = (ty1 - ty0 + 1) * 8 + 2 * sc.fph + 1;
+        for (int k = (int)tid; k < 4 * ww * wh; k += TR_BLOCK) s_win[k] = 0.0f;
+        if (tid == 0u) s_next = 0u;
+        __syncthreads();
+        const uint32_t n_pairs = per_sub * per_tile;
+        bool pairs_left = true, pending = false;
+        float sx = 0.0f, sy = 0.0f;
+        uint32_t slot = 0u, i_smp = 0u;
+        Lane ln;
         ln.flags = 0u;
-    }
-    while (__any(ln.flags & LF_ALIVE)) {
-#pragma nounroll
-        for (int stage = 0; stage < 3; ++stage) {
-            const bool alive = (ln.flags & LF_ALIVE) != 0u;
-            if (stage == 2 && alive) mis_ray_filter<ANIM>(sc, ln);
-            const bool want_ray = alive && (stage == 0 || (stage == 1 && (ln.flags & LF_SHADOW)) || (stage == 2 && (ln.flags & LF_MIS)));
-            TraceResult tr_;
-            tr_.hit = false;
-            tr_.rec.t = 0.0f; tr_.rec.inst = 0xffffffffu; tr_.rec.prim = 0u; tr_.rec.b1 = 0.0f; tr_.rec.b2 = 0.0f;
-            if (stage == 2 && alive && (ln.flags & LF_MIS_MISS)) cnt.rays++;
-            if (__any(want_ray)) {
-                if (want_ray) cnt.rays++;
-                const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
-                tr_ = trace<ANIM>(scp, my_stack, r, stage == 1, want_ray);
+        ln.illum = mk(0.0f, 0.0f, 0.0f);
+        ln.perm_lds = TR_LDS_B(s_perm);
+        for (;;) {   // one path vertex per live lane and step (k_path_tiles)
+            const bool idle = !(ln.flags & LF_ALIVE);
+            if (idle && pending) {   // the lane's previous sample is finished: RenderTarget::write it into the group's window, its luminance into the pixel's list
+                const f3 c = lane_result(ln);
+                film_splat_window(sc, s_win, wx0, wy0, ww, sc.filter_table, sx, sy, c);
+                if (sp.kind == TRAY_SAMPLER_ADAPTIVE) px_lum[(size_t)slot * sp.lum_cap + sp.before + i_smp] = 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z;   // Colorf::luminance (color.rs:43-45)
+                pending = false;
             }
-            if (stage == 1) {
-                vertex_queries<ANIM, FEAT>(sc, ln, tr_.hit, alive);
-            } else if (alive) {
-                if (stage == 0) {
-                    if (tr_.hit) vertex_begin<ANIM>(sc, ln, tr_.rec, cnt);
-                    else ln.flags &= ~LF_ALIVE;
-                } else {
-                    if (!vertex_end<ANIM>(sc, ln, tr_.hit, tr_.rec)) ln.flags &= ~LF_ALIVE;
+            const unsigned long long idle_m = __ballot(idle);
+            if (pairs_left && idle_m != 0ull) {
+                const uint32_t n_idle = (uint32_t)__popcll(idle_m), leader = (uint32_t)__ffsll((long long)idle_m) - 1u;
+                uint32_t base = 0u;
+                if (lane == leader) base = atomicAdd(&s_next, n_idle);
+                base = __shfl(base, (int)leader);
+                pairs_left = base + n_idle < n_pairs;
+                const uint32_t pair = base + (uint32_t)__popcll(idle_m & ((1ull << lane) - 1ull));
+                if (idle && pair < n_pairs) {
+                    // pair -> (tile of the pass, pixel of the tile in Region order, sample of the round): sampler/mod.rs:82-98 walks x fastest
+                    const uint32_t t_in = pair / per_tile, rem = pair - t_in * per_tile, pix = rem / sp.count, i = rem - pix * sp.count;
+                    const uint2 tile = s_tiles[first + t_in];
+                    slot = (g0 + first + t_in) * 64u + pix;   // the pixel's index in the batch (px_state / px_lum)
+                    if (!(sp.kind == TRAY_SAMPLER_ADAPTIVE && (px_state[slot] & 1u))) {   // (a pixel k_sampler_decide has finished sits out: its pairs are dropped)
+                        const uint32_t px = tile.x * 8u + (pix & 7u), py = tile.y * 8u + (pix >> 3);
+                        const uint32_t kp = key_pixel(kf, py * sc.width + px);
+                        float t;
+                        uint32_t ks;
+                        if (sp.kind == TRAY_SAMPLER_LOW_DISCREPANCY) {                          // the tile kernel's samples (scenes with an AnimatedMesh)
+                            pixel_sample(kp, i, sp.count, px, py, sx, sy, t);
+                            ks = key_sample(kp, i);
+                        } else if (sp.kind == TRAY_SAMPLER_UNIFORM) {
+                            sx = (float)px + 0.5f; sy = (float)py + 0.5f;                      // uniform.rs:28
+                            t = (float)(draw(kp, PD_SCR_T) >> 8) / 16777216.0f;                // uniform.rs:42-46
+                            ks = key_sample(kp, 0u);
+                        } else {
+                            const uint32_t kq = key_pass(kp, sp.pass);
+                            const uint32_t n_xy = permute(i, sp.count, draw(kq, PD_PERM_XY)) + sp.taken;
+                            sx = van_der_corput(n_xy, draw(kq, PD_SCR_X)) + (float)px;         // adaptive.rs:106-110
+                            sy = sobol(n_xy, draw(kq, PD_SCR_Y)) + (float)py;
+                            t = van_der_corput(permute(i, sp.max_spp, draw(kq, PD_PERM_T)) + sp.taken, draw(kq, PD_SCR_T));
+                            ks = key_sample(kq, i);
+                        }
+                        lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), ks);
+                        ln.smp_kind = sp.kind; ln.smp_offset = sp.taken;
+                        i_smp = i;
+                        pending = true;
+                        ++n_samples;
+                    }
+                }
+            }
+            if (!__any(ln.flags & LF_ALIVE)) { if (pairs_left) continue; break; }   // (dropped pairs can leave a wave without a live lane while pairs remain)
+            if (FEAT == (FEAT_ALL | FEAT_TEX) && sc.integrator == TRAY_INTEGRATOR_WHITTED) {   // every camera sample of the wave to its end (dev_whitted.h)
+                Ray cam;
+                cam.o = LN_O(ln); cam.d = ln.d; cam.min_t = 0.0f; cam.max_t = TR_INF; cam.time = ln.time; cam.col = ln.col;
+                uint32_t wv = 0u, wr = 0u;
+                ln.illum = whitted_run<ANIM>(sc, scp, my_stack, cam, ln.ks, (ln.flags & LF_ALIVE) != 0u, cnt, wv, wr, sp.kind, sp.taken);
+                ln.flags &= ~LF_ALIVE;
+                continue;
+            }
+#pragma nounroll
+            for (int stage = 0; stage < 3; ++stage) {
+                const bool alive = (ln.flags & LF_ALIVE) != 0u;
+                if (stage == 2 && alive) mis_ray_filter<ANIM>(sc, ln);
+                const bool want_ray = alive && (stage == 0 || (stage == 1 && (ln.flags & LF_SHADOW)) || (stage == 2 && (ln.flags & LF_MIS)));
+                TraceResult tr_;
+                tr_.hit = false;
+                tr_.rec.t = 0.0f; tr_.rec.inst = 0xffffffffu; tr_.rec.prim = 0u; tr_.rec.b1 = 0.0f; tr_.rec.b2 = 0.0f;
+                if (stage == 2 && alive && (ln.flags & LF_MIS_MISS)) cnt.rays++;
+                if (__any(want_ray)) {
+                    if (want_ray) cnt.rays++;
+                    const Ray r = stage == 0 ? stage_a_ray(ln) : (stage == 1 ? stage_b_ray(ln) : stage_c_ray(ln));
+                    tr_ = trace<ANIM>(scp, my_stack, r, stage == 1, want_ray);
+                }
+                if (stage == 1) {
+                    vertex_queries<ANIM, FEAT>(sc, ln, tr_.hit, alive);
+                } else if (alive) {
+                    if (stage == 0) {
+                        if (tr_.hit) vertex_begin<ANIM>(sc, ln, tr_.rec, cnt);
+                        else ln.flags &= ~LF_ALIVE;
+                    } else {
+                        if (!vertex_end<ANIM>(sc, ln, tr_.hit, tr_.rec)) ln.flags &= ~LF_ALIVE;
+                    }
                 }
             }
         }
-    }
-    if (active) {
-        const f3 c = lane_result(ln);
-        if (windowed) film_splat(sc, s_win, sc.filter_table, x0, y0, sx, sy, c);   // RenderTarget::write into the block's window (LDS atomics)
-        else film_splat_global(sc, rgbw, sc.filter_table, x0, y0, sx, sy, c);
-        if (sp.kind == TRAY_SAMPLER_ADAPTIVE) px_lum[(size_t)slot * sp.lum_cap + sp.before + i] = 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z;   // Colorf::luminance (color.rs:43-45)
-    }
-    __syncthreads();
-    if (windowed) {   // flush the window: film::Image::add_pixels semantics on the caller's RGBW buffer (as k_path_tiles)
-        const int wx0 = x0 - sc.fpw, wy0 = y0 - sc.fph;
-        const int ww = 8 + 2 * sc.fpw + 1, wh = 8 + 2 * sc.fph + 1;
-        for (int k = (int)threadIdx.x; k < ww * wh; k += TR_BLOCK) {
+        __syncthreads();
+        // flush the window: film::Image::add_pixels semantics on the caller's RGBW buffer (as k_path_tiles)
+        for (int k = (int)tid; k < ww * wh; k += TR_BLOCK) {
             const int wy = k / ww, wx = k - wy * ww;
             const int ix = wx0 + wx, iy = wy0 + wy;
             if (ix < 0 || iy < 0 || ix >= (int)sc.width || iy >= (int)sc.height) continue;
-            const int o = wy * WIN_STRIDE + wx;
-            const float a = s_win[o + 3 * WIN_PLANE];
-            if (a == 0.0f && s_win[o] == 0.0f && s_win[o + WIN_PLANE] == 0.0f && s_win[o + 2 * WIN_PLANE] == 0.0f) continue;
+            const float* __restrict__ o = s_win + 4 * k;
+            if (o[3] == 0.0f && o[0] == 0.0f && o[1] == 0.0f && o[2] == 0.0f) continue;
             float* dst = rgbw + ((size_t)iy * sc.width + ix) * 4;
-            atomicAdd(dst + 0, s_win[o]);
-            atomicAdd(dst + 1, s_win[o + WIN_PLANE]);
-            atomicAdd(dst + 2, s_win[o + 2 * WIN_PLANE]);
-            atomicAdd(dst + 3, a);
+            atomicAdd(dst + 0, o[0]); atomicAdd(dst + 1, o[1]); atomicAdd(dst + 2, o[2]); atomicAdd(dst + 3, o[3]);
         }
+        __syncthreads();
     }
-    if (stats && active) {   // (the compiler's atomic optimizer turns these into one atomic per wave)
-        atomicAdd(&stats->samples, 1ull);
-        atomicAdd(&stats->vertices, (unsigned long long)cnt.vertices);
-        atomicAdd(&stats->rays, (unsigned long long)cnt.rays);
+    if (stats) {   // one update per wave
+        for (int off = 32; off > 0; off >>= 1) { n_samples += __shfl_down(n_samples, off); cnt.vertices += __shfl_down(cnt.vertices, off); cnt.rays += __shfl_down(cnt.rays, off); }
+        if (lane == 0u && n_samples) {
+            atomicAdd(&stats->samples, (unsigned long long)n_samples);
+            atomicAdd(&stats->vertices, (unsigned long long)cnt.vertices);
+            atomicAdd(&stats->rays, (unsigned long long)cnt.rays);
+        }
     }
 }
 // Adaptive::report_results / needs_supersampling (adaptive.rs:55-75, 133-143) of every unfinished pixel of the batch, after round

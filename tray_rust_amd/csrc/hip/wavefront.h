@@ -856,6 +856,16 @@ __global__ __launch_bounds__(TR_BLOCK, WF_SHADE_WAVES) void k_wf_begin(const Dev
     bool dark = false;              // the slot's occlusion ray cannot matter: counted, not queued
     bool counted = false;
     uint32_t flags = i < n_active ? pu(pool, F_FLAGS, i) : 0u;
+    // Round 6: the slot's hit, ray and throughput records are fetched TOGETHER with its flags word, not after it was looked at -- nearly every slot of a
+    // round holds a vertex, and the kernel is a chain of dependent round trips (flags -> records -> instance / triangle -> material: three quarters of its
+    // wave cycles wait); this takes one link out of the chain. (A slot past n_active reads slot 0's records and ignores them.)
+    const uint32_t ip = i < n_active ? i : 0u;
+    HitRec rec;
+    ld_hit(pool, ip, rec);
+    const uint32_t p_bounce = pu(pool, F_BOUNCE, ip), p_ks = pu(pool, F_KS, ip);
+    const f3 p_o = ld3(pool, F_O, ip), p_d = ld3(pool, F_D, ip), p_t = ld3(pool, F_T, ip), p_illum = ld3(pool, F_ILLUM, ip);
+    const float p_time = ANIM ? pf(pool, F_TIME, ip) : 0.0f;
+    const uint32_t p_kidx = (ANIM && sc.xf_table) ? pu(pool, F_KIDX, ip) : ip;
     if (flags & WF_INVERTEX) {   // (WF_FOLD_C: the vertex is waiting for its stage C ray, which this round's traversal A carried: k_wf_advance closes it)
         flags = 0u;
     } else if ((flags & LF_ALIVE) && !(flags & WF_HIT_A)) {   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
@@ -864,17 +874,15 @@ __global__ __launch_bounds__(TR_BLOCK, WF_SHADE_WAVES) void k_wf_begin(const Dev
         Lane ln;
         ln.perm_lds = TR_LDS_B(s_perm);
         ln.flags = flags;
-        ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
-        LN_O(ln) = ld3(pool, F_O, i); ln.d = ld3(pool, F_D, i);
-        ln.throughput = ld3(pool, F_T, i); ln.illum = ld3(pool, F_ILLUM, i);
+        ln.bounce = p_bounce; ln.ks = p_ks;
+        LN_O(ln) = p_o; ln.d = p_d;
+        ln.throughput = p_t; ln.illum = p_illum;
         const f3 illum_in = ln.illum;
         // (hit.dg.ng of the camera ray's hit, quirk Q1: read by vertex_begin only on a specular chain -- at bounce 0 it is what vertex_begin writes)
         ln.first_ng = (ln.bounce != 0u && (flags & LF_SPECULAR)) ? ld3(pool, F_NG, i) : mk(0.0f, 0.0f, 0.0f);
-        HitRec rec;
-        ld_hit(pool, i, rec);
         Counters cnt;
         cnt.rays = 0; cnt.vertices = 0;
-        ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = (ANIM && sc.xf_table) ? pu(pool, F_KIDX, i) : i;
+        ln.time = p_time; ln.col = p_kidx;
         vertex_begin<ANIM>(sc, ln, rec, cnt);
         counted = true;
         // The occlusion ray of a light sample only matters if BSDF::eval of the light direction is not black (mod.rs:127-131 test the
