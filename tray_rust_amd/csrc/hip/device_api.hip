@@ -281,6 +281,16 @@ static uint32_t wf_slot_count(const TrayDeviceScene* s, size_t reclaimable = 0, 
         const uint64_t fit = budget / per_slot / TR_BLOCK * TR_BLOCK;
         slots = std::min<uint64_t>(slots, std::max<uint64_t>(fit, (uint64_t)64 * TR_BLOCK));   // (at least 64 chunks: below that the schedule cannot fill the chip)
     }
+    // (round 6) the schedule is fastest with ONE work item per chunk (profiles/r06_c5_pool_128m.txt: 96 M slots under 16 slices per tile lose to 64 M under 8), so a
+    // pool that memory cut below the film's 16 slices per tile is cut further to the next tiles x 256 x 2^k below it -- never to less than one chunk per tile
+    {
+        const uint64_t per_tile_level = (uint64_t)std::max<uint32_t>(s->n_tiles, 1u) * TR_BLOCK;
+        if (slots > per_tile_level && !s->wf_req_slots && !getenv("TRAYHIP_WF_SLOTS")) {
+            uint64_t fit = per_tile_level;
+            while (fit * 2u <= slots && fit * 2u <= per_tile_level * WF_MAX_SLICES) fit *= 2u;
+            slots = fit;
+        }
+    }
     return (uint32_t)slots;
 }
 
