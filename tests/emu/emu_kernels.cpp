@@ -358,8 +358,8 @@ int emu_wf_trace(const TrayFlatScene* f, int stage, uint32_t n, const TrayRay* r
     std::vector<DevStats> stats(WF_STAT_SLOTS);
     std::memset(stats.data(), 0, stats.size() * sizeof(DevStats));
     // (the traversal, then the rays it handed to the reference's binary traversal: wf_round of kernels.hip)
-#define EMU_TRACE(S) do { launch(blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, 0>(e.d, pool, queue.data(), qctl.data(), stats.data(), lds_depth, overflow.data(), fallback.data()); }); \
-                          launch(2, TR_BLOCK, [&] { k_wf_trace_fallback<S, 0>(e.d, pool, qctl.data(), fallback.data()); }); } while (0)
+#define EMU_TRACE(S) do { launch(blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, 0>(e.d, pool, queue.data(), qctl.data(), stats.data(), lds_depth, overflow.data(), fallback.data(), 0u); }); \
+                          launch(2, TR_BLOCK, [&] { k_wf_trace_fallback<S, 0>(e.d, pool, qctl.data(), fallback.data(), 0u); }); } while (0)
     if (stage == 0) EMU_TRACE(0); else if (stage == 1) EMU_TRACE(1); else EMU_TRACE(2);
 #undef EMU_TRACE
     g_wf_deferred += qctl[WF_FB_WORD + stage];
@@ -509,6 +509,8 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     int rc = 0;
     uint64_t rounds = 0;
     // ray binning before the traversal stages, as launch_wavefront sets it up (TRAYHIP_WF_BIN: bit 0 = stage A, bit 1 = stage B)
+    bool fused = sorted && WF_FOLD_C && WF_FUSED_DEFAULT != 0;   // launch_wavefront's choice of the shading form (TRAYHIP_WF_FUSED)
+    if (const char* fe = getenv("TRAYHIP_WF_FUSED")) fused = sorted && WF_FOLD_C && atoi(fe) != 0;
     uint32_t bin_stages = WF_BIN_DEFAULT;
     if (const char* be = getenv("TRAYHIP_WF_BIN")) bin_stages = (uint32_t)std::max(0, atoi(be)) & 3u;
     std::vector<uint32_t> bin_ctl((size_t)2u * 2u * WF_SEGS * WF_BINS, 0u);
@@ -523,6 +525,13 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
         if (WF_FOLD_C && (bin_stages & 1u)) { EMU_BIN(0, qa, qc, bin_ctl.data()); EMU_TRACE_STAGE(0, A, qc, qb); }   /* wf_round: the binned copy lies in the idle queue's buffer */ \
         else EMU_TRACE_STAGE(0, A, qa, qb);                                                                                                   \
         std::memset(qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t));   /* wf_round: the control words are cleared between trace A and k_wf_begin */ \
+        if (fused) {   /* wf_round: k_wf_sort + k_wf_shade_kind, then the occlusion stage */                                                  \
+            EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_sort<0>(e.d, pool, n_active, qctl, kind_queues.data()); });                                 \
+            EMU_SHADE_KIND(A, TRAY_MAT_MATTE); EMU_SHADE_KIND(A, TRAY_MAT_PLASTIC); EMU_SHADE_KIND(A, TRAY_MAT_METAL); EMU_SHADE_KIND(A, TRAY_MAT_GLASS); \
+            EMU_SHADE_KIND(A, TRAY_MAT_ROUGH_GLASS); EMU_SHADE_KIND(A, TRAY_MAT_SPECULAR_METAL); EMU_SHADE_KIND(A, TRAY_MAT_MERL);          \
+            EMU_TRACE_STAGE(1, A, qb, qc);                                                                                                  \
+            break;                                                                                                                          \
+        }                                                                                                                                   \
         EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_begin<A>(e.d, pool, n_active, stats.data(), qb, qctl, sorted ? kind_queues.data() : nullptr); }); \
         if (WF_FOLD_C && (bin_stages & 2u)) { EMU_BIN(1, qb, qa, bin_ctl.data() + 2u * WF_SEGS * WF_BINS); EMU_TRACE_STAGE(1, A, qa, qc); }     \
         else EMU_TRACE_STAGE(1, A, qb, qc);                                                                                                   \
@@ -532,11 +541,13 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
         } else EMU_K(n_chunks, TR_BLOCK, [&] { k_wf_query<A, FEAT_ALL | FEAT_TEX>(e.d, pool, n_active, WF_FOLD_C ? nullptr : qc, qctl, stats.data(), qa); });  \
         if (!WF_FOLD_C) EMU_TRACE_STAGE(2, A, qc, qb);                                                                                                        \
     } while (0)
+#define EMU_SHADE_KIND(A, K) do { if (kinds_present & (1u << K)) EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_shade_kind<A, K>(e.d, pool, kind_queues.data(), qctl, stats.data(), qa, qb); }); } while (0)
 #define EMU_QUERY_KIND(A, K) do { if (kinds_present & (1u << K)) EMU_K(q_blocks, TR_BLOCK, [&] { k_wf_query_kind<A, K>(e.d, pool, kind_queues.data(), WF_FOLD_C ? nullptr : qc, qctl, stats.data(), qa); }); } while (0)
 #define EMU_TRACE_STAGE(S, A, Q, FB) /* FB: the queue buffer that is idle during stage S takes the deferred rays' records (wf_round) */                                                                                                          \
     do {                                                                                                                                    \
-        EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data(), FB); }, dyn_lds); \
-        EMU_K(1u, TR_BLOCK, [&] { k_wf_trace_fallback<S, A>(e.d, pool, qctl, FB); }, fb_lds);                                    \
+        const uint32_t fu_ = (S == 1 && fused) ? 1u : 0u;                                                                                   \
+        EMU_K(trace_blocks, TR_BLOCK, [&] { k_wf_trace_dyn<S, A>(e.d, pool, Q, qctl, stats.data(), lds_depth, overflow.data(), FB, fu_); }, dyn_lds); \
+        EMU_K(1u, TR_BLOCK, [&] { k_wf_trace_fallback<S, A>(e.d, pool, qctl, FB, fu_); }, fb_lds);                                    \
         g_wf_deferred += qctl[WF_FB_WORD + S];                                                                                              \
     } while (0)
 #define EMU_BIN(S, Q, OUT, CTL) /* ray binning before stage S (wavefront.h: k_wf_bin_hist / k_wf_bin_scatter) */                          \
@@ -560,6 +571,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
 #undef EMU_BIN
 #undef EMU_TRACE_STAGE
 #undef EMU_QUERY_KIND
+#undef EMU_SHADE_KIND
 #undef EMU_ROUND
 #undef EMU_K
     if (stats_out) {

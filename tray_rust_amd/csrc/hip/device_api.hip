@@ -107,6 +107,7 @@ struct TrayDeviceScene {
     uint32_t* d_kind_queues = nullptr;   // WF_MAT_KINDS x n_slots slot indices
     uint32_t* d_bin_ctl = nullptr;       // ray binning before the traversal stages (wavefront.h: k_wf_bin_hist): per view and stage, histogram + cursors of every segment
     WfBinGrid bin_grid{};                // the cells of the frame's BVH<Instance> box
+    bool wf_fused = true;                // fused shading between the traversals (wavefront.h: k_wf_shade_kind); TRAYHIP_WF_FUSED=0|1 overrides
     uint32_t wf_bin_stages = 0u;         // bit 0: stage A rays are binned, bit 1: stage B rays (TRAYHIP_WF_BIN overrides)
     uint32_t mat_kinds_present = 0;   // bit per TRAY_MAT_* kind among the scene's materials
     // tray_scene_set_sampler: which Sampler the render calls stand for, and the per-pixel state of k_sampler_pass / k_sampler_decide
@@ -214,12 +215,25 @@ static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, ui
         hipLaunchKernelGGL(k_wf_bin_scatter<0>, bgrid, block, 0, stream, v.pool, v.qa, v.qc, v.qctl, v.bin_ctl, s->bin_grid);
         trace_a = v.qc;
     }
-    hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, trace_a, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qb);
-    hipLaunchKernelGGL((k_wf_trace_fallback<0, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qb);
+    hipLaunchKernelGGL((k_wf_trace_dyn<0, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, trace_a, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qb, 0u);
+    hipLaunchKernelGGL((k_wf_trace_fallback<0, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qb, 0u);
     // the control words of every queue are cleared HERE, between the traversal of stage A and the first shading kernel: queue A, its cursors, the
     // regeneration queue and stage A's fallback counter are consumed, stage B's and the material kinds' are not produced yet -- and the count of
     // queue A must survive from the query kernels below (which append the NEXT round's continuation rays) to the next round's traversal
     (void)hipMemsetAsync(v.qctl, 0, WF_QCTL_WORDS * sizeof(uint32_t), stream);
+    // Fused shading (wavefront.h: k_wf_sort + k_wf_shade_kind; scenes whose materials are sorted by kind, i.e. without textured ones): the vertex is shaded in ONE
+    // kernel between the two traversals, its light term pending until the occlusion ray is traced; TRAYHIP_WF_FUSED=0: the two-kernel form of rounds 2-5
+    const uint32_t fused = (v.kq && s->wf_fused && WF_FOLD_C) ? 1u : 0u;
+    if (fused) {
+        hipLaunchKernelGGL(k_wf_sort<0>, grid, block, 0, stream, v.dev, v.pool, n_active, v.qctl, v.kq);
+#define WF_SHADE_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_shade_kind<ANIM, K>), qgrid, block, 0, stream, v.dev, v.pool, v.kq, v.qctl, s->d_stats, v.qa, v.qb)
+        WF_SHADE_KIND(TRAY_MAT_MATTE); WF_SHADE_KIND(TRAY_MAT_PLASTIC); WF_SHADE_KIND(TRAY_MAT_METAL); WF_SHADE_KIND(TRAY_MAT_GLASS);
+        WF_SHADE_KIND(TRAY_MAT_ROUGH_GLASS); WF_SHADE_KIND(TRAY_MAT_SPECULAR_METAL); WF_SHADE_KIND(TRAY_MAT_MERL);
+#undef WF_SHADE_KIND
+        hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qb, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qc, 1u);
+        hipLaunchKernelGGL((k_wf_trace_fallback<1, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qc, 1u);
+        return;
+    }
     hipLaunchKernelGGL(k_wf_begin<ANIM>, grid, block, 0, stream, v.dev, v.pool, n_active, s->d_stats, v.qb, v.qctl, v.kq);
     const uint32_t* trace_b = v.qb;
     if (WF_FOLD_C && v.bin_ctl && (s->wf_bin_stages & 2u)) {
@@ -228,8 +242,8 @@ static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, ui
         hipLaunchKernelGGL(k_wf_bin_scatter<1>, bgrid, block, 0, stream, v.pool, v.qb, v.qa, v.qctl, ctl_b, s->bin_grid);
         trace_b = v.qa;
     }
-    hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, trace_b, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qc);
-    hipLaunchKernelGGL((k_wf_trace_fallback<1, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qc);
+    hipLaunchKernelGGL((k_wf_trace_dyn<1, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, trace_b, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qc, 0u);
+    hipLaunchKernelGGL((k_wf_trace_fallback<1, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qc, 0u);
     uint32_t* const qc = WF_FOLD_C ? nullptr : v.qc;   // (WF_FOLD_C: stage C rays travel with the next round's stage A rays, no queue and no launch of their own)
     if (v.kq) {   // kind-pure shading over the sorted queues: one launch per material kind the scene contains
 #define WF_QUERY_KIND(K) if (s->mat_kinds_present & (1u << K)) hipLaunchKernelGGL((k_wf_query_kind<ANIM, K>), qgrid, block, 0, stream, v.dev, v.pool, v.kq, qc, v.qctl, s->d_stats, v.qa)
@@ -239,8 +253,8 @@ static void wf_round(TrayDeviceScene* s, const WfView& v, const uint2* tiles, ui
     } else hipLaunchKernelGGL((k_wf_query<ANIM, FEAT_ALL | FEAT_TEX>), grid, block, 0, stream, v.dev, v.pool, n_active, qc, v.qctl, s->d_stats, v.qa);
     if (WF_FOLD_C) return;
     // (builds without WF_FOLD_C: the deferred rays of stage C go to B's buffer -- A's holds the next round's continuation rays by now)
-    hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qc, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qb);
-    hipLaunchKernelGGL((k_wf_trace_fallback<2, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qb);
+    hipLaunchKernelGGL((k_wf_trace_dyn<2, ANIM>), tgrid, block, s->trace_lds_bytes, stream, v.dev, v.pool, v.qc, v.qctl, s->d_stats, s->trace_lds_depth, v.overflow, v.qb, 0u);
+    hipLaunchKernelGGL((k_wf_trace_fallback<2, ANIM>), fgrid, block, s->stack_bytes, stream, v.dev, v.pool, v.qctl, v.qb, 0u);
 }
 
 // Path pool slots of the wavefront schedule: never more than the film has pixels x 4 x WF_MAX_SLICES (a chunk of 256 per tile slice), and for
@@ -475,6 +489,8 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         s->bin_grid = f->n_top_nodes ? wf_bin_grid(f->top_nodes[0].bmin, f->top_nodes[0].bmax) : WfBinGrid{};
         s->wf_bin_stages = WF_BIN_DEFAULT;
         if (const char* e = getenv("TRAYHIP_WF_BIN")) s->wf_bin_stages = (uint32_t)std::max(0, atoi(e)) & 3u;
+        s->wf_fused = WF_FUSED_DEFAULT != 0;
+        if (const char* e = getenv("TRAYHIP_WF_FUSED")) s->wf_fused = atoi(e) != 0;
     }
     UP(top_order, f->top_order, f->n_top_order)
     UPS(meshes, keep_trees ? f->meshes : paired.meshes.data(), f->n_meshes)          // (kept: the donor's copies are not written)
@@ -996,7 +1012,7 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             if (v.bin_ctl && s->wf_bin_stages) HIP_CHECK(hipMemsetAsync(v.bin_ctl, 0, (size_t)2u * 2u * WF_SEGS * WF_BINS * sizeof(uint32_t), v.stream));
             if (s->animated) wf_round<1>(s, v, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, slice_shift);
             else wf_round<0>(s, v, tiles, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, slice_shift);
-            launches += (WF_FOLD_C ? 8 : 10) + ((s->wf_bin_stages & 1u) ? 2 : 0) + ((s->wf_bin_stages & 2u) ? 2 : 0);
+            launches += (WF_FOLD_C ? 8 : 10) + ((s->wf_bin_stages & 1u) ? 2 : 0) + ((s->wf_bin_stages & 2u) ? 2 : 0);   // (nominal: a kind-pure launch per material kind present comes on top in both forms)
         }
         if (round % WF_POLL == WF_POLL - 1) {
             HIP_CHECK(hipGetLastError());

@@ -53,7 +53,7 @@ TR_K(tr::k_wf_trace_dyn<0, 1>) TR_K(tr::k_wf_trace_dyn<1, 1>) TR_K(tr::k_wf_trac
 TR_K(tr::k_wf_trace_fallback<0, 0>) TR_K(tr::k_wf_trace_fallback<1, 0>) TR_K(tr::k_wf_trace_fallback<2, 0>)
 TR_K(tr::k_wf_trace_fallback<0, 1>) TR_K(tr::k_wf_trace_fallback<1, 1>) TR_K(tr::k_wf_trace_fallback<2, 1>)
 TR_K(tr::k_wf_advance<0>) TR_K(tr::k_wf_advance<1>) TR_K(tr::k_wf_regen<0>) TR_K(tr::k_wf_regen<1>)
-TR_K(tr::k_wf_bin_hist<0>) TR_K(tr::k_wf_bin_hist<1>) TR_K(tr::k_wf_bin_scatter<0>) TR_K(tr::k_wf_bin_scatter<1>)
+TR_K(tr::k_wf_bin_hist<0>) TR_K(tr::k_wf_bin_hist<1>) TR_K(tr::k_wf_bin_scatter<0>) TR_K(tr::k_wf_bin_scatter<1>) TR_K(tr::k_wf_sort<0>)
 #endif
 #if TR_GROUP(7)   // ... shading side, static scenes
 TR_K(tr::k_wf_begin<0>)
@@ -61,6 +61,14 @@ TR_K(tr::k_wf_query_kind<0, TRAY_MAT_MATTE>) TR_K(tr::k_wf_query_kind<0, TRAY_MA
 TR_K(tr::k_wf_query_kind<0, TRAY_MAT_ROUGH_GLASS>) TR_K(tr::k_wf_query_kind<0, TRAY_MAT_SPECULAR_METAL>) TR_K(tr::k_wf_query_kind<0, TRAY_MAT_MERL>)
 TR_K(tr::k_wf_query<0, FEAT_ALL | FEAT_TEX>)
 TR_K(k_debug_sample_radiance<0>)
+#endif
+#if TR_GROUP(10)   // ... fused shading (round 6), static scenes
+TR_K(tr::k_wf_shade_kind<0, TRAY_MAT_MATTE>) TR_K(tr::k_wf_shade_kind<0, TRAY_MAT_PLASTIC>) TR_K(tr::k_wf_shade_kind<0, TRAY_MAT_METAL>) TR_K(tr::k_wf_shade_kind<0, TRAY_MAT_GLASS>)
+TR_K(tr::k_wf_shade_kind<0, TRAY_MAT_ROUGH_GLASS>) TR_K(tr::k_wf_shade_kind<0, TRAY_MAT_SPECULAR_METAL>) TR_K(tr::k_wf_shade_kind<0, TRAY_MAT_MERL>)
+#endif
+#if TR_GROUP(11)   // ... fused shading, moving scenes
+TR_K(tr::k_wf_shade_kind<1, TRAY_MAT_MATTE>) TR_K(tr::k_wf_shade_kind<1, TRAY_MAT_PLASTIC>) TR_K(tr::k_wf_shade_kind<1, TRAY_MAT_METAL>) TR_K(tr::k_wf_shade_kind<1, TRAY_MAT_GLASS>)
+TR_K(tr::k_wf_shade_kind<1, TRAY_MAT_ROUGH_GLASS>) TR_K(tr::k_wf_shade_kind<1, TRAY_MAT_SPECULAR_METAL>) TR_K(tr::k_wf_shade_kind<1, TRAY_MAT_MERL>)
 #endif
 #if TR_GROUP(8)   // ... shading side, moving scenes
 TR_K(tr::k_wf_begin<1>)
@@ -74,7 +82,7 @@ TR_K(k_sampler_pass<0, FEAT_NONE>) TR_K(k_sampler_pass<0, FEAT_ALL | FEAT_TEX>)
 TR_K(k_sampler_pass<2, FEAT_NONE>) TR_K(k_sampler_pass<2, FEAT_ALL | FEAT_TEX>)
 TR_K(k_sampler_pass<3, FEAT_NONE>) TR_K(k_sampler_pass<3, FEAT_ALL | FEAT_TEX>)
 #endif
-#define TR_INST_GROUPS 10
+#define TR_INST_GROUPS 12
 
 #undef TR_K_TILES_LF
 #undef TR_K

@@ -27,7 +27,9 @@ namespace tr {
 #define WF_STAT_SLOTS 1024
 enum : uint32_t {   // flags that only exist between wavefront stages
     WF_HIT_A = 32u, WF_OCCLUDED = 64u, WF_HIT_C = 128u, WF_INVERTEX = 256u, WF_FINISHED = 512u,
-    WF_CFLIGHT = 4096u   // the vertex's BSDF-sampled light ray (stage C) travels with this round's stage A rays (WF_FOLD_C)
+    WF_CFLIGHT = 4096u,  // the vertex's BSDF-sampled light ray (stage C) travels with this round's stage A rays (WF_FOLD_C)
+    WF_PENDING = 8192u   // fused shading (k_wf_shade_kind): the vertex's light term was computed before its occlusion ray was traced -- (F_PEND_TV, F_PEND_DL)
+                         // hold the factors, F_PEND_OCC the traversal's verdict; whoever touches the slot's radiance next applies `illum += tv * dl` if it says "free"
 };
 // Round 5: no traversal launch of its own for stage C. A few thousand of a round's millions of vertices trace a BSDF-sampled light ray
 // (estimate_direct's second half, mod.rs:141-166, for the samples mis_ray_filter could not dismiss); their launch was 95 % tail -- 0.5 ms per round
@@ -70,6 +72,8 @@ enum {
     F_U = F_TV + 3, F_V,   // hit.dg.u / v of the vertex (scenes with image textures)
     F_COUNT
 };
+// (fused shading: the vertex record's normal / tangent / material words hold the pending light term -- nobody stores a shading frame there in that schedule)
+enum { F_PEND_TV = F_N, F_PEND_DL = F_TAN, F_PEND_OCC = F_MAT };
 #define WF_HIT_WORDS 8
 static_assert(F_O == 8 && F_T == 16 && F_P == 24 && F_SOA == 44, "record groups of the pool: 8 (hit) + 16 (ray | throughput: one 64-byte record, pidx) + 20 (vertex) words");
 
@@ -144,6 +148,9 @@ TR_DEV void st_bsdf(const DevScene& sc, const WfPool& p, uint32_t i, const Bsdf&
 // Control words of segment s: qctl[s * WF_SEG_STRIDE + k]; k = 0..2 entries in queue A / B / C, 3..5 consumer cursors of the
 // traversal kernels, 6 entries in the regeneration queue, 8 + kind entries of the shading queue of a material kind (the material
 // sort of k_wf_begin). All zeroed at the start of every round.
+#ifndef WF_FUSED_DEFAULT
+#define WF_FUSED_DEFAULT 1   // k_wf_sort + k_wf_shade_kind instead of k_wf_begin + k_wf_query_kind (TRAYHIP_WF_FUSED overrides)
+#endif
 #define WF_SEGS 64u
 #define WF_SEG_STRIDE 32u
 #define WF_QCTL_WORDS (WF_SEGS * WF_SEG_STRIDE)
@@ -226,8 +233,14 @@ TR_DEV void wf_append_next_a(const WfPool& pool, uint32_t* __restrict__ queue_a,
 // the vertex is shaded, and the device functions in between vote over the lanes that are left): the barriers below count the threads that are still
 // there (a terminated wave is not waited for, a terminated lane is masked), so nothing may hang on a particular thread -- the counts s_cnt[0 .. 7] and
 // the ticket s_cnt[8] were zeroed while every thread was present; whoever draws ticket 0 reserves the workgroup's range.
+TR_DEV void wf_append_live(const WfPool& pool, uint32_t* __restrict__ queue, uint32_t* __restrict__ qctl, uint32_t k, bool want, uint32_t slot, f3 o, f3 d, uint32_t flags,
+                           uint32_t* s_cnt /* WF_SORT_KEYS + 1, zeroed */, uint32_t* s_base /* WF_SORT_KEYS */);
 TR_DEV void wf_append_next_a_live(const WfPool& pool, uint32_t* __restrict__ queue_a, uint32_t* __restrict__ qctl, bool want, uint32_t slot, f3 o, f3 d, uint32_t flags,
                                   uint32_t* s_cnt /* WF_SORT_KEYS + 1, zeroed */, uint32_t* s_base /* WF_SORT_KEYS */) {
+    wf_append_live(pool, queue_a, qctl, 0u, want, slot, o, d, flags, s_cnt, s_base);
+}
+TR_DEV void wf_append_live(const WfPool& pool, uint32_t* __restrict__ queue_a, uint32_t* __restrict__ qctl, uint32_t qk, bool want, uint32_t slot, f3 o, f3 d, uint32_t flags,
+                           uint32_t* s_cnt, uint32_t* s_base) {
 #ifndef WF_NO_OCTANT_SORT
     const uint32_t key = wf_octant(d);
     uint32_t rank = 0u;
@@ -236,14 +249,14 @@ TR_DEV void wf_append_next_a_live(const WfPool& pool, uint32_t* __restrict__ que
     if (atomicAdd(&s_cnt[WF_SORT_KEYS], 1u) == 0u) {
         uint32_t total = 0u;
         for (uint32_t b = 0; b < WF_SORT_KEYS; ++b) { const uint32_t c = s_cnt[b]; s_base[b] = total; total += c; }
-        const uint32_t base = total ? atomicAdd(qctl + wf_my_seg() * WF_SEG_STRIDE + 0u, total) : 0u;
+        const uint32_t base = total ? atomicAdd(qctl + wf_my_seg() * WF_SEG_STRIDE + qk, total) : 0u;
         for (uint32_t b = 0; b < WF_SORT_KEYS; ++b) s_base[b] += base;
     }
     __syncthreads();
     if (want) wf_put_ray(queue_a, (size_t)wf_my_seg() * pool.seg_cap + s_base[key] + rank, slot, o, d, flags);
 #else
     (void)s_cnt; (void)s_base;
-    wf_enqueue_ray(pool, queue_a, qctl, 0u, want, slot, o, d, flags);
+    wf_enqueue_ray(pool, queue_a, qctl, qk, want, slot, o, d, flags);
 #endif
 }
 // one thread per queue entry: the entry this thread owns, or false
@@ -313,7 +326,7 @@ TR_DEV bool wf_regular(f3 inv_dir) {
 template <int STAGE, int ANIM>
 __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const DevScene scv, WfPool pool, const uint32_t* __restrict__ queue,
                                                            uint32_t* __restrict__ qctl, DevStats* __restrict__ stats, uint32_t lds_depth,
-                                                           uint32_t* __restrict__ overflow, uint32_t* __restrict__ fallback) {
+                                                           uint32_t* __restrict__ overflow, uint32_t* __restrict__ fallback, uint32_t fused) {
     const DevScene& sc = scv;
     TR_DYN_LDS(uint32_t, s_stack);   // stack_depth x TR_BLOCK entries
     const LdsU stack = TR_LDS_U(s_stack) + threadIdx.x;   // (its own address space: a pop must not become a flat load that may hit either memory)
@@ -632,6 +645,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
                 flags = any ? (flags | bit) : (flags & ~bit);
             }
             if (STAGE != 1 && any) st_hit(pool, slot, flags, rec);   // one 20-byte piece of the slot's hit record + the flags word
+            else if (STAGE == 1 && fused) pu(pool, F_PEND_OCC, slot) = any ? 1u : 0u;   // (fused shading: the flags word has moved on -- the vertex is closed, its next ray queued)
             else pu(pool, F_FLAGS, slot) = flags;
             active = false;
         }
@@ -669,7 +683,7 @@ __global__ __launch_bounds__(TR_BLOCK, WF_TRACE_WAVES) void k_wf_trace_dyn(const
 // written exactly as k_wf_trace_dyn writes it. The ray is the record k_wf_trace_dyn copied there -- origin, direction, slot, flags, camera
 // bit -- whatever the pool holds (round 4 rebuilt it from pool fields its producers happened to store: ADVICE round 4).
 template <int STAGE, int ANIM>
-__global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_fallback(const DevScene scv, WfPool pool, const uint32_t* __restrict__ qctl, const uint32_t* __restrict__ fallback) {
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_fallback(const DevScene scv, WfPool pool, const uint32_t* __restrict__ qctl, const uint32_t* __restrict__ fallback, uint32_t fused) {
     const DevScene& sc = scv;
     TR_DYN_LDS(uint32_t, s_stack);
     const uint32_t n = qctl[WF_FB_WORD + STAGE];
@@ -695,6 +709,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_trace_fallback(const DevScene s
             flags = any ? (flags | bit) : (flags & ~bit);
         }
         if (STAGE != 1 && any) st_hit(pool, slot, flags, rec);
+        else if (STAGE == 1 && fused) pu(pool, F_PEND_OCC, slot) = any ? 1u : 0u;
         else pu(pool, F_FLAGS, slot) = flags;
     }
 }
@@ -940,6 +955,128 @@ __global__ __launch_bounds__(TR_BLOCK, WF_SHADE_WAVES) void k_wf_begin(const Dev
     }
 }
 
+// ---- Fused shading (round 6): k_wf_sort + k_wf_shade_kind replace k_wf_begin + k_wf_query_kind ----------------------------------------------
+// k_wf_begin set a vertex up, wrote its 80-byte record and queued the occlusion ray; after the traversal k_wf_query_kind read the record back (and the ray /
+// throughput record again) for the BSDF queries -- because ONE of the three queries, the light half of estimate_direct, is only added if the occlusion ray
+// finds nothing (mod.rs:127-131). Nothing else in the vertex depends on that ray: the BSDF half, the continuation and Russian roulette do not, and the light
+// half's VALUE does not either -- only whether it counts. So the vertex is shaded in one go, in registers: vertex_begin, the light term computed as if
+// unoccluded, the other queries, the end-of-vertex bookkeeping with the light term left out; the term's factors (throughput at the vertex, f * li * |cos| * w /
+// pdf) go to the slot's pending words, the occlusion ray is queued, the traversal writes its verdict into F_PEND_OCC, and whoever touches the slot's radiance
+// next -- this kernel at the path's next vertex, k_wf_advance for a finished sample or a vertex with a stage C ray -- performs the reference's own
+// `illum += throughput * direct` (path.rs:82) with direct = the term or zero. Same operations on the same values in the same order per sample: bit-identical.
+// A light term that is black needs no ray at all (the reference traces it and adds nothing): counted, not traced -- round 2's "dark" rays are the special case.
+// The material sort moves in front: k_wf_sort reads a slot's flags and the instance of its hit, ends the samples whose ray missed, and sorts the others by
+// material kind into the shading queues (counting sort in LDS, as k_wf_begin did).
+// the slot's pending light term, applied (flags & WF_PENDING; the caller clears the bit)
+TR_DEV f3 wf_apply_pending(const WfPool& pool, uint32_t i, f3 illum) {
+    const f3 tv = ld3(pool, F_PEND_TV, i), dl = ld3(pool, F_PEND_DL, i);
+    const f3 direct = pu(pool, F_PEND_OCC, i) != 0u ? mk(0.0f, 0.0f, 0.0f) : dl;
+    return illum + tv * direct;   // path.rs:82, as vertex_end writes it
+}
+template <int UNUSED>   // (a template so that it is instantiated in ONE translation unit: kernel_list.h)
+__global__ __launch_bounds__(TR_BLOCK) void k_wf_sort(const DevScene scv, WfPool pool, uint32_t n_active, uint32_t* __restrict__ qctl, uint32_t* __restrict__ kind_queues) {
+    __shared__ uint32_t s_cnt[8], s_base[8];
+    const DevScene& sc = scv;
+    const uint32_t tid = threadIdx.x, i = blockIdx.x * TR_BLOCK + tid;
+    if (tid < 8u) s_cnt[tid] = 0u;
+    __syncthreads();
+    uint32_t kind = WF_MAT_KINDS;
+    const uint32_t flags = i < n_active ? pu(pool, F_FLAGS, i) : 0u;
+    const uint32_t inst = reinterpret_cast<const uint32_t*>(pool.data)[(size_t)((i < n_active ? i : 0u) + pool.first) * WF_HIT_WORDS + 1u];   // (the hit record's instance, fetched with the flags)
+    if (flags & WF_INVERTEX) {
+        // (the vertex waits for its stage C ray: k_wf_advance closes it)
+    } else if ((flags & LF_ALIVE) && !(flags & WF_HIT_A)) {   // camera miss: black sample; continuation miss: path ends (path.rs:112-115)
+        pu(pool, F_FLAGS, i) = (flags & ~(LF_ALIVE | WF_INVERTEX)) | WF_FINISHED;
+    } else if (flags & LF_ALIVE) {
+        kind = sc.materials[sc.instances[inst].material_id].mat_kind;
+    }
+    uint32_t rank = 0u;
+    if (kind < WF_MAT_KINDS) rank = atomicAdd(&s_cnt[kind], 1u);
+    __syncthreads();
+    if (tid < WF_MAT_KINDS && s_cnt[tid]) s_base[tid] = atomicAdd(qctl + wf_my_seg() * WF_SEG_STRIDE + 8u + tid, s_cnt[tid]);
+    __syncthreads();
+    if (kind < WF_MAT_KINDS) kind_queues[((size_t)kind * WF_SEGS + wf_my_seg()) * pool.seg_cap + s_base[kind] + rank] = i;
+}
+template <int ANIM, int MK>
+__global__ __launch_bounds__(TR_BLOCK, WF_SHADE_WAVES) void k_wf_shade_kind(const DevScene scv, WfPool pool, const uint32_t* __restrict__ kind_queues, uint32_t* __restrict__ qctl,
+                                                                            DevStats* __restrict__ stats, uint32_t* __restrict__ queue_a, uint32_t* __restrict__ queue_b) {
+    const DevScene& sc = scv;
+    __shared__ uint4 s_perm[TR_PERM_BYTES / 16];
+    __shared__ uint32_t s_a_cnt[WF_SORT_KEYS + 1u], s_a_base[WF_SORT_KEYS], s_b_cnt[WF_SORT_KEYS + 1u], s_b_base[WF_SORT_KEYS];
+    if (blockIdx.x / WF_SEGS * TR_BLOCK >= qctl[wf_my_seg() * WF_SEG_STRIDE + 8u + MK]) return;   // (the whole workgroup lies past the queue's end)
+    s_perm[threadIdx.x] = reinterpret_cast<const uint4*>(sc.perm_pool)[threadIdx.x];
+    if (threadIdx.x <= WF_SORT_KEYS) { s_a_cnt[threadIdx.x] = 0u; s_b_cnt[threadIdx.x] = 0u; }
+    __syncthreads();
+    uint32_t i;
+    if (!wf_my_entry(pool, kind_queues + (size_t)MK * WF_SEGS * pool.seg_cap, qctl, 8u + MK, i)) return;
+    constexpr int FEAT = feat_of_material(MK);
+    constexpr uint32_t KM = km_of_material(MK);
+    const uint32_t flags = pu(pool, F_FLAGS, i);
+    HitRec rec;
+    ld_hit(pool, i, rec);
+    Lane ln;
+    ln.perm_lds = TR_LDS_B(s_perm);
+    ln.flags = flags & ~WF_PENDING;
+    ln.bounce = pu(pool, F_BOUNCE, i); ln.ks = pu(pool, F_KS, i);
+    LN_O(ln) = ld3(pool, F_O, i); ln.d = ld3(pool, F_D, i);
+    ln.throughput = ld3(pool, F_T, i); ln.illum = ld3(pool, F_ILLUM, i);
+    ln.time = ANIM ? pf(pool, F_TIME, i) : 0.0f; ln.col = (ANIM && sc.xf_table) ? pu(pool, F_KIDX, i) : i;
+    if (flags & WF_PENDING) ln.illum = wf_apply_pending(pool, i, ln.illum);   // the previous vertex's light term, now that its occlusion ray is traced
+    ln.first_ng = (ln.bounce != 0u && (flags & LF_SPECULAR)) ? ld3(pool, F_NG, i) : mk(0.0f, 0.0f, 0.0f);
+    Counters cnt;
+    cnt.rays = 0; cnt.vertices = 0;
+    vertex_begin<ANIM>(sc, ln, rec, cnt);
+    bool goes_on = false, shadow = false, skipped = false, mis_miss = false;
+    f3 ro = mk(0.0f, 0.0f, 0.0f), rd = ro, bo = ro, bd = ro;
+    uint32_t rf = 0u, bf = 0u;
+    if (!(ln.flags & LF_ALIVE)) {   // NormalsDebug: the sample ended at its first hit
+        pu(pool, F_FLAGS, i) = (ln.flags & ~WF_INVERTEX) | WF_FINISHED;
+        st3(pool, F_ILLUM, i, ln.illum);
+    } else {
+        if (ln.bounce == 0u) st3(pool, F_NG, i, ln.first_ng);
+        bo = ln.bsdf.p; bd = ln.aux_d;                    // the occlusion segment (vertex_begin), before the queries reuse aux_d
+        const bool had_shadow = (ln.flags & LF_SHADOW) != 0u;
+        vertex_queries<ANIM, FEAT, KM>(sc, ln, false);     // the light half as if unoccluded: ln.direct is the term, or stays zero
+        mis_ray_filter<ANIM>(sc, ln);
+        mis_miss = (ln.flags & LF_MIS_MISS) != 0u;
+        ln.flags &= ~(LF_MIS_MISS | LF_MIS_UNTESTED);
+        const f3 dl = ln.direct, tv = ln.t_vertex;
+        shadow = had_shadow && !is_black(dl);               // a black term: the reference traces the ray and adds nothing
+        skipped = had_shadow && !shadow;
+        st3(pool, F_T, i, ln.throughput);
+        if (!(ln.flags & LF_LAST)) { st3(pool, F_O, i, LN_O(ln)); st3(pool, F_D, i, ln.d); }
+        if (ln.flags & LF_MIS) {   // the vertex ends in k_wf_advance, after the BSDF-sampled light ray was traced (WF_FOLD_C): what it needs, field by field
+            pu(pool, F_FLAGS, i) = ln.flags | WF_INVERTEX | (shadow ? (uint32_t)WF_PENDING : 0u);
+            st3(pool, F_ILLUM, i, ln.illum);
+            st3(pool, F_DIRECT, i, dl); st3(pool, F_TV, i, tv);
+            st3(pool, F_AUX, i, ln.aux_d); st3(pool, F_MISF, i, ln.mis_f); st3(pool, F_LI, i, ln.li);
+            st3(pool, F_P, i, ln.bsdf.p); pu(pool, F_LINST, i) = ln.light_inst;
+        } else {
+            ln.direct = mk(0.0f, 0.0f, 0.0f);   // (the term is applied when its ray has been traced)
+            HitRec none;
+            none.t = 0.0f; none.inst = 0xffffffffu; none.prim = 0u; none.b1 = 0.0f; none.b2 = 0.0f;
+            const bool cont = vertex_end<ANIM>(sc, ln, false, none);
+            st3(pool, F_ILLUM, i, ln.illum);
+            pu(pool, F_BOUNCE, i) = ln.bounce;
+            uint32_t f2 = (ln.flags & ~(WF_INVERTEX | WF_HIT_A | WF_HIT_C | WF_OCCLUDED | LF_SHADOW | LF_MIS | LF_LAST)) | (shadow ? (uint32_t)WF_PENDING : 0u);
+            if (!cont) f2 = (f2 & ~LF_ALIVE) | WF_FINISHED;
+            pu(pool, F_FLAGS, i) = f2;
+            if (shadow) { st3(pool, F_PEND_TV, i, tv); st3(pool, F_PEND_DL, i, dl); }
+            if (cont) { goes_on = true; ro = LN_O(ln); rd = ln.d; rf = f2; }
+        }
+        bf = ln.flags;
+    }
+    {   // one counter update per wave: vertices; occlusion rays whose term is black and BSDF-sampled light rays proven to miss: counted like the reference's, not traced
+        const unsigned long long m = __ballot(1), sk = __ballot(skipped), mm = __ballot(mis_miss);
+        if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) {
+            atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].vertices, (unsigned long long)__popcll(m));
+            if ((sk | mm) != 0ull) atomicAdd(&stats[blockIdx.x & (WF_STAT_SLOTS - 1)].rays, (unsigned long long)(__popcll(sk) + __popcll(mm)));
+        }
+    }
+    wf_append_live(pool, queue_b, qctl, 1u, shadow, i, bo, bd, bf | WF_INVERTEX, s_b_cnt, s_b_base);
+    wf_append_live(pool, queue_a, qctl, 0u, goes_on, i, ro, rd, rf, s_a_cnt, s_a_base);
+}
+
 // Stage B shading of pool slot i: the BSDF queries of the vertex (light half, BSDF half, continuation)
 // Returns true when the path goes on from this vertex WITHOUT a stage C ray: (ray_o, ray_d, ray_flags) is then the ray towards the next vertex and
 // the slot's flags word as stored -- the caller appends it to the NEXT round's queue A (round 6: k_wf_advance used to re-read origin, direction and
@@ -1130,6 +1267,7 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
             ln.bounce = pu(pool, F_BOUNCE, i);
             ln.illum = ld3(pool, F_ILLUM, i);
             ln.direct = ld3(pool, F_DIRECT, i);
+            if ((flags & WF_PENDING) && pu(pool, F_PEND_OCC, i) != 0u) ln.direct = mk(0.0f, 0.0f, 0.0f);   // (fused shading: the stored light term was speculative, its ray found something)
             ln.t_vertex = ld3(pool, F_TV, i);
             ln.light_inst = pu(pool, F_LINST, i);
             if (flags & LF_MIS) {
@@ -1140,13 +1278,14 @@ __global__ __launch_bounds__(TR_BLOCK) void k_wf_advance(const DevScene scv, WfP
             const bool cont = vertex_end<ANIM>(sc, ln, (flags & WF_HIT_C) != 0u, rec);
             st3(pool, F_ILLUM, i, ln.illum);
             pu(pool, F_BOUNCE, i) = ln.bounce;
-            flags = ln.flags & ~(WF_INVERTEX | WF_HIT_A | WF_HIT_C | WF_OCCLUDED | LF_SHADOW | LF_MIS | LF_LAST | WF_CFLIGHT);
+            flags = ln.flags & ~(WF_INVERTEX | WF_HIT_A | WF_HIT_C | WF_OCCLUDED | LF_SHADOW | LF_MIS | LF_LAST | WF_CFLIGHT | WF_PENDING);
             if (!cont) flags = (flags & ~LF_ALIVE) | WF_FINISHED;
             closed_here = true;
         }
         // ---- RenderTarget::write of the samples that finished (here or in k_wf_begin)
         if (flags & WF_FINISHED) {
-            const f3 il = ld3(pool, F_ILLUM, i);
+            f3 il = ld3(pool, F_ILLUM, i);
+            if (flags & WF_PENDING) { il = wf_apply_pending(pool, i, il); flags &= ~WF_PENDING; }   // (fused shading: the last vertex's light term)
             const float sx = pf(pool, F_SX, i), sy = pf(pool, F_SY, i);
             const f3 col = mk(clampf(il.x, 0.0f, 1.0f), clampf(il.y, 0.0f, 1.0f), clampf(il.z, 0.0f, 1.0f));   // quirk Q3
             if (film_rows) film_splat_rows_global<true>(sc, s_bins, s_tx, rgbw, s_table, x0, y0, (int)((pu(pool, F_SNEXT, i) & 63u) >> 3), sx, sy, col);
