@@ -271,7 +271,7 @@ def main():
         roofline = {"bound": "valu" if (valu and valu["frac"] > frac) else "hbm",
                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac, 5), "traffic": traffic,
                     "valu": valu, "compute": compute,
-                    "kernel": "7 stage kernels per round (HIP events around the whole schedule)" if wave else "k_path_tiles",
+                    "kernel": "the stage kernels of a round -- advance, regen, trace A, sort, shade per material kind, trace B -- (HIP events around the whole schedule)" if wave else "k_path_tiles",
                     "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": int(algo_bytes),
                     "schedule": m.get("schedule"),
                     "counters_from_this_schedule": (None if not (compute and compute.get("schedule_of_the_counter_launch") and m.get("schedule")) else
