@@ -422,7 +422,7 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
     const uint32_t kf = key_frame_host(seed, e.d.frame);
     const int feat = feature_set(e);
     uint32_t levels = 1u;   // launch_tiles' rule: tiles are cut into progressive sample slices when there are few of them per workgroup
-    { const uint32_t most = work < 12u * blocks ? 5u : 3u; while (levels < most && (spp >> levels) >= 64u) ++levels; }
+    { const bool small = work < 12u * blocks; const uint32_t most = small ? 5u : 3u, least = small ? 64u : 256u; while (levels < most && (spp >> levels) >= least) ++levels; }
     if (const char* e_ = getenv("TRAYHIP_TILE_SLICES")) { levels = 1u; const uint32_t want = (uint32_t)std::max(1, atoi(e_)); while (levels < want && (spp >> levels) >= 1u) ++levels; }
     int rc;
     // tray_scene_create: the instantiation with mis_ray_filter for scenes with a sphere light or specular lobes

@@ -1254,7 +1254,7 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     { const int rc = xf_table_prepare(s, (uint64_t)tile_count * 64u * spp, stream); if (rc != TRAY_OK) return rc; }
     if (s->wavefront) return launch_wavefront(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
     // Items per tile (k_path_tiles: progressive slices, level-major: the launch ends with its smallest items). A slice costs its own film resolve and
-    // flush and keeps >= 64 samples per pixel. Measured (profiles/r06_tile_slices_progressive_ab.txt, items per tile 1 / 2 / 3 / 4 / 5): the whole
+    // flush and keeps >= 64 samples per pixel (>= 256 in a launch with many tiles per workgroup). Measured (profiles/r06_tile_slices_progressive_ab.txt, items per tile 1 / 2 / 3 / 4 / 5): the whole
     // dragon frame 718.5 / 740.6 / 750.3 / 752.7 / 755.1 Msamples/s (tiles that show the mesh cost several times a wall tile: with whole tiles the last
     // round of the 768 workgroups is one such tile), the whole cornell_box frame 1160.9 / 1163.5 / 1163.6 / 1159.9 / 1154.3; a GPU's eighth of the
     // frame (4050 tiles, slowest of the eight shards against an eighth of the whole frame): dragon 0.449 / 0.632 / 0.784 / 0.862 / 0.872,
@@ -1262,8 +1262,11 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     // TRAYHIP_TILE_SLICES=<items per tile> overrides.
     uint32_t levels = 1u;
     {
-        const uint32_t most = tile_count < 12u * (uint32_t)s->n_blocks ? 5u : 3u;
-        while (levels < most && (spp >> levels) >= 64u) ++levels;   // (the last two slices are spp >> (levels - 1) samples each)
+        // (a launch with many tiles per workgroup keeps >= 256 samples per slice: at 256 spp three items per tile cost cornell_box 2.8 %, 1114 against 1146
+        // Msamples/s, profiles/r06_c2_kept_gate_distance_ab.txt -- the resolves outweigh a tail that is 1 / 42 of the launch there)
+        const bool small = tile_count < 12u * (uint32_t)s->n_blocks;
+        const uint32_t most = small ? 5u : 3u, least = small ? 64u : 256u;
+        while (levels < most && (spp >> levels) >= least) ++levels;   // (the last two slices are spp >> (levels - 1) samples each)
     }
     if (const char* e = getenv("TRAYHIP_TILE_SLICES")) { levels = 1u; const uint32_t want = (uint32_t)std::max(1, atoi(e)); while (levels < want && (spp >> levels) >= 1u) ++levels; }
     int blocks = (int)std::min<uint64_t>((uint64_t)s->n_blocks, (uint64_t)tile_count * levels);
