@@ -29,6 +29,7 @@ def say(line):
 say(f"# tr15 stand-in, full detail (59 instances, 3.1 M triangles), 1920x1080, {spp} spp; one device scene, tray_scene_update_frame between frames")
 say("# frame  moving  Msamples/s  kernel ms  update+flatten s  launches  V       pool slots  views  slices  xf cache GB  transform table GB")
 total_s, total_ms = 0, 0.0
+t_wall0 = time.time()
 for fr in frames:
     t0 = time.time()
     flat = scene.flatten(fr).contents
@@ -48,3 +49,5 @@ for fr in frames:
     say(f"{fr:7d}  {moving:6d}  {t.samples / t.render_ms / 1e3:10.1f}  {t.render_ms:9.1f}  {t_up:16.2f}  {t.launches:8d}  {t.vertices / t.samples:.4f}  "
         f"{sch['pool_slots']:10d}  {sch['views']:5d}  {sch['slices']:6d}  {sch['xf_cache_bytes'] / 2**30:11.1f}  {sch['xf_table_bytes'] / 2**30:18.1f}")
 say(f"# all {len(frames)} frames: {total_s / total_ms / 1e3:.1f} Msamples/s over the frames' kernels")
+wall = time.time() - t_wall0   # (flatten + tray_scene_update_frame + kernels + the copy of every film to the host: what main.rs:91-106 loops, without the PNG writes)
+say(f"# wall clock of the loop over the frames (first frame's device-scene build included): {wall:.1f} s = {total_s / wall / 1e6:.1f} Msamples/s")
