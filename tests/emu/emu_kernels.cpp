@@ -477,7 +477,7 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
     if (moving && n_moving) {   // per-path transform cache, one column per pool slot (tray_scene_create)
         for (uint32_t i = 0; i < f->n_instances; ++i)
             if (f->instances[i].animated && f->instances[i].moving_slot < n_moving) moving_ids[f->instances[i].moving_slot] = i;
-        xf_cache.assign((size_t)n_moving * TR_XF_WORDS * n_slots, 0.0f);
+        xf_cache.assign((size_t)n_moving * TR_XF_REC * n_slots, 0.0f);
         e.d.xf_cache = xf_cache.data(); e.d.moving_ids = moving_ids.data(); e.d.n_moving = n_moving; e.d.xf_stride = n_moving; e.d.xf_cache_lanes = n_slots; e.d.xf_aos = 1u;
     }
     std::vector<WfChunk> chunks(n_chunks, WfChunk{WF_TILE_NEED, 0u});

@@ -165,6 +165,12 @@ TR_DEV void key_transform(const DevKey& k, float* __restrict__ mat, float* __res
 // by the same determinant accumulated in another order, so it comes out as 1 +- an ulp for some scalings / rotations -- and then
 // Transform * Point divides by it (quirk Q5, transform.rs:211-215: it divides exactly when |w - 1| < eps). xf_point_affine_w below does.
 #define TR_XF_WORDS 28
+// Where such records lie one after the other -- the frame's table by shutter-time index, the wavefront schedule's per-path cache -- each takes TR_XF_REC words:
+// 128 bytes, so a record is ONE cache line (and its inverse half lies in one) instead of 1.9 on average at 112 bytes; the tile kernel's cache columns have
+// TR_XF_WORDS rows. (Round 6: the table's records are fetched from random places of 10 - 26 GB, every line is a trip to HBM.)
+#ifndef TR_XF_REC
+#define TR_XF_REC 32
+#endif
 TR_ANIM_EVAL void eval_xform_stack(const TrayXformLevel* __restrict__ levels, const TrayKeyframe* __restrict__ kfs,
                                               const float* __restrict__ knots, uint32_t xf_first, uint32_t xf_count, float time,
                                               float* out24) {

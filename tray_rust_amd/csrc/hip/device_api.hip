@@ -291,7 +291,7 @@ static uint32_t wf_slot_count(const TrayDeviceScene* s, size_t reclaimable = 0, 
     if (with_cache && s->animated && s->deferred_n_moving > 0) {
         uint64_t budget = (free_b + reclaimable) / 5 * 2;   // (two fifths of the free memory: 112 B per slot and instance that moves within the frame -- the C5 stand-in has 2 .. 11 of them, 7 .. 39 GB at 32 M slots)
         if (const char* e = getenv("TRAYHIP_XF_CACHE_BYTES")) budget = (uint64_t)std::max(0ll, atoll(e));
-        const uint64_t per_slot = (uint64_t)s->deferred_n_moving * TR_XF_WORDS * sizeof(float);
+        const uint64_t per_slot = (uint64_t)s->deferred_n_moving * TR_XF_REC * sizeof(float);
         const uint64_t fit = budget / per_slot / TR_BLOCK * TR_BLOCK;
         slots = std::min<uint64_t>(slots, std::max<uint64_t>(fit, (uint64_t)64 * TR_BLOCK));   // (at least 64 chunks: below that the schedule cannot fill the chip)
     }
@@ -736,7 +736,7 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         uint32_t lanes = keep_lanes ? donor->dev.xf_cache_lanes : (s->wavefront ? wf_slot_count(s, reclaimable) : (uint32_t)s->n_blocks * TR_BLOCK);
         const uint32_t n_moving_for_msg = s->deferred_n_moving;
         void* cache = nullptr;
-        size_t cache_bytes = (size_t)s->deferred_n_moving * TR_XF_WORDS * lanes * sizeof(float);
+        size_t cache_bytes = (size_t)s->deferred_n_moving * (s->wavefront ? TR_XF_REC : TR_XF_WORDS) * lanes * sizeof(float);   // (records per path / rows of columns: dev_anim.h)
         // (the wavefront schedule's pool follows the cache: if the budget of wf_slot_count -- a share of what hipMemGetInfo calls free -- cannot be
         // had in one piece, halve the pool rather than fail; the tile kernel's cache has one column per resident thread and cannot shrink)
         // Round 5: the wavefront schedule's cache (112 B per pool slot and moving instance: 38.5 GB for the tr15 stand-in's 11 at 33 M slots) is
@@ -975,7 +975,7 @@ static int launch_wavefront(TrayDeviceScene* s, uint32_t tile_start, uint32_t ti
             WfView& v = views[k];
             v.n_chunks = c1 - c0;
             v.dev = s->launch_dev;
-            if (v.dev.xf_cache && !v.dev.xf_table) v.dev.xf_cache += (size_t)c0 * TR_BLOCK * v.dev.n_moving * TR_XF_WORDS;   // [slot][moving instance][TR_XF_WORDS] (the table is indexed by time, not by slot)
+            if (v.dev.xf_cache && !v.dev.xf_table) v.dev.xf_cache += (size_t)c0 * TR_BLOCK * v.dev.n_moving * TR_XF_REC;   // [slot][moving instance][TR_XF_REC] (the table is indexed by time, not by slot)
             v.pool = s->pool;
             v.pool.first = c0 * TR_BLOCK;   // (the hit records are slot-major, the other fields field-major: the accessors add the view's first slot)
             v.pool.seg_cap = wf_seg_cap(v.n_chunks);
@@ -1149,7 +1149,7 @@ static int xf_cache_ensure(TrayDeviceScene* s) {
     uint32_t lanes = std::max<uint32_t>(s->dev.xf_cache_lanes, s->wf_ready ? s->pool.n_slots : 0u);
     const uint32_t floor_lanes = s->wf_ready ? s->pool.n_slots : 64u * TR_BLOCK;
     for (;;) {
-        const size_t bytes = (size_t)s->dev.n_moving * TR_XF_WORDS * lanes * sizeof(float);
+        const size_t bytes = (size_t)s->dev.n_moving * TR_XF_REC * lanes * sizeof(float);
         void* p = nullptr;
         if (hipMalloc(&p, bytes) == hipSuccess) {
             s->allocs.push_back(p);
@@ -1182,7 +1182,7 @@ static int xf_table_prepare(TrayDeviceScene* s, uint64_t samples, hipStream_t st
         forget_alloc(s, s->d_xf_table); (void)hipFree(s->d_xf_table); s->d_xf_table = nullptr; s->xf_table_built = false;
     }
     if (!s->d_xf_table) {
-        const size_t bytes = ((size_t)1 << 24) * stride * TR_XF_WORDS * sizeof(float);   // 1.9 GB per moving instance
+        const size_t bytes = ((size_t)1 << 24) * stride * TR_XF_REC * sizeof(float);   // 1.9 GB per moving instance
         void* p = nullptr;
         // by the library's own rule (nobody asked for the table) it takes at most a third of what is free: on a device shared with other
         // allocators 22.5 GB for eleven movers must not be what starves them; then, or if hipMalloc refuses: per-path evaluation
@@ -1575,7 +1575,7 @@ int tray_last_schedule(TrayDeviceScene* s, TrayScheduleInfo* out) {
     out->tile_workgroups = (uint32_t)s->n_blocks;
     out->transform_table = s->last_used_table ? 1u : 0u;
     out->binned_stages = (s->last_was_wavefront && WF_FOLD_C) ? s->wf_bin_stages : 0u;
-    out->xf_table_bytes = s->d_xf_table ? ((uint64_t)1 << 24) * s->xf_table_stride * TR_XF_WORDS * sizeof(float) : 0u;
+    out->xf_table_bytes = s->d_xf_table ? ((uint64_t)1 << 24) * s->xf_table_stride * TR_XF_REC * sizeof(float) : 0u;
     return TRAY_OK;
 }
 
