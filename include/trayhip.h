@@ -415,7 +415,7 @@ int tray_last_schedule(TrayDeviceScene* s, TrayScheduleInfo* out);
 /* Moving scenes: where a path's AnimatedTransform::transform(ray.time) comes from (linalg/animated_transform.rs:40-56; the reference
  * rebuilds it at every instance visit, geometry/receiver.rs:30). A camera sample's shutter time is one of 2^24 values (sampler/ld.rs:100-104),
  * every ray of the path inherits it (path.rs:110), so the transform is a function of a 24-bit index. mode 1: build, per frame and on the
- * first launch, the TABLE of every moving instance's (and a moving camera's) transform at all 2^24 times -- 1.9 GB each, ~1.5 ms each to
+ * first launch, the TABLE of every moving instance's (and a moving camera's) transform at all 2^24 times -- 2.1 GB each (128-byte records), ~1.5 ms each to
  * build, the same evaluation at the same times: the same bits -- and read it; mode 0: evaluate per camera sample into a per-path cache
  * (112 B per path and instance); mode -1 (default): the table for launches of >= 3e7 camera samples (a 1080p frame at 16 spp: each index is needed about twice or more),
  * and for every later launch of the frame once it exists. If the table cannot be allocated the per-path cache serves, and vice versa.

@@ -120,7 +120,7 @@ struct Ray {
 // Transform of an instance at a ray's time as rows 0..2 of mat (x) and of inv (x + 12). Instance transforms are products
 // of TRS keyframes (AnimatedTransform::unanimated decomposes static ones too), so row 3 is (0,0,0,1) and the affine
 // point transform equals Transform * Point.
-#ifdef TR_XF_COL_MASK   // experiment (round 6, profiles/r06_moving_box_floor.txt): the threads share a few columns that stay in L2 -- WRONG pictures, the time cache-resident columns would give
+#ifdef TR_XF_COL_MASK   // experiment (round 6, profiles/r06_moving_box_fill_ab.txt): the threads share a few columns that stay in L2 -- WRONG pictures, the time cache-resident columns would give
 TR_DEV uint32_t xf_cache_lane() { return (blockIdx.x * blockDim.x + threadIdx.x) & (uint32_t)(TR_XF_COL_MASK); }
 #else
 TR_DEV uint32_t xf_cache_lane() { return blockIdx.x * blockDim.x + threadIdx.x; }   // megakernel: one column per thread
@@ -136,17 +136,8 @@ TR_DEV uint32_t xf_cache_lane() { return blockIdx.x * blockDim.x + threadIdx.x; 
 // path (C5 stand-in, frame 64: 186 -> 213 Msamples/s). The tile kernel keeps its per-thread cache columns (coalesced reads in the flat instance
 // loop; gathered 112-byte records there measured only +3.5 % on moving_box) and FILLS them from the table instead of evaluating. The host builds
 // the table for launches of enough samples (kernels.hip: xf_table_prepare), the per-path evaluation serves the others.
-#ifndef TR_XF_FILL_COOP   // the tile kernel's fill of its cache columns from the frame's table: 1 = dealt out to the whole wave (xf_cache_fill_wave)
+#ifndef TR_XF_FILL_COOP   // the tile kernel's fill of its cache columns from the frame's table: 1 = dealt out to the whole wave (xf_cache_fill_wave), 0 = by the starting lanes
 #define TR_XF_FILL_COOP 1
-#endif
-#ifndef TR_XF_FILL_TWO   // ... two records per lane and trip (xf_cache_fill_wave)
-#define TR_XF_FILL_TWO 0
-#endif
-#ifndef TR_XF_CAM_EARLY   // ... the moving camera's record requested before the fill, used after it (kernels.hip: k_path_tiles' hand-out)
-#define TR_XF_CAM_EARLY 0
-#endif
-#ifndef TR_XF_CAM_LATE   // ... and a moving camera's record comes with that fill (kernels.hip: k_path_tiles' hand-out) instead of a trip of its own in camera_ray
-#define TR_XF_CAM_LATE 0   // (measured, profiles/r06_moving_box_fill_ab.txt: 514 / 546 against 524 / 557 Msamples/s -- camera_ray's own fetch is in flight beside the fill's)
 #endif
 #ifdef TR_XF_KIDX_MASK   // experiment (round 5, profiles/r05_xf_table_locality_ceiling.txt): every path reads one of a few table records -- WRONG pictures, the time a perfectly cache-resident table would give
 TR_DEV uint32_t xf_time_index(float t) { return (uint32_t)(t * 16777216.0f) & (uint32_t)(TR_XF_KIDX_MASK); }
@@ -179,79 +170,24 @@ TR_DEV void xf_cache_fill(const DevScene& sc, float time, uint32_t lane) {
 // moving instance) pairs are dealt out to all the lanes of the wave -- instance-major, so neighbouring lanes evaluate the SAME stack at
 // different times and stay in step -- and every lane writes its result into the column of the lane it worked for. Values and layout are
 // exactly xf_cache_fill's; the stores are made visible to the wave before anybody reads its column.
-TR_DEV void xf_cache_fill_wave(const DevScene& sc, bool started, float time, uint32_t column, uint32_t time_index, float* cam_x = nullptr) {
+TR_DEV void xf_cache_fill_wave(const DevScene& sc, bool started, float time, uint32_t column, uint32_t time_index) {
     if (!sc.xf_cache || sc.xf_table) return;
 #if TR_XF_FILL_COOP
-    if (sc.xf_tab) {   // the frame's table has the path's transforms: copied, not evaluated. The (starting lane, record) pairs are dealt out to all
-        // the lanes of the wave, record-major: every lane fetches ONE 112-byte record from its random place in the table -- one trip to HBM for
-        // the wave instead of one per moving instance for the starting lanes -- and writes it into the column of the lane it works for
-        // (neighbouring lanes work for neighbouring columns of the same instance: the stores of a word share their lines).
-        // cam_x != nullptr (the camera moves, the wave is whole): the camera's records -- the last of a time index -- are the FIRST n_start tasks, so lane
-        // `which` holds the record of the which-th starting lane after the first round and hands its rows 0 .. 2 and [3][3] over through the
-        // wave's permute (no second trip to the table in camera_ray).
+    if (sc.xf_tab) {   // the frame's table has the path's transforms: copied, not evaluated. The (starting lane, moving instance) pairs are dealt out to all
+        // the lanes of the wave, instance-major: every lane fetches ONE record from its random place in the table -- one trip to HBM for the wave
+        // instead of one per moving instance for the starting lanes, and a third of the lanes start a sample in EVERY step -- and writes it into the
+        // column of the lane it works for (neighbouring lanes work for neighbouring columns of the same instance: the stores of a word share
+        // their lines). moving_box: 459 -> 524 Msamples/s at 32 spp, 475 -> 557 at 128 (profiles/r06_moving_box_fill_ab.txt).
         const unsigned long long start_m = __ballot(started), exec_m = __ballot(1);
         if (start_m == 0ull) return;
         const uint32_t lane = threadIdx.x & 63u;
         const uint32_t n_exec = (uint32_t)__popcll(exec_m), my_rank = (uint32_t)__popcll(exec_m & ((1ull << lane) - 1ull));
-        const bool with_cam = cam_x != nullptr && exec_m == ~0ull;
-        const uint32_t n_start = (uint32_t)__popcll(start_m), n_tasks = n_start * (sc.n_moving + (with_cam ? 1u : 0u));
-        const uint32_t my_which = (uint32_t)__popcll(start_m & ((1ull << lane) - 1ull));   // (of a starting lane: its place among the starting lanes)
+        const uint32_t n_start = (uint32_t)__popcll(start_m), n_tasks = n_start * sc.n_moving;
         const uint32_t lanes = sc.xf_cache_lanes;
-#if TR_XF_FILL_TWO   // two records per lane and trip: a step that starts more than 64 / (records per index) samples still makes ONE trip to the table
-        for (uint32_t base = 0; base < n_tasks; base += 2u * n_exec) {
-            const uint32_t task_a = base + my_rank, task_b = base + n_exec + my_rank;
-            const bool valid_a = task_a < n_tasks, valid_b = task_b < n_tasks;
-            const uint32_t rec_a = valid_a ? task_a / n_start : 0u, which_a = valid_a ? task_a % n_start : 0u;
-            const uint32_t rec_b = valid_b ? task_b / n_start : 0u, which_b = valid_b ? task_b % n_start : 0u;
-            const bool cam_task = with_cam && rec_a == 0u;
-            const uint32_t m_a = with_cam ? (cam_task ? sc.n_moving : rec_a - 1u) : rec_a, m_b = with_cam ? rec_b - 1u : rec_b;   // (task_b >= 64 > n_start: never the camera's)
-            uint32_t src_a = 0u, src_b = 0u, k = 0u;   // the which-th starting lane of the wave (a scalar walk over the mask's bits)
-            for (unsigned long long rest = start_m; rest != 0ull; rest &= rest - 1ull, ++k) {
-                const uint32_t bit = (uint32_t)__ffsll((long long)rest) - 1u;
-                if (k == which_a) src_a = bit;
-                if (k == which_b) src_b = bit;
-            }
-            const uint32_t kidx_a = __shfl(time_index, (int)src_a), col_a = __shfl(column, (int)src_a);
-            const uint32_t kidx_b = __shfl(time_index, (int)src_b), col_b = __shfl(column, (int)src_b);
-            float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, r6 = r0, q0 = r0, q1 = r0, q2 = r0, q3 = r0, q4 = r0, q5 = r0, q6 = r0;
-            if (valid_a) {
-                const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_tab + ((size_t)kidx_a * sc.xf_tab_stride + m_a) * TR_XF_REC);
-                r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r6 = rec[6];
-                if (!cam_task) { r3 = rec[3]; r4 = rec[4]; r5 = rec[5]; }
-            }
-            if (valid_b) {
-                const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_tab + ((size_t)kidx_b * sc.xf_tab_stride + m_b) * TR_XF_REC);
-                q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3]; q4 = rec[4]; q5 = rec[5]; q6 = rec[6];
-            }
-            if (valid_a && !cam_task) {
-                float* __restrict__ dst = sc.xf_cache + (size_t)m_a * TR_XF_WORDS * lanes + col_a;
-                const float v[26] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w,
-                                     r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w, r6.x, r6.y};
-#pragma unroll
-                for (int q = 0; q < 26; ++q) dst[(size_t)q * lanes] = v[q];
-            }
-            if (valid_b) {
-                float* __restrict__ dst = sc.xf_cache + (size_t)m_b * TR_XF_WORDS * lanes + col_b;
-                const float v[26] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
-                                     q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, q6.x, q6.y};
-#pragma unroll
-                for (int q = 0; q < 26; ++q) dst[(size_t)q * lanes] = v[q];
-            }
-            if (with_cam && base == 0u) {   // (n_start <= 64 = n_exec: every camera task is an `a` task of this round, task = which = the lane that holds it)
-                const int from = (int)my_which;
-                cam_x[0] = __shfl(r0.x, from); cam_x[1] = __shfl(r0.y, from); cam_x[2] = __shfl(r0.z, from); cam_x[3] = __shfl(r0.w, from);
-                cam_x[4] = __shfl(r1.x, from); cam_x[5] = __shfl(r1.y, from); cam_x[6] = __shfl(r1.z, from); cam_x[7] = __shfl(r1.w, from);
-                cam_x[8] = __shfl(r2.x, from); cam_x[9] = __shfl(r2.y, from); cam_x[10] = __shfl(r2.z, from); cam_x[11] = __shfl(r2.w, from);
-                cam_x[12] = __shfl(r6.y, from);   // mat[3][3] (word 25)
-            }
-        }
-#else
         for (uint32_t base = 0; base < n_tasks; base += n_exec) {
             const uint32_t task = base + my_rank;
             const bool valid = task < n_tasks;
-            const uint32_t rec_no = valid ? task / n_start : 0u, which = valid ? task % n_start : 0u;
-            const bool cam_task = with_cam && rec_no == 0u;
-            const uint32_t m = with_cam ? (cam_task ? sc.n_moving : rec_no - 1u) : rec_no;   // the record's place in its time index
+            const uint32_t m = valid ? task / n_start : 0u, which = valid ? task % n_start : 0u;
             uint32_t src = 0u, k = 0u;   // the which-th starting lane of the wave (a scalar walk over the mask's bits)
             for (unsigned long long rest = start_m; rest != 0ull; rest &= rest - 1ull, ++k) {
                 const uint32_t b = (uint32_t)__ffsll((long long)rest) - 1u;
@@ -259,28 +195,16 @@ TR_DEV void xf_cache_fill_wave(const DevScene& sc, bool started, float time, uin
             }
             const uint32_t kidx = __shfl(time_index, (int)src);
             const uint32_t col = __shfl(column, (int)src);
-            float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, r6 = r0;
             if (valid) {
                 const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_tab + ((size_t)kidx * sc.xf_tab_stride + m) * TR_XF_REC);
-                r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r6 = rec[6];
-                if (!cam_task) { r3 = rec[3]; r4 = rec[4]; r5 = rec[5]; }
-            }
-            if (valid && !cam_task) {
                 float* __restrict__ dst = sc.xf_cache + (size_t)m * TR_XF_WORDS * lanes + col;
+                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6];
                 const float v[26] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w,
                                      r4.x, r4.y, r4.z, r4.w, r5.x, r5.y, r5.z, r5.w, r6.x, r6.y};
 #pragma unroll
                 for (int q = 0; q < 26; ++q) dst[(size_t)q * lanes] = v[q];
             }
-            if (with_cam && base == 0u) {   // (n_start <= 64 = n_exec: every camera task is in this round, task = which = the lane that holds it)
-                const int from = (int)my_which;
-                cam_x[0] = __shfl(r0.x, from); cam_x[1] = __shfl(r0.y, from); cam_x[2] = __shfl(r0.z, from); cam_x[3] = __shfl(r0.w, from);
-                cam_x[4] = __shfl(r1.x, from); cam_x[5] = __shfl(r1.y, from); cam_x[6] = __shfl(r1.z, from); cam_x[7] = __shfl(r1.w, from);
-                cam_x[8] = __shfl(r2.x, from); cam_x[9] = __shfl(r2.y, from); cam_x[10] = __shfl(r2.z, from); cam_x[11] = __shfl(r2.w, from);
-                cam_x[12] = __shfl(r6.y, from);   // mat[3][3] (word 25)
-            }
         }
-#endif
         __builtin_amdgcn_wave_barrier();   // (as below: the host emulation's lanes meet here)
         __threadfence_block();             // (a lane reads its column next: written by another lane of this wave)
         return;
@@ -977,9 +901,6 @@ TR_DEV bool own_box_pass(const float* __restrict__ lo, const float* __restrict__
 #ifndef TR_FLAT_PEND
 #define TR_FLAT_PEND 1
 #endif
-#ifndef TR_FLAT_PEND_MOVING   // the pass also takes the moving spheres / rectangles / disks of a scene (FlatInst::lane_pass = 2), kernels built for moving scenes only
-#define TR_FLAT_PEND_MOVING 0   // (measured, profiles/r06_moving_box_fill_ab.txt: 447 against 459 Msamples/s on moving_box -- the wave-uniform loop reads a mover's column as coalesced lines)
-#endif
 template <int ANIM, bool GUARD_ACTIVE = false>
 TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const Ray& ray, bool any_hit, bool active, HitRec& rec, bool& hazard) {
     const float min_t = ray.min_t, gate_max_t = ray.max_t;
@@ -987,12 +908,6 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
     float best_gate = -TR_INF;        // G of that candidate
     bool any = false, done = !active;   // lanes without a ray run along: the cooperative leaf test uses their ALUs
     uint32_t pend = 0u;               // simple instances this lane's ray still has to test (bit = FlatInst index; TR_FLAT_MAX <= 32)
-#ifdef TR_FLAT_PEND_PREFETCH
-    uint32_t pre_k = 0xffffffffu;
-    float pre[13];
-#pragma unroll
-    for (int c = 0; c < 13; ++c) pre[c] = 0.0f;
-#endif
     static_assert(TR_FLAT_MAX <= 32, "one bit per instance of the flat loop");
     // the accept rule of a candidate (R1 / R2 above), shared by the uniform loop and the per-lane pass
 #define TR_FLAT_ACCEPT(t_, prim_, b1_, b2_, leaf_t_, hz_, box_t_, inst_id_) do {                                                          \
@@ -1044,17 +959,8 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
             const bool wanted = gate && !done && (!any_hit || own_redundant || own_box_pass(own_lo, own_hi, ray.o, w_inv_dir, wnx, wny, wnz, min_t, gate_max_t));
             if (!__any(wanted)) continue;   // nobody's ray comes near this instance
             const uint32_t gt = in->geom_type, mesh_id = in->mesh_id, inst_id = in->inst;
-            if (TR_FLAT_PEND && (in->lane_pass == 1u || (TR_FLAT_PEND_MOVING && ANIM == 1 && in->lane_pass == 2u))) {   // (host/gates.hpp: a rectangle / disk alone behind a flat gate; a moving sphere / rectangle / disk)
+            if (TR_FLAT_PEND && in->lane_pass != 0u) {   // (host/gates.hpp: a rectangle / disk alone behind a flat gate, not moving)
                 if (wanted) pend |= 1u << (first + k);   // the per-lane pass below tests it
-#ifdef TR_FLAT_PEND_PREFETCH   // experiment: the lane's FIRST pending moving instance has its transform requested here, the loop's remaining gates run under the loads
-                if (ANIM == 1 && in->lane_pass == 2u && wanted && pre_k == 0xffffffffu) {
-                    pre_k = first + k;
-                    const uint32_t lanes = sc.xf_cache_lanes;
-                    const float* __restrict__ col = sc.xf_cache + ((size_t)in->moving_slot * TR_XF_WORDS + 12u) * lanes + ray.col;
-#pragma unroll
-                    for (int c = 0; c < 13; ++c) pre[c] = col[(size_t)c * lanes];
-                }
-#endif
                 continue;
             }
             float inv[16];
@@ -1113,45 +1019,22 @@ TR_DEV bool trace_flat(const DevScene& sc, uint32_t* __restrict__ stack, const R
             pend &= pend - 1u;
             const tray::FlatInst* __restrict__ in = sc.flat_insts + k;   // (the lane's own record: vector loads; sixteen records at most, cache resident)
             const float4* __restrict__ q = reinterpret_cast<const float4*>(in);
-            const float4 g1 = q[5], g2 = q[6], g3 = q[7];   // (hi.y, hi.z, gp0, gp1); (geom_type, mesh_id, inst, animated); (leaf, lane_pass, moving_slot, -)
-            static_assert(offsetof(tray::FlatInst, gp0) == 88 && offsetof(tray::FlatInst, geom_type) == 96 && offsetof(tray::FlatInst, inst) == 104 &&
-                          offsetof(tray::FlatInst, leaf) == 112 && offsetof(tray::FlatInst, moving_slot) == 120, "the quarters of a FlatInst record");
+            const float4 m0 = q[0], m1 = q[1], m2 = q[2], m3 = q[3], g1 = q[5], g2 = q[6];   // inv rows 0 .. 3; (hi.y, hi.z, gp0, gp1); (geom_type, mesh_id, inst, animated)
+            const uint32_t leaf = in->leaf;
+            static_assert(offsetof(tray::FlatInst, gp0) == 88 && offsetof(tray::FlatInst, geom_type) == 96 && offsetof(tray::FlatInst, inst) == 104, "the quarters of a FlatInst record");
+            const float inv[16] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w, m3.x, m3.y, m3.z, m3.w};
             const float gp0 = g1.z, gp1 = g1.w;
-            const uint32_t gt = __float_as_uint(g2.x), inst_id = __float_as_uint(g2.z), leaf = __float_as_uint(g3.x);
-            f3 o, d;   // Instance::intersect (receiver.rs:29-35)
-            if (TR_FLAT_PEND_MOVING && ANIM == 1 && __float_as_uint(g2.w) != 0u) {   // a moving instance: transform.transform(ray.time) from the path's cache column
-                float x[TR_XF_WORDS];
-#ifdef TR_FLAT_PEND_PREFETCH
-                if (k == pre_k) {
-#pragma unroll
-                    for (int c = 0; c < 13; ++c) x[12 + c] = pre[c];
-                } else
-#endif
-                if (sc.xf_aos) instance_inv_cached(sc, __float_as_uint(g3.z), ray.col, x);
-                else {
-                    const uint32_t lanes = sc.xf_cache_lanes;
-                    const float* __restrict__ col = sc.xf_cache + ((size_t)__float_as_uint(g3.z) * TR_XF_WORDS + 12u) * lanes + ray.col;
-#pragma unroll
-                    for (int c = 0; c < 13; ++c) x[12 + c] = col[(size_t)c * lanes];
-                }
-                o = xf_point_affine_w(x + 12, x[24], ray.o);
-                d = xf_vector(x + 12, ray.d);
-            } else {
-                const float4 m0 = q[0], m1 = q[1], m2 = q[2], m3 = q[3];   // inv rows 0 .. 3
-                const float inv[16] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w, m3.x, m3.y, m3.z, m3.w};
-                o = xf_point(inv, ray.o);
-                d = xf_vector(inv, ray.d);
-            }
+            const uint32_t gt = __float_as_uint(g2.x), inst_id = __float_as_uint(g2.z);
             const float4* __restrict__ lq = reinterpret_cast<const float4*>(sc.flat_leaves + leaf);
             const float4 l0 = lq[0], l1 = lq[1];   // (bmin, bmax.x), (bmax.y, bmax.z, first, count)
             float box_t = 0.0f;
             // (the gate passed in the uniform loop -- that is why the instance is pending --; this is its entry distance again: same box, same ray, same arithmetic)
             (void)bbox_hit_t(l0, make_float4(l1.x, l1.y, 0.0f, 0.0f), ray.o, w_inv_dir, wnx, wny, wnz, min_t, gate_max_t, box_t);
+            const f3 o = xf_point(inv, ray.o), d = xf_vector(inv, ray.d);   // Instance::intersect (receiver.rs:29-35)
             const float bound = fmaxf(max_t, best_gate);
             float t = bound;
             bool hit;
             if (gt == TRAY_GEOM_RECT) hit = rect_test(gp0, gp1, o, d, min_t, bound, t);
-            else if (TR_FLAT_PEND_MOVING && ANIM == 1 && gt == TRAY_GEOM_SPHERE) hit = sphere_test(gp0, o, d, min_t, bound, t);
             else hit = disk_test(gp0, gp1, o, d, min_t, bound, t);
             if (hit) TR_FLAT_ACCEPT(t, 0u, 0.0f, 0.0f, -TR_INF, false, box_t, inst_id);
         }

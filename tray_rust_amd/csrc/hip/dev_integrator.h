@@ -21,10 +21,8 @@
 
 namespace tr {
 
-// cam_x: rows 0 .. 2 of the camera's transform at `time` and its [3][3], when the caller has fetched them from the frame's table already (the tile
-// kernel's cooperative fill, dev_geom.h: xf_cache_fill_wave), or null
 template <int ANIM>
-TR_DEV Ray camera_ray(const DevScene& sc, float px, float py, float time, const float* cam_x = nullptr) {
+TR_DEV Ray camera_ray(const DevScene& sc, float px, float py, float time) {
     const TrayCamera& c = *sc.camera_p;
     f3 q = xf_point(c.raster_to_cam, mk(px, py, 0.0f));
     f3 px_pos = mk(c.scaling[0], c.scaling[1], c.scaling[2]) * q;
@@ -33,10 +31,7 @@ TR_DEV Ray camera_ray(const DevScene& sc, float px, float py, float time, const 
     // the host evaluated already
     const float frame_time = (c.shutter_close - c.shutter_open) * time + c.shutter_open;
     Ray r;
-    if (ANIM == 1 && cam_x) {   // (c.animated, table mode: see cam_x)
-        r.o = xf_point_affine_w(cam_x, cam_x[12], mk(0.0f, 0.0f, 0.0f));
-        r.d = xf_vector(cam_x, d);
-    } else if (ANIM && c.animated) {   // cam_world.transform(frame_time) * Ray (camera.rs:156)
+    if (ANIM && c.animated) {   // cam_world.transform(frame_time) * Ray (camera.rs:156)
         float x[TR_XF_WORDS];
         if (ANIM == 1 && sc.xf_tab) {   // the frame's table holds the camera's transform at this time index as the last record of the index (dev_geom.h)
             const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_tab + ((size_t)xf_time_index(time) * sc.xf_tab_stride + sc.n_moving) * TR_XF_REC);

@@ -316,11 +316,6 @@ __global__ __launch_bounds__(TR_BLOCK, (FEAT == 15 || INTEG != TRAY_INTEGRATOR_P
                 base = __shfl(base, (int)leader);
                 pairs_left = base + n_idle < n_pairs;
                 const uint32_t pair = base + (uint32_t)__popcll(idle_m & ((1ull << lane) - 1ull));
-                // moving scene, the frame's table of transforms in use, the camera moves: the camera's record comes with the fill's one trip to the table
-                // (xf_cache_fill_wave hands it over), the camera ray is generated after it
-                const bool cam_late = ANIM == 1 && TR_XF_FILL_COOP && TR_XF_CAM_LATE && sc.xf_tab != nullptr && sc.camera_p->animated != 0u && __ballot(1) == ~0ull;
-                float t = 0.0f;
-                uint32_t ks_new = 0u;
                 if (idle && pair < n_pairs) {
 #ifdef TR_PAIR_BY_PIXEL   // experiment (round 5): consecutive pairs are the samples of ONE pixel, so a wave starts 64 samples of the same pixel
                     const uint32_t pix = pair / s_per_slice, s = s_lo + (pair % s_per_slice);
@@ -329,9 +324,10 @@ __global__ __launch_bounds__(TR_BLOCK, (FEAT == 15 || INTEG != TRAY_INTEGRATOR_P
 #endif
                     const uint32_t px = (uint32_t)x0 + (pix & 7u), py = (uint32_t)y0 + (pix >> 3);
                     const uint32_t kp = key_pixel(kf, py * sc.width + px);
+                    float t;
                     pixel_sample(kp, s, spp, px, py, sx, sy, t);
-                    ks_new = key_sample(kp, s);
-                    if (ANIM) kidx = xf_time_index(t);   // the camera sample's index into the frame's table (the fill copies from there)
+                    lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t), key_sample(kp, s));
+                    if (ANIM) { ln.col = xf_cache_lane(); kidx = xf_time_index(t); }   // the path's column of the transform cache; its index into the frame's table (the fill copies from there)
                     row_l = pix >> 3;
                     started = true;
                     pending = true;
@@ -339,23 +335,8 @@ __global__ __launch_bounds__(TR_BLOCK, (FEAT == 15 || INTEG != TRAY_INTEGRATOR_P
                     dump_idx = (size_t)(py * sc.width + px) * spp + s; dump_v = 0u;
 #endif
                 }
-                // the paths' transforms of the moving instances, once per camera sample, into the path's column of the transform cache: the whole wave
-                // copies (table) or evaluates (at the ray's frame time: camera_ray's expression) for the lanes that start one
-                float cam_x[13];
-                // (the moving camera's record of the table is requested BEFORE the fill and used after it: its trip runs beside the fill's instead of after it)
-                const bool cam_early = ANIM == 1 && TR_XF_CAM_EARLY && !cam_late && sc.xf_tab != nullptr && sc.camera_p->animated != 0u;
-                if (cam_early && started) {
-                    const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.xf_tab + ((size_t)kidx * sc.xf_tab_stride + sc.n_moving) * TR_XF_REC);
-                    const float4 c0 = rec[0], c1 = rec[1], c2 = rec[2], c6 = rec[6];
-                    cam_x[0] = c0.x; cam_x[1] = c0.y; cam_x[2] = c0.z; cam_x[3] = c0.w; cam_x[4] = c1.x; cam_x[5] = c1.y; cam_x[6] = c1.z; cam_x[7] = c1.w;
-                    cam_x[8] = c2.x; cam_x[9] = c2.y; cam_x[10] = c2.z; cam_x[11] = c2.w; cam_x[12] = c6.y;   // rows 0 .. 2 of mat, mat[3][3] (word 25)
-                }
-                if (ANIM) xf_cache_fill_wave(sc, started, (sc.camera_p->shutter_close - sc.camera_p->shutter_open) * t + sc.camera_p->shutter_open, xf_cache_lane(), kidx, cam_late ? cam_x : nullptr);
-                if (started) {
-                    lane_start_sample(ln, camera_ray<ANIM>(sc, sx, sy, t, (cam_late || cam_early) ? cam_x : nullptr), ks_new);
-                    if (ANIM) ln.col = xf_cache_lane();
-                }
             }
+            if (ANIM && idle_m != 0ull) xf_cache_fill_wave(sc, started, ln.time, ln.col, kidx);   // the paths' transforms of the moving instances, once per camera sample: the whole wave evaluates for the lanes that start one
             w_samples += (uint32_t)__popcll(__ballot(started));
             if (!__any(ln.flags & LF_ALIVE)) break;
             if (INTEG == TRAY_INTEGRATOR_WHITTED) {

@@ -39,11 +39,8 @@ struct FlatInst {   // 128 B
     uint32_t animated;        // the instance moves while the shutter is open: its transform is the path's (per-path cache), `inv` above is not used
     uint32_t leaf;            // index of its FlatLeaf (the per-lane pass of trace_flat re-derives the gate's entry distance from that box)
     uint32_t lane_pass;       // 1: tested in trace_flat's per-lane pass -- a rectangle or disk alone in a FLAT leaf box (thinnest side <= 1 % of the longest),
-                              // which a ray passes only where it crosses the surface; 2: a MOVING sphere / rectangle / disk (whatever its leaf): the pass
-                              // reads the path's transform once per lane that needs it instead of once per wave and instance; everything else stays in
-                              // the wave-uniform loop
-    uint32_t moving_slot;     // TrayInstance::moving_slot of an animated instance (the per-lane pass reads the path's cache column by it)
-    uint32_t pad;
+                              // which a ray passes only where it crosses the surface; everything else stays in the wave-uniform loop
+    uint32_t pad[2];
 };
 static_assert(sizeof(FlatLeaf) == 32 && sizeof(FlatInst) == 128, "records are read with aligned scalar loads");
 
@@ -380,8 +377,6 @@ inline void flat_loop_gates(const TrayFlatScene* f, const PairedTrees& paired, u
                 for (int c = 0; c < 3; ++c) { const float e = node.bmax[c] - node.bmin[c]; emin = std::min(emin, e); emax = std::max(emax, e); }
                 const bool flat_box = std::isfinite(emax) && emin >= 0.0f && emin <= 0.01f * emax;
                 fi.lane_pass = (node.count == 1 && flat_box && !in.animated && (in.geom_type == TRAY_GEOM_RECT || in.geom_type == TRAY_GEOM_DISK)) ? 1u : 0u;
-                if (in.animated && (in.geom_type == TRAY_GEOM_RECT || in.geom_type == TRAY_GEOM_DISK || in.geom_type == TRAY_GEOM_SPHERE)) fi.lane_pass = 2u;
-                fi.moving_slot = in.moving_slot;
             }
             insts.push_back(fi);
         }
