@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY: the device source of libtrayhip.so compiled for the host (hip_emu.h) and driven one thread at a
 // time. Entry points mirror what the library does around the same kernels (scene upload, pool fields, queues, launch geometry).
 #include "hip_emu.h"
+#include <sys/mman.h>   // (the sparse transform table of emu_render_tiles)
 #ifdef TR_COOP_HIST   // tools/coop_histogram.py: [rays staged][lanes that asked] of every cooperative small-mesh test (dev_geom.h: mesh_leaf_coop)
 namespace tr { unsigned long long tr_coop_hist[65 * 65]; }
 extern "C" unsigned long long* emu_coop_hist(void) { return tr::tr_coop_hist; }
@@ -372,6 +373,48 @@ int emu_wf_trace(const TrayFlatScene* f, int stage, uint32_t n, const TrayRay* r
     return 0;
 }
 
+// TRAYHIP_EMU_XF_TABLE=1: the frame's transform table (device_api.hip: xf_table_prepare, k_xf_table_build) under the emulated kernels. The table of all
+// 2^24 shutter-time indices is 2 GB per moving instance: here it is a sparse mapping whose records exist for the indices the rendered (pixel, sample)
+// pairs draw -- evaluated with k_xf_table_build's expressions --, which are the only ones the kernels read.
+struct SparseXfTable {
+    float* data = nullptr;
+    size_t bytes = 0;
+    uint32_t stride = 0;
+    ~SparseXfTable() { if (data) munmap(data, bytes); }
+    bool build(const TrayFlatScene* f, uint32_t frame, const uint32_t* moving_ids, uint32_t n_moving, const uint32_t* tiles_xy, uint32_t tile_count, uint32_t spp, uint64_t seed) {
+        stride = n_moving + (f->camera.animated ? 1u : 0u);
+        if (!stride) return true;
+        bytes = ((size_t)1 << 24) * stride * TR_XF_REC * sizeof(float);
+        void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (p == MAP_FAILED) return false;
+        data = static_cast<float*>(p);
+        std::vector<uint8_t> have((size_t)1 << 21, 0u);   // one bit per index
+        const uint32_t kf = key_frame_host(seed, frame);
+        const TrayCamera& c = f->camera;
+        for (uint32_t i = 0; i < tile_count; ++i)
+            for (uint32_t pix = 0; pix < 64u; ++pix) {
+                const uint32_t px = tiles_xy[2 * i] * 8u + (pix & 7u), py = tiles_xy[2 * i + 1] * 8u + (pix >> 3);   // (a queue entry is a tile's place in units of tiles)
+                if (px >= f->film.width || py >= f->film.height) continue;
+                const uint32_t kp = key_pixel(kf, py * f->film.width + px);
+                for (uint32_t s = 0; s < spp; ++s) {
+                    float x, y, t;
+                    pixel_sample(kp, s, spp, px, py, x, y, t);
+                    const uint32_t index = xf_time_index(t);
+                    if (have[index >> 3] & (1u << (index & 7u))) continue;
+                    have[index >> 3] |= (uint8_t)(1u << (index & 7u));
+                    const float frame_time = (c.shutter_close - c.shutter_open) * xf_index_time(index) + c.shutter_open;   // (k_xf_table_build)
+                    for (uint32_t m = 0; m < stride; ++m) {
+                        uint32_t first, count;
+                        if (m < n_moving) { const TrayInstance& in = f->instances[moving_ids[m]]; first = in.xf_first; count = in.xf_count; }
+                        else { first = c.xf_first; count = c.xf_count; }
+                        eval_xform_stack(f->xf_levels, f->keyframes, f->knots, first, count, frame_time, data + ((size_t)index * stride + m) * TR_XF_REC);
+                    }
+                }
+            }
+        return true;
+    }
+};
+
 // The tile worker itself: k_path_tiles<0, FEAT> over `tile_count` tiles of the given Morton queue, launched the way
 // launch_tiles does (feature set, row-binned film and cooperative small-mesh test chosen as tray_scene_create chooses them),
 // as a SIMT emulation: 256 fibers per workgroup, wave intrinsics and barriers are rendezvous. rgbw is accumulated into.
@@ -395,6 +438,11 @@ int emu_render_tiles(const TrayFlatScene* f, const uint32_t* tiles_xy, uint32_t 
             if (f->instances[i].animated && f->instances[i].moving_slot < n_moving) moving_ids[f->instances[i].moving_slot] = i;
         xf_cache.assign((size_t)n_moving * TR_XF_WORDS * blocks * TR_BLOCK, 0.0f);
         e.d.xf_cache = xf_cache.data(); e.d.moving_ids = moving_ids.data(); e.d.n_moving = n_moving; e.d.xf_stride = n_moving; e.d.xf_cache_lanes = blocks * TR_BLOCK;
+    }
+    SparseXfTable table;   // TRAYHIP_EMU_XF_TABLE=1: the fill of the cache columns FROM THE TABLE (dev_geom.h: xf_cache_fill_wave, camera_ray) runs in the emulation
+    if (moving && getenv("TRAYHIP_EMU_XF_TABLE") && atoi(getenv("TRAYHIP_EMU_XF_TABLE")) != 0) {
+        if (!table.build(f, e.d.frame, moving_ids.data(), n_moving, tiles_xy, tile_count, spp, seed)) return -5;
+        if (table.data) { e.d.moving_ids = moving_ids.data(); e.d.xf_tab = table.data; e.d.xf_tab_stride = table.stride; }
     }
     e.d.film_rows = (film_rows != 0 && film_rows_ok(f)) ? 1u : 0u;
     uint32_t stack_words = e.depth * TR_BLOCK;
@@ -479,6 +527,14 @@ int emu_render_wavefront(const TrayFlatScene* f, const uint32_t* tiles_xy, uint3
             if (f->instances[i].animated && f->instances[i].moving_slot < n_moving) moving_ids[f->instances[i].moving_slot] = i;
         xf_cache.assign((size_t)n_moving * TR_XF_REC * n_slots, 0.0f);
         e.d.xf_cache = xf_cache.data(); e.d.moving_ids = moving_ids.data(); e.d.n_moving = n_moving; e.d.xf_stride = n_moving; e.d.xf_cache_lanes = n_slots; e.d.xf_aos = 1u;
+    }
+    SparseXfTable table;   // TRAYHIP_EMU_XF_TABLE=1: the stage kernels index the frame's table by the path's time index (device_api.hip: xf_table_prepare's wavefront branch)
+    if (moving && getenv("TRAYHIP_EMU_XF_TABLE") && atoi(getenv("TRAYHIP_EMU_XF_TABLE")) != 0) {
+        if (!table.build(f, e.d.frame, moving_ids.data(), n_moving, tiles_xy, tile_count, spp, seed)) return -5;
+        if (table.data) {
+            e.d.moving_ids = moving_ids.data(); e.d.n_moving = n_moving; e.d.xf_tab = table.data; e.d.xf_tab_stride = table.stride;
+            e.d.xf_cache = table.data; e.d.xf_table = 1u; e.d.xf_aos = 1u; e.d.xf_stride = table.stride;
+        }
     }
     std::vector<WfChunk> chunks(n_chunks, WfChunk{WF_TILE_NEED, 0u});
     std::vector<float> bins((size_t)n_chunks * ROWBIN_SIZE, 0.0f);

@@ -498,7 +498,7 @@ WF_CASES = [("cornell_box", 0, 0), ("moving_box", 3, 0), ("tr15_like", 330, 0)]
 
 
 @pytest.mark.parametrize("name,frame,trace", WF_CASES, ids=[n for n, _, t in WF_CASES])
-def test_wavefront_schedule_emulated_as_simt(name, frame, trace, tmp_path, tr15_dir, built):
+def test_wavefront_schedule_emulated_as_simt(name, frame, trace, tmp_path, tr15_dir, built, monkeypatch):
     """The whole wavefront schedule -- k_wf_advance (film row bins, tile switch), k_wf_regen (camera samples, the per-path transform
     cache of moving scenes), the three traversal stages, k_wf_begin with its material sort, the kind-pure k_wf_query_kind, ray queues -- round
     after round until every tile is done, as fibers on the host: the oracle's samples, vertices, rays and image."""
@@ -520,6 +520,10 @@ def test_wavefront_schedule_emulated_as_simt(name, frame, trace, tmp_path, tr15_
     assert rgb(ref).max() > 0.05
     assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-6
     assert np.abs(img[..., 3] - ref[..., 3]).max() < 1e-4 * ref[..., 3].max()
+    if flat.contents.animated:   # ... and with the frame's transform table (128-byte records by shutter-time index, indexed by the stage kernels): the same film in every bit
+        monkeypatch.setenv("TRAYHIP_EMU_XF_TABLE", "1")
+        img_t, st_t = E.render_wavefront(flat, tile_queue(w, h), spp, 5, trace=trace, n_chunks=5, trace_blocks=2, lds_depth=4)
+        assert st_t == (samples, vertices, rays, rounds) and img_t.tobytes() == img.tobytes()
 
 
 @pytest.mark.parametrize("slices", [2, 4])
@@ -590,6 +594,29 @@ def test_tile_megakernel_of_moving_scenes_emulated_as_simt(tmp_path, built):
     ref, st = O.render_tiles(flat, spp, seed=2)
     assert samples == st.samples and abs(vertices - st.vertices) <= 2e-3 * st.vertices and abs(rays - st.rays) <= 2e-3 * st.rays
     assert float(np.sqrt(np.mean((rgb(img) - rgb(ref)) ** 2))) < 2e-3 and np.abs(img[..., 3] - ref[..., 3]).max() < 1e-4 * ref[..., 3].max()
+
+
+def test_tile_megakernel_fills_its_cache_columns_from_the_transform_table(tmp_path, built, monkeypatch):
+    """Round 5 / 6: launches of many samples read a moving scene's transforms from the frame's table over the 2^24 shutter-time indices
+    (k_xf_table_build) -- camera_ray gathers the camera's record, xf_cache_fill_wave deals the (starting lane, moving instance) pairs of a
+    step out to the whole wave, every lane copying one record into the column of the lane it works for. The emulation maps the table sparsely
+    (records for the indices the frame's camera samples draw) and must render what per-sample evaluation renders: the same film in every bit
+    (one schedule of the fibers, the same f32 sums), the same counts -- at one and at several workgroups, with whole and with sliced tiles."""
+    w, h, spp = 32, 24, 8
+    scenes.write_moving_box(str(tmp_path), width=w, height=h, samples=spp)
+    scene, *_ = T.Scene.load_file(str(tmp_path / "moving_box.json"))
+    for frame, blocks, slices in ((3, 2, None), (0, 1, "2")):
+        flat = scene.flatten(frame)
+        assert flat.contents.animated and flat.contents.camera.animated
+        if slices: monkeypatch.setenv("TRAYHIP_TILE_SLICES", slices)
+        monkeypatch.delenv("TRAYHIP_EMU_XF_TABLE", raising=False)
+        img0, st0 = E.render_tiles(flat, tile_queue(w, h), spp, 5, blocks=blocks)
+        monkeypatch.setenv("TRAYHIP_EMU_XF_TABLE", "1")
+        img1, st1 = E.render_tiles(flat, tile_queue(w, h), spp, 5, blocks=blocks)
+        assert st0 == st1 and st0[0] == w * h * spp
+        assert img0.tobytes() == img1.tobytes()
+        ref, st = O.render_tiles(flat, spp, seed=5)
+        assert float(np.sqrt(np.mean((rgb(img1) - rgb(ref)) ** 2))) < 2e-3
 
 
 def test_flat_loop_reproduces_the_samples_round_1_got_wrong(tmp_path, built):
