@@ -417,8 +417,9 @@ int tray_last_schedule(TrayDeviceScene* s, TrayScheduleInfo* out);
  * every ray of the path inherits it (path.rs:110), so the transform is a function of a 24-bit index. mode 1: build, per frame and on the
  * first launch, the TABLE of every moving instance's (and a moving camera's) transform at all 2^24 times -- 2.1 GB each (128-byte records), ~1.5 ms each to
  * build, the same evaluation at the same times: the same bits -- and read it; mode 0: evaluate per camera sample into a per-path cache
- * (112 B per path and instance); mode -1 (default): the table for launches of >= 3e7 camera samples (a 1080p frame at 16 spp: each index is needed about twice or more),
- * and for every later launch of the frame once it exists. If the table cannot be allocated the per-path cache serves, and vice versa.
+ * (128 B per path and instance); mode -1 (default): the table for launches of >= 3e7 camera samples (a 1080p frame at 16 spp: each index is needed about twice or more),
+ * for every later launch of the frame once it exists, and for the frames that follow it through tray_scene_update_frame (the buffer -- sized once for every
+ * instance whose transform has several keyframes -- and the wavefront pool are handed on). If the table cannot be allocated the per-path cache serves, and vice versa.
  * TRAYHIP_XF_TABLE=0|1 (measurement) overrides. tray_debug_transform_table compares n pseudo-random records of the frame's table with a fresh
  * evaluation, bit for bit, and reports how many differ (test hook; TRAY_E_INVALID if the frame has no table yet). */
 int tray_scene_set_transform_table(TrayDeviceScene* s, int mode);

@@ -404,6 +404,34 @@ def test_transform_table_renders_what_per_path_evaluation_renders(mode, tmp_path
         assert rmse(images[-1], cpu) < 1e-5
 
 
+def test_a_frame_sequence_keeps_its_pool_and_its_table_buffer(tmp_path, monkeypatch):
+    """scene.rs:152-176 moves the scene from frame to frame; tray_scene_update_frame hands the previous frame's buffers on. Round 6 found the wavefront
+    pool of a sequence that renders through the transform table freed and allocated again at every frame (the pool was compared with the bound of a per-path
+    cache such launches never allocate; 59 GB at 1080p, seconds at every third frame -- profiles/r06_d_frame_overheads.txt): the pool and the table's buffer
+    -- sized once for what any frame can move -- must be there BEFORE the new frame's first launch, and the frames must still be the oracle's."""
+    monkeypatch.setenv("TRAYHIP_MODE", "wave")
+    monkeypatch.setenv("TRAYHIP_WF_SLOTS", "65536")
+    scene, rt, _, fi = T.Scene.load_file(scenes.write_moving_box(str(tmp_path), width=128, height=128, samples=16))
+    hip = T.Hip(0, seed=4)
+    scene.device_scene(0, 0)
+    hip.set_transform_table(scene, 1)
+    first = None
+    for frame in (0, 1, 2):   # (frames whose BVH<Instance> has one depth: a deeper tree changes the traversal stacks, and with them the pool's buffers)
+        scene.device_scene(frame, 0)
+        if first is not None:
+            sch = hip.schedule(scene)   # (before this frame's first launch)
+            assert sch["pool_slots"] == first["pool_slots"] > 0 and sch["pool_bytes"] == first["pool_bytes"] > 0
+            assert sch["xf_table_bytes"] == first["xf_table_bytes"] > 0
+        rt.clear()
+        hip.render(scene, rt, _config_at(fi, frame, 16))
+        sch = hip.schedule(scene)
+        assert sch["transform_table"] == 1 and sch["launched_wavefront"] == 1
+        first = first or sch
+        cpu, st = O.render_tiles(scene.flatten(frame), 16, seed=4)
+        assert hip.last_timing.samples == st.samples and int(hip.last_timing.vertices) == int(st.vertices)
+        assert rmse(rt.get_renderf32().reshape(rt.height, rt.width, 4), cpu) < 1e-5
+
+
 # ---- moving scenes (SURVEY 8f rank 1): per-ray spline evaluation, animated emission and camera ----
 @pytest.fixture(scope="module")
 def moving(tmp_path_factory):

@@ -90,6 +90,8 @@ struct TrayDeviceScene {
     bool camera_animated = false;
     float* d_xf_table = nullptr;         // the frame's transform table (dev_geom.h: xf_time_index), built by the first launch that wants it
     uint32_t xf_table_stride = 0;
+    uint32_t xf_table_cap = 0;           // records per time index the buffer has room for (>= xf_table_stride: the next frames of a sequence may move more instances)
+    uint32_t xf_movable = 0;             // instances (+ camera) whose transform has a level of several keyframes: what ANY frame of the sequence can move
     bool xf_table_built = false;         // ... for THIS frame (a frame update takes the buffer over and builds anew)
     hipEvent_t xf_table_ev = nullptr;    // recorded behind k_xf_table_build: a later launch of the frame on ANOTHER stream waits for it
     hipStream_t xf_table_stream = nullptr;   // the stream the build was put on
@@ -717,6 +719,14 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
     if (occ != hipSuccess || per_cu < 1) per_cu = 1;
     s->deferred_n_moving = 0;
     for (uint32_t i = 0; i < f->n_instances; ++i) if (f->instances[i].animated) s->deferred_n_moving++;
+    {   // how many records per time index a later frame of this scene can need (xf_table_prepare sizes the table's buffer once)
+        auto movable = [&](uint32_t first, uint32_t count) {
+            for (uint32_t l = first; l < first + count && l < f->n_xf_levels; ++l) if (f->xf_levels[l].kf_count > 1u) return true;
+            return false;
+        };
+        s->xf_movable = movable(f->camera.xf_first, f->camera.xf_count) ? 1u : 0u;
+        for (uint32_t i = 0; i < f->n_instances; ++i) if (movable(f->instances[i].xf_first, f->instances[i].xf_count)) s->xf_movable++;
+    }
     if (cus < 1) cus = 256;
     s->n_blocks = cus * per_cu;
     if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] tile kernel: %d workgroups per CU (dynamic LDS %u B)\n", per_cu, s->stack_bytes);
@@ -768,14 +778,16 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
     }
     s->wf_req_slots = donor ? donor->wf_req_slots : 0u; s->wf_req_views = donor ? donor->wf_req_views : 0u; s->wf_req_slices = donor ? donor->wf_req_slices : 0u;
     s->xf_table_req = donor ? donor->xf_table_req : -1;
-    if (donor && donor->d_xf_table && donor->xf_table_stride == s->dev.n_moving + (s->camera_animated ? 1u : 0u)) {
-        // the previous frame's transform table serves as the buffer of this frame's (same number of records per time index): built anew by the first launch
+    if (donor && donor->d_xf_table) {
+        // the previous frame's transform table serves as the buffer of this frame's, built anew by the first launch (xf_table_prepare checks that this
+        // frame's records fit: freeing and allocating 20 GB costs 4 s -- profiles/r06_d_frame_overheads.txt --, so the buffer is sized once for a sequence)
         forget_alloc(donor, donor->d_xf_table); s->allocs.push_back(donor->d_xf_table);
-        s->d_xf_table = donor->d_xf_table; s->xf_table_stride = donor->xf_table_stride; s->xf_table_built = false;
-        donor->d_xf_table = nullptr;
+        s->d_xf_table = donor->d_xf_table; s->xf_table_cap = donor->xf_table_cap; s->xf_table_stride = 0u; s->xf_table_built = false;
+        donor->d_xf_table = nullptr; donor->xf_table_cap = 0u;
     }
     if (donor && donor->wf_ready && s->wavefront && donor->stack_bytes == s->stack_bytes && donor->quad_stack_words == s->quad_stack_words && donor->animated == s->animated &&
-        donor->pool.n_slots <= ((s->animated && s->dev.xf_cache_lanes) ? s->dev.xf_cache_lanes : wf_slot_wish(s))) {   // (a pool that came out smaller than wished -- memory -- stays as it is)
+        (donor->pool.n_slots <= ((s->animated && s->dev.xf_cache_lanes) ? s->dev.xf_cache_lanes : wf_slot_wish(s)) ||   // (a pool that came out smaller than wished -- memory -- stays as it is)
+         (donor->last_used_table && s->d_xf_table))) {   // (a pool sized for launches that read the frame's transform table -- no per-path cache bounds it --: this frame's launches read theirs, xf_table_prepare)
         // the wavefront schedule's pool, queues, chunk records and row bins (2.2 GB at 8 M slots) serve the next frame as they are:
         // launch_wavefront re-initialises the chunk records and the control words of every launch, the bins are zero between tiles
         for (void* p : {(void*)donor->pool.data, (void*)donor->d_chunks, (void*)donor->d_bins, (void*)donor->d_wf_counters, (void*)donor->d_queues,
@@ -791,6 +803,10 @@ static int scene_build(const TrayFlatScene* f, TrayDeviceScene* donor, TrayDevic
         s->wf_ready = true;
         donor->wf_ready = false; donor->pool.data = nullptr;
     }
+    if (donor && getenv("TRAYHIP_STATS"))
+        fprintf(stderr, "[trayhip] frame update: pool %s (donor ready %d, wavefront %d, stack %u / %u B, quad stack %u / %u, animated %d / %d, donor slots %u, cache lanes %u, donor used the table %d, table buffer %s)\n",
+                s->wf_ready ? "kept" : "not kept", donor->wf_ready || s->wf_ready ? 1 : 0, s->wavefront ? 1 : 0, donor->stack_bytes, s->stack_bytes, donor->quad_stack_words, s->quad_stack_words,
+                donor->animated ? 1 : 0, s->animated ? 1 : 0, s->pool.n_slots ? s->pool.n_slots : donor->pool.n_slots, s->dev.xf_cache_lanes, donor->last_used_table ? 1 : 0, s->d_xf_table ? "kept" : "none");
     s->donor = nullptr;
     *out = s;
     return TRAY_OK;
@@ -1172,27 +1188,40 @@ static int xf_table_prepare(TrayDeviceScene* s, uint64_t samples, hipStream_t st
     if (!s->animated || stride == 0u) return TRAY_OK;
     int want = s->xf_table_req;
     if (const char* e = getenv("TRAYHIP_XF_TABLE")) want = atoi(e) != 0 ? 1 : 0;
-    if (want < 0) want = (samples >= XF_TABLE_MIN_SAMPLES || s->xf_table_built) ? 1 : 0;   // (a table that exists for this frame serves every launch)
+    // (a table that exists for this frame serves every launch; so does the buffer of the previous frame's: a sequence that rendered through the table goes on
+    // doing so -- its pool may be larger than a per-path cache could cover)
+    if (want < 0) want = (samples >= XF_TABLE_MIN_SAMPLES || s->xf_table_built || s->d_xf_table) ? 1 : 0;
     if (!want) {
         const int rc = xf_cache_ensure(s);
         if (rc == TRAY_OK) { s->launch_dev = s->dev; return TRAY_OK; }
         if (rc != TRAY_E_NOMEM) return rc;   // (no room for the cache: the table is smaller from a few million slots on)
     }
-    if (s->d_xf_table && s->xf_table_stride != stride) {   // (cannot happen: the stride is the frame's, the buffer was taken over for this stride)
-        forget_alloc(s, s->d_xf_table); (void)hipFree(s->d_xf_table); s->d_xf_table = nullptr; s->xf_table_built = false;
+    if (s->d_xf_table && s->xf_table_cap < stride) {   // (the buffer taken over from the previous frame is too small for this frame's records)
+        forget_alloc(s, s->d_xf_table); (void)hipFree(s->d_xf_table); s->d_xf_table = nullptr; s->xf_table_cap = 0u; s->xf_table_built = false;
     }
+    if (s->d_xf_table && s->xf_table_stride != stride) { s->xf_table_stride = stride; s->xf_table_built = false; }
     if (!s->d_xf_table) {
-        const size_t bytes = ((size_t)1 << 24) * stride * TR_XF_REC * sizeof(float);   // 1.9 GB per moving instance
+        // room for what any frame of the sequence can move (instances whose transforms have several keyframes, tray_scene_create), if that much is to be had
+        uint32_t cap = std::max(stride, s->xf_movable);
+        size_t bytes = ((size_t)1 << 24) * cap * TR_XF_REC * sizeof(float);   // 2.1 GB per moving instance
         void* p = nullptr;
         // by the library's own rule (nobody asked for the table) it takes at most a third of what is free: on a device shared with other
         // allocators 22.5 GB for eleven movers must not be what starves them; then, or if hipMalloc refuses: per-path evaluation
         bool room = true;
-        if (s->xf_table_req < 0 && !getenv("TRAYHIP_XF_TABLE")) {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) room = bytes <= free_b / 3u; else (void)hipGetLastError();
-        }
-        if (!room || hipMalloc(&p, bytes) != hipSuccess) {
+        const bool own_rule = s->xf_table_req < 0 && !getenv("TRAYHIP_XF_TABLE");
+        for (;;) {   // (the sequence's headroom first, then this frame's records alone)
+            room = true;
+            if (own_rule) {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) room = bytes <= free_b / 3u; else (void)hipGetLastError();
+            }
+            if (room && hipMalloc(&p, bytes) == hipSuccess) break;
             (void)hipGetLastError();
+            p = nullptr;
+            if (cap == stride) break;
+            cap = stride; bytes = ((size_t)1 << 24) * cap * TR_XF_REC * sizeof(float);
+        }
+        if (!p) {
             const int rc = xf_cache_ensure(s);
             s->launch_dev = s->dev;
             return rc;
@@ -1200,6 +1229,7 @@ static int xf_table_prepare(TrayDeviceScene* s, uint64_t samples, hipStream_t st
         s->allocs.push_back(p);
         s->d_xf_table = static_cast<float*>(p);
         s->xf_table_stride = stride;
+        s->xf_table_cap = cap;
         s->xf_table_built = false;
     }
     if (!s->xf_table_built) {
@@ -1251,8 +1281,21 @@ static int launch_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_c
     kf = mix(kf + s->dev.frame);
     if (s->sampler_kind != TRAY_SAMPLER_LOW_DISCREPANCY || s->deforming) return launch_sampler(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
     s->last_was_wavefront = false;
-    { const int rc = xf_table_prepare(s, (uint64_t)tile_count * 64u * spp, stream); if (rc != TRAY_OK) return rc; }
-    if (s->wavefront) return launch_wavefront(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = xf_table_prepare(s, (uint64_t)tile_count * 64u * spp, stream);
+        if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] transform table / cache prepared in %.1f ms (table %s, %u of %u records per index in use)\n",
+                                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), s->last_used_table ? "on" : "off", s->xf_table_stride, s->xf_table_cap);
+        if (rc != TRAY_OK) return rc;
+    }
+    if (s->wavefront) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const bool had_pool = s->wf_ready;
+        const int rc = launch_wavefront(s, tile_start, tile_count, chunk, chunk_stride, spp, kf, rgbw_dev, stream);
+        if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] wavefront launch enqueued in %.1f ms (pool %s: %u slots)\n",
+                                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), had_pool ? "kept" : "allocated", s->pool.n_slots);
+        return rc;
+    }
     // Items per tile (k_path_tiles: progressive slices, level-major: the launch ends with its smallest items). A slice costs its own film resolve and
     // flush and keeps >= 64 samples per pixel (>= 256 in a launch with many tiles per workgroup). Measured (profiles/r06_tile_slices_progressive_ab.txt, items per tile 1 / 2 / 3 / 4 / 5): the whole
     // dragon frame 718.5 / 740.6 / 750.3 / 752.7 / 755.1 Msamples/s (tiles that show the mesh cost several times a wall tile: with whole tiles the last
@@ -1316,19 +1359,25 @@ int tray_render_tiles(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile_cou
     HIP_CHECK(hipSetDevice(s->device));
     size_t n = (size_t)s->dev.width * s->dev.height * 4;
     float* d = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     HIP_CHECK(hipMalloc(&d, n * sizeof(float)));
     int rc = TRAY_OK;
     hipError_t e = hipMemset(d, 0, n * sizeof(float));
+    double t_alloc = ms(), t_enq = 0.0, t_copy = 0.0;
     if (e == hipSuccess) {
         rc = tray_render_tiles_device(s, tile_start, tile_count, spp, seed, d, nullptr);
+        t_enq = ms();
         if (rc == TRAY_OK) {
             std::vector<float> tmp(n);
             e = hipMemcpy(tmp.data(), d, n * sizeof(float), hipMemcpyDeviceToHost);
+            t_copy = ms();
             if (e == hipSuccess)
                 for (size_t i = 0; i < n; ++i) rgbw_host[i] += tmp[i];
         }
     }
     (void)hipFree(d);
+    if (getenv("TRAYHIP_STATS")) fprintf(stderr, "[trayhip] tray_render_tiles: film buffer %.1f ms, enqueue %.1f, kernels + copy %.1f, add + free %.1f\n", t_alloc, t_enq - t_alloc, t_copy - t_enq, ms() - t_copy);
     if (e != hipSuccess) { set_error(std::string("tray_render_tiles: ") + hipGetErrorString(e)); return TRAY_E_DEVICE; }
     return rc;
 }
@@ -1575,7 +1624,7 @@ int tray_last_schedule(TrayDeviceScene* s, TrayScheduleInfo* out) {
     out->tile_workgroups = (uint32_t)s->n_blocks;
     out->transform_table = s->last_used_table ? 1u : 0u;
     out->binned_stages = (s->last_was_wavefront && WF_FOLD_C) ? s->wf_bin_stages : 0u;
-    out->xf_table_bytes = s->d_xf_table ? ((uint64_t)1 << 24) * s->xf_table_stride * TR_XF_REC * sizeof(float) : 0u;
+    out->xf_table_bytes = s->d_xf_table ? ((uint64_t)1 << 24) * s->xf_table_cap * TR_XF_REC * sizeof(float) : 0u;   // (the buffer: sized for what any frame of the sequence can move)
     return TRAY_OK;
 }
 
