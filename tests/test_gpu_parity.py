@@ -430,6 +430,16 @@ def test_a_frame_sequence_keeps_its_pool_and_its_table_buffer(tmp_path, monkeypa
         cpu, st = O.render_tiles(scene.flatten(frame), 16, seed=4)
         assert hip.last_timing.samples == st.samples and int(hip.last_timing.vertices) == int(st.vertices)
         assert rmse(rt.get_renderf32().reshape(rt.height, rt.width, 4), cpu) < 1e-5
+    # ... and a caller who turns the table off in the middle of the sequence gets per-path evaluation on the pool the sequence holds
+    hip.set_transform_table(scene, 0)
+    scene.device_scene(3, 0)
+    rt.clear()
+    hip.render(scene, rt, _config_at(fi, 3, 16))
+    sch = hip.schedule(scene)
+    assert sch["transform_table"] == 0 and sch["xf_cache_bytes"] > 0 and sch["pool_slots"] > 0
+    cpu, st = O.render_tiles(scene.flatten(3), 16, seed=4)
+    assert hip.last_timing.samples == st.samples and int(hip.last_timing.vertices) == int(st.vertices)
+    assert rmse(rt.get_renderf32().reshape(rt.height, rt.width, 4), cpu) < 1e-5
 
 
 # ---- moving scenes: per-ray spline evaluation, animated emission and camera ----

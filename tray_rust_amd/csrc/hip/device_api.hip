@@ -1162,6 +1162,14 @@ static int launch_sampler(TrayDeviceScene* s, uint32_t tile_start, uint32_t tile
 // columns as scene_build budgeted; halved while hipMalloc refuses and the pool does not exist yet, never below the pool's slots once it does
 static int xf_cache_ensure(TrayDeviceScene* s) {
     if (!s->wavefront || !s->animated || s->dev.n_moving == 0u || s->dev.xf_cache) return TRAY_OK;
+    // (a pool that was sized for launches reading the frame's table -- no cache bounded it -- can be larger than any cache the device holds: then the
+    // pool goes, the cache takes its budgeted size and launch_wavefront allocates a pool that fits it)
+    if (s->wf_ready && s->dev.xf_cache_lanes && s->pool.n_slots > s->dev.xf_cache_lanes) {
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)s->dev.n_moving * TR_XF_REC * s->pool.n_slots * sizeof(float);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        if (need > free_b / 5u * 2u) { HIP_CHECK(hipDeviceSynchronize()); wf_free(s); }
+    }
     uint32_t lanes = std::max<uint32_t>(s->dev.xf_cache_lanes, s->wf_ready ? s->pool.n_slots : 0u);
     const uint32_t floor_lanes = s->wf_ready ? s->pool.n_slots : 64u * TR_BLOCK;
     for (;;) {
