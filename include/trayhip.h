@@ -408,7 +408,7 @@ typedef struct TrayScheduleInfo {
     uint32_t transform_table;     /* 1: the last launch read the frame's transform table (tray_scene_set_transform_table) */
     uint32_t binned_stages;       /* wavefront schedule: traversal stages whose rays are sorted by (origin cell, direction octant) before they are
                                    * traced -- bit 0: camera / continuation rays, bit 1: occlusion rays (round 6; this word was padding before) */
-    uint64_t xf_table_bytes;                               /* the table, if this frame has one */
+    uint64_t xf_table_bytes;                               /* the transform table's buffer, if there is one: sized once for every instance that any frame of the sequence can move */
 } TrayScheduleInfo;
 int tray_last_schedule(TrayDeviceScene* s, TrayScheduleInfo* out);
 
