@@ -14,7 +14,7 @@ tag = sys.argv[1]
 items = sys.argv[2:] or ["cornell_box:64", "smallpt:64", "dragon:32", "tr15_like:256"]   # (round 6: 256 spp is the sample count from which launch_wavefront cuts tiles into 16 slices and fills the 132.7 M-slot pool, as at the bench's 512)
 dest = os.path.join(ROOT, "gpurun_out", f"summary_{tag}")
 os.makedirs(dest, exist_ok=True)
-D = "/tmp/mini_full"
+D = "/tmp/pmc_full"   # (its own directory: /tmp/mini_full is also what tools/ab.sh calls prepare, possibly with another MINI_TR15_DETAIL, and a GPU box can come back with its /tmp as it was)
 env0 = dict(os.environ, TMPDIR="/tmp", MINI_DRAGON_GRID=os.environ.get("MINI_DRAGON_GRID", "660"), MINI_TR15_DETAIL=os.environ.get("MINI_TR15_DETAIL", "1.0"))
 if not os.path.exists(os.path.join(D, "cornell_box.json")):
     subprocess.run(["python", os.path.join(ROOT, "tools", "mini_ab.py"), "prepare", D], env=env0, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
