@@ -4,6 +4,7 @@
 # The build runs in a SNAPSHOT of csrc/ and include/ under /tmp (the sources as they are when the script starts), so the tree can be edited
 # while a variant compiles -- hipcc maps its inputs and dies with a bus error when one of them is rewritten under it.
 # VARIANT_HIPFLAGS="..." replaces the Makefile's whole HIPFLAGS line (to REMOVE a default flag such as -fno-slp-vectorize).
+# VARIANT_MAKEARGS="'GROUPFLAGS_12=-mllvm -x=y' 'GROUPFLAGS_3=...'" (each assignment in single quotes) passes make variables (flags of single kernel groups: csrc/Makefile).
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 name=$1; shift
@@ -14,9 +15,9 @@ cp -r $ROOT/tray_rust_amd/csrc $SNAP/tray_rust_amd/csrc
 find $SNAP -name "*.o" -delete
 cd $SNAP/tray_rust_amd/csrc
 if [ -n "$VARIANT_HIPFLAGS" ]; then
-  make -s -j${VARIANT_JOBS:-8} OUT=../libtrayhip_$name.so HIPFLAGS="$VARIANT_HIPFLAGS $*" 2>&1 | grep -E "error|Error" || true
+  eval make -s -j${VARIANT_JOBS:-8} OUT=../libtrayhip_$name.so 'HIPFLAGS="$VARIANT_HIPFLAGS $*"' $VARIANT_MAKEARGS 2>&1 | grep -E "error|Error" || true
 else
-  make -s -j${VARIANT_JOBS:-8} OUT=../libtrayhip_$name.so EXTRA_HIPFLAGS="$*" 2>&1 | grep -E "error|Error" || true
+  eval make -s -j${VARIANT_JOBS:-8} OUT=../libtrayhip_$name.so 'EXTRA_HIPFLAGS="$*"' $VARIANT_MAKEARGS 2>&1 | grep -E "error|Error" || true
 fi
 cp ../libtrayhip_$name.so $ROOT/tray_rust_amd/libtrayhip_$name.so
 ls -la $ROOT/tray_rust_amd/libtrayhip_$name.so
