@@ -116,9 +116,11 @@ def pmc_views(workload, samples, kernel_seconds):
         valu = {"achieved": round(achieved, 3), "peak": round(VALU_PEAK_TLANE, 2), "unit": "T lane-instructions/s", "frac": round(achieved / VALU_PEAK_TLANE, 4),
                 "peak_nominal": round(VALU_PEAK_NOMINAL_TLANE, 2), "frac_nominal": round(achieved / VALU_PEAK_NOMINAL_TLANE, 4),
                 "wave_instructions_per_sample": round(d["valu_instructions_per_sample"], 1), "lane_utilisation": round(d["valu_lane_utilisation"], 4),
-                "note": VALU_PEAK_NOTE + (f"; the SQ counters show the VALU pipe {d.get('valu_busy', 0.0):.2f} time-busy" if d.get("valu_busy") else "")}
+                "note": VALU_PEAK_NOTE + (f"; the SQ counters show the VALU pipe {min(1.0, d.get('valu_busy', 0.0)):.2f} time-busy" if d.get("valu_busy") else "")}
     compute = {"source": "profiles/pmc_latest.json (rocprofv3 --pmc passes around a %d-spp launch of this device code, tools/pmc_workloads.py)" % d.get("spp", 0),
                "device_code_hash": have, "kernel": d.get("kernel"),
+               # (SQ_ACTIVE_INST_VALU x SQ_WAVES / (SIMDs x SQ_WAVE_CYCLES): an estimate -- counters of separate passes, waves that do not all live the whole launch --
+               # which can come out a few per cent above 1 for an issue-bound kernel; reported as measured, the note above clamps it)
                "valu_busy": d.get("valu_busy"), "valu_lane_util": d.get("valu_lane_utilisation"),
                "waves_per_simd": d.get("waves_per_simd"), "waiting_share_of_wave_cycles": d.get("waiting_share_of_wave_cycles"),
                "dominant_kernel_share_of_time": d.get("dominant_kernel_share_of_time"),
